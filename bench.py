@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- Tx->Rx link evaluations per second of the MI355X radio-medium engine.
+
+A "step" is one simulated tick: T = 1% of N nodes transmit a 127-byte frame; the engine
+evaluates all T x (N-1) links (log-distance path loss + log-normal shadowing, BASELINE.json
+configs[2]: 100k nodes, 1% concurrent Tx) and leaves the ordered heard-link records
+(receiver, rssi, verdict) in HBM.  Inputs (node state, the tick's source lists) are resident
+in HBM before the timed region starts.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|udgm]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: receivers are range-partitioned over the ranks (strong scaling, the node count stays
+100k); every tick each rank packs the Tx records of the transmitters it owns and the ranks
+all-gather them over RCCL/xGMI.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3    # vector fp32
+S_NODE, S_TX, S_REC = 37, 56, 25   # algorithmic bytes: SURVEY.md section 8(d)
+
+WORKLOADS = {
+    # name: (config index, N, tx fraction, model name, description)
+    "c2": (2, 10_000, 0.01, "logdist", "10k nodes, 1% concurrent-Tx, log-distance path loss"),
+    "c3": (3, 100_000, 0.01, "logdist_shadow", "100k nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
+    "udgm": (3, 100_000, 0.01, "udgm", "100k nodes, 1% concurrent-Tx, reference UDGM (unit disc)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-ticks", type=float, default=2.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, nodes, sources, cpu_ticks):
+    """The CPU oracle (a port of the reference loop; the reference is Java and no JVM exists on
+    the box) timed on a bounded sample of the same workload: one thread, as the reference
+    evaluates a packet on one thread (SimulatorJSONHandler.java:93)."""
+    from oracle import oracle as O
+    from radio_sim_amd import workload as W
+    idx, n, frac, model, _ = WORKLOADS[wl]
+    kind, kw = W.model_kwargs(model)
+    okind = {"udgm": O.MODEL_UDGM, "udgm_const": O.MODEL_UDGM_CONST, "logdist": O.MODEL_LOGDIST}[kind]
+    okw = {("ld_flags" if k == "flags" else k): v for k, v in kw.items()}
+    mdl = O.model(okind, **okw)
+    nd = O.NodeTable(n)
+    nd.x, nd.y, nd.z = nodes.x, nodes.y, nodes.z
+    t = len(sources[0])
+    n_pk = max(1, int(round(cpu_ticks * t)))
+    src = np.concatenate(sources[: (n_pk + t - 1) // t])[:n_pk]
+    pk = nd.packets(src, 0, W.AIR_US)
+    O.count_links(mdl, nd, pk[:2], 0, 1)     # page in
+    t0 = time.perf_counter()
+    heard, deliv = O.count_links(mdl, nd, pk, 0, 1)
+    dt = time.perf_counter() - t0
+    links = n_pk * (n - 1)
+    out = {"value": links / dt, "unit": "links/s", "cores": 1, "kind": "port",
+           "sample": "%d packets x %d receivers (%.1f ticks of this workload), %.1f s, oracle/rm_oracle.c "
+                     "single thread" % (n_pk, n - 1, n_pk / t, dt)}
+    threads = O.lib().orc_max_threads()
+    t0 = time.perf_counter()
+    O.count_links(mdl, nd, pk, 0, threads)
+    dt_mt = time.perf_counter() - t0
+    mt = {"value": links / dt_mt, "unit": "links/s", "cores": threads, "kind": "port",
+          "sample": "same sample, OpenMP over packets, %.1f s" % dt_mt}
+    return out, mt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import radio_sim_amd as rsa
+    from radio_sim_amd import workload as W
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    idx, n, frac, model, desc = WORKLOADS[args.workload]
+    t_per_tick = int(round(frac * n))
+    nodes = W.make_nodes(n, idx)
+    kind_name, kw = W.model_kwargs(model)
+    kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
+
+    eng = rsa.Engine(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
+    eng.upload_table(nodes)
+    eng.set_model(kind, **kw)
+    eng.set_link_capacity(1 << 21)
+
+    # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    if world > 1:
+        eng.set_partition(lo, hi - lo)
+
+    ticks = args.warmup + args.steps
+    base_seed = 0xC0FFEE00 + idx
+    sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(ticks)]
+
+    with torch.cuda.stream(stream):
+        if world == 1:
+            src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
+            rec_dev = torch.empty(t_per_tick * 64, dtype=torch.uint8, device=dev)    # rm_tx_record[T]
+            slot = t_per_tick
+        else:
+            # every rank packs the frames whose source it owns into a fixed number of slots
+            # (padded with src = -1), then the ranks all-gather the slots
+            mine = [s[(s >= lo) & (s < hi)] for s in sources]
+            slot = max(max(len(s[(s >= (n * r) // world) & (s < (n * (r + 1)) // world)]) for r in range(world))
+                       for s in sources)
+            pad = np.full((ticks, slot), -1, dtype=np.int32)
+            for k, s in enumerate(mine):
+                pad[k, : len(s)] = s
+            src_dev = torch.from_numpy(pad).to(dev)
+            mine_dev = torch.empty(slot * 64, dtype=torch.uint8, device=dev)
+            rec_dev = torch.empty(world * slot * 64, dtype=torch.uint8, device=dev)
+    stream.synchronize()
+
+    def run_tick(k):
+        t0 = k * W.TICK_US
+        with torch.cuda.stream(stream):
+            if world == 1:
+                eng.pack_tx_device(src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US, rec_dev.data_ptr())
+                eng.tick_run_device(t0, t0 + W.TICK_US, rec_dev.data_ptr(), t_per_tick)
+            else:
+                eng.pack_tx_device(src_dev[k].data_ptr(), slot, t0, W.AIR_US, mine_dev.data_ptr())
+                dist.all_gather_into_tensor(rec_dev, mine_dev)
+                eng.tick_run_device(t0, t0 + W.TICK_US, rec_dev.data_ptr(), world * slot)
+
+    def fence():
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        run_tick(k)
+    fence()
+    eng.profile_enable(True)
+    t_start = time.perf_counter()
+    for k in range(args.warmup, ticks):
+        run_tick(k)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    n_launch, kern_ms = eng.profile_read()
+    eng.profile_enable(False)
+    heard, dropped = eng.result_count()
+    if dropped:
+        raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        hsum = torch.tensor([heard], dtype=torch.float64, device=dev)
+        dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
+        heard_total = float(hsum.item())
+    else:
+        heard_total = float(heard)
+
+    links_per_tick = t_per_tick * (n - 1)
+    value = links_per_tick * args.steps / elapsed
+
+    if rank == 0:
+        # roofline of the dominant kernel (k_allpairs) on this rank, SURVEY.md section 8(d):
+        # algorithmic bytes per launch = N_loc*37 + T_act*56 + H_loc*25
+        n_loc = hi - lo
+        h_loc = heard
+        b_tick = n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC
+        kern_avg_s = (kern_ms / max(1, n_launch)) * 1e-3
+        achieved = b_tick / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
+        links_rank = t_per_tick * n_loc
+        out = {
+            "metric": "Tx->Rx link evaluations/sec",
+            "value": value,
+            "unit": "links/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US,
+                       "air_us": W.AIR_US, "model": model, "heard_links_last_tick": heard_total,
+                       "sharding": "receivers range-partitioned, RCCL all-gather of Tx records" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_allpairs", "kernel_avg_us": kern_avg_s * 1e6, "launches": n_launch,
+                         "algorithmic_bytes_per_launch": b_tick,
+                         "note": "brute-force all-pairs is VALU-bound by construction (SURVEY.md 8d); see valu"},
+            "valu": {"links_per_s_kernel": links_rank / kern_avg_s if kern_avg_s > 0 else 0.0,
+                     "fp32_ops_per_link": 8,
+                     "achieved_tflops": 8 * links_rank / kern_avg_s / 1e12 if kern_avg_s > 0 else 0.0,
+                     "peak_tflops": FP32_PEAK_TFLOPS},
+        }
+        out["valu"]["frac"] = out["valu"]["achieved_tflops"] / FP32_PEAK_TFLOPS
+        if world == 1 and not args.no_cpu_baseline:
+            st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
+            out["cpu_baseline"] = st
+            out["cpu_baseline_all_cores"] = mt
+        print(json.dumps(out))
+        sys.stdout.flush()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+/*
+ * radiomedium_hip.h -- C ABI of libradiomedium_hip.so, the MI355X (gfx950) engine for
+ * radio-sim's per-packet propagation / delivery-verdict pass.
+ *
+ * This is the drop-in boundary for the reference's RadioMedium plug-in contract
+ * (reference paths relative to /root/reference/radio-medium/java/se/sics/emul8/radiomedium/):
+ *
+ *     public interface RadioMedium {            RadioMedium.java:35-45
+ *         String getName();                     -> rm_get_name
+ *         void   setSimulator(Simulator sim);   -> rm_create / rm_nodes_upload / rm_seed / rm_set_time
+ *         void   transmit(RadioPacket packet);  -> rm_transmit   (or rm_enqueue_tx + rm_tick_flush)
+ *         double getBaseRSSI(Node node);        -> rm_get_base_rssi
+ *     }
+ *
+ * Plain C types only (pointers + sizes); no exceptions cross it; every function returns an
+ * int status (RM_OK or a negative RM_ERR_*) unless stated, and rm_last_error() gives the
+ * thread-local message of the last failure.  A context is NOT re-entrant: the caller
+ * serialises calls per context (the reference enters transmit() from per-socket reader
+ * threads, net/JSONClientConnection.java:118-131; the Java shim in INTEGRATION.md holds
+ * one lock).  There is no CPU fallback: without a usable HIP device rm_create fails with
+ * RM_ERR_NO_DEVICE.
+ *
+ * Node indices are positions in Simulator.getNodes() (registration order,
+ * Simulator.java:245,274) -- the order the reference's loop visits receivers in, and the
+ * order heard links are returned in.
+ */
+#ifndef RADIOMEDIUM_HIP_H
+#define RADIOMEDIUM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_ABI_VERSION 1
+
+#define RM_OK 0
+#define RM_ERR_INVALID (-1)   /* bad argument */
+#define RM_ERR_NO_DEVICE (-2) /* no usable HIP device / library built without one */
+#define RM_ERR_HIP (-3)       /* a HIP runtime call failed */
+#define RM_ERR_CAPACITY (-4)  /* caller buffer or link capacity too small (count is still returned) */
+#define RM_ERR_STATE (-5)     /* call sequence / configuration not valid for this call */
+
+typedef struct rm_context rm_context;
+
+/* which RadioMedium implementation the context behaves as */
+enum rm_model_kind {
+    RM_MODEL_NULL = 0,       /* NullRadioMedium.java:47-77 */
+    RM_MODEL_UDGM = 1,       /* UDGMRadioMedium.java:63-117 */
+    RM_MODEL_UDGM_CONST = 2, /* UDGMConstantLossRadioMedium.java:16-36 */
+    RM_MODEL_N2N = 3,        /* N2NRadioMedium.java:24-73 */
+    RM_MODEL_LOGDIST = 4     /* build-defined extension, DESIGN.md "Extension spec" */
+};
+
+/* events/ReceptionEvent.java:12-16: unheard links are never reported */
+enum rm_verdict { RM_UNHEARD = 0, RM_INTERFERED = 1, RM_DELIVERED = 2 };
+
+#define RM_LD_SINR 1 /* logdist: co-channel SINR capture + half duplex over the on-air list */
+
+typedef struct rm_model_params {
+    int32_t kind;  /* enum rm_model_kind */
+    int32_t flags; /* RM_LD_* */
+    /* UDGMRadioMedium.java:18-24 (setters :31-61) */
+    double udgm_success_ratio_tx;   /* declared by the reference, never used (kept for parity) */
+    double udgm_success_ratio_rx;
+    double udgm_transmission_range;
+    double udgm_interference_range; /* declared by the reference, never read */
+    /* UDGMConstantLossRadioMedium.java:8 */
+    double const_range;
+    /* extension */
+    double ld_pl0_db, ld_exponent, ld_d0;
+    double ld_sigma_db, ld_clip;
+    uint64_t ld_seed;
+    double ld_sensitivity_dbm, ld_noise_dbm, ld_capture_db, ld_ifloor_dbm;
+} rm_model_params;
+
+/* One frame on the air: RadioPacket.java:40-52 plus the source state transmit() reads
+ * (source position, Position.java; txProbability, Transciever.java:18).  This is also the
+ * record the ranks all-gather each tick in the receiver-sharded multi-GPU mode. */
+typedef struct rm_tx_record {
+    double x, y, z;
+    double txpower;
+    double txprob;
+    int64_t start_us;
+    int64_t air_us;
+    int32_t src;
+    int32_t channel;
+} rm_tx_record; /* 64 bytes */
+
+/* device-resident result of the last evaluated tick (all pointers are device memory owned by
+ * the context, valid until the next rm_tick_* / rm_transmit call) */
+typedef struct rm_device_result {
+    const uint32_t *count;      /* [1] heard links */
+    const uint32_t *pkt_offset; /* [n_new+1] first link of each new packet */
+    const int32_t *pkt;         /* [count] index into this tick's new packets */
+    const int32_t *dst;         /* [count] receiver node index */
+    const uint8_t *verdict;     /* [count] RM_INTERFERED / RM_DELIVERED */
+    const double *rssi;         /* [count] */
+    const double *sinr;         /* [count] (logdist+SINR only, else 0) */
+    uint32_t capacity;
+} rm_device_result;
+
+/* ---- life cycle ---------------------------------------------------------------------- */
+int rm_abi_version(void);
+int rm_device_count(void);                              /* >=0, or RM_ERR_* */
+int rm_create(int device_ordinal, rm_context **out);    /* Simulator.setRadioMedium(...) -> setSimulator */
+void rm_destroy(rm_context *ctx);
+const char *rm_last_error(void);
+const char *rm_get_name(const rm_context *ctx);         /* RadioMedium.getName() */
+int rm_set_stream(rm_context *ctx, void *hip_stream);   /* all work is enqueued on this stream */
+
+/* ---- model ---------------------------------------------------------------------------- */
+void rm_model_defaults(rm_model_params *p, int32_t kind); /* the reference's field defaults */
+int rm_set_model(rm_context *ctx, const rm_model_params *p);
+int rm_get_model(const rm_context *ctx, rm_model_params *out);
+/* N2NRadioMedium(double[][] m): row-major m x m (net/SimulatorJSONHandler.java:183-206) */
+int rm_set_n2n_matrix(rm_context *ctx, int32_t m, const double *row_major);
+int rm_set_base_rssi(rm_context *ctx, double rssi);       /* AbstractRadioMedium.java:51-53 */
+double rm_get_base_rssi(const rm_context *ctx, int32_t node); /* RadioMedium.getBaseRSSI */
+
+/* ---- Simulator.getRandom(): one java.util.Random shared by all packets ------------------ */
+int rm_seed(rm_context *ctx, int64_t seed);               /* new java.util.Random(seed) */
+int rm_get_rng_state(rm_context *ctx, uint64_t *state48);
+int rm_set_rng_state(rm_context *ctx, uint64_t state48);
+
+/* ---- node state (Simulator.getNodes() snapshot; Node/Position/Transciever fields) -------- */
+int rm_nodes_upload(rm_context *ctx, int32_t n,
+                    const double *x, const double *y, const double *z,
+                    const double *txpower, const int32_t *channel, const uint8_t *enabled,
+                    const double *rxprob, const double *txprob,
+                    const int32_t *int_id /* Node.getIdAsInteger(); NULL = index+1 */);
+int rm_node_update(rm_context *ctx, int32_t node, double x, double y, double z, double txpower,
+                   int32_t channel, uint8_t enabled, double rxprob, double txprob);
+int rm_node_count(const rm_context *ctx);
+/* receiver range owned by this context (multi-GPU range partitioning); default = all */
+int rm_set_partition(rm_context *ctx, int32_t first, int32_t count);
+int rm_set_link_capacity(rm_context *ctx, uint32_t max_links);
+
+/* ---- time ------------------------------------------------------------------------------ */
+int rm_set_time(rm_context *ctx, int64_t current_time_us);          /* Simulator.getTime() */
+int64_t rm_air_time_us(int64_t hex_length);                         /* RadioPacket.java:67-75 */
+/* Simulator.java:321-335: event times of a packet given the simulator's current time */
+void rm_event_times(int64_t start_us, int64_t air_us, int64_t current_time_us,
+                    int64_t *t_start, int64_t *t_end);
+
+/* ---- transmit(): one packet, reference semantics ------------------------------------------
+ * txpower / channel: optional overrides ("rf-power", "wireless-channel",
+ * net/SimulatorJSONHandler.java:83-90); NULL = the source radio's values.
+ * Heard receivers are returned in node order.  *count gets the number of heard links even
+ * when it exceeds cap (then RM_ERR_CAPACITY).  interference (may be NULL) gets the packet
+ * level Tx-failure flag (UDGMRadioMedium.java:88-92). */
+int rm_transmit(rm_context *ctx, int32_t src, int64_t start_us, int64_t hex_length,
+                const double *txpower, const int32_t *channel,
+                int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                uint32_t *count, uint8_t *interference);
+
+/* ---- batched: all frames of one simulated tick in one pass -------------------------------- */
+int rm_tick_begin(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us);
+int rm_enqueue_tx(rm_context *ctx, int32_t src, int64_t start_us, int64_t air_us,
+                  const double *txpower, const int32_t *channel);
+int rm_enqueue_tx_records(rm_context *ctx, const rm_tx_record *recs, int32_t n);
+/* evaluates the tick and copies the heard links (packet-major, receiver ascending) out */
+int rm_tick_flush(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict,
+                  double *rssi, double *sinr, uint32_t cap, uint32_t *count,
+                  uint8_t *pkt_interference /* [n_new] or NULL */,
+                  uint32_t *pkt_offset /* [n_new+1] or NULL */);
+
+/* ---- device-resident path (bench, multi-GPU): no host copies ------------------------------ */
+/* build tx records for sources `dev_src[0..n)` from the resident node state */
+int rm_pack_tx_device(rm_context *ctx, const int32_t *dev_src, int32_t n, int64_t start_us,
+                      int64_t air_us, rm_tx_record *dev_out);
+/* evaluate one tick whose new frames are `dev_new[0..n_new)` (device memory, canonical order) */
+int rm_tick_run_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
+                       const rm_tx_record *dev_new, int32_t n_new);
+int rm_result_device(rm_context *ctx, rm_device_result *out);
+int rm_result_count(rm_context *ctx, uint32_t *count, uint32_t *dropped); /* synchronises */
+int rm_sync(rm_context *ctx);
+
+/* timing of the dominant kernel on the context's stream (HIP events around each launch) */
+int rm_profile_enable(rm_context *ctx, int enable);
+int rm_profile_read(rm_context *ctx, uint32_t *launches, double *total_ms);
+/* number of Tx->Rx link evaluations resolved by the last tick ( T * (N_loc) minus self links ) */
+int64_t rm_last_link_evaluations(const rm_context *ctx);
+
+/* ---- host-side helpers exported for tests ------------------------------------------------- */
+/* java.util.Random LCG: state after `steps` next() calls */
+uint64_t rm_lcg_jump(uint64_t state48, uint64_t steps);
+double rm_lcg_next_double(uint64_t *state48);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADIOMEDIUM_HIP_H */

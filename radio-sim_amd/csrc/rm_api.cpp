@@ -1,0 +1,951 @@
+// rm_api.cpp -- C-ABI (include/radiomedium_hip.h) of the MI355X radio-medium engine: context,
+// device-resident node state, on-air list, the per-tick launch sequence.  Compiled by hipcc.
+//
+// There is deliberately no CPU fallback in this file: every evaluation goes through the gfx950
+// kernels of rm_kernels.hip, and rm_create fails when no HIP device can be used.
+//
+// Reference paths: /root/reference/radio-medium/java/se/sics/emul8/radiomedium/.
+
+#include "rm_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define RM_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(RM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+#define RM_TRY(call)                                                                                   \
+    do {                                                                                               \
+        int r_ = (call);                                                                               \
+        if (r_ != RM_OK) return r_;                                                                    \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t want, bool keep = false, hipStream_t s = nullptr)
+    {
+        if (want <= n) return hipSuccess;
+        size_t grow = std::max(want, n + n / 2);
+        T *q = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&q), grow * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && n) {
+            e = hipMemcpyAsync(q, p, n * sizeof(T), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                (void)hipFree(q);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        n = grow;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+const char *model_name(int kind)
+{
+    switch (kind) {
+    case RM_MODEL_NULL: return "Null radio medium - just forwards incoming packets to all other nodes"; // NullRadioMedium.java:44
+    case RM_MODEL_UDGM: return "UDGM Radio Medium";                                                   // UDGMRadioMedium.java:28
+    case RM_MODEL_UDGM_CONST: return "UDGM Constant Loss Radio Medium";                               // UDGMConstantLossRadioMedium.java:12
+    case RM_MODEL_N2N: return "Matrix Radio Medium";                                                  // N2NRadioMedium.java:17
+    case RM_MODEL_LOGDIST: return "Log-distance SINR Radio Medium (MI355X)";
+    default: return "?";
+    }
+}
+
+} // namespace
+
+struct rm_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    rm_model_params params{};
+    double base_rssi = -100.0; // AbstractRadioMedium.java:38
+
+    // host mirror of the node table (Simulator.getNodes() snapshot)
+    int n = 0;
+    std::vector<double> x, y, z, txpower, rxprob, txprob;
+    std::vector<int32_t> channel, int_id;
+    std::vector<uint8_t> enabled;
+    // device-resident node state (SoA)
+    DevBuf<double> d_x, d_y, d_z, d_txpower, d_rxprob, d_txprob;
+    DevBuf<int32_t> d_channel, d_int_id;
+    DevBuf<uint8_t> d_enabled;
+    DevBuf<float4> d_rxf;
+    DevBuf<double> d_n2n;
+    int n2n_m = 0;
+
+    bool prefilter_dirty = true;
+    double org[3] = {0, 0, 0};
+    double coord_bound = 0, f32_slack = 0;
+
+    int rx_first = 0, rx_count = -1; // -1 = all nodes
+    uint32_t cap = 1u << 22;
+
+    int64_t current_time = 0;
+    int64_t t_begin = 0, t_end = 0;
+    bool in_tick = false;
+
+    // on-air list (host-record mode)
+    std::vector<rm_tx_record> onair;   // frames of earlier ticks still on the air (SINR mode)
+    std::vector<rm_tx_record> pending; // frames enqueued in the current tick
+    DevBuf<rm_tx_record> d_tx;
+
+    // per-tick device buffers
+    DevBuf<float4> d_txf;
+    DevBuf<double> d_txd;
+    DevBuf<uint32_t> d_cnt, d_off, d_partial, d_slot_off;
+    DevBuf<uint32_t> d_counters; // [0..1] stage_count, [2..4] out_count
+    DevBuf<int32_t> d_st_pkt, d_st_dst, d_st_next, d_head;
+    DevBuf<uint32_t> d_st_rank;
+    DevBuf<double> d_st_aux, d_st_lin, d_st_sinr;
+    DevBuf<uint8_t> d_st_flags, d_st_coll;
+    DevBuf<int32_t> d_out_pkt, d_out_dst;
+    DevBuf<uint8_t> d_out_verdict, d_pkt_interf;
+    DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob;
+    DevBuf<uint32_t> d_draw_scan, d_scan_block;
+    DevBuf<uint64_t> d_rng, d_pkt_rng;
+    uint32_t alloc_cap = 0;
+
+    // last tick
+    rm::TickDev last{};
+    int last_n_new = 0;
+    bool have_result = false;
+    int64_t last_links = 0;
+
+    // profiling of the dominant kernel
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    uint32_t prof_launches = 0;
+    double prof_ms = 0;
+};
+
+namespace {
+
+bool is_sinr(const rm_context *c) { return c->params.kind == RM_MODEL_LOGDIST && (c->params.flags & RM_LD_SINR); }
+
+int part_first(const rm_context *c) { return c->rx_count < 0 ? 0 : c->rx_first; }
+int part_count(const rm_context *c) { return c->rx_count < 0 ? c->n : c->rx_count; }
+
+bool frac(double p) { return p > 0.0 && p < 1.0; }
+
+// can a java.util.Random draw ever be consumed with the current model + node table?
+bool maybe_draws(const rm_context *c)
+{
+    const int k = c->params.kind;
+    if (k == RM_MODEL_NULL || k == RM_MODEL_UDGM_CONST) return false;
+    if (k == RM_MODEL_N2N) return true;
+    if (k == RM_MODEL_UDGM && c->params.udgm_success_ratio_rx != 1.0) return true;
+    for (int i = 0; i < c->n; ++i)
+        if (frac(c->rxprob[i]) || frac(c->txprob[i])) return true;
+    return false;
+}
+
+int validate_model(const rm_model_params *p)
+{
+    if (p->kind < RM_MODEL_NULL || p->kind > RM_MODEL_LOGDIST) return fail(RM_ERR_INVALID, "unknown model kind");
+    if (p->kind == RM_MODEL_LOGDIST) {
+        if (!(p->ld_d0 > 0.0) || !(p->ld_exponent >= 0.0) || !(p->ld_sigma_db >= 0.0) || !(p->ld_clip >= 0.0))
+            return fail(RM_ERR_INVALID, "logdist: need d0 > 0, exponent >= 0, sigma >= 0, clip >= 0");
+    }
+    return RM_OK;
+}
+
+void recompute_frame(rm_context *c)
+{
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int i = 0; i < c->n; ++i) {
+        const double v[3] = {c->x[i], c->y[i], c->z[i]};
+        for (int a = 0; a < 3; ++a) {
+            if (i == 0 || v[a] < lo[a]) lo[a] = v[a];
+            if (i == 0 || v[a] > hi[a]) hi[a] = v[a];
+        }
+    }
+    double bound = 0;
+    for (int a = 0; a < 3; ++a) {
+        c->org[a] = 0.5 * (lo[a] + hi[a]);
+        bound = std::max(bound, std::max(hi[a] - c->org[a], c->org[a] - lo[a]));
+    }
+    c->coord_bound = bound * (1.0 + 1e-9) + 1e-300;
+    // fp32 frame: each coordinate is off by at most 2^-24 * bound; see DESIGN.md "Pre-filter"
+    c->f32_slack = 4.0 * std::sqrt(3.0) * std::ldexp(1.0, -24) * c->coord_bound;
+    c->prefilter_dirty = true;
+}
+
+rm::ModelDev model_dev(const rm_context *c)
+{
+    rm::ModelDev m{};
+    const rm_model_params &p = c->params;
+    m.kind = p.kind;
+    m.flags = p.flags;
+    m.udgm_ratio_rx = p.udgm_success_ratio_rx;
+    m.udgm_range = p.udgm_transmission_range;
+    m.const_range = p.const_range;
+    m.n2n = c->d_n2n.p;
+    m.n2n_m = c->n2n_m;
+    m.ld_pl0 = p.ld_pl0_db;
+    m.ld_exp = p.ld_exponent;
+    m.ld_d0 = p.ld_d0;
+    m.ld_sigma = p.ld_sigma_db;
+    m.ld_clip = p.ld_clip;
+    m.ld_seed_mixed = rm::host_mix64(p.ld_seed + 0x9E3779B97F4A7C15ull);
+    m.ld_sens = p.ld_sensitivity_dbm;
+    m.ld_noise = p.ld_noise_dbm;
+    m.ld_capture = p.ld_capture_db;
+    m.ld_ifloor = p.ld_ifloor_dbm;
+    m.ld_noise_lin = rm::host_det_pow10(p.ld_noise_dbm / 10.0);
+    m.ld_level = p.ld_sensitivity_dbm;
+    if ((p.flags & RM_LD_SINR) && p.ld_ifloor_dbm < m.ld_level) m.ld_level = p.ld_ifloor_dbm;
+    m.org_x = c->org[0];
+    m.org_y = c->org[1];
+    m.org_z = c->org[2];
+    m.coord_bound = c->coord_bound;
+    m.f32_slack = c->f32_slack;
+    m.geo_cut = -1.0;
+    if (p.kind == RM_MODEL_UDGM) {
+        const double r = std::fabs(p.udgm_transmission_range);
+        m.geo_cut = (r == 0.0) ? -1.0 : r * (1.0 + 1e-9); // ratio > 1.0 -> unheard, d == range is in
+    } else if (p.kind == RM_MODEL_UDGM_CONST) {
+        m.geo_cut = (p.const_range > 0.0) ? p.const_range * (1.0 + 1e-9) : -1.0; // strict distance < range
+    }
+    return m;
+}
+
+rm::NodesDev nodes_dev(rm_context *c)
+{
+    rm::NodesDev nd{};
+    nd.n = c->n;
+    nd.x = c->d_x.p;
+    nd.y = c->d_y.p;
+    nd.z = c->d_z.p;
+    nd.rxprob = c->d_rxprob.p;
+    nd.txprob = c->d_txprob.p;
+    nd.txpower = c->d_txpower.p;
+    nd.channel = c->d_channel.p;
+    nd.enabled = c->d_enabled.p;
+    nd.int_id = c->d_int_id.p;
+    nd.rxf = c->d_rxf.p;
+    return nd;
+}
+
+int ensure_link_buffers(rm_context *c)
+{
+    if (c->alloc_cap == c->cap && c->d_counters.p) return RM_OK;
+    const size_t cap = c->cap;
+    RM_HIP(c->d_counters.ensure(8));
+    RM_HIP(c->d_st_pkt.ensure(cap));
+    RM_HIP(c->d_st_dst.ensure(cap));
+    RM_HIP(c->d_st_next.ensure(cap));
+    RM_HIP(c->d_st_rank.ensure(cap));
+    RM_HIP(c->d_st_aux.ensure(cap));
+    RM_HIP(c->d_st_lin.ensure(cap));
+    RM_HIP(c->d_st_sinr.ensure(cap));
+    RM_HIP(c->d_st_flags.ensure(cap));
+    RM_HIP(c->d_st_coll.ensure(cap));
+    RM_HIP(c->d_out_pkt.ensure(cap));
+    RM_HIP(c->d_out_dst.ensure(cap));
+    RM_HIP(c->d_out_verdict.ensure(cap));
+    RM_HIP(c->d_out_rssi.ensure(cap));
+    RM_HIP(c->d_out_sinr.ensure(cap));
+    RM_HIP(c->d_out_prob.ensure(cap));
+    RM_HIP(c->d_draw_scan.ensure(cap + 1));
+    RM_HIP(c->d_scan_block.ensure(cap / 2048 + 2));
+    c->alloc_cap = c->cap;
+    return RM_OK;
+}
+
+int prepare_nodes(rm_context *c)
+{
+    if (!c->prefilter_dirty) return RM_OK;
+    RM_HIP(c->d_rxf.ensure(std::max(c->n, 1)));
+    RM_HIP(rm::launch_prep_rx(c->stream, nodes_dev(c), model_dev(c)));
+    c->prefilter_dirty = false;
+    return RM_OK;
+}
+
+// the per-tick launch sequence; `tx` is the on-air list in device memory
+int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
+{
+    const int n_new = n_active - first_new;
+    c->have_result = false;
+    c->last_n_new = n_new;
+    RM_TRY(ensure_link_buffers(c));
+    RM_TRY(prepare_nodes(c));
+
+    const bool sinr = is_sinr(c);
+    const bool stochastic = maybe_draws(c);
+    const int rx_first = part_first(c), rx_count = part_count(c);
+    if (stochastic && (rx_first != 0 || rx_count != c->n))
+        return fail(RM_ERR_STATE, "receiver partitions with probabilistic links (java.util.Random draws) are not "
+                                  "supported yet: the draw order spans the ranks");
+
+    rm::TickDev t{};
+    t.tx = tx;
+    t.n_active = n_active;
+    t.first_new = first_new;
+    t.first_eval = sinr ? 0 : first_new;
+    const int n_eval = n_active - t.first_eval;
+    const int n_chunks = (n_eval + rm::kTxChunk - 1) / rm::kTxChunk;
+    t.cnt_base = ((first_new - t.first_eval) / rm::kTxChunk) * rm::kTxChunk;
+    t.shift = (first_new - t.first_eval) - t.cnt_base;
+    t.n_cnt = n_chunks * rm::kTxChunk - t.cnt_base;
+    t.rx_first = rx_first;
+    t.rx_count = rx_count;
+    // enough waves to fill 256 CUs x 4 SIMDs several times over, else one receiver per lane
+    const long waves4 = long((rx_count + 255) / 256) * n_chunks;
+    t.rpt = (waves4 >= 4096) ? 4 : 1;
+    t.n_slabs = (rx_count + 64 * t.rpt - 1) / (64 * t.rpt);
+    if (n_new > 0 && t.n_slabs > 0) {
+        const int want_groups = std::max(1, std::min(t.n_slabs, 16384 / std::max(1, t.n_cnt)));
+        t.slabs_per_group = (t.n_slabs + want_groups - 1) / want_groups;
+        t.n_groups = (t.n_slabs + t.slabs_per_group - 1) / t.slabs_per_group;
+    } else {
+        t.slabs_per_group = 1;
+        t.n_groups = 0;
+    }
+
+    const size_t cells = size_t(std::max(t.n_cnt, 0) / rm::kTxChunk) * std::max(t.n_slabs, 1) * 64;
+    RM_HIP(c->d_txf.ensure(std::max(n_eval, 1)));
+    RM_HIP(c->d_txd.ensure(std::max(n_eval, 1)));
+    RM_HIP(c->d_cnt.ensure(std::max<size_t>(cells, 1)));
+    RM_HIP(c->d_off.ensure(std::max<size_t>(cells, 1)));
+    RM_HIP(c->d_partial.ensure(std::max<size_t>(size_t(std::max(t.n_cnt, 0)) * std::max(t.n_groups, 1), 1)));
+    RM_HIP(c->d_slot_off.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
+    RM_HIP(c->d_pkt_interf.ensure(std::max(n_new, 1)));
+    RM_HIP(c->d_pkt_rng.ensure(std::max(n_new, 1)));
+    RM_HIP(c->d_head.ensure(std::max(rx_count, 1)));
+    if (!c->d_rng.p) {
+        RM_HIP(c->d_rng.ensure(1));
+        const uint64_t s0 = (uint64_t(0) ^ 0x5DEECE66Dull) & ((1ull << 48) - 1);
+        RM_HIP(hipMemcpyAsync(c->d_rng.p, &s0, 8, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+    }
+
+    t.txf = c->d_txf.p;
+    t.txd = c->d_txd.p;
+    t.cnt = c->d_cnt.p;
+    t.off = c->d_off.p;
+    t.partial = c->d_partial.p;
+    t.slot_off = c->d_slot_off.p;
+    t.stage_count = c->d_counters.p;
+    t.cap = c->cap;
+    t.st_pkt = c->d_st_pkt.p;
+    t.st_dst = c->d_st_dst.p;
+    t.st_rank = c->d_st_rank.p;
+    t.st_aux = c->d_st_aux.p;
+    t.st_lin = c->d_st_lin.p;
+    t.st_sinr = c->d_st_sinr.p;
+    t.st_next = c->d_st_next.p;
+    t.st_flags = c->d_st_flags.p;
+    t.st_coll = c->d_st_coll.p;
+    t.head = c->d_head.p;
+    t.out_count = c->d_counters.p + 2;
+    t.out_pkt = c->d_out_pkt.p;
+    t.out_dst = c->d_out_dst.p;
+    t.out_verdict = c->d_out_verdict.p;
+    t.out_rssi = c->d_out_rssi.p;
+    t.out_sinr = c->d_out_sinr.p;
+    t.out_prob = c->d_out_prob.p;
+    t.pkt_interference = c->d_pkt_interf.p;
+    t.draw_scan = c->d_draw_scan.p;
+    t.scan_block = c->d_scan_block.p;
+    t.rng_state = c->d_rng.p;
+    t.pkt_rng = c->d_pkt_rng.p;
+
+    hipStream_t s = c->stream;
+    RM_HIP(hipMemsetAsync(c->d_counters.p, 0, 8 * sizeof(uint32_t), s));
+    c->last = t;
+    c->last_links = 0;
+    if (n_new <= 0 || rx_count <= 0) {
+        c->have_result = true;
+        return RM_OK;
+    }
+    if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+
+    const rm::ModelDev m = model_dev(c);
+    const rm::NodesDev nd = nodes_dev(c);
+    rm::LaunchCfg cfg{};
+    cfg.stochastic = stochastic;
+    cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
+
+    RM_HIP(rm::launch_prep_tx(s, m, t));
+    if (c->profile) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            RM_HIP(hipEventCreate(&a));
+            RM_HIP(hipEventCreate(&b));
+            c->ev_pool.emplace_back(a, b);
+        }
+        RM_HIP(hipEventRecord(c->ev_pool[c->ev_used].first, s));
+    }
+    RM_HIP(rm::launch_allpairs(s, nd, m, t, cfg));
+    if (c->profile) {
+        RM_HIP(hipEventRecord(c->ev_pool[c->ev_used].second, s));
+        c->ev_used++;
+    }
+    if (sinr) RM_HIP(rm::launch_self_entries(s, t));
+    RM_HIP(rm::launch_offsets(s, t));
+    if (sinr) RM_HIP(rm::launch_sinr(s, m, t));
+    RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
+    if (stochastic) RM_HIP(rm::launch_draws(s, m, t));
+
+    // links resolved: every evaluated frame against every other node (T * (N-1)); for a receiver
+    // partition the frame's own source may lie outside it, so the product is reported as is
+    c->last_links = (rx_count == c->n) ? int64_t(n_eval) * (rx_count - 1) : int64_t(n_eval) * rx_count;
+    c->have_result = true;
+    return RM_OK;
+}
+
+int drain_profile(rm_context *c)
+{
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        RM_HIP(hipEventSynchronize(c->ev_pool[i].second));
+        RM_HIP(hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+        c->prof_ms += ms;
+        c->prof_launches++;
+    }
+    c->ev_used = 0;
+    return RM_OK;
+}
+
+template <typename T> int upload(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
+{
+    RM_HIP(d.ensure(std::max<size_t>(h.size(), 1)));
+    if (!h.empty()) RM_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return RM_OK;
+}
+
+rm_tx_record make_record(const rm_context *c, int32_t src, int64_t start_us, int64_t air_us, const double *txpower,
+                         const int32_t *channel)
+{
+    rm_tx_record r;
+    r.x = c->x[src];
+    r.y = c->y[src];
+    r.z = c->z[src];
+    r.txpower = txpower ? *txpower : c->txpower[src];   // RadioPacket.java:49 / setTransmitPower
+    r.txprob = c->txprob[src];
+    r.start_us = start_us;
+    r.air_us = air_us;
+    r.src = src;
+    r.channel = channel ? *channel : c->channel[src];   // RadioPacket.java:50 / setWirelessChannel
+    return r;
+}
+
+bool still_on_air(const rm_tx_record &r, int64_t t_begin) { return r.start_us + r.air_us > t_begin; }
+
+} // namespace
+
+extern "C" {
+
+int rm_abi_version(void) { return RM_ABI_VERSION; }
+
+const char *rm_last_error(void) { return g_err.c_str(); }
+
+int rm_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RM_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int rm_create(int device_ordinal, rm_context **out)
+{
+    if (!out) return fail(RM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RM_ERR_NO_DEVICE, std::string("no HIP device available (") +
+                                          (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                                          "); this engine has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(RM_ERR_INVALID, "device ordinal out of range");
+    RM_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    RM_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    rm_context *c = new rm_context();
+    c->device = device_ordinal;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(RM_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    c->own_stream = true;
+    rm_model_defaults(&c->params, RM_MODEL_NULL); // Main.java:66-70: NullRadioMedium is the default
+    *out = c;
+    return RM_OK;
+}
+
+void rm_destroy(rm_context *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &p : c->ev_pool) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_rxprob.release();
+    c->d_txprob.release(); c->d_channel.release(); c->d_int_id.release(); c->d_enabled.release();
+    c->d_rxf.release(); c->d_n2n.release(); c->d_tx.release(); c->d_txf.release(); c->d_txd.release();
+    c->d_cnt.release(); c->d_off.release(); c->d_partial.release(); c->d_slot_off.release();
+    c->d_counters.release(); c->d_st_pkt.release(); c->d_st_dst.release(); c->d_st_next.release();
+    c->d_head.release(); c->d_st_rank.release(); c->d_st_aux.release(); c->d_st_lin.release();
+    c->d_st_sinr.release(); c->d_st_flags.release(); c->d_st_coll.release(); c->d_out_pkt.release();
+    c->d_out_dst.release(); c->d_out_verdict.release(); c->d_pkt_interf.release(); c->d_out_rssi.release();
+    c->d_out_sinr.release(); c->d_out_prob.release(); c->d_draw_scan.release(); c->d_scan_block.release();
+    c->d_rng.release(); c->d_pkt_rng.release();
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *rm_get_name(const rm_context *c) { return c ? model_name(c->params.kind) : ""; }
+
+int rm_set_stream(rm_context *c, void *hip_stream)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    RM_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream) RM_HIP(hipStreamDestroy(c->stream));
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return RM_OK;
+}
+
+void rm_model_defaults(rm_model_params *p, int32_t kind)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->kind = kind;
+    p->udgm_success_ratio_tx = 1.0;     // UDGMRadioMedium.java:18
+    p->udgm_success_ratio_rx = 1.0;     // :20
+    p->udgm_transmission_range = 50.0;  // :22
+    p->udgm_interference_range = 100.0; // :24
+    p->const_range = 100.0;             // UDGMConstantLossRadioMedium.java:8
+    p->ld_pl0_db = 40.0;
+    p->ld_exponent = 3.0;
+    p->ld_d0 = 1.0;
+    p->ld_sigma_db = 0.0;
+    p->ld_clip = 3.0;
+    p->ld_seed = 0;
+    p->ld_sensitivity_dbm = -95.0;
+    p->ld_noise_dbm = -100.0;           // AbstractRadioMedium.java:38
+    p->ld_capture_db = 3.0;
+    p->ld_ifloor_dbm = -110.0;
+}
+
+int rm_set_model(rm_context *c, const rm_model_params *p)
+{
+    if (!c || !p) return fail(RM_ERR_INVALID, "NULL argument");
+    RM_TRY(validate_model(p));
+    c->params = *p;
+    c->prefilter_dirty = true;
+    c->onair.clear();
+    c->pending.clear();
+    return RM_OK;
+}
+
+int rm_get_model(const rm_context *c, rm_model_params *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    *out = c->params;
+    return RM_OK;
+}
+
+int rm_set_n2n_matrix(rm_context *c, int32_t m, const double *row_major)
+{
+    if (!c || m < 0 || (m > 0 && !row_major)) return fail(RM_ERR_INVALID, "bad matrix");
+    RM_HIP(hipSetDevice(c->device));
+    c->n2n_m = m;
+    if (m == 0) {
+        c->d_n2n.release();
+        return RM_OK;
+    }
+    RM_HIP(c->d_n2n.ensure(size_t(m) * m));
+    RM_HIP(hipMemcpyAsync(c->d_n2n.p, row_major, size_t(m) * m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_set_base_rssi(rm_context *c, double rssi)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    c->base_rssi = rssi;
+    return RM_OK;
+}
+
+double rm_get_base_rssi(const rm_context *c, int32_t node)
+{
+    (void)node; // AbstractRadioMedium.java:46-48: the same value for every node
+    return c ? c->base_rssi : -100.0;
+}
+
+int rm_seed(rm_context *c, int64_t seed)
+{
+    return rm_set_rng_state(c, (uint64_t(seed) ^ 0x5DEECE66Dull) & ((1ull << 48) - 1));
+}
+
+int rm_set_rng_state(rm_context *c, uint64_t state48)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    RM_HIP(hipSetDevice(c->device));
+    RM_HIP(c->d_rng.ensure(1));
+    state48 &= (1ull << 48) - 1;
+    RM_HIP(hipMemcpyAsync(c->d_rng.p, &state48, 8, hipMemcpyHostToDevice, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_get_rng_state(rm_context *c, uint64_t *state48)
+{
+    if (!c || !state48) return fail(RM_ERR_INVALID, "NULL argument");
+    RM_HIP(hipSetDevice(c->device));
+    if (!c->d_rng.p) RM_TRY(rm_seed(c, 0));
+    RM_HIP(hipMemcpyAsync(state48, c->d_rng.p, 8, hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, const double *z,
+                    const double *txpower, const int32_t *channel, const uint8_t *enabled, const double *rxprob,
+                    const double *txprob, const int32_t *int_id)
+{
+    if (!c || n < 0) return fail(RM_ERR_INVALID, "bad arguments");
+    if (n > 0 && (!x || !y)) return fail(RM_ERR_INVALID, "x and y are required");
+    for (int i = 0; i < n; ++i) {
+        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || (z && !std::isfinite(z[i])))
+            return fail(RM_ERR_INVALID, "node positions must be finite");
+    }
+    RM_HIP(hipSetDevice(c->device));
+    c->n = n;
+    c->x.assign(x, x + n);
+    c->y.assign(y, y + n);
+    if (z) c->z.assign(z, z + n); else c->z.assign(n, 0.0);                          // Position.java:44-46
+    if (txpower) c->txpower.assign(txpower, txpower + n); else c->txpower.assign(n, 0.0);   // Transciever.java:11
+    if (channel) c->channel.assign(channel, channel + n); else c->channel.assign(n, 26);    // :12
+    if (enabled) c->enabled.assign(enabled, enabled + n); else c->enabled.assign(n, 1);     // :13
+    if (rxprob) c->rxprob.assign(rxprob, rxprob + n); else c->rxprob.assign(n, 1.0);        // :17
+    if (txprob) c->txprob.assign(txprob, txprob + n); else c->txprob.assign(n, 1.0);        // :18
+    if (int_id) c->int_id.assign(int_id, int_id + n);
+    else {
+        c->int_id.resize(n);
+        for (int i = 0; i < n; ++i) c->int_id[i] = i + 1;
+    }
+    RM_TRY(upload(c->d_x, c->x, c->stream));
+    RM_TRY(upload(c->d_y, c->y, c->stream));
+    RM_TRY(upload(c->d_z, c->z, c->stream));
+    RM_TRY(upload(c->d_txpower, c->txpower, c->stream));
+    RM_TRY(upload(c->d_rxprob, c->rxprob, c->stream));
+    RM_TRY(upload(c->d_txprob, c->txprob, c->stream));
+    RM_TRY(upload(c->d_channel, c->channel, c->stream));
+    RM_TRY(upload(c->d_int_id, c->int_id, c->stream));
+    RM_TRY(upload(c->d_enabled, c->enabled, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    recompute_frame(c);
+    c->onair.clear();
+    c->pending.clear();
+    if (c->rx_count >= 0 && c->rx_first + c->rx_count > n) {
+        c->rx_first = 0;
+        c->rx_count = -1;
+    }
+    return RM_OK;
+}
+
+int rm_node_update(rm_context *c, int32_t i, double x, double y, double z, double txpower, int32_t channel,
+                   uint8_t enabled, double rxprob, double txprob)
+{
+    if (!c || i < 0 || i >= c->n) return fail(RM_ERR_INVALID, "node index out of range");
+    if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return fail(RM_ERR_INVALID, "position must be finite");
+    RM_HIP(hipSetDevice(c->device));
+    c->x[i] = x; c->y[i] = y; c->z[i] = z; c->txpower[i] = txpower; c->channel[i] = channel;
+    c->enabled[i] = enabled; c->rxprob[i] = rxprob; c->txprob[i] = txprob;
+    hipStream_t s = c->stream;
+    RM_HIP(hipMemcpyAsync(c->d_x.p + i, &c->x[i], 8, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_y.p + i, &c->y[i], 8, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_z.p + i, &c->z[i], 8, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_txpower.p + i, &c->txpower[i], 8, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_rxprob.p + i, &c->rxprob[i], 8, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_txprob.p + i, &c->txprob[i], 8, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_channel.p + i, &c->channel[i], 4, hipMemcpyHostToDevice, s));
+    RM_HIP(hipMemcpyAsync(c->d_enabled.p + i, &c->enabled[i], 1, hipMemcpyHostToDevice, s));
+    RM_HIP(hipStreamSynchronize(s));
+    const double dv[3] = {x - c->org[0], y - c->org[1], z - c->org[2]};
+    if (std::fabs(dv[0]) > c->coord_bound || std::fabs(dv[1]) > c->coord_bound || std::fabs(dv[2]) > c->coord_bound)
+        recompute_frame(c);
+    c->prefilter_dirty = true;
+    return RM_OK;
+}
+
+int rm_node_count(const rm_context *c) { return c ? c->n : fail(RM_ERR_INVALID, "ctx is NULL"); }
+
+int rm_set_partition(rm_context *c, int32_t first, int32_t count)
+{
+    if (!c || first < 0 || count < 0 || first + count > c->n) return fail(RM_ERR_INVALID, "partition out of range");
+    c->rx_first = first;
+    c->rx_count = count;
+    return RM_OK;
+}
+
+int rm_set_link_capacity(rm_context *c, uint32_t max_links)
+{
+    if (!c || max_links == 0) return fail(RM_ERR_INVALID, "bad capacity");
+    c->cap = max_links;
+    return RM_OK;
+}
+
+int rm_set_time(rm_context *c, int64_t t)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    c->current_time = t;
+    return RM_OK;
+}
+
+int64_t rm_air_time_us(int64_t hex_length) { return hex_length * 32; } // RadioPacket.java:72
+
+void rm_event_times(int64_t start_us, int64_t air_us, int64_t current_time_us, int64_t *t_start, int64_t *t_end)
+{
+    int64_t packetTime = start_us; // Simulator.java:323-326
+    if (packetTime < current_time_us) packetTime = current_time_us;
+    if (t_start) *t_start = packetTime;
+    if (t_end) *t_end = packetTime + air_us;
+}
+
+int rm_tick_begin(rm_context *c, int64_t t_begin_us, int64_t t_end_us)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    c->t_begin = t_begin_us;
+    c->t_end = t_end_us;
+    c->pending.clear();
+    if (is_sinr(c)) {
+        size_t k = 0;
+        for (size_t i = 0; i < c->onair.size(); ++i)
+            if (still_on_air(c->onair[i], t_begin_us)) c->onair[k++] = c->onair[i];
+        c->onair.resize(k);
+    } else {
+        c->onair.clear();
+    }
+    c->in_tick = true;
+    return RM_OK;
+}
+
+int rm_enqueue_tx(rm_context *c, int32_t src, int64_t start_us, int64_t air_us, const double *txpower,
+                  const int32_t *channel)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (!c->in_tick) return fail(RM_ERR_STATE, "rm_enqueue_tx outside rm_tick_begin / rm_tick_flush");
+    if (src < 0 || src >= c->n) return fail(RM_ERR_INVALID, "could not find source node"); // SimulatorJSONHandler.java:75-77
+    if (air_us < 0) return fail(RM_ERR_INVALID, "negative air time");
+    c->pending.push_back(make_record(c, src, start_us, air_us, txpower, channel));
+    return RM_OK;
+}
+
+int rm_enqueue_tx_records(rm_context *c, const rm_tx_record *recs, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && !recs)) return fail(RM_ERR_INVALID, "bad arguments");
+    if (!c->in_tick) return fail(RM_ERR_STATE, "rm_enqueue_tx_records outside a tick");
+    for (int i = 0; i < n; ++i) {
+        if (recs[i].src >= c->n) return fail(RM_ERR_INVALID, "record source out of range");
+        c->pending.push_back(recs[i]);
+    }
+    return RM_OK;
+}
+
+static int copy_out(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
+                    uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    hipStream_t s = c->stream;
+    uint32_t oc[3] = {0, 0, 0};
+    RM_HIP(hipMemcpyAsync(oc, c->d_counters.p + 2, sizeof(oc), hipMemcpyDeviceToHost, s));
+    RM_HIP(hipStreamSynchronize(s));
+    if (count) *count = oc[2];
+    const uint32_t k = std::min(oc[0], cap);
+    if (k) {
+        if (pkt) RM_HIP(hipMemcpyAsync(pkt, c->d_out_pkt.p, k * 4ull, hipMemcpyDeviceToHost, s));
+        if (dst) RM_HIP(hipMemcpyAsync(dst, c->d_out_dst.p, k * 4ull, hipMemcpyDeviceToHost, s));
+        if (verdict) RM_HIP(hipMemcpyAsync(verdict, c->d_out_verdict.p, k, hipMemcpyDeviceToHost, s));
+        if (rssi) RM_HIP(hipMemcpyAsync(rssi, c->d_out_rssi.p, k * 8ull, hipMemcpyDeviceToHost, s));
+        if (sinr) RM_HIP(hipMemcpyAsync(sinr, c->d_out_sinr.p, k * 8ull, hipMemcpyDeviceToHost, s));
+    }
+    const int n_new = c->last_n_new;
+    if (pkt_interference && n_new > 0)
+        RM_HIP(hipMemcpyAsync(pkt_interference, c->d_pkt_interf.p, size_t(n_new), hipMemcpyDeviceToHost, s));
+    if (pkt_offset) {
+        if (n_new > 0 && part_count(c) > 0)
+            RM_HIP(hipMemcpyAsync(pkt_offset, c->d_slot_off.p + c->last.shift, (size_t(n_new) + 1) * 4,
+                                  hipMemcpyDeviceToHost, s));
+        else
+            for (int i = 0; i <= std::max(n_new, 0); ++i) pkt_offset[i] = 0;
+    }
+    RM_HIP(hipStreamSynchronize(s));
+    if (oc[1]) return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    if (oc[2] > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
+    return RM_OK;
+}
+
+int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
+                  uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (!c->in_tick) return fail(RM_ERR_STATE, "rm_tick_flush without rm_tick_begin");
+    RM_HIP(hipSetDevice(c->device));
+    c->in_tick = false;
+    const int first_new = int(c->onair.size());
+    std::vector<rm_tx_record> all;
+    all.reserve(c->onair.size() + c->pending.size());
+    all.insert(all.end(), c->onair.begin(), c->onair.end());
+    all.insert(all.end(), c->pending.begin(), c->pending.end());
+    RM_HIP(c->d_tx.ensure(std::max<size_t>(all.size(), 1)));
+    if (!all.empty())
+        RM_HIP(hipMemcpyAsync(c->d_tx.p, all.data(), all.size() * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
+    // the host vector must outlive the async copy
+    RM_HIP(hipStreamSynchronize(c->stream));
+    RM_TRY(run_tick(c, c->d_tx.p, int(all.size()), first_new));
+    if (is_sinr(c)) c->onair.swap(all);
+    c->pending.clear();
+    return copy_out(c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+}
+
+int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length, const double *txpower,
+                const int32_t *channel, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                uint32_t *count, uint8_t *interference)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (src < 0 || src >= c->n) return fail(RM_ERR_INVALID, "could not find source node");
+    if (hex_length < 0) return fail(RM_ERR_INVALID, "negative packet length");
+    RM_TRY(rm_tick_begin(c, start_us, start_us));
+    RM_TRY(rm_enqueue_tx(c, src, start_us, rm_air_time_us(hex_length), txpower, channel));
+    return rm_tick_flush(c, nullptr, dst, verdict, rssi, sinr, cap, count, interference, nullptr);
+}
+
+int rm_pack_tx_device(rm_context *c, const int32_t *dev_src, int32_t n, int64_t start_us, int64_t air_us,
+                      rm_tx_record *dev_out)
+{
+    if (!c || n < 0 || (n > 0 && (!dev_src || !dev_out))) return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    RM_HIP(rm::launch_pack_tx(c->stream, nodes_dev(c), dev_src, n, start_us, air_us, dev_out));
+    return RM_OK;
+}
+
+int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const rm_tx_record *dev_new, int32_t n_new)
+{
+    if (!c || n_new < 0 || (n_new > 0 && !dev_new)) return fail(RM_ERR_INVALID, "bad arguments");
+    if (is_sinr(c))
+        return fail(RM_ERR_STATE, "device-resident ticks with the SINR on-air list are not available yet; "
+                                  "use rm_tick_begin / rm_enqueue_tx_records / rm_tick_flush");
+    RM_HIP(hipSetDevice(c->device));
+    c->t_begin = t_begin_us;
+    c->t_end = t_end_us;
+    return run_tick(c, dev_new, n_new, 0);
+}
+
+int rm_result_device(rm_context *c, rm_device_result *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    out->count = c->d_counters.p + 2;
+    out->pkt_offset = c->d_slot_off.p + c->last.shift;
+    out->pkt = c->d_out_pkt.p;
+    out->dst = c->d_out_dst.p;
+    out->verdict = c->d_out_verdict.p;
+    out->rssi = c->d_out_rssi.p;
+    out->sinr = c->d_out_sinr.p;
+    out->capacity = c->cap;
+    return RM_OK;
+}
+
+int rm_result_count(rm_context *c, uint32_t *count, uint32_t *dropped)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    uint32_t oc[3];
+    RM_HIP(hipMemcpyAsync(oc, c->d_counters.p + 2, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    if (count) *count = oc[2];
+    if (dropped) *dropped = oc[1];
+    return RM_OK;
+}
+
+int rm_sync(rm_context *c)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    RM_HIP(hipSetDevice(c->device));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_profile_enable(rm_context *c, int enable)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(drain_profile(c));
+    c->profile = enable != 0;
+    c->prof_launches = 0;
+    c->prof_ms = 0;
+    return RM_OK;
+}
+
+int rm_profile_read(rm_context *c, uint32_t *launches, double *total_ms)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(drain_profile(c));
+    if (launches) *launches = c->prof_launches;
+    if (total_ms) *total_ms = c->prof_ms;
+    return RM_OK;
+}
+
+int64_t rm_last_link_evaluations(const rm_context *c) { return c ? c->last_links : 0; }
+
+uint64_t rm_lcg_jump(uint64_t state48, uint64_t steps)
+{
+    uint64_t A, C;
+    rm::host_lcg_jump_map(steps, &A, &C);
+    return (A * state48 + C) & ((1ull << 48) - 1);
+}
+
+double rm_lcg_next_double(uint64_t *state48)
+{
+    const uint64_t a = 0x5DEECE66Dull, cc = 0xBull, mask = (1ull << 48) - 1;
+    uint64_t s = *state48;
+    s = (s * a + cc) & mask;
+    const int64_t hi = int64_t(s >> 22);
+    s = (s * a + cc) & mask;
+    const int64_t lo = int64_t(s >> 21);
+    *state48 = s;
+    return double((hi << 27) + lo) * 0x1.0p-53;
+}
+
+} // extern "C"

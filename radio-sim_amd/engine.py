@@ -1,0 +1,208 @@
+"""Object wrapper over one rm_context of libradiomedium_hip.so (no computation here)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ModelParams, DeviceResult, TX_RECORD_DTYPE, check
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class TickResult:
+    """Heard links of one evaluated tick, packet-major / receiver ascending."""
+
+    def __init__(self, count, pkt, dst, verdict, rssi, sinr, pkt_interference, pkt_offset):
+        self.count = count
+        self.pkt, self.dst, self.verdict, self.rssi, self.sinr = pkt, dst, verdict, rssi, sinr
+        self.pkt_interference, self.pkt_offset = pkt_interference, pkt_offset
+
+
+class Engine:
+    """One GPU context == one Simulator's radio medium (RadioMedium.java:35-45)."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        check(self._L.rm_create(device, C.byref(h)))
+        self._h = h
+        self.n = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- RadioMedium.getName / getBaseRSSI
+    def get_name(self):
+        return self._L.rm_get_name(self._h).decode()
+
+    def get_base_rssi(self, node=0):
+        return self._L.rm_get_base_rssi(self._h, node)
+
+    def set_base_rssi(self, v):
+        check(self._L.rm_set_base_rssi(self._h, v))
+
+    # -- model
+    @staticmethod
+    def default_params(kind):
+        p = ModelParams()
+        _lib.lib().rm_model_defaults(C.byref(p), kind)
+        return p
+
+    def set_model(self, kind, **kw):
+        p = self.default_params(kind)
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        check(self._L.rm_set_model(self._h, C.byref(p)))
+        return p
+
+    def set_n2n_matrix(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        assert m.ndim == 2 and m.shape[0] == m.shape[1]
+        check(self._L.rm_set_n2n_matrix(self._h, m.shape[0], m.ctypes.data))
+
+    # -- java.util.Random
+    def seed(self, seed):
+        check(self._L.rm_seed(self._h, seed))
+
+    @property
+    def rng_state(self):
+        s = C.c_uint64()
+        check(self._L.rm_get_rng_state(self._h, C.byref(s)))
+        return s.value
+
+    @rng_state.setter
+    def rng_state(self, v):
+        check(self._L.rm_set_rng_state(self._h, v))
+
+    # -- node state
+    def upload_nodes(self, x, y, z=None, txpower=None, channel=None, enabled=None, rxprob=None, txprob=None,
+                     int_id=None):
+        def arr(a, dt):
+            return None if a is None else np.ascontiguousarray(a, dtype=dt)
+        x = arr(x, np.float64)
+        n = len(x)
+        args = [x, arr(y, np.float64), arr(z, np.float64), arr(txpower, np.float64), arr(channel, np.int32),
+                arr(enabled, np.uint8), arr(rxprob, np.float64), arr(txprob, np.float64), arr(int_id, np.int32)]
+        for a in args:
+            assert a is None or a.shape == (n,)
+        check(self._L.rm_nodes_upload(self._h, n, *[_ptr(a) for a in args]))
+        self.n = n
+
+    def upload_table(self, nd):
+        """nd: any object with x,y,z,txpower,channel,enabled,rxprob,txprob,int_id arrays."""
+        self.upload_nodes(nd.x, nd.y, nd.z, nd.txpower, nd.channel, nd.enabled, nd.rxprob, nd.txprob, nd.int_id)
+
+    def update_node(self, i, x, y, z, txpower, channel, enabled, rxprob, txprob):
+        check(self._L.rm_node_update(self._h, i, x, y, z, txpower, channel, enabled, rxprob, txprob))
+
+    def set_partition(self, first, count):
+        check(self._L.rm_set_partition(self._h, first, count))
+
+    def set_link_capacity(self, cap):
+        check(self._L.rm_set_link_capacity(self._h, cap))
+
+    def set_time(self, t):
+        check(self._L.rm_set_time(self._h, t))
+
+    def set_stream(self, stream_ptr):
+        check(self._L.rm_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # -- transmit(): one packet
+    def transmit(self, src, start_us=0, hex_length=0, txpower=None, channel=None, cap=None):
+        cap = cap if cap is not None else max(1, self.n)
+        dst = np.empty(cap, dtype=np.int32)
+        verdict = np.empty(cap, dtype=np.uint8)
+        rssi = np.empty(cap, dtype=np.float64)
+        sinr = np.empty(cap, dtype=np.float64)
+        cnt = C.c_uint32()
+        interf = C.c_uint8()
+        tp = C.byref(C.c_double(txpower)) if txpower is not None else None
+        ch = C.byref(C.c_int32(channel)) if channel is not None else None
+        check(self._L.rm_transmit(self._h, src, start_us, hex_length, tp, ch, dst.ctypes.data, verdict.ctypes.data,
+                                  rssi.ctypes.data, sinr.ctypes.data, cap, C.byref(cnt), C.byref(interf)))
+        k = cnt.value
+        return TickResult(k, np.zeros(k, dtype=np.int32), dst[:k], verdict[:k], rssi[:k], sinr[:k],
+                          np.array([interf.value], dtype=np.uint8), np.array([0, k], dtype=np.uint32))
+
+    # -- batched tick (host records)
+    def tick_begin(self, t_begin, t_end):
+        check(self._L.rm_tick_begin(self._h, t_begin, t_end))
+        self._n_new = 0
+
+    def enqueue_tx(self, src, start_us, air_us, txpower=None, channel=None):
+        tp = C.byref(C.c_double(txpower)) if txpower is not None else None
+        ch = C.byref(C.c_int32(channel)) if channel is not None else None
+        check(self._L.rm_enqueue_tx(self._h, src, start_us, air_us, tp, ch))
+        self._n_new += 1
+
+    def enqueue_records(self, recs):
+        recs = np.ascontiguousarray(recs, dtype=TX_RECORD_DTYPE)
+        check(self._L.rm_enqueue_tx_records(self._h, recs.ctypes.data, len(recs)))
+        self._n_new += len(recs)
+
+    def tick_flush(self, cap=None):
+        n_new = self._n_new
+        cap = cap if cap is not None else max(1, n_new) * max(1, self.n)
+        cap = min(cap, 1 << 26)
+        pkt = np.empty(cap, dtype=np.int32)
+        dst = np.empty(cap, dtype=np.int32)
+        verdict = np.empty(cap, dtype=np.uint8)
+        rssi = np.empty(cap, dtype=np.float64)
+        sinr = np.empty(cap, dtype=np.float64)
+        pint = np.zeros(max(1, n_new), dtype=np.uint8)
+        poff = np.zeros(n_new + 1, dtype=np.uint32)
+        cnt = C.c_uint32()
+        check(self._L.rm_tick_flush(self._h, pkt.ctypes.data, dst.ctypes.data, verdict.ctypes.data, rssi.ctypes.data,
+                                    sinr.ctypes.data, cap, C.byref(cnt), pint.ctypes.data, poff.ctypes.data))
+        k = cnt.value
+        return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
+
+    def tick(self, recs, t_begin=0, t_end=0, cap=None):
+        self.tick_begin(t_begin, t_end)
+        self.enqueue_records(recs)
+        return self.tick_flush(cap)
+
+    # -- device-resident path
+    def pack_tx_device(self, dev_src_ptr, n, start_us, air_us, dev_out_ptr):
+        check(self._L.rm_pack_tx_device(self._h, C.c_void_p(dev_src_ptr), n, start_us, air_us,
+                                        C.c_void_p(dev_out_ptr)))
+
+    def tick_run_device(self, t_begin, t_end, dev_new_ptr, n_new):
+        check(self._L.rm_tick_run_device(self._h, t_begin, t_end, C.c_void_p(dev_new_ptr), n_new))
+
+    def result_device(self):
+        r = DeviceResult()
+        check(self._L.rm_result_device(self._h, C.byref(r)))
+        return r
+
+    def result_count(self):
+        cnt, dropped = C.c_uint32(), C.c_uint32()
+        check(self._L.rm_result_count(self._h, C.byref(cnt), C.byref(dropped)))
+        return cnt.value, dropped.value
+
+    def sync(self):
+        check(self._L.rm_sync(self._h))
+
+    def profile_enable(self, on=True):
+        check(self._L.rm_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        n, ms = C.c_uint32(), C.c_double()
+        check(self._L.rm_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def last_link_evaluations(self):
+        return self._L.rm_last_link_evaluations(self._h)

@@ -1,0 +1,184 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle: the four reference media.
+Bit-exact on heard sets / verdicts / draw consumption; rssi is the packet's transmit power."""
+import numpy as np
+import pytest
+
+from util import run_both, assert_same, random_nodes, to_tx_records, configure_engine, oracle_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _line(O, pts):
+    nd = O.NodeTable(len(pts))
+    for i, p in enumerate(pts):
+        nd.x[i], nd.y[i], nd.z[i] = p
+    return nd
+
+
+def test_get_name_and_base_rssi(engine, rsa):
+    assert engine.get_name().startswith("Null radio medium")          # Main.java:66-70 default
+    engine.set_model(rsa.MODEL_UDGM)
+    assert engine.get_name() == "UDGM Radio Medium"
+    assert engine.get_base_rssi(0) == -100.0                          # AbstractRadioMedium.java:38
+    engine.set_base_rssi(-91.0)
+    assert engine.get_base_rssi(3) == -91.0
+
+
+def test_k2_k3_boundaries(engine, rsa, O):
+    nd = _line(O, [(0, 0, 0), (30, 40, 0), (30, 40, 0.001), (60, 80, 0), (59.999, 80, 0)])
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {}, nd.packet(0))
+    assert_same(gpu, cpu, "K2")
+    assert list(gpu.dst) == [1]
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm_const", {}, nd.packet(0))
+    assert_same(gpu, cpu, "K3")
+    assert list(gpu.dst) == [1, 2, 4]            # d == 100 exactly is out (strict <)
+
+
+def test_k5_filters_all_models(engine, rsa, O):
+    nd = _line(O, [(0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0)])
+    nd.channel[1] = 25
+    nd.enabled[2] = 0
+    for kind in ("null", "udgm", "udgm_const"):
+        gpu, cpu = run_both(O, rsa, engine, nd, kind, {}, nd.packet(0))
+        assert_same(gpu, cpu, kind)
+        assert list(gpu.dst) == [3]
+    # packet channel override ("wireless-channel", SimulatorJSONHandler.java:87-90)
+    gpu, cpu = run_both(O, rsa, engine, nd, "null", {}, nd.packet(0, channel=25, txpower=-7.0))
+    assert_same(gpu, cpu, "override")
+    assert list(gpu.dst) == [1] and list(gpu.rssi) == [-7.0]
+
+
+def test_k6_k7_draw_accounting(engine, rsa, O):
+    nd = _line(O, [(0, 0, 0), (10, 0, 0), (20, 0, 0), (30, 0, 0), (500, 0, 0)])
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {"udgm_success_ratio_rx": 0.5}, nd.packet(0), seed=42)
+    assert_same(gpu, cpu, "K6a")
+    assert list(gpu.verdict) == [rsa.INTERFERED] * 3 and engine.rng_state == cpu.rng_state
+    nd.rxprob[:] = [1.0, 0.5, 1.0, 0.5, 1.0]
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {}, nd.packet(0), seed=42)
+    assert_same(gpu, cpu, "K6b")
+    assert list(gpu.verdict) == [rsa.INTERFERED, rsa.DELIVERED, rsa.INTERFERED]
+    assert engine.rng_state == cpu.rng_state
+    nd.rxprob[:] = 1.0
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {}, nd.packets([0, 1, 2]), seed=7)
+    assert_same(gpu, cpu, "K7")
+    assert engine.rng_state == O.lib().orc_jrandom_seed(7)
+
+
+@pytest.mark.parametrize("kind", ["null", "udgm", "udgm_const"])
+@pytest.mark.parametrize("n,t,z", [(64, 1, 0.0), (1000, 37, 0.0), (3000, 130, 25.0)])
+def test_random_layouts_deterministic(engine, rsa, O, kind, n, t, z):
+    if kind == "null" and n > 1000:
+        pytest.skip("dense output, covered at n = 1000")
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd = random_nodes(O, n, side, seed=n + t, z_span=z)
+    rng = np.random.default_rng(5)
+    nd.channel[rng.random(n) < 0.1] = 25
+    nd.enabled[rng.random(n) < 0.05] = 0
+    nd.txpower[:] = rng.uniform(-25, 0, n)
+    src = rng.choice(n, t, replace=False)
+    gpu, cpu = run_both(O, rsa, engine, nd, kind, {}, nd.packets(src))
+    assert cpu.count > 0
+    assert_same(gpu, cpu, "%s n=%d" % (kind, n))
+
+
+@pytest.mark.parametrize("ratio_rx", [1.0, 0.6])
+def test_random_layouts_stochastic_udgm(engine, rsa, O, ratio_rx):
+    n, t = 2500, 90
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd = random_nodes(O, n, side, seed=99)
+    rng = np.random.default_rng(6)
+    nd.rxprob[:] = np.where(rng.random(n) < 0.5, 1.0, rng.uniform(0, 1, n))
+    nd.rxprob[rng.random(n) < 0.05] = 0.0
+    nd.txprob[:] = np.where(rng.random(n) < 0.5, 1.0, rng.uniform(0, 1.2, n))
+    nd.txprob[rng.random(n) < 0.05] = 0.0
+    src = rng.choice(n, t, replace=False)
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {"udgm_success_ratio_rx": ratio_rx}, nd.packets(src), seed=2024)
+    assert cpu.pkt_draws.sum() > 50
+    assert_same(gpu, cpu, "udgm stochastic")
+    assert engine.rng_state == cpu.rng_state
+    # a second tick continues the same generator
+    src2 = rng.choice(n, t, replace=False)
+    mdl = oracle_model(O, "udgm", {"udgm_success_ratio_rx": ratio_rx})
+    cpu2 = O.tick(mdl, nd, nd.packets(src2), rng_state=cpu.rng_state)
+    gpu2 = engine.tick(to_tx_records(rsa, nd.packets(src2)))
+    assert_same(gpu2, cpu2, "udgm stochastic tick 2")
+    assert engine.rng_state == cpu2.rng_state
+
+
+def test_n2n_matrix(engine, rsa, O):
+    n = 300
+    rng = np.random.default_rng(8)
+    nd = random_nodes(O, n, 100.0, seed=3)
+    m = np.where(rng.random((n, n)) < 0.1, rng.uniform(0, 1.3, (n, n)), 0.0)
+    nd.int_id[:] = np.arange(1, n + 1)
+    nd.int_id[5] = -1           # non-numeric id
+    nd.int_id[6] = n + 7        # outside the matrix
+    nd.rxprob[10:20] = 0.5
+    nd.txprob[30:40] = 0.7
+    src = rng.choice(n, 60, replace=False)
+    gpu, cpu = run_both(O, rsa, engine, nd, "n2n", {}, nd.packets(src), matrix=m, seed=11)
+    assert cpu.count > 100
+    assert_same(gpu, cpu, "n2n")
+    assert engine.rng_state == cpu.rng_state
+
+
+def test_single_transmit_api(engine, rsa, O):
+    nd = random_nodes(O, 500, 300.0, seed=17)
+    configure_engine(engine, nd, "udgm", {})
+    mdl = oracle_model(O, "udgm", {})
+    for src in (0, 77, 499):
+        cpu = O.tick(mdl, nd, nd.packet(src, start_us=123, air_us=320))
+        res = engine.transmit(src, start_us=123, hex_length=10)
+        assert res.count == cpu.count
+        np.testing.assert_array_equal(res.dst, cpu.dst)
+        np.testing.assert_array_equal(res.verdict, cpu.verdict)
+    with pytest.raises(rsa.RadioMediumError):     # "could not find source node"
+        engine.transmit(500)
+
+
+def test_empty_and_ragged(engine, rsa, O):
+    nd = random_nodes(O, 130, 100.0, seed=2)      # not a multiple of 64
+    configure_engine(engine, nd, "udgm", {})
+    res = engine.tick(np.zeros(0, dtype=rsa.TX_RECORD_DTYPE))
+    assert res.count == 0
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {}, nd.packets(np.arange(130)))   # every node transmits
+    assert_same(gpu, cpu, "ragged")
+    nd1 = random_nodes(O, 1, 10.0, seed=1)
+    gpu, cpu = run_both(O, rsa, engine, nd1, "null", {}, nd1.packet(0))
+    assert gpu.count == cpu.count == 0
+    # link capacity smaller than the heard links -> RM_ERR_CAPACITY, count still reported
+    configure_engine(engine, nd, "null", {})
+    engine.set_link_capacity(100)
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.tick(to_tx_records(rsa, nd.packets([0, 1])))
+    assert e.value.code == -4
+
+
+def test_large_coordinates_use_fp64_filter(engine, rsa, O):
+    """Far-from-origin layouts make the fp32 frame too coarse; results must not change."""
+    n = 2000
+    nd = random_nodes(O, n, 500.0, seed=12)
+    nd.x += 3.0e7
+    nd.y -= 9.0e7
+    rng = np.random.default_rng(1)
+    src = rng.choice(n, 64, replace=False)
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {}, nd.packets(src))
+    assert cpu.count > 500
+    assert_same(gpu, cpu, "far origin")
+    # one outlier node stretches the frame: still exact
+    nd.x[7] = -4.0e9
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm_const", {}, nd.packets(src))
+    assert_same(gpu, cpu, "outlier")
+
+
+def test_boundary_lattice(engine, rsa, O):
+    """Integer lattice: many pairs sit exactly on d == range (3-4-5 triples)."""
+    g = np.arange(0, 40) * 10.0
+    xx, yy = np.meshgrid(g, g)
+    nd = O.NodeTable(xx.size)
+    nd.x, nd.y = xx.ravel().copy(), yy.ravel().copy()
+    src = np.arange(0, nd.n, 23)
+    for kind, params in (("udgm", {}), ("udgm_const", {}), ("udgm", {"udgm_transmission_range": 100.0}),
+                         ("udgm_const", {"const_range": 50.0})):
+        gpu, cpu = run_both(O, rsa, engine, nd, kind, params, nd.packets(src))
+        assert_same(gpu, cpu, kind + str(params))
