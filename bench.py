@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ticks", type=float, default=2.0)
+    ap.add_argument("--profile-every", type=int, default=16,
+                    help="HIP-event sample of the dominant kernel every n-th tick of the timed region")
     return ap.parse_args()
 
 
@@ -170,14 +172,14 @@ def main():
     for k in range(args.warmup):
         run_tick(k)
     fence()
-    eng.profile_enable(True)
+    eng.profile_enable(args.profile_every)
     t_start = time.perf_counter()
     for k in range(args.warmup, ticks):
         run_tick(k)
     fence()
     elapsed = time.perf_counter() - t_start
     n_launch, kern_ms = eng.profile_read()
-    eng.profile_enable(False)
+    eng.profile_enable(0)
     heard, dropped = eng.result_count()
     if dropped:
         raise SystemExit("heard links were dropped for capacity: the measurement is invalid")

@@ -178,8 +178,10 @@ int rm_result_device(rm_context *ctx, rm_device_result *out);
 int rm_result_count(rm_context *ctx, uint32_t *count, uint32_t *dropped); /* synchronises */
 int rm_sync(rm_context *ctx);
 
-/* timing of the dominant kernel on the context's stream (HIP events around each launch) */
-int rm_profile_enable(rm_context *ctx, int enable);
+/* timing of the dominant kernel on the context's stream: HIP events around its launch on every
+ * `every_n`-th tick (0 = off; an event pair costs tens of microseconds of stream time on this
+ * runtime, so dense sampling perturbs the throughput it measures) */
+int rm_profile_enable(rm_context *ctx, int every_n);
 int rm_profile_read(rm_context *ctx, uint32_t *launches, double *total_ms);
 /* number of Tx->Rx link evaluations resolved by the last tick ( T * (N_loc) minus self links ) */
 int64_t rm_last_link_evaluations(const rm_context *ctx);

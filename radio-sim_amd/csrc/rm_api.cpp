@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,15 +97,23 @@ struct rm_context {
     std::vector<double> x, y, z, txpower, rxprob, txprob;
     std::vector<int32_t> channel, int_id;
     std::vector<uint8_t> enabled;
-    // device-resident node state (SoA)
-    DevBuf<double> d_x, d_y, d_z, d_txpower, d_rxprob, d_txprob;
+    // device-resident source table (SoA, node-index order): what a packet copies from its source
+    DevBuf<double> d_x, d_y, d_z, d_txpower, d_txprob;
     DevBuf<int32_t> d_channel, d_int_id;
-    DevBuf<uint8_t> d_enabled;
-    DevBuf<float4> d_rxf;
+    // device-resident receiver table of this partition (SoA, engine order = spatially sorted)
+    DevBuf<double> d_rx_x, d_rx_y, d_rx_z, d_rx_rxprob;
+    DevBuf<int32_t> d_rx_channel, d_rx_int_id, d_rx_orig, d_pos_of;
+    DevBuf<uint8_t> d_rx_enabled;
+    DevBuf<float4> d_rxf, d_bbox_xy;
+    DevBuf<float2> d_bbox_z;
     DevBuf<double> d_n2n;
     int n2n_m = 0;
+    int n_rx = 0;            // receivers in the table
+    bool rx_sorted = false;  // engine order != node-index order
 
-    bool prefilter_dirty = true;
+    int frac_probs = -1;         // cached: any rx/tx probability strictly between 0 and 1 (-1 = unknown)
+    bool rx_dirty = true;        // receiver table has to be rebuilt (positions / partition / model class)
+    bool prefilter_dirty = true; // pre-filter records have to be recomputed
     double org[3] = {0, 0, 0};
     double coord_bound = 0, f32_slack = 0;
 
@@ -121,17 +130,18 @@ struct rm_context {
     DevBuf<rm_tx_record> d_tx;
 
     // per-tick device buffers
-    DevBuf<float4> d_txf;
-    DevBuf<double> d_txd;
-    DevBuf<uint32_t> d_cnt, d_off, d_partial, d_slot_off;
-    DevBuf<uint32_t> d_counters; // [0..1] stage_count, [2..4] out_count
+    DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
+    DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
+    DevBuf<uint32_t> d_shards;   // two parities x kShards x kShardStride append counters
+    DevBuf<uint32_t> d_cursor;
+    int parity = 0;
     DevBuf<int32_t> d_st_pkt, d_st_dst, d_st_next, d_head;
-    DevBuf<uint32_t> d_st_rank;
+    DevBuf<uint32_t> d_st_blk;
     DevBuf<double> d_st_aux, d_st_lin, d_st_sinr;
     DevBuf<uint8_t> d_st_flags, d_st_coll;
-    DevBuf<int32_t> d_out_pkt, d_out_dst;
-    DevBuf<uint8_t> d_out_verdict, d_pkt_interf;
-    DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob;
+    DevBuf<int32_t> d_out_pkt, d_out_dst, d_a_pkt, d_a_dst;
+    DevBuf<uint8_t> d_out_verdict, d_pkt_interf, d_a_verdict;
+    DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob, d_a_rssi, d_a_sinr, d_a_prob;
     DevBuf<uint32_t> d_draw_scan, d_scan_block;
     DevBuf<uint64_t> d_rng, d_pkt_rng;
     uint32_t alloc_cap = 0;
@@ -142,8 +152,20 @@ struct rm_context {
     bool have_result = false;
     int64_t last_links = 0;
 
+    // instantiated hipGraphs of the per-tick launch sequence, keyed by a hash of every launch argument
+    struct GraphEntry {
+        uint64_t key;
+        hipGraphExec_t exec;
+        uint64_t last_use;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    bool use_graphs = true;
+
     // profiling of the dominant kernel
-    bool profile = false;
+    bool profile = false;   // sampling on
+    int profile_every = 1;  // take an event-timed sample every n-th tick
+    uint64_t tick_index = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     uint32_t prof_launches = 0;
@@ -160,15 +182,22 @@ int part_count(const rm_context *c) { return c->rx_count < 0 ? c->n : c->rx_coun
 bool frac(double p) { return p > 0.0 && p < 1.0; }
 
 // can a java.util.Random draw ever be consumed with the current model + node table?
-bool maybe_draws(const rm_context *c)
+// (the O(N) scan of the probabilities is cached until the node table changes)
+bool maybe_draws(rm_context *c)
 {
     const int k = c->params.kind;
     if (k == RM_MODEL_NULL || k == RM_MODEL_UDGM_CONST) return false;
     if (k == RM_MODEL_N2N) return true;
     if (k == RM_MODEL_UDGM && c->params.udgm_success_ratio_rx != 1.0) return true;
-    for (int i = 0; i < c->n; ++i)
-        if (frac(c->rxprob[i]) || frac(c->txprob[i])) return true;
-    return false;
+    if (c->frac_probs < 0) {
+        c->frac_probs = 0;
+        for (int i = 0; i < c->n; ++i)
+            if (frac(c->rxprob[i]) || frac(c->txprob[i])) {
+                c->frac_probs = 1;
+                break;
+            }
+    }
+    return c->frac_probs == 1;
 }
 
 int validate_model(const rm_model_params *p)
@@ -245,28 +274,123 @@ rm::NodesDev nodes_dev(rm_context *c)
 {
     rm::NodesDev nd{};
     nd.n = c->n;
-    nd.x = c->d_x.p;
-    nd.y = c->d_y.p;
-    nd.z = c->d_z.p;
-    nd.rxprob = c->d_rxprob.p;
-    nd.txprob = c->d_txprob.p;
-    nd.txpower = c->d_txpower.p;
-    nd.channel = c->d_channel.p;
-    nd.enabled = c->d_enabled.p;
-    nd.int_id = c->d_int_id.p;
+    nd.sx = c->d_x.p;
+    nd.sy = c->d_y.p;
+    nd.sz = c->d_z.p;
+    nd.stxpower = c->d_txpower.p;
+    nd.stxprob = c->d_txprob.p;
+    nd.schannel = c->d_channel.p;
+    nd.sint_id = c->d_int_id.p;
+    nd.n_rx = c->n_rx;
+    nd.x = c->d_rx_x.p;
+    nd.y = c->d_rx_y.p;
+    nd.z = c->d_rx_z.p;
+    nd.rxprob = c->d_rx_rxprob.p;
+    nd.channel = c->d_rx_channel.p;
+    nd.int_id = c->d_rx_int_id.p;
+    nd.orig = c->d_rx_orig.p;
+    nd.enabled = c->d_rx_enabled.p;
+    nd.pos_of = c->d_pos_of.p;
+    nd.rx_first = part_first(c);
     nd.rxf = c->d_rxf.p;
+    nd.bbox_xy = c->d_bbox_xy.p;
+    nd.bbox_z = c->d_bbox_z.p;
     return nd;
+}
+
+bool is_geometric(const rm_context *c)
+{
+    const int k = c->params.kind;
+    return k == RM_MODEL_UDGM || k == RM_MODEL_UDGM_CONST || k == RM_MODEL_LOGDIST;
+}
+
+// k-d split of perm[lo, hi) down to groups of 64: the left part always holds a multiple of 64
+// receivers, so every group of 64 consecutive engine positions is one leaf (a compact box)
+void kd_split(const rm_context *c, std::vector<int32_t> &perm, int lo, int hi)
+{
+    const int cnt = hi - lo;
+    if (cnt <= rm::kGroup) return;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int i = lo; i < hi; ++i) {
+        const int k = perm[i];
+        const double v[3] = {c->x[k], c->y[k], c->z[k]};
+        for (int a = 0; a < 3; ++a) {
+            if (i == lo || v[a] < mn[a]) mn[a] = v[a];
+            if (i == lo || v[a] > mx[a]) mx[a] = v[a];
+        }
+    }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    const std::vector<double> &coord = axis == 0 ? c->x : (axis == 1 ? c->y : c->z);
+    const int groups = (cnt + rm::kGroup - 1) / rm::kGroup;
+    const int mid = lo + ((groups + 1) / 2) * rm::kGroup;
+    std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi,
+                     [&](int32_t a, int32_t b) { return coord[a] < coord[b] || (coord[a] == coord[b] && a < b); });
+    kd_split(c, perm, lo, mid);
+    kd_split(c, perm, mid, hi);
+}
+
+template <typename T> int upload_gather(DevBuf<T> &d, const std::vector<T> &src, const std::vector<int32_t> &perm,
+                                        hipStream_t s, std::vector<T> &tmp)
+{
+    tmp.resize(perm.size());
+    for (size_t i = 0; i < perm.size(); ++i) tmp[i] = src[perm[i]];
+    RM_HIP(d.ensure(std::max<size_t>(tmp.size(), 1)));
+    if (!tmp.empty()) RM_HIP(hipMemcpyAsync(d.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    RM_HIP(hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+// (re)build the receiver table of the partition in engine order
+int rebuild_receivers(rm_context *c)
+{
+    const int first = part_first(c), count = part_count(c);
+    std::vector<int32_t> perm(count);
+    for (int i = 0; i < count; ++i) perm[i] = first + i;
+    c->rx_sorted = false;
+    if (is_geometric(c) && count > rm::kGroup) {
+        kd_split(c, perm, 0, count);
+        c->rx_sorted = true;
+    }
+    std::vector<double> td;
+    std::vector<int32_t> ti;
+    std::vector<uint8_t> tb;
+    RM_TRY(upload_gather(c->d_rx_x, c->x, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_y, c->y, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_z, c->z, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_rxprob, c->rxprob, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_channel, c->channel, perm, c->stream, ti));
+    RM_TRY(upload_gather(c->d_rx_int_id, c->int_id, perm, c->stream, ti));
+    RM_TRY(upload_gather(c->d_rx_enabled, c->enabled, perm, c->stream, tb));
+    RM_HIP(c->d_rx_orig.ensure(std::max(count, 1)));
+    RM_HIP(c->d_pos_of.ensure(std::max(count, 1)));
+    std::vector<int32_t> pos_of(count);
+    for (int i = 0; i < count; ++i) pos_of[perm[i] - first] = i;
+    if (count) {
+        RM_HIP(hipMemcpyAsync(c->d_rx_orig.p, perm.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipMemcpyAsync(c->d_pos_of.p, pos_of.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->n_rx = count;
+    c->rx_dirty = false;
+    c->prefilter_dirty = true;
+    return RM_OK;
 }
 
 int ensure_link_buffers(rm_context *c)
 {
     if (c->alloc_cap == c->cap && c->d_counters.p) return RM_OK;
-    const size_t cap = c->cap;
-    RM_HIP(c->d_counters.ensure(8));
+    const size_t cap = size_t((c->cap + rm::kShards - 1) / rm::kShards) * rm::kShards;
+    RM_HIP(c->d_counters.ensure(16));
+    RM_HIP(hipMemsetAsync(c->d_counters.p, 0, 16 * sizeof(uint32_t), c->stream));
+    RM_HIP(c->d_shards.ensure(2 * rm::kShards * rm::kShardStride));
+    RM_HIP(hipMemsetAsync(c->d_shards.p, 0, 2 * rm::kShards * rm::kShardStride * sizeof(uint32_t), c->stream));
+    c->parity = 0;
     RM_HIP(c->d_st_pkt.ensure(cap));
     RM_HIP(c->d_st_dst.ensure(cap));
     RM_HIP(c->d_st_next.ensure(cap));
-    RM_HIP(c->d_st_rank.ensure(cap));
+    RM_HIP(c->d_st_blk.ensure(cap));
     RM_HIP(c->d_st_aux.ensure(cap));
     RM_HIP(c->d_st_lin.ensure(cap));
     RM_HIP(c->d_st_sinr.ensure(cap));
@@ -278,6 +402,12 @@ int ensure_link_buffers(rm_context *c)
     RM_HIP(c->d_out_rssi.ensure(cap));
     RM_HIP(c->d_out_sinr.ensure(cap));
     RM_HIP(c->d_out_prob.ensure(cap));
+    RM_HIP(c->d_a_pkt.ensure(cap));
+    RM_HIP(c->d_a_dst.ensure(cap));
+    RM_HIP(c->d_a_verdict.ensure(cap));
+    RM_HIP(c->d_a_rssi.ensure(cap));
+    RM_HIP(c->d_a_sinr.ensure(cap));
+    RM_HIP(c->d_a_prob.ensure(cap));
     RM_HIP(c->d_draw_scan.ensure(cap + 1));
     RM_HIP(c->d_scan_block.ensure(cap / 2048 + 2));
     c->alloc_cap = c->cap;
@@ -286,8 +416,12 @@ int ensure_link_buffers(rm_context *c)
 
 int prepare_nodes(rm_context *c)
 {
+    if (c->rx_dirty) RM_TRY(rebuild_receivers(c));
     if (!c->prefilter_dirty) return RM_OK;
-    RM_HIP(c->d_rxf.ensure(std::max(c->n, 1)));
+    const int groups = (c->n_rx + rm::kGroup - 1) / rm::kGroup;
+    RM_HIP(c->d_rxf.ensure(std::max(c->n_rx, 1)));
+    RM_HIP(c->d_bbox_xy.ensure(std::max(groups, 1)));
+    RM_HIP(c->d_bbox_z.ensure(std::max(groups, 1)));
     RM_HIP(rm::launch_prep_rx(c->stream, nodes_dev(c), model_dev(c)));
     c->prefilter_dirty = false;
     return RM_OK;
@@ -304,8 +438,8 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
 
     const bool sinr = is_sinr(c);
     const bool stochastic = maybe_draws(c);
-    const int rx_first = part_first(c), rx_count = part_count(c);
-    if (stochastic && (rx_first != 0 || rx_count != c->n))
+    const int rx_count = c->n_rx;
+    if (stochastic && rx_count != c->n)
         return fail(RM_ERR_STATE, "receiver partitions with probabilistic links (java.util.Random draws) are not "
                                   "supported yet: the draw order spans the ranks");
 
@@ -319,27 +453,19 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
     t.cnt_base = ((first_new - t.first_eval) / rm::kTxChunk) * rm::kTxChunk;
     t.shift = (first_new - t.first_eval) - t.cnt_base;
     t.n_cnt = n_chunks * rm::kTxChunk - t.cnt_base;
-    t.rx_first = rx_first;
-    t.rx_count = rx_count;
-    // enough waves to fill 256 CUs x 4 SIMDs several times over, else one receiver per lane
+    t.n_rx = rx_count;
+    // enough waves to fill 256 CUs x 4 SIMDs several times over, else one group per wave
     const long waves4 = long((rx_count + 255) / 256) * n_chunks;
     t.rpt = (waves4 >= 4096) ? 4 : 1;
     t.n_slabs = (rx_count + 64 * t.rpt - 1) / (64 * t.rpt);
-    if (n_new > 0 && t.n_slabs > 0) {
-        const int want_groups = std::max(1, std::min(t.n_slabs, 16384 / std::max(1, t.n_cnt)));
-        t.slabs_per_group = (t.n_slabs + want_groups - 1) / want_groups;
-        t.n_groups = (t.n_slabs + t.slabs_per_group - 1) / t.slabs_per_group;
-    } else {
-        t.slabs_per_group = 1;
-        t.n_groups = 0;
-    }
 
     const size_t cells = size_t(std::max(t.n_cnt, 0) / rm::kTxChunk) * std::max(t.n_slabs, 1) * 64;
-    RM_HIP(c->d_txf.ensure(std::max(n_eval, 1)));
-    RM_HIP(c->d_txd.ensure(std::max(n_eval, 1)));
-    RM_HIP(c->d_cnt.ensure(std::max<size_t>(cells, 1)));
-    RM_HIP(c->d_off.ensure(std::max<size_t>(cells, 1)));
-    RM_HIP(c->d_partial.ensure(std::max<size_t>(size_t(std::max(t.n_cnt, 0)) * std::max(t.n_groups, 1), 1)));
+    if (!c->rx_sorted) {
+        RM_HIP(c->d_cnt.ensure(std::max<size_t>(cells, 1)));
+        RM_HIP(c->d_off.ensure(std::max<size_t>(cells, 1)));
+    }
+    RM_HIP(c->d_slot_tot.ensure(size_t(std::max(t.n_cnt, 0)) + 1));
+    RM_HIP(c->d_cursor.ensure(size_t(std::max(t.n_cnt, 0)) + 1));
     RM_HIP(c->d_slot_off.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
     RM_HIP(c->d_pkt_interf.ensure(std::max(n_new, 1)));
     RM_HIP(c->d_pkt_rng.ensure(std::max(n_new, 1)));
@@ -351,17 +477,30 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         RM_HIP(hipStreamSynchronize(c->stream));
     }
 
-    t.txf = c->d_txf.p;
-    t.txd = c->d_txd.p;
+    const rm::ModelDev m = model_dev(c);
+    const rm::NodesDev nd = nodes_dev(c);
+    rm::LaunchCfg cfg{};
+    cfg.stochastic = stochastic;
+    cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
+    cfg.sorted = c->rx_sorted;
+    cfg.bbox = c->rx_sorted && !cfg.f64_filter;
+
     t.cnt = c->d_cnt.p;
     t.off = c->d_off.p;
-    t.partial = c->d_partial.p;
+    t.slot_tot = c->d_slot_tot.p;
     t.slot_off = c->d_slot_off.p;
-    t.stage_count = c->d_counters.p;
+    uint32_t *counters = c->d_counters.p + 8 * c->parity;
+    t.stage_count = counters;
+    t.next_counters = c->d_counters.p + 8 * (c->parity ^ 1);
+    t.shard_count = c->d_shards.p + size_t(c->parity) * rm::kShards * rm::kShardStride;
+    t.next_shard_count = c->d_shards.p + size_t(c->parity ^ 1) * rm::kShards * rm::kShardStride;
     t.cap = c->cap;
+    t.seg_cap = (c->cap + rm::kShards - 1) / rm::kShards;
+    t.use_matrix = cfg.sorted ? 0 : 1;
+    t.cursor = c->d_cursor.p;
     t.st_pkt = c->d_st_pkt.p;
     t.st_dst = c->d_st_dst.p;
-    t.st_rank = c->d_st_rank.p;
+    t.st_blk = c->d_st_blk.p;
     t.st_aux = c->d_st_aux.p;
     t.st_lin = c->d_st_lin.p;
     t.st_sinr = c->d_st_sinr.p;
@@ -369,13 +508,28 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
     t.st_flags = c->d_st_flags.p;
     t.st_coll = c->d_st_coll.p;
     t.head = c->d_head.p;
-    t.out_count = c->d_counters.p + 2;
+    t.out_count = counters + 2;
     t.out_pkt = c->d_out_pkt.p;
     t.out_dst = c->d_out_dst.p;
     t.out_verdict = c->d_out_verdict.p;
     t.out_rssi = c->d_out_rssi.p;
     t.out_sinr = c->d_out_sinr.p;
     t.out_prob = c->d_out_prob.p;
+    if (cfg.sorted) {
+        t.a_pkt = c->d_a_pkt.p;
+        t.a_dst = c->d_a_dst.p;
+        t.a_verdict = c->d_a_verdict.p;
+        t.a_rssi = c->d_a_rssi.p;
+        t.a_sinr = c->d_a_sinr.p;
+        t.a_prob = c->d_a_prob.p;
+    } else { // engine order == node-index order: the scatter writes the final records directly
+        t.a_pkt = t.out_pkt;
+        t.a_dst = t.out_dst;
+        t.a_verdict = t.out_verdict;
+        t.a_rssi = t.out_rssi;
+        t.a_sinr = t.out_sinr;
+        t.a_prob = t.out_prob;
+    }
     t.pkt_interference = c->d_pkt_interf.p;
     t.draw_scan = c->d_draw_scan.p;
     t.scan_block = c->d_scan_block.p;
@@ -383,23 +537,33 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
     t.pkt_rng = c->d_pkt_rng.p;
 
     hipStream_t s = c->stream;
-    RM_HIP(hipMemsetAsync(c->d_counters.p, 0, 8 * sizeof(uint32_t), s));
     c->last = t;
     c->last_links = 0;
     if (n_new <= 0 || rx_count <= 0) {
+        // nothing to sweep: publish an empty result in this parity's counters
+        RM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), s));
         c->have_result = true;
         return RM_OK;
     }
-    if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
-
-    const rm::ModelDev m = model_dev(c);
-    const rm::NodesDev nd = nodes_dev(c);
-    rm::LaunchCfg cfg{};
-    cfg.stochastic = stochastic;
-    cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
-
-    RM_HIP(rm::launch_prep_tx(s, m, t));
-    if (c->profile) {
+    c->parity ^= 1; // k_filter zeroes the other parity for the next tick
+    // The launch sequence.  Launch-bound (a handful of short kernels per tick), so it is replayed
+    // from an instantiated hipGraph whenever the launch arguments repeat; with event profiling on,
+    // the dominant kernel is launched eagerly between two HIP events and only the rest is a graph.
+    auto tail = [&](bool with_filter) -> int {
+        if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        if (with_filter) RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
+        RM_HIP(rm::launch_exact(s, nd, m, t));
+        if (sinr) RM_HIP(rm::launch_self_entries(s, nd, t));
+        RM_HIP(rm::launch_offsets(s, t));
+        if (sinr) RM_HIP(rm::launch_sinr(s, m, t));
+        RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
+        if (cfg.sorted) RM_HIP(rm::launch_reorder(s, t));
+        if (stochastic) RM_HIP(rm::launch_draws(s, m, t));
+        return RM_OK;
+    };
+    const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
+    const bool with_filter = !sample;
+    if (sample) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
             RM_HIP(hipEventCreate(&a));
@@ -407,17 +571,53 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
             c->ev_pool.emplace_back(a, b);
         }
         RM_HIP(hipEventRecord(c->ev_pool[c->ev_used].first, s));
-    }
-    RM_HIP(rm::launch_allpairs(s, nd, m, t, cfg));
-    if (c->profile) {
+        RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
         RM_HIP(hipEventRecord(c->ev_pool[c->ev_used].second, s));
         c->ev_used++;
     }
-    if (sinr) RM_HIP(rm::launch_self_entries(s, t));
-    RM_HIP(rm::launch_offsets(s, t));
-    if (sinr) RM_HIP(rm::launch_sinr(s, m, t));
-    RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
-    if (stochastic) RM_HIP(rm::launch_draws(s, m, t));
+    if (c->use_graphs) {
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) {
+            const unsigned char *b = static_cast<const unsigned char *>(p);
+            for (size_t i = 0; i < n; ++i) key = (key ^ b[i]) * 1099511628211ull;
+        };
+        mix(&nd, sizeof(nd));
+        mix(&m, sizeof(m));
+        mix(&t, sizeof(t));
+        const int bits[6] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, with_filter};
+        mix(bits, sizeof(bits));
+        hipGraphExec_t exec = nullptr;
+        for (auto &g : c->graphs)
+            if (g.key == key) {
+                exec = g.exec;
+                g.last_use = ++c->graph_clock;
+            }
+        if (!exec) {
+            RM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rc = tail(with_filter);
+            hipGraph_t graph = nullptr;
+            const hipError_t e_end = hipStreamEndCapture(s, &graph);
+            if (rc != RM_OK) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            if (e_end != hipSuccess) return fail(RM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
+            const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e_inst != hipSuccess) return fail(RM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
+            if (c->graphs.size() >= 16) { // evict the least recently used
+                size_t victim = 0;
+                for (size_t i = 1; i < c->graphs.size(); ++i)
+                    if (c->graphs[i].last_use < c->graphs[victim].last_use) victim = i;
+                (void)hipGraphExecDestroy(c->graphs[victim].exec);
+                c->graphs.erase(c->graphs.begin() + victim);
+            }
+            c->graphs.push_back({key, exec, ++c->graph_clock});
+        }
+        RM_HIP(hipGraphLaunch(exec, s));
+    } else {
+        RM_TRY(tail(with_filter));
+    }
 
     // links resolved: every evaluated frame against every other node (T * (N-1)); for a receiver
     // partition the frame's own source may lie outside it, so the product is reported as is
@@ -504,6 +704,7 @@ int rm_create(int device_ordinal, rm_context **out)
         return fail(RM_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     c->own_stream = true;
+    if (const char *ng = std::getenv("RM_NO_GRAPH")) c->use_graphs = !(ng[0] == '1');
     rm_model_defaults(&c->params, RM_MODEL_NULL); // Main.java:66-70: NullRadioMedium is the default
     *out = c;
     return RM_OK;
@@ -512,23 +713,27 @@ int rm_create(int device_ordinal, rm_context **out)
 void rm_destroy(rm_context *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : c->ev_pool) {
-        hipEventDestroy(p.first);
-        hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
     }
-    c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_rxprob.release();
-    c->d_txprob.release(); c->d_channel.release(); c->d_int_id.release(); c->d_enabled.release();
-    c->d_rxf.release(); c->d_n2n.release(); c->d_tx.release(); c->d_txf.release(); c->d_txd.release();
-    c->d_cnt.release(); c->d_off.release(); c->d_partial.release(); c->d_slot_off.release();
+    c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release();
+    c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
+    c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
+    c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rxf.release(); c->d_bbox_xy.release();
+    c->d_bbox_z.release(); c->d_n2n.release(); c->d_tx.release();
+    c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_slot_off.release();
     c->d_counters.release(); c->d_st_pkt.release(); c->d_st_dst.release(); c->d_st_next.release();
-    c->d_head.release(); c->d_st_rank.release(); c->d_st_aux.release(); c->d_st_lin.release();
+    c->d_head.release(); c->d_st_blk.release(); c->d_st_aux.release(); c->d_st_lin.release();
     c->d_st_sinr.release(); c->d_st_flags.release(); c->d_st_coll.release(); c->d_out_pkt.release();
     c->d_out_dst.release(); c->d_out_verdict.release(); c->d_pkt_interf.release(); c->d_out_rssi.release();
-    c->d_out_sinr.release(); c->d_out_prob.release(); c->d_draw_scan.release(); c->d_scan_block.release();
-    c->d_rng.release(); c->d_pkt_rng.release();
-    if (c->own_stream) hipStreamDestroy(c->stream);
+    c->d_out_sinr.release(); c->d_out_prob.release(); c->d_a_pkt.release(); c->d_a_dst.release();
+    c->d_a_verdict.release(); c->d_a_rssi.release(); c->d_a_sinr.release(); c->d_a_prob.release();
+    c->d_draw_scan.release(); c->d_scan_block.release(); c->d_rng.release(); c->d_pkt_rng.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -570,7 +775,9 @@ int rm_set_model(rm_context *c, const rm_model_params *p)
 {
     if (!c || !p) return fail(RM_ERR_INVALID, "NULL argument");
     RM_TRY(validate_model(p));
+    const bool was_geo = is_geometric(c);
     c->params = *p;
+    if (was_geo != is_geometric(c)) c->rx_dirty = true;
     c->prefilter_dirty = true;
     c->onair.clear();
     c->pending.clear();
@@ -667,19 +874,20 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     RM_TRY(upload(c->d_y, c->y, c->stream));
     RM_TRY(upload(c->d_z, c->z, c->stream));
     RM_TRY(upload(c->d_txpower, c->txpower, c->stream));
-    RM_TRY(upload(c->d_rxprob, c->rxprob, c->stream));
     RM_TRY(upload(c->d_txprob, c->txprob, c->stream));
     RM_TRY(upload(c->d_channel, c->channel, c->stream));
     RM_TRY(upload(c->d_int_id, c->int_id, c->stream));
-    RM_TRY(upload(c->d_enabled, c->enabled, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
     recompute_frame(c);
+    c->rx_dirty = true;
+    c->frac_probs = -1;
     c->onair.clear();
     c->pending.clear();
     if (c->rx_count >= 0 && c->rx_first + c->rx_count > n) {
         c->rx_first = 0;
         c->rx_count = -1;
     }
+    c->rx_dirty = true;
     return RM_OK;
 }
 
@@ -696,15 +904,14 @@ int rm_node_update(rm_context *c, int32_t i, double x, double y, double z, doubl
     RM_HIP(hipMemcpyAsync(c->d_y.p + i, &c->y[i], 8, hipMemcpyHostToDevice, s));
     RM_HIP(hipMemcpyAsync(c->d_z.p + i, &c->z[i], 8, hipMemcpyHostToDevice, s));
     RM_HIP(hipMemcpyAsync(c->d_txpower.p + i, &c->txpower[i], 8, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_rxprob.p + i, &c->rxprob[i], 8, hipMemcpyHostToDevice, s));
     RM_HIP(hipMemcpyAsync(c->d_txprob.p + i, &c->txprob[i], 8, hipMemcpyHostToDevice, s));
     RM_HIP(hipMemcpyAsync(c->d_channel.p + i, &c->channel[i], 4, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_enabled.p + i, &c->enabled[i], 1, hipMemcpyHostToDevice, s));
     RM_HIP(hipStreamSynchronize(s));
     const double dv[3] = {x - c->org[0], y - c->org[1], z - c->org[2]};
     if (std::fabs(dv[0]) > c->coord_bound || std::fabs(dv[1]) > c->coord_bound || std::fabs(dv[2]) > c->coord_bound)
         recompute_frame(c);
-    c->prefilter_dirty = true;
+    c->rx_dirty = true; // the receiver table is rebuilt (and re-sorted) before the next tick
+    c->frac_probs = -1;
     return RM_OK;
 }
 
@@ -715,6 +922,7 @@ int rm_set_partition(rm_context *c, int32_t first, int32_t count)
     if (!c || first < 0 || count < 0 || first + count > c->n) return fail(RM_ERR_INVALID, "partition out of range");
     c->rx_first = first;
     c->rx_count = count;
+    c->rx_dirty = true;
     return RM_OK;
 }
 
@@ -787,7 +995,7 @@ static int copy_out(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict,
 {
     hipStream_t s = c->stream;
     uint32_t oc[3] = {0, 0, 0};
-    RM_HIP(hipMemcpyAsync(oc, c->d_counters.p + 2, sizeof(oc), hipMemcpyDeviceToHost, s));
+    RM_HIP(hipMemcpyAsync(oc, c->last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
     RM_HIP(hipStreamSynchronize(s));
     if (count) *count = oc[2];
     const uint32_t k = std::min(oc[0], cap);
@@ -874,7 +1082,7 @@ int rm_result_device(rm_context *c, rm_device_result *out)
 {
     if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
     if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
-    out->count = c->d_counters.p + 2;
+    out->count = c->last.out_count;
     out->pkt_offset = c->d_slot_off.p + c->last.shift;
     out->pkt = c->d_out_pkt.p;
     out->dst = c->d_out_dst.p;
@@ -891,7 +1099,7 @@ int rm_result_count(rm_context *c, uint32_t *count, uint32_t *dropped)
     if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
     uint32_t oc[3];
-    RM_HIP(hipMemcpyAsync(oc, c->d_counters.p + 2, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipMemcpyAsync(oc, c->last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
     if (count) *count = oc[2];
     if (dropped) *dropped = oc[1];
@@ -912,6 +1120,8 @@ int rm_profile_enable(rm_context *c, int enable)
     RM_HIP(hipSetDevice(c->device));
     RM_TRY(drain_profile(c));
     c->profile = enable != 0;
+    c->profile_every = enable > 0 ? enable : 1;
+    c->tick_index = 0;
     c->prof_launches = 0;
     c->prof_ms = 0;
     return RM_OK;

@@ -9,12 +9,15 @@
 
 namespace rm {
 
-constexpr int kTxChunk = 64;        // transmitters per LDS tile == wave width (one count lane per tx)
+constexpr int kTxChunk = 64;        // transmitters per LDS tile == wave width (one lane per frame)
 constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
 constexpr int kBlock = 64 * kWavesPerBlock;
+constexpr int kGroup = 64;          // receivers per bounding-box group (one per lane)
+constexpr int kShards = 256;        // append counters of the candidate list (one word sustains only ~88 atomics/us)
+constexpr int kShardStride = 32;    // u32 words between shard counters: one 128-byte line each
 
-// staging-entry flags
-constexpr uint8_t kFlagHeardNew = 1;   // gets an output record (has a slab rank)
+// link-entry flags
+constexpr uint8_t kFlagHeardNew = 1;   // gets an output record
 constexpr uint8_t kFlagInterferer = 2; // rssi >= interference floor (SINR mode)
 constexpr uint8_t kFlagSelf = 4;       // receiver is the source of this on-air frame (half duplex)
 
@@ -32,55 +35,74 @@ struct ModelDev {
     double ld_sens, ld_noise, ld_capture, ld_ifloor;
     double ld_noise_lin;      // det_pow10(noise/10)
     double ld_level;          // candidate level L = sens, or min(sens, ifloor) with SINR
-    // prefilter
+    // pre-filter
     double org_x, org_y, org_z; // origin of the fp32 frame
     double coord_bound;         // max |coord - origin| the fp32 slack was computed for
     double f32_slack;           // Delta (metres) added to every cut-off distance
     double geo_cut;             // cut-off distance for UDGM / CONST (metres), <0 = nobody
 };
 
+// Node state resident in HBM.
+//  * source table, indexed by node index (registration order): what a RadioPacket copies from
+//    its source (RadioPacket.java:46-52) -- used to build Tx records on the device;
+//  * receiver table of this rank's partition, in ENGINE ORDER: receivers are spatially sorted
+//    (k-d split down to groups of 64) so that a wave's 64 receivers share a small bounding box;
+//    orig[pos] maps back to the node index.
 struct NodesDev {
-    int n;
-    const double *x, *y, *z, *rxprob, *txprob, *txpower;
-    const int32_t *channel;
+    int n;                                   // nodes in the simulator
+    const double *sx, *sy, *sz, *stxpower, *stxprob;
+    const int32_t *schannel, *sint_id;
+    int n_rx;                                // receivers of this partition
+    const double *x, *y, *z, *rxprob;
+    const int32_t *channel, *int_id, *orig;
     const uint8_t *enabled;
-    const int32_t *int_id;
-    float4 *rxf; // prefilter record per node: (fx, fy, fz, channel bits); NaN position = never a candidate
+    const int32_t *pos_of;                   // [rx_count] node index - rx_first -> engine position
+    int rx_first;
+    float4 *rxf;                             // pre-filter record: (fx, fy, fz, channel bits); NaN = never a candidate
+    float4 *bbox_xy;                         // per group of 64: (minx, miny, maxx, maxy) in the fp32 frame
+    float2 *bbox_z;                          //                 (minz, maxz)
 };
 
 struct TickDev {
     const rm_tx_record *tx; // on-air list, canonical order [n_active]
-    float4 *txf;            // prefilter record per frame: (fx, fy, fz, threshold on d^2)
-    double *txd;            // fp64 filter: thr64 per frame
     int n_active;
     int first_new;          // frames [first_new, n_active) get verdicts
-    int first_eval;         // frames [first_eval, n_active) are swept by the all-pairs kernel
+    int first_eval;         // frames [first_eval, n_active) are swept by the filter kernel
     int cnt_base;           // eval-relative index of the first counted slot (multiple of 64)
-    int shift;              // slot of new packet 0 = shift
+    int shift;              // slot of new packet 0
     int n_cnt;              // counted slots (multiple of 64)
-    int rx_first, rx_count; // receiver partition
-    int rpt;                // receivers per thread in the all-pairs kernel
-    int n_slabs;            // ceil(rx_count / (64*rpt))
-    // per (slot, slab) heard counts / offsets, layout [(chunk*n_slabs + slab)*64 + lane]
+    int n_rx;               // receivers of the partition
+    int rpt;                // receiver groups per wave in the filter kernel
+    int n_slabs;            // ceil(n_rx / (64*rpt))
+    // per (slot, slab) heard counts / offsets (off is relative to the frame's first link), layout [(chunk*n_slabs + slab)*64 + lane]
     uint32_t *cnt, *off;
-    uint32_t *partial;      // [n_cnt * n_groups]
-    int n_groups, slabs_per_group;
-    uint32_t *slot_off;     // [n_cnt + 1] exclusive scan of per-slot totals
-    // staging (unordered, filled by the all-pairs kernel)
-    uint32_t *stage_count;  // [0] entries appended, [1] dropped-for-capacity flag
-    uint32_t cap;
+    uint32_t *slot_tot;     // [n_cnt] heard links per frame slot
+    uint32_t *slot_off;     // [n_cnt + 1] exclusive scan of slot_tot
+    // candidate / link list (unordered; appended by the filter kernel, completed by the exact kernel)
+    uint32_t *stage_count;  // [1] dropped-for-capacity flag
+    uint32_t *next_counters; // the other parity's 8 counters, zeroed for the next tick by k_filter
+    uint32_t *shard_count;  // [kShards * kShardStride] entries appended per shard
+    uint32_t *next_shard_count;
+    uint32_t cap;           // capacity of the ordered output records
+    uint32_t seg_cap;       // candidate entries per shard (shard s owns [s*seg_cap, (s+1)*seg_cap))
+    int use_matrix;         // 1: ordered scatter through the (frame, slab) cell matrix (unsorted table)
+                            // 0: per-frame counts + cursor, order restored by k_reorder (sorted table)
+    uint32_t *cursor;       // [n_cnt] per-frame scatter cursor (use_matrix == 0)
     int32_t *st_pkt;        // eval-relative frame index
-    int32_t *st_dst;
-    uint32_t *st_rank;
+    int32_t *st_dst;        // receiver engine position
+    uint32_t *st_blk;       // index of the first entry of this entry's (frame, slab) block
     double *st_aux;         // probability (UDGM/N2N) or rssi (logdist)
     double *st_lin;         // linear power (SINR)
     double *st_sinr;
     int32_t *st_next;       // per-receiver list (SINR)
-    uint8_t *st_flags;
+    uint8_t *st_flags;      // 0 = dead candidate
     uint8_t *st_coll;
-    int32_t *head;          // [rx_count]
-    // final, ordered records
-    uint32_t *out_count;    // [0] heard links stored, [1] dropped flag, [2] heard links total
+    int32_t *head;          // [n_rx]
+    // ordered records: A = (packet, engine position) order, B = (packet, node index) order
+    uint32_t *out_count;    // [0] heard links stored, [1] dropped flag, [2] heard links total, [3] max per frame
+    int32_t *a_pkt, *a_dst;
+    uint8_t *a_verdict;
+    double *a_rssi, *a_sinr, *a_prob;
     int32_t *out_pkt, *out_dst;
     uint8_t *out_verdict;
     double *out_rssi, *out_sinr, *out_prob;
@@ -93,22 +115,25 @@ struct TickDev {
 };
 
 struct LaunchCfg {
-    bool f64_filter;
-    bool stochastic;
+    bool f64_filter;  // fp32 frame too coarse: filter in fp64, no bounding boxes
+    bool stochastic;  // java.util.Random draws may be consumed
+    bool sorted;      // receiver table is spatially sorted (needs the per-packet reorder pass)
+    bool bbox;        // use the bounding-box variant of the filter kernel
 };
 
 // kernels' host launchers (rm_kernels.hip)
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m);
-hipError_t launch_prep_tx(hipStream_t s, const ModelDev &m, const TickDev &t);
 hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n, int64_t start_us,
                           int64_t air_us, rm_tx_record *out);
-hipError_t launch_allpairs(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
-                           const LaunchCfg &cfg);
-hipError_t launch_self_entries(hipStream_t s, const TickDev &t);
+hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
+                         const LaunchCfg &cfg);
+hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t);
+hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);
 hipError_t launch_offsets(hipStream_t s, const TickDev &t);
 hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t);
 hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                            const LaunchCfg &cfg);
+hipError_t launch_reorder(hipStream_t s, const TickDev &t);
 hipError_t launch_draws(hipStream_t s, const ModelDev &m, const TickDev &t);
 
 // host-side mirrors of device math used for constants (rm_kernels.hip, __host__ __device__)

@@ -1,13 +1,14 @@
 // rm_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the radio-medium engine.
 //
-// One heavy kernel, k_allpairs, sweeps every (frame on the air) x (receiver of this rank's
-// partition) link: one receiver per lane (RPT receivers per thread in registers), transmitter
-// tiles of 64 frames staged in LDS, a conservative fp32 (or fp64) geometric pre-filter whose
-// wave ballot decides whether the exact fp64 evaluation -- the reference's arithmetic, in the
-// reference's operation order -- has to run for that (frame, 64 receivers) step.  Heard links
-// are appended to an unordered staging list together with their rank inside the
-// (frame, receiver-slab) cell; everything after that is O(heard links): offsets from the cell
-// counts, SINR over per-receiver lists, ordered scatter, Java-RNG draws.
+// k_filter sweeps every (frame on the air) x (receiver of this rank's partition) link: one
+// receiver per lane (RPT groups of 64 per wave, resident in registers), transmitter tiles of 64
+// frames staged in LDS, a bounding-box test of the tile against each spatially sorted receiver
+// group (one frame per lane, one ballot), then a conservative fp32 (or fp64) geometric pre-filter
+// on the near frames whose ballots append candidate links to a compact list (one atomic per wave
+// step).  k_exact evaluates the candidates with full lanes: the reference's fp64 arithmetic in the
+// reference's operation order.  Everything after that is O(heard links): offsets from the
+// (frame, slab) cell counts, SINR over per-receiver lists, ordered scatter, per-packet reorder to
+// node-index order, Java-RNG draws.
 //
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (no fast-math): the exact path relies
 // on every fp64 operation being one IEEE-754 rounding, as in Java.
@@ -282,25 +283,56 @@ RM_HD double lcg_next_double(uint64_t &s)
 
 // ============================================================================ small kernels
 
-// per-node pre-filter record: (fx, fy, fz, channel bits); a disabled radio gets a NaN position so
-// that the geometric test can never pass (Transciever.isEnabled(), UDGMRadioMedium.java:102)
-__global__ void __launch_bounds__(256) k_prep_rx(NodesDev nd, ModelDev m)
+RM_D float wave_min(float v)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nd.n) return;
-    float4 r;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+    return v;
+}
+RM_D float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+// Pre-filter record per receiver: (fx, fy, fz, channel bits) in the fp32 frame; a disabled radio
+// gets a NaN position so that the geometric test can never pass (Transciever.isEnabled(),
+// UDGMRadioMedium.java:102).  One wave per group of 64 receivers; the group's bounding box is the
+// min/max of exactly these fp32 coordinates, so the box test is conservative w.r.t. the
+// per-receiver test by monotonicity of fp32 rounding.
+__global__ void __launch_bounds__(64) k_prep_rx(NodesDev nd, ModelDev m)
+{
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = g * kGroup + lane;
     const bool geometric = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_UDGM_CONST || m.kind == RM_MODEL_LOGDIST);
-    if (!nd.enabled[i]) {
-        r.x = r.y = r.z = __builtin_nanf("");
-    } else if (geometric) {
-        r.x = float(nd.x[i] - m.org_x);
-        r.y = float(nd.y[i] - m.org_y);
-        r.z = float(nd.z[i] - m.org_z);
-    } else {
-        r.x = r.y = r.z = 0.f;
+    const float nanf_ = __builtin_nanf("");
+    const float inf_ = __builtin_inff();
+    float4 r;
+    r.x = r.y = r.z = nanf_;
+    r.w = 0.f;
+    if (i < nd.n_rx) {
+        if (nd.enabled[i]) {
+            if (geometric) {
+                r.x = float(nd.x[i] - m.org_x);
+                r.y = float(nd.y[i] - m.org_y);
+                r.z = float(nd.z[i] - m.org_z);
+            } else {
+                r.x = r.y = r.z = 0.f;
+            }
+        }
+        r.w = __int_as_float(nd.channel[i]);
+        nd.rxf[i] = r;
     }
-    r.w = __int_as_float(nd.channel[i]);
-    nd.rxf[i] = r;
+    const bool ok = (r.x == r.x);
+    const float lox = wave_min(ok ? r.x : inf_), hix = wave_max(ok ? r.x : -inf_);
+    const float loy = wave_min(ok ? r.y : inf_), hiy = wave_max(ok ? r.y : -inf_);
+    const float loz = wave_min(ok ? r.z : inf_), hiz = wave_max(ok ? r.z : -inf_);
+    if (lane == 0) {
+        nd.bbox_xy[g] = make_float4(lox, loy, hix, hiy);
+        nd.bbox_z[g] = make_float2(loz, hiz);
+    }
 }
 
 RM_D float round_up_to_float(double v)
@@ -310,15 +342,14 @@ RM_D float round_up_to_float(double v)
     return f;
 }
 
-// per-frame pre-filter record: (fx, fy, fz, threshold on the fp32 squared distance)
-__global__ void __launch_bounds__(256) k_prep_tx(ModelDev m, TickDev t)
+// Pre-filter record of one frame: position in the fp32 frame + threshold on the squared fp32
+// distance (and the fp64 threshold for the fp64 variant).  thr < 0: nobody can be a candidate;
+// thr = +inf: every enabled same-channel receiver is one (non-geometric media, or a frame whose
+// position lies outside the frame the fp32 slack was computed for).
+RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, double &thr64)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x; // eval-relative
-    const int n_eval = t.n_active - t.first_eval;
-    if (i >= n_eval) return;
-    const rm_tx_record tx = t.tx[t.first_eval + i];
-    double cut; // cut-off distance (metres): no link beyond it can matter; <0 nobody, inf everybody
     const double inf = u2f(0x7FF0000000000000ull);
+    double cut; // cut-off distance (metres): no link beyond it can matter
     if (tx.src < 0) {
         cut = -1.0; // padding record
     } else if (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_UDGM_CONST) {
@@ -336,18 +367,14 @@ __global__ void __launch_bounds__(256) k_prep_tx(ModelDev m, TickDev t)
     } else {
         cut = inf; // Null / N2N: no geometry
     }
-    float4 f;
-    double thr64;
     const double rx_ = tx.x - m.org_x, ry_ = tx.y - m.org_y, rz_ = tx.z - m.org_z;
     const bool geometric = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_UDGM_CONST || m.kind == RM_MODEL_LOGDIST);
     const bool in_frame = fabs(rx_) <= m.coord_bound && fabs(ry_) <= m.coord_bound && fabs(rz_) <= m.coord_bound;
+    f.x = f.y = f.z = 0.f;
     if (cut < 0.0) {
-        f.x = f.y = f.z = 0.f;
         f.w = -1.f;
         thr64 = -1.0;
     } else if (!geometric || !in_frame || cut == inf) {
-        // everything (enabled, same channel) is a candidate; the exact path decides
-        f.x = f.y = f.z = 0.f;
         f.w = __builtin_inff();
         thr64 = inf;
         if (geometric && in_frame) {
@@ -364,8 +391,6 @@ __global__ void __launch_bounds__(256) k_prep_tx(ModelDev m, TickDev t)
         f.w = round_up_to_float(c * c * (1.0 + 16.0 * eps));
         thr64 = (cut * cut) * (1.0 + 1e-12);
     }
-    t.txf[i] = f;
-    t.txd[i] = thr64;
 }
 
 // RadioPacket(node, time, data): copies the source radio's txpower / channel (RadioPacket.java:46-52)
@@ -385,23 +410,260 @@ k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_
         r.src = -1;
         r.channel = 0;
     } else {
-        r.x = nd.x[s];
-        r.y = nd.y[s];
-        r.z = nd.z[s];
-        r.txpower = nd.txpower[s];
-        r.txprob = nd.txprob[s];
+        r.x = nd.sx[s];
+        r.y = nd.sy[s];
+        r.z = nd.sz[s];
+        r.txpower = nd.stxpower[s];
+        r.txprob = nd.stxprob[s];
         r.start_us = start_us;
         r.air_us = air_us;
         r.src = s;
-        r.channel = nd.channel[s];
+        r.channel = nd.schannel[s];
     }
     out[i] = r;
 }
 
-// ============================================================================ the all-pairs kernel
+// ============================================================================ the filter kernel
+
+RM_D uint32_t lane_prefix(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+
+RM_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Consecutive lanes with equal `key` form a run (candidate entries of one frame are contiguous in
+// the list).  For the lanes with `pred`: how many such lanes precede me inside my run, how many
+// the run has, and which lane leads it -- so that one atomic per run replaces one per link.
+struct RunInfo {
+    int start;
+    uint32_t before, total;
+};
+RM_D RunInfo run_prefix(int key, bool pred, int lane)
+{
+    const int prev = __shfl_up(key, 1);
+    const uint64_t starts = ballot64(lane == 0 || key != prev);
+    const uint64_t preds = ballot64(pred);
+    const uint64_t upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull); // lanes 0..lane
+    RunInfo r;
+    r.start = 63 - __clzll((long long)(starts & upto));
+    const uint64_t later = starts & ~upto;
+    const int end = later ? (__ffsll((long long)later) - 1) : 64;
+    const uint64_t run = ((end == 64) ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << r.start) - 1ull);
+    r.before = uint32_t(__popcll(preds & run & ((1ull << lane) - 1ull)));
+    r.total = uint32_t(__popcll(preds & run));
+    return r;
+}
+
+// squared fp32 distance; fma is fine here: the filter only has to be conservative, and the box
+// test uses the very same expression (monotone in each |d|)
+RM_D float dist2_f32(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+
+template <int RPT, bool F64, bool BBOX>
+__global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    __shared__ float4 s_txf[kTxChunk];
+    __shared__ int s_ch[kTxChunk];
+    __shared__ double s_td[F64 ? kTxChunk * 4 : 1];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT]; // candidate ballots of the near frames
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int slab = blockIdx.x * kWavesPerBlock + wave;
+    const int chunk = blockIdx.y;
+    const int n_eval = t.n_active - t.first_eval;
+    const int e0 = chunk * kTxChunk; // eval-relative index of the tile's first frame
+    const int nt = min(kTxChunk, n_eval - e0);
+    const int jbase = slab * (kGroup * RPT);
+
+    // the next tick's counters (other parity) are zeroed here: nothing touches them during this tick
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x < 8) t.next_counters[threadIdx.x] = 0u;
+        t.next_shard_count[threadIdx.x * kShardStride] = 0u; // kBlock == kShards
+    }
+
+    // receivers of this lane (coalesced 16-byte loads), resident in registers for the whole tile;
+    // issued before the tile is staged so that both round trips overlap
+    float fx[RPT], fy[RPT], fz[RPT];
+    int fch[RPT];
+    double gx[RPT], gy[RPT], gz[RPT];
+    float4 bxy[RPT];
+    float2 bz[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int j = jbase + r * kGroup + lane;
+        fx[r] = fy[r] = fz[r] = __builtin_nanf("");
+        fch[r] = 0;
+        if (F64) gx[r] = gy[r] = gz[r] = u2f(0x7FF8000000000000ull);
+        if (j < t.n_rx) {
+            const float4 v = nd.rxf[j];
+            fx[r] = v.x;
+            fy[r] = v.y;
+            fz[r] = v.z;
+            fch[r] = __float_as_int(v.w);
+            if (F64 && v.x == v.x) {
+                gx[r] = nd.x[j];
+                gy[r] = nd.y[j];
+                gz[r] = nd.z[j];
+            }
+        }
+        if (BBOX) {
+            const int g = slab * RPT + r;
+            const bool ok = g * kGroup < t.n_rx;
+            bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
+        }
+    }
+
+    // stage the transmitter tile in LDS: one frame per lane of wave 0, pre-filter record computed
+    // on the fly from the on-air record
+    if (threadIdx.x < kTxChunk) {
+        float4 f = make_float4(0.f, 0.f, 0.f, -1.f);
+        double thr64 = -1.0;
+        int ch = 0;
+        double px = 0, py = 0, pz = 0;
+        if (int(threadIdx.x) < nt) {
+            const rm_tx_record tx = t.tx[t.first_eval + e0 + threadIdx.x];
+            tx_prefilter(m, tx, f, thr64);
+            ch = tx.channel;
+            px = tx.x;
+            py = tx.y;
+            pz = tx.z;
+        }
+        s_txf[threadIdx.x] = f;
+        s_ch[threadIdx.x] = ch;
+        if (F64) {
+            s_td[threadIdx.x * 4 + 0] = px;
+            s_td[threadIdx.x * 4 + 1] = py;
+            s_td[threadIdx.x * 4 + 2] = pz;
+            s_td[threadIdx.x * 4 + 3] = thr64;
+        }
+    }
+    __syncthreads();
+    if (slab >= t.n_slabs) return;
+
+    // heard-link counters start at zero; k_exact adds to them
+    if (e0 >= t.cnt_base) {
+        const int cc = (e0 - t.cnt_base) / kTxChunk;
+        if (t.use_matrix) {
+            t.cnt[(size_t(cc) * t.n_slabs + slab) * 64 + lane] = 0u;
+        } else if (slab == 0) {
+            t.slot_tot[cc * 64 + lane] = 0u;
+            t.cursor[cc * 64 + lane] = 0u;
+        }
+    }
+
+    // which frames of the tile can reach which receiver group: one frame per lane against the
+    // group's bounding box, one ballot per group
+    uint64_t near[RPT];
+    uint64_t todo = 0;
+    if (BBOX) {
+        const float4 tf = s_txf[lane];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            near[r] = 0;
+            if ((slab * RPT + r) * kGroup < t.n_rx) {
+                const float dx = fmaxf(fmaxf(bxy[r].x - tf.x, tf.x - bxy[r].z), 0.f);
+                const float dy = fmaxf(fmaxf(bxy[r].y - tf.y, tf.y - bxy[r].w), 0.f);
+                const float dz = fmaxf(fmaxf(bz[r].x - tf.z, tf.z - bz[r].y), 0.f);
+                near[r] = ballot64(dist2_f32(dx, dy, dz) <= tf.w);
+            }
+            todo |= near[r];
+        }
+    } else {
+        todo = (nt >= 64) ? ~0ull : ((1ull << nt) - 1ull);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) near[r] = todo;
+    }
+
+    // pass 1: per near frame, the candidate ballots of the RPT groups; lane ti keeps frame ti's count
+    uint32_t my_total = 0;
+    uint64_t walk = todo;
+    while (walk) {
+        const int ti = __ffsll((long long)walk) - 1; // wave-uniform
+        walk &= walk - 1;
+        const float4 tf = s_txf[ti];
+        const int tch = s_ch[ti];
+        uint64_t mask[RPT];
+        uint32_t total = 0;
+        if (F64) {
+            const double px = s_td[ti * 4 + 0], py = s_td[ti * 4 + 1], pz = s_td[ti * 4 + 2], thr = s_td[ti * 4 + 3];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const double dx = px - gx[r], dy = py - gy[r], dz = pz - gz[r];
+                const double s2 = dx * dx + dy * dy + dz * dz;
+                mask[r] = ballot64((s2 <= thr) && (fch[r] == tch));
+                total += uint32_t(__popcll(mask[r]));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                mask[r] = 0;
+                if ((near[r] >> ti) & 1ull) { // wave-uniform
+                    const float s2 = dist2_f32(fx[r] - tf.x, fy[r] - tf.y, fz[r] - tf.z);
+                    mask[r] = ballot64((s2 <= tf.w) && (fch[r] == tch));
+                    total += uint32_t(__popcll(mask[r]));
+                }
+            }
+        }
+        if (total) {
+            if (lane == ti) my_total = total;
+            if (lane < RPT) {
+                uint64_t v = mask[0];
+#pragma unroll
+                for (int r = 1; r < RPT; ++r) v = (lane == r) ? mask[r] : v;
+                s_mask[wave][ti][lane] = v;
+            }
+        }
+    }
+    const uint64_t have = ballot64(my_total != 0u);
+    if (have == 0) return; // the common case: far from every transmitter of the tile
+
+    // one atomic reserves the contiguous run of candidate entries of this (tile, slab); the frames'
+    // blocks follow each other inside it in frame order
+    uint32_t inc = my_total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    const uint32_t wave_total = __shfl(inc, 63);
+    const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) & (kShards - 1);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + wave_total > t.seg_cap) { // the shard is full: drop the run, flag the tick
+        if (lane == 0) t.stage_count[1] = 1u;
+        return;
+    }
+    const uint32_t my_base = shard * t.seg_cap + base + inc - my_total;
+
+    // pass 2: fill the blocks in receiver order
+    walk = have;
+    while (walk) {
+        const int ti = __ffsll((long long)walk) - 1;
+        walk &= walk - 1;
+        const uint32_t fbase = __shfl(my_base, ti);
+        uint32_t pre = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const uint64_t mk = s_mask[wave][ti][r];
+            if (mk == 0) continue;
+            if ((mk >> lane) & 1ull) {
+                const uint32_t idx = fbase + pre + lane_prefix(mk);
+                t.st_pkt[idx] = e0 + ti;
+                t.st_dst[idx] = jbase + r * kGroup + lane;
+                t.st_blk[idx] = fbase;
+            }
+            pre += uint32_t(__popcll(mk));
+        }
+    }
+}
+
+// ============================================================================ exact evaluation
 
 struct LinkEval {
-    bool append;   // goes to the staging list
+    bool append;   // stays in the link list
     bool wanted;   // heard link of a new frame: gets an output record
     uint8_t flags;
     double aux;    // probability (UDGM / N2N) or rssi (logdist)
@@ -410,9 +672,9 @@ struct LinkEval {
 
 // Exact evaluation of one link, in the reference's order of tests
 // (UDGMRadioMedium.java:99-111, N2NRadioMedium.java:55-67, NullRadioMedium.java:62-73,
-//  UDGMConstantLossRadioMedium.java:25-33).
+//  UDGMConstantLossRadioMedium.java:25-33).  `pos` is the receiver's engine position.
 template <int MODEL, bool SINR>
-RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_record &tx, int j, bool is_new)
+RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_record &tx, int pos, bool is_new)
 {
     LinkEval r;
     r.append = false;
@@ -420,33 +682,34 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
     r.flags = 0;
     r.aux = 0.0;
     r.lin = 0.0;
-    if (j == tx.src) return r;                  // node != source
-    if (!nd.enabled[j]) return r;               // radio.isEnabled()
-    if (nd.channel[j] != tx.channel) return r;  // radio.getWirelessChannel() == channel
+    const int j = nd.orig[pos];
+    if (j == tx.src) return r;                    // node != source
+    if (!nd.enabled[pos]) return r;               // radio.isEnabled()
+    if (nd.channel[pos] != tx.channel) return r;  // radio.getWirelessChannel() == channel
     if (MODEL == RM_MODEL_NULL) {
-        r.append = r.wanted = true;
+        r.append = r.wanted = is_new;
         r.flags = kFlagHeardNew;
         return r;
     }
     if (MODEL == RM_MODEL_N2N) {
         // N2NRadioMedium.java:28-37
-        const int sid = nd.int_id[tx.src];
-        const int did = nd.int_id[j];
+        const int sid = nd.sint_id[tx.src];
+        const int did = nd.int_id[pos];
         double p = 0.0;
         if (m.n2n != nullptr && sid > 0 && did > 0 && sid <= m.n2n_m && did <= m.n2n_m) {
-            p = m.n2n[int64_t(sid - 1) * m.n2n_m + (did - 1)] * nd.rxprob[j];
+            p = m.n2n[int64_t(sid - 1) * m.n2n_m + (did - 1)] * nd.rxprob[pos];
         }
         if (p <= 0.0) return r;
-        r.append = r.wanted = true;
+        r.append = r.wanted = is_new;
         r.flags = kFlagHeardNew;
         r.aux = p;
         return r;
     }
-    const double rx = nd.x[j], ry = nd.y[j], rz = nd.z[j];
+    const double rx = nd.x[pos], ry = nd.y[pos], rz = nd.z[pos];
     if (MODEL == RM_MODEL_UDGM_CONST) {
         const double d = ref_distance(tx.x, tx.y, tx.z, rx, ry, rz);
         if (d < m.const_range) {
-            r.append = r.wanted = true;
+            r.append = r.wanted = is_new;
             r.flags = kFlagHeardNew;
         }
         return r;
@@ -461,16 +724,16 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
         double ratio = d2 / dmax2;
         if (ratio > 1.0) return r;
         ratio = 1.0 - ratio * (1.0 - m.udgm_ratio_rx);
-        const double p = ratio * nd.rxprob[j];
+        const double p = ratio * nd.rxprob[pos];
         if (p <= 0.0) return r;
-        r.append = r.wanted = true;
+        r.append = r.wanted = is_new;
         r.flags = kFlagHeardNew;
         r.aux = p;
         return r;
     }
     if (MODEL == RM_MODEL_LOGDIST) {
         const double rssi = logdist_rssi(m, tx, rx, ry, rz, j);
-        const bool heard = is_new && (rssi >= m.ld_sens) && !(nd.rxprob[j] <= 0.0);
+        const bool heard = is_new && (rssi >= m.ld_sens) && !(nd.rxprob[pos] <= 0.0);
         r.aux = rssi;
         if (SINR) {
             const bool interferer = rssi >= m.ld_ifloor;
@@ -488,178 +751,69 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
     return r;
 }
 
-RM_D uint32_t lane_prefix(uint64_t mask)
+// one lane per candidate link (full waves): the reference's fp64 arithmetic
+template <int MODEL, bool SINR>
+__global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev m, const TickDev t)
 {
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-}
-
-template <int MODEL, int RPT, bool F64, bool SINR>
-__global__ void __launch_bounds__(kBlock) k_allpairs(const NodesDev nd, const ModelDev m, const TickDev t)
-{
-    __shared__ float4 s_txf[kTxChunk];
-    __shared__ double s_thr[kTxChunk];
-
+    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const int per_slab = kGroup * t.rpt;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int slab = blockIdx.x * kWavesPerBlock + wave;
-    const int chunk = blockIdx.y;
-    const int n_eval = t.n_active - t.first_eval;
-    const int e0 = chunk * kTxChunk;                    // eval-relative index of the tile's first frame
-    const int nt = min(kTxChunk, n_eval - e0);
-
-    // stage the transmitter tile (coalesced) -- the north-star's "LDS-staged transmitter tiles"
-    if (threadIdx.x < nt) {
-        s_txf[threadIdx.x] = t.txf[e0 + threadIdx.x];
-        if (F64) s_thr[threadIdx.x] = t.txd[e0 + threadIdx.x];
-    }
-    __syncthreads();
-    if (slab >= t.n_slabs) return;
-
-    const int rx_end = t.rx_first + t.rx_count;
-    const int jbase = t.rx_first + slab * (64 * RPT);
-
-    // receivers of this lane, resident in registers for the whole tile
-    float fx[RPT], fy[RPT], fz[RPT];
-    int fch[RPT];
-    double gx[RPT], gy[RPT], gz[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int j = jbase + r * 64 + lane;
-        if (j < rx_end) {
-            const float4 v = nd.rxf[j];
-            fx[r] = v.x;
-            fy[r] = v.y;
-            fz[r] = v.z;
-            fch[r] = __float_as_int(v.w);
-            if (F64) {
-                gx[r] = nd.x[j];
-                gy[r] = nd.y[j];
-                gz[r] = nd.z[j];
-                if (v.x != v.x) gx[r] = u2f(0x7FF8000000000000ull); // disabled
-            }
-        } else {
-            fx[r] = fy[r] = fz[r] = __builtin_nanf("");
-            fch[r] = 0;
-            if (F64) gx[r] = gy[r] = gz[r] = u2f(0x7FF8000000000000ull);
-        }
-    }
-
-    uint32_t cnt_lane = 0; // lane l ends up holding the heard count of the tile's l-th frame
-    const rm_tx_record *txg = t.tx + t.first_eval + e0;
-
-    for (int ti = 0; ti < nt; ++ti) {
-        const float4 tf = s_txf[ti];
-        const int tch = txg[ti].channel; // wave-uniform: scalar load
-        uint64_t mask[RPT];
-        uint64_t any = 0;
-        if (F64) {
-            const double tx_ = txg[ti].x, ty_ = txg[ti].y, tz_ = txg[ti].z;
-            const double thr = s_thr[ti];
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const double dx = tx_ - gx[r], dy = ty_ - gy[r], dz = tz_ - gz[r];
-                const double s = dx * dx + dy * dy + dz * dz;
-                mask[r] = __ballot((s <= thr) && (fch[r] == tch));
-                any |= mask[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const float dx = fx[r] - tf.x, dy = fy[r] - tf.y, dz = fz[r] - tf.z;
-                const float s = dx * dx + dy * dy + dz * dz;
-                mask[r] = __ballot((s <= tf.w) && (fch[r] == tch));
-                any |= mask[r];
-            }
-        }
-        if (any == 0) continue; // the common case: nobody of these 64*RPT receivers is near this frame
-
-        // ---- exact path (rare): the reference's arithmetic on the candidate lanes
-        const rm_tx_record tx = txg[ti];
-        const int e_abs = e0 + ti;
-        const bool is_new = (t.first_eval + e_abs) >= t.first_new;
-        uint32_t run = 0;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            if (mask[r] == 0) continue; // wave-uniform
-            const int j = jbase + r * 64 + lane;
-            LinkEval ev;
-            ev.append = ev.wanted = false;
-            ev.flags = 0;
-            ev.aux = ev.lin = 0.0;
-            if ((mask[r] >> lane) & 1ull) ev = eval_link<MODEL, SINR>(m, nd, tx, j, is_new);
-            const uint64_t ab = __ballot(ev.append);
-            if (ab == 0) continue;
-            const uint64_t wb = __ballot(ev.wanted);
-            // one atomic per wave step: the first appending lane reserves the block of entries
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)ab) - 1;
-            if (lane == leader) base = atomicAdd(t.stage_count, uint32_t(__popcll(ab)));
-            base = __shfl(base, leader);
+    for (uint32_t it = blockIdx.x * blockDim.x; it < n; it += stride) { // block-uniform trip count
+        const uint32_t i = it + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t idx = blockIdx.y * t.seg_cap + i;
+        bool wanted = false;
+        int key = -1; // counter this link is added to: the frame slot, or the (frame, slab) cell
+        if (valid) {
+            const int erel = t.st_pkt[idx];
+            const int pos = t.st_dst[idx];
+            const rm_tx_record tx = t.tx[t.first_eval + erel];
+            const bool is_new = (t.first_eval + erel) >= t.first_new;
+            const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, pos, is_new);
+            t.st_flags[idx] = ev.append ? ev.flags : uint8_t(0);
             if (ev.append) {
-                const uint32_t idx = base + lane_prefix(ab);
-                if (idx < t.cap) {
-                    t.st_pkt[idx] = e_abs;
-                    t.st_dst[idx] = j;
-                    t.st_rank[idx] = run + lane_prefix(wb);
-                    t.st_flags[idx] = ev.flags;
-                    if (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_N2N || MODEL == RM_MODEL_LOGDIST)
-                        t.st_aux[idx] = ev.aux;
-                    if (SINR) {
-                        t.st_lin[idx] = ev.lin;
-                        t.st_next[idx] = atomicExch(&t.head[j - t.rx_first], int(idx));
-                    }
-                } else {
-                    t.stage_count[1] = 1u;
+                if (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_N2N || MODEL == RM_MODEL_LOGDIST) t.st_aux[idx] = ev.aux;
+                if (SINR) {
+                    t.st_lin[idx] = ev.lin;
+                    t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
                 }
+                wanted = ev.wanted;
             }
-            run += uint32_t(__popcll(wb));
+            const int slot = erel - t.cnt_base;
+            key = t.use_matrix ? int((size_t(slot >> 6) * t.n_slabs + pos / per_slab) * 64 + (slot & 63)) : slot;
         }
-        if (lane == ti) cnt_lane = run;
+        const RunInfo ri = run_prefix(key, wanted, lane);
+        if (valid && lane == ri.start && ri.total) atomicAdd(t.use_matrix ? &t.cnt[key] : &t.slot_tot[key], ri.total);
     }
-
-    // heard counts of this (tile, slab) cell: one coalesced 256-byte store per wave
-    const int cc = (e0 - t.cnt_base) / kTxChunk;
-    if (cc >= 0) t.cnt[(size_t(cc) * t.n_slabs + slab) * 64 + lane] = cnt_lane;
 }
 
 // half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
-__global__ void __launch_bounds__(256) k_self_entries(TickDev t)
+__global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_eval = t.n_active - t.first_eval;
     if (e >= n_eval) return;
     const int src = t.tx[t.first_eval + e].src;
-    if (src < t.rx_first || src >= t.rx_first + t.rx_count) return;
-    const uint32_t idx = atomicAdd(t.stage_count, 1u);
-    if (idx >= t.cap) {
+    if (src < nd.rx_first || src >= nd.rx_first + nd.n_rx) return;
+    const int pos = nd.pos_of[src - nd.rx_first];
+    const uint32_t shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kShards - 1);
+    const uint32_t local = atomicAdd(&t.shard_count[shard * kShardStride], 1u);
+    if (local >= t.seg_cap) {
         t.stage_count[1] = 1u;
         return;
     }
+    const uint32_t idx = shard * t.seg_cap + local;
     t.st_pkt[idx] = e;
-    t.st_dst[idx] = src;
-    t.st_rank[idx] = 0;
+    t.st_dst[idx] = pos;
+    t.st_blk[idx] = idx;
     t.st_flags[idx] = kFlagSelf;
     t.st_aux[idx] = 0.0;
     t.st_lin[idx] = 0.0;
-    t.st_next[idx] = atomicExch(&t.head[src - t.rx_first], int(idx));
+    t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
 }
 
 // ============================================================================ offsets (tiny scans)
-
-// partial[g][slot] = sum of cnt over the slabs of group g
-__global__ void __launch_bounds__(256) k_partial(TickDev t)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= t.n_cnt * t.n_groups) return;
-    const int slot = idx % t.n_cnt;
-    const int g = idx / t.n_cnt;
-    const int cc = slot >> 6, tl = slot & 63;
-    const int s0 = g * t.slabs_per_group;
-    const int s1 = min(t.n_slabs, s0 + t.slabs_per_group);
-    uint32_t sum = 0;
-    for (int s = s0; s < s1; ++s) sum += t.cnt[(size_t(cc) * t.n_slabs + s) * 64 + tl];
-    t.partial[size_t(g) * t.n_cnt + slot] = sum;
-}
 
 RM_D uint32_t wave_inclusive_scan(uint32_t v, int lane)
 {
@@ -690,46 +844,58 @@ RM_D uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave /*[16]*/, u
     return wave_off + inc - v;
 }
 
-// slot_off = exclusive scan over slots of the per-slot totals; also publishes the heard-link count
+// off[cell] = heard links of the same frame in lower slabs; slot_tot[slot] = heard links of the
+// frame.  One 1024-thread workgroup per tile of 64 frames: lane = frame, each wave owns a
+// contiguous range of slabs (coalesced 256-byte rows).
+__global__ void __launch_bounds__(1024) k_cell_off(TickDev t)
+{
+    __shared__ uint32_t s_part[16][64];
+    const int cc = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (t.n_slabs + 15) / 16;
+    const int s0 = min(t.n_slabs, wave * per), s1 = min(t.n_slabs, s0 + per);
+    const size_t row0 = size_t(cc) * t.n_slabs;
+    uint32_t sum = 0;
+    for (int s = s0; s < s1; ++s) sum += t.cnt[(row0 + s) * 64 + lane];
+    s_part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t x = s_part[w][lane];
+        if (w < wave) run += x;
+        total += x;
+    }
+    for (int s = s0; s < s1; ++s) {
+        const size_t c = (row0 + s) * 64 + lane;
+        t.off[c] = run;
+        run += t.cnt[c];
+    }
+    if (wave == 0) t.slot_tot[cc * 64 + lane] = total;
+}
+
+// slot_off = exclusive scan over frames of their heard-link totals; publishes the link count
 __global__ void __launch_bounds__(1024) k_slot_scan(TickDev t)
 {
     __shared__ uint32_t s_wave[16];
     uint32_t carry = 0;
+    uint32_t vmax = 0;
     for (int base = 0; base < t.n_cnt; base += 1024) {
         const int slot = base + threadIdx.x;
-        uint32_t v = 0;
-        if (slot < t.n_cnt) {
-            for (int g = 0; g < t.n_groups; ++g) v += t.partial[size_t(g) * t.n_cnt + slot];
-        }
+        const uint32_t v = (slot < t.n_cnt) ? t.slot_tot[slot] : 0u;
+        vmax = max(vmax, v);
         uint32_t total;
         const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
         if (slot < t.n_cnt) t.slot_off[slot] = carry + ex;
         carry += total;
     }
+    for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), d)));
+    if ((threadIdx.x & 63) == 0 && vmax) atomicMax(&t.out_count[3], vmax);
     if (threadIdx.x == 0) {
         t.slot_off[t.n_cnt] = carry;
         t.out_count[0] = carry < t.cap ? carry : t.cap;
         t.out_count[1] = (carry > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
         t.out_count[2] = carry;
-    }
-}
-
-// off[cell] = first output position of the (slot, slab) cell
-__global__ void __launch_bounds__(256) k_slab_off(TickDev t)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= t.n_cnt * t.n_groups) return;
-    const int slot = idx % t.n_cnt;
-    const int g = idx / t.n_cnt;
-    const int cc = slot >> 6, tl = slot & 63;
-    uint32_t run = t.slot_off[slot];
-    for (int gg = 0; gg < g; ++gg) run += t.partial[size_t(gg) * t.n_cnt + slot];
-    const int s0 = g * t.slabs_per_group;
-    const int s1 = min(t.n_slabs, s0 + t.slabs_per_group);
-    for (int s = s0; s < s1; ++s) {
-        const size_t c = (size_t(cc) * t.n_slabs + s) * 64 + tl;
-        t.off[c] = run;
-        run += t.cnt[c];
     }
 }
 
@@ -740,18 +906,19 @@ RM_D bool frames_overlap(const rm_tx_record &w, const rm_tx_record &k)
     return k.start_us < w.start_us + w.air_us && k.start_us + k.air_us > w.start_us;
 }
 
-// one thread per staging entry that is a heard link of a new frame: walk the receiver's list,
+// one thread per link entry that is a heard link of a new frame: walk the receiver's list,
 // sum the co-channel, time-overlapping interferers exactly (Q80), apply capture + half duplex
 __global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t)
 {
-    const uint32_t n = min(t.stage_count[0], t.cap);
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t e = blockIdx.y * t.seg_cap + i;
         if (!(t.st_flags[e] & kFlagHeardNew)) continue;
-        const int j = t.st_dst[e];
+        const int pos = t.st_dst[e];
         const rm_tx_record w = t.tx[t.first_eval + t.st_pkt[e]];
         U128 acc = {0, 0};
         bool half_duplex = false;
-        for (int idx = t.head[j - t.rx_first]; idx >= 0; idx = t.st_next[idx]) {
+        for (int idx = t.head[pos]; idx >= 0; idx = t.st_next[idx]) {
             if (uint32_t(idx) == e) continue;
             const rm_tx_record k = t.tx[t.first_eval + t.st_pkt[idx]];
             if (!frames_overlap(w, k)) continue;
@@ -780,50 +947,96 @@ RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
     return tx.txprob;
 }
 
-// staging entry -> final position off[cell] + rank ; verdict for everything that needs no draw
+// link entry -> position off[cell] + rank inside its (frame, slab) block; verdict for everything
+// that needs no draw.  Output order here: (packet, engine position).
 template <bool STOCH>
-__global__ void __launch_bounds__(256) k_finalize_impl(ModelDev m, TickDev t, const double *rxprob)
+__global__ void __launch_bounds__(256) k_finalize(NodesDev nd, ModelDev m, TickDev t)
 {
-    const uint32_t n = min(t.stage_count[0], t.cap);
+    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
     const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
     const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        if (!(t.st_flags[e] & kFlagHeardNew)) continue;
-        const int erel = t.st_pkt[e];
-        const int j = t.st_dst[e];
-        const int slot = erel - t.cnt_base;
-        const int slab = (j - t.rx_first) / (64 * t.rpt);
-        const uint32_t pos = t.off[(size_t(slot >> 6) * t.n_slabs + slab) * 64 + (slot & 63)] + t.st_rank[e];
-        if (pos >= t.cap) continue;
+    const int per_slab = kGroup * t.rpt;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t it = blockIdx.x * blockDim.x; it < n; it += stride) { // block-uniform trip count
+        const uint32_t i = it + threadIdx.x;
+        const uint32_t e = blockIdx.y * t.seg_cap + i;
+        const bool heard = (i < n) && (t.st_flags[e] & kFlagHeardNew);
+        int erel = 0, pos = 0, slot = -1;
+        if (i < n) { // the frame slot of every entry, heard or not: it delimits the runs
+            erel = t.st_pkt[e];
+            slot = erel - t.cnt_base;
+        }
+        if (heard) pos = t.st_dst[e];
+        uint32_t o = 0;
+        if (t.use_matrix) { // deterministic position: cell offset + rank inside the (frame, slab) block
+            if (heard) {
+                const int slab = pos / per_slab;
+                uint32_t rank = 0;
+                for (uint32_t k = t.st_blk[e]; k < e; ++k) rank += (t.st_flags[k] & kFlagHeardNew) ? 1u : 0u;
+                o = t.slot_off[slot] + t.off[(size_t(slot >> 6) * t.n_slabs + slab) * 64 + (slot & 63)] + rank;
+            }
+        } else { // any position inside the frame's segment (k_reorder restores node-index order):
+                 // one cursor atomic per run of same-frame links
+            const RunInfo ri = run_prefix(slot, heard, lane);
+            uint32_t base = 0;
+            if (slot >= 0 && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total); // the leader need not be heard itself
+            base = __shfl(base, ri.start);
+            if (heard) o = t.slot_off[slot] + base + ri.before;
+        }
+        if (!heard) continue;
+        if (o >= t.cap) continue;
         const rm_tx_record tx = t.tx[t.first_eval + erel];
-        t.out_pkt[pos] = slot - t.shift;
-        t.out_dst[pos] = j;
-        double rssi = tx.txpower; // reference models hand the packet's transmit power through
+        t.a_pkt[o] = slot - t.shift;
+        t.a_dst[o] = nd.orig[pos];
+        double rssi = tx.txpower; // reference media hand the packet's transmit power through
         double prob = 1.0;
         if (m.kind == RM_MODEL_LOGDIST) {
             rssi = t.st_aux[e];
-            prob = rxprob[j];
+            prob = nd.rxprob[pos];
         } else if (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N) {
             prob = t.st_aux[e];
         }
-        t.out_rssi[pos] = rssi;
-        t.out_sinr[pos] = sinr ? t.st_sinr[e] : 0.0;
+        t.a_rssi[o] = rssi;
+        t.a_sinr[o] = sinr ? t.st_sinr[e] : 0.0;
         const bool collided = sinr && t.st_coll[e];
         if (STOCH) {
-            t.out_prob[pos] = prob;
-            t.out_verdict[pos] = collided ? uint8_t(RM_INTERFERED) : uint8_t(0); // 0 = pending
+            t.a_prob[o] = prob;
+            t.a_verdict[o] = collided ? uint8_t(RM_INTERFERED) : uint8_t(0); // 0 = pending
         } else {
             const bool interference = draws_possible && (tx_success(m, tx) <= 0.0);
-            t.out_verdict[pos] = (interference || collided) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+            t.a_verdict[o] = (interference || collided) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
         }
     }
-    if (!STOCH) {
+    if (!STOCH && blockIdx.y == 0) {
         const int n_new = t.n_active - t.first_new;
         for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < uint32_t(n_new); q += stride) {
             const rm_tx_record tx = t.tx[t.first_new + q];
             t.pkt_interference[q] = (draws_possible && tx_success(m, tx) <= 0.0) ? 1 : 0;
         }
+    }
+}
+
+// (packet, engine position) order -> (packet, node index) order: the order the reference's loop
+// visits receivers in (UDGMRadioMedium.java:99).  Rank by counting inside the packet's segment.
+__global__ void __launch_bounds__(256) k_reorder(TickDev t)
+{
+    const uint32_t n = t.out_count[0];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += stride) {
+        const int q = t.a_pkt[o];
+        const uint32_t b = min(t.slot_off[q + t.shift], n);
+        const uint32_t e = min(t.slot_off[q + t.shift + 1], n);
+        const int mine = t.a_dst[o];
+        uint32_t rank = 0;
+        for (uint32_t k = b; k < e; ++k) rank += (t.a_dst[k] < mine) ? 1u : 0u;
+        const uint32_t d = b + rank;
+        t.out_pkt[d] = q;
+        t.out_dst[d] = mine;
+        t.out_verdict[d] = t.a_verdict[o];
+        t.out_rssi[d] = t.a_rssi[o];
+        t.out_sinr[d] = t.a_sinr[o];
+        t.out_prob[d] = t.a_prob[o];
     }
 }
 
@@ -977,16 +1190,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m)
 {
-    if (nd.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_rx, dim3(cdiv(nd.n, 256)), dim3(256), 0, s, nd, m);
-    return hipGetLastError();
-}
-
-hipError_t launch_prep_tx(hipStream_t s, const ModelDev &m, const TickDev &t)
-{
-    const int n_eval = t.n_active - t.first_eval;
-    if (n_eval <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_tx, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, m, t);
+    if (nd.n_rx <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_rx, dim3(cdiv(nd.n_rx, kGroup)), dim3(64), 0, s, nd, m);
     return hipGetLastError();
 }
 
@@ -998,69 +1203,77 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
     return hipGetLastError();
 }
 
-template <int MODEL, bool SINR>
-static hipError_t launch_allpairs_m(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
-                                    const LaunchCfg &cfg)
+hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
+                         const LaunchCfg &cfg)
 {
     const int n_eval = t.n_active - t.first_eval;
+    if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
     const dim3 grid(cdiv(t.n_slabs, kWavesPerBlock), cdiv(n_eval, kTxChunk));
     const dim3 block(kBlock);
-#define RM_LAUNCH(RPT, F64) hipLaunchKernelGGL((k_allpairs<MODEL, RPT, F64, SINR>), grid, block, 0, s, nd, m, t)
+#define RM_LAUNCH(RPT, F64, BBOX) hipLaunchKernelGGL((k_filter<RPT, F64, BBOX>), grid, block, 0, s, nd, m, t)
     if (t.rpt == 4) {
-        if (cfg.f64_filter) RM_LAUNCH(4, true); else RM_LAUNCH(4, false);
+        if (cfg.f64_filter) RM_LAUNCH(4, true, false);
+        else if (cfg.bbox) RM_LAUNCH(4, false, true);
+        else RM_LAUNCH(4, false, false);
     } else {
-        if (cfg.f64_filter) RM_LAUNCH(1, true); else RM_LAUNCH(1, false);
+        if (cfg.f64_filter) RM_LAUNCH(1, true, false);
+        else if (cfg.bbox) RM_LAUNCH(1, false, true);
+        else RM_LAUNCH(1, false, false);
     }
 #undef RM_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t launch_allpairs(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
-                           const LaunchCfg &cfg)
+hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t)
 {
-    if (t.n_active - t.first_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
+    const dim3 grid(4, kShards), block(256);
     switch (m.kind) {
-    case RM_MODEL_NULL: return launch_allpairs_m<RM_MODEL_NULL, false>(s, nd, m, t, cfg);
-    case RM_MODEL_UDGM: return launch_allpairs_m<RM_MODEL_UDGM, false>(s, nd, m, t, cfg);
-    case RM_MODEL_UDGM_CONST: return launch_allpairs_m<RM_MODEL_UDGM_CONST, false>(s, nd, m, t, cfg);
-    case RM_MODEL_N2N: return launch_allpairs_m<RM_MODEL_N2N, false>(s, nd, m, t, cfg);
+    case RM_MODEL_NULL: hipLaunchKernelGGL((k_exact<RM_MODEL_NULL, false>), grid, block, 0, s, nd, m, t); break;
+    case RM_MODEL_UDGM: hipLaunchKernelGGL((k_exact<RM_MODEL_UDGM, false>), grid, block, 0, s, nd, m, t); break;
+    case RM_MODEL_UDGM_CONST: hipLaunchKernelGGL((k_exact<RM_MODEL_UDGM_CONST, false>), grid, block, 0, s, nd, m, t); break;
+    case RM_MODEL_N2N: hipLaunchKernelGGL((k_exact<RM_MODEL_N2N, false>), grid, block, 0, s, nd, m, t); break;
     case RM_MODEL_LOGDIST:
-        if (m.flags & RM_LD_SINR) return launch_allpairs_m<RM_MODEL_LOGDIST, true>(s, nd, m, t, cfg);
-        return launch_allpairs_m<RM_MODEL_LOGDIST, false>(s, nd, m, t, cfg);
+        if (m.flags & RM_LD_SINR) hipLaunchKernelGGL((k_exact<RM_MODEL_LOGDIST, true>), grid, block, 0, s, nd, m, t);
+        else hipLaunchKernelGGL((k_exact<RM_MODEL_LOGDIST, false>), grid, block, 0, s, nd, m, t);
+        break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
 }
 
-hipError_t launch_self_entries(hipStream_t s, const TickDev &t)
+hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t)
 {
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_self_entries, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_self_entries, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, t);
     return hipGetLastError();
 }
 
 hipError_t launch_offsets(hipStream_t s, const TickDev &t)
 {
-    const int work = t.n_cnt * t.n_groups;
-    if (work > 0) hipLaunchKernelGGL(k_partial, dim3(cdiv(work, 256)), dim3(256), 0, s, t);
+    if (t.use_matrix && t.n_cnt > 0 && t.n_slabs > 0)
+        hipLaunchKernelGGL(k_cell_off, dim3(t.n_cnt / 64), dim3(1024), 0, s, t);
     hipLaunchKernelGGL(k_slot_scan, dim3(1), dim3(1024), 0, s, t);
-    if (work > 0) hipLaunchKernelGGL(k_slab_off, dim3(cdiv(work, 256)), dim3(256), 0, s, t);
     return hipGetLastError();
 }
 
 hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t)
 {
-    hipLaunchKernelGGL(k_sinr, dim3(1024), dim3(256), 0, s, m, t);
+    hipLaunchKernelGGL(k_sinr, dim3(4, kShards), dim3(256), 0, s, m, t);
     return hipGetLastError();
 }
 
 hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                            const LaunchCfg &cfg)
 {
-    if (cfg.stochastic)
-        hipLaunchKernelGGL(k_finalize_impl<true>, dim3(1024), dim3(256), 0, s, m, t, nd.rxprob);
-    else
-        hipLaunchKernelGGL(k_finalize_impl<false>, dim3(1024), dim3(256), 0, s, m, t, nd.rxprob);
+    if (cfg.stochastic) hipLaunchKernelGGL(k_finalize<true>, dim3(4, kShards), dim3(256), 0, s, nd, m, t);
+    else hipLaunchKernelGGL(k_finalize<false>, dim3(4, kShards), dim3(256), 0, s, nd, m, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_reorder(hipStream_t s, const TickDev &t)
+{
+    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, s, t);
     return hipGetLastError();
 }
 

@@ -196,8 +196,8 @@ class Engine:
     def sync(self):
         check(self._L.rm_sync(self._h))
 
-    def profile_enable(self, on=True):
-        check(self._L.rm_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, every_n=1):
+        check(self._L.rm_profile_enable(self._h, int(every_n)))
 
     def profile_read(self):
         n, ms = C.c_uint32(), C.c_double()
