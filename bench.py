@@ -125,42 +125,34 @@ def main():
     # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
     lo = (n * rank) // world
     hi = (n * (rank + 1)) // world
-    if world > 1:
-        eng.set_partition(lo, hi - lo)
 
     ticks = args.warmup + args.steps
     base_seed = 0xC0FFEE00 + idx
     sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(ticks)]
 
+    from radio_sim_amd import dist as D
     with torch.cuda.stream(stream):
         if world == 1:
             src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
             rec_dev = torch.empty(t_per_tick * 64, dtype=torch.uint8, device=dev)    # rm_tx_record[T]
-            slot = t_per_tick
+            sharded = None
         else:
             # every rank packs the frames whose source it owns into a fixed number of slots
-            # (padded with src = -1), then the ranks all-gather the slots
-            mine = [s[(s >= lo) & (s < hi)] for s in sources]
-            slot = max(max(len(s[(s >= (n * r) // world) & (s < (n * (r + 1)) // world)]) for r in range(world))
-                       for s in sources)
-            pad = np.full((ticks, slot), -1, dtype=np.int32)
-            for k, s in enumerate(mine):
-                pad[k, : len(s)] = s
+            # (padded with src = -1), then the ranks all-gather the slots over RCCL
+            slots = D.slots_needed(n, world, sources)
+            pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
             src_dev = torch.from_numpy(pad).to(dev)
-            mine_dev = torch.empty(slot * 64, dtype=torch.uint8, device=dev)
-            rec_dev = torch.empty(world * slot * 64, dtype=torch.uint8, device=dev)
+            sharded = D.ShardedTick(eng, dist, n, rank, world, slots, dev)
     stream.synchronize()
 
     def run_tick(k):
         t0 = k * W.TICK_US
         with torch.cuda.stream(stream):
-            if world == 1:
+            if sharded is None:
                 eng.pack_tx_device(src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US, rec_dev.data_ptr())
                 eng.tick_run_device(t0, t0 + W.TICK_US, rec_dev.data_ptr(), t_per_tick)
             else:
-                eng.pack_tx_device(src_dev[k].data_ptr(), slot, t0, W.AIR_US, mine_dev.data_ptr())
-                dist.all_gather_into_tensor(rec_dev, mine_dev)
-                eng.tick_run_device(t0, t0 + W.TICK_US, rec_dev.data_ptr(), world * slot)
+                sharded.run(src_dev[k].data_ptr(), t0, t0 + W.TICK_US, W.AIR_US)
 
     def fence():
         stream.synchronize()

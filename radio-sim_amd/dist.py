@@ -1,0 +1,111 @@
+"""Receiver-sharded multi-GPU tick: one process per GPU, receivers range-partitioned by node
+index, one RCCL all-gather of the tick's Tx records over xGMI.
+
+Every rank owns the nodes [lo, hi): their receiver state lives in its HBM (sorted, boxed), and it
+is the rank that learns about their transmissions (the emulators of those nodes are attached to
+its host process).  Per tick each rank packs the frames of ITS transmitters into a fixed number of
+64-byte slots (padding slots carry src = -1), the ranks all-gather the slots, and every rank then
+sweeps the full on-air list against its own receivers.  Because the partition is by index range
+and each rank's frames are in node order, the gathered list is in canonical (node index) order;
+the heard links of rank r for packet p are exactly the [lo_r, hi_r) slice of the global list.
+
+Only plumbing here (torch.distributed tensors, numpy); the compute is Engine.tick_run_device.
+"""
+import numpy as np
+
+from ._lib import TX_RECORD_DTYPE
+
+RECORD_BYTES = TX_RECORD_DTYPE.itemsize  # 64
+
+
+def partition(n, rank, world):
+    """Receiver / source range [lo, hi) owned by `rank`."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def owner_of(n, world, node):
+    """Rank owning `node` under partition()."""
+    edges = np.array([(n * r) // world for r in range(world + 1)], dtype=np.int64)
+    return np.searchsorted(edges, np.asarray(node, dtype=np.int64), side="right") - 1
+
+
+def slots_needed(n, world, source_lists):
+    """Smallest slot count that fits every rank's share of every tick."""
+    need = 1
+    for s in source_lists:
+        if len(s):
+            need = max(need, int(np.bincount(owner_of(n, world, s), minlength=world).max()))
+    return need
+
+
+def pad_sources(local_sources, slots):
+    out = np.full(slots, -1, dtype=np.int32)
+    out[: len(local_sources)] = local_sources
+    return out
+
+
+def pad_records(local_records, slots):
+    """Host-side variant of the device packing: fixed slot count, src = -1 marks padding."""
+    out = np.zeros(slots, dtype=TX_RECORD_DTYPE)
+    out["src"] = -1
+    out[: len(local_records)] = local_records
+    return out
+
+
+def all_gather_records(dist, local, world, out=None):
+    """All-gather one rank's slot buffer (torch uint8 tensor of slots*64 bytes).
+
+    NCCL/RCCL: one all_gather_into_tensor on the current stream.  gloo (CPU tests): list form."""
+    import torch
+    if out is None:
+        out = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local)
+    else:
+        parts = list(out.view(world, local.numel()).unbind(0))
+        dist.all_gather(parts, local)
+    return out
+
+
+def records_from_bytes(buf):
+    """uint8 tensor / array -> structured rm_tx_record array (CPU)."""
+    a = buf.cpu().numpy() if hasattr(buf, "cpu") else np.asarray(buf)
+    return a.view(TX_RECORD_DTYPE)
+
+
+def drop_padding(records):
+    """(valid records, gathered-slot index of each valid record)."""
+    idx = np.nonzero(records["src"] >= 0)[0]
+    return records[idx], idx
+
+
+def merge_shard_links(shards, n_slots):
+    """Global packet-major heard-link list from the per-rank lists.
+
+    shards: per rank (pkt, dst, verdict, rssi, sinr) with pkt = gathered slot index; ranks in order.
+    Rank r's links of a packet all have dst in [lo_r, hi_r), so concatenating the ranks' segments
+    per packet in rank order yields ascending receiver order."""
+    pkt = np.concatenate([s[0] for s in shards])
+    rank_of = np.concatenate([np.full(len(s[0]), r, dtype=np.int64) for r, s in enumerate(shards)])
+    order = np.lexsort((np.concatenate([s[1] for s in shards]), rank_of, pkt))
+    cols = [np.concatenate([s[i] for s in shards])[order] for i in range(len(shards[0]))]
+    assert cols[0].max(initial=-1) < n_slots
+    return cols
+
+
+class ShardedTick:
+    """Device-resident multi-GPU tick driver used by bench.py (one instance per rank)."""
+
+    def __init__(self, engine, dist, n, rank, world, slots, device):
+        import torch
+        self.eng, self.dist, self.n, self.rank, self.world, self.slots = engine, dist, n, rank, world, slots
+        self.lo, self.hi = partition(n, rank, world)
+        engine.set_partition(self.lo, self.hi - self.lo)
+        self.mine = torch.empty(slots * RECORD_BYTES, dtype=torch.uint8, device=device)
+        self.all = torch.empty(world * slots * RECORD_BYTES, dtype=torch.uint8, device=device)
+
+    def run(self, dev_src_ptr, t_begin, t_end, air_us):
+        """dev_src_ptr: device int32[slots] with this rank's transmitters (-1 padded)."""
+        self.eng.pack_tx_device(dev_src_ptr, self.slots, t_begin, air_us, self.mine.data_ptr())
+        all_gather_records(self.dist, self.mine, self.world, self.all)
+        self.eng.tick_run_device(t_begin, t_end, self.all.data_ptr(), self.world * self.slots)

@@ -1,0 +1,113 @@
+"""World-size-2 gloo test of the multi-GPU exchange path on CPU: packing into slots, the
+all-gather of Tx records, canonical order, partition arithmetic and the merge of per-rank link
+lists.  The per-rank sweep itself is the GPU engine's job; here the oracle stands in for it
+(restricted to the rank's receivers), which is what lets the merged result be checked against the
+global oracle run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, seed, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as dist
+    import radio_sim_amd as rsa
+    from radio_sim_amd import dist as D
+    from oracle import oracle as O
+    from util import to_tx_records
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(seed)                 # same layout on every rank
+        nd = O.NodeTable(n)
+        side = 50.0 * np.sqrt(np.pi * n / 20.0)
+        nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+        lists = [np.sort(rng.choice(n, 30, replace=False)).astype(np.int32) for _ in range(3)]
+        lists.append(np.array([n - 1], dtype=np.int32))   # only the last rank transmits
+        lists.append(np.zeros(0, dtype=np.int32))         # silent tick
+        slots = D.slots_needed(n, world, lists)
+        lo, hi = D.partition(n, rank, world)
+        mdl = O.model(O.MODEL_LOGDIST, ld_sigma_db=4.0, ld_seed=3)
+        out = []
+        for k, srcs in enumerate(lists):
+            mine = srcs[(srcs >= lo) & (srcs < hi)]
+            assert np.all(D.owner_of(n, world, mine) == rank)
+            local = D.pad_records(to_tx_records(rsa, nd.packets(mine, k * 1000, 8128)), slots)
+            buf = torch.from_numpy(local.view(np.uint8).copy())
+            gathered = D.records_from_bytes(D.all_gather_records(dist, buf, world))
+            assert len(gathered) == world * slots
+            valid, slot_idx = D.drop_padding(gathered)
+            # canonical order: the gathered frames are the global list, ascending node index
+            assert np.array_equal(valid["src"], srcs)
+            # this rank's sweep: gathered frames against its receivers [lo, hi)
+            pk = np.zeros(len(valid), dtype=O.PACKET_DTYPE)
+            for f in ("src", "channel", "x", "y", "z", "txpower", "txprob", "start_us", "air_us"):
+                pk[f] = valid[f]
+            r = O.tick(mdl, nd, pk)
+            keep = (r.dst >= lo) & (r.dst < hi)
+            out.append((slot_idx[r.pkt[keep]], r.dst[keep], r.verdict[keep], r.rssi[keep], r.sinr[keep]))
+        gathered_out = [None] * world
+        dist.all_gather_object(gathered_out, out)
+        if rank == 0:
+            ok = True
+            for k, srcs in enumerate(lists):
+                merged = D.merge_shard_links([gathered_out[r][k] for r in range(world)], world * slots)
+                ref = O.tick(mdl, nd, nd.packets(srcs, k * 1000, 8128))
+                # map gathered slot index back to the position in the global list
+                slot_of = {}
+                for r in range(world):
+                    rl, rh = D.partition(n, r, world)
+                    for j, s in enumerate(srcs[(srcs >= rl) & (srcs < rh)]):
+                        slot_of[r * slots + j] = int(np.searchsorted(srcs, s))
+                pkt = np.array([slot_of[int(p)] for p in merged[0]], dtype=np.int32)
+                ok &= (len(pkt) == ref.count and np.array_equal(pkt, ref.pkt) and np.array_equal(merged[1], ref.dst)
+                       and np.array_equal(merged[2], ref.verdict) and np.array_equal(merged[3], ref.rssi))
+            q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_exchange_and_merge():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 700, 11, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
+
+
+def test_partition_arithmetic(rsa):
+    from radio_sim_amd import dist as D
+    for n in (1, 7, 64, 1000, 100000):
+        for world in (1, 2, 3, 8):
+            edges = [D.partition(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            nodes = np.arange(n)
+            own = D.owner_of(n, world, nodes)
+            for r, (lo, hi) in enumerate(edges):
+                assert np.all(own[lo:hi] == r)
+    s = [np.array([0, 1, 2, 900]), np.array([999])]
+    assert D.slots_needed(1000, 2, s) == 3
+    assert list(D.pad_sources(np.array([4, 5]), 4)) == [4, 5, -1, -1]

@@ -1,0 +1,161 @@
+"""Parity of the extension medium (log-distance path loss, log-normal shadowing, co-channel SINR
+capture, multi-tick overlap -- DESIGN.md "Extension spec") with the CPU oracle's independent
+implementation of the same text.  Verdicts / heard sets bit-exact; rssi and sinr are compared
+bit-exactly as well (tolerance of the north star: 1e-5 relative)."""
+import numpy as np
+import pytest
+
+from util import (run_both, assert_same, random_nodes, to_tx_records, configure_engine, oracle_model)
+
+pytestmark = pytest.mark.gpu
+
+
+def _layout(O, n, seed, z=0.0, k=20.0):
+    side = 50.0 * np.sqrt(np.pi * n / k)
+    return random_nodes(O, n, side, seed=seed, z_span=z)
+
+
+@pytest.mark.parametrize("params", [
+    {},
+    {"ld_exponent": 2.0, "ld_pl0_db": 46.7, "ld_sensitivity_dbm": -90.0},
+    {"ld_exponent": 3.5, "ld_d0": 2.5},
+    {"ld_sigma_db": 4.0, "ld_seed": 12345},
+    {"ld_sigma_db": 8.0, "ld_seed": 7, "ld_clip": 2.0, "ld_exponent": 2.7},
+])
+def test_logdist_models(engine, rsa, O, params):
+    n, t = 4000, 150
+    nd = _layout(O, n, seed=31, z=10.0)
+    rng = np.random.default_rng(3)
+    nd.txpower[:] = rng.choice([0.0, -3.0, -7.0, 3.0], n)
+    nd.channel[rng.random(n) < 0.1] = 25
+    nd.enabled[rng.random(n) < 0.03] = 0
+    src = np.sort(rng.choice(n, t, replace=False))
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", params, nd.packets(src, 0, 8128))
+    assert cpu.count > 1000
+    assert_same(gpu, cpu, "logdist %s" % params)
+    assert np.all(gpu.rssi >= params.get("ld_sensitivity_dbm", -95.0))
+
+
+def test_logdist_tx_power_override_and_probabilities(engine, rsa, O):
+    n = 3000
+    nd = _layout(O, n, seed=5)
+    rng = np.random.default_rng(9)
+    nd.rxprob[:] = np.where(rng.random(n) < 0.6, 1.0, rng.uniform(0, 1, n))
+    nd.rxprob[::50] = 0.0
+    nd.txprob[:] = np.where(rng.random(n) < 0.7, 1.0, rng.uniform(0, 1, n))
+    src = np.sort(rng.choice(n, 80, replace=False))
+    pk = nd.packets(src, 0, 8128)
+    pk["txpower"] = rng.uniform(-20, 10, len(pk))     # "rf-power" override per packet
+    pk["txpower"][3] = -200.0                          # nobody can hear this one
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", {"ld_sigma_db": 3.0, "ld_seed": 1}, pk, seed=99)
+    assert cpu.pkt_draws.sum() > 100
+    assert_same(gpu, cpu, "logdist stochastic")
+    assert engine.rng_state == cpu.rng_state
+
+
+def test_shadowing_is_symmetric_and_seeded(engine, rsa, O):
+    nd = _layout(O, 600, seed=8)
+    p = {"ld_sigma_db": 6.0, "ld_seed": 42}
+    configure_engine(engine, nd, "logdist", p)
+    a = engine.tick(to_tx_records(rsa, nd.packets([10])))
+    b = engine.tick(to_tx_records(rsa, nd.packets(a.dst[:5])))
+    # link (10 -> j) and (j -> 10) see the same shadowing deviate (equal tx power): equal rssi
+    for q, j in enumerate(a.dst[:5]):
+        back = b.rssi[(b.pkt == q) & (b.dst == 10)]
+        assert len(back) == 1 and back[0] == a.rssi[q]
+    configure_engine(engine, nd, "logdist", {"ld_sigma_db": 6.0, "ld_seed": 43})
+    c = engine.tick(to_tx_records(rsa, nd.packets([10])))
+    assert not (len(c.rssi) == len(a.rssi) and np.array_equal(c.rssi, a.rssi))
+
+
+def _sinr_params(**kw):
+    p = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 77}
+    p.update(kw)
+    return p
+
+
+def test_sinr_single_tick_16_channels(engine, rsa, O):
+    n, t = 3000, 400          # dense traffic: many co-channel collisions
+    nd = _layout(O, n, seed=21)
+    rng = np.random.default_rng(4)
+    nd.channel[:] = 11 + rng.integers(0, 16, n)
+    src = np.sort(rng.choice(n, t, replace=False))
+    pk = nd.packets(src, 0, 8128)
+    pk["start_us"] = rng.integers(0, 1000, t)
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", _sinr_params(), pk)
+    assert cpu.count > 500
+    assert (cpu.verdict == O.INTERFERED).sum() > 20 and (cpu.verdict == O.DELIVERED).sum() > 20
+    assert_same(gpu, cpu, "sinr 16ch")
+
+
+def test_sinr_single_channel_heavy_interference(engine, rsa, O):
+    n, t = 2000, 300
+    nd = _layout(O, n, seed=22)
+    rng = np.random.default_rng(5)
+    src = np.sort(rng.choice(n, t, replace=False))
+    pk = nd.packets(src, 0, 4000)
+    pk["start_us"] = rng.integers(0, 3000, t)
+    pk["air_us"] = rng.choice([320, 1280, 4064, 8128], t)       # short frames may not overlap
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", _sinr_params(ld_sigma_db=0.0, ld_capture_db=6.0), pk)
+    assert (cpu.verdict == O.INTERFERED).sum() > 100
+    assert_same(gpu, cpu, "sinr 1ch")
+
+
+def test_sinr_multi_tick_overlap_and_half_duplex(engine, rsa, O):
+    """Frames stay on the air over several ticks (8128 us frames, 1000 us ticks)."""
+    n = 2500
+    nd = _layout(O, n, seed=23)
+    rng = np.random.default_rng(6)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    total_interfered = 0
+    for tick in range(12):
+        t0 = tick * 1000
+        onair = onair[onair["start_us"] + onair["air_us"] > t0]            # rm_tick_begin pruning rule
+        src = np.sort(rng.choice(n, 40, replace=False))
+        if tick == 3:
+            src[0] = int(onair["src"][0])                                    # a node transmits again while on air
+            src = np.sort(src)
+        new = nd.packets(src, 0, 0)
+        new["start_us"] = t0 + rng.integers(0, 1000, len(new))
+        new["air_us"] = rng.choice([320, 2048, 8128], len(new))
+        active = np.concatenate([onair, new])
+        cpu = O.tick(mdl, nd, active, first_new=len(onair))
+        engine.tick_begin(t0, t0 + 1000)
+        engine.enqueue_records(to_tx_records(rsa, new))
+        gpu = engine.tick_flush()
+        assert_same(gpu, cpu, "overlap tick %d" % tick)
+        total_interfered += int((cpu.verdict == O.INTERFERED).sum())
+        onair = active
+    assert total_interfered > 50
+
+
+def test_sinr_receiver_is_transmitting(engine, rsa, O):
+    """Half duplex: a node that is itself on the air cannot receive an overlapping frame."""
+    nd = O.NodeTable(3)
+    nd.x[:] = [0.0, 20.0, 40.0]
+    params = {"ld_flags": 1}
+    pk = nd.packets([0, 1], 0, 1000)
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", params, pk)
+    assert_same(gpu, cpu, "half duplex")
+    # node 1 hears node 0 but transmits itself -> interfered; node 2 hears both -> collision
+    v = {(p, d): x for p, d, x in zip(gpu.pkt, gpu.dst, gpu.verdict)}
+    assert v[(0, 1)] == rsa.INTERFERED and v[(1, 0)] == rsa.INTERFERED
+    pk2 = nd.packets([0, 1], 0, 1000)
+    pk2["start_us"] = [0, 5000]                                                # no time overlap
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", params, pk2)
+    assert_same(gpu, cpu, "no overlap")
+    assert set(gpu.verdict.tolist()) == {rsa.DELIVERED}
+    assert np.all(gpu.sinr > 10.0) and np.all(gpu.sinr == gpu.rssi - (-100.0))
+
+
+def test_logdist_far_origin(engine, rsa, O):
+    nd = _layout(O, 1500, seed=3)
+    nd.x += 8.0e8
+    nd.y += 8.0e8
+    src = np.arange(0, 1500, 30)
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", {"ld_sigma_db": 4.0, "ld_seed": 5}, nd.packets(src))
+    assert cpu.count > 500
+    assert_same(gpu, cpu, "logdist far origin")
