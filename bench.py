@@ -27,7 +27,6 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3    # vector fp32
 S_NODE, S_TX, S_REC = 37, 56, 25   # algorithmic bytes: SURVEY.md section 8(d)
 
 WORKLOADS = {
@@ -35,6 +34,8 @@ WORKLOADS = {
     "c2": (2, 10_000, 0.01, "logdist", "10k nodes, 1% concurrent-Tx, log-distance path loss"),
     "c3": (3, 100_000, 0.01, "logdist_shadow", "100k nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
     "udgm": (3, 100_000, 0.01, "udgm", "100k nodes, 1% concurrent-Tx, reference UDGM (unit disc)"),
+    "m1": (5, 1_000_000, 0.001, "logdist_shadow", "1M nodes, 0.1% concurrent-Tx, log-distance + log-normal shadowing"),
+    "m1x": (5, 1_000_000, 0.01, "logdist_shadow", "1M nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
 }
 
 
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-ticks", type=float, default=2.0)
+    ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
     ap.add_argument("--profile-every", type=int, default=16,
                     help="HIP-event sample of the dominant kernel every n-th tick of the timed region")
     return ap.parse_args()
@@ -170,7 +171,7 @@ def main():
         run_tick(k)
     fence()
     elapsed = time.perf_counter() - t_start
-    n_launch, kern_ms = eng.profile_read()
+    n_samples, stage_ms = eng.profile_read()
     eng.profile_enable(0)
     heard, dropped = eng.result_count()
     if dropped:
@@ -190,14 +191,28 @@ def main():
     value = links_per_tick * args.steps / elapsed
 
     if rank == 0:
-        # roofline of the dominant kernel (k_allpairs) on this rank, SURVEY.md section 8(d):
-        # algorithmic bytes per launch = N_loc*37 + T_act*56 + H_loc*25
+        # Roofline of the dominant kernel on this rank.  Per-stage durations
+        # come from HIP events recorded on the engine's stream around every stage of each
+        # `profile_every`-th tick of the timed region; the dominant kernel is the stage with the
+        # largest share.  Algorithmic bytes per launch = N_loc*37 + T_act*56 + H_loc*25.
         n_loc = hi - lo
         h_loc = heard
         b_tick = n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC
-        kern_avg_s = (kern_ms / max(1, n_launch)) * 1e-3
+        per_stage_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
+        dominant = max(per_stage_us, key=per_stage_us.get) if per_stage_us else "k_filter"
+        kern_avg_s = per_stage_us.get(dominant, 0.0) * 1e-6
+        pass_s = sum(per_stage_us.values()) * 1e-6
         achieved = b_tick / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
-        links_rank = t_per_tick * n_loc
+        traffic = None
+        pmc_note = "no PMC pass on file for this workload"
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = pmc.get(args.workload, {}).get(dominant)
+            if ent and world == 1:
+                traffic = ent["hbm_bytes_per_launch"]
+                pmc_note = ent["source"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "Tx->Rx link evaluations/sec",
             "value": value,
@@ -215,16 +230,16 @@ def main():
                        "air_us": W.AIR_US, "model": model, "heard_links_last_tick": heard_total,
                        "sharding": "receivers range-partitioned, RCCL all-gather of Tx records" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_allpairs", "kernel_avg_us": kern_avg_s * 1e6, "launches": n_launch,
-                         "algorithmic_bytes_per_launch": b_tick,
-                         "note": "brute-force all-pairs is VALU-bound by construction (SURVEY.md 8d); see valu"},
-            "valu": {"links_per_s_kernel": links_rank / kern_avg_s if kern_avg_s > 0 else 0.0,
-                     "fp32_ops_per_link": 8,
-                     "achieved_tflops": 8 * links_rank / kern_avg_s / 1e12 if kern_avg_s > 0 else 0.0,
-                     "peak_tflops": FP32_PEAK_TFLOPS},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
+                         "algorithmic_bytes_per_launch": b_tick, "traffic_source": pmc_note,
+                         "stages_avg_us": per_stage_us,
+                         "whole_pass": {"gpu_us": pass_s * 1e6,
+                                        "achieved": b_tick / pass_s / 1e9 if pass_s > 0 else 0.0,
+                                        "frac": (b_tick / pass_s / 1e9 / HBM_PEAK_GBS) if pass_s > 0 else 0.0},
+                         "note": "a tick of this size moves ~5 MB through 5 short dependent kernels: latency-bound, "
+                                 "not bandwidth-bound; see DESIGN.md section 5 and profiles/README.md"},
         }
-        out["valu"]["frac"] = out["valu"]["achieved_tflops"] / FP32_PEAK_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
             st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
             out["cpu_baseline"] = st

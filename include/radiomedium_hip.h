@@ -178,11 +178,23 @@ int rm_result_device(rm_context *ctx, rm_device_result *out);
 int rm_result_count(rm_context *ctx, uint32_t *count, uint32_t *dropped); /* synchronises */
 int rm_sync(rm_context *ctx);
 
-/* timing of the dominant kernel on the context's stream: HIP events around its launch on every
- * `every_n`-th tick (0 = off; an event pair costs tens of microseconds of stream time on this
- * runtime, so dense sampling perturbs the throughput it measures) */
+/* Per-stage timing on the context's stream: on every `every_n`-th tick each stage of the launch
+ * sequence is bracketed by HIP events (0 = off; an event costs microseconds of stream time on
+ * this runtime, so dense sampling perturbs the throughput it measures).  rm_profile_read returns
+ * the number of sampled ticks and the summed milliseconds per stage. */
+enum rm_profile_stage {
+    RM_STAGE_FILTER = 0,  /* k_filter: all (frame, receiver) pairs, conservative */
+    RM_STAGE_EXACT = 1,   /* k_exact: the reference's fp64 arithmetic on the candidates */
+    RM_STAGE_SELF = 2,    /* k_self_entries (SINR) */
+    RM_STAGE_OFFSETS = 3, /* k_cell_off + k_slot_scan */
+    RM_STAGE_SINR = 4,    /* k_sinr */
+    RM_STAGE_SCATTER = 5, /* k_finalize */
+    RM_STAGE_REORDER = 6, /* k_reorder */
+    RM_STAGE_DRAWS = 7,   /* java.util.Random kernels */
+    RM_PROFILE_STAGES = 8
+};
 int rm_profile_enable(rm_context *ctx, int every_n);
-int rm_profile_read(rm_context *ctx, uint32_t *launches, double *total_ms);
+int rm_profile_read(rm_context *ctx, uint32_t *samples, double *stage_ms /* [RM_PROFILE_STAGES] */);
 /* number of Tx->Rx link evaluations resolved by the last tick ( T * (N_loc) minus self links ) */
 int64_t rm_last_link_evaluations(const rm_context *ctx);
 

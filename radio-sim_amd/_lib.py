@@ -111,7 +111,7 @@ SIGNATURES = {
     "rm_result_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rm_sync": (C.c_int, [C.c_void_p]),
     "rm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
+    "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
     "rm_last_link_evaluations": (C.c_int64, [C.c_void_p]),
     "rm_lcg_jump": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "rm_lcg_next_double": (C.c_double, [C.POINTER(C.c_uint64)]),

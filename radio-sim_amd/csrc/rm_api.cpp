@@ -167,10 +167,16 @@ struct rm_context {
     bool profile = false;   // sampling on
     int profile_every = 1;  // take an event-timed sample every n-th tick
     uint64_t tick_index = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // a sampled tick records one event before every stage and one after the last
+    struct Sample {
+        hipEvent_t ev[RM_PROFILE_STAGES + 1];
+        int stage[RM_PROFILE_STAGES];
+        int n = 0;
+    };
+    std::vector<Sample> ev_pool;
     size_t ev_used = 0;
-    uint32_t prof_launches = 0;
-    double prof_ms = 0;
+    uint32_t prof_samples = 0;
+    double prof_ms[RM_PROFILE_STAGES] = {0};
 };
 
 namespace {
@@ -547,36 +553,57 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         return RM_OK;
     }
     c->parity ^= 1; // k_filter zeroes the other parity for the next tick
-    // The launch sequence.  Launch-bound (a handful of short kernels per tick), so it is replayed
-    // from an instantiated hipGraph whenever the launch arguments repeat; with event profiling on,
-    // the dominant kernel is launched eagerly between two HIP events and only the rest is a graph.
-    auto tail = [&](bool with_filter) -> int {
-        if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
-        if (with_filter) RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
-        RM_HIP(rm::launch_exact(s, nd, m, t));
-        if (sinr) RM_HIP(rm::launch_self_entries(s, nd, t));
-        RM_HIP(rm::launch_offsets(s, t));
-        if (sinr) RM_HIP(rm::launch_sinr(s, m, t));
-        RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
-        if (cfg.sorted) RM_HIP(rm::launch_reorder(s, t));
-        if (stochastic) RM_HIP(rm::launch_draws(s, m, t));
-        return RM_OK;
-    };
+    // The launch sequence.  On a sampled tick (rm_profile_enable) every stage is bracketed by HIP
+    // events on the stream; otherwise the stages are launched back to back (or, with RM_GRAPH=1,
+    // replayed from an instantiated hipGraph keyed by the launch arguments).
     const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
-    const bool with_filter = !sample;
+    rm_context::Sample *smp = nullptr;
     if (sample) {
         if (c->ev_used == c->ev_pool.size()) {
-            hipEvent_t a, b;
-            RM_HIP(hipEventCreate(&a));
-            RM_HIP(hipEventCreate(&b));
-            c->ev_pool.emplace_back(a, b);
+            rm_context::Sample ns;
+            for (auto &e : ns.ev) RM_HIP(hipEventCreate(&e));
+            c->ev_pool.push_back(ns);
         }
-        RM_HIP(hipEventRecord(c->ev_pool[c->ev_used].first, s));
-        RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
-        RM_HIP(hipEventRecord(c->ev_pool[c->ev_used].second, s));
-        c->ev_used++;
+        smp = &c->ev_pool[c->ev_used++];
+        smp->n = 0;
     }
-    if (c->use_graphs) {
+    auto stage = [&](int id) -> int {
+        if (smp) {
+            RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+            smp->stage[smp->n++] = id;
+        }
+        return RM_OK;
+    };
+    auto sequence = [&]() -> int {
+        if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        RM_TRY(stage(RM_STAGE_FILTER));
+        RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
+        RM_TRY(stage(RM_STAGE_EXACT));
+        RM_HIP(rm::launch_exact(s, nd, m, t));
+        if (sinr) {
+            RM_TRY(stage(RM_STAGE_SELF));
+            RM_HIP(rm::launch_self_entries(s, nd, t));
+        }
+        RM_TRY(stage(RM_STAGE_OFFSETS));
+        RM_HIP(rm::launch_offsets(s, t));
+        if (sinr) {
+            RM_TRY(stage(RM_STAGE_SINR));
+            RM_HIP(rm::launch_sinr(s, m, t));
+        }
+        RM_TRY(stage(RM_STAGE_SCATTER));
+        RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
+        if (cfg.sorted) {
+            RM_TRY(stage(RM_STAGE_REORDER));
+            RM_HIP(rm::launch_reorder(s, t));
+        }
+        if (stochastic) {
+            RM_TRY(stage(RM_STAGE_DRAWS));
+            RM_HIP(rm::launch_draws(s, m, t));
+        }
+        if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+        return RM_OK;
+    };
+    if (c->use_graphs && !sample) {
         uint64_t key = 1469598103934665603ull;
         auto mix = [&](const void *p, size_t n) {
             const unsigned char *b = static_cast<const unsigned char *>(p);
@@ -585,7 +612,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         mix(&nd, sizeof(nd));
         mix(&m, sizeof(m));
         mix(&t, sizeof(t));
-        const int bits[6] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, with_filter};
+        const int bits[5] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr};
         mix(bits, sizeof(bits));
         hipGraphExec_t exec = nullptr;
         for (auto &g : c->graphs)
@@ -595,7 +622,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
             }
         if (!exec) {
             RM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = tail(with_filter);
+            const int rc = sequence();
             hipGraph_t graph = nullptr;
             const hipError_t e_end = hipStreamEndCapture(s, &graph);
             if (rc != RM_OK) {
@@ -617,7 +644,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         }
         RM_HIP(hipGraphLaunch(exec, s));
     } else {
-        RM_TRY(tail(with_filter));
+        RM_TRY(sequence());
     }
 
     // links resolved: every evaluated frame against every other node (T * (N-1)); for a receiver
@@ -630,11 +657,14 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
 int drain_profile(rm_context *c)
 {
     for (size_t i = 0; i < c->ev_used; ++i) {
-        float ms = 0;
-        RM_HIP(hipEventSynchronize(c->ev_pool[i].second));
-        RM_HIP(hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
-        c->prof_ms += ms;
-        c->prof_launches++;
+        rm_context::Sample &sm = c->ev_pool[i];
+        RM_HIP(hipEventSynchronize(sm.ev[sm.n]));
+        for (int k = 0; k < sm.n; ++k) {
+            float ms = 0;
+            RM_HIP(hipEventElapsedTime(&ms, sm.ev[k], sm.ev[k + 1]));
+            c->prof_ms[sm.stage[k]] += ms;
+        }
+        c->prof_samples++;
     }
     c->ev_used = 0;
     return RM_OK;
@@ -717,10 +747,8 @@ void rm_destroy(rm_context *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (auto &p : c->ev_pool) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
-    }
+    for (auto &sm : c->ev_pool)
+        for (auto &e : sm.ev) (void)hipEventDestroy(e);
     c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release();
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
@@ -1123,18 +1151,19 @@ int rm_profile_enable(rm_context *c, int enable)
     c->profile = enable != 0;
     c->profile_every = enable > 0 ? enable : 1;
     c->tick_index = 0;
-    c->prof_launches = 0;
-    c->prof_ms = 0;
+    c->prof_samples = 0;
+    for (double &v : c->prof_ms) v = 0;
     return RM_OK;
 }
 
-int rm_profile_read(rm_context *c, uint32_t *launches, double *total_ms)
+int rm_profile_read(rm_context *c, uint32_t *samples, double *stage_ms)
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     RM_HIP(hipSetDevice(c->device));
     RM_TRY(drain_profile(c));
-    if (launches) *launches = c->prof_launches;
-    if (total_ms) *total_ms = c->prof_ms;
+    if (samples) *samples = c->prof_samples;
+    if (stage_ms)
+        for (int k = 0; k < RM_PROFILE_STAGES; ++k) stage_ms[k] = c->prof_ms[k];
     return RM_OK;
 }
 

@@ -199,10 +199,15 @@ class Engine:
     def profile_enable(self, every_n=1):
         check(self._L.rm_profile_enable(self._h, int(every_n)))
 
+    STAGES = ("k_filter", "k_exact", "k_self_entries", "k_cell_off+k_slot_scan", "k_sinr", "k_finalize",
+              "k_reorder", "draw kernels")
+
     def profile_read(self):
-        n, ms = C.c_uint32(), C.c_double()
-        check(self._L.rm_profile_read(self._h, C.byref(n), C.byref(ms)))
-        return n.value, ms.value
+        """-> (sampled ticks, {stage name: summed milliseconds})"""
+        n = C.c_uint32()
+        ms = (C.c_double * 8)()
+        check(self._L.rm_profile_read(self._h, C.byref(n), ms))
+        return n.value, {name: ms[i] for i, name in enumerate(self.STAGES)}
 
     def last_link_evaluations(self):
         return self._L.rm_last_link_evaluations(self._h)
