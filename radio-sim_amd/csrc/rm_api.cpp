@@ -108,6 +108,8 @@ struct rm_context {
     DevBuf<float2> d_bbox_z;
     DevBuf<double> d_n2n;
     int n2n_m = 0;
+    DevBuf<uint32_t> d_shadow_tbl;
+    bool shadow_tbl_valid = false;
     int n_rx = 0;            // receivers in the table
     bool rx_sorted = false;  // engine order != node-index order
 
@@ -133,11 +135,14 @@ struct rm_context {
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
     DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
     DevBuf<uint32_t> d_shards;   // two parities x kShards x kShardStride append counters
-    DevBuf<uint32_t> d_cursor;
+    DevBuf<uint32_t> d_cursor, d_cand_tot, d_seg_off;
+    DevBuf<int32_t> d_a_e;
+    int zero_len = 0;        // slots of cursor / cand_tot that may be non-zero
     int parity = 0;
     DevBuf<int32_t> d_st_pkt, d_st_dst, d_st_next, d_head;
     DevBuf<uint32_t> d_st_blk;
-    DevBuf<double> d_st_aux, d_st_lin, d_st_sinr;
+    DevBuf<double> d_st_aux, d_st_lin, d_st_sinr, d_st_prob;
+    DevBuf<int32_t> d_st_orig;
     DevBuf<uint8_t> d_st_flags, d_st_coll;
     DevBuf<int32_t> d_out_pkt, d_out_dst, d_a_pkt, d_a_dst;
     DevBuf<uint8_t> d_out_verdict, d_pkt_interf, d_a_verdict;
@@ -268,6 +273,7 @@ rm::ModelDev model_dev(const rm_context *c)
     m.coord_bound = c->coord_bound;
     m.f32_slack = c->f32_slack;
     m.geo_cut = -1.0;
+    m.shadow_tbl = c->shadow_tbl_valid ? c->d_shadow_tbl.p : nullptr;
     if (p.kind == RM_MODEL_UDGM) {
         const double r = std::fabs(p.udgm_transmission_range);
         m.geo_cut = (r == 0.0) ? -1.0 : r * (1.0 + 1e-9); // ratio > 1.0 -> unheard, d == range is in
@@ -399,6 +405,8 @@ int ensure_link_buffers(rm_context *c)
     RM_HIP(c->d_st_next.ensure(cap));
     RM_HIP(c->d_st_blk.ensure(cap));
     RM_HIP(c->d_st_aux.ensure(cap));
+    RM_HIP(c->d_st_prob.ensure(cap));
+    RM_HIP(c->d_st_orig.ensure(cap));
     RM_HIP(c->d_st_lin.ensure(cap));
     RM_HIP(c->d_st_sinr.ensure(cap));
     RM_HIP(c->d_st_flags.ensure(cap));
@@ -415,9 +423,38 @@ int ensure_link_buffers(rm_context *c)
     RM_HIP(c->d_a_rssi.ensure(cap));
     RM_HIP(c->d_a_sinr.ensure(cap));
     RM_HIP(c->d_a_prob.ensure(cap));
+    RM_HIP(c->d_a_e.ensure(cap));
     RM_HIP(c->d_draw_scan.ensure(cap + 1));
     RM_HIP(c->d_scan_block.ensure(cap / 2048 + 2));
     c->alloc_cap = c->cap;
+    return RM_OK;
+}
+
+// Second-level filter of the shadowed log-distance medium: for a link at rho = d^2/cut^2 the
+// deviate may be at most x(rho) = (5 n log10(1/rho) - sigma*clip)/sigma for the link to reach the
+// candidate level, i.e. the hash's uniform at most Phi(x).  One conservative 32-bit threshold per
+// bin (lower bin edge, rho padded by kShadowPad, x padded for the quantile approximation).
+int build_shadow_table(rm_context *c)
+{
+    const rm_model_params &p = c->params;
+    c->shadow_tbl_valid = false;
+    if (p.kind != RM_MODEL_LOGDIST || !(p.ld_sigma_db > 0.0) || !(p.ld_exponent > 0.0)) return RM_OK;
+    std::vector<uint32_t> tbl(rm::kShadowBins);
+    for (int b = 0; b < rm::kShadowBins; ++b) {
+        const double rho = (double(b) / rm::kShadowBins) * (1.0 - rm::kShadowPad);
+        double umax = 1.0;
+        if (rho > 0.0) {
+            const double margin = 5.0 * p.ld_exponent * std::log10(1.0 / rho) - p.ld_sigma_db * p.ld_clip;
+            const double x = margin / p.ld_sigma_db + 1e-6;
+            if (x < p.ld_clip) umax = 0.5 * std::erfc(-x / std::sqrt(2.0));
+        }
+        const double v = std::floor(umax * 4294967296.0) + 2.0;
+        tbl[b] = v >= 4294967295.0 ? 0xFFFFFFFFu : uint32_t(v);
+    }
+    RM_HIP(c->d_shadow_tbl.ensure(rm::kShadowBins));
+    RM_HIP(hipMemcpyAsync(c->d_shadow_tbl.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    c->shadow_tbl_valid = true;
     return RM_OK;
 }
 
@@ -472,7 +509,19 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         RM_HIP(c->d_off.ensure(std::max<size_t>(cells, 1)));
     }
     RM_HIP(c->d_slot_tot.ensure(size_t(std::max(t.n_cnt, 0)) + 1));
-    RM_HIP(c->d_cursor.ensure(size_t(std::max(t.n_cnt, 0)) + 1));
+    {
+        // per-frame counters that kernels add to: zero-filled when (re)allocated, then kept zero by
+        // k_filter (cursor: same tick; candidate totals: the other parity for the next tick)
+        const size_t need = size_t(std::max(t.n_cnt, 0)) + 1;
+        if (need > c->d_cursor.n || 2 * need > c->d_cand_tot.n) {
+            RM_HIP(c->d_cursor.ensure(need * 2));
+            RM_HIP(c->d_cand_tot.ensure(need * 4));
+            RM_HIP(hipMemsetAsync(c->d_cursor.p, 0, c->d_cursor.n * 4, c->stream));
+            RM_HIP(hipMemsetAsync(c->d_cand_tot.p, 0, c->d_cand_tot.n * 4, c->stream));
+            c->zero_len = 0;
+        }
+        RM_HIP(c->d_seg_off.ensure(need + 1));
+    }
     RM_HIP(c->d_slot_off.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
     RM_HIP(c->d_pkt_interf.ensure(std::max(n_new, 1)));
     RM_HIP(c->d_pkt_rng.ensure(std::max(n_new, 1)));
@@ -491,6 +540,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
     cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
     cfg.sorted = c->rx_sorted;
     cfg.bbox = c->rx_sorted && !cfg.f64_filter;
+    cfg.shadow = c->shadow_tbl_valid && !cfg.f64_filter && std::getenv("RM_NO_SHADOW_TABLE") == nullptr;
 
     t.cnt = c->d_cnt.p;
     t.off = c->d_off.p;
@@ -505,10 +555,21 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
     t.seg_cap = (c->cap + rm::kShards - 1) / rm::kShards;
     t.use_matrix = cfg.sorted ? 0 : 1;
     t.cursor = c->d_cursor.p;
+    {
+        const size_t half = c->d_cand_tot.n / 2;
+        t.cand_tot = c->d_cand_tot.p + size_t(c->parity) * half;
+        t.cand_tot_next = c->d_cand_tot.p + size_t(c->parity ^ 1) * half;
+    }
+    t.seg_off = c->d_seg_off.p;
+    c->zero_len = std::max(c->zero_len, std::max(t.n_cnt, 0));
+    t.zero_len = c->zero_len;
+    t.a_e = c->d_a_e.p;
     t.st_pkt = c->d_st_pkt.p;
     t.st_dst = c->d_st_dst.p;
     t.st_blk = c->d_st_blk.p;
     t.st_aux = c->d_st_aux.p;
+    t.st_prob = c->d_st_prob.p;
+    t.st_orig = c->d_st_orig.p;
     t.st_lin = c->d_st_lin.p;
     t.st_sinr = c->d_st_sinr.p;
     t.st_next = c->d_st_next.p;
@@ -579,22 +640,26 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         RM_TRY(stage(RM_STAGE_FILTER));
         RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
         RM_TRY(stage(RM_STAGE_EXACT));
-        RM_HIP(rm::launch_exact(s, nd, m, t));
+        RM_HIP(rm::launch_seg_scan(s, t));
+        RM_HIP(rm::launch_exact(s, nd, m, t, cfg));
         if (sinr) {
             RM_TRY(stage(RM_STAGE_SELF));
             RM_HIP(rm::launch_self_entries(s, nd, t));
         }
-        RM_TRY(stage(RM_STAGE_OFFSETS));
-        RM_HIP(rm::launch_offsets(s, t));
+        if (t.use_matrix || t.n_cnt > 8192) {
+            RM_TRY(stage(RM_STAGE_OFFSETS));
+            RM_HIP(rm::launch_offsets(s, t));
+        }
         if (sinr) {
             RM_TRY(stage(RM_STAGE_SINR));
             RM_HIP(rm::launch_sinr(s, m, t));
         }
-        RM_TRY(stage(RM_STAGE_SCATTER));
-        RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
         if (cfg.sorted) {
             RM_TRY(stage(RM_STAGE_REORDER));
-            RM_HIP(rm::launch_reorder(s, t));
+            RM_HIP(rm::launch_reorder(s, m, t, cfg));
+        } else {
+            RM_TRY(stage(RM_STAGE_SCATTER));
+            RM_HIP(rm::launch_finalize(s, nd, m, t, cfg));
         }
         if (stochastic) {
             RM_TRY(stage(RM_STAGE_DRAWS));
@@ -612,7 +677,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
         mix(&nd, sizeof(nd));
         mix(&m, sizeof(m));
         mix(&t, sizeof(t));
-        const int bits[5] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr};
+        const int bits[6] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, cfg.shadow};
         mix(bits, sizeof(bits));
         hipGraphExec_t exec = nullptr;
         for (auto &g : c->graphs)
@@ -753,10 +818,11 @@ void rm_destroy(rm_context *c)
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rxf.release(); c->d_bbox_xy.release();
-    c->d_bbox_z.release(); c->d_n2n.release(); c->d_tx.release();
-    c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_slot_off.release();
+    c->d_bbox_z.release(); c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_tx.release();
+    c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_cand_tot.release();
+    c->d_seg_off.release(); c->d_a_e.release(); c->d_slot_off.release();
     c->d_counters.release(); c->d_st_pkt.release(); c->d_st_dst.release(); c->d_st_next.release();
-    c->d_head.release(); c->d_st_blk.release(); c->d_st_aux.release(); c->d_st_lin.release();
+    c->d_head.release(); c->d_st_blk.release(); c->d_st_aux.release(); c->d_st_prob.release(); c->d_st_orig.release(); c->d_st_lin.release();
     c->d_st_sinr.release(); c->d_st_flags.release(); c->d_st_coll.release(); c->d_out_pkt.release();
     c->d_out_dst.release(); c->d_out_verdict.release(); c->d_pkt_interf.release(); c->d_out_rssi.release();
     c->d_out_sinr.release(); c->d_out_prob.release(); c->d_a_pkt.release(); c->d_a_dst.release();
@@ -808,6 +874,8 @@ int rm_set_model(rm_context *c, const rm_model_params *p)
     c->params = *p;
     if (was_geo != is_geometric(c)) c->rx_dirty = true;
     c->prefilter_dirty = true;
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(build_shadow_table(c));
     c->onair.clear();
     c->pending.clear();
     return RM_OK;

@@ -14,12 +14,15 @@ constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
 constexpr int kBlock = 64 * kWavesPerBlock;
 constexpr int kGroup = 64;          // receivers per bounding-box group (one per lane)
 constexpr int kShards = 256;        // append counters of the candidate list (one word sustains only ~88 atomics/us)
+constexpr int kShadowBins = 256;    // bins over rho = d^2 / cut^2 of the shadowing table
+constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
 constexpr int kShardStride = 32;    // u32 words between shard counters: one 128-byte line each
 
 // link-entry flags
 constexpr uint8_t kFlagHeardNew = 1;   // gets an output record
 constexpr uint8_t kFlagInterferer = 2; // rssi >= interference floor (SINR mode)
 constexpr uint8_t kFlagSelf = 4;       // receiver is the source of this on-air frame (half duplex)
+constexpr uint8_t kFlagTxDead = 8;     // the frame's txSuccess is <= 0: every heard link is interfered, no draw
 
 // model constants as the kernels need them
 struct ModelDev {
@@ -40,6 +43,7 @@ struct ModelDev {
     double coord_bound;         // max |coord - origin| the fp32 slack was computed for
     double f32_slack;           // Delta (metres) added to every cut-off distance
     double geo_cut;             // cut-off distance for UDGM / CONST (metres), <0 = nobody
+    const uint32_t *shadow_tbl; // [kShadowBins] second-level filter of the shadowed log-distance medium (or null)
 };
 
 // Node state resident in HBM.
@@ -87,11 +91,18 @@ struct TickDev {
     uint32_t seg_cap;       // candidate entries per shard (shard s owns [s*seg_cap, (s+1)*seg_cap))
     int use_matrix;         // 1: ordered scatter through the (frame, slab) cell matrix (unsorted table)
                             // 0: per-frame counts + cursor, order restored by k_reorder (sorted table)
-    uint32_t *cursor;       // [n_cnt] per-frame scatter cursor (use_matrix == 0)
+    uint32_t *cursor;       // [n_cnt] per-frame scatter cursor = heard links of the frame (use_matrix == 0)
+    uint32_t *cand_tot;     // [n_cnt] candidate links per frame, this tick's parity (use_matrix == 0)
+    uint32_t *cand_tot_next; // the other parity, zeroed by k_filter for the next tick
+    uint32_t *seg_off;      // [n_cnt + 1] exclusive scan of cand_tot: the frame's segment in the A records
+    int zero_len;           // slots of cursor / cand_tot_next that k_filter has to zero
+    int32_t *a_e;           // [..] link-entry index of an A record (SINR results are looked up through it)
     int32_t *st_pkt;        // eval-relative frame index
     int32_t *st_dst;        // receiver engine position
     uint32_t *st_blk;       // index of the first entry of this entry's (frame, slab) block
-    double *st_aux;         // probability (UDGM/N2N) or rssi (logdist)
+    double *st_aux;         // rssi as reported (packet txpower for the reference media)
+    double *st_prob;        // receive probability of the link
+    int32_t *st_orig;       // receiver node index
     double *st_lin;         // linear power (SINR)
     double *st_sinr;
     int32_t *st_next;       // per-receiver list (SINR)
@@ -119,6 +130,7 @@ struct LaunchCfg {
     bool stochastic;  // java.util.Random draws may be consumed
     bool sorted;      // receiver table is spatially sorted (needs the per-packet reorder pass)
     bool bbox;        // use the bounding-box variant of the filter kernel
+    bool shadow;      // second-level shadowing filter (table lookup on the link hash)
 };
 
 // kernels' host launchers (rm_kernels.hip)
@@ -127,13 +139,15 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
                           int64_t air_us, rm_tx_record *out);
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
-hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t);
+hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
+                        const LaunchCfg &cfg);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);
 hipError_t launch_offsets(hipStream_t s, const TickDev &t);
 hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t);
 hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                            const LaunchCfg &cfg);
-hipError_t launch_reorder(hipStream_t s, const TickDev &t);
+hipError_t launch_seg_scan(hipStream_t s, const TickDev &t);
+hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_draws(hipStream_t s, const ModelDev &m, const TickDev &t);
 
 // host-side mirrors of device math used for constants (rm_kernels.hip, __host__ __device__)

@@ -361,7 +361,8 @@ RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, dou
         } else if (!(m.ld_exp > 0.0)) {
             cut = inf;
         } else {
-            cut = m.ld_d0 * exp2(margin / (10.0 * m.ld_exp) * 3.3219280948873622) * (1.0 + 1e-6);
+            // hardware fp32 exp2 (relative error ~1e-6 at these arguments) with a 1e-4 pad
+            cut = m.ld_d0 * double(__builtin_amdgcn_exp2f(float(margin / (10.0 * m.ld_exp) * 3.3219280948873622))) * (1.0 + 1e-4);
             if (cut < m.ld_d0) cut = m.ld_d0;
         }
     } else {
@@ -459,13 +460,16 @@ RM_D RunInfo run_prefix(int key, bool pred, int lane)
 // test uses the very same expression (monotone in each |d|)
 RM_D float dist2_f32(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
 
-template <int RPT, bool F64, bool BBOX>
-__global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const ModelDev m, const TickDev t)
+template <int RPT, bool F64, bool BBOX, bool SHADOW>
+__global__ void __launch_bounds__(kBlock, F64 ? 2 : 8) k_filter(const NodesDev nd, const ModelDev m, const TickDev t)
 {
     __shared__ float4 s_txf[kTxChunk];
     __shared__ int s_ch[kTxChunk];
     __shared__ double s_td[F64 ? kTxChunk * 4 : 1];
     __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT]; // candidate ballots of the near frames
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
+    __shared__ float s_inv[SHADOW ? kTxChunk : 1]; // bins / thr of the frame (0: table not usable for it)
+    __shared__ int s_src[SHADOW ? kTxChunk : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -486,14 +490,17 @@ __global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const Mode
     // issued before the tile is staged so that both round trips overlap
     float fx[RPT], fy[RPT], fz[RPT];
     int fch[RPT];
+    int forig[RPT];
     double gx[RPT], gy[RPT], gz[RPT];
     float4 bxy[RPT];
+    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x]; // kBlock == kShadowBins
     float2 bz[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int j = jbase + r * kGroup + lane;
         fx[r] = fy[r] = fz[r] = __builtin_nanf("");
         fch[r] = 0;
+        forig[r] = 0;
         if (F64) gx[r] = gy[r] = gz[r] = u2f(0x7FF8000000000000ull);
         if (j < t.n_rx) {
             const float4 v = nd.rxf[j];
@@ -501,6 +508,7 @@ __global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const Mode
             fy[r] = v.y;
             fz[r] = v.z;
             fch[r] = __float_as_int(v.w);
+            if (SHADOW) forig[r] = nd.orig[j];
             if (F64 && v.x == v.x) {
                 gx[r] = nd.x[j];
                 gy[r] = nd.y[j];
@@ -521,17 +529,30 @@ __global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const Mode
         float4 f = make_float4(0.f, 0.f, 0.f, -1.f);
         double thr64 = -1.0;
         int ch = 0;
+        int src_id = -1;
         double px = 0, py = 0, pz = 0;
         if (int(threadIdx.x) < nt) {
             const rm_tx_record tx = t.tx[t.first_eval + e0 + threadIdx.x];
             tx_prefilter(m, tx, f, thr64);
             ch = tx.channel;
+            src_id = tx.src;
             px = tx.x;
             py = tx.y;
             pz = tx.z;
         }
         s_txf[threadIdx.x] = f;
         s_ch[threadIdx.x] = ch;
+        if (SHADOW) {
+            // the table is indexed by rho = s2 / thr; usable if the fp32 frame error is small against
+            // the distances where it decides anything (d > 0.15 cut), else bin 0 (always pass)
+            float inv = 0.f;
+            if (f.w > 0.f && f.w < __builtin_inff()) {
+                const double cut = sqrt(double(f.w));
+                if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
+            }
+            s_inv[threadIdx.x] = inv;
+            s_src[threadIdx.x] = src_id;
+        }
         if (F64) {
             s_td[threadIdx.x * 4 + 0] = px;
             s_td[threadIdx.x * 4 + 1] = py;
@@ -542,14 +563,14 @@ __global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const Mode
     __syncthreads();
     if (slab >= t.n_slabs) return;
 
-    // heard-link counters start at zero; k_exact adds to them
-    if (e0 >= t.cnt_base) {
-        const int cc = (e0 - t.cnt_base) / kTxChunk;
-        if (t.use_matrix) {
-            t.cnt[(size_t(cc) * t.n_slabs + slab) * 64 + lane] = 0u;
-        } else if (slab == 0) {
-            t.slot_tot[cc * 64 + lane] = 0u;
-            t.cursor[cc * 64 + lane] = 0u;
+    // counters that later kernels of this tick (cursor) or the next tick's filter (candidate
+    // totals, other parity) add to start at zero
+    if (t.use_matrix) {
+        if (e0 >= t.cnt_base) t.cnt[(size_t((e0 - t.cnt_base) / kTxChunk) * t.n_slabs + slab) * 64 + lane] = 0u;
+    } else if (blockIdx.x == 0) {
+        for (int i = blockIdx.y * kBlock + threadIdx.x; i < t.zero_len; i += gridDim.y * kBlock) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
         }
     }
 
@@ -601,7 +622,16 @@ __global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const Mode
                 mask[r] = 0;
                 if ((near[r] >> ti) & 1ull) { // wave-uniform
                     const float s2 = dist2_f32(fx[r] - tf.x, fy[r] - tf.y, fz[r] - tf.z);
-                    mask[r] = ballot64((s2 <= tf.w) && (fch[r] == tch));
+                    bool hit = (s2 <= tf.w) && (fch[r] == tch);
+                    if (SHADOW && hit) {
+                        // second level: with this link's shadowing deviate, can it still reach the
+                        // level?  Conservative table of the largest hash that can, per bin of d^2/cut^2.
+                        const int bin = min(kShadowBins - 1, int(s2 * s_inv[ti]));
+                        const uint32_t a = uint32_t(s_src[ti]), b = uint32_t(forig[r]);
+                        const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
+                        hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                    }
+                    mask[r] = ballot64(hit);
                     total += uint32_t(__popcll(mask[r]));
                 }
             }
@@ -618,6 +648,10 @@ __global__ void __launch_bounds__(kBlock) k_filter(const NodesDev nd, const Mode
     }
     const uint64_t have = ballot64(my_total != 0u);
     if (have == 0) return; // the common case: far from every transmitter of the tile
+
+    // candidate links per frame (frames that get verdicts only): sizes the frame's segment
+    if (!t.use_matrix && my_total != 0u && t.first_eval + e0 + lane >= t.first_new)
+        atomicAdd(&t.cand_tot[e0 + lane - t.cnt_base], my_total);
 
     // one atomic reserves the contiguous run of candidate entries of this (tile, slab); the frames'
     // blocks follow each other inside it in frame order
@@ -751,10 +785,66 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
     return r;
 }
 
-// one lane per candidate link (full waves): the reference's fp64 arithmetic
-template <int MODEL, bool SINR>
+// Exclusive scan of n per-frame counts inside one 256-thread workgroup, result in LDS (and in
+// `pub` if not null).  Every workgroup of a consumer kernel redoes it (T counts, a few KB from L2)
+// instead of paying a separate kernel for it.  Returns the total; *vmax gets the largest count.
+constexpr int kFusedScanMax = 8192;
+RM_D uint32_t block_scan_counts(const uint32_t *cnt, int n, uint32_t *s_off, uint32_t *s_wave /*[4]*/, uint32_t *pub,
+                                uint32_t *vmax_out)
+{
+    const int per = (n + 255) / 256;
+    const int i0 = min(n, int(threadIdx.x) * per), i1 = min(n, i0 + per);
+    uint32_t sum = 0, vmax = 0;
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t v = cnt[i];
+        sum += v;
+        vmax = max(vmax, v);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    for (int i = i0; i < i1; ++i) {
+        s_off[i] = run;
+        if (pub) pub[i] = run;
+        run += cnt[i];
+    }
+    if (pub && threadIdx.x == 0) pub[n] = total;
+    if (vmax_out) {
+        for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), d)));
+        *vmax_out = vmax;
+    }
+    __syncthreads();
+    return total;
+}
+
+RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
+{
+    // UDGMRadioMedium.java:63-65 uses successRatioRx (sic); N2NRadioMedium.java:24-26
+    if (m.kind == RM_MODEL_UDGM) return m.udgm_ratio_rx * tx.txprob;
+    return tx.txprob;
+}
+
+// One lane per candidate link (full waves): the reference's fp64 arithmetic.
+// SEG 0: unsorted table, heard links are counted per (frame, slab) cell (ordered scatter later).
+// SEG 1/2: sorted table, heard links go straight into the frame's segment of the A records (any
+// order inside it); the segment offsets are the scan of the per-frame candidate counts, redone in
+// LDS by every workgroup (1) or read from k_scan_counts' output (2).
+template <int MODEL, bool SINR, bool STOCH, int SEG>
 __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev m, const TickDev t)
 {
+    __shared__ uint32_t s_seg[SEG == 1 ? kFusedScanMax + 1 : 1];
+    __shared__ uint32_t s_wave[4];
+    if (SEG == 1)
+        block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, (blockIdx.x == 0 && blockIdx.y == 0) ? t.seg_off : nullptr, nullptr);
     const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
@@ -764,27 +854,63 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
         const bool valid = i < n;
         const uint32_t idx = blockIdx.y * t.seg_cap + i;
         bool wanted = false;
-        int key = -1; // counter this link is added to: the frame slot, or the (frame, slab) cell
+        int slot = -1, key = -1;
+        uint8_t fl = 0;
+        double rssi = 0.0, prob = 1.0;
+        int orig = 0;
         if (valid) {
             const int erel = t.st_pkt[idx];
             const int pos = t.st_dst[idx];
             const rm_tx_record tx = t.tx[t.first_eval + erel];
             const bool is_new = (t.first_eval + erel) >= t.first_new;
             const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, pos, is_new);
-            t.st_flags[idx] = ev.append ? ev.flags : uint8_t(0);
+            fl = ev.append ? ev.flags : uint8_t(0);
+            if (ev.append && MODEL != RM_MODEL_NULL && MODEL != RM_MODEL_UDGM_CONST && tx_success(m, tx) <= 0.0) fl |= kFlagTxDead;
+            t.st_flags[idx] = fl;
             if (ev.append) {
-                if (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_N2N || MODEL == RM_MODEL_LOGDIST) t.st_aux[idx] = ev.aux;
+                orig = nd.orig[pos];
+                if (MODEL == RM_MODEL_LOGDIST) {
+                    rssi = ev.aux;
+                    prob = nd.rxprob[pos];
+                } else {
+                    rssi = tx.txpower; // reference media hand the packet's transmit power through
+                    prob = (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_N2N) ? ev.aux : 1.0;
+                }
+                if (SEG == 0 || SINR) { // the ordered scatter / the SINR pass read these from the entry
+                    t.st_orig[idx] = orig;
+                    t.st_aux[idx] = rssi;
+                    t.st_prob[idx] = prob;
+                }
                 if (SINR) {
                     t.st_lin[idx] = ev.lin;
                     t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
                 }
                 wanted = ev.wanted;
             }
-            const int slot = erel - t.cnt_base;
-            key = t.use_matrix ? int((size_t(slot >> 6) * t.n_slabs + pos / per_slab) * 64 + (slot & 63)) : slot;
+            slot = erel - t.cnt_base;
+            key = (SEG == 0) ? int((size_t(slot >> 6) * t.n_slabs + pos / per_slab) * 64 + (slot & 63)) : slot;
         }
+        // one atomic per run of same-frame (same-cell) entries
         const RunInfo ri = run_prefix(key, wanted, lane);
-        if (valid && lane == ri.start && ri.total) atomicAdd(t.use_matrix ? &t.cnt[key] : &t.slot_tot[key], ri.total);
+        if (SEG == 0) {
+            if (valid && lane == ri.start && ri.total) atomicAdd(&t.cnt[key], ri.total);
+        } else {
+            uint32_t base = 0;
+            if (valid && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total);
+            base = __shfl(base, ri.start);
+            if (wanted) {
+                const uint32_t o = ((SEG == 1) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
+                t.a_dst[o] = orig;
+                t.a_rssi[o] = rssi;
+                if (SINR) t.a_e[o] = int(idx);
+                if (STOCH) {
+                    t.a_prob[o] = prob;
+                    t.a_verdict[o] = uint8_t(0); // pending: k_apply_draws decides
+                } else {
+                    t.a_verdict[o] = (fl & kFlagTxDead) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+                }
+            }
+        }
     }
 }
 
@@ -809,6 +935,8 @@ __global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t)
     t.st_blk[idx] = idx;
     t.st_flags[idx] = kFlagSelf;
     t.st_aux[idx] = 0.0;
+    t.st_prob[idx] = 0.0;
+    t.st_orig[idx] = src;
     t.st_lin[idx] = 0.0;
     t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
 }
@@ -940,104 +1068,130 @@ __global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t)
 
 // ============================================================================ ordered scatter
 
-RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
+// frames beyond what the fused scans hold: seg_off / slot_off from a one-workgroup scan kernel
+__global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t *cnt, uint32_t *off, int n)
 {
-    // UDGMRadioMedium.java:63-65 uses successRatioRx (sic); N2NRadioMedium.java:24-26
-    if (m.kind == RM_MODEL_UDGM) return m.udgm_ratio_rx * tx.txprob;
-    return tx.txprob;
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < n) ? cnt[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (i < n) off[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) off[n] = carry;
 }
 
-// link entry -> position off[cell] + rank inside its (frame, slab) block; verdict for everything
-// that needs no draw.  Output order here: (packet, engine position).
+// Unsorted tables (Null / N2N media): link entry -> cell offset + rank inside the (frame, slab)
+// block -- directly the final (packet, node index) order; verdict for everything that needs no draw.
 template <bool STOCH>
-__global__ void __launch_bounds__(256) k_finalize(NodesDev nd, ModelDev m, TickDev t)
+__global__ void __launch_bounds__(256) k_finalize(ModelDev m, TickDev t)
 {
     const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
-    const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
-    const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
-    const int lane = threadIdx.x & 63;
-    for (uint32_t it = blockIdx.x * blockDim.x; it < n; it += stride) { // block-uniform trip count
-        const uint32_t i = it + threadIdx.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t e = blockIdx.y * t.seg_cap + i;
-        const bool heard = (i < n) && (t.st_flags[e] & kFlagHeardNew);
-        int erel = 0, pos = 0, slot = -1;
-        if (i < n) { // the frame slot of every entry, heard or not: it delimits the runs
-            erel = t.st_pkt[e];
-            slot = erel - t.cnt_base;
-        }
-        if (heard) pos = t.st_dst[e];
-        uint32_t o = 0;
-        if (t.use_matrix) { // deterministic position: cell offset + rank inside the (frame, slab) block
-            if (heard) {
-                const int slab = pos / per_slab;
-                uint32_t rank = 0;
-                for (uint32_t k = t.st_blk[e]; k < e; ++k) rank += (t.st_flags[k] & kFlagHeardNew) ? 1u : 0u;
-                o = t.slot_off[slot] + t.off[(size_t(slot >> 6) * t.n_slabs + slab) * 64 + (slot & 63)] + rank;
-            }
-        } else { // any position inside the frame's segment (k_reorder restores node-index order):
-                 // one cursor atomic per run of same-frame links
-            const RunInfo ri = run_prefix(slot, heard, lane);
-            uint32_t base = 0;
-            if (slot >= 0 && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total); // the leader need not be heard itself
-            base = __shfl(base, ri.start);
-            if (heard) o = t.slot_off[slot] + base + ri.before;
-        }
-        if (!heard) continue;
+        const uint8_t fl = t.st_flags[e];
+        if (!(fl & kFlagHeardNew)) continue;
+        const int slot = t.st_pkt[e] - t.cnt_base;
+        const int slab = t.st_dst[e] / per_slab;
+        uint32_t rank = 0;
+        for (uint32_t k = t.st_blk[e]; k < e; ++k) rank += (t.st_flags[k] & kFlagHeardNew) ? 1u : 0u;
+        const uint32_t o = t.slot_off[slot] + t.off[(size_t(slot >> 6) * t.n_slabs + slab) * 64 + (slot & 63)] + rank;
         if (o >= t.cap) continue;
-        const rm_tx_record tx = t.tx[t.first_eval + erel];
-        t.a_pkt[o] = slot - t.shift;
-        t.a_dst[o] = nd.orig[pos];
-        double rssi = tx.txpower; // reference media hand the packet's transmit power through
-        double prob = 1.0;
-        if (m.kind == RM_MODEL_LOGDIST) {
-            rssi = t.st_aux[e];
-            prob = nd.rxprob[pos];
-        } else if (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N) {
-            prob = t.st_aux[e];
-        }
-        t.a_rssi[o] = rssi;
-        t.a_sinr[o] = sinr ? t.st_sinr[e] : 0.0;
+        t.out_pkt[o] = slot - t.shift;
+        t.out_dst[o] = t.st_orig[e];
+        t.out_rssi[o] = t.st_aux[e];
+        const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
+        t.out_sinr[o] = sinr ? t.st_sinr[e] : 0.0;
         const bool collided = sinr && t.st_coll[e];
         if (STOCH) {
-            t.a_prob[o] = prob;
-            t.a_verdict[o] = collided ? uint8_t(RM_INTERFERED) : uint8_t(0); // 0 = pending
+            t.out_prob[o] = t.st_prob[e];
+            t.out_verdict[o] = collided ? uint8_t(RM_INTERFERED) : uint8_t(0); // 0 = pending
         } else {
-            const bool interference = draws_possible && (tx_success(m, tx) <= 0.0);
-            t.a_verdict[o] = (interference || collided) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
-        }
-    }
-    if (!STOCH && blockIdx.y == 0) {
-        const int n_new = t.n_active - t.first_new;
-        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < uint32_t(n_new); q += stride) {
-            const rm_tx_record tx = t.tx[t.first_new + q];
-            t.pkt_interference[q] = (draws_possible && tx_success(m, tx) <= 0.0) ? 1 : 0;
+            t.out_verdict[o] = ((fl & kFlagTxDead) || collided) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
         }
     }
 }
 
-// (packet, engine position) order -> (packet, node index) order: the order the reference's loop
-// visits receivers in (UDGMRadioMedium.java:99).  Rank by counting inside the packet's segment.
-__global__ void __launch_bounds__(256) k_reorder(TickDev t)
+// per-packet Tx-failure flag where no draw can happen (txSuccess <= 0 is the only way to fail)
+RM_D void write_pkt_interference(const ModelDev &m, const TickDev &t, uint32_t first, uint32_t stride)
 {
-    const uint32_t n = t.out_count[0];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += stride) {
-        const int q = t.a_pkt[o];
-        const uint32_t b = min(t.slot_off[q + t.shift], n);
-        const uint32_t e = min(t.slot_off[q + t.shift + 1], n);
-        const int mine = t.a_dst[o];
-        uint32_t rank = 0;
-        for (uint32_t k = b; k < e; ++k) rank += (t.a_dst[k] < mine) ? 1u : 0u;
-        const uint32_t d = b + rank;
-        t.out_pkt[d] = q;
-        t.out_dst[d] = mine;
-        t.out_verdict[d] = t.a_verdict[o];
-        t.out_rssi[d] = t.a_rssi[o];
-        t.out_sinr[d] = t.a_sinr[o];
-        t.out_prob[d] = t.a_prob[o];
+    const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
+    const int n_new = t.n_active - t.first_new;
+    for (uint32_t q = first; q < uint32_t(n_new); q += stride) {
+        const rm_tx_record tx = t.tx[t.first_new + q];
+        t.pkt_interference[q] = (draws_possible && tx_success(m, tx) <= 0.0) ? 1 : 0;
     }
+}
+
+// Sorted tables: the heard links of a frame sit unordered in the frame's segment of the A
+// records.  One wave per frame ranks them by node index -- the order the reference's loop visits
+// receivers in (UDGMRadioMedium.java:99) -- and writes them to their final, compact place.
+// A segment of up to 64 links sits one per lane and is ranked with a readlane loop, longer ones by
+// counting through memory.  MODE 1: the scan of the per-frame heard counts is redone in every
+// workgroup (LDS); MODE 2: slot_off comes from k_scan_counts.
+template <bool STOCH, bool SINR, int MODE>
+__global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
+{
+    __shared__ uint32_t s_off[MODE == 1 ? kFusedScanMax + 1 : 1];
+    __shared__ uint32_t s_wave[4];
+    const bool publisher = blockIdx.x == 0;
+    if (MODE == 1) {
+        uint32_t vmax = 0;
+        const uint32_t total = block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr,
+                                                 publisher ? &vmax : nullptr);
+        if (publisher && threadIdx.x == 0) {
+            t.out_count[0] = total < t.cap ? total : t.cap;
+            t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+            t.out_count[2] = total;
+            t.out_count[3] = vmax;
+        }
+    } else if (publisher && threadIdx.x == 0) {
+        const uint32_t total = t.slot_off[t.n_cnt];
+        t.out_count[0] = total < t.cap ? total : t.cap;
+        t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+        t.out_count[2] = total;
+    }
+    const int lane = threadIdx.x & 63;
+    const int n_new = t.n_active - t.first_new;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < n_new; q += gridDim.x * 4) { // wave-uniform
+        const int slot = q + t.shift;
+        const uint32_t src0 = t.seg_off[slot];
+        const uint32_t len = t.cursor[slot];
+        const uint32_t dst0 = (MODE == 1) ? s_off[slot] : t.slot_off[slot];
+        for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+            const uint32_t o = src0 + c0 + lane;
+            const bool valid = c0 + lane < len;
+            const int mine = valid ? t.a_dst[o] : 0x7fffffff;
+            uint32_t rank = 0;
+            if (len <= 64) {
+                for (uint32_t i = 0; i < len; ++i) rank += (__builtin_amdgcn_readlane(mine, int(i)) < mine) ? 1u : 0u;
+            } else if (valid) {
+                for (uint32_t k = 0; k < len; ++k) rank += (t.a_dst[src0 + k] < mine) ? 1u : 0u;
+            }
+            const uint32_t d = dst0 + rank;
+            if (valid && d < t.cap) {
+                t.out_pkt[d] = q;
+                t.out_dst[d] = mine;
+                t.out_rssi[d] = t.a_rssi[o];
+                uint8_t v = t.a_verdict[o];
+                if (SINR) {
+                    const int e = t.a_e[o];
+                    t.out_sinr[d] = t.st_sinr[e];
+                    if (t.st_coll[e]) v = RM_INTERFERED;
+                } else {
+                    t.out_sinr[d] = 0.0;
+                }
+                t.out_verdict[d] = v;
+                if (STOCH) t.out_prob[d] = t.a_prob[o];
+            }
+        }
+    }
+    if (!STOCH) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ============================================================================ Java-RNG draws
@@ -1210,34 +1364,59 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
     if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
     const dim3 grid(cdiv(t.n_slabs, kWavesPerBlock), cdiv(n_eval, kTxChunk));
     const dim3 block(kBlock);
-#define RM_LAUNCH(RPT, F64, BBOX) hipLaunchKernelGGL((k_filter<RPT, F64, BBOX>), grid, block, 0, s, nd, m, t)
+#define RM_LAUNCH(RPT, F64, BBOX, SH) hipLaunchKernelGGL((k_filter<RPT, F64, BBOX, SH>), grid, block, 0, s, nd, m, t)
     if (t.rpt == 4) {
-        if (cfg.f64_filter) RM_LAUNCH(4, true, false);
-        else if (cfg.bbox) RM_LAUNCH(4, false, true);
-        else RM_LAUNCH(4, false, false);
+        if (cfg.f64_filter) RM_LAUNCH(4, true, false, false);
+        else if (cfg.bbox && cfg.shadow) RM_LAUNCH(4, false, true, true);
+        else if (cfg.bbox) RM_LAUNCH(4, false, true, false);
+        else if (cfg.shadow) RM_LAUNCH(4, false, false, true);
+        else RM_LAUNCH(4, false, false, false);
     } else {
-        if (cfg.f64_filter) RM_LAUNCH(1, true, false);
-        else if (cfg.bbox) RM_LAUNCH(1, false, true);
-        else RM_LAUNCH(1, false, false);
+        if (cfg.f64_filter) RM_LAUNCH(1, true, false, false);
+        else if (cfg.bbox && cfg.shadow) RM_LAUNCH(1, false, true, true);
+        else if (cfg.bbox) RM_LAUNCH(1, false, true, false);
+        else if (cfg.shadow) RM_LAUNCH(1, false, false, true);
+        else RM_LAUNCH(1, false, false, false);
     }
 #undef RM_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t)
+template <int MODEL, bool SINR>
+static void launch_exact_m(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
 {
     const dim3 grid(4, kShards), block(256);
+    const int seg = t.use_matrix ? 0 : (t.n_cnt <= kFusedScanMax ? 1 : 2);
+#define RM_EX(ST, SG) hipLaunchKernelGGL((k_exact<MODEL, SINR, ST, SG>), grid, block, 0, s, nd, m, t)
+    if (cfg.stochastic) {
+        if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else RM_EX(true, 2);
+    } else {
+        if (seg == 0) RM_EX(false, 0); else if (seg == 1) RM_EX(false, 1); else RM_EX(false, 2);
+    }
+#undef RM_EX
+}
+
+hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
+{
     switch (m.kind) {
-    case RM_MODEL_NULL: hipLaunchKernelGGL((k_exact<RM_MODEL_NULL, false>), grid, block, 0, s, nd, m, t); break;
-    case RM_MODEL_UDGM: hipLaunchKernelGGL((k_exact<RM_MODEL_UDGM, false>), grid, block, 0, s, nd, m, t); break;
-    case RM_MODEL_UDGM_CONST: hipLaunchKernelGGL((k_exact<RM_MODEL_UDGM_CONST, false>), grid, block, 0, s, nd, m, t); break;
-    case RM_MODEL_N2N: hipLaunchKernelGGL((k_exact<RM_MODEL_N2N, false>), grid, block, 0, s, nd, m, t); break;
+    case RM_MODEL_NULL: launch_exact_m<RM_MODEL_NULL, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_UDGM: launch_exact_m<RM_MODEL_UDGM, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_UDGM_CONST: launch_exact_m<RM_MODEL_UDGM_CONST, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_N2N: launch_exact_m<RM_MODEL_N2N, false>(s, nd, m, t, cfg); break;
     case RM_MODEL_LOGDIST:
-        if (m.flags & RM_LD_SINR) hipLaunchKernelGGL((k_exact<RM_MODEL_LOGDIST, true>), grid, block, 0, s, nd, m, t);
-        else hipLaunchKernelGGL((k_exact<RM_MODEL_LOGDIST, false>), grid, block, 0, s, nd, m, t);
+        if (m.flags & RM_LD_SINR) launch_exact_m<RM_MODEL_LOGDIST, true>(s, nd, m, t, cfg);
+        else launch_exact_m<RM_MODEL_LOGDIST, false>(s, nd, m, t, cfg);
         break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// sorted tables with more frames than the fused scans hold: seg_off before k_exact
+hipError_t launch_seg_scan(hipStream_t s, const TickDev &t)
+{
+    if (!t.use_matrix && t.n_cnt > kFusedScanMax)
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cand_tot, t.seg_off, t.n_cnt);
     return hipGetLastError();
 }
 
@@ -1249,11 +1428,15 @@ hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev 
     return hipGetLastError();
 }
 
+// unsorted tables: cell offsets + frame scan; sorted tables with very many frames: slot_off
 hipError_t launch_offsets(hipStream_t s, const TickDev &t)
 {
-    if (t.use_matrix && t.n_cnt > 0 && t.n_slabs > 0)
-        hipLaunchKernelGGL(k_cell_off, dim3(t.n_cnt / 64), dim3(1024), 0, s, t);
-    hipLaunchKernelGGL(k_slot_scan, dim3(1), dim3(1024), 0, s, t);
+    if (t.use_matrix) {
+        if (t.n_cnt > 0 && t.n_slabs > 0) hipLaunchKernelGGL(k_cell_off, dim3(t.n_cnt / 64), dim3(1024), 0, s, t);
+        hipLaunchKernelGGL(k_slot_scan, dim3(1), dim3(1024), 0, s, t);
+    } else if (t.n_cnt > kFusedScanMax) {
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cursor, t.slot_off, t.n_cnt);
+    }
     return hipGetLastError();
 }
 
@@ -1263,17 +1446,42 @@ hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t)
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) k_pkt_interference(ModelDev m, TickDev t)
+{
+    write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// unsorted tables only
 hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                            const LaunchCfg &cfg)
 {
-    if (cfg.stochastic) hipLaunchKernelGGL(k_finalize<true>, dim3(4, kShards), dim3(256), 0, s, nd, m, t);
-    else hipLaunchKernelGGL(k_finalize<false>, dim3(4, kShards), dim3(256), 0, s, nd, m, t);
+    (void)nd;
+    const dim3 grid(4, kShards), block(256);
+    if (cfg.stochastic) {
+        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, s, m, t);
+    } else {
+        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, s, m, t);
+        hipLaunchKernelGGL(k_pkt_interference, dim3(8), dim3(256), 0, s, m, t);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_reorder(hipStream_t s, const TickDev &t)
+// sorted tables only
+hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
 {
-    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, s, t);
+    const int n_new = t.n_active - t.first_new;
+    const dim3 grid(max(1, min(2048, (n_new + 3) / 4))), block(256);
+    const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
+    const int mode = t.n_cnt <= kFusedScanMax ? 1 : 2;
+#define RM_RE(ST, SI, MO) hipLaunchKernelGGL((k_reorder<ST, SI, MO>), grid, block, 0, s, m, t)
+    if (mode == 1) {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 1); else RM_RE(true, false, 1); }
+        else { if (sinr) RM_RE(false, true, 1); else RM_RE(false, false, 1); }
+    } else {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 2); else RM_RE(true, false, 2); }
+        else { if (sinr) RM_RE(false, true, 2); else RM_RE(false, false, 2); }
+    }
+#undef RM_RE
     return hipGetLastError();
 }
 
