@@ -135,7 +135,6 @@ def main():
     with torch.cuda.stream(stream):
         if world == 1:
             src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
-            rec_dev = torch.empty(t_per_tick * 64, dtype=torch.uint8, device=dev)    # rm_tx_record[T]
             sharded = None
         else:
             # every rank packs the frames whose source it owns into a fixed number of slots
@@ -150,8 +149,8 @@ def main():
         t0 = k * W.TICK_US
         with torch.cuda.stream(stream):
             if sharded is None:
-                eng.pack_tx_device(src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US, rec_dev.data_ptr())
-                eng.tick_run_device(t0, t0 + W.TICK_US, rec_dev.data_ptr(), t_per_tick)
+                # one call: the frames' Tx records are built from the resident node state inside the sweep
+                eng.tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
             else:
                 sharded.run(src_dev[k].data_ptr(), t0, t0 + W.TICK_US, W.AIR_US)
 

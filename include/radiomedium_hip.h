@@ -174,8 +174,17 @@ int rm_pack_tx_device(rm_context *ctx, const int32_t *dev_src, int32_t n, int64_
 /* evaluate one tick whose new frames are `dev_new[0..n_new)` (device memory, canonical order) */
 int rm_tick_run_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
                        const rm_tx_record *dev_new, int32_t n_new);
+/* the same with the new frames given as source node indices (device int32[n], -1 = padding): the
+ * Tx records are built from the resident node state inside the sweep -- RadioPacket(node, time,
+ * data) copies txpower / channel from its source, RadioPacket.java:46-52 -- one call per tick */
+int rm_tick_run_sources_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
+                               const int32_t *dev_src, int32_t n, int64_t start_us, int64_t air_us);
 int rm_result_device(rm_context *ctx, rm_device_result *out);
 int rm_result_count(rm_context *ctx, uint32_t *count, uint32_t *dropped); /* synchronises */
+/* copy the last evaluated tick's heard links to host buffers (same layout as rm_tick_flush) */
+int rm_result_copy(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,
+                   double *sinr, uint32_t cap, uint32_t *count, uint8_t *pkt_interference,
+                   uint32_t *pkt_offset);
 int rm_sync(rm_context *ctx);
 
 /* Per-stage timing on the context's stream: on every `every_n`-th tick each stage of the launch

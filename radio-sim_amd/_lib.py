@@ -107,8 +107,12 @@ SIGNATURES = {
                                 C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rm_pack_tx_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "rm_tick_run_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
+    "rm_tick_run_sources_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
+                                             C.c_int64]),
     "rm_result_device": (C.c_int, [C.c_void_p, C.POINTER(DeviceResult)]),
     "rm_result_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rm_result_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                 C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rm_sync": (C.c_int, [C.c_void_p]),
     "rm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),

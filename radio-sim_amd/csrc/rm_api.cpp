@@ -472,7 +472,8 @@ int prepare_nodes(rm_context *c)
 }
 
 // the per-tick launch sequence; `tx` is the on-air list in device memory
-int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
+int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
+             int64_t src_start_us = 0, int64_t src_air_us = 0)
 {
     const int n_new = n_active - first_new;
     c->have_result = false;
@@ -489,6 +490,10 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new)
 
     rm::TickDev t{};
     t.tx = tx;
+    t.src_list = src_list;
+    t.tx_build = src_list ? const_cast<rm_tx_record *>(tx) : nullptr;
+    t.src_start_us = src_start_us;
+    t.src_air_us = src_air_us;
     t.n_active = n_active;
     t.first_new = first_new;
     t.first_eval = sinr ? 0 : first_new;
@@ -1175,6 +1180,19 @@ int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, cons
     return run_tick(c, dev_new, n_new, 0);
 }
 
+int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t n,
+                               int64_t start_us, int64_t air_us)
+{
+    if (!c || n < 0 || (n > 0 && !dev_src) || air_us < 0) return fail(RM_ERR_INVALID, "bad arguments");
+    if (is_sinr(c))
+        return fail(RM_ERR_STATE, "the SINR on-air list needs Tx records: use rm_tick_begin / rm_enqueue_tx / rm_tick_flush");
+    RM_HIP(hipSetDevice(c->device));
+    c->t_begin = t_begin_us;
+    c->t_end = t_end_us;
+    RM_HIP(c->d_tx.ensure(std::max(n, 1)));
+    return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us);
+}
+
 int rm_result_device(rm_context *c, rm_device_result *out)
 {
     if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
@@ -1188,6 +1206,15 @@ int rm_result_device(rm_context *c, rm_device_result *out)
     out->sinr = c->d_out_sinr.p;
     out->capacity = c->cap;
     return RM_OK;
+}
+
+int rm_result_copy(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                   uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    return copy_out(c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
 }
 
 int rm_result_count(rm_context *c, uint32_t *count, uint32_t *dropped)

@@ -69,6 +69,11 @@ struct NodesDev {
 
 struct TickDev {
     const rm_tx_record *tx; // on-air list, canonical order [n_active]
+    // build mode (single tick of new frames given as source indices): k_filter builds the records
+    // from the source table while staging its tile and writes them to tx_build (== tx) for k_exact
+    const int32_t *src_list;
+    rm_tx_record *tx_build;
+    int64_t src_start_us, src_air_us;
     int n_active;
     int first_new;          // frames [first_new, n_active) get verdicts
     int first_eval;         // frames [first_eval, n_active) are swept by the filter kernel

@@ -395,14 +395,10 @@ RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, dou
 }
 
 // RadioPacket(node, time, data): copies the source radio's txpower / channel (RadioPacket.java:46-52)
-__global__ void __launch_bounds__(256)
-k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_us, rm_tx_record *out)
+RM_D rm_tx_record make_tx_record(const NodesDev &nd, int s, int64_t start_us, int64_t air_us)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int s = src[i];
     rm_tx_record r;
-    if (s < 0 || s >= nd.n) {
+    if (s < 0 || s >= nd.n) { // padding slot
         r.x = r.y = r.z = 0.0;
         r.txpower = 0.0;
         r.txprob = 0.0;
@@ -421,6 +417,15 @@ k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_
         r.src = s;
         r.channel = nd.schannel[s];
     }
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_us, rm_tx_record *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rm_tx_record r = make_tx_record(nd, src[i], start_us, air_us);
     out[i] = r;
 }
 
@@ -461,7 +466,7 @@ RM_D RunInfo run_prefix(int key, bool pred, int lane)
 RM_D float dist2_f32(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
 
 template <int RPT, bool F64, bool BBOX, bool SHADOW>
-__global__ void __launch_bounds__(kBlock, F64 ? 2 : 8) k_filter(const NodesDev nd, const ModelDev m, const TickDev t)
+__global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev nd, const ModelDev m, const TickDev t)
 {
     __shared__ float4 s_txf[kTxChunk];
     __shared__ int s_ch[kTxChunk];
@@ -532,7 +537,13 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 8) k_filter(const NodesDev n
         int src_id = -1;
         double px = 0, py = 0, pz = 0;
         if (int(threadIdx.x) < nt) {
-            const rm_tx_record tx = t.tx[t.first_eval + e0 + threadIdx.x];
+            rm_tx_record tx;
+            if (t.src_list) { // build mode: the record comes from the source table
+                tx = make_tx_record(nd, t.src_list[e0 + threadIdx.x], t.src_start_us, t.src_air_us);
+                if (blockIdx.x == 0) t.tx_build[e0 + threadIdx.x] = tx;
+            } else {
+                tx = t.tx[t.first_eval + e0 + threadIdx.x];
+            }
             tx_prefilter(m, tx, f, thr64);
             ch = tx.channel;
             src_id = tx.src;

@@ -183,10 +183,29 @@ class Engine:
     def tick_run_device(self, t_begin, t_end, dev_new_ptr, n_new):
         check(self._L.rm_tick_run_device(self._h, t_begin, t_end, C.c_void_p(dev_new_ptr), n_new))
 
+    def tick_run_sources_device(self, t_begin, t_end, dev_src_ptr, n, start_us, air_us):
+        check(self._L.rm_tick_run_sources_device(self._h, t_begin, t_end, C.c_void_p(dev_src_ptr), n, start_us, air_us))
+
     def result_device(self):
         r = DeviceResult()
         check(self._L.rm_result_device(self._h, C.byref(r)))
         return r
+
+    def result_copy(self, n_new, cap=None):
+        """Heard links of the last device-path tick, copied to the host."""
+        cap = cap if cap is not None else min(max(1, n_new) * max(1, self.n), 1 << 26)
+        pkt = np.empty(cap, dtype=np.int32)
+        dst = np.empty(cap, dtype=np.int32)
+        verdict = np.empty(cap, dtype=np.uint8)
+        rssi = np.empty(cap, dtype=np.float64)
+        sinr = np.empty(cap, dtype=np.float64)
+        pint = np.zeros(max(1, n_new), dtype=np.uint8)
+        poff = np.zeros(n_new + 1, dtype=np.uint32)
+        cnt = C.c_uint32()
+        check(self._L.rm_result_copy(self._h, pkt.ctypes.data, dst.ctypes.data, verdict.ctypes.data, rssi.ctypes.data,
+                                     sinr.ctypes.data, cap, C.byref(cnt), pint.ctypes.data, poff.ctypes.data))
+        k = cnt.value
+        return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
 
     def result_count(self):
         cnt, dropped = C.c_uint32(), C.c_uint32()

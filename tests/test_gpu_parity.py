@@ -182,3 +182,39 @@ def test_boundary_lattice(engine, rsa, O):
                          ("udgm_const", {"const_range": 50.0})):
         gpu, cpu = run_both(O, rsa, engine, nd, kind, params, nd.packets(src))
         assert_same(gpu, cpu, kind + str(params))
+
+
+def test_device_resident_paths(engine, rsa, O):
+    """rm_pack_tx_device + rm_tick_run_device and the fused rm_tick_run_sources_device give the same
+    links as the host-record path / the oracle (sources with -1 padding included)."""
+    from util import DeviceArray
+    n = 5000
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=44)
+    rng = np.random.default_rng(2)
+    nd.txpower[:] = rng.uniform(-10, 0, n)
+    nd.channel[rng.random(n) < 0.2] = 20
+    params = {"ld_sigma_db": 4.0, "ld_seed": 3}
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    srcs = np.sort(rng.choice(n, 100, replace=False)).astype(np.int32)
+    padded = np.concatenate([srcs[:50], [-1, -1, -1], srcs[50:]]).astype(np.int32)
+    cpu = O.tick(mdl, nd, nd.packets(srcs, 7000, 8128))
+    slot_of_valid = np.nonzero(padded >= 0)[0]
+    src_dev = DeviceArray(padded)
+    rec_dev = DeviceArray(nbytes=len(padded) * 64)
+    for fused in (False, True):
+        if fused:
+            engine.tick_run_sources_device(7000, 8000, src_dev.ptr.value, len(padded), 7000, 8128)
+        else:
+            engine.pack_tx_device(src_dev.ptr.value, len(padded), 7000, 8128, rec_dev.ptr.value)
+            engine.tick_run_device(7000, 8000, rec_dev.ptr.value, len(padded))
+        gpu = engine.result_copy(len(padded))
+        assert gpu.count == cpu.count > 1000
+        np.testing.assert_array_equal(gpu.pkt, slot_of_valid[cpu.pkt])
+        np.testing.assert_array_equal(gpu.dst, cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+        np.testing.assert_array_equal(gpu.rssi, cpu.rssi)
+        assert gpu.pkt_offset[-1] == gpu.count
+        assert engine.result_count() == (cpu.count, 0)
+    src_dev.free()
+    rec_dev.free()

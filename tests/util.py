@@ -75,3 +75,24 @@ def random_nodes(O, n, side, seed, z_span=0.0):
     nd.y = rng.uniform(0, side, n)
     nd.z = rng.uniform(0, z_span, n) if z_span else np.zeros(n)
     return nd
+
+
+class DeviceArray:
+    """A device buffer through the HIP runtime the engine itself uses (ctypes; no torch in the process:
+    torch wheels carry their own HIP/HSA runtime, and two runtimes in one process do not mix)."""
+
+    def __init__(self, host_array=None, nbytes=None):
+        import ctypes as C
+        self._C = C
+        self._hip = C.CDLL("libamdhip64.so.7")
+        self.ptr = C.c_void_p()
+        n = host_array.nbytes if host_array is not None else nbytes
+        assert self._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(n, 1))) == 0
+        if host_array is not None:
+            a = np.ascontiguousarray(host_array)
+            assert self._hip.hipMemcpy(self.ptr, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0   # H2D
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = None
