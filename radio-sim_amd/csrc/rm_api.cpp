@@ -104,6 +104,7 @@ struct rm_context {
     DevBuf<double> d_rx_x, d_rx_y, d_rx_z, d_rx_rxprob;
     DevBuf<int32_t> d_rx_channel, d_rx_int_id, d_rx_orig, d_pos_of;
     DevBuf<uint8_t> d_rx_enabled;
+    DevBuf<rm::RxRecord> d_rx_rec;
     DevBuf<float4> d_rxf, d_bbox_xy;
     DevBuf<float2> d_bbox_z;
     DevBuf<double> d_n2n;
@@ -303,6 +304,7 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.int_id = c->d_rx_int_id.p;
     nd.orig = c->d_rx_orig.p;
     nd.enabled = c->d_rx_enabled.p;
+    nd.rec = c->d_rx_rec.p;
     nd.pos_of = c->d_pos_of.p;
     nd.rx_first = part_first(c);
     nd.rxf = c->d_rxf.p;
@@ -384,6 +386,27 @@ int rebuild_receivers(rm_context *c)
         RM_HIP(hipMemcpyAsync(c->d_rx_orig.p, perm.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
         RM_HIP(hipMemcpyAsync(c->d_pos_of.p, pos_of.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
         RM_HIP(hipStreamSynchronize(c->stream));
+    }
+    {
+        std::vector<rm::RxRecord> recs(count);
+        for (int i = 0; i < count; ++i) {
+            const int k = perm[i];
+            rm::RxRecord &r = recs[i];
+            std::memset(&r, 0, sizeof(r));
+            r.x = c->x[k];
+            r.y = c->y[k];
+            r.z = c->z[k];
+            r.rxprob = c->rxprob[k];
+            r.orig = k;
+            r.int_id = c->int_id[k];
+            r.channel = c->channel[k];
+            r.enabled = c->enabled[k];
+        }
+        RM_HIP(c->d_rx_rec.ensure(std::max(count, 1)));
+        if (count) {
+            RM_HIP(hipMemcpyAsync(c->d_rx_rec.p, recs.data(), size_t(count) * sizeof(rm::RxRecord), hipMemcpyHostToDevice, c->stream));
+            RM_HIP(hipStreamSynchronize(c->stream));
+        }
     }
     c->n_rx = count;
     c->rx_dirty = false;
@@ -822,7 +845,7 @@ void rm_destroy(rm_context *c)
     c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release();
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
-    c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rxf.release(); c->d_bbox_xy.release();
+    c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_tx.release();
     c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_cand_tot.release();
     c->d_seg_off.release(); c->d_a_e.release(); c->d_slot_off.release();

@@ -52,6 +52,17 @@ struct ModelDev {
 //  * receiver table of this rank's partition, in ENGINE ORDER: receivers are spatially sorted
 //    (k-d split down to groups of 64) so that a wave's 64 receivers share a small bounding box;
 //    orig[pos] maps back to the node index.
+// exact-path view of one receiver: one aligned 64-byte record, one gather per candidate link
+struct alignas(64) RxRecord {
+    double x, y, z;   // Position.java:37-39
+    double rxprob;    // Transciever.java:17
+    int32_t orig;     // node index (registration order)
+    int32_t int_id;   // Node.getIdAsInteger()
+    int32_t channel;
+    int32_t enabled;
+    double pad[2];
+};
+
 struct NodesDev {
     int n;                                   // nodes in the simulator
     const double *sx, *sy, *sz, *stxpower, *stxprob;
@@ -60,6 +71,7 @@ struct NodesDev {
     const double *x, *y, *z, *rxprob;
     const int32_t *channel, *int_id, *orig;
     const uint8_t *enabled;
+    const RxRecord *rec;                     // [n_rx] the same data as one record per receiver (k_exact)
     const int32_t *pos_of;                   // [rx_count] node index - rx_first -> engine position
     int rx_first;
     float4 *rxf;                             // pre-filter record: (fx, fy, fz, channel bits); NaN = never a candidate

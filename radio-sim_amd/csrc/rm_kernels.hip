@@ -719,7 +719,7 @@ struct LinkEval {
 // (UDGMRadioMedium.java:99-111, N2NRadioMedium.java:55-67, NullRadioMedium.java:62-73,
 //  UDGMConstantLossRadioMedium.java:25-33).  `pos` is the receiver's engine position.
 template <int MODEL, bool SINR>
-RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_record &tx, int pos, bool is_new)
+RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_record &tx, const RxRecord &rx_, bool is_new)
 {
     LinkEval r;
     r.append = false;
@@ -727,10 +727,10 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
     r.flags = 0;
     r.aux = 0.0;
     r.lin = 0.0;
-    const int j = nd.orig[pos];
-    if (j == tx.src) return r;                    // node != source
-    if (!nd.enabled[pos]) return r;               // radio.isEnabled()
-    if (nd.channel[pos] != tx.channel) return r;  // radio.getWirelessChannel() == channel
+    const int j = rx_.orig;
+    if (j == tx.src) return r;                  // node != source
+    if (!rx_.enabled) return r;                 // radio.isEnabled()
+    if (rx_.channel != tx.channel) return r;    // radio.getWirelessChannel() == channel
     if (MODEL == RM_MODEL_NULL) {
         r.append = r.wanted = is_new;
         r.flags = kFlagHeardNew;
@@ -739,10 +739,10 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
     if (MODEL == RM_MODEL_N2N) {
         // N2NRadioMedium.java:28-37
         const int sid = nd.sint_id[tx.src];
-        const int did = nd.int_id[pos];
+        const int did = rx_.int_id;
         double p = 0.0;
         if (m.n2n != nullptr && sid > 0 && did > 0 && sid <= m.n2n_m && did <= m.n2n_m) {
-            p = m.n2n[int64_t(sid - 1) * m.n2n_m + (did - 1)] * nd.rxprob[pos];
+            p = m.n2n[int64_t(sid - 1) * m.n2n_m + (did - 1)] * rx_.rxprob;
         }
         if (p <= 0.0) return r;
         r.append = r.wanted = is_new;
@@ -750,7 +750,7 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
         r.aux = p;
         return r;
     }
-    const double rx = nd.x[pos], ry = nd.y[pos], rz = nd.z[pos];
+    const double rx = rx_.x, ry = rx_.y, rz = rx_.z;
     if (MODEL == RM_MODEL_UDGM_CONST) {
         const double d = ref_distance(tx.x, tx.y, tx.z, rx, ry, rz);
         if (d < m.const_range) {
@@ -769,7 +769,7 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
         double ratio = d2 / dmax2;
         if (ratio > 1.0) return r;
         ratio = 1.0 - ratio * (1.0 - m.udgm_ratio_rx);
-        const double p = ratio * nd.rxprob[pos];
+        const double p = ratio * rx_.rxprob;
         if (p <= 0.0) return r;
         r.append = r.wanted = is_new;
         r.flags = kFlagHeardNew;
@@ -778,7 +778,7 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
     }
     if (MODEL == RM_MODEL_LOGDIST) {
         const double rssi = logdist_rssi(m, tx, rx, ry, rz, j);
-        const bool heard = is_new && (rssi >= m.ld_sens) && !(nd.rxprob[pos] <= 0.0);
+        const bool heard = is_new && (rssi >= m.ld_sens) && !(rx_.rxprob <= 0.0);
         r.aux = rssi;
         if (SINR) {
             const bool interferer = rssi >= m.ld_ifloor;
@@ -874,15 +874,16 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
             const int pos = t.st_dst[idx];
             const rm_tx_record tx = t.tx[t.first_eval + erel];
             const bool is_new = (t.first_eval + erel) >= t.first_new;
-            const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, pos, is_new);
+            const RxRecord rx_ = nd.rec[pos];
+            const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, rx_, is_new);
             fl = ev.append ? ev.flags : uint8_t(0);
             if (ev.append && MODEL != RM_MODEL_NULL && MODEL != RM_MODEL_UDGM_CONST && tx_success(m, tx) <= 0.0) fl |= kFlagTxDead;
             t.st_flags[idx] = fl;
             if (ev.append) {
-                orig = nd.orig[pos];
+                orig = rx_.orig;
                 if (MODEL == RM_MODEL_LOGDIST) {
                     rssi = ev.aux;
-                    prob = nd.rxprob[pos];
+                    prob = rx_.rxprob;
                 } else {
                     rssi = tx.txpower; // reference media hand the packet's transmit power through
                     prob = (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_N2N) ? ev.aux : 1.0;
@@ -1178,6 +1179,11 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
             const uint32_t o = src0 + c0 + lane;
             const bool valid = c0 + lane < len;
             const int mine = valid ? t.a_dst[o] : 0x7fffffff;
+            // the record's other fields are fetched now, under the same round trip
+            const double in_rssi = valid ? t.a_rssi[o] : 0.0;
+            uint8_t v = valid ? t.a_verdict[o] : uint8_t(0);
+            const double in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
+            const int in_e = (SINR && valid) ? t.a_e[o] : 0;
             uint32_t rank = 0;
             if (len <= 64) {
                 for (uint32_t i = 0; i < len; ++i) rank += (__builtin_amdgcn_readlane(mine, int(i)) < mine) ? 1u : 0u;
@@ -1188,17 +1194,15 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
             if (valid && d < t.cap) {
                 t.out_pkt[d] = q;
                 t.out_dst[d] = mine;
-                t.out_rssi[d] = t.a_rssi[o];
-                uint8_t v = t.a_verdict[o];
+                t.out_rssi[d] = in_rssi;
                 if (SINR) {
-                    const int e = t.a_e[o];
-                    t.out_sinr[d] = t.st_sinr[e];
-                    if (t.st_coll[e]) v = RM_INTERFERED;
+                    t.out_sinr[d] = t.st_sinr[in_e];
+                    if (t.st_coll[in_e]) v = RM_INTERFERED;
                 } else {
                     t.out_sinr[d] = 0.0;
                 }
                 t.out_verdict[d] = v;
-                if (STOCH) t.out_prob[d] = t.a_prob[o];
+                if (STOCH) t.out_prob[d] = in_prob;
             }
         }
     }
