@@ -10,9 +10,13 @@ in HBM before the timed region starts.
     python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|udgm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: receivers are range-partitioned over the ranks (strong scaling, the node count stays
-100k); every tick each rank packs the Tx records of the transmitters it owns and the ranks
-all-gather them over RCCL/xGMI.  Rank 0 prints ONE JSON line.
+N > 1: receivers are range-partitioned over the ranks; every tick each rank packs the Tx records of
+the transmitters it owns and the ranks all-gather them over RCCL/xGMI (packing + all-gather of
+tick t+1 overlap the sweep of tick t on a second stream).  Default scaling is WEAK: the link
+evaluations per GPU and tick stay those of the 1-GPU config (T x N_loc = 1e8), i.e. the node
+count grows as 100k x sqrt(N) at constant density and Tx fraction -- one tick of the 100k-node
+config is ~34 us of dependent kernel launches on ONE GPU, so splitting it further (--scaling
+strong) only adds a collective to a latency floor.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -47,6 +51,9 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the pipelined multi-GPU tick driver even on one GPU (testing)")
     ap.add_argument("--profile-every", type=int, default=16,
                     help="HIP-event sample of the dominant kernel every n-th tick of the timed region")
     return ap.parse_args()
@@ -111,6 +118,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     idx, n, frac, model, desc = WORKLOADS[args.workload]
+    if world > 1 and args.scaling == "weak":
+        # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
+        n = int(round(n * world ** 0.5))
+        desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
     t_per_tick = int(round(frac * n))
     nodes = W.make_nodes(n, idx)
     kind_name, kw = W.model_kwargs(model)
@@ -132,8 +143,9 @@ def main():
     sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(ticks)]
 
     from radio_sim_amd import dist as D
+    use_sharded = world > 1 or args.force_sharded
     with torch.cuda.stream(stream):
-        if world == 1:
+        if not use_sharded:
             src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
             sharded = None
         else:
@@ -142,32 +154,38 @@ def main():
             slots = D.slots_needed(n, world, sources)
             pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
             src_dev = torch.from_numpy(pad).to(dev)
-            sharded = D.ShardedTick(eng, dist, n, rank, world, slots, dev)
+            sharded = D.ShardedTick(eng, dist, n, rank, world, slots, dev, stream)
     stream.synchronize()
 
-    def run_tick(k):
-        t0 = k * W.TICK_US
+    def run_range(k0, k1):
+        """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
         with torch.cuda.stream(stream):
             if sharded is None:
-                # one call: the frames' Tx records are built from the resident node state inside the sweep
-                eng.tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+                for k in range(k0, k1):
+                    t0 = k * W.TICK_US
+                    # one call: the frames' Tx records are built from the resident node state inside the sweep
+                    eng.tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
             else:
-                sharded.run(src_dev[k].data_ptr(), t0, t0 + W.TICK_US, W.AIR_US)
+                if k1 > k0:
+                    sharded.stage(src_dev[k0].data_ptr(), k0 * W.TICK_US, W.AIR_US)
+                for k in range(k0, k1):
+                    cur = sharded.staged
+                    if k + 1 < k1:
+                        sharded.stage(src_dev[k + 1].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
+                    sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
 
     def fence():
         stream.synchronize()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()   # includes the communication stream
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        run_tick(k)
+    run_range(0, args.warmup)
     fence()
     eng.profile_enable(args.profile_every)
     t_start = time.perf_counter()
-    for k in range(args.warmup, ticks):
-        run_tick(k)
+    run_range(args.warmup, ticks)
     fence()
     elapsed = time.perf_counter() - t_start
     n_samples, stage_ms = eng.profile_read()
@@ -221,13 +239,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US,
                        "air_us": W.AIR_US, "model": model, "heard_links_last_tick": heard_total,
-                       "sharding": "receivers range-partitioned, RCCL all-gather of Tx records" if world > 1 else "none"},
+                       "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per tick, "
+                                    "overlapped with the previous tick's sweep" % world) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,

@@ -171,6 +171,9 @@ int rm_tick_flush(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict,
 /* build tx records for sources `dev_src[0..n)` from the resident node state */
 int rm_pack_tx_device(rm_context *ctx, const int32_t *dev_src, int32_t n, int64_t start_us,
                       int64_t air_us, rm_tx_record *dev_out);
+/* the same on another stream (packing + all-gather of tick t+1 can overlap the sweep of tick t) */
+int rm_pack_tx_device_on(rm_context *ctx, void *hip_stream, const int32_t *dev_src, int32_t n,
+                         int64_t start_us, int64_t air_us, rm_tx_record *dev_out);
 /* evaluate one tick whose new frames are `dev_new[0..n_new)` (device memory, canonical order) */
 int rm_tick_run_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
                        const rm_tx_record *dev_new, int32_t n_new);

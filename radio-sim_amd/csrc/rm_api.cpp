@@ -1182,13 +1182,20 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
     return rm_tick_flush(c, nullptr, dst, verdict, rssi, sinr, cap, count, interference, nullptr);
 }
 
-int rm_pack_tx_device(rm_context *c, const int32_t *dev_src, int32_t n, int64_t start_us, int64_t air_us,
-                      rm_tx_record *dev_out)
+int rm_pack_tx_device_on(rm_context *c, void *hip_stream, const int32_t *dev_src, int32_t n, int64_t start_us,
+                         int64_t air_us, rm_tx_record *dev_out)
 {
     if (!c || n < 0 || (n > 0 && (!dev_src || !dev_out))) return fail(RM_ERR_INVALID, "bad arguments");
     RM_HIP(hipSetDevice(c->device));
-    RM_HIP(rm::launch_pack_tx(c->stream, nodes_dev(c), dev_src, n, start_us, air_us, dev_out));
+    RM_HIP(rm::launch_pack_tx(static_cast<hipStream_t>(hip_stream), nodes_dev(c), dev_src, n, start_us, air_us, dev_out));
     return RM_OK;
+}
+
+int rm_pack_tx_device(rm_context *c, const int32_t *dev_src, int32_t n, int64_t start_us, int64_t air_us,
+                      rm_tx_record *dev_out)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    return rm_pack_tx_device_on(c, c->stream, dev_src, n, start_us, air_us, dev_out);
 }
 
 int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const rm_tx_record *dev_new, int32_t n_new)

@@ -94,18 +94,56 @@ def merge_shard_links(shards, n_slots):
 
 
 class ShardedTick:
-    """Device-resident multi-GPU tick driver used by bench.py (one instance per rank)."""
+    """Device-resident multi-GPU tick driver used by bench.py (one instance per rank).
 
-    def __init__(self, engine, dist, n, rank, world, slots, device):
+    Two-deep pipeline: packing + the RCCL all-gather of tick t+1 run on a communication stream
+    while the sweep of tick t runs on the engine's stream (the messages are tiny -- `slots` x 64 B
+    per rank -- so the collective is latency-bound and hides completely behind the sweep).
+    Works with world == 1 as well (no collective), which is how the choreography is tested on one GPU."""
+
+    def __init__(self, engine, dist, n, rank, world, slots, device, compute_stream):
         import torch
+        self.torch = torch
         self.eng, self.dist, self.n, self.rank, self.world, self.slots = engine, dist, n, rank, world, slots
         self.lo, self.hi = partition(n, rank, world)
-        engine.set_partition(self.lo, self.hi - self.lo)
-        self.mine = torch.empty(slots * RECORD_BYTES, dtype=torch.uint8, device=device)
-        self.all = torch.empty(world * slots * RECORD_BYTES, dtype=torch.uint8, device=device)
+        if world > 1:
+            engine.set_partition(self.lo, self.hi - self.lo)
+        self.compute = compute_stream
+        self.comm = torch.cuda.Stream(device=device)
+        self.mine = [torch.empty(slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.all = [torch.empty(world * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]   # gathered records of the buffer are complete
+        self.done = [torch.cuda.Event() for _ in range(2)]    # the sweep that read the buffer has finished
+        self.used = [False, False]
+        self.staged = None
+
+    def stage(self, dev_src_ptr, t_begin, air_us):
+        """Enqueue packing + all-gather of a tick on the communication stream."""
+        torch = self.torch
+        b = 0 if self.staged is None else 1 - self.staged[0]
+        with torch.cuda.stream(self.comm):
+            if self.used[b]:
+                self.comm.wait_event(self.done[b])         # the previous sweep on this buffer
+            self.eng.pack_tx_device_on(self.comm.cuda_stream, dev_src_ptr, self.slots, t_begin, air_us,
+                                       self.mine[b].data_ptr())
+            if self.world > 1:
+                all_gather_records(self.dist, self.mine[b], self.world, self.all[b])
+            else:
+                self.all[b].copy_(self.mine[b], non_blocking=True)
+            self.ready[b].record(self.comm)
+        prev = self.staged
+        self.staged = (b, t_begin)
+        return prev
+
+    def sweep(self, staged, t_end):
+        """Run the sweep of a staged tick on the engine's stream."""
+        b, t_begin = staged
+        self.compute.wait_event(self.ready[b])
+        self.eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
+        self.done[b].record(self.compute)
+        self.used[b] = True
 
     def run(self, dev_src_ptr, t_begin, t_end, air_us):
-        """dev_src_ptr: device int32[slots] with this rank's transmitters (-1 padded)."""
-        self.eng.pack_tx_device(dev_src_ptr, self.slots, t_begin, air_us, self.mine.data_ptr())
-        all_gather_records(self.dist, self.mine, self.world, self.all)
-        self.eng.tick_run_device(t_begin, t_end, self.all.data_ptr(), self.world * self.slots)
+        """Unpipelined convenience: stage and sweep one tick."""
+        self.stage(dev_src_ptr, t_begin, air_us)
+        self.sweep(self.staged, t_end)

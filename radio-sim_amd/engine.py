@@ -180,6 +180,10 @@ class Engine:
         check(self._L.rm_pack_tx_device(self._h, C.c_void_p(dev_src_ptr), n, start_us, air_us,
                                         C.c_void_p(dev_out_ptr)))
 
+    def pack_tx_device_on(self, stream_ptr, dev_src_ptr, n, start_us, air_us, dev_out_ptr):
+        check(self._L.rm_pack_tx_device_on(self._h, C.c_void_p(stream_ptr), C.c_void_p(dev_src_ptr), n, start_us, air_us,
+                                           C.c_void_p(dev_out_ptr)))
+
     def tick_run_device(self, t_begin, t_end, dev_new_ptr, n_new):
         check(self._L.rm_tick_run_device(self._h, t_begin, t_end, C.c_void_p(dev_new_ptr), n_new))
 

@@ -75,3 +75,24 @@ def test_partition_with_draws_is_refused(rsa, O):
         assert e.value.code == -5
     finally:
         eng.close()
+
+
+def test_pipelined_sharded_driver_on_one_gpu():
+    """The two-stream tick driver of the multi-GPU path (pack + gather of tick t+1 overlapping the
+    sweep of tick t), run with world == 1: it must see exactly the heard links the plain path sees.
+    Run in fresh processes: the driver needs torch, and torch's bundled HIP runtime must be the
+    first one loaded in its process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ["--force-sharded"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "40",
+                            "--warmup", "5", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        outs.append(json.loads(line))
+    assert outs[0]["config"]["heard_links_last_tick"] == outs[1]["config"]["heard_links_last_tick"] > 0
+    assert outs[1]["value"] > 0
