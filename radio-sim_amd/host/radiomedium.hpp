@@ -1,0 +1,362 @@
+// radiomedium.hpp -- C++ host-side mirror of the reference's radio-medium plug-in API, above the
+// C ABI (include/radiomedium_hip.h).  Same class and method names, argument meaning and error
+// behaviour as the reference's Java (paths relative to
+// /root/reference/radio-medium/java/se/sics/emul8/radiomedium/), written from scratch:
+//
+//   Position            Position.java:35-65        x, y, z, set(x,y[,z]), getDistance
+//   Transciever         Transciever.java:3-114     txpower 0.0, channel 26, enabled, rx/txProbability 1.0,
+//                                                  getRSSI / getReceivingState / setReceiving / clearReceiving ...
+//   Node                Node.java:39-99            id, getIdAsInteger (-1 if not numeric), position, radio
+//   RadioPacket         RadioPacket.java:38-111    source, start time, txpower / channel copied from the source,
+//                                                  getPacketAirTime = 32 us per hex character
+//   Simulator           Simulator.java             only what a medium touches: addNode / getNodes / getNode,
+//                                                  getTime, getRandom seed, generateTransmissionEvents,
+//                                                  generateReceptionEvents, deliverRadioPacket (recorded, in call order)
+//   RadioMedium         RadioMedium.java:35-45     getName / setSimulator / transmit / getBaseRSSI
+//   AbstractRadioMedium AbstractRadioMedium.java   baseRSSI = -100.0, setBaseRSSI
+//   NullRadioMedium, UDGMRadioMedium, UDGMConstantLossRadioMedium, N2NRadioMedium
+//                       the four reference media, here backed by the MI355X engine: transmit() is one
+//                       rm_transmit call, and the heard links -- returned in node order -- become exactly the
+//                       Simulator calls the reference's loops make.
+//
+// There is no CPU evaluation in this file: without a gfx950 device the medium's constructor throws.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/radiomedium_hip.h"
+
+namespace emul8 {
+
+class Simulator;
+class RadioMedium;
+class RadioPacket;
+
+class Position {
+public:
+    double x = 0, y = 0, z = 0;
+    void set(double x_, double y_) { set(x_, y_, 0.0); }
+    void set(double x_, double y_, double z_) { x = x_; y = y_; z = z_; }
+};
+
+class Node;
+
+class Transciever {
+public:
+    static constexpr int LISTENING = 0, TRANSMITTING = 1, RECEIVING = 2, DISABLED = 3;
+    explicit Transciever(Node *node) : node_(node) {}
+    Node *getNode() const { return node_; }
+    bool isEnabled() const { return enabled_; }
+    void setEnabled(bool e) { enabled_ = e; }
+    double getTransmitPower() const { return txpower_; }
+    void setTransmitPower(double p) { txpower_ = p; }
+    int getWirelessChannel() const { return channel_; }
+    void setWirelessChannel(int c) { channel_ = c; }
+    double getRxProbability() const { return rxProbability_; }
+    void setRxProbability(double p) { rxProbability_ = p; }
+    double getTxProbability() const { return txProbability_; }
+    void setTxProbability(double p) { txProbability_ = p; }
+    bool isReceiving() const { return receiving_ != nullptr; }
+    double getRSSI() const; // latched rssi while receiving, else the medium's base RSSI, else -99.99
+    int getReceivingState() const
+    {
+        if (!enabled_) return DISABLED;
+        if (receiving_) return RECEIVING;
+        if (sending_) return TRANSMITTING;
+        return LISTENING;
+    }
+    void setReceiving(const RadioPacket *p, double rssi) { clearSending(); receiving_ = p; receivingRSSI_ = rssi; }
+    void clearReceiving() { receiving_ = nullptr; }
+    void setSending(const RadioPacket *p) { clearReceiving(); sending_ = p; }
+    void clearSending() { sending_ = nullptr; }
+
+private:
+    Node *node_;
+    double txpower_ = 0.0;
+    int channel_ = 26;
+    bool enabled_ = true;
+    const RadioPacket *receiving_ = nullptr, *sending_ = nullptr;
+    double receivingRSSI_ = 0.0;
+    double rxProbability_ = 1.0, txProbability_ = 1.0;
+};
+
+class Node {
+public:
+    Node(const std::string &id, Simulator *sim) : id_(id), sim_(sim), radio_(this)
+    {
+        char *end = nullptr;
+        const long v = std::strtol(id.c_str(), &end, 10);
+        intID_ = (!id.empty() && end && *end == '\0') ? int(v) : -1; // Integer.parseInt failed -> -1
+    }
+    const std::string &getId() const { return id_; }
+    int getIdAsInteger() const { return intID_; }
+    Position &getPosition() { return pos_; }
+    Transciever &getRadio() { return radio_; }
+    Simulator *getSimulator() const { return sim_; }
+    RadioMedium *getRadioMedium() const;
+    int index = -1; // position in Simulator.getNodes() (registration order)
+
+private:
+    std::string id_;
+    int intID_;
+    Simulator *sim_;
+    Position pos_;
+    Transciever radio_;
+};
+
+class RadioPacket {
+public:
+    RadioPacket(Node *node, int64_t time, const std::string &packetData)
+        : node_(node), time_(time), txpower_(node->getRadio().getTransmitPower()),
+          channel_(node->getRadio().getWirelessChannel()), data_(packetData) {}
+    Node *getSource() const { return node_; }
+    int64_t getStartTime() const { return time_; }
+    int64_t getEndTime() const { return time_ + getPacketAirTime(); }
+    int64_t getPacketAirTime() const { return int64_t(data_.size()) * 32; }
+    double getTransmitPower() const { return txpower_; }
+    void setTransmitPower(double p) { txpower_ = p; }
+    int getWirelessChannel() const { return channel_; }
+    void setWirelessChannel(int c) { channel_ = c; }
+    const std::string &getPacketDataAsHex() const { return data_; }
+
+private:
+    Node *node_;
+    int64_t time_;
+    double txpower_;
+    int channel_;
+    std::string data_;
+};
+
+class RadioMedium {
+public:
+    virtual ~RadioMedium() = default;
+    virtual std::string getName() = 0;
+    virtual void setSimulator(Simulator *sim) = 0;
+    virtual void transmit(RadioPacket &packet) = 0;
+    virtual double getBaseRSSI(Node &node) = 0;
+};
+
+// what the medium hands back to the simulation core, recorded in call order
+struct MediumCall {
+    enum Kind { TRANSMISSION_EVENTS, RECEPTION_EVENTS, DELIVER } kind;
+    const RadioPacket *packet;
+    Node *destination;   // null for TRANSMISSION_EVENTS
+    double rssi;
+    bool doDeliver;
+    int64_t timeStart, timeEnd; // Simulator.java:323-333: max(start, currentTime), + air time
+};
+
+class Simulator {
+public:
+    explicit Simulator(int64_t randomSeed = 0) : seed_(randomSeed) {}
+    int64_t getRandomSeed() const { return seed_; }
+    int64_t getTime() const { return currentTime_; }
+    void setTime(int64_t t) { currentTime_ = t; }
+    RadioMedium *getRadioMedium() const { return medium_; }
+    void setRadioMedium(RadioMedium *m)
+    {
+        if (m) m->setSimulator(this);
+        medium_ = m;
+    }
+    Node *getNode(const std::string &id)
+    {
+        auto it = table_.find(id);
+        return it == table_.end() ? nullptr : it->second;
+    }
+    const std::vector<Node *> &getNodes() const { return nodes_; }
+    uint64_t nodesVersion() const { return version_; }
+    void nodesChanged() { ++version_; } // call after changing fields of existing nodes (no hook in the reference)
+    Node *addNode(const std::string &id)
+    {
+        if (Node *n = getNode(id)) return n; // already handled
+        owned_.emplace_back(new Node(id, this));
+        Node *n = owned_.back().get();
+        n->index = int(nodes_.size());
+        nodes_.push_back(n);
+        table_[id] = n;
+        ++version_;
+        return n;
+    }
+    void generateTransmissionEvents(RadioPacket &p) { record(MediumCall::TRANSMISSION_EVENTS, p, nullptr, 0.0, false); }
+    void generateReceptionEvents(RadioPacket &p, Node *dst, double rssi, bool doDeliver)
+    {
+        record(MediumCall::RECEPTION_EVENTS, p, dst, rssi, doDeliver);
+    }
+    void deliverRadioPacket(RadioPacket &p, Node *dst, double rssi) { record(MediumCall::DELIVER, p, dst, rssi, true); }
+    std::vector<MediumCall> calls;
+
+private:
+    void record(MediumCall::Kind k, RadioPacket &p, Node *dst, double rssi, bool deliver)
+    {
+        int64_t t0 = p.getStartTime();
+        if (t0 < currentTime_) t0 = currentTime_;
+        calls.push_back({k, &p, dst, rssi, deliver, t0, t0 + p.getPacketAirTime()});
+    }
+    int64_t seed_;
+    int64_t currentTime_ = 0;
+    RadioMedium *medium_ = nullptr;
+    std::vector<std::unique_ptr<Node>> owned_;
+    std::vector<Node *> nodes_;
+    std::unordered_map<std::string, Node *> table_;
+    uint64_t version_ = 0;
+};
+
+inline RadioMedium *Node::getRadioMedium() const { return sim_->getRadioMedium(); }
+inline double Transciever::getRSSI() const
+{
+    if (isReceiving()) return receivingRSSI_;
+    RadioMedium *m = node_->getRadioMedium();
+    return m ? m->getBaseRSSI(*node_) : -99.99;
+}
+
+class AbstractRadioMedium : public RadioMedium {
+public:
+    void setSimulator(Simulator *sim) override { simulator = sim; }
+    double getBaseRSSI(Node &) override { return baseRSSI; }
+    void setBaseRSSI(double rssi) { baseRSSI = rssi; }
+
+protected:
+    Simulator *simulator = nullptr;
+    double baseRSSI = -100.0;
+};
+
+// One MI355X context behind the RadioMedium contract.
+class GpuRadioMedium : public AbstractRadioMedium {
+public:
+    explicit GpuRadioMedium(int kind, int device = 0) : kind_(kind)
+    {
+        if (rm_create(device, &ctx_) != RM_OK) throw std::runtime_error(std::string("no MI355X radio medium: ") + rm_last_error());
+        rm_model_defaults(&params_, kind);
+        apply();
+    }
+    ~GpuRadioMedium() override { rm_destroy(ctx_); }
+    GpuRadioMedium(const GpuRadioMedium &) = delete;
+    GpuRadioMedium &operator=(const GpuRadioMedium &) = delete;
+
+    std::string getName() override { return rm_get_name(ctx_); }
+    void setSimulator(Simulator *sim) override
+    {
+        simulator = sim;
+        if (sim) rm_seed(ctx_, sim->getRandomSeed()); // Simulator.getRandom(): one generator for all packets
+        uploaded_ = ~0ull;
+    }
+    double getBaseRSSI(Node &n) override { return rm_get_base_rssi(ctx_, n.index); }
+    void setBaseRSSI(double rssi)
+    {
+        baseRSSI = rssi;
+        rm_set_base_rssi(ctx_, rssi);
+    }
+
+    // transmit(): never throws (the reference's returns void); failures are reported through lastError
+    void transmit(RadioPacket &packet) override
+    {
+        lastError.clear();
+        Simulator *sim = simulator;
+        if (!sim) { lastError = "No simulator"; return; }
+        const std::vector<Node *> &nodes = sim->getNodes();
+        if (!sync(sim, nodes)) return;
+        rm_set_time(ctx_, sim->getTime());
+        const double txp = packet.getTransmitPower();
+        const int32_t ch = packet.getWirelessChannel();
+        uint32_t heard = 0;
+        uint8_t interference = 0;
+        const int rc = rm_transmit(ctx_, packet.getSource()->index, packet.getStartTime(),
+                                   int64_t(packet.getPacketDataAsHex().size()), &txp, &ch, dst_.data(), verdict_.data(),
+                                   rssi_.data(), sinr_.data(), uint32_t(dst_.size()), &heard, &interference);
+        if (rc != RM_OK) { lastError = rm_last_error(); return; }
+        lastInterference = interference != 0;
+        if (kind_ != RM_MODEL_UDGM_CONST) sim->generateTransmissionEvents(packet);
+        for (uint32_t i = 0; i < heard; ++i) { // node order, as the reference's for (Node node : nodes)
+            Node *node = nodes[dst_[i]];
+            if (kind_ == RM_MODEL_UDGM_CONST) sim->deliverRadioPacket(packet, node, rssi_[i]);
+            else sim->generateReceptionEvents(packet, node, rssi_[i], verdict_[i] == RM_DELIVERED);
+        }
+    }
+    std::string lastError;
+    bool lastInterference = false;
+
+protected:
+    rm_model_params params_{};
+    void apply()
+    {
+        if (rm_set_model(ctx_, &params_) != RM_OK) throw std::invalid_argument(rm_last_error());
+    }
+    rm_context *ctx_ = nullptr;
+
+private:
+    bool sync(Simulator *sim, const std::vector<Node *> &nodes)
+    {
+        if (uploaded_ == sim->nodesVersion()) return true;
+        const size_t n = nodes.size();
+        std::vector<double> x(n), y(n), z(n), tp(n), rp(n), xp(n);
+        std::vector<int32_t> ch(n), id(n);
+        std::vector<uint8_t> en(n);
+        for (size_t i = 0; i < n; ++i) {
+            Node &nd = *nodes[i];
+            x[i] = nd.getPosition().x; y[i] = nd.getPosition().y; z[i] = nd.getPosition().z;
+            tp[i] = nd.getRadio().getTransmitPower(); ch[i] = nd.getRadio().getWirelessChannel();
+            en[i] = nd.getRadio().isEnabled(); rp[i] = nd.getRadio().getRxProbability();
+            xp[i] = nd.getRadio().getTxProbability(); id[i] = nd.getIdAsInteger();
+        }
+        if (rm_nodes_upload(ctx_, int32_t(n), x.data(), y.data(), z.data(), tp.data(), ch.data(), en.data(), rp.data(),
+                            xp.data(), id.data()) != RM_OK) {
+            lastError = rm_last_error();
+            return false;
+        }
+        dst_.resize(n + 1); verdict_.resize(n + 1); rssi_.resize(n + 1); sinr_.resize(n + 1);
+        uploaded_ = sim->nodesVersion();
+        return true;
+    }
+    int kind_;
+    uint64_t uploaded_ = ~0ull;
+    std::vector<int32_t> dst_;
+    std::vector<uint8_t> verdict_;
+    std::vector<double> rssi_, sinr_;
+};
+
+class NullRadioMedium : public GpuRadioMedium {
+public:
+    explicit NullRadioMedium(int device = 0) : GpuRadioMedium(RM_MODEL_NULL, device) {}
+};
+
+class UDGMRadioMedium : public GpuRadioMedium {
+public:
+    explicit UDGMRadioMedium(int device = 0) : GpuRadioMedium(RM_MODEL_UDGM, device) {}
+    double getSuccessRatioTx() const { return params_.udgm_success_ratio_tx; }
+    void setSuccessRatioTx(double v) { params_.udgm_success_ratio_tx = v; apply(); }
+    double getSuccessRatioRx() const { return params_.udgm_success_ratio_rx; }
+    void setSuccessRatioRx(double v) { params_.udgm_success_ratio_rx = v; apply(); }
+    double getTransmissionRange() const { return params_.udgm_transmission_range; }
+    void setTransmissionRange(double v) { params_.udgm_transmission_range = v; apply(); }
+    double getInterferenceRange() const { return params_.udgm_interference_range; }
+    void setInterferenceRange(double v) { params_.udgm_interference_range = v; apply(); }
+};
+
+class UDGMConstantLossRadioMedium : public GpuRadioMedium {
+public:
+    explicit UDGMConstantLossRadioMedium(int device = 0) : GpuRadioMedium(RM_MODEL_UDGM_CONST, device) {}
+};
+
+class N2NRadioMedium : public GpuRadioMedium {
+public:
+    explicit N2NRadioMedium(const std::vector<std::vector<double>> &m, int device = 0) : GpuRadioMedium(RM_MODEL_N2N, device)
+    {
+        setMatrix(m);
+    }
+    void setMatrix(const std::vector<std::vector<double>> &m)
+    {
+        const size_t n = m.size();
+        std::vector<double> flat(n * n, 0.0);
+        for (size_t i = 0; i < n; ++i)
+            for (size_t j = 0; j < n && j < m[i].size(); ++j) flat[i * n + j] = m[i][j];
+        if (rm_set_n2n_matrix(ctx_, int32_t(n), flat.data()) != RM_OK) throw std::invalid_argument(rm_last_error());
+    }
+};
+
+} // namespace emul8
