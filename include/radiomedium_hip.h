@@ -167,6 +167,22 @@ int rm_tick_flush(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict,
                   uint8_t *pkt_interference /* [n_new] or NULL */,
                   uint32_t *pkt_offset /* [n_new+1] or NULL */);
 
+/* evaluate the enqueued tick without copying anything out (then rm_result_copy / rm_result_device) */
+int rm_tick_run(rm_context *ctx);
+
+/* ---- receiver partitions with probabilistic links --------------------------------------------
+ * The shared java.util.Random is consumed in packet order, then node order = rank order, so a
+ * rank needs every rank's per-packet draw counts before it can place its own draws.  After
+ * rm_tick_run / rm_tick_run_device on a partitioned context whose links may draw,
+ * rm_draws_pending() is 1: all-gather rm_draw_counts_device (uint32[n_new] per rank, rank-major)
+ * and call rm_tick_finish_draws; only then are verdicts, Tx-failure flags and the generator
+ * state final (identical on all ranks). */
+int rm_draws_pending(const rm_context *ctx);
+int rm_draw_counts_device(rm_context *ctx, const uint32_t **dev_counts, int32_t *n_new);
+int rm_draw_counts_to(rm_context *ctx, uint32_t *dev_out); /* async copy into a caller's device buffer */
+int rm_tick_finish_draws(rm_context *ctx, const uint32_t *all_counts /* [world][n_new] */, int32_t world,
+                         int32_t rank, int on_device);
+
 /* ---- device-resident path (bench, multi-GPU): no host copies ------------------------------ */
 /* build tx records for sources `dev_src[0..n)` from the resident node state */
 int rm_pack_tx_device(rm_context *ctx, const int32_t *dev_src, int32_t n, int64_t start_us,

@@ -105,6 +105,11 @@ SIGNATURES = {
     "rm_enqueue_tx_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rm_tick_flush": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
+    "rm_tick_run": (C.c_int, [C.c_void_p]),
+    "rm_draws_pending": (C.c_int, [C.c_void_p]),
+    "rm_draw_counts_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    "rm_draw_counts_to": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rm_tick_finish_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int]),
     "rm_pack_tx_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "rm_pack_tx_device_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "rm_tick_run_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),

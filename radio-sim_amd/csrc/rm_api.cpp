@@ -150,6 +150,9 @@ struct rm_context {
     DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob, d_a_rssi, d_a_sinr, d_a_prob;
     DevBuf<uint32_t> d_draw_scan, d_scan_block;
     DevBuf<uint64_t> d_rng, d_pkt_rng;
+    DevBuf<uint32_t> d_pkt_draw_cnt, d_all_cnt;
+    bool draws_pending = false; // partitioned + probabilistic: waiting for rm_tick_finish_draws
+    rm::ModelDev pending_model{};
     uint32_t alloc_cap = 0;
 
     // last tick
@@ -507,9 +510,8 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     const bool sinr = is_sinr(c);
     const bool stochastic = maybe_draws(c);
     const int rx_count = c->n_rx;
-    if (stochastic && rx_count != c->n)
-        return fail(RM_ERR_STATE, "receiver partitions with probabilistic links (java.util.Random draws) are not "
-                                  "supported yet: the draw order spans the ranks");
+    const bool partitioned = rx_count != c->n;
+    c->draws_pending = false;
 
     rm::TickDev t{};
     t.tx = tx;
@@ -553,6 +555,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     RM_HIP(c->d_slot_off.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
     RM_HIP(c->d_pkt_interf.ensure(std::max(n_new, 1)));
     RM_HIP(c->d_pkt_rng.ensure(std::max(n_new, 1)));
+    RM_HIP(c->d_pkt_draw_cnt.ensure(std::max(n_new, 1)));
     RM_HIP(c->d_head.ensure(std::max(rx_count, 1)));
     if (!c->d_rng.p) {
         RM_HIP(c->d_rng.ensure(1));
@@ -631,6 +634,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     t.scan_block = c->d_scan_block.p;
     t.rng_state = c->d_rng.p;
     t.pkt_rng = c->d_pkt_rng.p;
+    t.pkt_draw_cnt = c->d_pkt_draw_cnt.p;
 
     hipStream_t s = c->stream;
     c->last = t;
@@ -691,7 +695,10 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         }
         if (stochastic) {
             RM_TRY(stage(RM_STAGE_DRAWS));
-            RM_HIP(rm::launch_draws(s, m, t));
+            RM_HIP(rm::launch_draws_scan(s, t));
+            // a receiver partition sees only its share of every packet's draws: the caller exchanges
+            // the per-packet counts (rm_draw_counts_device) and calls rm_tick_finish_draws
+            if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
         }
         if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
         return RM_OK;
@@ -705,7 +712,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         mix(&nd, sizeof(nd));
         mix(&m, sizeof(m));
         mix(&t, sizeof(t));
-        const int bits[6] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, cfg.shadow};
+        const int bits[7] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, cfg.shadow, partitioned};
         mix(bits, sizeof(bits));
         hipGraphExec_t exec = nullptr;
         for (auto &g : c->graphs)
@@ -742,6 +749,10 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
 
     // links resolved: every evaluated frame against every other node (T * (N-1)); for a receiver
     // partition the frame's own source may lie outside it, so the product is reported as is
+    if (stochastic && partitioned) {
+        c->draws_pending = true;
+        c->pending_model = m;
+    }
     c->last_links = (rx_count == c->n) ? int64_t(n_eval) * (rx_count - 1) : int64_t(n_eval) * rx_count;
     c->have_result = true;
     return RM_OK;
@@ -855,7 +866,7 @@ void rm_destroy(rm_context *c)
     c->d_out_dst.release(); c->d_out_verdict.release(); c->d_pkt_interf.release(); c->d_out_rssi.release();
     c->d_out_sinr.release(); c->d_out_prob.release(); c->d_a_pkt.release(); c->d_a_dst.release();
     c->d_a_verdict.release(); c->d_a_rssi.release(); c->d_a_sinr.release(); c->d_a_prob.release();
-    c->d_draw_scan.release(); c->d_scan_block.release(); c->d_rng.release(); c->d_pkt_rng.release();
+    c->d_draw_scan.release(); c->d_scan_block.release(); c->d_rng.release(); c->d_pkt_rng.release(); c->d_pkt_draw_cnt.release(); c->d_all_cnt.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1118,6 +1129,9 @@ int rm_enqueue_tx_records(rm_context *c, const rm_tx_record *recs, int32_t n)
 static int copy_out(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
                     uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
 {
+    if (c->draws_pending)
+        return fail(RM_ERR_STATE, "this rank's verdicts wait for the other ranks' draw counts: exchange "
+                                  "rm_draw_counts_device and call rm_tick_finish_draws first");
     hipStream_t s = c->stream;
     uint32_t oc[3] = {0, 0, 0};
     RM_HIP(hipMemcpyAsync(oc, c->last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
@@ -1147,8 +1161,24 @@ static int copy_out(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict,
     return RM_OK;
 }
 
+static int tick_run_host(rm_context *c);
+
+int rm_tick_run(rm_context *c)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    return tick_run_host(c);
+}
+
 int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
                   uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    RM_TRY(tick_run_host(c));
+    return copy_out(c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+}
+
+// evaluate the tick enqueued with rm_tick_begin / rm_enqueue_tx* (results stay on the device)
+static int tick_run_host(rm_context *c)
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     if (!c->in_tick) return fail(RM_ERR_STATE, "rm_tick_flush without rm_tick_begin");
@@ -1167,7 +1197,7 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
     RM_TRY(run_tick(c, c->d_tx.p, int(all.size()), first_new));
     if (is_sinr(c)) c->onair.swap(all);
     c->pending.clear();
-    return copy_out(c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+    return RM_OK;
 }
 
 int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length, const double *txpower,
@@ -1235,6 +1265,45 @@ int rm_result_device(rm_context *c, rm_device_result *out)
     out->rssi = c->d_out_rssi.p;
     out->sinr = c->d_out_sinr.p;
     out->capacity = c->cap;
+    return RM_OK;
+}
+
+int rm_draws_pending(const rm_context *c) { return (c && c->draws_pending) ? 1 : 0; }
+
+int rm_draw_counts_device(rm_context *c, const uint32_t **dev_counts, int32_t *n_new)
+{
+    if (!c || !dev_counts) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    *dev_counts = c->d_pkt_draw_cnt.p;
+    if (n_new) *n_new = c->last_n_new;
+    return RM_OK;
+}
+
+int rm_draw_counts_to(rm_context *c, uint32_t *dev_out)
+{
+    if (!c || !dev_out) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    if (c->last_n_new > 0)
+        RM_HIP(hipMemcpyAsync(dev_out, c->d_pkt_draw_cnt.p, size_t(c->last_n_new) * 4, hipMemcpyDeviceToDevice, c->stream));
+    return RM_OK;
+}
+
+int rm_tick_finish_draws(rm_context *c, const uint32_t *all_counts, int32_t world, int32_t rank, int on_device)
+{
+    if (!c || !all_counts || world < 1 || rank < 0 || rank >= world) return fail(RM_ERR_INVALID, "bad arguments");
+    if (!c->draws_pending) return fail(RM_ERR_STATE, "no tick is waiting for draw counts");
+    RM_HIP(hipSetDevice(c->device));
+    const uint32_t *dev = all_counts;
+    if (!on_device) {
+        const size_t n = size_t(world) * std::max(c->last_n_new, 1);
+        RM_HIP(c->d_all_cnt.ensure(n));
+        RM_HIP(hipMemcpyAsync(c->d_all_cnt.p, all_counts, size_t(world) * c->last_n_new * 4, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream)); // the caller's buffer may go away
+        dev = c->d_all_cnt.p;
+    }
+    RM_HIP(rm::launch_draws_apply(c->stream, c->pending_model, c->last, dev, world, rank));
+    c->draws_pending = false;
     return RM_OK;
 }
 

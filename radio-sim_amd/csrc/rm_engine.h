@@ -139,7 +139,8 @@ struct TickDev {
     uint32_t *draw_scan;    // [cap+1]
     uint32_t *scan_block;   // scratch for the generic scan
     uint64_t *rng_state;    // [1] java.util.Random state (48 bit)
-    uint64_t *pkt_rng;      // [n_new] state before the packet's receiver draws
+    uint64_t *pkt_rng;      // [n_new] state before this rank's receiver draws of the packet
+    uint32_t *pkt_draw_cnt; // [n_new] receiver draws of this rank for the packet
 };
 
 struct LaunchCfg {
@@ -165,7 +166,9 @@ hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m,
                            const LaunchCfg &cfg);
 hipError_t launch_seg_scan(hipStream_t s, const TickDev &t);
 hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg);
-hipError_t launch_draws(hipStream_t s, const ModelDev &m, const TickDev &t);
+hipError_t launch_draws_scan(hipStream_t s, const TickDev &t);
+hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
+                              int rank);
 
 // host-side mirrors of device math used for constants (rm_kernels.hip, __host__ __device__)
 double host_det_pow10(double y);

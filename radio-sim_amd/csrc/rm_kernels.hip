@@ -1280,28 +1280,52 @@ __global__ void __launch_bounds__(256) k_draw_scan(TickDev t)
     }
 }
 
+// per-packet number of receiver draws this rank would consume (if the packet's Tx does not fail)
+__global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t)
+{
+    const int n_new = t.n_active - t.first_new;
+    const uint32_t n = t.out_count[0];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_new) return;
+    const uint32_t b = min(t.slot_off[q + t.shift], n);
+    const uint32_t e = min(t.slot_off[q + t.shift + 1], n);
+    t.pkt_draw_cnt[q] = t.draw_scan[e] - t.draw_scan[b];
+}
+
 // The only sequential part: the shared generator is consumed packet after packet
 // (Simulator.getRandom(); UDGMRadioMedium.java:85-92,106).  One workgroup: the per-packet jump
-// maps are built in parallel, then one lane walks the packets.
-__global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t)
+// maps are built in parallel, then one lane walks the packets.  Receiver-sharded ranks all run
+// the same chain on the all-gathered per-(rank, packet) draw counts `all_cnt[world][n_new]`: a
+// packet's receivers are visited in node order = rank order, so this rank's first draw of packet q
+// comes after the draws of the lower ranks, and the generator moves on by the sum over all ranks.
+__global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const uint32_t *all_cnt, int world, int rank)
 {
-    __shared__ uint64_t s_A[1024], s_C[1024];
+    __shared__ uint64_t s_A[1024], s_C[1024], s_Ab[1024], s_Cb[1024];
     __shared__ double s_txs[1024];
     __shared__ uint64_t s_state;
     const int n_new = t.n_active - t.first_new;
-    const uint32_t n = t.out_count[0];
     if (threadIdx.x == 0) s_state = *t.rng_state & kLcgMask;
     __syncthreads();
     for (int base = 0; base < n_new; base += 1024) {
         const int q = base + threadIdx.x;
         if (q < n_new) {
-            const uint32_t b = min(t.slot_off[q + t.shift], n);
-            const uint32_t e = min(t.slot_off[q + t.shift + 1], n);
-            const uint32_t draws = t.draw_scan[e] - t.draw_scan[b];
+            uint64_t total = 0, before = 0;
+            if (all_cnt) {
+                for (int r = 0; r < world; ++r) {
+                    const uint32_t v = all_cnt[size_t(r) * n_new + q];
+                    if (r < rank) before += v;
+                    total += v;
+                }
+            } else {
+                total = t.pkt_draw_cnt[q];
+            }
             uint64_t A, C;
-            lcg_jump_map(2ull * draws, A, C);
+            lcg_jump_map(2ull * total, A, C);
             s_A[threadIdx.x] = A;
             s_C[threadIdx.x] = C;
+            lcg_jump_map(2ull * before, A, C);
+            s_Ab[threadIdx.x] = A;
+            s_Cb[threadIdx.x] = C;
             s_txs[threadIdx.x] = tx_success(m, t.tx[t.first_new + q]);
         }
         __syncthreads();
@@ -1317,7 +1341,7 @@ __global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t)
                     if (lcg_next_double(s) > txs) interference = true;
                 }
                 t.pkt_interference[base + i] = interference ? 1 : 0;
-                t.pkt_rng[base + i] = s;
+                t.pkt_rng[base + i] = (s_Ab[i] * s + s_Cb[i]) & kLcgMask; // this rank's first receiver draw
                 if (!interference) s = (s_A[i] * s + s_C[i]) & kLcgMask;
             }
             s_state = s;
@@ -1500,13 +1524,23 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
     return hipGetLastError();
 }
 
-hipError_t launch_draws(hipStream_t s, const ModelDev &m, const TickDev &t)
+// draws, part 1: which ordered records need a draw, and how many per packet
+hipError_t launch_draws_scan(hipStream_t s, const TickDev &t)
 {
     const int tiles = cdiv(int(t.cap), kScanTile);
+    const int n_new = t.n_active - t.first_new;
     hipLaunchKernelGGL(k_draw_tile_sums, dim3(tiles), dim3(256), 0, s, t);
     hipLaunchKernelGGL(k_draw_tile_scan, dim3(1), dim3(1024), 0, s, t);
     hipLaunchKernelGGL(k_draw_scan, dim3(tiles), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t);
+    hipLaunchKernelGGL(k_pkt_draw_counts, dim3(max(1, cdiv(n_new, 256))), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
+// draws, part 2: walk the generator over the packets, then every flagged record draws at its place
+hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
+                              int rank)
+{
+    hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, rank);
     hipLaunchKernelGGL(k_apply_draws, dim3(1024), dim3(256), 0, s, t);
     return hipGetLastError();
 }

@@ -116,6 +116,7 @@ class ShardedTick:
         self.done = [torch.cuda.Event() for _ in range(2)]    # the sweep that read the buffer has finished
         self.used = [False, False]
         self.staged = None
+        self.cnt_mine = self.cnt_all = None
 
     def stage(self, dev_src_ptr, t_begin, air_us):
         """Enqueue packing + all-gather of a tick on the communication stream."""
@@ -140,6 +141,21 @@ class ShardedTick:
         b, t_begin = staged
         self.compute.wait_event(self.ready[b])
         self.eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
+        if self.eng.draws_pending():
+            # probabilistic links: the shared java.util.Random is consumed in node order = rank order;
+            # one more tiny all-gather (per-packet draw counts), then every rank places its draws
+            torch = self.torch
+            n_new = self.world * self.slots
+            if self.cnt_mine is None or self.cnt_mine.numel() != n_new:
+                self.cnt_mine = torch.empty(n_new, dtype=torch.int32, device=self.all[b].device)
+                self.cnt_all = torch.empty(self.world * n_new, dtype=torch.int32, device=self.all[b].device)
+            with torch.cuda.stream(self.compute):
+                self.eng.draw_counts_to(self.cnt_mine.data_ptr())
+                if self.world > 1:
+                    self.dist.all_gather_into_tensor(self.cnt_all, self.cnt_mine)
+                else:
+                    self.cnt_all.copy_(self.cnt_mine, non_blocking=True)
+                self.eng.finish_draws(self.cnt_all.data_ptr(), self.world, self.rank)
         self.done[b].record(self.compute)
         self.used[b] = True
 

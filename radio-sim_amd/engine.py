@@ -170,6 +170,29 @@ class Engine:
         k = cnt.value
         return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
 
+    def tick_run(self):
+        """Evaluate the enqueued tick; results stay on the device (result_copy / result_device)."""
+        check(self._L.rm_tick_run(self._h))
+
+    def draws_pending(self):
+        return bool(self._L.rm_draws_pending(self._h))
+
+    def draw_counts_device(self):
+        p, n = C.c_void_p(), C.c_int32()
+        check(self._L.rm_draw_counts_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def draw_counts_to(self, dev_out_ptr):
+        check(self._L.rm_draw_counts_to(self._h, C.c_void_p(dev_out_ptr)))
+
+    def finish_draws(self, all_counts, world, rank):
+        """all_counts: host uint32 array [world, n_new] or a device pointer (int)."""
+        if isinstance(all_counts, int):
+            check(self._L.rm_tick_finish_draws(self._h, C.c_void_p(all_counts), world, rank, 1))
+        else:
+            a = np.ascontiguousarray(all_counts, dtype=np.uint32)
+            check(self._L.rm_tick_finish_draws(self._h, a.ctypes.data, world, rank, 0))
+
     def tick(self, recs, t_begin=0, t_end=0, cap=None):
         self.tick_begin(t_begin, t_end)
         self.enqueue_records(recs)

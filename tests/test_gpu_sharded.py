@@ -60,21 +60,72 @@ def test_sharded_equals_global(rsa, O, kind, params, world):
     np.testing.assert_array_equal(sinr, ref.sinr)
 
 
-def test_partition_with_draws_is_refused(rsa, O):
-    """Probabilistic links need the global draw order: refused loudly, never silently wrong."""
-    nd = O.NodeTable(200)
-    nd.x = np.arange(200.0)
-    nd.rxprob[:] = 0.5
-    eng = rsa.Engine(0)
+@pytest.mark.parametrize("kind,params", [("udgm", {"udgm_success_ratio_rx": 0.7}), ("logdist", {"ld_sigma_db": 3.0, "ld_seed": 2}),
+                                         ("n2n", {})])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_probabilistic_links_follow_the_global_draw_order(rsa, O, kind, params, world):
+    """Receiver partitions with java.util.Random draws: every rank runs the sweep, the per-packet
+    draw counts are exchanged (the all-gather), rm_tick_finish_draws places each rank's draws after
+    the lower ranks' -- verdicts, Tx-failure flags and the generator state equal the one-process
+    oracle, on every rank."""
+    from radio_sim_amd import dist as D
+    from util import DeviceArray
+    n = 1500
+    rng = np.random.default_rng(5)
+    nd = O.NodeTable(n)
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    nd.rxprob[:] = np.where(rng.random(n) < 0.4, 1.0, rng.uniform(0, 1, n))
+    nd.txprob[:] = np.where(rng.random(n) < 0.5, 1.0, rng.uniform(0, 1.1, n))
+    matrix = np.where(rng.random((n, n)) < 0.02, rng.uniform(0, 1.2, (n, n)), 0.0) if kind == "n2n" else None
+    ticks = [np.sort(rng.choice(n, 70, replace=False)).astype(np.int32) for _ in range(3)]
+    engines = []
     try:
-        eng.upload_table(nd)
-        eng.set_model(rsa.MODEL_UDGM)
-        eng.set_partition(0, 100)
-        with pytest.raises(rsa.RadioMediumError) as e:
-            eng.tick(to_tx_records(rsa, nd.packets([5])))
-        assert e.value.code == -5
+        for r in range(world):
+            lo, hi = D.partition(n, r, world)
+            eng = rsa.Engine(0)
+            eng.upload_table(nd)
+            eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            if matrix is not None:
+                eng.set_n2n_matrix(matrix)
+            eng.set_partition(lo, hi - lo)
+            eng.seed(77)
+            engines.append(eng)
+        state = O.lib().orc_jrandom_seed(77)
+        mdl = oracle_model(O, kind, params, matrix)
+        for k, srcs in enumerate(ticks):
+            pk = nd.packets(srcs, 1000 * k, 8128)
+            recs = to_tx_records(rsa, pk)
+            counts = []
+            for eng in engines:
+                eng.tick_begin(1000 * k, 1000 * k + 1000)
+                eng.enqueue_records(recs)
+                eng.tick_run()
+                assert eng.draws_pending()
+                with pytest.raises(rsa.RadioMediumError):      # not final yet
+                    eng.result_copy(len(srcs))
+                ptr, n_new = eng.draw_counts_device()
+                counts.append(DeviceArray.read(ptr, np.uint32, n_new))
+            allc = np.stack(counts)                              # what the all-gather delivers
+            shards = []
+            for r, eng in enumerate(engines):
+                eng.finish_draws(allc, world, r)
+                res = eng.result_copy(len(srcs))
+                shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
+                last = res
+            merged = D.merge_shard_links(shards, len(srcs))
+            ref = O.tick(mdl, nd, pk, rng_state=state)
+            state = ref.rng_state
+            assert ref.pkt_draws.sum() > 100
+            np.testing.assert_array_equal(merged[0], ref.pkt)
+            np.testing.assert_array_equal(merged[1], ref.dst)
+            np.testing.assert_array_equal(merged[2], ref.verdict)
+            np.testing.assert_array_equal(last.pkt_interference, ref.pkt_interference)
+            for eng in engines:
+                assert eng.rng_state == state
     finally:
-        eng.close()
+        for eng in engines:
+            eng.close()
 
 
 def test_pipelined_sharded_driver_on_one_gpu():

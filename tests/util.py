@@ -92,6 +92,16 @@ class DeviceArray:
             a = np.ascontiguousarray(host_array)
             assert self._hip.hipMemcpy(self.ptr, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0   # H2D
 
+    @staticmethod
+    def read(ptr, dtype, count):
+        """device pointer -> numpy array (D2H through the same runtime)"""
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so.7")
+        out = np.empty(count, dtype=dtype)
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0   # D2H
+        return out
+
     def free(self):
         if self.ptr:
             self._hip.hipFree(self.ptr)
