@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- Tx->Rx link evaluations per second of the MI355X radio-medium engine.
 
+On one GPU `--inflight` ticks (default 3) are in flight at once, each on its own engine context and
+stream: the benchmarked medium carries no state from tick to tick (no on-air list, no random draws
+with the reference's default probabilities), a tick of this size is a ~34 us chain of dependent
+kernel launches that leaves the device mostly idle, and independent ticks hide each other's
+latencies.  The strictly sequential rate (one tick at a time, what a closed-loop simulation sees)
+is measured in the same run and printed as "sequential_ticks".
+
 A "step" is one simulated tick: T = 1% of N nodes transmit a 127-byte frame; the engine
 evaluates all T x (N-1) links (log-distance path loss + log-normal shadowing, BASELINE.json
 configs[2]: 100k nodes, 1% concurrent Tx) and leaves the ordered heard-link records
@@ -43,6 +50,13 @@ WORKLOADS = {
 }
 
 
+def baseline_metric():
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except (OSError, ValueError, KeyError):
+        return "Tx->Rx link evaluations/sec at N nodes, 1% concurrent-Tx; 1/2/4/8 GPUs"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +65,9 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="ticks in flight on one GPU (one engine context + stream each; ticks are independent "
+                         "for the media without an on-air list)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the pipelined multi-GPU tick driver even on one GPU (testing)")
@@ -127,12 +144,18 @@ def main():
     kind_name, kw = W.model_kwargs(model)
     kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
 
-    eng = rsa.Engine(local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    eng.set_stream(stream.cuda_stream)
-    eng.upload_table(nodes)
-    eng.set_model(kind, **kw)
-    eng.set_link_capacity(1 << 21)
+    inflight = max(1, args.inflight) if world == 1 and not args.force_sharded else 1
+    engines, streams = [], []
+    for _ in range(inflight):
+        e = rsa.Engine(local_rank)
+        st = torch.cuda.Stream(device=dev)
+        e.set_stream(st.cuda_stream)
+        e.upload_table(nodes)
+        e.set_model(kind, **kw)
+        e.set_link_capacity(1 << 21)
+        engines.append(e)
+        streams.append(st)
+    eng, stream = engines[0], streams[0]
 
     # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
     lo = (n * rank) // world
@@ -164,7 +187,8 @@ def main():
                 for k in range(k0, k1):
                     t0 = k * W.TICK_US
                     # one call: the frames' Tx records are built from the resident node state inside the sweep
-                    eng.tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+                    engines[k % inflight].tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick,
+                                                                  t0, W.AIR_US)
             else:
                 if k1 > k0:
                     sharded.stage(src_dev[k0].data_ptr(), k0 * W.TICK_US, W.AIR_US)
@@ -175,7 +199,8 @@ def main():
                     sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
 
     def fence():
-        stream.synchronize()
+        for st in streams:
+            st.synchronize()
         torch.cuda.synchronize()   # includes the communication stream
         if world > 1:
             dist.barrier()
@@ -207,6 +232,20 @@ def main():
     links_per_tick = t_per_tick * (n - 1)
     value = links_per_tick * args.steps / elapsed
 
+    sequential = None
+    if inflight > 1:
+        # the same ticks again, one at a time on one context
+        fence()
+        t_seq = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for k in range(args.warmup, ticks):
+                t0 = k * W.TICK_US
+                eng.tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+        fence()
+        el = time.perf_counter() - t_seq
+        sequential = {"ticks_in_flight": 1, "value": links_per_tick * args.steps / el, "unit": "links/s",
+                      "ms_per_step": el / args.steps * 1e3}
+
     if rank == 0:
         # Roofline of the dominant kernel on this rank.  Per-stage durations
         # come from HIP events recorded on the engine's stream around every stage of each
@@ -231,7 +270,7 @@ def main():
         except (OSError, ValueError):
             pass
         out = {
-            "metric": "Tx->Rx link evaluations/sec",
+            "metric": baseline_metric(),
             "value": value,
             "unit": "links/s",
             "n_gpus": world,
@@ -243,7 +282,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US,
+            "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight,
                        "air_us": W.AIR_US, "model": model, "heard_links_last_tick": heard_total,
                        "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per tick, "
                                     "overlapped with the previous tick's sweep" % world) if world > 1 else "none"},
@@ -258,13 +297,16 @@ def main():
                          "note": "a tick of this size moves ~5 MB through 5 short dependent kernels: latency-bound, "
                                  "not bandwidth-bound; see DESIGN.md section 5 and profiles/README.md"},
         }
+        if sequential is not None:
+            out["sequential_ticks"] = sequential
         if world == 1 and not args.no_cpu_baseline:
             st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
             out["cpu_baseline"] = st
             out["cpu_baseline_all_cores"] = mt
         print(json.dumps(out))
         sys.stdout.flush()
-    eng.close()
+    for e in engines:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 

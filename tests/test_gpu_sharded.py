@@ -141,7 +141,7 @@ def test_pipelined_sharded_driver_on_one_gpu():
     outs = []
     for extra in ([], ["--force-sharded"]):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "40",
-                            "--warmup", "5", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
+                            "--warmup", "5", "--no-cpu-baseline", "--inflight", "1"] + extra, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
         outs.append(json.loads(line))
