@@ -1,0 +1,119 @@
+"""Parity and size-independent properties at BASELINE.json's full sizes (configs[2]: 100k nodes /
+1000 frames per tick; the 1M-node layout of configs[4]), synthetic inputs of SURVEY.md section 8d."""
+import numpy as np
+import pytest
+
+from util import to_tx_records, KINDS, _PARAM_MAP, oracle_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(rsa, O, n, idx, kind, params):
+    from radio_sim_amd import workload as W
+    src_nd = W.make_nodes(n, idx)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = src_nd.x, src_nd.y
+    eng = rsa.Engine(0)
+    eng.upload_table(nd)
+    eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
+    return nd, eng, W
+
+
+def test_c3_full_tick_equals_oracle(rsa, O):
+    """100k nodes, 1000 concurrent frames, log-distance + shadowing: one whole tick, bit for bit."""
+    params = {"ld_sigma_db": 4.0, "ld_seed": 0xC0FFEE}
+    nd, eng, W = _setup(rsa, O, 100_000, 3, "logdist", params)
+    try:
+        srcs = W.choose_sources(100_000, 1000, 0xC0FFEE03, 0)
+        pk = nd.packets(srcs, 0, W.AIR_US)
+        gpu = eng.tick(to_tx_records(rsa, pk), cap=1 << 20)
+        cpu = O.tick(oracle_model(O, "logdist", params), nd, pk, cap=1 << 20)
+        assert cpu.count > 30_000 and gpu.count == cpu.count
+        np.testing.assert_array_equal(gpu.pkt, cpu.pkt)
+        np.testing.assert_array_equal(gpu.dst, cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+        np.testing.assert_array_equal(gpu.rssi, cpu.rssi)
+        # structure: packet-major, receiver ascending inside a packet, offsets consistent
+        assert np.all(np.diff(gpu.pkt) >= 0)
+        same = np.diff(gpu.pkt) == 0
+        assert np.all(np.diff(gpu.dst)[same] > 0)
+        assert gpu.pkt_offset[0] == 0 and gpu.pkt_offset[-1] == gpu.count
+        np.testing.assert_array_equal(np.diff(gpu.pkt_offset.astype(np.int64)), np.bincount(gpu.pkt, minlength=1000))
+        # idempotence / determinism: the unordered staging never leaks into the result
+        for _ in range(3):
+            again = eng.tick(to_tx_records(rsa, pk), cap=1 << 20)
+            assert again.count == gpu.count and np.array_equal(again.dst, gpu.dst) and np.array_equal(again.rssi, gpu.rssi)
+    finally:
+        eng.close()
+
+
+def test_c3_udgm_reference_medium_full_tick(rsa, O):
+    nd, eng, W = _setup(rsa, O, 100_000, 3, "udgm", {})
+    try:
+        srcs = W.choose_sources(100_000, 1000, 0xC0FFEE03, 7)
+        pk = nd.packets(srcs, 7000, W.AIR_US)
+        gpu = eng.tick(to_tx_records(rsa, pk), cap=1 << 20)
+        cpu = O.tick(oracle_model(O, "udgm", {}), nd, pk, cap=1 << 20)
+        assert cpu.count > 15_000 and gpu.count == cpu.count
+        np.testing.assert_array_equal(gpu.pkt, cpu.pkt)
+        np.testing.assert_array_equal(gpu.dst, cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+        # reciprocity of the unit disc: i hears j  <=>  j hears i   (equal channels, all enabled)
+        a = srcs[:200]
+        fwd = eng.tick(to_tx_records(rsa, nd.packets(a)), cap=1 << 20)
+        pairs = set(zip(a[fwd.pkt].tolist(), fwd.dst.tolist()))
+        back_src = np.unique(fwd.dst)[:1500]
+        back = eng.tick(to_tx_records(rsa, nd.packets(back_src)), cap=1 << 20)
+        heard_back = set(zip(back_src[back.pkt].tolist(), back.dst.tolist()))
+        for (i, j) in list(pairs)[:3000]:
+            if j in set(back_src.tolist()):
+                assert (j, i) in heard_back
+    finally:
+        eng.close()
+
+
+def test_range_monotonicity_and_capacity_at_full_size(rsa, O):
+    """heard(range r) is a subset of heard(range r' > r); a too small link capacity is reported,
+    never silently truncated."""
+    nd, eng, W = _setup(rsa, O, 100_000, 3, "udgm", {})
+    try:
+        srcs = W.choose_sources(100_000, 300, 1, 1)
+        recs = to_tx_records(rsa, nd.packets(srcs))
+        small = eng.tick(recs, cap=1 << 20)
+        eng.set_model(KINDS["udgm"], udgm_transmission_range=80.0)
+        big = eng.tick(recs, cap=1 << 20)
+        s = set(zip(small.pkt.tolist(), small.dst.tolist()))
+        b = set(zip(big.pkt.tolist(), big.dst.tolist()))
+        assert s < b and len(b) > 2 * len(s)
+        eng.set_link_capacity(1000)
+        with pytest.raises(rsa.RadioMediumError) as e:
+            eng.tick(recs, cap=1 << 20)
+        assert e.value.code == -4
+    finally:
+        eng.close()
+
+
+def test_one_million_nodes_sampled_against_oracle(rsa, O):
+    """1M-node layout (configs[4] size): a tick of 1000 frames; 12 sampled packets are checked link by
+    link against the oracle, the rest through counts and ordering."""
+    params = {"ld_sigma_db": 4.0, "ld_seed": 5}
+    n = 1_000_000
+    nd, eng, W = _setup(rsa, O, n, 5, "logdist", params)
+    try:
+        srcs = W.choose_sources(n, 1000, 0xC0FFEE05, 0)
+        pk = nd.packets(srcs, 0, W.AIR_US)
+        gpu = eng.tick(to_tx_records(rsa, pk), cap=1 << 20)
+        assert gpu.count > 30_000
+        assert np.all(np.diff(gpu.pkt) >= 0) and gpu.pkt_offset[-1] == gpu.count
+        sample = np.arange(0, 1000, 83)
+        cpu = O.tick(oracle_model(O, "logdist", params), nd, pk[sample], cap=1 << 20)
+        sel = np.isin(gpu.pkt, sample)
+        remap = {int(q): i for i, q in enumerate(sample)}
+        got_pkt = np.array([remap[int(q)] for q in gpu.pkt[sel]], dtype=np.int32)
+        assert cpu.count == sel.sum() > 300
+        np.testing.assert_array_equal(got_pkt, cpu.pkt)
+        np.testing.assert_array_equal(gpu.dst[sel], cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict[sel], cpu.verdict)
+        np.testing.assert_array_equal(gpu.rssi[sel], cpu.rssi)
+    finally:
+        eng.close()
