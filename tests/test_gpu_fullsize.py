@@ -117,3 +117,83 @@ def test_one_million_nodes_sampled_against_oracle(rsa, O):
         np.testing.assert_array_equal(gpu.rssi[sel], cpu.rssi)
     finally:
         eng.close()
+
+
+def _sampled_sinr_check(O, mdl, nd, onair_all, new_all, gpu, sample):
+    """Oracle verdicts for the sampled new frames, with every other on-air frame as interferer."""
+    others = np.delete(np.arange(len(new_all)), sample)
+    active = np.concatenate([onair_all, new_all[others], new_all[sample]])
+    cpu = O.tick(mdl, nd, active, first_new=len(active) - len(sample), cap=1 << 20)
+    sel = np.isin(gpu.pkt, sample)
+    remap = {int(q): i for i, q in enumerate(sample)}
+    got_pkt = np.array([remap[int(q)] for q in gpu.pkt[sel]], dtype=np.int32)
+    assert cpu.count == sel.sum() > 100
+    np.testing.assert_array_equal(got_pkt, cpu.pkt)
+    np.testing.assert_array_equal(gpu.dst[sel], cpu.dst)
+    np.testing.assert_array_equal(gpu.verdict[sel], cpu.verdict)
+    np.testing.assert_array_equal(gpu.rssi[sel], cpu.rssi)
+    np.testing.assert_array_equal(gpu.sinr[sel], cpu.sinr)
+    return cpu
+
+
+def test_c4_16_channels_sinr_capture_full_size(rsa, O):
+    """BASELINE configs[3]: 100k nodes, 5% concurrent Tx (5000 frames), 16 channels, co-channel SINR
+    capture -- one full tick on the GPU; 24 sampled frames checked against the oracle with all 5000
+    frames as potential interferers."""
+    from radio_sim_amd import workload as W
+    n, t = 100_000, 5000
+    src_nd = W.make_nodes(n, 4, channels16=True)
+    nd = O.NodeTable(n)
+    nd.x, nd.y, nd.channel = src_nd.x, src_nd.y, src_nd.channel
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 0xC0FFEE}
+    eng = rsa.Engine(0)
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+        srcs = W.choose_sources(n, t, 0xC0FFEE04, 0)
+        pk = nd.packets(srcs, 0, W.AIR_US)
+        pk["start_us"] = np.random.default_rng(4).integers(0, 1000, t)
+        eng.tick_begin(0, 1000)
+        eng.enqueue_records(to_tx_records(rsa, pk))
+        gpu = eng.tick_flush(cap=1 << 21)
+        assert gpu.count > 10_000          # 5000 frames x ~44 neighbours / 16 channels
+        frac_interfered = (gpu.verdict == rsa.INTERFERED).mean()
+        assert 0.005 < frac_interfered < 0.6
+        sample = np.arange(0, t, 50)
+        _sampled_sinr_check(O, oracle_model(O, "logdist", params), nd, pk[:0], pk, gpu, sample)
+    finally:
+        eng.close()
+
+
+def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
+    """BASELINE configs[4] shape: 1M nodes, 0.1% new frames per tick (1000), 8128 us frames over
+    1000 us ticks: the on-air list grows over the ticks; SINR with time overlap.  Three ticks; the
+    third is checked (sampled) against the oracle with the full on-air list."""
+    from radio_sim_amd import workload as W
+    n, t = 1_000_000, 1000
+    src_nd = W.make_nodes(n, 5)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = src_nd.x, src_nd.y
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 11}
+    eng = rsa.Engine(0)
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+        rng = np.random.default_rng(5)
+        onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+        for tick in range(3):
+            t0 = tick * 1000
+            onair = onair[onair["start_us"] + onair["air_us"] > t0]
+            srcs = W.choose_sources(n, t, 0xC0FFEE05, tick)
+            new = nd.packets(srcs, 0, W.AIR_US)
+            new["start_us"] = t0 + rng.integers(0, 1000, t)
+            eng.tick_begin(t0, t0 + 1000)
+            eng.enqueue_records(to_tx_records(rsa, new))
+            gpu = eng.tick_flush(cap=1 << 20)
+            assert gpu.count > 30_000
+            if tick == 2:
+                assert len(onair) == 2000
+                _sampled_sinr_check(O, oracle_model(O, "logdist", params), nd, onair, new, gpu, np.arange(0, t, 67))
+            onair = np.concatenate([onair, new])
+    finally:
+        eng.close()
