@@ -126,13 +126,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RM_FORCE_DEVICE / RM_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with one GPU
+    device_ordinal = int(os.environ.get("RM_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("RM_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(device_ordinal)
+    dev = torch.device("cuda", device_ordinal)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     idx, n, frac, model, desc = WORKLOADS[args.workload]
     if world > 1 and args.scaling == "weak":
@@ -147,7 +153,7 @@ def main():
     inflight = max(1, args.inflight) if world == 1 and not args.force_sharded else 1
     engines, streams = [], []
     for _ in range(inflight):
-        e = rsa.Engine(local_rank)
+        e = rsa.Engine(device_ordinal)
         st = torch.cuda.Stream(device=dev)
         e.set_stream(st.cuda_stream)
         e.upload_table(nodes)
@@ -220,10 +226,11 @@ def main():
         raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        hsum = torch.tensor([heard], dtype=torch.float64, device=dev)
+        hsum = torch.tensor([heard], dtype=torch.float64, device=rdev)
         dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
         heard_total = float(hsum.item())
     else:

@@ -59,8 +59,15 @@ def all_gather_records(dist, local, world, out=None):
     import torch
     if out is None:
         out = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
-    if local.is_cuda:
+    if local.is_cuda and dist.get_backend() != "gloo":
         dist.all_gather_into_tensor(out, local)
+    elif local.is_cuda:
+        # rehearsal on a box without RCCL peers (gloo): stage through the host, synchronously
+        torch.cuda.current_stream(local.device).synchronize()
+        host = local.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        out.copy_(torch.cat(parts).to(local.device))
     else:
         parts = list(out.view(world, local.numel()).unbind(0))
         dist.all_gather(parts, local)
