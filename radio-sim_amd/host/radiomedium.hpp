@@ -207,6 +207,50 @@ private:
     uint64_t version_ = 0;
 };
 
+// The receiver-side state machine the verdicts drive (events/ReceptionEvent.java:12-46,
+// events/TransmissionEvent.java:18-26): the start flank latches packet + rssi (and clears a pending
+// transmission), the end flank clears the reception -- whichever packet it belongs to -- and
+// delivers only in delivery mode.
+enum class ReceptionMode { start, interference, delivery };
+
+struct ReceptionEvent {
+    int64_t time;
+    Simulator *simulator;
+    RadioPacket *packet;
+    Node *destination;
+    double rssi;
+    ReceptionMode mode;
+    void execute(int64_t /*currentTime*/)
+    {
+        Transciever &t = destination->getRadio();
+        if (mode == ReceptionMode::start) {
+            t.setReceiving(packet, rssi);
+        } else {
+            t.clearReceiving();
+            if (mode == ReceptionMode::delivery) simulator->deliverRadioPacket(*packet, destination, rssi);
+        }
+    }
+};
+
+struct TransmissionEvent {
+    int64_t time;
+    RadioPacket *packet;
+    bool isStart;
+    void execute(int64_t /*currentTime*/)
+    {
+        Transciever &t = packet->getSource()->getRadio();
+        if (isStart) t.setSending(packet);
+        else t.clearSending();
+    }
+};
+
+// the two events generateReceptionEvents queues for one heard link (Simulator.java:321-335)
+inline void makeReceptionEvents(Simulator &sim, const MediumCall &c, RadioPacket &p, ReceptionEvent &startEv, ReceptionEvent &endEv)
+{
+    startEv = {c.timeStart, &sim, &p, c.destination, c.rssi, ReceptionMode::start};
+    endEv = {c.timeEnd, &sim, &p, c.destination, c.rssi, c.doDeliver ? ReceptionMode::delivery : ReceptionMode::interference};
+}
+
 inline RadioMedium *Node::getRadioMedium() const { return sim_->getRadioMedium(); }
 inline double Transciever::getRSSI() const
 {
