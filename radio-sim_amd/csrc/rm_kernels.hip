@@ -1401,7 +1401,11 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
 {
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
-    const dim3 grid(cdiv(t.n_slabs, kWavesPerBlock), cdiv(n_eval, kTxChunk));
+    // XCD-aware launch: workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest),
+    // so with gridDim.x a multiple of 8 every tile-workgroup of one receiver slab has the same
+    // blockIdx.x % 8 -- one XCD, one L2 -- and the slab's records leave HBM once per tick, not once
+    // per XCD (placement is a speed matter only; the padding workgroups exit at once)
+    const dim3 grid((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8, cdiv(n_eval, kTxChunk));
     const dim3 block(kBlock);
 #define RM_LAUNCH(RPT, F64, BBOX, SH) hipLaunchKernelGGL((k_filter<RPT, F64, BBOX, SH>), grid, block, 0, s, nd, m, t)
     if (t.rpt == 4) {
