@@ -131,6 +131,15 @@ struct rm_context {
     std::vector<rm_tx_record> onair;   // frames of earlier ticks still on the air (SINR mode)
     std::vector<rm_tx_record> pending; // frames enqueued in the current tick
     DevBuf<rm_tx_record> d_tx;
+    // on-air list (device-source mode, SINR): the live batches are a window [air_head, air_tail) of
+    // d_air; a batch = the frames of one rm_tick_run_sources_device call (same start and air time)
+    struct AirBatch {
+        int count;
+        int64_t end_us;
+    };
+    DevBuf<rm_tx_record> d_air;
+    std::vector<AirBatch> air_batches;
+    size_t air_head = 0, air_tail = 0;
 
     // per-tick device buffers
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
@@ -857,7 +866,7 @@ void rm_destroy(rm_context *c)
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
-    c->d_bbox_z.release(); c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_tx.release();
+    c->d_bbox_z.release(); c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_tx.release();
     c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_cand_tot.release();
     c->d_seg_off.release(); c->d_a_e.release(); c->d_slot_off.release();
     c->d_counters.release(); c->d_st_pkt.release(); c->d_st_dst.release(); c->d_st_next.release();
@@ -915,6 +924,8 @@ int rm_set_model(rm_context *c, const rm_model_params *p)
     c->prefilter_dirty = true;
     RM_HIP(hipSetDevice(c->device));
     RM_TRY(build_shadow_table(c));
+    c->air_batches.clear();
+    c->air_head = c->air_tail = 0;
     c->onair.clear();
     c->pending.clear();
     return RM_OK;
@@ -1017,6 +1028,8 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     recompute_frame(c);
     c->rx_dirty = true;
     c->frac_probs = -1;
+    c->air_batches.clear();
+    c->air_head = c->air_tail = 0;
     c->onair.clear();
     c->pending.clear();
     if (c->rx_count >= 0 && c->rx_first + c->rx_count > n) {
@@ -1244,13 +1257,68 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
                                int64_t start_us, int64_t air_us)
 {
     if (!c || n < 0 || (n > 0 && !dev_src) || air_us < 0) return fail(RM_ERR_INVALID, "bad arguments");
-    if (is_sinr(c))
-        return fail(RM_ERR_STATE, "the SINR on-air list needs Tx records: use rm_tick_begin / rm_enqueue_tx / rm_tick_flush");
     RM_HIP(hipSetDevice(c->device));
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
-    RM_HIP(c->d_tx.ensure(std::max(n, 1)));
-    return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us);
+    if (!is_sinr(c)) {
+        RM_HIP(c->d_tx.ensure(std::max(n, 1)));
+        return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us);
+    }
+    // SINR: the frames of earlier calls that are still on the air stay resident on the device.
+    // Expire whole batches (rm_tick_begin's rule: start + air > t_begin stays).
+    {
+        bool fifo = true; // live batches form a suffix of the window?
+        size_t first_live = c->air_batches.size();
+        for (size_t i = 0; i < c->air_batches.size(); ++i) {
+            const bool live = c->air_batches[i].end_us > t_begin_us;
+            if (live && first_live == c->air_batches.size()) first_live = i;
+            if (!live && first_live != c->air_batches.size()) fifo = false;
+        }
+        if (fifo) {
+            for (size_t i = 0; i < first_live; ++i) c->air_head += size_t(c->air_batches[i].count);
+            c->air_batches.erase(c->air_batches.begin(), c->air_batches.begin() + first_live);
+        } else { // an earlier batch outlives a later one: compact the live batches to the front
+            DevBuf<rm_tx_record> fresh;
+            RM_HIP(fresh.ensure(std::max<size_t>(c->d_air.n, 1)));
+            size_t src = c->air_head, dst = 0;
+            std::vector<rm_context::AirBatch> keep;
+            for (const auto &bt : c->air_batches) {
+                if (bt.end_us > t_begin_us) {
+                    RM_HIP(hipMemcpyAsync(fresh.p + dst, c->d_air.p + src, size_t(bt.count) * sizeof(rm_tx_record),
+                                          hipMemcpyDeviceToDevice, c->stream));
+                    dst += size_t(bt.count);
+                    keep.push_back(bt);
+                }
+                src += size_t(bt.count);
+            }
+            RM_HIP(hipStreamSynchronize(c->stream));
+            c->d_air.release();
+            c->d_air = fresh;
+            c->air_batches.swap(keep);
+            c->air_head = 0;
+            c->air_tail = dst;
+        }
+    }
+    // room for the new batch at the tail; slide the window to the front when the buffer is used up
+    const size_t live = c->air_tail - c->air_head;
+    if (c->air_tail + size_t(n) > c->d_air.n) {
+        const size_t want = std::max<size_t>(4 * (live + size_t(n)), 1 << 16);
+        DevBuf<rm_tx_record> fresh;
+        RM_HIP(fresh.ensure(want));
+        if (live)
+            RM_HIP(hipMemcpyAsync(fresh.p, c->d_air.p + c->air_head, live * sizeof(rm_tx_record), hipMemcpyDeviceToDevice, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+        c->d_air.release();
+        c->d_air = fresh;
+        c->air_head = 0;
+        c->air_tail = live;
+    }
+    const int first_new = int(live);
+    const int rc = run_tick(c, c->d_air.p + c->air_head, first_new + n, first_new, dev_src, start_us, air_us);
+    if (rc != RM_OK) return rc;
+    c->air_tail += size_t(n);
+    if (n > 0) c->air_batches.push_back({n, start_us + air_us});
+    return RM_OK;
 }
 
 int rm_result_device(rm_context *c, rm_device_result *out)

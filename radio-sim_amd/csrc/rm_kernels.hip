@@ -538,11 +538,12 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
         double px = 0, py = 0, pz = 0;
         if (int(threadIdx.x) < nt) {
             rm_tx_record tx;
-            if (t.src_list) { // build mode: the record comes from the source table
-                tx = make_tx_record(nd, t.src_list[e0 + threadIdx.x], t.src_start_us, t.src_air_us);
-                if (blockIdx.x == 0) t.tx_build[e0 + threadIdx.x] = tx;
-            } else {
-                tx = t.tx[t.first_eval + e0 + threadIdx.x];
+            const int abs_i = t.first_eval + e0 + int(threadIdx.x);
+            if (t.src_list && abs_i >= t.first_new) { // build mode: a new frame's record comes from the source table
+                tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
+                if (blockIdx.x == 0) t.tx_build[abs_i] = tx;
+            } else { // a frame already on the air (or records given by the caller)
+                tx = t.tx[abs_i];
             }
             tx_prefilter(m, tx, f, thr64);
             ch = tx.channel;

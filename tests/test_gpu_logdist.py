@@ -159,3 +159,34 @@ def test_logdist_far_origin(engine, rsa, O):
     gpu, cpu = run_both(O, rsa, engine, nd, "logdist", {"ld_sigma_db": 4.0, "ld_seed": 5}, nd.packets(src))
     assert cpu.count > 500
     assert_same(gpu, cpu, "logdist far origin")
+
+
+def test_sinr_device_resident_on_air_list(engine, rsa, O):
+    """rm_tick_run_sources_device with the SINR medium: the frames of earlier ticks stay on the
+    device as interferers (batches expire by start + air > t_begin, also out of order)."""
+    from util import DeviceArray
+    n = 3000
+    nd = _layout(O, n, seed=29)
+    rng = np.random.default_rng(8)
+    nd.channel[:] = 11 + rng.integers(0, 2, n)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    airs = [8128, 2048, 320, 8128, 4064, 320, 2048, 8128, 8128, 320]
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    interfered = 0
+    for tick, air in enumerate(airs):
+        t0 = tick * 1000
+        onair = onair[onair["start_us"] + onair["air_us"] > t0]
+        srcs = np.sort(rng.choice(n, 50, replace=False)).astype(np.int32)
+        new = nd.packets(srcs, t0, air)
+        active = np.concatenate([onair, new])
+        cpu = O.tick(mdl, nd, active, first_new=len(onair))
+        dev = DeviceArray(srcs)
+        engine.tick_run_sources_device(t0, t0 + 1000, dev.ptr.value, len(srcs), t0, air)
+        gpu = engine.result_copy(len(srcs))
+        dev.free()
+        assert_same(gpu, cpu, "device on-air list, tick %d" % tick)
+        interfered += int((cpu.verdict == O.INTERFERED).sum())
+        onair = active
+    assert interfered > 100
