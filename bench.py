@@ -47,7 +47,12 @@ WORKLOADS = {
     "udgm": (3, 100_000, 0.01, "udgm", "100k nodes, 1% concurrent-Tx, reference UDGM (unit disc)"),
     "m1": (5, 1_000_000, 0.001, "logdist_shadow", "1M nodes, 0.1% concurrent-Tx, log-distance + log-normal shadowing"),
     "m1x": (5, 1_000_000, 0.01, "logdist_shadow", "1M nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
+    # the 8-GPU configs of BASELINE.json, runnable on one GPU as well (parity cases, not the headline):
+    "c4": (4, 100_000, 0.05, "logdist_sinr16", "100k nodes, 5% concurrent-Tx, 16 channels with co-channel SINR capture"),
+    "c5": (5, 1_000_000, 0.001, "logdist_sinr_overlap", "1M nodes, 0.1% new Tx per tick, multi-tick packet overlap (SINR)"),
 }
+# per-workload overrides: 16 channels; tick length (c4: one frame time, so the 5% are the concurrent set)
+EXTRA = {"c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23), "c5": dict(link_capacity=1 << 25)}
 
 
 def baseline_metric():
@@ -141,16 +146,21 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     idx, n, frac, model, desc = WORKLOADS[args.workload]
+    if args.workload in EXTRA and world > 1:
+        raise SystemExit("the SINR workloads run on one GPU in this round (sharded on-air list: host-record path only)")
     if world > 1 and args.scaling == "weak":
         # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
         n = int(round(n * world ** 0.5))
         desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
     t_per_tick = int(round(frac * n))
-    nodes = W.make_nodes(n, idx)
+    extra = EXTRA.get(args.workload, {})
+    tick_us = extra.get("tick_us", W.TICK_US)
+    stateful = model in ("logdist_sinr16", "logdist_sinr_overlap")   # on-air list: ticks are chained
+    nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
     kind_name, kw = W.model_kwargs(model)
     kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
 
-    inflight = max(1, args.inflight) if world == 1 and not args.force_sharded else 1
+    inflight = max(1, args.inflight) if world == 1 and not args.force_sharded and not stateful else 1
     engines, streams = [], []
     for _ in range(inflight):
         e = rsa.Engine(device_ordinal)
@@ -158,7 +168,7 @@ def main():
         e.set_stream(st.cuda_stream)
         e.upload_table(nodes)
         e.set_model(kind, **kw)
-        e.set_link_capacity(1 << 21)
+        e.set_link_capacity(extra.get("link_capacity", 1 << 21))
         engines.append(e)
         streams.append(st)
     eng, stream = engines[0], streams[0]
@@ -186,15 +196,19 @@ def main():
             sharded = D.ShardedTick(eng, dist, n, rank, world, slots, dev, stream)
     stream.synchronize()
 
+    links_done = [0]
+
     def run_range(k0, k1):
         """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
         with torch.cuda.stream(stream):
             if sharded is None:
                 for k in range(k0, k1):
-                    t0 = k * W.TICK_US
+                    t0 = k * tick_us
                     # one call: the frames' Tx records are built from the resident node state inside the sweep
-                    engines[k % inflight].tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick,
+                    engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k].data_ptr(), t_per_tick,
                                                                   t0, W.AIR_US)
+                    if stateful:
+                        links_done[0] += engines[0].last_link_evaluations()
             else:
                 if k1 > k0:
                     sharded.stage(src_dev[k0].data_ptr(), k0 * W.TICK_US, W.AIR_US)
@@ -216,6 +230,7 @@ def main():
     fence()
     eng.profile_enable(args.profile_every)
     t_start = time.perf_counter()
+    links_done[0] = 0
     run_range(args.warmup, ticks)
     fence()
     elapsed = time.perf_counter() - t_start
@@ -238,8 +253,13 @@ def main():
 
     links_per_tick = t_per_tick * (n - 1)
     value = links_per_tick * args.steps / elapsed
+    if stateful:
+        # every frame on the air is swept against every receiver each tick
+        value = links_done[0] / elapsed
 
     sequential = None
+    if stateful:
+        desc += " -- %.2e link evaluations per tick incl. the frames still on the air" % (links_done[0] / args.steps)
     if inflight > 1:
         # the same ticks again, one at a time on one context
         fence()
