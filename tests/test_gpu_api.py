@@ -1,0 +1,92 @@
+"""C-ABI behaviour beyond the evaluation itself: node updates (the reference has no change hook, so
+the shim re-uploads or updates nodes), error codes, call-sequence rules, capacity handling."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import configure_engine, oracle_model, to_tx_records, random_nodes, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def test_node_update_moves_a_receiver_and_resorts(engine, rsa, O):
+    n = 2000
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=1)
+    configure_engine(engine, nd, "udgm", {})
+    mdl = oracle_model(O, "udgm", {})
+    srcs = np.arange(0, n, 25)
+    rng = np.random.default_rng(3)
+    for step in range(4):
+        # node-config-set: new position / channel / radio-state / rx-loss for a few nodes
+        for i in rng.choice(n, 20, replace=False):
+            nd.x[i], nd.y[i] = rng.uniform(0, 400, 2)
+            nd.channel[i] = 26 if rng.random() < 0.8 else 25
+            nd.enabled[i] = 0 if rng.random() < 0.2 else 1
+            nd.txpower[i] = -float(step)
+            engine.update_node(int(i), nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]),
+                               nd.rxprob[i], nd.txprob[i])
+        if step == 2:          # far outside the old frame: the fp32 frame is recomputed
+            nd.x[5] = 1.0e6
+            engine.update_node(5, nd.x[5], nd.y[5], nd.z[5], nd.txpower[5], int(nd.channel[5]), int(nd.enabled[5]),
+                               nd.rxprob[5], nd.txprob[5])
+        pk = nd.packets(srcs)
+        gpu = engine.tick(to_tx_records(rsa, pk))
+        cpu = O.tick(mdl, nd, pk)
+        assert_same(gpu, cpu, "after update %d" % step)
+
+
+def test_error_codes_and_call_sequence(engine, rsa, O):
+    from radio_sim_amd import _lib
+    L = _lib.lib()
+    h = engine._h
+    nd = random_nodes(O, 100, 100.0, seed=2)
+    engine.upload_table(nd)
+    assert L.rm_node_count(h) == 100
+    p = _lib.ModelParams()
+    L.rm_model_defaults(C.byref(p), 99)
+    assert L.rm_set_model(h, C.byref(p)) == _lib.RM_ERR_INVALID and b"unknown model" in L.rm_last_error()
+    L.rm_model_defaults(C.byref(p), 4)
+    p.ld_d0 = 0.0
+    assert L.rm_set_model(h, C.byref(p)) == _lib.RM_ERR_INVALID
+    assert L.rm_enqueue_tx(h, 1, 0, 0, None, None) == _lib.RM_ERR_STATE            # outside a tick
+    assert L.rm_tick_flush(h, None, None, None, None, None, 0, None, None, None) == _lib.RM_ERR_STATE
+    assert L.rm_tick_begin(h, 0, 1000) == 0
+    assert L.rm_enqueue_tx(h, 100, 0, 0, None, None) == _lib.RM_ERR_INVALID        # "could not find source node"
+    assert L.rm_enqueue_tx(h, 3, 0, -5, None, None) == _lib.RM_ERR_INVALID
+    assert L.rm_set_partition(h, 50, 51) == _lib.RM_ERR_INVALID
+    assert L.rm_node_update(h, 100, 0.0, 0.0, 0.0, 0.0, 26, 1, 1.0, 1.0) == _lib.RM_ERR_INVALID
+    assert L.rm_node_update(h, 1, float("nan"), 0.0, 0.0, 0.0, 26, 1, 1.0, 1.0) == _lib.RM_ERR_INVALID
+    x = np.array([0.0, np.inf])
+    assert L.rm_nodes_upload(h, 2, x.ctypes.data, x.ctypes.data, None, None, None, None, None, None, None) == _lib.RM_ERR_INVALID
+    assert L.rm_create(7, C.byref(C.c_void_p())) == _lib.RM_ERR_INVALID            # device ordinal out of range
+    assert L.rm_result_count(h, None, None) in (0, _lib.RM_ERR_STATE)
+
+
+def test_caller_buffer_smaller_than_the_links(engine, rsa, O):
+    nd = random_nodes(O, 500, 150.0, seed=4)
+    configure_engine(engine, nd, "udgm", {})
+    recs = to_tx_records(rsa, nd.packets([1, 2, 3]))
+    full = engine.tick(recs)
+    assert full.count > 50
+    engine.tick_begin(0, 0)
+    engine.enqueue_records(recs)
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.tick_flush(cap=10)                   # count is still reported through the error path
+    assert e.value.code == -4
+    again = engine.tick(recs)                       # the context stays usable
+    assert again.count == full.count
+
+
+def test_defaults_of_optional_arrays(engine, rsa, O):
+    """NULL arrays in rm_nodes_upload mean the reference's field defaults (Transciever.java:11-18)."""
+    x = np.array([0.0, 10.0, 200.0])
+    y = np.zeros(3)
+    engine.upload_nodes(x, y)
+    engine.set_model(rsa.MODEL_UDGM)
+    r = engine.transmit(0, start_us=5, hex_length=10)
+    assert list(r.dst) == [1] and list(r.verdict) == [rsa.DELIVERED] and list(r.rssi) == [0.0]
+    engine.set_model(rsa.MODEL_N2N)
+    engine.set_n2n_matrix(np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]], dtype=float))   # int_id default = index + 1
+    r = engine.transmit(2)
+    assert list(r.dst) == [0, 1]
