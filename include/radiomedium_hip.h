@@ -219,7 +219,8 @@ enum rm_profile_stage {
     RM_STAGE_SCATTER = 5, /* k_finalize */
     RM_STAGE_REORDER = 6, /* k_reorder */
     RM_STAGE_DRAWS = 7,   /* java.util.Random kernels */
-    RM_PROFILE_STAGES = 8
+    RM_STAGE_EMPTY = 8,   /* two events with nothing between them: the cost of the bracketing itself */
+    RM_PROFILE_STAGES = 9
 };
 int rm_profile_enable(rm_context *ctx, int every_n);
 int rm_profile_read(rm_context *ctx, uint32_t *samples, double *stage_ms /* [RM_PROFILE_STAGES] */);

@@ -678,6 +678,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     };
     auto sequence = [&]() -> int {
         if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         RM_TRY(stage(RM_STAGE_FILTER));
         RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
         RM_TRY(stage(RM_STAGE_EXACT));

@@ -246,12 +246,12 @@ class Engine:
         check(self._L.rm_profile_enable(self._h, int(every_n)))
 
     STAGES = ("k_filter", "k_exact", "k_self_entries", "k_cell_off+k_slot_scan", "k_sinr", "k_finalize",
-              "k_reorder", "draw kernels")
+              "k_reorder", "draw kernels", "empty bracket")
 
     def profile_read(self):
         """-> (sampled ticks, {stage name: summed milliseconds})"""
         n = C.c_uint32()
-        ms = (C.c_double * 8)()
+        ms = (C.c_double * 9)()
         check(self._L.rm_profile_read(self._h, C.byref(n), ms))
         return n.value, {name: ms[i] for i, name in enumerate(self.STAGES)}
 
