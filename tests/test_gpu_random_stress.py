@@ -1,0 +1,84 @@
+"""Seeded randomized parity sweep: small, awkward scenarios over all media and parameter corners
+(the conservative pre-filter, the shadowing table, the on-air list and the draw machinery all have
+special cases: thr = -1 / +inf, exponent 0, clip 0, d < d0, coincident nodes, ragged sizes ...)."""
+import numpy as np
+import pytest
+
+from util import configure_engine, oracle_model, to_tx_records, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenario(O, rng):
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 129, 257, 700, 1500]))
+    kind = str(rng.choice(["null", "udgm", "udgm_const", "n2n", "logdist", "logdist", "logdist_sinr"]))
+    nd = O.NodeTable(n)
+    layout = rng.choice(["uniform", "line", "clustered", "coincident", "3d"])
+    side = float(rng.choice([10.0, 200.0, 2000.0]))
+    if layout == "uniform":
+        nd.x, nd.y = rng.uniform(-side, side, n), rng.uniform(-side, side, n)
+    elif layout == "line":
+        nd.x = np.arange(n) * float(rng.choice([0.5, 10.0, 50.0]))
+    elif layout == "clustered":
+        c = rng.uniform(-side, side, (4, 2))
+        k = rng.integers(0, 4, n)
+        nd.x, nd.y = c[k, 0] + rng.normal(0, 15, n), c[k, 1] + rng.normal(0, 15, n)
+    elif layout == "coincident":
+        nd.x[:] = 5.0
+        nd.y[:] = -3.0
+    else:
+        nd.x, nd.y, nd.z = rng.uniform(0, side, n), rng.uniform(0, side, n), rng.uniform(0, side / 4, n)
+    nd.channel[:] = rng.choice([26, 26, 26, 11, -4, 2 ** 31 - 1], n)
+    nd.enabled[:] = rng.random(n) > rng.choice([0.0, 0.1, 1.0, 0.5])
+    nd.txpower[:] = rng.choice([0.0, -25.0, 20.0, -300.0, 5.5], n)
+    if rng.random() < 0.5:
+        nd.rxprob[:] = rng.choice([1.0, 0.0, 0.3, 1.5, -0.2], n)
+        nd.txprob[:] = rng.choice([1.0, 0.0, 0.6, 2.0], n)
+    params, matrix = {}, None
+    if kind == "udgm":
+        params = {"udgm_transmission_range": float(rng.choice([50.0, 0.0, 1e-3, 1e9, -50.0])),
+                  "udgm_success_ratio_rx": float(rng.choice([1.0, 0.5, 0.0, 1.2]))}
+    elif kind == "udgm_const":
+        params = {"const_range": float(rng.choice([100.0, 0.0, -1.0, 1e12, 10.0]))}
+    elif kind == "n2n":
+        m = int(rng.choice([n, max(1, n // 2), n + 3]))
+        matrix = np.where(rng.random((m, m)) < 0.3, rng.uniform(-0.1, 1.3, (m, m)), 0.0)
+        nd.int_id[:] = rng.choice([1, 2, 3, -1, 0, m, m + 1], n) if rng.random() < 0.3 else np.arange(1, n + 1)
+    else:
+        params = {"ld_exponent": float(rng.choice([3.0, 2.0, 0.0, 6.5])), "ld_d0": float(rng.choice([1.0, 30.0, 0.01])),
+                  "ld_pl0_db": float(rng.choice([40.0, 0.0, 90.0])), "ld_sigma_db": float(rng.choice([0.0, 4.0, 12.0])),
+                  "ld_clip": float(rng.choice([3.0, 0.0, 1.0])), "ld_seed": int(rng.integers(0, 2 ** 40)),
+                  "ld_sensitivity_dbm": float(rng.choice([-95.0, -40.0, -200.0]))}
+        if kind == "logdist_sinr":
+            params.update({"ld_flags": 1, "ld_capture_db": float(rng.choice([3.0, -10.0, 30.0])),
+                           "ld_ifloor_dbm": float(rng.choice([-110.0, -60.0, -95.0, -300.0])),
+                           "ld_noise_dbm": float(rng.choice([-100.0, -60.0]))})
+        kind = "logdist"
+    t = int(min(n, rng.choice([1, 2, 63, 64, 65, 130])))
+    src = rng.choice(n, t, replace=False)
+    pk = nd.packets(src, 0, 0)
+    pk["start_us"] = rng.integers(0, 2000, t)
+    pk["air_us"] = rng.choice([0, 320, 2000, 8128], t)
+    if rng.random() < 0.3:
+        pk["txpower"] = rng.uniform(-60, 30, t)
+        pk["channel"] = rng.choice([26, 11], t)
+    return nd, kind, params, matrix, pk
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_randomized_scenarios(engine, rsa, O, block):
+    rng = np.random.default_rng(1000 + block)
+    checked = 0
+    for it in range(12):
+        nd, kind, params, matrix, pk = _scenario(O, rng)
+        if kind == "logdist" and params.get("ld_flags") and (len(pk) * nd.n > 60_000):
+            pk = pk[:40]
+        configure_engine(engine, nd, kind, params, matrix)
+        seed = int(rng.integers(0, 2 ** 31))
+        engine.seed(seed)
+        cpu = O.tick(oracle_model(O, kind, params, matrix), nd, pk, rng_state=O.lib().orc_jrandom_seed(seed))
+        gpu = engine.tick(to_tx_records(rsa, pk))
+        assert_same(gpu, cpu, "block %d it %d %s %s n=%d t=%d" % (block, it, kind, params, nd.n, len(pk)))
+        assert engine.rng_state == cpu.rng_state
+        checked += cpu.count
+    assert checked > 0
