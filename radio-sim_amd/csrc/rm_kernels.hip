@@ -855,8 +855,8 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
 {
     __shared__ uint32_t s_seg[SEG == 1 ? kFusedScanMax + 1 : 1];
     __shared__ uint32_t s_wave[4];
-    if (SEG == 1)
-        block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, (blockIdx.x == 0 && blockIdx.y == 0) ? t.seg_off : nullptr, nullptr);
+    const bool publisher = (blockIdx.x == 0 && blockIdx.y == 0);
+    bool scanned = false; // the scan is only needed by the scatter: it runs after the first evaluation
     const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
@@ -903,6 +903,10 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
             slot = erel - t.cnt_base;
             key = (SEG == 0) ? int((size_t(slot >> 6) * t.n_slabs + pos / per_slab) * 64 + (slot & 63)) : slot;
         }
+        if (SEG == 1 && !scanned) { // block-uniform
+            block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
+            scanned = true;
+        }
         // one atomic per run of same-frame (same-cell) entries
         const RunInfo ri = run_prefix(key, wanted, lane);
         if (SEG == 0) {
@@ -925,6 +929,8 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
             }
         }
     }
+    if (SEG == 1 && !scanned && publisher) // seg_off is published even if this shard was empty
+        block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
 }
 
 // half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
@@ -1153,6 +1159,29 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
     __shared__ uint32_t s_off[MODE == 1 ? kFusedScanMax + 1 : 1];
     __shared__ uint32_t s_wave[4];
     const bool publisher = blockIdx.x == 0;
+    const int lane = threadIdx.x & 63;
+    const int n_new = t.n_active - t.first_new;
+
+    // the first frame of this wave: its records are requested before the scan below, so that the
+    // scan's round trip and the records' overlap
+    const int q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t src0 = 0, len = 0;
+    int mine = 0x7fffffff, in_e = 0;
+    double in_rssi = 0.0, in_prob = 1.0;
+    uint8_t v = 0;
+    if (q0 < n_new) {
+        src0 = t.seg_off[q0 + t.shift];
+        len = t.cursor[q0 + t.shift];
+        if (uint32_t(lane) < len) {
+            const uint32_t o = src0 + lane;
+            mine = t.a_dst[o];
+            in_rssi = t.a_rssi[o];
+            v = t.a_verdict[o];
+            if (STOCH) in_prob = t.a_prob[o];
+            if (SINR) in_e = t.a_e[o];
+        }
+    }
+
     if (MODE == 1) {
         uint32_t vmax = 0;
         const uint32_t total = block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr,
@@ -1169,22 +1198,24 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
         t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
         t.out_count[2] = total;
     }
-    const int lane = threadIdx.x & 63;
-    const int n_new = t.n_active - t.first_new;
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < n_new; q += gridDim.x * 4) { // wave-uniform
+
+    for (int q = q0; q < n_new; q += gridDim.x * 4) { // wave-uniform
         const int slot = q + t.shift;
-        const uint32_t src0 = t.seg_off[slot];
-        const uint32_t len = t.cursor[slot];
+        if (q != q0) {
+            src0 = t.seg_off[slot];
+            len = t.cursor[slot];
+        }
         const uint32_t dst0 = (MODE == 1) ? s_off[slot] : t.slot_off[slot];
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {
             const uint32_t o = src0 + c0 + lane;
             const bool valid = c0 + lane < len;
-            const int mine = valid ? t.a_dst[o] : 0x7fffffff;
-            // the record's other fields are fetched now, under the same round trip
-            const double in_rssi = valid ? t.a_rssi[o] : 0.0;
-            uint8_t v = valid ? t.a_verdict[o] : uint8_t(0);
-            const double in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
-            const int in_e = (SINR && valid) ? t.a_e[o] : 0;
+            if (q != q0 || c0 != 0) { // everything but the prefetched first chunk
+                mine = valid ? t.a_dst[o] : 0x7fffffff;
+                in_rssi = valid ? t.a_rssi[o] : 0.0;
+                v = valid ? t.a_verdict[o] : uint8_t(0);
+                in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
+                in_e = (SINR && valid) ? t.a_e[o] : 0;
+            }
             uint32_t rank = 0;
             if (len <= 64) {
                 for (uint32_t i = 0; i < len; ++i) rank += (__builtin_amdgcn_readlane(mine, int(i)) < mine) ? 1u : 0u;
@@ -1196,13 +1227,14 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
                 t.out_pkt[d] = q;
                 t.out_dst[d] = mine;
                 t.out_rssi[d] = in_rssi;
+                uint8_t vv = v;
                 if (SINR) {
                     t.out_sinr[d] = t.st_sinr[in_e];
-                    if (t.st_coll[in_e]) v = RM_INTERFERED;
+                    if (t.st_coll[in_e]) vv = RM_INTERFERED;
                 } else {
                     t.out_sinr[d] = 0.0;
                 }
-                t.out_verdict[d] = v;
+                t.out_verdict[d] = vv;
                 if (STOCH) t.out_prob[d] = in_prob;
             }
         }
