@@ -105,7 +105,11 @@ struct rm_context {
     DevBuf<int32_t> d_rx_channel, d_rx_int_id, d_rx_orig, d_pos_of;
     DevBuf<uint8_t> d_rx_enabled;
     DevBuf<rm::RxRecord> d_rx_rec;
-    DevBuf<float4> d_rxf, d_bbox_xy;
+    DevBuf<float4> d_rxf, d_bbox_xy, d_wg_box_xy, d_p_txf;
+    DevBuf<float2> d_wg_box_z;
+    DevBuf<int32_t> d_p_ch, d_p_src, d_near_list;
+    DevBuf<float> d_p_inv;
+    DevBuf<uint32_t> d_near_cnt, d_work;
     DevBuf<float2> d_bbox_z;
     DevBuf<double> d_n2n;
     int n2n_m = 0;
@@ -322,6 +326,8 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.rxf = c->d_rxf.p;
     nd.bbox_xy = c->d_bbox_xy.p;
     nd.bbox_z = c->d_bbox_z.p;
+    nd.wg_box_xy = c->d_wg_box_xy.p;
+    nd.wg_box_z = c->d_wg_box_z.p;
     return nd;
 }
 
@@ -501,6 +507,8 @@ int prepare_nodes(rm_context *c)
     RM_HIP(c->d_rxf.ensure(std::max(c->n_rx, 1)));
     RM_HIP(c->d_bbox_xy.ensure(std::max(groups, 1)));
     RM_HIP(c->d_bbox_z.ensure(std::max(groups, 1)));
+    RM_HIP(c->d_wg_box_xy.ensure(std::max(groups / 16 + 1, 1)));
+    RM_HIP(c->d_wg_box_z.ensure(std::max(groups / 16 + 1, 1)));
     RM_HIP(rm::launch_prep_rx(c->stream, nodes_dev(c), model_dev(c)));
     c->prefilter_dirty = false;
     return RM_OK;
@@ -604,6 +612,24 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     c->zero_len = std::max(c->zero_len, std::max(t.n_cnt, 0));
     t.zero_len = c->zero_len;
     t.a_e = c->d_a_e.p;
+    t.n_wg = (rx_count + rm::kGroup * 16 - 1) / (rm::kGroup * 16);
+    if (rm::filter_uses_lists(t, cfg)) {
+        // large-grid path: per-frame records, near lists, work queue
+        RM_HIP(c->d_p_txf.ensure(std::max(n_eval, 1)));
+        RM_HIP(c->d_p_ch.ensure(std::max(n_eval, 1)));
+        RM_HIP(c->d_p_src.ensure(std::max(n_eval, 1)));
+        RM_HIP(c->d_p_inv.ensure(std::max(n_eval, 1)));
+        RM_HIP(c->d_near_cnt.ensure(size_t(t.n_wg) + 2));
+        RM_HIP(c->d_near_list.ensure(size_t(t.n_wg) * rm::kNearCap));
+        RM_HIP(c->d_work.ensure(size_t(t.n_wg) * (rm::kNearCap / 64)));
+        t.p_txf = c->d_p_txf.p;
+        t.p_ch = c->d_p_ch.p;
+        t.p_src = c->d_p_src.p;
+        t.p_inv = c->d_p_inv.p;
+        t.near_cnt = c->d_near_cnt.p;
+        t.near_list = c->d_near_list.p;
+        t.work = c->d_work.p;
+    }
     t.st_pkt = c->d_st_pkt.p;
     t.st_dst = c->d_st_dst.p;
     t.st_blk = c->d_st_blk.p;
@@ -867,7 +893,9 @@ void rm_destroy(rm_context *c)
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
-    c->d_bbox_z.release(); c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_tx.release();
+    c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release(); c->d_p_txf.release(); c->d_p_ch.release();
+    c->d_p_src.release(); c->d_p_inv.release(); c->d_near_cnt.release(); c->d_near_list.release(); c->d_work.release();
+    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_tx.release();
     c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_cand_tot.release();
     c->d_seg_off.release(); c->d_a_e.release(); c->d_slot_off.release();
     c->d_counters.release(); c->d_st_pkt.release(); c->d_st_dst.release(); c->d_st_next.release();

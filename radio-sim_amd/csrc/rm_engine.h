@@ -16,6 +16,7 @@ constexpr int kGroup = 64;          // receivers per bounding-box group (one per
 constexpr int kShards = 256;        // append counters of the candidate list (one word sustains only ~88 atomics/us)
 constexpr int kShadowBins = 256;    // bins over rho = d^2 / cut^2 of the shadowing table
 constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
+constexpr int kNearCap = 4096;      // near frames one workgroup (1024 receivers) can list per tick (large-grid path)
 constexpr int kShardStride = 32;    // u32 words between shard counters: one 128-byte line each
 
 // link-entry flags
@@ -77,6 +78,8 @@ struct NodesDev {
     float4 *rxf;                             // pre-filter record: (fx, fy, fz, channel bits); NaN = never a candidate
     float4 *bbox_xy;                         // per group of 64: (minx, miny, maxx, maxy) in the fp32 frame
     float2 *bbox_z;                          //                 (minz, maxz)
+    float4 *wg_box_xy;                       // per filter workgroup (16 groups = 1024 receivers): union of its boxes
+    float2 *wg_box_z;
 };
 
 struct TickDev {
@@ -113,6 +116,14 @@ struct TickDev {
     uint32_t *cand_tot_next; // the other parity, zeroed by k_filter for the next tick
     uint32_t *seg_off;      // [n_cnt + 1] exclusive scan of cand_tot: the frame's segment in the A records
     int zero_len;           // slots of cursor / cand_tot_next that k_filter has to zero
+    // large-grid path: per-frame pre-filter records, per-workgroup lists of near frames, work queue
+    float4 *p_txf;          // [n_eval]
+    int32_t *p_ch, *p_src;  // [n_eval]
+    float *p_inv;           // [n_eval]
+    uint32_t *near_cnt;     // [n_wg] (+ [n_wg]: n_work, [n_wg+1]: overflow flag)
+    int32_t *near_list;     // [n_wg * kNearCap] eval-relative frame indices
+    uint32_t *work;         // [n_wg * kNearCap / 64] items (workgroup << 6 | chunk of 64 near frames)
+    int n_wg;
     int32_t *a_e;           // [..] link-entry index of an A record (SINR results are looked up through it)
     int32_t *st_pkt;        // eval-relative frame index
     int32_t *st_dst;        // receiver engine position
@@ -157,6 +168,7 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
                           int64_t air_us, rm_tx_record *out);
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
+bool filter_uses_lists(const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                         const LaunchCfg &cfg);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);

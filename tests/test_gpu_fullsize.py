@@ -179,6 +179,7 @@ def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
     try:
         eng.upload_table(nd)
         eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+        eng.set_link_capacity(1 << 23)      # ~1.5 M candidate links per tick with 3000 frames on the air
         rng = np.random.default_rng(5)
         onair = np.zeros(0, dtype=O.PACKET_DTYPE)
         for tick in range(3):
