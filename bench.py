@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=3,
                     help="ticks in flight on one GPU (one engine context + stream each; ticks are independent "
                          "for the media without an on-air list)")
+    ap.add_argument("--no-scale-probe", action="store_true",
+                    help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the pipelined multi-GPU tick driver even on one GPU (testing)")
@@ -113,6 +115,63 @@ def cpu_baseline(wl, nodes, sources, cpu_ticks):
     mt = {"value": links / dt_mt, "unit": "links/s", "cores": threads, "kind": "port",
           "sample": "same sample, OpenMP over packets, %.1f s" % dt_mt}
     return out, mt
+
+
+def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, ticks=60, warm=12):
+    """The same medium at 1M nodes / 1000 frames per tick (38 MB of algorithmic traffic per tick): where
+    the sweep stops being launch-latency-bound.  Same measurement rules as the main run."""
+    idx, n, frac, model, desc = WORKLOADS["m1"]
+    t_per_tick = int(round(frac * n))
+    nodes = W.make_nodes(n, idx)
+    kind_name, kw = W.model_kwargs(model)
+    engines, streams = [], []
+    for _ in range(inflight):
+        e = rsa.Engine(device_ordinal)
+        st = torch.cuda.Stream(device=dev)
+        e.set_stream(st.cuda_stream)
+        e.upload_table(nodes)
+        e.set_model(rsa.MODEL_LOGDIST, **kw)
+        e.set_link_capacity(1 << 21)
+        engines.append(e)
+        streams.append(st)
+    sources = [W.choose_sources(n, t_per_tick, 0xC0FFEE00 + idx, k) for k in range(warm + ticks)]
+    with torch.cuda.stream(streams[0]):
+        src_dev = torch.from_numpy(np.stack(sources)).to(dev)
+    streams[0].synchronize()
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            t0 = k * W.TICK_US
+            engines[k % inflight].tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+
+    def fence():
+        for st in streams:
+            st.synchronize()
+        torch.cuda.synchronize()
+
+    run(0, warm)
+    fence()
+    engines[0].profile_enable(4)
+    t0 = time.perf_counter()
+    run(warm, warm + ticks)
+    fence()
+    el = time.perf_counter() - t0
+    n_samples, stage_ms = engines[0].profile_read()
+    engines[0].profile_enable(0)
+    heard, dropped = engines[0].result_count()
+    raw = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
+    bracket = raw.pop("empty bracket", 0.0)
+    stages = {k: max(v - bracket, 0.0) for k, v in raw.items()}
+    dominant = max(stages, key=stages.get)
+    b_tick = n * S_NODE + t_per_tick * S_TX + heard * S_REC
+    per_tick = el / ticks
+    for e in engines:
+        e.close()
+    return {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "ticks_in_flight": inflight,
+            "value": t_per_tick * (n - 1) / per_tick, "unit": "links/s", "ms_per_step": per_tick * 1e3,
+            "algorithmic_bytes_per_tick": b_tick, "dominant_kernel": dominant, "stages_avg_us": stages,
+            "hbm_frac_dominant_kernel": b_tick / (stages[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac_whole_tick": b_tick / per_tick / 1e9 / HBM_PEAK_GBS, "dropped": bool(dropped)}
 
 
 def main():
@@ -330,6 +389,8 @@ def main():
         }
         if sequential is not None:
             out["sequential_ticks"] = sequential
+        if world == 1 and args.workload == "c3" and not args.no_scale_probe:
+            out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight)
         if world == 1 and not args.no_cpu_baseline:
             st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
             out["cpu_baseline"] = st
