@@ -619,7 +619,10 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         RM_HIP(c->d_p_ch.ensure(std::max(n_eval, 1)));
         RM_HIP(c->d_p_src.ensure(std::max(n_eval, 1)));
         RM_HIP(c->d_p_inv.ensure(std::max(n_eval, 1)));
-        RM_HIP(c->d_near_cnt.ensure(size_t(t.n_wg) + 2));
+        if (size_t(t.n_wg) + 2 > c->d_near_cnt.n) {
+            RM_HIP(c->d_near_cnt.ensure(size_t(t.n_wg) + 2));
+            RM_HIP(hipMemsetAsync(c->d_near_cnt.p, 0, c->d_near_cnt.n * sizeof(uint32_t), c->stream));
+        }
         RM_HIP(c->d_near_list.ensure(size_t(t.n_wg) * rm::kNearCap));
         RM_HIP(c->d_work.ensure(size_t(t.n_wg) * (rm::kNearCap / 64)));
         t.p_txf = c->d_p_txf.p;

@@ -1454,6 +1454,11 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
         t.out_count[2] = total;
     }
 
+    if (publisher && t.near_cnt) { // large-grid path: the near counters of the next tick start at zero
+        __syncthreads();           // thread 0 has read the overflow flag above
+        for (int i = threadIdx.x; i < t.n_wg + 2; i += blockDim.x) t.near_cnt[i] = 0u;
+    }
+
     for (int q = q0; q < n_new; q += gridDim.x * 4) { // wave-uniform
         const int slot = q + t.shift;
         if (q != q0) {
@@ -1700,8 +1705,7 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
     if (filter_uses_lists(t, cfg)) {
-        hipError_t e = hipMemsetAsync(t.near_cnt, 0, size_t(t.n_wg + 2) * sizeof(uint32_t), s);
-        if (e != hipSuccess) return e;
+        // near_cnt is all zero here: zero-filled at allocation, re-zeroed by every tick's k_reorder
         hipLaunchKernelGGL(k_near_pairs, dim3(cdiv(n_eval, 4)), dim3(256), 0, s, nd, m, t);
         if (cfg.shadow) hipLaunchKernelGGL(k_filter_list<true>, dim3(1536), dim3(kBlock), 0, s, nd, m, t);
         else hipLaunchKernelGGL(k_filter_list<false>, dim3(1536), dim3(kBlock), 0, s, nd, m, t);
