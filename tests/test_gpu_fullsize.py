@@ -198,3 +198,86 @@ def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
             onair = np.concatenate([onair, new])
     finally:
         eng.close()
+
+
+def test_more_frames_than_the_fused_scans_hold(rsa, O):
+    """> 8192 frames in one tick: segment / packet offsets come from the stand-alone scan kernel."""
+    n, t = 30_000, 9_000
+    rng = np.random.default_rng(12)
+    nd = O.NodeTable(n)
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    nd.rxprob[:] = np.where(rng.random(n) < 0.7, 1.0, rng.uniform(0, 1, n))
+    eng = rsa.Engine(0)
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["udgm"])
+        eng.seed(5)
+        srcs = np.sort(rng.choice(n, t, replace=False))
+        pk = nd.packets(srcs, 0, 8128)
+        gpu = eng.tick(to_tx_records(rsa, pk), cap=1 << 21)
+        cpu = O.tick(oracle_model(O, "udgm", {}), nd, pk, rng_state=O.lib().orc_jrandom_seed(5), cap=1 << 21)
+        assert cpu.count > 150_000 and gpu.count == cpu.count and cpu.pkt_draws.sum() > 10_000
+        np.testing.assert_array_equal(gpu.pkt, cpu.pkt)
+        np.testing.assert_array_equal(gpu.dst, cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+        assert eng.rng_state == cpu.rng_state
+    finally:
+        eng.close()
+
+
+def test_large_grid_path_with_draws_and_partitions(rsa, O):
+    """1M receivers (near-list path of the filter) with probabilistic links, whole and in two
+    partitions; sampled packets against the oracle, draw order through the generator state."""
+    from radio_sim_amd import workload as W
+    from radio_sim_amd import dist as D
+    from util import DeviceArray
+    n, t = 1_000_000, 600
+    src_nd = W.make_nodes(n, 5)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = src_nd.x, src_nd.y
+    rng = np.random.default_rng(3)
+    nd.rxprob[:] = np.where(rng.random(n) < 0.5, 1.0, 0.5)
+    srcs = W.choose_sources(n, t, 77, 0)
+    pk = nd.packets(srcs, 0, W.AIR_US)
+    recs = to_tx_records(rsa, pk)
+    cpu = O.tick(oracle_model(O, "udgm", {}), nd, pk, rng_state=O.lib().orc_jrandom_seed(9), cap=1 << 20)
+    assert cpu.pkt_draws.sum() > 3000
+    eng = rsa.Engine(0)
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["udgm"])
+        eng.seed(9)
+        gpu = eng.tick(recs, cap=1 << 20)
+        assert gpu.count == cpu.count
+        np.testing.assert_array_equal(gpu.dst, cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+        assert eng.rng_state == cpu.rng_state
+    finally:
+        eng.close()
+    engines, shards, counts = [], [], []
+    try:
+        for r in range(2):
+            lo, hi = D.partition(n, r, 2)
+            e = rsa.Engine(0)
+            e.upload_table(nd)
+            e.set_model(KINDS["udgm"])
+            e.set_partition(lo, hi - lo)
+            e.seed(9)
+            e.tick_begin(0, 1000)
+            e.enqueue_records(recs)
+            e.tick_run()
+            ptr, n_new = e.draw_counts_device()
+            counts.append(DeviceArray.read(ptr, np.uint32, n_new))
+            engines.append(e)
+        for r, e in enumerate(engines):
+            e.finish_draws(np.stack(counts), 2, r)
+            res = e.result_copy(t, cap=1 << 20)
+            shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
+            assert e.rng_state == cpu.rng_state
+        merged = D.merge_shard_links(shards, t)
+        np.testing.assert_array_equal(merged[1], cpu.dst)
+        np.testing.assert_array_equal(merged[2], cpu.verdict)
+    finally:
+        for e in engines:
+            e.close()
