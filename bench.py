@@ -219,7 +219,7 @@ def main():
     kind_name, kw = W.model_kwargs(model)
     kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
 
-    inflight = max(1, args.inflight) if world == 1 and not args.force_sharded and not stateful else 1
+    inflight = max(1, args.inflight) if not stateful else 1
     engines, streams = [], []
     for _ in range(inflight):
         e = rsa.Engine(device_ordinal)
@@ -252,7 +252,7 @@ def main():
             slots = D.slots_needed(n, world, sources)
             pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
             src_dev = torch.from_numpy(pad).to(dev)
-            sharded = D.ShardedTick(eng, dist, n, rank, world, slots, dev, stream)
+            sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams)
     stream.synchronize()
 
     links_done = [0]
@@ -319,7 +319,7 @@ def main():
     sequential = None
     if stateful:
         desc += " -- %.2e link evaluations per tick incl. the frames still on the air" % (links_done[0] / args.steps)
-    if inflight > 1:
+    if inflight > 1 and sharded is None:
         # the same ticks again, one at a time on one context
         fence()
         t_seq = time.perf_counter()

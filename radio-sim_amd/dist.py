@@ -103,52 +103,65 @@ def merge_shard_links(shards, n_slots):
 class ShardedTick:
     """Device-resident multi-GPU tick driver used by bench.py (one instance per rank).
 
-    Two-deep pipeline: packing + the RCCL all-gather of tick t+1 run on a communication stream
-    while the sweep of tick t runs on the engine's stream (the messages are tiny -- `slots` x 64 B
-    per rank -- so the collective is latency-bound and hides completely behind the sweep).
+    Pipeline: packing + the RCCL all-gather of tick k+1 run on a communication stream while earlier
+    ticks are swept (the messages are tiny -- `slots` x 64 B per rank -- so the collective is
+    latency-bound and hides behind the sweeps).  With several engine contexts (`engines`, each on
+    its own stream) that many ticks are swept concurrently, as on one GPU: the benchmarked medium
+    carries no state from tick to tick.  Media with draws or an on-air list must use ONE context.
     Works with world == 1 as well (no collective), which is how the choreography is tested on one GPU."""
 
-    def __init__(self, engine, dist, n, rank, world, slots, device, compute_stream):
+    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams):
         import torch
         self.torch = torch
-        self.eng, self.dist, self.n, self.rank, self.world, self.slots = engine, dist, n, rank, world, slots
+        if not isinstance(engines, (list, tuple)):
+            engines, compute_streams = [engines], [compute_streams]
+        self.engines, self.streams = list(engines), list(compute_streams)
+        self.eng = self.engines[0]
+        self.dist, self.n, self.rank, self.world, self.slots = dist, n, rank, world, slots
         self.lo, self.hi = partition(n, rank, world)
         if world > 1:
-            engine.set_partition(self.lo, self.hi - self.lo)
-        self.compute = compute_stream
+            for e in self.engines:
+                e.set_partition(self.lo, self.hi - self.lo)
         self.comm = torch.cuda.Stream(device=device)
-        self.mine = [torch.empty(slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.all = [torch.empty(world * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.ready = [torch.cuda.Event() for _ in range(2)]   # gathered records of the buffer are complete
-        self.done = [torch.cuda.Event() for _ in range(2)]    # the sweep that read the buffer has finished
-        self.used = [False, False]
+        ring = len(self.engines) + 1
+        self.mine = [torch.empty(slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
+        self.all = [torch.empty(world * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
+        self.ready = [torch.cuda.Event() for _ in range(ring)]  # gathered records of the buffer are complete
+        self.done = [torch.cuda.Event() for _ in range(ring)]   # the sweep that read the buffer has finished
+        self.used = [False] * ring
+        self.seq = 0           # ticks staged so far
         self.staged = None
         self.cnt_mine = self.cnt_all = None
 
     def stage(self, dev_src_ptr, t_begin, air_us):
-        """Enqueue packing + all-gather of a tick on the communication stream."""
+        """Enqueue packing + all-gather of the next tick on the communication stream."""
         torch = self.torch
-        b = 0 if self.staged is None else 1 - self.staged[0]
+        k = self.seq
+        self.seq += 1
+        b = k % len(self.mine)
+        eng = self.engines[k % len(self.engines)]
         with torch.cuda.stream(self.comm):
             if self.used[b]:
-                self.comm.wait_event(self.done[b])         # the previous sweep on this buffer
-            self.eng.pack_tx_device_on(self.comm.cuda_stream, dev_src_ptr, self.slots, t_begin, air_us,
-                                       self.mine[b].data_ptr())
+                self.comm.wait_event(self.done[b])         # the sweep that last read this buffer
+            eng.pack_tx_device_on(self.comm.cuda_stream, dev_src_ptr, self.slots, t_begin, air_us,
+                                  self.mine[b].data_ptr())
             if self.world > 1:
                 all_gather_records(self.dist, self.mine[b], self.world, self.all[b])
             else:
                 self.all[b].copy_(self.mine[b], non_blocking=True)
             self.ready[b].record(self.comm)
         prev = self.staged
-        self.staged = (b, t_begin)
+        self.staged = (b, t_begin, k)
         return prev
 
     def sweep(self, staged, t_end):
-        """Run the sweep of a staged tick on the engine's stream."""
-        b, t_begin = staged
-        self.compute.wait_event(self.ready[b])
-        self.eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
-        if self.eng.draws_pending():
+        """Run the sweep of a staged tick on its context's stream."""
+        b, t_begin, k = staged
+        eng = self.engines[k % len(self.engines)]
+        stream = self.streams[k % len(self.streams)]
+        stream.wait_event(self.ready[b])
+        eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
+        if eng.draws_pending():
             # probabilistic links: the shared java.util.Random is consumed in node order = rank order;
             # one more tiny all-gather (per-packet draw counts), then every rank places its draws
             torch = self.torch
@@ -156,14 +169,14 @@ class ShardedTick:
             if self.cnt_mine is None or self.cnt_mine.numel() != n_new:
                 self.cnt_mine = torch.empty(n_new, dtype=torch.int32, device=self.all[b].device)
                 self.cnt_all = torch.empty(self.world * n_new, dtype=torch.int32, device=self.all[b].device)
-            with torch.cuda.stream(self.compute):
-                self.eng.draw_counts_to(self.cnt_mine.data_ptr())
+            with torch.cuda.stream(stream):
+                eng.draw_counts_to(self.cnt_mine.data_ptr())
                 if self.world > 1:
                     self.dist.all_gather_into_tensor(self.cnt_all, self.cnt_mine)
                 else:
                     self.cnt_all.copy_(self.cnt_mine, non_blocking=True)
-                self.eng.finish_draws(self.cnt_all.data_ptr(), self.world, self.rank)
-        self.done[b].record(self.compute)
+                eng.finish_draws(self.cnt_all.data_ptr(), self.world, self.rank)
+        self.done[b].record(stream)
         self.used[b] = True
 
     def run(self, dev_src_ptr, t_begin, t_end, air_us):
