@@ -252,14 +252,14 @@ def main():
             slots = D.slots_needed(n, world, sources)
             pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
             src_dev = torch.from_numpy(pad).to(dev)
-            sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams)
+            sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False)
     stream.synchronize()
 
     links_done = [0]
 
     def run_range(k0, k1):
         """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream if sharded is None else sharded.comm):
             if sharded is None:
                 for k in range(k0, k1):
                     t0 = k * tick_us
@@ -373,7 +373,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight,
-                       "air_us": W.AIR_US, "model": model, "heard_links_last_tick": heard_total,
+                       "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total,
                        "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per tick, "
                                     "overlapped with the previous tick's sweep" % world) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

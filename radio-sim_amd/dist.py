@@ -110,7 +110,7 @@ class ShardedTick:
     carries no state from tick to tick.  Media with draws or an on-air list must use ONE context.
     Works with world == 1 as well (no collective), which is how the choreography is tested on one GPU."""
 
-    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams):
+    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True):
         import torch
         self.torch = torch
         if not isinstance(engines, (list, tuple)):
@@ -132,6 +132,7 @@ class ShardedTick:
         self.seq = 0           # ticks staged so far
         self.staged = None
         self.cnt_mine = self.cnt_all = None
+        self.may_draw = may_draw   # False: the caller knows no java.util.Random draw can happen (saves a call per tick)
 
     def stage(self, dev_src_ptr, t_begin, air_us):
         """Enqueue packing + all-gather of the next tick on the communication stream."""
@@ -140,16 +141,17 @@ class ShardedTick:
         self.seq += 1
         b = k % len(self.mine)
         eng = self.engines[k % len(self.engines)]
-        with torch.cuda.stream(self.comm):
-            if self.used[b]:
-                self.comm.wait_event(self.done[b])         # the sweep that last read this buffer
-            eng.pack_tx_device_on(self.comm.cuda_stream, dev_src_ptr, self.slots, t_begin, air_us,
-                                  self.mine[b].data_ptr())
-            if self.world > 1:
-                all_gather_records(self.dist, self.mine[b], self.world, self.all[b])
-            else:
-                self.all[b].copy_(self.mine[b], non_blocking=True)
-            self.ready[b].record(self.comm)
+        # the caller keeps the communication stream current (`with torch.cuda.stream(self.comm)` around
+        # its tick loop): the collective is enqueued on the current stream, everything else names its stream
+        if self.used[b]:
+            self.comm.wait_event(self.done[b])         # the sweep that last read this buffer
+        eng.pack_tx_device_on(self.comm.cuda_stream, dev_src_ptr, self.slots, t_begin, air_us,
+                              self.mine[b].data_ptr())
+        if self.world > 1:
+            all_gather_records(self.dist, self.mine[b], self.world, self.all[b])
+        else:
+            self.all[b].copy_(self.mine[b], non_blocking=True)
+        self.ready[b].record(self.comm)
         prev = self.staged
         self.staged = (b, t_begin, k)
         return prev
@@ -161,7 +163,7 @@ class ShardedTick:
         stream = self.streams[k % len(self.streams)]
         stream.wait_event(self.ready[b])
         eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
-        if eng.draws_pending():
+        if self.may_draw and eng.draws_pending():
             # probabilistic links: the shared java.util.Random is consumed in node order = rank order;
             # one more tiny all-gather (per-packet draw counts), then every rank places its draws
             torch = self.torch
@@ -181,5 +183,6 @@ class ShardedTick:
 
     def run(self, dev_src_ptr, t_begin, t_end, air_us):
         """Unpipelined convenience: stage and sweep one tick."""
-        self.stage(dev_src_ptr, t_begin, air_us)
-        self.sweep(self.staged, t_end)
+        with self.torch.cuda.stream(self.comm):
+            self.stage(dev_src_ptr, t_begin, air_us)
+            self.sweep(self.staged, t_end)
