@@ -45,6 +45,7 @@ WORKLOADS = {
     "c2": (2, 10_000, 0.01, "logdist", "10k nodes, 1% concurrent-Tx, log-distance path loss"),
     "c3": (3, 100_000, 0.01, "logdist_shadow", "100k nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
     "udgm": (3, 100_000, 0.01, "udgm", "100k nodes, 1% concurrent-Tx, reference UDGM (unit disc)"),
+    "c3x6": (3, 100_000, 0.06, "logdist_shadow", "100k nodes, 6% concurrent-Tx (six ticks' worth of frames in one pass)"),
     "m1": (5, 1_000_000, 0.001, "logdist_shadow", "1M nodes, 0.1% concurrent-Tx, log-distance + log-normal shadowing"),
     "m1x": (5, 1_000_000, 0.01, "logdist_shadow", "1M nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
     # the 8-GPU configs of BASELINE.json, runnable on one GPU as well (parity cases, not the headline):
@@ -52,7 +53,7 @@ WORKLOADS = {
     "c5": (5, 1_000_000, 0.001, "logdist_sinr_overlap", "1M nodes, 0.1% new Tx per tick, multi-tick packet overlap (SINR)"),
 }
 # per-workload overrides: 16 channels; tick length (c4: one frame time, so the 5% are the concurrent set)
-EXTRA = {"c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23), "c5": dict(link_capacity=1 << 25)}
+EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23), "c5": dict(link_capacity=1 << 25)}
 
 
 def baseline_metric():
@@ -73,6 +74,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=3,
                     help="ticks in flight on one GPU (one engine context + stream each; ticks are independent "
                          "for the media without an on-air list)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 6); 1 = one tick per sequence")
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -256,11 +259,27 @@ def main():
     stream.synchronize()
 
     links_done = [0]
+    batch = 1 if (stateful or use_sharded) else max(1, min(args.batch, rsa.MAX_BATCH))
+    _bargs = {}
+
+    def batch_args(k, nb):
+        """arguments of one rm_batch_run_sources_device call for ticks k .. k+nb-1 (built once)"""
+        if (k, nb) not in _bargs:
+            t0 = np.arange(k, k + nb, dtype=np.int64) * tick_us
+            _bargs[(k, nb)] = (t0, t0 + tick_us, np.array([src_dev[kk].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
+                               np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
+        return _bargs[(k, nb)]
 
     def run_range(k0, k1):
         """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
         with torch.cuda.stream(stream if sharded is None else sharded.comm):
-            if sharded is None:
+            if sharded is None and batch > 1:
+                g = 0
+                for k in range(k0, k1, batch):
+                    a = batch_args(k, min(batch, k1 - k))
+                    engines[g % inflight].batch_run_sources_device(*a)
+                    g += 1
+            elif sharded is None:
                 for k in range(k0, k1):
                     t0 = k * tick_us
                     # one call: the frames' Tx records are built from the resident node state inside the sweep
@@ -339,7 +358,7 @@ def main():
         # largest share.  Algorithmic bytes per launch = N_loc*37 + T_act*56 + H_loc*25.
         n_loc = hi - lo
         h_loc = heard
-        b_tick = n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC
+        b_tick = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * batch   # per launch: `batch` ticks
         raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
         # an event pair with nothing between it measures the bracketing itself (a few us on this
         # runtime): subtracted from every stage so that the durations are the kernels'
@@ -372,7 +391,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight,
+            "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight * batch,
+                       "ticks_per_launch": batch, "contexts": inflight,
                        "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total,
                        "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per tick, "
                                     "overlapped with the previous tick's sweep" % world) if world > 1 else "none"},

@@ -206,12 +206,36 @@ int rm_result_copy(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict
                    uint32_t *pkt_offset);
 int rm_sync(rm_context *ctx);
 
+/* ---- several independent ticks per pass ---------------------------------------------------------
+ * RadioMedium.transmit treats every packet on its own (UDGMRadioMedium.java:63-117 reads nothing
+ * but the packet, the node table and the shared Random), so the frames of n_ticks consecutive
+ * ticks can be swept together: one launch sequence for all of them instead of one per tick,
+ * which is what fills an MI355X at the 100k-node sizes (a single tick is a few dependent
+ * launches of a few microseconds each).  Tick b's results live in result slot b of the context
+ * (slot 0 is also what rm_result_* read) until the next rm_batch_* / rm_tick_* call.  The
+ * java.util.Random draws are consumed tick by tick in slot order, i.e. exactly as n_ticks
+ * single rm_tick_run_sources_device calls would.  Media that carry state from tick to tick
+ * (RM_LD_SINR: the on-air list) and partitioned contexts whose links draw are refused with
+ * RM_ERR_STATE -- run those one tick at a time. */
+#define RM_MAX_BATCH 6
+int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,
+                                const int64_t *t_end_us, const int32_t *const *dev_src /* device int32[n_src[b]] each */,
+                                const int32_t *n_src, const int64_t *start_us, const int64_t *air_us);
+/* the same with the ticks' Tx records given (device memory, canonical order), as rm_tick_run_device */
+int rm_batch_run_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                        const rm_tx_record *const *dev_new, const int32_t *n_new);
+int rm_batch_result_device(rm_context *ctx, int32_t slot, rm_device_result *out);
+int rm_batch_result_count(rm_context *ctx, int32_t slot, uint32_t *count, uint32_t *dropped); /* synchronises */
+int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,
+                         double *sinr, uint32_t cap, uint32_t *count, uint8_t *pkt_interference,
+                         uint32_t *pkt_offset);
+
 /* Per-stage timing on the context's stream: on every `every_n`-th tick each stage of the launch
  * sequence is bracketed by HIP events (0 = off; an event costs microseconds of stream time on
  * this runtime, so dense sampling perturbs the throughput it measures).  rm_profile_read returns
  * the number of sampled ticks and the summed milliseconds per stage. */
 enum rm_profile_stage {
-    RM_STAGE_FILTER = 0,  /* k_filter: all (frame, receiver) pairs, conservative */
+    RM_STAGE_FILTER = 0,  /* k_filter (or k_tick_prep + k_filter_wg): all (frame, receiver) pairs, conservative */
     RM_STAGE_EXACT = 1,   /* k_exact: the reference's fp64 arithmetic on the candidates */
     RM_STAGE_SELF = 2,    /* k_self_entries (SINR) */
     RM_STAGE_OFFSETS = 3, /* k_cell_off + k_slot_scan */

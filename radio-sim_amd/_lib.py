@@ -16,6 +16,7 @@ _SO = os.path.join(_CSRC, "libradiomedium_hip.so")
 MODEL_NULL, MODEL_UDGM, MODEL_UDGM_CONST, MODEL_N2N, MODEL_LOGDIST = range(5)
 UNHEARD, INTERFERED, DELIVERED = 0, 1, 2
 LD_SINR = 1
+MAX_BATCH = 6
 RM_OK, RM_ERR_INVALID, RM_ERR_NO_DEVICE, RM_ERR_HIP, RM_ERR_CAPACITY, RM_ERR_STATE = 0, -1, -2, -3, -4, -5
 
 
@@ -120,6 +121,13 @@ SIGNATURES = {
     "rm_result_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                  C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rm_sync": (C.c_int, [C.c_void_p]),
+    "rm_batch_run_sources_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "rm_batch_run_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rm_batch_result_device": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(DeviceResult)]),
+    "rm_batch_result_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rm_batch_result_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
     "rm_last_link_evaluations": (C.c_int64, [C.c_void_p]),

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -84,7 +85,47 @@ const char *model_name(int kind)
 
 } // namespace
 
-struct rm_context {
+// Everything one evaluated tick owns on the device.  A context is its own slot 0; rm_batch_*
+// adds further slots so that several ticks can be in flight through one launch sequence.
+struct TickSlot {
+    DevBuf<rm_tx_record> d_tx;   // records uploaded by the host / built from source indices
+    DevBuf<float4> d_p_txf;      // per-frame pre-filter records
+    DevBuf<int32_t> d_p_ch, d_p_src, d_near_list;
+    DevBuf<float> d_p_inv;
+    DevBuf<uint32_t> d_near_cnt, d_work;
+
+    DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
+    DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
+    DevBuf<uint32_t> d_shards;   // two parities x kShards x kShardStride append counters
+    DevBuf<uint32_t> d_cursor, d_cand_tot, d_seg_off;
+    DevBuf<int32_t> d_a_e;
+    int zero_len = 0;        // slots of cursor / cand_tot that may be non-zero
+    int parity = 0;
+    DevBuf<int32_t> d_st_pkt, d_st_dst, d_st_next, d_head;
+    DevBuf<uint32_t> d_st_blk;
+    DevBuf<double> d_st_aux, d_st_lin, d_st_sinr, d_st_prob;
+    DevBuf<int32_t> d_st_orig;
+    DevBuf<uint8_t> d_st_flags, d_st_coll;
+    DevBuf<int32_t> d_out_pkt, d_out_dst, d_a_pkt, d_a_dst;
+    DevBuf<uint8_t> d_out_verdict, d_pkt_interf, d_a_verdict;
+    DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob, d_a_rssi, d_a_sinr, d_a_prob;
+    DevBuf<uint32_t> d_draw_scan, d_scan_block;
+    DevBuf<uint64_t> d_pkt_rng;
+    DevBuf<uint32_t> d_pkt_draw_cnt, d_all_cnt;
+    bool draws_pending = false; // partitioned + probabilistic: waiting for rm_tick_finish_draws
+    rm::ModelDev pending_model{};
+    uint32_t alloc_cap = 0;
+
+    // last tick
+    rm::TickDev last{};
+    int last_n_new = 0;
+    bool have_result = false;
+    int64_t last_links = 0;
+
+    void release_all();
+};
+
+struct rm_context : TickSlot {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -105,11 +146,8 @@ struct rm_context {
     DevBuf<int32_t> d_rx_channel, d_rx_int_id, d_rx_orig, d_pos_of;
     DevBuf<uint8_t> d_rx_enabled;
     DevBuf<rm::RxRecord> d_rx_rec;
-    DevBuf<float4> d_rxf, d_bbox_xy, d_wg_box_xy, d_p_txf;
+    DevBuf<float4> d_rxf, d_bbox_xy, d_wg_box_xy;
     DevBuf<float2> d_wg_box_z;
-    DevBuf<int32_t> d_p_ch, d_p_src, d_near_list;
-    DevBuf<float> d_p_inv;
-    DevBuf<uint32_t> d_near_cnt, d_work;
     DevBuf<float2> d_bbox_z;
     DevBuf<double> d_n2n;
     int n2n_m = 0;
@@ -134,7 +172,6 @@ struct rm_context {
     // on-air list (host-record mode)
     std::vector<rm_tx_record> onair;   // frames of earlier ticks still on the air (SINR mode)
     std::vector<rm_tx_record> pending; // frames enqueued in the current tick
-    DevBuf<rm_tx_record> d_tx;
     // on-air list (device-source mode, SINR): the live batches are a window [air_head, air_tail) of
     // d_air; a batch = the frames of one rm_tick_run_sources_device call (same start and air time)
     struct AirBatch {
@@ -145,34 +182,8 @@ struct rm_context {
     std::vector<AirBatch> air_batches;
     size_t air_head = 0, air_tail = 0;
 
-    // per-tick device buffers
-    DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
-    DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
-    DevBuf<uint32_t> d_shards;   // two parities x kShards x kShardStride append counters
-    DevBuf<uint32_t> d_cursor, d_cand_tot, d_seg_off;
-    DevBuf<int32_t> d_a_e;
-    int zero_len = 0;        // slots of cursor / cand_tot that may be non-zero
-    int parity = 0;
-    DevBuf<int32_t> d_st_pkt, d_st_dst, d_st_next, d_head;
-    DevBuf<uint32_t> d_st_blk;
-    DevBuf<double> d_st_aux, d_st_lin, d_st_sinr, d_st_prob;
-    DevBuf<int32_t> d_st_orig;
-    DevBuf<uint8_t> d_st_flags, d_st_coll;
-    DevBuf<int32_t> d_out_pkt, d_out_dst, d_a_pkt, d_a_dst;
-    DevBuf<uint8_t> d_out_verdict, d_pkt_interf, d_a_verdict;
-    DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob, d_a_rssi, d_a_sinr, d_a_prob;
-    DevBuf<uint32_t> d_draw_scan, d_scan_block;
-    DevBuf<uint64_t> d_rng, d_pkt_rng;
-    DevBuf<uint32_t> d_pkt_draw_cnt, d_all_cnt;
-    bool draws_pending = false; // partitioned + probabilistic: waiting for rm_tick_finish_draws
-    rm::ModelDev pending_model{};
-    uint32_t alloc_cap = 0;
-
-    // last tick
-    rm::TickDev last{};
-    int last_n_new = 0;
-    bool have_result = false;
-    int64_t last_links = 0;
+    DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
+    std::vector<std::unique_ptr<TickSlot>> extra_slots; // result slots 1.. of rm_batch_*
 
     // instantiated hipGraphs of the per-tick launch sequence, keyed by a hash of every launch argument
     struct GraphEntry {
@@ -200,6 +211,20 @@ struct rm_context {
     uint32_t prof_samples = 0;
     double prof_ms[RM_PROFILE_STAGES] = {0};
 };
+
+void TickSlot::release_all()
+{
+    d_tx.release(); d_p_txf.release(); d_p_ch.release(); d_p_src.release(); d_near_list.release(); d_p_inv.release();
+    d_near_cnt.release(); d_work.release(); d_cnt.release(); d_off.release(); d_slot_tot.release(); d_slot_off.release();
+    d_counters.release(); d_shards.release(); d_cursor.release(); d_cand_tot.release(); d_seg_off.release(); d_a_e.release();
+    d_st_pkt.release(); d_st_dst.release(); d_st_next.release(); d_head.release(); d_st_blk.release(); d_st_aux.release();
+    d_st_lin.release(); d_st_sinr.release(); d_st_prob.release(); d_st_orig.release(); d_st_flags.release(); d_st_coll.release();
+    d_out_pkt.release(); d_out_dst.release(); d_a_pkt.release(); d_a_dst.release(); d_out_verdict.release(); d_pkt_interf.release();
+    d_a_verdict.release(); d_out_rssi.release(); d_out_sinr.release(); d_out_prob.release(); d_a_rssi.release(); d_a_sinr.release();
+    d_a_prob.release(); d_draw_scan.release(); d_scan_block.release(); d_pkt_rng.release(); d_pkt_draw_cnt.release(); d_all_cnt.release();
+    alloc_cap = 0;
+    have_result = false;
+}
 
 namespace {
 
@@ -432,42 +457,42 @@ int rebuild_receivers(rm_context *c)
     return RM_OK;
 }
 
-int ensure_link_buffers(rm_context *c)
+int ensure_link_buffers(rm_context *c, TickSlot &ts)
 {
-    if (c->alloc_cap == c->cap && c->d_counters.p) return RM_OK;
+    if (ts.alloc_cap == c->cap && ts.d_counters.p) return RM_OK;
     const size_t cap = size_t((c->cap + rm::kShards - 1) / rm::kShards) * rm::kShards;
-    RM_HIP(c->d_counters.ensure(16));
-    RM_HIP(hipMemsetAsync(c->d_counters.p, 0, 16 * sizeof(uint32_t), c->stream));
-    RM_HIP(c->d_shards.ensure(2 * rm::kShards * rm::kShardStride));
-    RM_HIP(hipMemsetAsync(c->d_shards.p, 0, 2 * rm::kShards * rm::kShardStride * sizeof(uint32_t), c->stream));
-    c->parity = 0;
-    RM_HIP(c->d_st_pkt.ensure(cap));
-    RM_HIP(c->d_st_dst.ensure(cap));
-    RM_HIP(c->d_st_next.ensure(cap));
-    RM_HIP(c->d_st_blk.ensure(cap));
-    RM_HIP(c->d_st_aux.ensure(cap));
-    RM_HIP(c->d_st_prob.ensure(cap));
-    RM_HIP(c->d_st_orig.ensure(cap));
-    RM_HIP(c->d_st_lin.ensure(cap));
-    RM_HIP(c->d_st_sinr.ensure(cap));
-    RM_HIP(c->d_st_flags.ensure(cap));
-    RM_HIP(c->d_st_coll.ensure(cap));
-    RM_HIP(c->d_out_pkt.ensure(cap));
-    RM_HIP(c->d_out_dst.ensure(cap));
-    RM_HIP(c->d_out_verdict.ensure(cap));
-    RM_HIP(c->d_out_rssi.ensure(cap));
-    RM_HIP(c->d_out_sinr.ensure(cap));
-    RM_HIP(c->d_out_prob.ensure(cap));
-    RM_HIP(c->d_a_pkt.ensure(cap));
-    RM_HIP(c->d_a_dst.ensure(cap));
-    RM_HIP(c->d_a_verdict.ensure(cap));
-    RM_HIP(c->d_a_rssi.ensure(cap));
-    RM_HIP(c->d_a_sinr.ensure(cap));
-    RM_HIP(c->d_a_prob.ensure(cap));
-    RM_HIP(c->d_a_e.ensure(cap));
-    RM_HIP(c->d_draw_scan.ensure(cap + 1));
-    RM_HIP(c->d_scan_block.ensure(cap / 2048 + 2));
-    c->alloc_cap = c->cap;
+    RM_HIP(ts.d_counters.ensure(16));
+    RM_HIP(hipMemsetAsync(ts.d_counters.p, 0, 16 * sizeof(uint32_t), c->stream));
+    RM_HIP(ts.d_shards.ensure(2 * rm::kShards * rm::kShardStride));
+    RM_HIP(hipMemsetAsync(ts.d_shards.p, 0, 2 * rm::kShards * rm::kShardStride * sizeof(uint32_t), c->stream));
+    ts.parity = 0;
+    RM_HIP(ts.d_st_pkt.ensure(cap));
+    RM_HIP(ts.d_st_dst.ensure(cap));
+    RM_HIP(ts.d_st_next.ensure(cap));
+    RM_HIP(ts.d_st_blk.ensure(cap));
+    RM_HIP(ts.d_st_aux.ensure(cap));
+    RM_HIP(ts.d_st_prob.ensure(cap));
+    RM_HIP(ts.d_st_orig.ensure(cap));
+    RM_HIP(ts.d_st_lin.ensure(cap));
+    RM_HIP(ts.d_st_sinr.ensure(cap));
+    RM_HIP(ts.d_st_flags.ensure(cap));
+    RM_HIP(ts.d_st_coll.ensure(cap));
+    RM_HIP(ts.d_out_pkt.ensure(cap));
+    RM_HIP(ts.d_out_dst.ensure(cap));
+    RM_HIP(ts.d_out_verdict.ensure(cap));
+    RM_HIP(ts.d_out_rssi.ensure(cap));
+    RM_HIP(ts.d_out_sinr.ensure(cap));
+    RM_HIP(ts.d_out_prob.ensure(cap));
+    RM_HIP(ts.d_a_pkt.ensure(cap));
+    RM_HIP(ts.d_a_dst.ensure(cap));
+    RM_HIP(ts.d_a_verdict.ensure(cap));
+    RM_HIP(ts.d_a_rssi.ensure(cap));
+    RM_HIP(ts.d_a_sinr.ensure(cap));
+    RM_HIP(ts.d_a_prob.ensure(cap));
+    RM_HIP(ts.d_a_e.ensure(cap));
+    RM_HIP(ts.d_draw_scan.ensure(cap + 1));
+    RM_HIP(ts.d_scan_block.ensure(cap / 2048 + 2));
+    ts.alloc_cap = c->cap;
     return RM_OK;
 }
 
@@ -514,23 +539,33 @@ int prepare_nodes(rm_context *c)
     return RM_OK;
 }
 
-// the per-tick launch sequence; `tx` is the on-air list in device memory
-int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
-             int64_t src_start_us = 0, int64_t src_air_us = 0)
+// What one tick's launch sequence needs besides the slot: filled by prepare_tick.
+struct TickPlan {
+    rm::TickDev t{};
+    rm::LaunchCfg cfg{};
+    bool sinr = false, stochastic = false, partitioned = false;
+    bool empty = false; // nothing to sweep: the result is an empty one
+};
+
+// Buffers and descriptor of one tick in result slot `ts`; `tx` is the on-air list in device memory
+// (build mode: where the records of the source indices `src_list` are written).
+int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, const rm_tx_record *tx, int n_active,
+                 int first_new, const int32_t *src_list = nullptr, int64_t src_start_us = 0, int64_t src_air_us = 0)
 {
     const int n_new = n_active - first_new;
-    c->have_result = false;
-    c->last_n_new = n_new;
-    RM_TRY(ensure_link_buffers(c));
+    ts.have_result = false;
+    ts.last_n_new = n_new;
+    RM_TRY(ensure_link_buffers(c, ts));
     RM_TRY(prepare_nodes(c));
 
     const bool sinr = is_sinr(c);
     const bool stochastic = maybe_draws(c);
     const int rx_count = c->n_rx;
     const bool partitioned = rx_count != c->n;
-    c->draws_pending = false;
+    ts.draws_pending = false;
 
-    rm::TickDev t{};
+    rm::TickDev &t = plan.t;
+    t = rm::TickDev{};
     t.tx = tx;
     t.src_list = src_list;
     t.tx_build = src_list ? const_cast<rm_tx_record *>(tx) : nullptr;
@@ -545,35 +580,40 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     t.shift = (first_new - t.first_eval) - t.cnt_base;
     t.n_cnt = n_chunks * rm::kTxChunk - t.cnt_base;
     t.n_rx = rx_count;
-    // enough waves to fill 256 CUs x 4 SIMDs several times over, else one group per wave
-    const long waves4 = long((rx_count + 255) / 256) * n_chunks;
-    t.rpt = (waves4 >= 4096) ? 4 : 1;
-    t.n_slabs = (rx_count + 64 * t.rpt - 1) / (64 * t.rpt);
+    const rm::ModelDev m = model_dev(c);
+    rm::LaunchCfg &cfg = plan.cfg;
+    cfg = rm::LaunchCfg{};
+    cfg.stochastic = stochastic;
+    cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
+    cfg.sorted = c->rx_sorted;
+    cfg.bbox = c->rx_sorted && !cfg.f64_filter;
+    cfg.shadow = c->shadow_tbl_valid && !cfg.f64_filter && std::getenv("RM_NO_SHADOW_TABLE") == nullptr;
+    const int filter_mode = rm::plan_filter(t, cfg, want_wg); // fixes t.rpt / t.n_slabs
 
     const size_t cells = size_t(std::max(t.n_cnt, 0) / rm::kTxChunk) * std::max(t.n_slabs, 1) * 64;
     if (!c->rx_sorted) {
-        RM_HIP(c->d_cnt.ensure(std::max<size_t>(cells, 1)));
-        RM_HIP(c->d_off.ensure(std::max<size_t>(cells, 1)));
+        RM_HIP(ts.d_cnt.ensure(std::max<size_t>(cells, 1)));
+        RM_HIP(ts.d_off.ensure(std::max<size_t>(cells, 1)));
     }
-    RM_HIP(c->d_slot_tot.ensure(size_t(std::max(t.n_cnt, 0)) + 1));
+    RM_HIP(ts.d_slot_tot.ensure(size_t(std::max(t.n_cnt, 0)) + 1));
     {
         // per-frame counters that kernels add to: zero-filled when (re)allocated, then kept zero by
         // k_filter (cursor: same tick; candidate totals: the other parity for the next tick)
         const size_t need = size_t(std::max(t.n_cnt, 0)) + 1;
-        if (need > c->d_cursor.n || 2 * need > c->d_cand_tot.n) {
-            RM_HIP(c->d_cursor.ensure(need * 2));
-            RM_HIP(c->d_cand_tot.ensure(need * 4));
-            RM_HIP(hipMemsetAsync(c->d_cursor.p, 0, c->d_cursor.n * 4, c->stream));
-            RM_HIP(hipMemsetAsync(c->d_cand_tot.p, 0, c->d_cand_tot.n * 4, c->stream));
-            c->zero_len = 0;
+        if (need > ts.d_cursor.n || 2 * need > ts.d_cand_tot.n) {
+            RM_HIP(ts.d_cursor.ensure(need * 2));
+            RM_HIP(ts.d_cand_tot.ensure(need * 4));
+            RM_HIP(hipMemsetAsync(ts.d_cursor.p, 0, ts.d_cursor.n * 4, c->stream));
+            RM_HIP(hipMemsetAsync(ts.d_cand_tot.p, 0, ts.d_cand_tot.n * 4, c->stream));
+            ts.zero_len = 0;
         }
-        RM_HIP(c->d_seg_off.ensure(need + 1));
+        RM_HIP(ts.d_seg_off.ensure(need + 1));
     }
-    RM_HIP(c->d_slot_off.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
-    RM_HIP(c->d_pkt_interf.ensure(std::max(n_new, 1)));
-    RM_HIP(c->d_pkt_rng.ensure(std::max(n_new, 1)));
-    RM_HIP(c->d_pkt_draw_cnt.ensure(std::max(n_new, 1)));
-    RM_HIP(c->d_head.ensure(std::max(rx_count, 1)));
+    RM_HIP(ts.d_slot_off.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
+    RM_HIP(ts.d_pkt_interf.ensure(std::max(n_new, 1)));
+    RM_HIP(ts.d_pkt_rng.ensure(std::max(n_new, 1)));
+    RM_HIP(ts.d_pkt_draw_cnt.ensure(std::max(n_new, 1)));
+    RM_HIP(ts.d_head.ensure(std::max(rx_count, 1)));
     if (!c->d_rng.p) {
         RM_HIP(c->d_rng.ensure(1));
         const uint64_t s0 = (uint64_t(0) ^ 0x5DEECE66Dull) & ((1ull << 48) - 1);
@@ -581,84 +621,76 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         RM_HIP(hipStreamSynchronize(c->stream));
     }
 
-    const rm::ModelDev m = model_dev(c);
-    const rm::NodesDev nd = nodes_dev(c);
-    rm::LaunchCfg cfg{};
-    cfg.stochastic = stochastic;
-    cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
-    cfg.sorted = c->rx_sorted;
-    cfg.bbox = c->rx_sorted && !cfg.f64_filter;
-    cfg.shadow = c->shadow_tbl_valid && !cfg.f64_filter && std::getenv("RM_NO_SHADOW_TABLE") == nullptr;
-
-    t.cnt = c->d_cnt.p;
-    t.off = c->d_off.p;
-    t.slot_tot = c->d_slot_tot.p;
-    t.slot_off = c->d_slot_off.p;
-    uint32_t *counters = c->d_counters.p + 8 * c->parity;
+    t.cnt = ts.d_cnt.p;
+    t.off = ts.d_off.p;
+    t.slot_tot = ts.d_slot_tot.p;
+    t.slot_off = ts.d_slot_off.p;
+    uint32_t *counters = ts.d_counters.p + 8 * ts.parity;
     t.stage_count = counters;
-    t.next_counters = c->d_counters.p + 8 * (c->parity ^ 1);
-    t.shard_count = c->d_shards.p + size_t(c->parity) * rm::kShards * rm::kShardStride;
-    t.next_shard_count = c->d_shards.p + size_t(c->parity ^ 1) * rm::kShards * rm::kShardStride;
+    t.next_counters = ts.d_counters.p + 8 * (ts.parity ^ 1);
+    t.shard_count = ts.d_shards.p + size_t(ts.parity) * rm::kShards * rm::kShardStride;
+    t.next_shard_count = ts.d_shards.p + size_t(ts.parity ^ 1) * rm::kShards * rm::kShardStride;
     t.cap = c->cap;
     t.seg_cap = (c->cap + rm::kShards - 1) / rm::kShards;
     t.use_matrix = cfg.sorted ? 0 : 1;
-    t.cursor = c->d_cursor.p;
+    t.cursor = ts.d_cursor.p;
     {
-        const size_t half = c->d_cand_tot.n / 2;
-        t.cand_tot = c->d_cand_tot.p + size_t(c->parity) * half;
-        t.cand_tot_next = c->d_cand_tot.p + size_t(c->parity ^ 1) * half;
+        const size_t half = ts.d_cand_tot.n / 2;
+        t.cand_tot = ts.d_cand_tot.p + size_t(ts.parity) * half;
+        t.cand_tot_next = ts.d_cand_tot.p + size_t(ts.parity ^ 1) * half;
     }
-    t.seg_off = c->d_seg_off.p;
-    c->zero_len = std::max(c->zero_len, std::max(t.n_cnt, 0));
-    t.zero_len = c->zero_len;
-    t.a_e = c->d_a_e.p;
+    t.seg_off = ts.d_seg_off.p;
+    ts.zero_len = std::max(ts.zero_len, std::max(t.n_cnt, 0));
+    t.zero_len = ts.zero_len;
+    t.a_e = ts.d_a_e.p;
     t.n_wg = (rx_count + rm::kGroup * 16 - 1) / (rm::kGroup * 16);
-    if (rm::filter_uses_lists(t, cfg)) {
-        // large-grid path: per-frame records, near lists, work queue
-        RM_HIP(c->d_p_txf.ensure(std::max(n_eval, 1)));
-        RM_HIP(c->d_p_ch.ensure(std::max(n_eval, 1)));
-        RM_HIP(c->d_p_src.ensure(std::max(n_eval, 1)));
-        RM_HIP(c->d_p_inv.ensure(std::max(n_eval, 1)));
-        if (size_t(t.n_wg) + 2 > c->d_near_cnt.n) {
-            RM_HIP(c->d_near_cnt.ensure(size_t(t.n_wg) + 2));
-            RM_HIP(hipMemsetAsync(c->d_near_cnt.p, 0, c->d_near_cnt.n * sizeof(uint32_t), c->stream));
-        }
-        RM_HIP(c->d_near_list.ensure(size_t(t.n_wg) * rm::kNearCap));
-        RM_HIP(c->d_work.ensure(size_t(t.n_wg) * (rm::kNearCap / 64)));
-        t.p_txf = c->d_p_txf.p;
-        t.p_ch = c->d_p_ch.p;
-        t.p_src = c->d_p_src.p;
-        t.p_inv = c->d_p_inv.p;
-        t.near_cnt = c->d_near_cnt.p;
-        t.near_list = c->d_near_list.p;
-        t.work = c->d_work.p;
+    if (filter_mode != rm::kFilterGrid) { // per-frame pre-filter records
+        RM_HIP(ts.d_p_txf.ensure(std::max(n_eval, 1)));
+        RM_HIP(ts.d_p_ch.ensure(std::max(n_eval, 1)));
+        RM_HIP(ts.d_p_src.ensure(std::max(n_eval, 1)));
+        RM_HIP(ts.d_p_inv.ensure(std::max(n_eval, 1)));
+        t.p_txf = ts.d_p_txf.p;
+        t.p_ch = ts.d_p_ch.p;
+        t.p_src = ts.d_p_src.p;
+        t.p_inv = ts.d_p_inv.p;
     }
-    t.st_pkt = c->d_st_pkt.p;
-    t.st_dst = c->d_st_dst.p;
-    t.st_blk = c->d_st_blk.p;
-    t.st_aux = c->d_st_aux.p;
-    t.st_prob = c->d_st_prob.p;
-    t.st_orig = c->d_st_orig.p;
-    t.st_lin = c->d_st_lin.p;
-    t.st_sinr = c->d_st_sinr.p;
-    t.st_next = c->d_st_next.p;
-    t.st_flags = c->d_st_flags.p;
-    t.st_coll = c->d_st_coll.p;
-    t.head = c->d_head.p;
+    if (filter_mode == rm::kFilterList) { // large-grid path: near lists, work queue
+        if (size_t(t.n_wg) + 2 > ts.d_near_cnt.n) {
+            RM_HIP(ts.d_near_cnt.ensure(size_t(t.n_wg) + 2));
+            RM_HIP(hipMemsetAsync(ts.d_near_cnt.p, 0, ts.d_near_cnt.n * sizeof(uint32_t), c->stream));
+        }
+        RM_HIP(ts.d_near_list.ensure(size_t(t.n_wg) * rm::kNearCap));
+        RM_HIP(ts.d_work.ensure(size_t(t.n_wg) * (rm::kNearCap / 64)));
+        t.near_cnt = ts.d_near_cnt.p;
+        t.near_list = ts.d_near_list.p;
+        t.work = ts.d_work.p;
+    }
+    t.st_pkt = ts.d_st_pkt.p;
+    t.st_dst = ts.d_st_dst.p;
+    t.st_blk = ts.d_st_blk.p;
+    t.st_aux = ts.d_st_aux.p;
+    t.st_prob = ts.d_st_prob.p;
+    t.st_orig = ts.d_st_orig.p;
+    t.st_lin = ts.d_st_lin.p;
+    t.st_sinr = ts.d_st_sinr.p;
+    t.st_next = ts.d_st_next.p;
+    t.st_flags = ts.d_st_flags.p;
+    t.st_coll = ts.d_st_coll.p;
+    t.head = ts.d_head.p;
     t.out_count = counters + 2;
-    t.out_pkt = c->d_out_pkt.p;
-    t.out_dst = c->d_out_dst.p;
-    t.out_verdict = c->d_out_verdict.p;
-    t.out_rssi = c->d_out_rssi.p;
-    t.out_sinr = c->d_out_sinr.p;
-    t.out_prob = c->d_out_prob.p;
+    t.out_pkt = ts.d_out_pkt.p;
+    t.out_dst = ts.d_out_dst.p;
+    t.out_verdict = ts.d_out_verdict.p;
+    t.out_rssi = ts.d_out_rssi.p;
+    t.out_sinr = ts.d_out_sinr.p;
+    t.out_prob = ts.d_out_prob.p;
     if (cfg.sorted) {
-        t.a_pkt = c->d_a_pkt.p;
-        t.a_dst = c->d_a_dst.p;
-        t.a_verdict = c->d_a_verdict.p;
-        t.a_rssi = c->d_a_rssi.p;
-        t.a_sinr = c->d_a_sinr.p;
-        t.a_prob = c->d_a_prob.p;
+        t.a_pkt = ts.d_a_pkt.p;
+        t.a_dst = ts.d_a_dst.p;
+        t.a_verdict = ts.d_a_verdict.p;
+        t.a_rssi = ts.d_a_rssi.p;
+        t.a_sinr = ts.d_a_sinr.p;
+        t.a_prob = ts.d_a_prob.p;
     } else { // engine order == node-index order: the scatter writes the final records directly
         t.a_pkt = t.out_pkt;
         t.a_dst = t.out_dst;
@@ -667,23 +699,43 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         t.a_sinr = t.out_sinr;
         t.a_prob = t.out_prob;
     }
-    t.pkt_interference = c->d_pkt_interf.p;
-    t.draw_scan = c->d_draw_scan.p;
-    t.scan_block = c->d_scan_block.p;
+    t.pkt_interference = ts.d_pkt_interf.p;
+    t.draw_scan = ts.d_draw_scan.p;
+    t.scan_block = ts.d_scan_block.p;
     t.rng_state = c->d_rng.p;
-    t.pkt_rng = c->d_pkt_rng.p;
-    t.pkt_draw_cnt = c->d_pkt_draw_cnt.p;
+    t.pkt_rng = ts.d_pkt_rng.p;
+    t.pkt_draw_cnt = ts.d_pkt_draw_cnt.p;
 
-    hipStream_t s = c->stream;
-    c->last = t;
-    c->last_links = 0;
-    if (n_new <= 0 || rx_count <= 0) {
+    ts.last = t;
+    ts.last_links = 0;
+    plan.sinr = sinr;
+    plan.stochastic = stochastic;
+    plan.partitioned = partitioned;
+    plan.empty = (n_new <= 0 || rx_count <= 0);
+    if (plan.empty) {
         // nothing to sweep: publish an empty result in this parity's counters
-        RM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), s));
-        c->have_result = true;
+        RM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), c->stream));
+        ts.have_result = true;
         return RM_OK;
     }
-    c->parity ^= 1; // k_filter zeroes the other parity for the next tick
+    ts.parity ^= 1; // the filter stage zeroes the other parity for the next tick
+    // links resolved: every evaluated frame against every other node (T * (N-1)); for a receiver
+    // partition the frame's own source may lie outside it, so the product is reported as is
+    ts.last_links = (rx_count == c->n) ? int64_t(n_eval) * (rx_count - 1) : int64_t(n_eval) * rx_count;
+    return RM_OK;
+}
+
+// the launch sequence of one prepared tick
+int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
+{
+    if (plan.empty) return RM_OK;
+    const rm::TickDev &t = plan.t;
+    const rm::LaunchCfg &cfg = plan.cfg;
+    const bool sinr = plan.sinr, stochastic = plan.stochastic, partitioned = plan.partitioned;
+    const int rx_count = t.n_rx;
+    const rm::ModelDev m = model_dev(c);
+    const rm::NodesDev nd = nodes_dev(c);
+    hipStream_t s = c->stream;
     // The launch sequence.  On a sampled tick (rm_profile_enable) every stage is bracketed by HIP
     // events on the stream; otherwise the stages are launched back to back (or, with RM_GRAPH=1,
     // replayed from an instantiated hipGraph keyed by the launch arguments).
@@ -706,7 +758,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         return RM_OK;
     };
     auto sequence = [&]() -> int {
-        if (sinr) RM_HIP(hipMemsetAsync(c->d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        if (sinr) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
         if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         RM_TRY(stage(RM_STAGE_FILTER));
         RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
@@ -786,15 +838,20 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
         RM_TRY(sequence());
     }
 
-    // links resolved: every evaluated frame against every other node (T * (N-1)); for a receiver
-    // partition the frame's own source may lie outside it, so the product is reported as is
     if (stochastic && partitioned) {
-        c->draws_pending = true;
-        c->pending_model = m;
+        ts.draws_pending = true;
+        ts.pending_model = m;
     }
-    c->last_links = (rx_count == c->n) ? int64_t(n_eval) * (rx_count - 1) : int64_t(n_eval) * rx_count;
-    c->have_result = true;
+    ts.have_result = true;
     return RM_OK;
+}
+
+int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
+             int64_t src_start_us = 0, int64_t src_air_us = 0)
+{
+    TickPlan plan;
+    RM_TRY(prepare_tick(c, *c, plan, false, tx, n_active, first_new, src_list, src_start_us, src_air_us));
+    return launch_tick(c, *c, plan);
 }
 
 int drain_profile(rm_context *c)
@@ -896,18 +953,10 @@ void rm_destroy(rm_context *c)
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
-    c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release(); c->d_p_txf.release(); c->d_p_ch.release();
-    c->d_p_src.release(); c->d_p_inv.release(); c->d_near_cnt.release(); c->d_near_list.release(); c->d_work.release();
-    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_tx.release();
-    c->d_cnt.release(); c->d_off.release(); c->d_slot_tot.release(); c->d_cursor.release(); c->d_shards.release(); c->d_cand_tot.release();
-    c->d_seg_off.release(); c->d_a_e.release(); c->d_slot_off.release();
-    c->d_counters.release(); c->d_st_pkt.release(); c->d_st_dst.release(); c->d_st_next.release();
-    c->d_head.release(); c->d_st_blk.release(); c->d_st_aux.release(); c->d_st_prob.release(); c->d_st_orig.release(); c->d_st_lin.release();
-    c->d_st_sinr.release(); c->d_st_flags.release(); c->d_st_coll.release(); c->d_out_pkt.release();
-    c->d_out_dst.release(); c->d_out_verdict.release(); c->d_pkt_interf.release(); c->d_out_rssi.release();
-    c->d_out_sinr.release(); c->d_out_prob.release(); c->d_a_pkt.release(); c->d_a_dst.release();
-    c->d_a_verdict.release(); c->d_a_rssi.release(); c->d_a_sinr.release(); c->d_a_prob.release();
-    c->d_draw_scan.release(); c->d_scan_block.release(); c->d_rng.release(); c->d_pkt_rng.release(); c->d_pkt_draw_cnt.release(); c->d_all_cnt.release();
+    c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
+    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release();
+    c->release_all();
+    for (auto &sl : c->extra_slots) sl->release_all();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1171,31 +1220,31 @@ int rm_enqueue_tx_records(rm_context *c, const rm_tx_record *recs, int32_t n)
     return RM_OK;
 }
 
-static int copy_out(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
+static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
                     uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
 {
-    if (c->draws_pending)
+    if (ts.draws_pending)
         return fail(RM_ERR_STATE, "this rank's verdicts wait for the other ranks' draw counts: exchange "
                                   "rm_draw_counts_device and call rm_tick_finish_draws first");
     hipStream_t s = c->stream;
     uint32_t oc[3] = {0, 0, 0};
-    RM_HIP(hipMemcpyAsync(oc, c->last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
+    RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
     RM_HIP(hipStreamSynchronize(s));
     if (count) *count = oc[2];
     const uint32_t k = std::min(oc[0], cap);
     if (k) {
-        if (pkt) RM_HIP(hipMemcpyAsync(pkt, c->d_out_pkt.p, k * 4ull, hipMemcpyDeviceToHost, s));
-        if (dst) RM_HIP(hipMemcpyAsync(dst, c->d_out_dst.p, k * 4ull, hipMemcpyDeviceToHost, s));
-        if (verdict) RM_HIP(hipMemcpyAsync(verdict, c->d_out_verdict.p, k, hipMemcpyDeviceToHost, s));
-        if (rssi) RM_HIP(hipMemcpyAsync(rssi, c->d_out_rssi.p, k * 8ull, hipMemcpyDeviceToHost, s));
-        if (sinr) RM_HIP(hipMemcpyAsync(sinr, c->d_out_sinr.p, k * 8ull, hipMemcpyDeviceToHost, s));
+        if (pkt) RM_HIP(hipMemcpyAsync(pkt, ts.d_out_pkt.p, k * 4ull, hipMemcpyDeviceToHost, s));
+        if (dst) RM_HIP(hipMemcpyAsync(dst, ts.d_out_dst.p, k * 4ull, hipMemcpyDeviceToHost, s));
+        if (verdict) RM_HIP(hipMemcpyAsync(verdict, ts.d_out_verdict.p, k, hipMemcpyDeviceToHost, s));
+        if (rssi) RM_HIP(hipMemcpyAsync(rssi, ts.d_out_rssi.p, k * 8ull, hipMemcpyDeviceToHost, s));
+        if (sinr) RM_HIP(hipMemcpyAsync(sinr, ts.d_out_sinr.p, k * 8ull, hipMemcpyDeviceToHost, s));
     }
-    const int n_new = c->last_n_new;
+    const int n_new = ts.last_n_new;
     if (pkt_interference && n_new > 0)
-        RM_HIP(hipMemcpyAsync(pkt_interference, c->d_pkt_interf.p, size_t(n_new), hipMemcpyDeviceToHost, s));
+        RM_HIP(hipMemcpyAsync(pkt_interference, ts.d_pkt_interf.p, size_t(n_new), hipMemcpyDeviceToHost, s));
     if (pkt_offset) {
         if (n_new > 0 && part_count(c) > 0)
-            RM_HIP(hipMemcpyAsync(pkt_offset, c->d_slot_off.p + c->last.shift, (size_t(n_new) + 1) * 4,
+            RM_HIP(hipMemcpyAsync(pkt_offset, ts.d_slot_off.p + ts.last.shift, (size_t(n_new) + 1) * 4,
                                   hipMemcpyDeviceToHost, s));
         else
             for (int i = 0; i <= std::max(n_new, 0); ++i) pkt_offset[i] = 0;
@@ -1219,7 +1268,7 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     RM_TRY(tick_run_host(c));
-    return copy_out(c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+    return copy_out(c, *c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
 }
 
 // evaluate the tick enqueued with rm_tick_begin / rm_enqueue_tx* (results stay on the device)
@@ -1353,19 +1402,24 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
     return RM_OK;
 }
 
+static int result_device(rm_context *c, TickSlot &ts, rm_device_result *out)
+{
+    if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    out->count = ts.last.out_count;
+    out->pkt_offset = ts.d_slot_off.p + ts.last.shift;
+    out->pkt = ts.d_out_pkt.p;
+    out->dst = ts.d_out_dst.p;
+    out->verdict = ts.d_out_verdict.p;
+    out->rssi = ts.d_out_rssi.p;
+    out->sinr = ts.d_out_sinr.p;
+    out->capacity = c->cap;
+    return RM_OK;
+}
+
 int rm_result_device(rm_context *c, rm_device_result *out)
 {
     if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
-    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
-    out->count = c->last.out_count;
-    out->pkt_offset = c->d_slot_off.p + c->last.shift;
-    out->pkt = c->d_out_pkt.p;
-    out->dst = c->d_out_dst.p;
-    out->verdict = c->d_out_verdict.p;
-    out->rssi = c->d_out_rssi.p;
-    out->sinr = c->d_out_sinr.p;
-    out->capacity = c->cap;
-    return RM_OK;
+    return result_device(c, *c, out);
 }
 
 int rm_draws_pending(const rm_context *c) { return (c && c->draws_pending) ? 1 : 0; }
@@ -1413,20 +1467,168 @@ int rm_result_copy(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, 
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
-    return copy_out(c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+    return copy_out(c, *c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+}
+
+static int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *dropped)
+{
+    if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    uint32_t oc[3];
+    RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    if (count) *count = oc[2];
+    if (dropped) *dropped = oc[1];
+    return RM_OK;
 }
 
 int rm_result_count(rm_context *c, uint32_t *count, uint32_t *dropped)
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
-    if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
-    RM_HIP(hipSetDevice(c->device));
-    uint32_t oc[3];
-    RM_HIP(hipMemcpyAsync(oc, c->last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
-    RM_HIP(hipStreamSynchronize(c->stream));
-    if (count) *count = oc[2];
-    if (dropped) *dropped = oc[1];
+    return result_count(c, *c, count, dropped);
+}
+
+// ---- several independent ticks per pass ------------------------------------------------------------
+
+static TickSlot *slot_of(rm_context *c, int32_t slot)
+{
+    if (slot == 0) return c;
+    if (slot < 0 || size_t(slot) > c->extra_slots.size()) return nullptr;
+    return c->extra_slots[size_t(slot) - 1].get();
+}
+
+// the launch sequence of n prepared ticks in four launches (sorted table, fp32 frame, no SINR)
+static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n)
+{
+    rm::TickDev ticks[RM_MAX_BATCH];
+    for (int b = 0; b < n; ++b) ticks[b] = plans[b].t;
+    const rm::ModelDev m = model_dev(c);
+    const rm::NodesDev nd = nodes_dev(c);
+    const rm::LaunchCfg &cfg = plans[0].cfg;
+    hipStream_t s = c->stream;
+    const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
+    rm_context::Sample *smp = nullptr;
+    if (sample) {
+        if (c->ev_used == c->ev_pool.size()) {
+            rm_context::Sample ns;
+            for (auto &e : ns.ev) RM_HIP(hipEventCreate(&e));
+            c->ev_pool.push_back(ns);
+        }
+        smp = &c->ev_pool[c->ev_used++];
+        smp->n = 0;
+    }
+    auto stage = [&](int id) -> int {
+        if (smp) {
+            RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+            smp->stage[smp->n++] = id;
+        }
+        return RM_OK;
+    };
+    if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
+    RM_TRY(stage(RM_STAGE_FILTER));
+    RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, cfg));
+    RM_TRY(stage(RM_STAGE_EXACT));
+    RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, cfg));
+    RM_TRY(stage(RM_STAGE_REORDER));
+    RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, cfg));
+    if (cfg.stochastic) {
+        // the shared generator is walked tick by tick, in slot order
+        RM_TRY(stage(RM_STAGE_DRAWS));
+        for (int b = 0; b < n; ++b) {
+            RM_HIP(rm::launch_draws_scan(s, ticks[b]));
+            RM_HIP(rm::launch_draws_apply(s, m, ticks[b], nullptr, 1, 0));
+        }
+    }
+    if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+    for (int b = 0; b < n; ++b) slots[b]->have_result = true;
     return RM_OK;
+}
+
+static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                     const int32_t *const *dev_src, const rm_tx_record *const *dev_new, const int32_t *n_per,
+                     const int64_t *start_us, const int64_t *air_us)
+{
+    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || !n_per || (!dev_src && !dev_new) ||
+        (dev_src && (!start_us || !air_us)))
+        return fail(RM_ERR_INVALID, "bad arguments");
+    for (int b = 0; b < n_ticks; ++b)
+        if (n_per[b] < 0 || (n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
+            (dev_src && air_us[b] < 0))
+            return fail(RM_ERR_INVALID, "bad arguments");
+    if (is_sinr(c))
+        return fail(RM_ERR_STATE, "the SINR medium carries its on-air list from tick to tick: run it one tick at a time");
+    RM_HIP(hipSetDevice(c->device));
+    if (maybe_draws(c) && part_count(c) != c->n)
+        return fail(RM_ERR_STATE, "a receiver partition whose links draw needs rm_tick_finish_draws per tick: run it one "
+                                  "tick at a time");
+    while (c->extra_slots.size() + 1 < size_t(n_ticks)) c->extra_slots.emplace_back(new TickSlot());
+    TickSlot *slots[RM_MAX_BATCH];
+    TickPlan plans[RM_MAX_BATCH];
+    bool batched = true;
+    for (int b = 0; b < n_ticks; ++b) {
+        TickSlot &ts = *slot_of(c, b);
+        slots[b] = &ts;
+        const rm_tx_record *tx = nullptr;
+        if (dev_src) {
+            RM_HIP(ts.d_tx.ensure(std::max(n_per[b], 1)));
+            tx = ts.d_tx.p;
+        } else {
+            tx = dev_new[b];
+        }
+        RM_TRY(prepare_tick(c, ts, plans[b], true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr,
+                            dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0));
+        batched = batched && !plans[b].empty && rm::batch_eligible(plans[b].t, plans[b].cfg, model_dev(c)) &&
+                  plans[b].t.rpt == plans[0].t.rpt;
+    }
+    c->t_begin = t_begin_us[0];
+    c->t_end = t_end_us[n_ticks - 1];
+    if (batched) return launch_batch(c, slots, plans, n_ticks);
+    // configurations the batched kernels do not cover (fp64 frame, unsorted table, very many frames,
+    // empty ticks): the same ticks, one launch sequence each
+    for (int b = 0; b < n_ticks; ++b) RM_TRY(launch_tick(c, *slots[b], plans[b]));
+    return RM_OK;
+}
+
+int rm_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                const int32_t *const *dev_src, const int32_t *n_src, const int64_t *start_us,
+                                const int64_t *air_us)
+{
+    if (!dev_src) return fail(RM_ERR_INVALID, "bad arguments");
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, dev_src, nullptr, n_src, start_us, air_us);
+}
+
+int rm_batch_run_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                        const rm_tx_record *const *dev_new, const int32_t *n_new)
+{
+    if (!dev_new) return fail(RM_ERR_INVALID, "bad arguments");
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, dev_new, n_new, nullptr, nullptr);
+}
+
+int rm_batch_result_device(rm_context *c, int32_t slot, rm_device_result *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts) return fail(RM_ERR_INVALID, "no such result slot");
+    return result_device(c, *ts, out);
+}
+
+int rm_batch_result_count(rm_context *c, int32_t slot, uint32_t *count, uint32_t *dropped)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts) return fail(RM_ERR_INVALID, "no such result slot");
+    return result_count(c, *ts, count, dropped);
+}
+
+int rm_batch_result_copy(rm_context *c, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,
+                         double *sinr, uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts) return fail(RM_ERR_INVALID, "no such result slot");
+    if (!ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    return copy_out(c, *ts, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
 }
 
 int rm_sync(rm_context *c)

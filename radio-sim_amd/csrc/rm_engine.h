@@ -17,7 +17,9 @@ constexpr int kShards = 256;        // append counters of the candidate list (on
 constexpr int kShadowBins = 256;    // bins over rho = d^2 / cut^2 of the shadowing table
 constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
 constexpr int kNearCap = 4096;      // near frames one workgroup (1024 receivers) can list per tick (large-grid path)
-constexpr int kShardStride = 32;    // u32 words between shard counters: one 128-byte line each
+enum { kFilterGrid = 0, kFilterList = 1, kFilterWg = 2 }; // TickDev::filter_mode (plan_filter)
+constexpr int kShardStride = 32;
+constexpr int kMaxBatch = RM_MAX_BATCH; // ticks per batched launch: their descriptors fit the 4 KB of kernel arguments    // u32 words between shard counters: one 128-byte line each
 
 // link-entry flags
 constexpr uint8_t kFlagHeardNew = 1;   // gets an output record
@@ -98,6 +100,7 @@ struct TickDev {
     int n_rx;               // receivers of the partition
     int rpt;                // receiver groups per wave in the filter kernel
     int n_slabs;            // ceil(n_rx / (64*rpt))
+    int filter_mode;        // kFilterGrid / kFilterList / kFilterWg
     // per (slot, slab) heard counts / offsets (off is relative to the frame's first link), layout [(chunk*n_slabs + slab)*64 + lane]
     uint32_t *cnt, *off;
     uint32_t *slot_tot;     // [n_cnt] heard links per frame slot
@@ -168,7 +171,10 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
                           int64_t air_us, rm_tx_record *out);
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
-bool filter_uses_lists(const TickDev &t, const LaunchCfg &cfg);
+int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);
+bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
+hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                              const LaunchCfg &cfg);
 hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                         const LaunchCfg &cfg);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);

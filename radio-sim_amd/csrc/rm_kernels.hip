@@ -17,6 +17,9 @@
 
 #include "rm_engine.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 #include <math.h>
 
 namespace rm {
@@ -961,6 +964,320 @@ __global__ void __launch_bounds__(kBlock, 6) k_filter_list(const NodesDev nd, co
     }
 }
 
+
+// ============================================================================ two-level filter
+// k_tick_prep: one thread per swept frame -- builds the frame's on-air record (build mode) and its
+// pre-filter record once per tick, and zeroes the counters later kernels add to.
+// k_filter_wg: one workgroup per 4*RPT receiver groups.  Phase A: every thread tests frames
+// against the union box of the workgroup's receivers and the near ones are compacted into LDS
+// (a few dozen of a thousand at the bench densities).  Phase B: each wave runs the two-pass
+// filter of k_filter over chunks of 64 near frames for its own RPT groups.
+
+constexpr int kNearLds = 512; // near-frame records held in LDS between two phase-B rounds
+
+RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
+{
+    const int n_eval = t.n_active - t.first_eval;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 8) t.next_counters[threadIdx.x] = 0u;
+        t.next_shard_count[threadIdx.x * kShardStride] = 0u; // kBlock == kShards
+    }
+    if (!t.use_matrix)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.zero_len; i += gridDim.x * blockDim.x) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
+        }
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_eval) return;
+    const int abs_i = t.first_eval + e;
+    rm_tx_record tx;
+    if (t.src_list && abs_i >= t.first_new) {
+        tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
+        t.tx_build[abs_i] = tx;
+    } else {
+        tx = t.tx[abs_i];
+    }
+    float4 f;
+    double thr64;
+    tx_prefilter(m, tx, f, thr64);
+    float inv = 0.f;
+    if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) {
+        const double cut = sqrt(double(f.w));
+        if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
+    }
+    t.p_txf[e] = f;
+    t.p_ch[e] = tx.channel;
+    t.p_src[e] = tx.src;
+    t.p_inv[e] = inv;
+}
+
+__global__ void __launch_bounds__(256) k_tick_prep(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    tick_prep_body(nd, m, t);
+}
+
+template <int RPT, bool SHADOW>
+RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
+{
+    __shared__ float4 s_txf[kNearLds];
+    __shared__ int s_ch[kNearLds];
+    __shared__ int s_e[kNearLds];
+    __shared__ float s_inv[SHADOW ? kNearLds : 1];
+    __shared__ int s_src[SHADOW ? kNearLds : 1];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT];
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
+    __shared__ uint32_t s_n;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wg = blockIdx.x;
+    const int slab = wg * kWavesPerBlock + wave;
+    const int jbase = slab * (kGroup * RPT);
+    const bool live = slab < t.n_slabs;
+    const int n_eval = t.n_active - t.first_eval;
+    const int n_groups = (t.n_rx + kGroup - 1) / kGroup;
+
+    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
+    if (threadIdx.x == 0) s_n = 0u;
+
+    // phase A works on kUnrollA x 256 frames at a time: their records are requested together (one
+    // exposed round trip per 1024 frames), the first ones before anything else
+    constexpr int kUnrollA = 4;
+    float4 af[kUnrollA];
+    int ach[kUnrollA], asrc[kUnrollA];
+    float ainv[kUnrollA];
+    auto request = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < kUnrollA; ++u) {
+            const int e = g0 + u * kBlock + int(threadIdx.x);
+            af[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+            ach[u] = 0;
+            asrc[u] = -1;
+            ainv[u] = 0.f;
+            if (e < n_eval) {
+                af[u] = t.p_txf[e];
+                ach[u] = t.p_ch[e];
+                if (SHADOW) {
+                    ainv[u] = t.p_inv[e];
+                    asrc[u] = t.p_src[e];
+                }
+            }
+        }
+    };
+    request(0);
+
+    // this wave's receivers, resident in registers for the whole tick
+    float fx[RPT], fy[RPT], fz[RPT];
+    int fch[RPT], forig[RPT];
+    float4 bxy[RPT];
+    float2 bz[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int j = jbase + r * kGroup + lane;
+        fx[r] = fy[r] = fz[r] = __builtin_nanf("");
+        fch[r] = 0;
+        forig[r] = 0;
+        if (live && j < t.n_rx) {
+            const float4 v = nd.rxf[j];
+            fx[r] = v.x;
+            fy[r] = v.y;
+            fz[r] = v.z;
+            fch[r] = __float_as_int(v.w);
+            if (SHADOW) forig[r] = nd.orig[j];
+        }
+        const int g = slab * RPT + r;
+        const bool ok = live && g * kGroup < t.n_rx;
+        bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
+    }
+
+    // union box of the workgroup's 4*RPT groups
+    float4 wxy;
+    float2 wz;
+    if (RPT == 4) {
+        wxy = nd.wg_box_xy[wg];
+        wz = nd.wg_box_z[wg];
+    } else {
+        const float inf_ = __builtin_inff();
+        wxy = make_float4(inf_, inf_, -inf_, -inf_);
+        wz = make_float2(inf_, -inf_);
+        for (int g = wg * kWavesPerBlock * RPT; g < min(n_groups, (wg + 1) * kWavesPerBlock * RPT); ++g) { // uniform
+            const float4 q = nd.bbox_xy[g];
+            const float2 qz = nd.bbox_z[g];
+            wxy.x = fminf(wxy.x, q.x);
+            wxy.y = fminf(wxy.y, q.y);
+            wxy.z = fmaxf(wxy.z, q.z);
+            wxy.w = fmaxf(wxy.w, q.w);
+            wz.x = fminf(wz.x, qz.x);
+            wz.y = fmaxf(wz.y, qz.y);
+        }
+    }
+    __syncthreads();
+
+    uint32_t round = 0;
+    for (int g0 = 0; g0 < n_eval; g0 += kUnrollA * kBlock) { // block-uniform
+    if (g0) request(g0);
+#pragma unroll 1
+    for (int u = 0; u < kUnrollA; ++u) { // rolled: one copy of phase B; the records are selected, not indexed
+        const int f0 = g0 + u * kBlock;
+        if (f0 >= n_eval) break; // block-uniform
+        // phase A: this thread's frame against the workgroup box
+        const int e = f0 + int(threadIdx.x);
+        float4 tfa = af[0];
+        int cha = ach[0], srca = asrc[0];
+        float inva = ainv[0];
+#pragma unroll
+        for (int k = 1; k < kUnrollA; ++k) {
+            tfa.x = (u == k) ? af[k].x : tfa.x;
+            tfa.y = (u == k) ? af[k].y : tfa.y;
+            tfa.z = (u == k) ? af[k].z : tfa.z;
+            tfa.w = (u == k) ? af[k].w : tfa.w;
+            cha = (u == k) ? ach[k] : cha;
+            srca = (u == k) ? asrc[k] : srca;
+            inva = (u == k) ? ainv[k] : inva;
+        }
+        bool hit = false;
+        if (e < n_eval) {
+            const float dx = fmaxf(fmaxf(wxy.x - tfa.x, tfa.x - wxy.z), 0.f);
+            const float dy = fmaxf(fmaxf(wxy.y - tfa.y, tfa.y - wxy.w), 0.f);
+            const float dz = fmaxf(fmaxf(wz.x - tfa.z, tfa.z - wz.y), 0.f);
+            hit = dist2_f32(dx, dy, dz) <= tfa.w;
+        }
+        const uint64_t hm = ballot64(hit);
+        if (hm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, uint32_t(__popcll(hm)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const uint32_t k = base + lane_prefix(hm);
+                s_txf[k] = tfa;
+                s_ch[k] = cha;
+                s_e[k] = e;
+                if (SHADOW) {
+                    s_inv[k] = inva;
+                    s_src[k] = srca;
+                }
+            }
+        }
+        __syncthreads();
+        const int n_near = int(s_n);
+        const bool last = f0 + kBlock >= n_eval;
+        if (!last && n_near + kBlock <= kNearLds) continue; // room for another 256 frames
+
+        // phase B: chunks of 64 near frames, every wave for its own groups
+        if (live) {
+            for (int c0 = 0; c0 < n_near; c0 += kTxChunk) {
+                const int nt = min(kTxChunk, n_near - c0);
+                uint64_t near[RPT];
+                uint64_t todo = 0;
+                {
+                    const float4 tf = s_txf[c0 + min(lane, nt - 1)];
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        near[r] = 0;
+                        if ((slab * RPT + r) * kGroup < t.n_rx) {
+                            const float dx = fmaxf(fmaxf(bxy[r].x - tf.x, tf.x - bxy[r].z), 0.f);
+                            const float dy = fmaxf(fmaxf(bxy[r].y - tf.y, tf.y - bxy[r].w), 0.f);
+                            const float dz = fmaxf(fmaxf(bz[r].x - tf.z, tf.z - bz[r].y), 0.f);
+                            near[r] = ballot64(lane < nt && dist2_f32(dx, dy, dz) <= tf.w);
+                        }
+                        todo |= near[r];
+                    }
+                }
+                uint32_t my_total = 0;
+                uint64_t walk = todo;
+                while (walk) {
+                    const int ti = __ffsll((long long)walk) - 1; // wave-uniform
+                    walk &= walk - 1;
+                    const float4 tf = s_txf[c0 + ti];
+                    const int tch = s_ch[c0 + ti];
+                    uint64_t mask[RPT];
+                    uint32_t total = 0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        mask[r] = 0;
+                        if ((near[r] >> ti) & 1ull) {
+                            const float s2 = dist2_f32(fx[r] - tf.x, fy[r] - tf.y, fz[r] - tf.z);
+                            bool h = (s2 <= tf.w) && (fch[r] == tch);
+                            if (SHADOW && h) {
+                                const int bin = min(kShadowBins - 1, int(s2 * s_inv[c0 + ti]));
+                                const uint32_t a = uint32_t(s_src[c0 + ti]), bb = uint32_t(forig[r]);
+                                const uint64_t key = (uint64_t(a < bb ? a : bb) << 32) | uint64_t(a < bb ? bb : a);
+                                h = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                            }
+                            mask[r] = ballot64(h);
+                            total += uint32_t(__popcll(mask[r]));
+                        }
+                    }
+                    if (total) {
+                        if (lane == ti) my_total = total;
+                        if (lane < RPT) {
+                            uint64_t v = mask[0];
+#pragma unroll
+                            for (int r = 1; r < RPT; ++r) v = (lane == r) ? mask[r] : v;
+                            s_mask[wave][ti][lane] = v;
+                        }
+                    }
+                }
+                const uint64_t have = ballot64(my_total != 0u);
+                if (have == 0) continue;
+                const int my_e = s_e[c0 + min(lane, nt - 1)];
+                if (!t.use_matrix && my_total != 0u && t.first_eval + my_e >= t.first_new)
+                    atomicAdd(&t.cand_tot[my_e - t.cnt_base], my_total);
+                uint32_t inc = my_total;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d);
+                    if (lane >= d) inc += o;
+                }
+                const uint32_t wave_total = __shfl(inc, 63);
+                const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + blockIdx.z * 101u) & (kShards - 1);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + wave_total > t.seg_cap) { // the shard is full: drop the run, flag the tick
+                    if (lane == 0) t.stage_count[1] = 1u;
+                    continue;
+                }
+                const uint32_t my_base = shard * t.seg_cap + base + inc - my_total;
+                walk = have;
+                while (walk) {
+                    const int ti = __ffsll((long long)walk) - 1;
+                    walk &= walk - 1;
+                    const uint32_t fbase = __shfl(my_base, ti);
+                    const int e_ti = s_e[c0 + ti];
+                    uint32_t pre = 0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const uint64_t mk = s_mask[wave][ti][r];
+                        if (mk == 0) continue;
+                        if ((mk >> lane) & 1ull) {
+                            const uint32_t idx = fbase + pre + lane_prefix(mk);
+                            t.st_pkt[idx] = e_ti;
+                            t.st_dst[idx] = jbase + r * kGroup + lane;
+                            t.st_blk[idx] = fbase;
+                        }
+                        pre += uint32_t(__popcll(mk));
+                    }
+                }
+            }
+        }
+        round += uint32_t(kNearLds / kTxChunk);
+        if (!last) {
+            __syncthreads(); // every wave is done with the LDS records
+            if (threadIdx.x == 0) s_n = 0u;
+            __syncthreads();
+        }
+    }
+    }
+}
+
+template <int RPT, bool SHADOW>
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : 6) k_filter_wg(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    filter_wg_body<RPT, SHADOW>(nd, m, t);
+}
+
 // ============================================================================ exact evaluation
 
 struct LinkEval {
@@ -1093,6 +1410,61 @@ RM_D uint32_t block_scan_counts(const uint32_t *cnt, int n, uint32_t *s_off, uin
     return total;
 }
 
+// The same for at most kSmallScan counts (the bench's 1000 frames per tick): four counts per thread,
+// requested with small_scan_load at the top of the kernel so that the round trip overlaps the
+// kernel's own first loads, and only 4 KB of LDS (the occupancy of the consumers is LDS-bound).
+constexpr int kSmallScan = 1024;
+struct SmallCounts {
+    uint32_t v[4];
+};
+RM_D SmallCounts small_scan_load(const uint32_t *cnt, int n)
+{
+    SmallCounts c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = int(threadIdx.x) * 4 + k;
+        c.v[k] = (i < n) ? cnt[i] : 0u;
+    }
+    return c;
+}
+RM_D uint32_t small_scan(const SmallCounts &c, int n, uint32_t *s_off, uint32_t *s_wave /*[4]*/, uint32_t *pub, uint32_t *vmax_out)
+{
+    const uint32_t sum = c.v[0] + c.v[1] + c.v[2] + c.v[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = int(threadIdx.x) * 4 + k;
+        if (i < n) {
+            s_off[i] = run;
+            if (pub) pub[i] = run;
+        }
+        run += c.v[k];
+    }
+    if (pub && threadIdx.x == 0) pub[n] = total;
+    if (vmax_out) {
+        uint32_t vmax = max(max(c.v[0], c.v[1]), max(c.v[2], c.v[3]));
+        for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), d)));
+        // the publisher needs the maximum over the whole workgroup
+        __shared__ uint32_t s_vmax[4];
+        if (lane == 0) s_vmax[wave] = vmax;
+        __syncthreads();
+        *vmax_out = max(max(s_vmax[0], s_vmax[1]), max(s_vmax[2], s_vmax[3]));
+    }
+    __syncthreads();
+    return total;
+}
+
 RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
 {
     // UDGMRadioMedium.java:63-65 uses successRatioRx (sic); N2NRadioMedium.java:24-26
@@ -1104,15 +1476,17 @@ RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
 // SEG 0: unsorted table, heard links are counted per (frame, slab) cell (ordered scatter later).
 // SEG 1/2: sorted table, heard links go straight into the frame's segment of the A records (any
 // order inside it); the segment offsets are the scan of the per-frame candidate counts, redone in
-// LDS by every workgroup (1) or read from k_scan_counts' output (2).
+// LDS by every workgroup (1; 3 = the same for at most kSmallScan frames) or read from k_scan_counts' output (2).
 template <int MODEL, bool SINR, bool STOCH, int SEG>
-__global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev m, const TickDev t)
+RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
 {
-    __shared__ uint32_t s_seg[SEG == 1 ? kFusedScanMax + 1 : 1];
+    __shared__ uint32_t s_seg[SEG == 1 ? kFusedScanMax + 1 : (SEG == 3 ? kSmallScan + 1 : 1)];
     __shared__ uint32_t s_wave[4];
     const bool publisher = (blockIdx.x == 0 && blockIdx.y == 0);
     bool scanned = false; // the scan is only needed by the scatter: it runs after the first evaluation
     const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    SmallCounts pre{};
+    if (SEG == 3 && (blockIdx.x == 0 || blockIdx.x * blockDim.x < n)) pre = small_scan_load(t.cand_tot, t.n_cnt);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
     const int lane = threadIdx.x & 63;
@@ -1162,6 +1536,10 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
             block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
             scanned = true;
         }
+        if (SEG == 3 && !scanned) {
+            small_scan(pre, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
+            scanned = true;
+        }
         // one atomic per run of same-frame (same-cell) entries
         const RunInfo ri = run_prefix(key, wanted, lane);
         if (SEG == 0) {
@@ -1171,7 +1549,7 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
             if (valid && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total);
             base = __shfl(base, ri.start);
             if (wanted) {
-                const uint32_t o = ((SEG == 1) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
+                const uint32_t o = ((SEG == 1 || SEG == 3) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
                 t.a_dst[o] = orig;
                 t.a_rssi[o] = rssi;
                 if (SINR) t.a_e[o] = int(idx);
@@ -1186,6 +1564,26 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
     }
     if (SEG == 1 && !scanned && publisher) // seg_off is published even if this shard was empty
         block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
+    if (SEG == 3 && !scanned && publisher) small_scan(pre, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
+}
+
+template <int MODEL, bool SINR, bool STOCH, int SEG>
+__global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    exact_body<MODEL, SINR, STOCH, SEG>(nd, m, t);
+}
+
+// Several independent ticks per launch (rm_batch_*): blockIdx.z selects the tick.  The ticks'
+// descriptors travel in the kernel arguments (scalar loads at a uniform offset).
+struct TickBatch {
+    TickDev t[kMaxBatch];
+};
+static_assert(sizeof(TickBatch) + sizeof(NodesDev) + sizeof(ModelDev) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <int MODEL, bool STOCH, bool SMALL>
+__global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickBatch b)
+{
+    exact_body<MODEL, false, STOCH, SMALL ? 3 : 1>(nd, m, b.t[blockIdx.z]);
 }
 
 // half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
@@ -1409,13 +1807,15 @@ RM_D void write_pkt_interference(const ModelDev &m, const TickDev &t, uint32_t f
 // counting through memory.  MODE 1: the scan of the per-frame heard counts is redone in every
 // workgroup (LDS); MODE 2: slot_off comes from k_scan_counts.
 template <bool STOCH, bool SINR, int MODE>
-__global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
+RM_D void reorder_body(const ModelDev &m, const TickDev &t)
 {
-    __shared__ uint32_t s_off[MODE == 1 ? kFusedScanMax + 1 : 1];
+    __shared__ uint32_t s_off[MODE == 1 ? kFusedScanMax + 1 : (MODE == 3 ? kSmallScan + 1 : 1)];
     __shared__ uint32_t s_wave[4];
     const bool publisher = blockIdx.x == 0;
     const int lane = threadIdx.x & 63;
     const int n_new = t.n_active - t.first_new;
+    SmallCounts pre{};
+    if (MODE == 3) pre = small_scan_load(t.cursor, t.n_cnt);
 
     // the first frame of this wave: its records are requested before the scan below, so that the
     // scan's round trip and the records' overlap
@@ -1437,10 +1837,12 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
         }
     }
 
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         uint32_t vmax = 0;
-        const uint32_t total = block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr,
-                                                 publisher ? &vmax : nullptr);
+        const uint32_t total = (MODE == 3)
+                                   ? small_scan(pre, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr, publisher ? &vmax : nullptr)
+                                   : block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr,
+                                                       publisher ? &vmax : nullptr);
         if (publisher && threadIdx.x == 0) {
             t.out_count[0] = total < t.cap ? total : t.cap;
             t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u || (t.near_cnt && t.near_cnt[t.n_wg + 1] != 0u)) ? 1u : 0u;
@@ -1465,7 +1867,7 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
             src0 = t.seg_off[slot];
             len = t.cursor[slot];
         }
-        const uint32_t dst0 = (MODE == 1) ? s_off[slot] : t.slot_off[slot];
+        const uint32_t dst0 = (MODE == 1 || MODE == 3) ? s_off[slot] : t.slot_off[slot];
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {
             const uint32_t o = src0 + c0 + lane;
             const bool valid = c0 + lane < len;
@@ -1500,6 +1902,29 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
         }
     }
     if (!STOCH) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+template <bool STOCH, bool SINR, int MODE>
+__global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
+{
+    reorder_body<STOCH, SINR, MODE>(m, t);
+}
+
+template <bool STOCH, bool SMALL>
+__global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickBatch b)
+{
+    reorder_body<STOCH, false, SMALL ? 3 : 1>(m, b.t[blockIdx.z]);
+}
+
+__global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickBatch b)
+{
+    tick_prep_body(nd, m, b.t[blockIdx.z]);
+}
+
+template <int RPT, bool SHADOW>
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : 6) k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickBatch b)
+{
+    filter_wg_body<RPT, SHADOW>(nd, m, b.t[blockIdx.z]);
 }
 
 // ============================================================================ Java-RNG draws
@@ -1691,12 +2116,37 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
     return hipGetLastError();
 }
 
-bool filter_uses_lists(const TickDev &t, const LaunchCfg &cfg)
+// Chooses the filter variant for this tick and fixes the receiver tiling (t.rpt, t.n_slabs):
+//  kFilterGrid: k_filter on a (slab, tile) grid -- the general variant (fp64 frame, unsorted tables);
+//  kFilterList: k_near_pairs + persistent k_filter_list (RM_FILTER=list);
+//  kFilterWg:   k_tick_prep + k_filter_wg, two-level cull inside one workgroup per 4*rpt groups.
+int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
 {
     const int n_eval = t.n_active - t.first_eval;
-    const long pairs = long((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8) * cdiv(max(n_eval, 1), kTxChunk);
-    // worth it when there are enough filter workgroups to fill the device with list items
-    return cfg.bbox && t.rpt == 4 && pairs > 8192 && t.n_slabs >= 4 * 256;
+    const int n_chunks = cdiv(max(n_eval, 1), kTxChunk);
+    const long waves4 = long(cdiv(t.n_rx, 256)) * n_chunks;
+    // enough waves to fill 256 CUs x 4 SIMDs several times over, else one group per wave
+    t.rpt = (waves4 >= 4096) ? 4 : 1;
+    t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
+    int mode = kFilterGrid;
+    if (cfg.bbox && !cfg.f64_filter) {
+        const long pairs = long((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8) * n_chunks;
+        if (t.rpt == 4 && pairs > 8192 && t.n_slabs >= 4 * 256) mode = kFilterList;
+        if (const char *e = getenv("RM_FILTER")) {
+            if (!strcmp(e, "grid")) mode = kFilterGrid;
+            else if (!strcmp(e, "list")) mode = (t.rpt == 4) ? kFilterList : kFilterGrid;
+            else if (!strcmp(e, "wg")) mode = kFilterWg;
+        }
+        if (want_wg) mode = kFilterWg;
+        if (mode == kFilterWg) {
+            int rpt = (t.n_rx > 400000) ? 4 : 1;
+            if (const char *e = getenv("RM_WG_RPT")) rpt = (atoi(e) == 4) ? 4 : 1;
+            t.rpt = rpt;
+            t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
+        }
+    }
+    t.filter_mode = mode;
+    return mode;
 }
 
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
@@ -1704,7 +2154,19 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
 {
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
-    if (filter_uses_lists(t, cfg)) {
+    if (t.filter_mode == kFilterWg) {
+        hipLaunchKernelGGL(k_tick_prep, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, m, t);
+        const dim3 grid(cdiv(t.n_slabs, kWavesPerBlock)), block(kBlock);
+        if (t.rpt == 4) {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<4, true>), grid, block, 0, s, nd, m, t);
+            else hipLaunchKernelGGL((k_filter_wg<4, false>), grid, block, 0, s, nd, m, t);
+        } else {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<1, true>), grid, block, 0, s, nd, m, t);
+            else hipLaunchKernelGGL((k_filter_wg<1, false>), grid, block, 0, s, nd, m, t);
+        }
+        return hipGetLastError();
+    }
+    if (t.filter_mode == kFilterList) {
         // near_cnt is all zero here: zero-filled at allocation, re-zeroed by every tick's k_reorder
         hipLaunchKernelGGL(k_near_pairs, dim3(cdiv(n_eval, 4)), dim3(256), 0, s, nd, m, t);
         if (cfg.shadow) hipLaunchKernelGGL(k_filter_list<true>, dim3(1536), dim3(kBlock), 0, s, nd, m, t);
@@ -1739,12 +2201,12 @@ template <int MODEL, bool SINR>
 static void launch_exact_m(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
 {
     const dim3 grid(4, kShards), block(256);
-    const int seg = t.use_matrix ? 0 : (t.n_cnt <= kFusedScanMax ? 1 : 2);
+    const int seg = t.use_matrix ? 0 : (t.n_cnt <= kSmallScan ? 3 : (t.n_cnt <= kFusedScanMax ? 1 : 2));
 #define RM_EX(ST, SG) hipLaunchKernelGGL((k_exact<MODEL, SINR, ST, SG>), grid, block, 0, s, nd, m, t)
     if (cfg.stochastic) {
-        if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else RM_EX(true, 2);
+        if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else if (seg == 3) RM_EX(true, 3); else RM_EX(true, 2);
     } else {
-        if (seg == 0) RM_EX(false, 0); else if (seg == 1) RM_EX(false, 1); else RM_EX(false, 2);
+        if (seg == 0) RM_EX(false, 0); else if (seg == 1) RM_EX(false, 1); else if (seg == 3) RM_EX(false, 3); else RM_EX(false, 2);
     }
 #undef RM_EX
 }
@@ -1825,9 +2287,12 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
     const int n_new = t.n_active - t.first_new;
     const dim3 grid(max(1, min(2048, (n_new + 3) / 4))), block(256);
     const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
-    const int mode = t.n_cnt <= kFusedScanMax ? 1 : 2;
+    const int mode = t.n_cnt <= kSmallScan ? 3 : (t.n_cnt <= kFusedScanMax ? 1 : 2);
 #define RM_RE(ST, SI, MO) hipLaunchKernelGGL((k_reorder<ST, SI, MO>), grid, block, 0, s, m, t)
-    if (mode == 1) {
+    if (mode == 3) {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 3); else RM_RE(true, false, 3); }
+        else { if (sinr) RM_RE(false, true, 3); else RM_RE(false, false, 3); }
+    } else if (mode == 1) {
         if (cfg.stochastic) { if (sinr) RM_RE(true, true, 1); else RM_RE(true, false, 1); }
         else { if (sinr) RM_RE(false, true, 1); else RM_RE(false, false, 1); }
     } else {
@@ -1835,6 +2300,73 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
         else { if (sinr) RM_RE(false, true, 2); else RM_RE(false, false, 2); }
     }
 #undef RM_RE
+    return hipGetLastError();
+}
+
+// rm_batch_*: n independent ticks (sorted table, fp32 frame, no SINR, <= kFusedScanMax frames each)
+// in four launches.  stage 0: k_tick_prep + k_filter_wg, 1: k_exact, 2: k_reorder.
+bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
+{
+    const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
+    return cfg.sorted && cfg.bbox && !cfg.f64_filter && !sinr && !t.use_matrix && t.n_cnt <= kFusedScanMax &&
+           t.filter_mode == kFilterWg && t.n_active > t.first_new && t.n_rx > 0;
+}
+
+hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                              const LaunchCfg &cfg)
+{
+    if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
+    TickBatch b{};
+    int max_eval = 0, max_new = 0;
+    bool small = true; // every tick's counts fit the small fused scan
+    for (int i = 0; i < n; ++i) {
+        b.t[i] = ticks[i];
+        small = small && ticks[i].n_cnt <= kSmallScan;
+        max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
+        max_new = max(max_new, ticks[i].n_active - ticks[i].first_new);
+    }
+    const TickDev &t0 = ticks[0];
+    if (stage == 0) {
+        hipLaunchKernelGGL(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
+        const dim3 grid(cdiv(t0.n_slabs, kWavesPerBlock), 1, n), block(kBlock);
+        if (t0.rpt == 4) {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b);
+            else hipLaunchKernelGGL((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b);
+        } else {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b);
+            else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b);
+        }
+    } else if (stage == 1) {
+        const dim3 grid(4, kShards, n), block(256);
+#define RM_EXB(MODEL)                                                                                                \
+    do {                                                                                                             \
+        if (cfg.stochastic) {                                                                                        \
+            if (small) hipLaunchKernelGGL((k_exact_batch<MODEL, true, true>), grid, block, 0, s, nd, m, b);          \
+            else hipLaunchKernelGGL((k_exact_batch<MODEL, true, false>), grid, block, 0, s, nd, m, b);               \
+        } else {                                                                                                     \
+            if (small) hipLaunchKernelGGL((k_exact_batch<MODEL, false, true>), grid, block, 0, s, nd, m, b);         \
+            else hipLaunchKernelGGL((k_exact_batch<MODEL, false, false>), grid, block, 0, s, nd, m, b);              \
+        }                                                                                                            \
+    } while (0)
+        switch (m.kind) {
+        case RM_MODEL_NULL: RM_EXB(RM_MODEL_NULL); break;
+        case RM_MODEL_UDGM: RM_EXB(RM_MODEL_UDGM); break;
+        case RM_MODEL_UDGM_CONST: RM_EXB(RM_MODEL_UDGM_CONST); break;
+        case RM_MODEL_N2N: RM_EXB(RM_MODEL_N2N); break;
+        case RM_MODEL_LOGDIST: RM_EXB(RM_MODEL_LOGDIST); break;
+        default: return hipErrorInvalidValue;
+        }
+#undef RM_EXB
+    } else {
+        const dim3 grid(max(1, min(2048, (max_new + 3) / 4)), 1, n), block(256);
+        if (cfg.stochastic) {
+            if (small) hipLaunchKernelGGL((k_reorder_batch<true, true>), grid, block, 0, s, m, b);
+            else hipLaunchKernelGGL((k_reorder_batch<true, false>), grid, block, 0, s, m, b);
+        } else {
+            if (small) hipLaunchKernelGGL((k_reorder_batch<false, true>), grid, block, 0, s, m, b);
+            else hipLaunchKernelGGL((k_reorder_batch<false, false>), grid, block, 0, s, m, b);
+        }
+    }
     return hipGetLastError();
 }
 

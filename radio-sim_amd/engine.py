@@ -213,6 +213,54 @@ class Engine:
     def tick_run_sources_device(self, t_begin, t_end, dev_src_ptr, n, start_us, air_us):
         check(self._L.rm_tick_run_sources_device(self._h, t_begin, t_end, C.c_void_p(dev_src_ptr), n, start_us, air_us))
 
+    # -- several independent ticks per pass (rm_batch_*)
+    def batch_run_sources_device(self, t_begin, t_end, dev_src_ptrs, n_src, start_us, air_us):
+        """Tick b: sources dev_src_ptrs[b] (device int32[n_src[b]]), frames start at start_us[b]."""
+        n = len(dev_src_ptrs)
+        i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
+        tb, te, st, ai = i64(t_begin), i64(t_end), i64(start_us), i64(air_us)
+        ptrs = np.ascontiguousarray(dev_src_ptrs, dtype=np.uint64)
+        cnt = np.ascontiguousarray(n_src, dtype=np.int32)
+        assert len(tb) == len(te) == len(st) == len(ai) == len(cnt) == n
+        check(self._L.rm_batch_run_sources_device(self._h, n, tb.ctypes.data, te.ctypes.data, ptrs.ctypes.data,
+                                                  cnt.ctypes.data, st.ctypes.data, ai.ctypes.data))
+
+    def batch_run_device(self, t_begin, t_end, dev_rec_ptrs, n_new):
+        n = len(dev_rec_ptrs)
+        tb = np.ascontiguousarray(t_begin, dtype=np.int64)
+        te = np.ascontiguousarray(t_end, dtype=np.int64)
+        ptrs = np.ascontiguousarray(dev_rec_ptrs, dtype=np.uint64)
+        cnt = np.ascontiguousarray(n_new, dtype=np.int32)
+        assert len(tb) == len(te) == len(cnt) == n
+        check(self._L.rm_batch_run_device(self._h, n, tb.ctypes.data, te.ctypes.data, ptrs.ctypes.data, cnt.ctypes.data))
+
+    def batch_result_device(self, slot):
+        r = DeviceResult()
+        check(self._L.rm_batch_result_device(self._h, slot, C.byref(r)))
+        return r
+
+    def batch_result_count(self, slot):
+        cnt, dropped = C.c_uint32(), C.c_uint32()
+        check(self._L.rm_batch_result_count(self._h, slot, C.byref(cnt), C.byref(dropped)))
+        return cnt.value, dropped.value
+
+    def batch_result_copy(self, slot, n_new, cap=None):
+        """Heard links of tick `slot` of the last batch, copied to the host."""
+        cap = cap if cap is not None else min(max(1, n_new) * max(1, self.n), 1 << 26)
+        pkt = np.empty(cap, dtype=np.int32)
+        dst = np.empty(cap, dtype=np.int32)
+        verdict = np.empty(cap, dtype=np.uint8)
+        rssi = np.empty(cap, dtype=np.float64)
+        sinr = np.empty(cap, dtype=np.float64)
+        pint = np.zeros(max(1, n_new), dtype=np.uint8)
+        poff = np.zeros(n_new + 1, dtype=np.uint32)
+        cnt = C.c_uint32()
+        check(self._L.rm_batch_result_copy(self._h, slot, pkt.ctypes.data, dst.ctypes.data, verdict.ctypes.data,
+                                           rssi.ctypes.data, sinr.ctypes.data, cap, C.byref(cnt), pint.ctypes.data,
+                                           poff.ctypes.data))
+        k = cnt.value
+        return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
+
     def result_device(self):
         r = DeviceResult()
         check(self._L.rm_result_device(self._h, C.byref(r)))

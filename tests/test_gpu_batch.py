@@ -1,0 +1,166 @@
+"""rm_batch_*: several independent ticks in one launch sequence.  Every tick of a batch must be what
+the oracle (and a single rm_tick_run_sources_device call) gives for it -- including the order in
+which the shared java.util.Random is consumed from tick to tick."""
+import numpy as np
+import pytest
+
+from util import configure_engine, oracle_model, to_tx_records, random_nodes, assert_same, DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+AIR = 8128
+
+CASES = [
+    ("udgm", {}, False),                                                    # reference UDGM, no draws
+    ("udgm", dict(udgm_success_ratio_rx=0.8), True),                        # every heard link draws
+    ("udgm_const", {}, False),
+    ("logdist", dict(ld_sigma_db=0.0), False),
+    ("logdist", dict(ld_sigma_db=4.0, ld_seed=11), False),                  # shadowing table in the filter
+]
+
+
+def _layout(O, n, seed, lossy=False):
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=seed)
+    if lossy:
+        rng = np.random.default_rng(seed + 100)
+        nd.rxprob[rng.choice(n, n // 5, replace=False)] = 0.6
+        nd.txprob[rng.choice(n, n // 50, replace=False)] = 0.5
+        nd.enabled[rng.choice(n, n // 40, replace=False)] = 0
+    return nd
+
+
+def _ticks(n, n_ticks, per_tick, seed, ragged=False):
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(n_ticks):
+        t = per_tick if not ragged else max(1, per_tick - 37 * b)
+        out.append(np.sort(rng.choice(n, t, replace=False)).astype(np.int32))
+    return out
+
+
+@pytest.mark.parametrize("kind,params,lossy", CASES)
+@pytest.mark.parametrize("n_ticks", [1, 3, 6])
+def test_batch_matches_the_oracle_tick_by_tick(engine, rsa, O, kind, params, lossy, n_ticks):
+    n = 6000
+    nd = _layout(O, n, seed=5, lossy=lossy)
+    configure_engine(engine, nd, kind, params)
+    engine.seed(77)
+    state = O.lib().orc_jrandom_seed(77)
+    mdl = oracle_model(O, kind, params)
+    srcs = _ticks(n, n_ticks, 150, seed=n_ticks, ragged=True)
+    dev = [DeviceArray(s) for s in srcs]
+    starts = [1000 * b for b in range(n_ticks)]
+    engine.batch_run_sources_device(starts, [s + 1000 for s in starts], [d.ptr.value for d in dev],
+                                    [len(s) for s in srcs], starts, [AIR] * n_ticks)
+    for b in range(n_ticks):
+        pk = nd.packets(srcs[b], start_us=starts[b], air_us=AIR)
+        cpu = O.tick(mdl, nd, pk, rng_state=state)
+        state = cpu.rng_state
+        gpu = engine.batch_result_copy(b, len(srcs[b]))
+        assert cpu.count > 0
+        assert_same(gpu, cpu, "%s tick %d of %d" % (kind, b, n_ticks))
+        assert engine.batch_result_count(b) == (cpu.count, 0)
+    assert engine.rng_state == state
+    for d in dev:
+        d.free()
+
+
+def test_batch_equals_single_ticks_and_slot0_is_the_plain_result(engine, rsa, O):
+    n = 20000
+    nd = _layout(O, n, seed=9, lossy=True)
+    params = dict(udgm_success_ratio_rx=0.9)
+    configure_engine(engine, nd, "udgm", params)
+    srcs = _ticks(n, 5, 400, seed=2)
+    dev = [DeviceArray(s) for s in srcs]
+    starts = [1000 * b for b in range(5)]
+    engine.seed(5)
+    singles = []
+    for b in range(5):
+        engine.tick_run_sources_device(starts[b], starts[b] + 1000, dev[b].ptr.value, len(srcs[b]), starts[b], AIR)
+        singles.append(engine.result_copy(len(srcs[b])))
+    after_singles = engine.rng_state
+    engine.seed(5)
+    engine.batch_run_sources_device(starts, [s + 1000 for s in starts], [d.ptr.value for d in dev], [400] * 5, starts, [AIR] * 5)
+    for b in range(5):
+        assert_same(engine.batch_result_copy(b, 400), singles[b], "tick %d" % b)
+    assert engine.rng_state == after_singles
+    assert_same(engine.result_copy(400), singles[0], "slot 0 through rm_result_copy")
+    # a plain tick after a batch reuses slot 0 and is unaffected by the other slots
+    engine.seed(5)
+    engine.tick_run_sources_device(0, 1000, dev[0].ptr.value, 400, 0, AIR)
+    assert_same(engine.result_copy(400), singles[0], "single tick after a batch")
+    assert_same(engine.batch_result_copy(3, 400), singles[3], "slot 3 still holds its tick")
+    for d in dev:
+        d.free()
+
+
+def test_batch_of_given_records_and_repeated_batches(engine, rsa, O):
+    """rm_batch_run_device (records given) + the parity double buffers over several batches."""
+    n = 8000
+    nd = _layout(O, n, seed=21)
+    params = dict(ld_sigma_db=3.0, ld_seed=4)
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    rng = np.random.default_rng(8)
+    for rep in range(3):
+        n_ticks = 4 - rep
+        srcs = _ticks(n, n_ticks, 120 + 50 * rep, seed=30 + rep)
+        pks = [nd.packets(s, start_us=1000 * b, air_us=AIR) for b, s in enumerate(srcs)]
+        for pk in pks:                                            # per-packet overrides (rf-power, channel)
+            pk["txpower"] = rng.uniform(-3.0, 0.0, len(pk))
+        dev = [DeviceArray(to_tx_records(rsa, pk)) for pk in pks]
+        tb = [1000 * b for b in range(n_ticks)]
+        engine.batch_run_device(tb, [t + 1000 for t in tb], [d.ptr.value for d in dev], [len(pk) for pk in pks])
+        for b in range(n_ticks):
+            assert_same(engine.batch_result_copy(b, len(pks[b])), O.tick(mdl, nd, pks[b]), "batch %d tick %d" % (rep, b))
+        for d in dev:
+            d.free()
+
+
+def test_batch_falls_back_to_single_sequences_where_the_batched_kernels_do_not_apply(engine, rsa, O):
+    """Coordinates of 1e6 m: the fp32 frame is too coarse (fp64 filter), no batched kernels -- the
+    same API still returns every tick's result; an empty tick in the batch does too."""
+    n = 3000
+    nd = random_nodes(O, n, 400.0, seed=3)
+    nd.x += 1.0e9
+    configure_engine(engine, nd, "udgm", {})
+    mdl = oracle_model(O, "udgm", {})
+    srcs = _ticks(n, 3, 40, seed=1)
+    srcs[1] = srcs[1][:0]
+    dev = [DeviceArray(s) if len(s) else DeviceArray(nbytes=4) for s in srcs]
+    tb = [0, 1000, 2000]
+    engine.batch_run_sources_device(tb, [1000, 2000, 3000], [d.ptr.value for d in dev], [len(s) for s in srcs], tb, [AIR] * 3)
+    for b in range(3):
+        gpu = engine.batch_result_copy(b, len(srcs[b]))
+        if len(srcs[b]) == 0:
+            assert gpu.count == 0
+            continue
+        assert_same(gpu, O.tick(mdl, nd, nd.packets(srcs[b], start_us=tb[b], air_us=AIR)), "tick %d" % b)
+    for d in dev:
+        d.free()
+
+
+def test_batch_refusals(engine, rsa, O):
+    from radio_sim_amd import _lib
+    n = 500
+    nd = random_nodes(O, n, 200.0, seed=1)
+    configure_engine(engine, nd, "logdist", dict(ld_flags=1))
+    src = DeviceArray(np.arange(10, dtype=np.int32))
+    args = ([0], [1000], [src.ptr.value], [10], [0], [AIR])
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.batch_run_sources_device(*args)
+    assert e.value.code == _lib.RM_ERR_STATE                       # SINR carries an on-air list
+    configure_engine(engine, nd, "udgm", dict(udgm_success_ratio_rx=0.5))
+    engine.set_partition(0, n // 2)
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.batch_run_sources_device(*args)
+    assert e.value.code == _lib.RM_ERR_STATE                       # partition + draws: finish_draws per tick
+    engine.set_partition(0, n)
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.batch_run_sources_device([0] * 7, [0] * 7, [src.ptr.value] * 7, [10] * 7, [0] * 7, [AIR] * 7)
+    assert e.value.code == _lib.RM_ERR_INVALID                     # more than RM_MAX_BATCH ticks
+    with pytest.raises(rsa.RadioMediumError):
+        engine.batch_result_copy(5, 10)                            # no such slot yet
+    engine.batch_run_sources_device(*args)
+    assert engine.batch_result_copy(0, 10).count > 0
+    src.free()
