@@ -75,7 +75,7 @@ def parse():
                     help="ticks in flight on one GPU (one engine context + stream each; ticks are independent "
                          "for the media without an on-air list)")
     ap.add_argument("--batch", type=int, default=1,
-                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 6); 1 = one tick per sequence")
+                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 32); 1 = one tick per sequence")
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])

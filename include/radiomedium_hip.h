@@ -217,7 +217,7 @@ int rm_sync(rm_context *ctx);
  * single rm_tick_run_sources_device calls would.  Media that carry state from tick to tick
  * (RM_LD_SINR: the on-air list) and partitioned contexts whose links draw are refused with
  * RM_ERR_STATE -- run those one tick at a time. */
-#define RM_MAX_BATCH 6
+#define RM_MAX_BATCH 32
 int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,
                                 const int64_t *t_end_us, const int32_t *const *dev_src /* device int32[n_src[b]] each */,
                                 const int32_t *n_src, const int64_t *start_us, const int64_t *air_us);

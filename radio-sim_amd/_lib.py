@@ -16,7 +16,7 @@ _SO = os.path.join(_CSRC, "libradiomedium_hip.so")
 MODEL_NULL, MODEL_UDGM, MODEL_UDGM_CONST, MODEL_N2N, MODEL_LOGDIST = range(5)
 UNHEARD, INTERFERED, DELIVERED = 0, 1, 2
 LD_SINR = 1
-MAX_BATCH = 6
+MAX_BATCH = 32
 RM_OK, RM_ERR_INVALID, RM_ERR_NO_DEVICE, RM_ERR_HIP, RM_ERR_CAPACITY, RM_ERR_STATE = 0, -1, -2, -3, -4, -5
 
 

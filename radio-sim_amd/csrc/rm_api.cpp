@@ -115,6 +115,7 @@ struct TickSlot {
     bool draws_pending = false; // partitioned + probabilistic: waiting for rm_tick_finish_draws
     rm::ModelDev pending_model{};
     uint32_t alloc_cap = 0;
+    int alloc_feat = 0; // kFeat* buffers allocated at alloc_cap
 
     // last tick
     rm::TickDev last{};
@@ -183,6 +184,7 @@ struct rm_context : TickSlot {
     size_t air_head = 0, air_tail = 0;
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
+    DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
     std::vector<std::unique_ptr<TickSlot>> extra_slots; // result slots 1.. of rm_batch_*
 
     // instantiated hipGraphs of the per-tick launch sequence, keyed by a hash of every launch argument
@@ -223,6 +225,7 @@ void TickSlot::release_all()
     d_a_verdict.release(); d_out_rssi.release(); d_out_sinr.release(); d_out_prob.release(); d_a_rssi.release(); d_a_sinr.release();
     d_a_prob.release(); d_draw_scan.release(); d_scan_block.release(); d_pkt_rng.release(); d_pkt_draw_cnt.release(); d_all_cnt.release();
     alloc_cap = 0;
+    alloc_feat = 0;
     have_result = false;
 }
 
@@ -457,42 +460,58 @@ int rebuild_receivers(rm_context *c)
     return RM_OK;
 }
 
-int ensure_link_buffers(rm_context *c, TickSlot &ts)
+// Link-sized buffers of a result slot.  Only what the configuration touches is allocated (a
+// batch keeps up to RM_MAX_BATCH slots): `payload` = per-entry rssi / probability / node index
+// (unsorted tables and SINR), `sinr` = per-receiver lists and linear powers, `draws` = the
+// java.util.Random scan and the probabilities carried to it.
+enum { kFeatPayload = 1, kFeatSinr = 2, kFeatDraws = 4 };
+int ensure_link_buffers(rm_context *c, TickSlot &ts, int feat)
 {
-    if (ts.alloc_cap == c->cap && ts.d_counters.p) return RM_OK;
+    if (ts.alloc_cap == c->cap && ts.d_counters.p && (feat & ~ts.alloc_feat) == 0) return RM_OK;
     const size_t cap = size_t((c->cap + rm::kShards - 1) / rm::kShards) * rm::kShards;
-    RM_HIP(ts.d_counters.ensure(16));
-    RM_HIP(hipMemsetAsync(ts.d_counters.p, 0, 16 * sizeof(uint32_t), c->stream));
-    RM_HIP(ts.d_shards.ensure(2 * rm::kShards * rm::kShardStride));
-    RM_HIP(hipMemsetAsync(ts.d_shards.p, 0, 2 * rm::kShards * rm::kShardStride * sizeof(uint32_t), c->stream));
-    ts.parity = 0;
-    RM_HIP(ts.d_st_pkt.ensure(cap));
-    RM_HIP(ts.d_st_dst.ensure(cap));
-    RM_HIP(ts.d_st_next.ensure(cap));
-    RM_HIP(ts.d_st_blk.ensure(cap));
-    RM_HIP(ts.d_st_aux.ensure(cap));
-    RM_HIP(ts.d_st_prob.ensure(cap));
-    RM_HIP(ts.d_st_orig.ensure(cap));
-    RM_HIP(ts.d_st_lin.ensure(cap));
-    RM_HIP(ts.d_st_sinr.ensure(cap));
-    RM_HIP(ts.d_st_flags.ensure(cap));
-    RM_HIP(ts.d_st_coll.ensure(cap));
-    RM_HIP(ts.d_out_pkt.ensure(cap));
-    RM_HIP(ts.d_out_dst.ensure(cap));
-    RM_HIP(ts.d_out_verdict.ensure(cap));
-    RM_HIP(ts.d_out_rssi.ensure(cap));
-    RM_HIP(ts.d_out_sinr.ensure(cap));
-    RM_HIP(ts.d_out_prob.ensure(cap));
-    RM_HIP(ts.d_a_pkt.ensure(cap));
-    RM_HIP(ts.d_a_dst.ensure(cap));
-    RM_HIP(ts.d_a_verdict.ensure(cap));
-    RM_HIP(ts.d_a_rssi.ensure(cap));
-    RM_HIP(ts.d_a_sinr.ensure(cap));
-    RM_HIP(ts.d_a_prob.ensure(cap));
-    RM_HIP(ts.d_a_e.ensure(cap));
-    RM_HIP(ts.d_draw_scan.ensure(cap + 1));
-    RM_HIP(ts.d_scan_block.ensure(cap / 2048 + 2));
+    if (ts.alloc_cap != c->cap || !ts.d_counters.p) {
+        RM_HIP(ts.d_counters.ensure(16));
+        RM_HIP(hipMemsetAsync(ts.d_counters.p, 0, 16 * sizeof(uint32_t), c->stream));
+        RM_HIP(ts.d_shards.ensure(2 * rm::kShards * rm::kShardStride));
+        RM_HIP(hipMemsetAsync(ts.d_shards.p, 0, 2 * rm::kShards * rm::kShardStride * sizeof(uint32_t), c->stream));
+        ts.parity = 0;
+        RM_HIP(ts.d_st_pkt.ensure(cap));
+        RM_HIP(ts.d_st_dst.ensure(cap));
+        RM_HIP(ts.d_st_blk.ensure(cap));
+        RM_HIP(ts.d_st_flags.ensure(cap));
+        RM_HIP(ts.d_out_pkt.ensure(cap));
+        RM_HIP(ts.d_out_dst.ensure(cap));
+        RM_HIP(ts.d_out_verdict.ensure(cap));
+        RM_HIP(ts.d_out_rssi.ensure(cap));
+        RM_HIP(ts.d_out_sinr.ensure(cap));
+        RM_HIP(ts.d_a_pkt.ensure(cap));
+        RM_HIP(ts.d_a_dst.ensure(cap));
+        RM_HIP(ts.d_a_verdict.ensure(cap));
+        RM_HIP(ts.d_a_rssi.ensure(cap));
+        ts.alloc_feat = 0;
+    }
+    feat |= ts.alloc_feat;
+    if (feat & kFeatPayload) {
+        RM_HIP(ts.d_st_aux.ensure(cap));
+        RM_HIP(ts.d_st_prob.ensure(cap));
+        RM_HIP(ts.d_st_orig.ensure(cap));
+    }
+    if (feat & kFeatSinr) {
+        RM_HIP(ts.d_st_next.ensure(cap));
+        RM_HIP(ts.d_st_lin.ensure(cap));
+        RM_HIP(ts.d_st_sinr.ensure(cap));
+        RM_HIP(ts.d_st_coll.ensure(cap));
+        RM_HIP(ts.d_a_sinr.ensure(cap));
+        RM_HIP(ts.d_a_e.ensure(cap));
+    }
+    if (feat & kFeatDraws) {
+        RM_HIP(ts.d_out_prob.ensure(cap));
+        RM_HIP(ts.d_a_prob.ensure(cap));
+        RM_HIP(ts.d_draw_scan.ensure(cap + 1));
+        RM_HIP(ts.d_scan_block.ensure(cap / 2048 + 2));
+    }
     ts.alloc_cap = c->cap;
+    ts.alloc_feat = feat;
     return RM_OK;
 }
 
@@ -555,11 +574,12 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     const int n_new = n_active - first_new;
     ts.have_result = false;
     ts.last_n_new = n_new;
-    RM_TRY(ensure_link_buffers(c, ts));
     RM_TRY(prepare_nodes(c));
 
     const bool sinr = is_sinr(c);
     const bool stochastic = maybe_draws(c);
+    RM_TRY(ensure_link_buffers(c, ts, ((!c->rx_sorted || sinr) ? kFeatPayload : 0) | (sinr ? kFeatSinr : 0) |
+                                          (stochastic ? kFeatDraws : 0)));
     const int rx_count = c->n_rx;
     const bool partitioned = rx_count != c->n;
     ts.draws_pending = false;
@@ -954,7 +974,7 @@ void rm_destroy(rm_context *c)
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
-    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release();
+    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1502,6 +1522,10 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
 {
     rm::TickDev ticks[RM_MAX_BATCH];
     for (int b = 0; b < n; ++b) ticks[b] = plans[b].t;
+    // the descriptors go to device memory (k_store_ticks, ordered on the stream after the previous
+    // batch's kernels, which read the same array)
+    RM_HIP(c->d_ticks.ensure(RM_MAX_BATCH));
+    rm::TickDev *dev_ticks = c->d_ticks.p;
     const rm::ModelDev m = model_dev(c);
     const rm::NodesDev nd = nodes_dev(c);
     const rm::LaunchCfg &cfg = plans[0].cfg;
@@ -1524,13 +1548,14 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
         }
         return RM_OK;
     };
+    RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
     if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
     RM_TRY(stage(RM_STAGE_FILTER));
-    RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, cfg));
+    RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, dev_ticks, cfg));
     RM_TRY(stage(RM_STAGE_EXACT));
-    RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, cfg));
+    RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, dev_ticks, cfg));
     RM_TRY(stage(RM_STAGE_REORDER));
-    RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, cfg));
+    RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, dev_ticks, cfg));
     if (cfg.stochastic) {
         // the shared generator is walked tick by tick, in slot order
         RM_TRY(stage(RM_STAGE_DRAWS));

@@ -19,7 +19,7 @@ constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
 constexpr int kNearCap = 4096;      // near frames one workgroup (1024 receivers) can list per tick (large-grid path)
 enum { kFilterGrid = 0, kFilterList = 1, kFilterWg = 2 }; // TickDev::filter_mode (plan_filter)
 constexpr int kShardStride = 32;
-constexpr int kMaxBatch = RM_MAX_BATCH; // ticks per batched launch: their descriptors fit the 4 KB of kernel arguments    // u32 words between shard counters: one 128-byte line each
+constexpr int kMaxBatch = RM_MAX_BATCH; // ticks per batched launch (descriptors in device memory)    // u32 words between shard counters: one 128-byte line each
 
 // link-entry flags
 constexpr uint8_t kFlagHeardNew = 1;   // gets an output record
@@ -173,8 +173,9 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
                          const LaunchCfg &cfg);
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
+hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDev *dev_ticks);
 hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
-                              const LaunchCfg &cfg);
+                              const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                         const LaunchCfg &cfg);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);

@@ -1477,23 +1477,46 @@ RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
 // SEG 1/2: sorted table, heard links go straight into the frame's segment of the A records (any
 // order inside it); the segment offsets are the scan of the per-frame candidate counts, redone in
 // LDS by every workgroup (1; 3 = the same for at most kSmallScan frames) or read from k_scan_counts' output (2).
-template <int MODEL, bool SINR, bool STOCH, int SEG>
+// PACKED: a 1-D grid whose workgroups walk the started 256-entry chunks of all shards (no workgroup
+// without entries); otherwise blockIdx.y is the shard and blockIdx.x strides over its entries.
+template <int MODEL, bool SINR, bool STOCH, int SEG, bool PACKED = false>
 RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
 {
     __shared__ uint32_t s_seg[SEG == 1 ? kFusedScanMax + 1 : (SEG == 3 ? kSmallScan + 1 : 1)];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_cs[PACKED ? kShards + 1 : 1]; // exclusive scan of the shards' chunk counts
+    __shared__ uint32_t s_sn[PACKED ? kShards : 1];     // entries per shard
     const bool publisher = (blockIdx.x == 0 && blockIdx.y == 0);
     bool scanned = false; // the scan is only needed by the scatter: it runs after the first evaluation
-    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    const uint32_t n_own = min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
     SmallCounts pre{};
-    if (SEG == 3 && (blockIdx.x == 0 || blockIdx.x * blockDim.x < n)) pre = small_scan_load(t.cand_tot, t.n_cnt);
+    if (SEG == 3 && (PACKED || blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load(t.cand_tot, t.n_cnt);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
     const int lane = threadIdx.x & 63;
-    for (uint32_t it = blockIdx.x * blockDim.x; it < n; it += stride) { // block-uniform trip count
+    uint32_t n_chunks = 0;
+    if (PACKED) {
+        const uint32_t mine = (n_own + 255u) >> 8;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) s_wave[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine;
+        for (int w = 0; w < int(threadIdx.x >> 6); ++w) run += s_wave[w];
+        s_cs[threadIdx.x] = run;
+        s_sn[threadIdx.x] = n_own;
+        n_chunks = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (threadIdx.x == 0) s_cs[kShards] = n_chunks;
+        __syncthreads();
+    }
+    auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) {
         const uint32_t i = it + threadIdx.x;
         const bool valid = i < n;
-        const uint32_t idx = blockIdx.y * t.seg_cap + i;
+        const uint32_t idx = shard * t.seg_cap + i;
         bool wanted = false;
         int slot = -1, key = -1;
         uint8_t fl = 0;
@@ -1561,6 +1584,18 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
                 }
             }
         }
+    };
+    if (PACKED) {
+        for (uint32_t u = blockIdx.x; u < n_chunks; u += gridDim.x) { // block-uniform
+            uint32_t lo = 0, hi = kShards; // the shard whose chunk range holds u: s_cs[lo] <= u < s_cs[lo + 1]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_cs[mid] <= u) lo = mid; else hi = mid;
+            }
+            entries(lo, (u - s_cs[lo]) << 8, s_sn[lo]);
+        }
+    } else {
+        for (uint32_t it = blockIdx.x * blockDim.x; it < n_own; it += stride) entries(blockIdx.y, it, n_own); // block-uniform trip count
     }
     if (SEG == 1 && !scanned && publisher) // seg_off is published even if this shard was empty
         block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
@@ -1574,16 +1609,28 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
 }
 
 // Several independent ticks per launch (rm_batch_*): blockIdx.z selects the tick.  The ticks'
-// descriptors travel in the kernel arguments (scalar loads at a uniform offset).
-struct TickBatch {
-    TickDev t[kMaxBatch];
+// descriptors sit in device memory (read with scalar loads at a uniform address); k_store_ticks
+// writes them there from its kernel arguments, kStoreTicks at a time (4 KB of arguments).
+constexpr int kStoreTicks = 6;
+struct TickGroup {
+    TickDev t[kStoreTicks];
 };
-static_assert(sizeof(TickBatch) + sizeof(NodesDev) + sizeof(ModelDev) <= 4096, "kernel arguments are limited to 4 KB");
+static_assert(sizeof(TickGroup) + 32 <= 4096, "kernel arguments are limited to 4 KB");
+
+__global__ void __launch_bounds__(64) k_store_ticks(const TickGroup g, TickDev *dst, int n)
+{
+    // one descriptor per workgroup, copied as 32-bit words
+    static_assert(sizeof(TickDev) % 4 == 0, "");
+    if (int(blockIdx.x) >= n) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&g.t[blockIdx.x]);
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst + blockIdx.x);
+    for (int i = threadIdx.x; i < int(sizeof(TickDev) / 4); i += blockDim.x) out[i] = src[i];
+}
 
 template <int MODEL, bool STOCH, bool SMALL>
-__global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickBatch b)
+__global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    exact_body<MODEL, false, STOCH, SMALL ? 3 : 1>(nd, m, b.t[blockIdx.z]);
+    exact_body<MODEL, false, STOCH, SMALL ? 3 : 1, true>(nd, m, ticks[blockIdx.z]);
 }
 
 // half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
@@ -1911,20 +1958,21 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
 }
 
 template <bool STOCH, bool SMALL>
-__global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickBatch b)
+__global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    reorder_body<STOCH, false, SMALL ? 3 : 1>(m, b.t[blockIdx.z]);
+    reorder_body<STOCH, false, SMALL ? 3 : 1>(m, ticks[blockIdx.z]);
 }
 
-__global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickBatch b)
+__global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    tick_prep_body(nd, m, b.t[blockIdx.z]);
+    tick_prep_body(nd, m, ticks[blockIdx.z]);
 }
 
 template <int RPT, bool SHADOW>
-__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : 6) k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickBatch b)
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : 6)
+k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    filter_wg_body<RPT, SHADOW>(nd, m, b.t[blockIdx.z]);
+    filter_wg_body<RPT, SHADOW>(nd, m, ticks[blockIdx.z]);
 }
 
 // ============================================================================ Java-RNG draws
@@ -2304,7 +2352,7 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
 }
 
 // rm_batch_*: n independent ticks (sorted table, fp32 frame, no SINR, <= kFusedScanMax frames each)
-// in four launches.  stage 0: k_tick_prep + k_filter_wg, 1: k_exact, 2: k_reorder.
+// in four launches (+ k_store_ticks).  stage 0: k_tick_prep + k_filter_wg, 1: k_exact, 2: k_reorder.
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
 {
     const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
@@ -2312,15 +2360,25 @@ bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
            t.filter_mode == kFilterWg && t.n_active > t.first_new && t.n_rx > 0;
 }
 
+hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDev *dev_ticks)
+{
+    for (int b0 = 0; b0 < n; b0 += kStoreTicks) {
+        TickGroup g{};
+        const int k = min(kStoreTicks, n - b0);
+        for (int i = 0; i < k; ++i) g.t[i] = ticks[b0 + i];
+        hipLaunchKernelGGL(k_store_ticks, dim3(k), dim3(64), 0, s, g, dev_ticks + b0, k);
+    }
+    return hipGetLastError();
+}
+
+// `ticks`: the host copies (grid sizes), `b`: the same descriptors in device memory
 hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
-                              const LaunchCfg &cfg)
+                              const TickDev *b, const LaunchCfg &cfg)
 {
     if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
-    TickBatch b{};
     int max_eval = 0, max_new = 0;
     bool small = true; // every tick's counts fit the small fused scan
     for (int i = 0; i < n; ++i) {
-        b.t[i] = ticks[i];
         small = small && ticks[i].n_cnt <= kSmallScan;
         max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
         max_new = max(max_new, ticks[i].n_active - ticks[i].first_new);
@@ -2337,7 +2395,7 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
             else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b);
         }
     } else if (stage == 1) {
-        const dim3 grid(4, kShards, n), block(256);
+        const dim3 grid(kShards, 1, n), block(256); // packed: one started chunk of 256 entries per workgroup at the bench sizes
 #define RM_EXB(MODEL)                                                                                                \
     do {                                                                                                             \
         if (cfg.stochastic) {                                                                                        \

@@ -33,13 +33,13 @@ def _ticks(n, n_ticks, per_tick, seed, ragged=False):
     rng = np.random.default_rng(seed)
     out = []
     for b in range(n_ticks):
-        t = per_tick if not ragged else max(1, per_tick - 37 * b)
+        t = per_tick if not ragged else max(1, per_tick - 11 * b)
         out.append(np.sort(rng.choice(n, t, replace=False)).astype(np.int32))
     return out
 
 
 @pytest.mark.parametrize("kind,params,lossy", CASES)
-@pytest.mark.parametrize("n_ticks", [1, 3, 6])
+@pytest.mark.parametrize("n_ticks", [1, 3, 6, 13])
 def test_batch_matches_the_oracle_tick_by_tick(engine, rsa, O, kind, params, lossy, n_ticks):
     n = 6000
     nd = _layout(O, n, seed=5, lossy=lossy)
@@ -157,7 +157,8 @@ def test_batch_refusals(engine, rsa, O):
     assert e.value.code == _lib.RM_ERR_STATE                       # partition + draws: finish_draws per tick
     engine.set_partition(0, n)
     with pytest.raises(rsa.RadioMediumError) as e:
-        engine.batch_run_sources_device([0] * 7, [0] * 7, [src.ptr.value] * 7, [10] * 7, [0] * 7, [AIR] * 7)
+        k = rsa.MAX_BATCH + 1
+        engine.batch_run_sources_device([0] * k, [0] * k, [src.ptr.value] * k, [10] * k, [0] * k, [AIR] * k)
     assert e.value.code == _lib.RM_ERR_INVALID                     # more than RM_MAX_BATCH ticks
     with pytest.raises(rsa.RadioMediumError):
         engine.batch_result_copy(5, 10)                            # no such slot yet
