@@ -66,16 +66,17 @@ def baseline_metric():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1920)
+    ap.add_argument("--warmup", type=int, default=192)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="ticks in flight on one GPU (one engine context + stream each; ticks are independent "
                          "for the media without an on-air list)")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 32); 1 = one tick per sequence")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 128); 1 = one tick per sequence")
+    ap.add_argument("--nodes", type=int, default=0, help="override the workload's node count (same density and Tx fraction)")
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -120,7 +121,7 @@ def cpu_baseline(wl, nodes, sources, cpu_ticks):
     return out, mt
 
 
-def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, ticks=60, warm=12):
+def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=192, warm=48):
     """The same medium at 1M nodes / 1000 frames per tick (38 MB of algorithmic traffic per tick): where
     the sweep stops being launch-latency-bound.  Same measurement rules as the main run."""
     idx, n, frac, model, desc = WORKLOADS["m1"]
@@ -142,10 +143,21 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, ticks=60, warm=12)
         src_dev = torch.from_numpy(np.stack(sources)).to(dev)
     streams[0].synchronize()
 
+    batch = max(1, min(batch, 8))   # 8 ticks of this size already fill the device
+
     def run(k0, k1):
-        for k in range(k0, k1):
-            t0 = k * W.TICK_US
-            engines[k % inflight].tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+        g = 0
+        for k in range(k0, k1, batch):
+            nb = min(batch, k1 - k)
+            t0 = np.arange(k, k + nb, dtype=np.int64) * W.TICK_US
+            ptrs = np.array([src_dev[kk].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64)
+            if batch == 1:
+                engines[g % inflight].tick_run_sources_device(int(t0[0]), int(t0[0]) + W.TICK_US, int(ptrs[0]), t_per_tick,
+                                                              int(t0[0]), W.AIR_US)
+            else:
+                engines[g % inflight].batch_run_sources_device(t0, t0 + W.TICK_US, ptrs, np.full(nb, t_per_tick, dtype=np.int32),
+                                                               t0, np.full(nb, W.AIR_US, dtype=np.int64))
+            g += 1
 
     def fence():
         for st in streams:
@@ -170,10 +182,11 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, ticks=60, warm=12)
     per_tick = el / ticks
     for e in engines:
         e.close()
-    return {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "ticks_in_flight": inflight,
+    return {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "ticks_in_flight": inflight * batch,
+            "ticks_per_launch": batch, "contexts": inflight,
             "value": t_per_tick * (n - 1) / per_tick, "unit": "links/s", "ms_per_step": per_tick * 1e3,
             "algorithmic_bytes_per_tick": b_tick, "dominant_kernel": dominant, "stages_avg_us": stages,
-            "hbm_frac_dominant_kernel": b_tick / (stages[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac_dominant_kernel": b_tick * batch / (stages[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_whole_tick": b_tick / per_tick / 1e9 / HBM_PEAK_GBS, "dropped": bool(dropped)}
 
 
@@ -210,7 +223,10 @@ def main():
     idx, n, frac, model, desc = WORKLOADS[args.workload]
     if args.workload in EXTRA and world > 1:
         raise SystemExit("the SINR workloads run on one GPU in this round (sharded on-air list: host-record path only)")
-    if world > 1 and args.scaling == "weak":
+    if args.nodes > 0:
+        n = args.nodes
+        desc += " -- node count overridden: %d" % n
+    elif world > 1 and args.scaling == "weak":
         # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
         n = int(round(n * world ** 0.5))
         desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
@@ -245,6 +261,7 @@ def main():
 
     from radio_sim_amd import dist as D
     use_sharded = world > 1 or args.force_sharded
+    batch = 1 if stateful else max(1, min(args.batch, rsa.MAX_BATCH))
     with torch.cuda.stream(stream):
         if not use_sharded:
             src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
@@ -255,11 +272,12 @@ def main():
             slots = D.slots_needed(n, world, sources)
             pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
             src_dev = torch.from_numpy(pad).to(dev)
-            sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False)
+            sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch)
     stream.synchronize()
 
     links_done = [0]
-    batch = 1 if (stateful or use_sharded) else max(1, min(args.batch, rsa.MAX_BATCH))
+    last_run = [eng, 0]     # (context, result slot) of the last tick issued
+    ctx_rr = [0]
     _bargs = {}
 
     def batch_args(k, nb):
@@ -274,11 +292,20 @@ def main():
         """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
         with torch.cuda.stream(stream if sharded is None else sharded.comm):
             if sharded is None and batch > 1:
-                g = 0
                 for k in range(k0, k1, batch):
                     a = batch_args(k, min(batch, k1 - k))
-                    engines[g % inflight].batch_run_sources_device(*a)
-                    g += 1
+                    g = ctx_rr[0] % inflight       # contexts take the batches in turn
+                    ctx_rr[0] += 1
+                    engines[g].batch_run_sources_device(*a)
+                    last_run[:] = [engines[g], min(batch, k1 - k) - 1]
+            elif batch > 1:
+                # sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream
+                for k in range(k0, k1, batch):
+                    t_b = np.arange(k, min(k + batch, k1), dtype=np.int64) * W.TICK_US
+                    g = ctx_rr[0] % inflight
+                    ctx_rr[0] += 1
+                    sharded.run_batch(g, src_dev[k].data_ptr(), t_b, W.AIR_US, W.TICK_US)
+                    last_run[:] = [engines[g], len(t_b) - 1]
             elif sharded is None:
                 for k in range(k0, k1):
                     t0 = k * tick_us
@@ -304,9 +331,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # set-up, not a step: every context sweeps one batch once, so that its result slots and link
+    # buffers exist before the warm-up (the W warm-up steps alone need not reach every context)
+    for _ in range(inflight):
+        run_range(0, min(ticks, batch))
+    fence()
     run_range(0, args.warmup)
     fence()
-    eng.profile_enable(args.profile_every)
+    eng.profile_enable(args.profile_every if batch == 1 else max(1, args.profile_every // 4))
     t_start = time.perf_counter()
     links_done[0] = 0
     run_range(args.warmup, ticks)
@@ -314,7 +346,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     n_samples, stage_ms = eng.profile_read()
     eng.profile_enable(0)
-    heard, dropped = eng.result_count()
+    heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
     if dropped:
         raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
 
@@ -338,7 +370,7 @@ def main():
     sequential = None
     if stateful:
         desc += " -- %.2e link evaluations per tick incl. the frames still on the air" % (links_done[0] / args.steps)
-    if inflight > 1 and sharded is None:
+    if (inflight > 1 or batch > 1) and sharded is None:
         # the same ticks again, one at a time on one context
         fence()
         t_seq = time.perf_counter()
@@ -404,13 +436,15 @@ def main():
                          "whole_pass": {"gpu_us": pass_s * 1e6,
                                         "achieved": b_tick / pass_s / 1e9 if pass_s > 0 else 0.0,
                                         "frac": (b_tick / pass_s / 1e9 / HBM_PEAK_GBS) if pass_s > 0 else 0.0},
-                         "note": "a tick of this size moves ~5 MB through 5 short dependent kernels: latency-bound, "
-                                 "not bandwidth-bound; see DESIGN.md section 5 and profiles/README.md"},
+                         "note": "one launch sweeps `ticks_per_launch` ticks; durations are HIP-event brackets on the "
+                                 "context's stream while the other contexts' launches share the device; the sweep is "
+                                 "integer/fp32 VALU work, its HBM traffic is far below the HBM roofline by construction "
+                                 "(DESIGN.md section 5, profiles/README.md)"},
         }
         if sequential is not None:
             out["sequential_ticks"] = sequential
         if world == 1 and args.workload == "c3" and not args.no_scale_probe:
-            out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight)
+            out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch)
         if world == 1 and not args.no_cpu_baseline:
             st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
             out["cpu_baseline"] = st

@@ -190,6 +190,10 @@ int rm_pack_tx_device(rm_context *ctx, const int32_t *dev_src, int32_t n, int64_
 /* the same on another stream (packing + all-gather of tick t+1 can overlap the sweep of tick t) */
 int rm_pack_tx_device_on(rm_context *ctx, void *hip_stream, const int32_t *dev_src, int32_t n,
                          int64_t start_us, int64_t air_us, rm_tx_record *dev_out);
+/* the same for n_ticks ticks in one launch: dev_src / dev_out hold n_ticks rows of n entries, row b
+ * starts at start_us[b] (host array) -- feeds one RCCL all-gather per batch of ticks */
+int rm_pack_tx_batch_device_on(rm_context *ctx, void *hip_stream, const int32_t *dev_src, int32_t n_ticks, int32_t n,
+                               const int64_t *start_us, int64_t air_us, rm_tx_record *dev_out);
 /* evaluate one tick whose new frames are `dev_new[0..n_new)` (device memory, canonical order) */
 int rm_tick_run_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
                        const rm_tx_record *dev_new, int32_t n_new);
@@ -217,7 +221,7 @@ int rm_sync(rm_context *ctx);
  * single rm_tick_run_sources_device calls would.  Media that carry state from tick to tick
  * (RM_LD_SINR: the on-air list) and partitioned contexts whose links draw are refused with
  * RM_ERR_STATE -- run those one tick at a time. */
-#define RM_MAX_BATCH 32
+#define RM_MAX_BATCH 128
 int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,
                                 const int64_t *t_end_us, const int32_t *const *dev_src /* device int32[n_src[b]] each */,
                                 const int32_t *n_src, const int64_t *start_us, const int64_t *air_us);

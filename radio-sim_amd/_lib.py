@@ -16,7 +16,7 @@ _SO = os.path.join(_CSRC, "libradiomedium_hip.so")
 MODEL_NULL, MODEL_UDGM, MODEL_UDGM_CONST, MODEL_N2N, MODEL_LOGDIST = range(5)
 UNHEARD, INTERFERED, DELIVERED = 0, 1, 2
 LD_SINR = 1
-MAX_BATCH = 32
+MAX_BATCH = 128
 RM_OK, RM_ERR_INVALID, RM_ERR_NO_DEVICE, RM_ERR_HIP, RM_ERR_CAPACITY, RM_ERR_STATE = 0, -1, -2, -3, -4, -5
 
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "rm_tick_finish_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int]),
     "rm_pack_tx_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "rm_pack_tx_device_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "rm_pack_tx_batch_device_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                             C.c_void_p]),
     "rm_tick_run_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
     "rm_tick_run_sources_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
                                              C.c_int64]),

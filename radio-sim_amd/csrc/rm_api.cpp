@@ -185,6 +185,11 @@ struct rm_context : TickSlot {
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
+    // larger batches upload them with one copy from pinned host memory (two staging buffers, each
+    // guarded by an event: it is rewritten only after the copy that read it has completed)
+    rm::TickDev *h_ticks[2] = {nullptr, nullptr};
+    hipEvent_t h_ticks_ev[2] = {nullptr, nullptr};
+    int h_ticks_gen = 0;
     std::vector<std::unique_ptr<TickSlot>> extra_slots; // result slots 1.. of rm_batch_*
 
     // instantiated hipGraphs of the per-tick launch sequence, keyed by a hash of every launch argument
@@ -977,6 +982,10 @@ void rm_destroy(rm_context *c)
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();
+    for (int g = 0; g < 2; ++g) {
+        if (c->h_ticks_ev[g]) (void)hipEventDestroy(c->h_ticks_ev[g]);
+        if (c->h_ticks[g]) (void)hipHostFree(c->h_ticks[g]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1335,6 +1344,17 @@ int rm_pack_tx_device_on(rm_context *c, void *hip_stream, const int32_t *dev_src
     return RM_OK;
 }
 
+int rm_pack_tx_batch_device_on(rm_context *c, void *hip_stream, const int32_t *dev_src, int32_t n_ticks, int32_t n,
+                               const int64_t *start_us, int64_t air_us, rm_tx_record *dev_out)
+{
+    if (!c || n < 0 || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !start_us || (n > 0 && (!dev_src || !dev_out)))
+        return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    RM_HIP(rm::launch_pack_tx_batch(static_cast<hipStream_t>(hip_stream), nodes_dev(c), dev_src, n_ticks, n, start_us, air_us,
+                                    dev_out));
+    return RM_OK;
+}
+
 int rm_pack_tx_device(rm_context *c, const int32_t *dev_src, int32_t n, int64_t start_us, int64_t air_us,
                       rm_tx_record *dev_out)
 {
@@ -1526,6 +1546,20 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     // batch's kernels, which read the same array)
     RM_HIP(c->d_ticks.ensure(RM_MAX_BATCH));
     rm::TickDev *dev_ticks = c->d_ticks.p;
+    const bool by_copy = n > 2 * 6; // beyond two k_store_ticks launches one pinned copy is cheaper
+    if (by_copy) {
+        const int g = c->h_ticks_gen;
+        c->h_ticks_gen ^= 1;
+        if (!c->h_ticks[g]) {
+            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ticks[g]), sizeof(rm::TickDev) * RM_MAX_BATCH, hipHostMallocDefault));
+            RM_HIP(hipEventCreateWithFlags(&c->h_ticks_ev[g], hipEventDisableTiming));
+        } else {
+            RM_HIP(hipEventSynchronize(c->h_ticks_ev[g]));
+        }
+        std::memcpy(c->h_ticks[g], ticks, sizeof(rm::TickDev) * size_t(n));
+        RM_HIP(hipMemcpyAsync(dev_ticks, c->h_ticks[g], sizeof(rm::TickDev) * size_t(n), hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipEventRecord(c->h_ticks_ev[g], c->stream));
+    }
     const rm::ModelDev m = model_dev(c);
     const rm::NodesDev nd = nodes_dev(c);
     const rm::LaunchCfg &cfg = plans[0].cfg;
@@ -1548,7 +1582,7 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
         }
         return RM_OK;
     };
-    RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
+    if (!by_copy) RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
     if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
     RM_TRY(stage(RM_STAGE_FILTER));
     RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, dev_ticks, cfg));

@@ -169,6 +169,8 @@ struct LaunchCfg {
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m);
 hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n, int64_t start_us,
                           int64_t air_us, rm_tx_record *out);
+hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
+                                const int64_t *start_us, int64_t air_us, rm_tx_record *out);
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);

@@ -455,6 +455,20 @@ k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_
     out[i] = r;
 }
 
+struct PackStarts {
+    int64_t start_us[kMaxBatch];
+};
+
+__global__ void __launch_bounds__(256)
+k_pack_tx_batch(NodesDev nd, const int32_t *src, int n, PackStarts st, int64_t air_us, rm_tx_record *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = size_t(blockIdx.y) * n + i;
+    const rm_tx_record r = make_tx_record(nd, src[o], st.start_us[blockIdx.y], air_us);
+    out[o] = r;
+}
+
 // ============================================================================ the filter kernel
 
 RM_D uint32_t lane_prefix(uint64_t mask)
@@ -1410,26 +1424,30 @@ RM_D uint32_t block_scan_counts(const uint32_t *cnt, int n, uint32_t *s_off, uin
     return total;
 }
 
-// The same for at most kSmallScan counts (the bench's 1000 frames per tick): four counts per thread,
-// requested with small_scan_load at the top of the kernel so that the round trip overlaps the
-// kernel's own first loads, and only 4 KB of LDS (the occupancy of the consumers is LDS-bound).
-constexpr int kSmallScan = 1024;
-struct SmallCounts {
-    uint32_t v[4];
+// The same for at most 256*PER counts (PER = 4: the bench's 1000 frames per tick, 16: up to 4096):
+// PER counts per thread, requested with small_scan_load at the top of the kernel so that the
+// round trip overlaps the kernel's own first loads, and only 1 KB * PER of LDS (the occupancy of
+// the consumers is LDS-bound with the general 32 KB variant).
+constexpr int kSmallScan = 1024, kMediumScan = 4096;
+template <int PER> struct SmallCounts {
+    uint32_t v[PER];
 };
-RM_D SmallCounts small_scan_load(const uint32_t *cnt, int n)
+template <int PER> RM_D SmallCounts<PER> small_scan_load(const uint32_t *cnt, int n)
 {
-    SmallCounts c;
+    SmallCounts<PER> c;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = int(threadIdx.x) * 4 + k;
+    for (int k = 0; k < PER; ++k) {
+        const int i = int(threadIdx.x) * PER + k;
         c.v[k] = (i < n) ? cnt[i] : 0u;
     }
     return c;
 }
-RM_D uint32_t small_scan(const SmallCounts &c, int n, uint32_t *s_off, uint32_t *s_wave /*[4]*/, uint32_t *pub, uint32_t *vmax_out)
+template <int PER>
+RM_D uint32_t small_scan(const SmallCounts<PER> &c, int n, uint32_t *s_off, uint32_t *s_wave /*[4]*/, uint32_t *pub, uint32_t *vmax_out)
 {
-    const uint32_t sum = c.v[0] + c.v[1] + c.v[2] + c.v[3];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sum += c.v[k];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = sum;
 #pragma unroll
@@ -1443,8 +1461,8 @@ RM_D uint32_t small_scan(const SmallCounts &c, int n, uint32_t *s_off, uint32_t 
     for (int w = 0; w < wave; ++w) run += s_wave[w];
     const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = int(threadIdx.x) * 4 + k;
+    for (int k = 0; k < PER; ++k) {
+        const int i = int(threadIdx.x) * PER + k;
         if (i < n) {
             s_off[i] = run;
             if (pub) pub[i] = run;
@@ -1453,7 +1471,9 @@ RM_D uint32_t small_scan(const SmallCounts &c, int n, uint32_t *s_off, uint32_t 
     }
     if (pub && threadIdx.x == 0) pub[n] = total;
     if (vmax_out) {
-        uint32_t vmax = max(max(c.v[0], c.v[1]), max(c.v[2], c.v[3]));
+        uint32_t vmax = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) vmax = max(vmax, c.v[k]);
         for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), d)));
         // the publisher needs the maximum over the whole workgroup
         __shared__ uint32_t s_vmax[4];
@@ -1464,6 +1484,10 @@ RM_D uint32_t small_scan(const SmallCounts &c, int n, uint32_t *s_off, uint32_t 
     __syncthreads();
     return total;
 }
+// scan variant of a kernel template parameter: 1 general (<= kFusedScanMax), 3 small, 4 medium
+constexpr int scan_per(int v) { return v == 3 ? 4 : 16; }
+constexpr int scan_lds(int v) { return v == 1 ? kFusedScanMax + 1 : (v == 3 ? kSmallScan + 1 : (v == 4 ? kMediumScan + 1 : 1)); }
+static inline int scan_variant(int n_cnt) { return n_cnt <= kSmallScan ? 3 : (n_cnt <= kMediumScan ? 4 : (n_cnt <= kFusedScanMax ? 1 : 2)); }
 
 RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
 {
@@ -1476,21 +1500,22 @@ RM_D double tx_success(const ModelDev &m, const rm_tx_record &tx)
 // SEG 0: unsorted table, heard links are counted per (frame, slab) cell (ordered scatter later).
 // SEG 1/2: sorted table, heard links go straight into the frame's segment of the A records (any
 // order inside it); the segment offsets are the scan of the per-frame candidate counts, redone in
-// LDS by every workgroup (1; 3 = the same for at most kSmallScan frames) or read from k_scan_counts' output (2).
+// LDS by every workgroup (1; 3 / 4 = the same for at most kSmallScan / kMediumScan frames) or read from k_scan_counts' output (2).
 // PACKED: a 1-D grid whose workgroups walk the started 256-entry chunks of all shards (no workgroup
 // without entries); otherwise blockIdx.y is the shard and blockIdx.x strides over its entries.
 template <int MODEL, bool SINR, bool STOCH, int SEG, bool PACKED = false>
 RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
 {
-    __shared__ uint32_t s_seg[SEG == 1 ? kFusedScanMax + 1 : (SEG == 3 ? kSmallScan + 1 : 1)];
+    __shared__ uint32_t s_seg[scan_lds(SEG)];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_cs[PACKED ? kShards + 1 : 1]; // exclusive scan of the shards' chunk counts
     __shared__ uint32_t s_sn[PACKED ? kShards : 1];     // entries per shard
     const bool publisher = (blockIdx.x == 0 && blockIdx.y == 0);
     bool scanned = false; // the scan is only needed by the scatter: it runs after the first evaluation
     const uint32_t n_own = min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
-    SmallCounts pre{};
-    if (SEG == 3 && (PACKED || blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load(t.cand_tot, t.n_cnt);
+    constexpr bool kRegScan = (SEG == 3 || SEG == 4);
+    SmallCounts<scan_per(SEG)> pre{};
+    if (kRegScan && (PACKED || blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
     const int lane = threadIdx.x & 63;
@@ -1559,7 +1584,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
             scanned = true;
         }
-        if (SEG == 3 && !scanned) {
+        if (kRegScan && !scanned) {
             small_scan(pre, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
             scanned = true;
         }
@@ -1572,7 +1597,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             if (valid && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total);
             base = __shfl(base, ri.start);
             if (wanted) {
-                const uint32_t o = ((SEG == 1 || SEG == 3) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
+                const uint32_t o = ((SEG == 1 || kRegScan) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
                 t.a_dst[o] = orig;
                 t.a_rssi[o] = rssi;
                 if (SINR) t.a_e[o] = int(idx);
@@ -1599,7 +1624,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
     }
     if (SEG == 1 && !scanned && publisher) // seg_off is published even if this shard was empty
         block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
-    if (SEG == 3 && !scanned && publisher) small_scan(pre, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
+    if (kRegScan && !scanned && publisher) small_scan(pre, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
 }
 
 template <int MODEL, bool SINR, bool STOCH, int SEG>
@@ -1627,10 +1652,10 @@ __global__ void __launch_bounds__(64) k_store_ticks(const TickGroup g, TickDev *
     for (int i = threadIdx.x; i < int(sizeof(TickDev) / 4); i += blockDim.x) out[i] = src[i];
 }
 
-template <int MODEL, bool STOCH, bool SMALL>
+template <int MODEL, bool STOCH, int SCAN>
 __global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    exact_body<MODEL, false, STOCH, SMALL ? 3 : 1, true>(nd, m, ticks[blockIdx.z]);
+    exact_body<MODEL, false, STOCH, SCAN, true>(nd, m, ticks[blockIdx.z]);
 }
 
 // half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
@@ -1856,13 +1881,14 @@ RM_D void write_pkt_interference(const ModelDev &m, const TickDev &t, uint32_t f
 template <bool STOCH, bool SINR, int MODE>
 RM_D void reorder_body(const ModelDev &m, const TickDev &t)
 {
-    __shared__ uint32_t s_off[MODE == 1 ? kFusedScanMax + 1 : (MODE == 3 ? kSmallScan + 1 : 1)];
+    __shared__ uint32_t s_off[scan_lds(MODE)];
     __shared__ uint32_t s_wave[4];
     const bool publisher = blockIdx.x == 0;
     const int lane = threadIdx.x & 63;
     const int n_new = t.n_active - t.first_new;
-    SmallCounts pre{};
-    if (MODE == 3) pre = small_scan_load(t.cursor, t.n_cnt);
+    constexpr bool kRegScan = (MODE == 3 || MODE == 4);
+    SmallCounts<scan_per(MODE)> pre{};
+    if (kRegScan) pre = small_scan_load<scan_per(MODE)>(t.cursor, t.n_cnt);
 
     // the first frame of this wave: its records are requested before the scan below, so that the
     // scan's round trip and the records' overlap
@@ -1884,9 +1910,9 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         }
     }
 
-    if (MODE == 1 || MODE == 3) {
+    if (MODE == 1 || kRegScan) {
         uint32_t vmax = 0;
-        const uint32_t total = (MODE == 3)
+        const uint32_t total = kRegScan
                                    ? small_scan(pre, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr, publisher ? &vmax : nullptr)
                                    : block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr,
                                                        publisher ? &vmax : nullptr);
@@ -1914,7 +1940,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
             src0 = t.seg_off[slot];
             len = t.cursor[slot];
         }
-        const uint32_t dst0 = (MODE == 1 || MODE == 3) ? s_off[slot] : t.slot_off[slot];
+        const uint32_t dst0 = (MODE == 1 || kRegScan) ? s_off[slot] : t.slot_off[slot];
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {
             const uint32_t o = src0 + c0 + lane;
             const bool valid = c0 + lane < len;
@@ -1957,10 +1983,10 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
     reorder_body<STOCH, SINR, MODE>(m, t);
 }
 
-template <bool STOCH, bool SMALL>
+template <bool STOCH, int SCAN>
 __global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    reorder_body<STOCH, false, SMALL ? 3 : 1>(m, ticks[blockIdx.z]);
+    reorder_body<STOCH, false, SCAN>(m, ticks[blockIdx.z]);
 }
 
 __global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
@@ -2249,12 +2275,12 @@ template <int MODEL, bool SINR>
 static void launch_exact_m(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
 {
     const dim3 grid(4, kShards), block(256);
-    const int seg = t.use_matrix ? 0 : (t.n_cnt <= kSmallScan ? 3 : (t.n_cnt <= kFusedScanMax ? 1 : 2));
+    const int seg = t.use_matrix ? 0 : scan_variant(t.n_cnt);
 #define RM_EX(ST, SG) hipLaunchKernelGGL((k_exact<MODEL, SINR, ST, SG>), grid, block, 0, s, nd, m, t)
     if (cfg.stochastic) {
-        if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else if (seg == 3) RM_EX(true, 3); else RM_EX(true, 2);
+        if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else if (seg == 3) RM_EX(true, 3); else if (seg == 4) RM_EX(true, 4); else RM_EX(true, 2);
     } else {
-        if (seg == 0) RM_EX(false, 0); else if (seg == 1) RM_EX(false, 1); else if (seg == 3) RM_EX(false, 3); else RM_EX(false, 2);
+        if (seg == 0) RM_EX(false, 0); else if (seg == 1) RM_EX(false, 1); else if (seg == 3) RM_EX(false, 3); else if (seg == 4) RM_EX(false, 4); else RM_EX(false, 2);
     }
 #undef RM_EX
 }
@@ -2335,11 +2361,14 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
     const int n_new = t.n_active - t.first_new;
     const dim3 grid(max(1, min(2048, (n_new + 3) / 4))), block(256);
     const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
-    const int mode = t.n_cnt <= kSmallScan ? 3 : (t.n_cnt <= kFusedScanMax ? 1 : 2);
+    const int mode = scan_variant(t.n_cnt);
 #define RM_RE(ST, SI, MO) hipLaunchKernelGGL((k_reorder<ST, SI, MO>), grid, block, 0, s, m, t)
     if (mode == 3) {
         if (cfg.stochastic) { if (sinr) RM_RE(true, true, 3); else RM_RE(true, false, 3); }
         else { if (sinr) RM_RE(false, true, 3); else RM_RE(false, false, 3); }
+    } else if (mode == 4) {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 4); else RM_RE(true, false, 4); }
+        else { if (sinr) RM_RE(false, true, 4); else RM_RE(false, false, 4); }
     } else if (mode == 1) {
         if (cfg.stochastic) { if (sinr) RM_RE(true, true, 1); else RM_RE(true, false, 1); }
         else { if (sinr) RM_RE(false, true, 1); else RM_RE(false, false, 1); }
@@ -2353,6 +2382,17 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
 
 // rm_batch_*: n independent ticks (sorted table, fp32 frame, no SINR, <= kFusedScanMax frames each)
 // in four launches (+ k_store_ticks).  stage 0: k_tick_prep + k_filter_wg, 1: k_exact, 2: k_reorder.
+hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
+                                const int64_t *start_us, int64_t air_us, rm_tx_record *out)
+{
+    if (n <= 0 || n_ticks <= 0) return hipSuccess;
+    if (n_ticks > kMaxBatch) return hipErrorInvalidValue;
+    PackStarts st{};
+    for (int b = 0; b < n_ticks; ++b) st.start_us[b] = start_us[b];
+    hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), n_ticks), dim3(256), 0, s, nd, dev_src, n, st, air_us, out);
+    return hipGetLastError();
+}
+
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
 {
     const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
@@ -2377,9 +2417,10 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
 {
     if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
     int max_eval = 0, max_new = 0;
-    bool small = true; // every tick's counts fit the small fused scan
+    int scan = 3; // the smallest fused-scan variant that holds every tick's counts
     for (int i = 0; i < n; ++i) {
-        small = small && ticks[i].n_cnt <= kSmallScan;
+        const int v = scan_variant(ticks[i].n_cnt);
+        scan = (v == 1 || scan == 1) ? 1 : max(scan, v);
         max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
         max_new = max(max_new, ticks[i].n_active - ticks[i].first_new);
     }
@@ -2399,11 +2440,13 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
 #define RM_EXB(MODEL)                                                                                                \
     do {                                                                                                             \
         if (cfg.stochastic) {                                                                                        \
-            if (small) hipLaunchKernelGGL((k_exact_batch<MODEL, true, true>), grid, block, 0, s, nd, m, b);          \
-            else hipLaunchKernelGGL((k_exact_batch<MODEL, true, false>), grid, block, 0, s, nd, m, b);               \
+            if (scan == 3) hipLaunchKernelGGL((k_exact_batch<MODEL, true, 3>), grid, block, 0, s, nd, m, b);         \
+            else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<MODEL, true, 4>), grid, block, 0, s, nd, m, b);    \
+            else hipLaunchKernelGGL((k_exact_batch<MODEL, true, 1>), grid, block, 0, s, nd, m, b);                   \
         } else {                                                                                                     \
-            if (small) hipLaunchKernelGGL((k_exact_batch<MODEL, false, true>), grid, block, 0, s, nd, m, b);         \
-            else hipLaunchKernelGGL((k_exact_batch<MODEL, false, false>), grid, block, 0, s, nd, m, b);              \
+            if (scan == 3) hipLaunchKernelGGL((k_exact_batch<MODEL, false, 3>), grid, block, 0, s, nd, m, b);        \
+            else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<MODEL, false, 4>), grid, block, 0, s, nd, m, b);   \
+            else hipLaunchKernelGGL((k_exact_batch<MODEL, false, 1>), grid, block, 0, s, nd, m, b);                  \
         }                                                                                                            \
     } while (0)
         switch (m.kind) {
@@ -2418,11 +2461,13 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
     } else {
         const dim3 grid(max(1, min(2048, (max_new + 3) / 4)), 1, n), block(256);
         if (cfg.stochastic) {
-            if (small) hipLaunchKernelGGL((k_reorder_batch<true, true>), grid, block, 0, s, m, b);
-            else hipLaunchKernelGGL((k_reorder_batch<true, false>), grid, block, 0, s, m, b);
+            if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
+            else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
+            else hipLaunchKernelGGL((k_reorder_batch<true, 1>), grid, block, 0, s, m, b);
         } else {
-            if (small) hipLaunchKernelGGL((k_reorder_batch<false, true>), grid, block, 0, s, m, b);
-            else hipLaunchKernelGGL((k_reorder_batch<false, false>), grid, block, 0, s, m, b);
+            if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<false, 3>), grid, block, 0, s, m, b);
+            else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<false, 4>), grid, block, 0, s, m, b);
+            else hipLaunchKernelGGL((k_reorder_batch<false, 1>), grid, block, 0, s, m, b);
         }
     }
     return hipGetLastError();

@@ -52,7 +52,7 @@ def pad_records(local_records, slots):
     return out
 
 
-def all_gather_records(dist, local, world, out=None):
+def all_gather_records(dist, local, world, out=None, group=None):
     """All-gather one rank's slot buffer (torch uint8 tensor of slots*64 bytes).
 
     NCCL/RCCL: one all_gather_into_tensor on the current stream.  gloo (CPU tests): list form."""
@@ -60,17 +60,17 @@ def all_gather_records(dist, local, world, out=None):
     if out is None:
         out = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
     if local.is_cuda and dist.get_backend() != "gloo":
-        dist.all_gather_into_tensor(out, local)
+        dist.all_gather_into_tensor(out, local, group=group)
     elif local.is_cuda:
         # rehearsal on a box without RCCL peers (gloo): stage through the host, synchronously
         torch.cuda.current_stream(local.device).synchronize()
         host = local.cpu()
         parts = [torch.empty_like(host) for _ in range(world)]
-        dist.all_gather(parts, host)
+        dist.all_gather(parts, host, group=group)
         out.copy_(torch.cat(parts).to(local.device))
     else:
         parts = list(out.view(world, local.numel()).unbind(0))
-        dist.all_gather(parts, local)
+        dist.all_gather(parts, local, group=group)
     return out
 
 
@@ -110,7 +110,7 @@ class ShardedTick:
     carries no state from tick to tick.  Media with draws or an on-air list must use ONE context.
     Works with world == 1 as well (no collective), which is how the choreography is tested on one GPU."""
 
-    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True):
+    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True, batch=1):
         import torch
         self.torch = torch
         if not isinstance(engines, (list, tuple)):
@@ -124,8 +124,16 @@ class ShardedTick:
                 e.set_partition(self.lo, self.hi - self.lo)
         self.comm = torch.cuda.Stream(device=device)
         ring = len(self.engines) + 1
-        self.mine = [torch.empty(slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
-        self.all = [torch.empty(world * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
+        # batch > 1: a stage covers `batch` ticks -- one packing launch, ONE all-gather of
+        # world x batch x slots records (xGMI likes few, larger collectives), one transposition to
+        # tick-major order, and the sweep of all of them through rm_batch_run_device
+        self.batch = batch
+        self.mine = [torch.empty(batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
+        self.all = [torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
+        self.tick_major = ([torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device)
+                            for _ in range(ring)] if batch > 1 else None)
+        # one process group (RCCL communicator) per context: their collectives are independent
+        self.groups = ([dist.new_group() for _ in self.engines] if (batch > 1 and world > 1) else None)
         self.ready = [torch.cuda.Event() for _ in range(ring)]  # gathered records of the buffer are complete
         self.done = [torch.cuda.Event() for _ in range(ring)]   # the sweep that read the buffer has finished
         self.used = [False] * ring
@@ -180,6 +188,30 @@ class ShardedTick:
                 eng.finish_draws(self.cnt_all.data_ptr(), self.world, self.rank)
         self.done[b].record(stream)
         self.used[b] = True
+
+    def run_batch(self, ctx, dev_src_ptr, t_begins, air_us, tick_us):
+        """len(t_begins) <= batch ticks on context `ctx`, everything on that context's own stream:
+        one packing launch (sources: rows of `slots` int32 at dev_src_ptr), ONE all-gather of
+        world x ticks x slots records on the context's own process group, one transposition to
+        tick-major order, the sweep through rm_batch_run_device.  No cross-stream events: on this
+        runtime an event wait between two streams costs far more than the collective it would hide,
+        and with two contexts the other context's sweep runs under this one's all-gather anyway."""
+        torch = self.torch
+        eng, stream = self.engines[ctx], self.streams[ctx]
+        nb, row = len(t_begins), self.slots * RECORD_BYTES
+        with torch.cuda.stream(stream):
+            eng.pack_tx_batch_device_on(stream.cuda_stream, dev_src_ptr, nb, self.slots, t_begins, air_us,
+                                        self.mine[ctx].data_ptr())
+            src = self.mine[ctx]
+            if self.world > 1:
+                mine, gathered = self.mine[ctx][: nb * row], self.all[ctx][: self.world * nb * row]
+                all_gather_records(self.dist, mine, self.world, gathered, group=self.groups[ctx])
+                # [rank][tick][slot] -> [tick][rank][slot]: a tick's frames in canonical (rank = source range) order
+                src = self.tick_major[ctx]
+                src[: self.world * nb * row].view(nb, self.world, row).copy_(gathered.view(self.world, nb, row).permute(1, 0, 2))
+            per_tick = self.world * self.slots
+            ptrs = src.data_ptr() + np.arange(nb, dtype=np.uint64) * np.uint64(per_tick * RECORD_BYTES)
+            eng.batch_run_device(t_begins, t_begins + tick_us, ptrs, np.full(nb, per_tick, dtype=np.int32))
 
     def run(self, dev_src_ptr, t_begin, t_end, air_us):
         """Unpipelined convenience: stage and sweep one tick."""

@@ -207,6 +207,12 @@ class Engine:
         check(self._L.rm_pack_tx_device_on(self._h, C.c_void_p(stream_ptr), C.c_void_p(dev_src_ptr), n, start_us, air_us,
                                            C.c_void_p(dev_out_ptr)))
 
+    def pack_tx_batch_device_on(self, stream_ptr, dev_src_ptr, n_ticks, n, start_us, air_us, dev_out_ptr):
+        st = np.ascontiguousarray(start_us, dtype=np.int64)
+        assert len(st) == n_ticks
+        check(self._L.rm_pack_tx_batch_device_on(self._h, C.c_void_p(stream_ptr), C.c_void_p(dev_src_ptr), n_ticks, n,
+                                                 st.ctypes.data, air_us, C.c_void_p(dev_out_ptr)))
+
     def tick_run_device(self, t_begin, t_end, dev_new_ptr, n_new):
         check(self._L.rm_tick_run_device(self._h, t_begin, t_end, C.c_void_p(dev_new_ptr), n_new))
 
