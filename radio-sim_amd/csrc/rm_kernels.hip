@@ -478,6 +478,13 @@ RM_D uint32_t lane_prefix(uint64_t mask)
 
 RM_D uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// Values that are the same in every lane of a wave but that the compiler cannot know to be (the wave
+// index, anything read from LDS or memory at a wave-uniform address): moved to a scalar register,
+// so that the loops and branches they steer run on the scalar unit instead of as masked vector code.
+RM_D int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+RM_D uint32_t uniform_u(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+RM_D int wave_index() { return __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)); }
+
 // Consecutive lanes with equal `key` form a run (candidate entries of one frame are contiguous in
 // the list).  For the lanes with `pred`: how many such lanes precede me inside my run, how many
 // the run has, and which lane leads it -- so that one atomic per run replaces one per link.
@@ -517,7 +524,7 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
     __shared__ int s_src[SHADOW ? kTxChunk : 1];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_index();
     const int slab = blockIdx.x * kWavesPerBlock + wave;
     const int chunk = blockIdx.y;
     const int n_eval = t.n_active - t.first_eval;
@@ -766,7 +773,7 @@ __global__ void __launch_bounds__(256) k_near_pairs(const NodesDev nd, const Mod
             t.cursor[i] = 0u;
             t.cand_tot_next[i] = 0u;
         }
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6); // wave-uniform
+    const int e = blockIdx.x * 4 + wave_index();
     if (e >= n_eval) return;
     const int abs_i = t.first_eval + e;
     rm_tx_record tx;
@@ -822,14 +829,14 @@ __global__ void __launch_bounds__(kBlock, 6) k_filter_list(const NodesDev nd, co
     __shared__ int s_src[SHADOW ? kTxChunk : 1];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_index();
     if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
-    const uint32_t n_work = t.near_cnt[t.n_wg];
+    const uint32_t n_work = uniform_u(t.near_cnt[t.n_wg]);
 
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) { // block-uniform; nothing is carried over
-        const uint32_t item = t.work[w];
+        const uint32_t item = uniform_u(t.work[w]);
         const int b = int(item >> 6), k = int(item & 63u);
-        const int cnt = int(min(t.near_cnt[b], uint32_t(kNearCap)));
+        const int cnt = uniform_i(int(min(t.near_cnt[b], uint32_t(kNearCap))));
         const int nt = min(kTxChunk, cnt - k * kTxChunk);
         const int slab = b * kWavesPerBlock + wave;
         const int jbase = slab * (kGroup * RPT);
@@ -1043,7 +1050,7 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     __shared__ uint32_t s_n;
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_index();
     const int wg = blockIdx.x;
     const int slab = wg * kWavesPerBlock + wave;
     const int jbase = slab * (kGroup * RPT);
@@ -1174,7 +1181,7 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
             }
         }
         __syncthreads();
-        const int n_near = int(s_n);
+        const int n_near = uniform_i(int(s_n));
         const bool last = f0 + kBlock >= n_eval;
         if (!last && n_near + kBlock <= kNearLds) continue; // room for another 256 frames
 
@@ -1287,7 +1294,7 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
 }
 
 template <int RPT, bool SHADOW>
-__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : 6) k_filter_wg(const NodesDev nd, const ModelDev m, const TickDev t)
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6)) k_filter_wg(const NodesDev nd, const ModelDev m, const TickDev t)
 {
     filter_wg_body<RPT, SHADOW>(nd, m, t);
 }
@@ -1534,7 +1541,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
         for (int w = 0; w < int(threadIdx.x >> 6); ++w) run += s_wave[w];
         s_cs[threadIdx.x] = run;
         s_sn[threadIdx.x] = n_own;
-        n_chunks = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        n_chunks = uniform_u(s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
         if (threadIdx.x == 0) s_cs[kShards] = n_chunks;
         __syncthreads();
     }
@@ -1615,9 +1622,9 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             uint32_t lo = 0, hi = kShards; // the shard whose chunk range holds u: s_cs[lo] <= u < s_cs[lo + 1]
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (s_cs[mid] <= u) lo = mid; else hi = mid;
+                if (uniform_u(s_cs[mid]) <= u) lo = mid; else hi = mid;
             }
-            entries(lo, (u - s_cs[lo]) << 8, s_sn[lo]);
+            entries(lo, (u - uniform_u(s_cs[lo])) << 8, uniform_u(s_sn[lo]));
         }
     } else {
         for (uint32_t it = blockIdx.x * blockDim.x; it < n_own; it += stride) entries(blockIdx.y, it, n_own); // block-uniform trip count
@@ -1892,14 +1899,14 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
 
     // the first frame of this wave: its records are requested before the scan below, so that the
     // scan's round trip and the records' overlap
-    const int q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q0 = blockIdx.x * 4 + wave_index();
     uint32_t src0 = 0, len = 0;
     int mine = 0x7fffffff, in_e = 0;
     double in_rssi = 0.0, in_prob = 1.0;
     uint8_t v = 0;
     if (q0 < n_new) {
-        src0 = t.seg_off[q0 + t.shift];
-        len = t.cursor[q0 + t.shift];
+        src0 = uniform_u(t.seg_off[q0 + t.shift]);
+        len = uniform_u(t.cursor[q0 + t.shift]);
         if (uint32_t(lane) < len) {
             const uint32_t o = src0 + lane;
             mine = t.a_dst[o];
@@ -1937,10 +1944,10 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
     for (int q = q0; q < n_new; q += gridDim.x * 4) { // wave-uniform
         const int slot = q + t.shift;
         if (q != q0) {
-            src0 = t.seg_off[slot];
-            len = t.cursor[slot];
+            src0 = uniform_u(t.seg_off[slot]);
+            len = uniform_u(t.cursor[slot]);
         }
-        const uint32_t dst0 = (MODE == 1 || kRegScan) ? s_off[slot] : t.slot_off[slot];
+        const uint32_t dst0 = uniform_u((MODE == 1 || kRegScan) ? s_off[slot] : t.slot_off[slot]);
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {
             const uint32_t o = src0 + c0 + lane;
             const bool valid = c0 + lane < len;
@@ -1995,7 +2002,7 @@ __global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, cons
 }
 
 template <int RPT, bool SHADOW>
-__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : 6)
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6))
 k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
     filter_wg_body<RPT, SHADOW>(nd, m, ticks[blockIdx.z]);
@@ -2213,8 +2220,10 @@ int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
         }
         if (want_wg) mode = kFilterWg;
         if (mode == kFilterWg) {
-            int rpt = (t.n_rx > 400000) ? 4 : 1;
-            if (const char *e = getenv("RM_WG_RPT")) rpt = (atoi(e) == 4) ? 4 : 1;
+            // batches bring their own parallelism (workgroups x ticks): the coarse tiling halves the frame x
+            // workgroup-box tests of phase A twice over; a lone tick needs the workgroups
+            int rpt = (t.n_rx > 400000 || (want_wg && t.n_rx >= 16384)) ? 4 : 1;
+            if (const char *e = getenv("RM_WG_RPT")) rpt = (atoi(e) == 4) ? 4 : (atoi(e) == 2 ? 2 : 1);
             t.rpt = rpt;
             t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
         }
@@ -2234,6 +2243,9 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
         if (t.rpt == 4) {
             if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<4, true>), grid, block, 0, s, nd, m, t);
             else hipLaunchKernelGGL((k_filter_wg<4, false>), grid, block, 0, s, nd, m, t);
+        } else if (t.rpt == 2) {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<2, true>), grid, block, 0, s, nd, m, t);
+            else hipLaunchKernelGGL((k_filter_wg<2, false>), grid, block, 0, s, nd, m, t);
         } else {
             if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<1, true>), grid, block, 0, s, nd, m, t);
             else hipLaunchKernelGGL((k_filter_wg<1, false>), grid, block, 0, s, nd, m, t);
@@ -2431,6 +2443,9 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
         if (t0.rpt == 4) {
             if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b);
             else hipLaunchKernelGGL((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b);
+        } else if (t0.rpt == 2) {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<2, true>), grid, block, 0, s, nd, m, b);
+            else hipLaunchKernelGGL((k_filter_wg_batch<2, false>), grid, block, 0, s, nd, m, b);
         } else {
             if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b);
             else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b);
