@@ -656,7 +656,8 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.shard_count = ts.d_shards.p + size_t(ts.parity) * rm::kShards * rm::kShardStride;
     t.next_shard_count = ts.d_shards.p + size_t(ts.parity ^ 1) * rm::kShards * rm::kShardStride;
     t.cap = c->cap;
-    t.seg_cap = (c->cap + rm::kShards - 1) / rm::kShards;
+    t.shard_mask = (want_wg && filter_mode == rm::kFilterWg && t.rpt == 4) ? 63u : uint32_t(rm::kShards - 1);
+    t.seg_cap = uint32_t((size_t((c->cap + rm::kShards - 1) / rm::kShards) * rm::kShards) / (t.shard_mask + 1));
     t.use_matrix = cfg.sorted ? 0 : 1;
     t.cursor = ts.d_cursor.p;
     {

@@ -112,6 +112,8 @@ struct TickDev {
     uint32_t *next_shard_count;
     uint32_t cap;           // capacity of the ordered output records
     uint32_t seg_cap;       // candidate entries per shard (shard s owns [s*seg_cap, (s+1)*seg_cap))
+    uint32_t shard_mask;    // shards in use - 1: all kShards for a lone tick; a batch appends fewer, longer runs and uses
+                            // 64, so that the exact kernel's 256-entry chunks are full (195 entries per shard fill 76 %)
     int use_matrix;         // 1: ordered scatter through the (frame, slab) cell matrix (unsorted table)
                             // 0: per-frame counts + cursor, order restored by k_reorder (sorted table)
     uint32_t *cursor;       // [n_cnt] per-frame scatter cursor = heard links of the frame (use_matrix == 0)

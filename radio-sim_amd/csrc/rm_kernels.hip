@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
         if (lane >= d) inc += o;
     }
     const uint32_t wave_total = __shfl(inc, 63);
-    const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) & (kShards - 1);
+    const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) & t.shard_mask;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
     base = __builtin_amdgcn_readfirstlane(base);
@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(kBlock, 6) k_filter_list(const NodesDev nd, co
             if (lane >= d) inc += o;
         }
         const uint32_t wave_total = __shfl(inc, 63);
-        const uint32_t shard = (uint32_t(b) * 4u + uint32_t(wave) + w * 37u) & (kShards - 1); // per wave: items are heavy
+        const uint32_t shard = (uint32_t(b) * 4u + uint32_t(wave) + w * 37u) & t.shard_mask; // per wave: items are heavy
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
         base = __builtin_amdgcn_readfirstlane(base);
@@ -1252,7 +1252,7 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
                     if (lane >= d) inc += o;
                 }
                 const uint32_t wave_total = __shfl(inc, 63);
-                const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + blockIdx.z * 101u) & (kShards - 1);
+                const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + blockIdx.z * 101u) & t.shard_mask;
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -1542,7 +1542,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
         s_cs[threadIdx.x] = run;
         s_sn[threadIdx.x] = n_own;
         n_chunks = uniform_u(s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
-        if (threadIdx.x == 0) s_cs[kShards] = n_chunks;
+        if (threadIdx.x == 0) s_cs[PACKED ? kShards : 0] = n_chunks;
         __syncthreads();
     }
     auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) {
@@ -1674,7 +1674,7 @@ __global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t)
     const int src = t.tx[t.first_eval + e].src;
     if (src < nd.rx_first || src >= nd.rx_first + nd.n_rx) return;
     const int pos = nd.pos_of[src - nd.rx_first];
-    const uint32_t shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kShards - 1);
+    const uint32_t shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) & t.shard_mask;
     const uint32_t local = atomicAdd(&t.shard_count[shard * kShardStride], 1u);
     if (local >= t.seg_cap) {
         t.stage_count[1] = 1u;
