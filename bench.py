@@ -143,7 +143,7 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=192, 
         src_dev = torch.from_numpy(np.stack(sources)).to(dev)
     streams[0].synchronize()
 
-    batch = max(1, min(batch, 8))   # 8 ticks of this size already fill the device
+    batch = max(1, min(batch, 16))  # 16 ticks of this size already fill the device
 
     def run(k0, k1):
         g = 0
@@ -404,8 +404,9 @@ def main():
         pmc_note = "no PMC pass on file for this workload"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = pmc.get(args.workload, {}).get(dominant)
-            if ent and world == 1:
+            wl = pmc.get(args.workload, {})
+            ent = wl.get(dominant)
+            if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
                 traffic = ent["hbm_bytes_per_launch"]
                 pmc_note = ent["source"]
         except (OSError, ValueError):
