@@ -62,6 +62,20 @@ def _worker(rank, world, port, n, seed, q):
             r = O.tick(mdl, nd, pk)
             keep = (r.dst >= lo) & (r.dst < hi)
             out.append((slot_idx[r.pkt[keep]], r.dst[keep], r.verdict[keep], r.rssi[keep], r.sinr[keep]))
+        # the batched exchange of ShardedTick.run_batch: all ticks' slots in ONE all-gather on the
+        # context's own process group, then rank-major -> tick-major
+        grp = dist.new_group()
+        nb, row = len(lists), slots * D.RECORD_BYTES
+        mine_all = np.concatenate([D.pad_records(to_tx_records(rsa, nd.packets(s[(s >= lo) & (s < hi)], k * 1000, 8128)), slots)
+                                   for k, s in enumerate(lists)])
+        buf = torch.from_numpy(mine_all.view(np.uint8).copy())
+        gathered = D.all_gather_records(dist, buf, world, group=grp)
+        tick_major = torch.empty_like(gathered)
+        tick_major.view(nb, world, row).copy_(gathered.view(world, nb, row).permute(1, 0, 2))
+        for k, srcs in enumerate(lists):
+            recs = D.records_from_bytes(tick_major.view(nb, world * row)[k])
+            valid, _ = D.drop_padding(recs)
+            assert np.array_equal(valid["src"], srcs) and np.all(valid["start_us"] == k * 1000)
         gathered_out = [None] * world
         dist.all_gather_object(gathered_out, out)
         if rank == 0:

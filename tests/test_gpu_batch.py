@@ -165,3 +165,61 @@ def test_batch_refusals(engine, rsa, O):
     engine.batch_run_sources_device(*args)
     assert engine.batch_result_copy(0, 10).count > 0
     src.free()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_batch_equals_global(rsa, O, world):
+    """The multi-GPU batch sequence on one GPU: every 'rank' packs its own transmitters of all ticks with
+    rm_pack_tx_batch_device_on, the 'all-gather' + transposition to tick-major order is done on the
+    host, every rank sweeps the gathered ticks against its receiver range with rm_batch_run_device;
+    the merged links of every tick equal the global oracle run."""
+    from radio_sim_amd import dist as D
+    from util import KINDS, _PARAM_MAP
+    n, n_ticks = 5000, 5
+    params = {"ld_sigma_db": 4.0, "ld_seed": 5}
+    nd = _layout(O, n, seed=31)
+    mdl = oracle_model(O, "logdist", params)
+    srcs = _ticks(n, n_ticks, 120, seed=7, ragged=True)
+    slots = D.slots_needed(n, world, srcs)
+    starts = np.arange(n_ticks, dtype=np.int64) * 1000
+    engines = []
+    try:
+        mine_bytes = []
+        for r in range(world):
+            lo, hi = D.partition(n, r, world)
+            eng = rsa.Engine(0)
+            engines.append(eng)
+            eng.upload_table(nd)
+            eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            eng.set_partition(lo, hi - lo)
+            padded = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in srcs])     # [ticks][slots]
+            d_src, d_out = DeviceArray(padded), DeviceArray(nbytes=n_ticks * slots * 64)
+            eng.pack_tx_batch_device_on(0, d_src.ptr.value, n_ticks, slots, starts, AIR, d_out.ptr.value)
+            mine_bytes.append(DeviceArray.read(d_out.ptr.value, np.uint8, n_ticks * slots * 64).reshape(n_ticks, slots * 64))
+            d_src.free()
+            d_out.free()
+        tick_major = np.ascontiguousarray(np.stack(mine_bytes).transpose(1, 0, 2))                # [ticks][rank][slots*64]
+        d_all = DeviceArray(tick_major)
+        per_tick = world * slots
+        ptrs = d_all.ptr.value + np.arange(n_ticks, dtype=np.uint64) * np.uint64(per_tick * 64)
+        for eng in engines:
+            eng.batch_run_device(starts, starts + 1000, ptrs, [per_tick] * n_ticks)
+        for b in range(n_ticks):
+            shards = []
+            for eng in engines:
+                res = eng.batch_result_copy(b, per_tick)
+                shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
+            pkt, dst, verdict, rssi, _ = D.merge_shard_links(shards, per_tick)
+            gathered = D.records_from_bytes(tick_major[b].reshape(-1))
+            valid, slot_idx = D.drop_padding(gathered)
+            np.testing.assert_array_equal(valid["src"], srcs[b])                                  # canonical order survives
+            ref = O.tick(mdl, nd, nd.packets(srcs[b], start_us=int(starts[b]), air_us=AIR))
+            assert ref.count > 100 and len(pkt) == ref.count
+            np.testing.assert_array_equal(pkt, slot_idx[ref.pkt])
+            np.testing.assert_array_equal(dst, ref.dst)
+            np.testing.assert_array_equal(verdict, ref.verdict)
+            np.testing.assert_array_equal(rssi, ref.rssi)
+        d_all.free()
+    finally:
+        for eng in engines:
+            eng.close()
