@@ -184,6 +184,7 @@ struct rm_context : TickSlot {
     size_t air_head = 0, air_tail = 0;
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
+    rm::TransmitResult *h_transmit = nullptr; // host-mapped result block of rm_transmit
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
     // larger batches upload them with one copy from pinned host memory (two staging buffers, each
     // guarded by an event: it is rewritten only after the copy that read it has completed)
@@ -987,6 +988,7 @@ void rm_destroy(rm_context *c)
         if (c->h_ticks_ev[g]) (void)hipEventDestroy(c->h_ticks_ev[g]);
         if (c->h_ticks[g]) (void)hipHostFree(c->h_ticks[g]);
     }
+    if (c->h_transmit) (void)hipHostFree(c->h_transmit);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1331,9 +1333,48 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     if (src < 0 || src >= c->n) return fail(RM_ERR_INVALID, "could not find source node");
     if (hex_length < 0) return fail(RM_ERR_INVALID, "negative packet length");
-    RM_TRY(rm_tick_begin(c, start_us, start_us));
-    RM_TRY(rm_enqueue_tx(c, src, start_us, rm_air_time_us(hex_length), txpower, channel));
-    return rm_tick_flush(c, nullptr, dst, verdict, rssi, sinr, cap, count, interference, nullptr);
+    const bool draws_need_exchange = maybe_draws(c) && part_count(c) != c->n;
+    if (is_sinr(c) || draws_need_exchange) {
+        // the on-air list of earlier calls / the per-rank draw exchange: the general tick path
+        RM_TRY(rm_tick_begin(c, start_us, start_us));
+        RM_TRY(rm_enqueue_tx(c, src, start_us, rm_air_time_us(hex_length), txpower, channel));
+        return rm_tick_flush(c, nullptr, dst, verdict, rssi, sinr, cap, count, interference, nullptr);
+    }
+    // One packet, no state besides the generator: record in through the kernel arguments, links out
+    // through one host-mapped block, one synchronisation.
+    RM_HIP(hipSetDevice(c->device));
+    c->t_begin = c->t_end = start_us;
+    c->in_tick = false;
+    c->pending.clear();
+    c->onair.clear();
+    if (!c->h_transmit)
+        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_transmit), sizeof(rm::TransmitResult), hipHostMallocMapped));
+    const rm_tx_record rec = make_record(c, src, start_us, rm_air_time_us(hex_length), txpower, channel);
+    RM_HIP(c->d_tx.ensure(1));
+    RM_HIP(rm::launch_store_record(c->stream, rec, c->d_tx.p));
+    RM_TRY(run_tick(c, c->d_tx.p, 1, 0));
+    if (part_count(c) <= 0) { // no receivers in this partition
+        if (count) *count = 0;
+        if (interference) *interference = 0;
+        return RM_OK;
+    }
+    RM_HIP(rm::launch_pack_result(c->stream, c->last, c->h_transmit));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    const rm::TransmitResult &r = *c->h_transmit;
+    if (r.total > uint32_t(rm::kTransmitMax)) // more links than the block holds: the general copy-out
+        return copy_out(c, *c, nullptr, dst, verdict, rssi, sinr, cap, count, interference, nullptr);
+    if (count) *count = r.total;
+    if (interference) *interference = uint8_t(r.interference);
+    const uint32_t k = std::min(r.stored, cap);
+    if (k) {
+        if (dst) std::memcpy(dst, r.dst, k * sizeof(int32_t));
+        if (verdict) std::memcpy(verdict, r.verdict, k);
+        if (rssi) std::memcpy(rssi, r.rssi, k * sizeof(double));
+        if (sinr) std::memcpy(sinr, r.sinr, k * sizeof(double));
+    }
+    if (r.dropped) return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    if (r.total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
+    return RM_OK;
 }
 
 int rm_pack_tx_device_on(rm_context *c, void *hip_stream, const int32_t *dev_src, int32_t n, int64_t start_us,

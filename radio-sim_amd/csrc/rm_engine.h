@@ -159,6 +159,16 @@ struct TickDev {
     uint32_t *pkt_draw_cnt; // [n_new] receiver draws of this rank for the packet
 };
 
+// rm_transmit's result block in host-mapped (pinned) memory, written by k_pack_result
+constexpr int kTransmitMax = 2048;
+struct TransmitResult {
+    uint32_t stored, dropped, total, interference;
+    int32_t dst[kTransmitMax];
+    double rssi[kTransmitMax];
+    double sinr[kTransmitMax];
+    uint8_t verdict[kTransmitMax];
+};
+
 struct LaunchCfg {
     bool f64_filter;  // fp32 frame too coarse: filter in fp64, no bounding boxes
     bool stochastic;  // java.util.Random draws may be consumed
@@ -173,6 +183,8 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
                           int64_t air_us, rm_tx_record *out);
 hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
                                 const int64_t *start_us, int64_t air_us, rm_tx_record *out);
+hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst);
+hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped);
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);

@@ -2176,6 +2176,35 @@ __global__ void __launch_bounds__(256) k_apply_draws(TickDev t)
     }
 }
 
+// ============================================================================ per-packet call
+// rm_transmit (one RadioMedium.transmit): the packet's record travels in the kernel arguments, and
+// its heard links come back through ONE block of host-mapped memory (header + up to kTransmitMax
+// links), so that the call is a handful of launches and one stream synchronisation -- no staging
+// copies in either direction.
+
+__global__ void __launch_bounds__(64) k_store_record(rm_tx_record r, rm_tx_record *dst)
+{
+    if (threadIdx.x == 0) *dst = r;
+}
+
+__global__ void __launch_bounds__(256) k_pack_result(TickDev t, TransmitResult *out)
+{
+    const uint32_t total = t.out_count[2];
+    const uint32_t n = min(min(t.out_count[0], total), uint32_t(kTransmitMax));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out->stored = n;
+        out->dropped = t.out_count[1];
+        out->total = total;
+        out->interference = t.pkt_interference[0];
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        out->dst[i] = t.out_dst[i];
+        out->verdict[i] = t.out_verdict[i];
+        out->rssi[i] = t.out_rssi[i];
+        out->sinr[i] = t.out_sinr[i];
+    }
+}
+
 // ============================================================================ launchers
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -2402,6 +2431,18 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
     PackStarts st{};
     for (int b = 0; b < n_ticks; ++b) st.start_us[b] = start_us[b];
     hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), n_ticks), dim3(256), 0, s, nd, dev_src, n, st, air_us, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst)
+{
+    hipLaunchKernelGGL(k_store_record, dim3(1), dim3(64), 0, s, r, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped)
+{
+    hipLaunchKernelGGL(k_pack_result, dim3(4), dim3(256), 0, s, t, host_mapped);
     return hipGetLastError();
 }
 

@@ -90,3 +90,43 @@ def test_defaults_of_optional_arrays(engine, rsa, O):
     engine.set_n2n_matrix(np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]], dtype=float))   # int_id default = index + 1
     r = engine.transmit(2)
     assert list(r.dst) == [0, 1]
+
+
+def test_transmit_fast_path_and_its_fallbacks(engine, rsa, O):
+    """rm_transmit returns through one host-mapped block of 2048 links; more links than that, a
+    caller buffer smaller than the links, and per-packet overrides all keep the reference's answers."""
+    n = 3000
+    nd = random_nodes(O, n, 300.0, seed=8)
+    nd.rxprob[::5] = 0.5
+    # Null medium: every other node hears the packet (NullRadioMedium.java:47-77) -> 2999 links > 2048
+    configure_engine(engine, nd, "null", {})
+    got = engine.transmit(7, start_us=5, hex_length=20)
+    want = O.tick(oracle_model(O, "null", {}), nd, nd.packets([7], 5, 640))
+    assert got.count == want.count == n - 1
+    np.testing.assert_array_equal(got.dst, want.dst)
+    np.testing.assert_array_equal(got.verdict, want.verdict)
+    np.testing.assert_array_equal(got.rssi, want.rssi)
+    # UDGM with draws: the generator advances exactly as in the oracle, call after call
+    params = dict(udgm_success_ratio_rx=0.9)
+    configure_engine(engine, nd, "udgm", params)
+    engine.seed(3)
+    state = O.lib().orc_jrandom_seed(3)
+    mdl = oracle_model(O, "udgm", params)
+    for src, power, ch in ((11, None, None), (12, -7.5, None), (13, None, 26), (2999, -1.0, 26)):
+        got = engine.transmit(src, start_us=100, hex_length=254, txpower=power, channel=ch)
+        pk = nd.packets([src], 100, 8128)
+        if power is not None:
+            pk["txpower"] = power
+        if ch is not None:
+            pk["channel"] = ch
+        want = O.tick(mdl, nd, pk, rng_state=state)
+        state = want.rng_state
+        assert got.count == want.count > 0
+        np.testing.assert_array_equal(got.dst, want.dst)
+        np.testing.assert_array_equal(got.verdict, want.verdict)
+        np.testing.assert_array_equal(got.rssi, want.rssi)
+        assert bool(got.pkt_interference[0]) == bool(want.pkt_interference[0])
+        assert engine.rng_state == state
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.transmit(11, hex_length=254, cap=3)
+    assert e.value.code == -4
