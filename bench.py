@@ -76,6 +76,9 @@ def parse():
                          "for the media without an on-air list)")
     ap.add_argument("--batch", type=int, default=64,
                     help="ticks per launch sequence (rm_batch_run_sources_device, at most 128); 1 = one tick per sequence")
+    ap.add_argument("--as-rank", default="", metavar="R:W",
+                    help="one process, no collective: sweep the weak-scaling workload of W ranks against the receiver "
+                         "range of rank R only (what one GPU of a W-GPU run computes per tick)")
     ap.add_argument("--nodes", type=int, default=0, help="override the workload's node count (same density and Tx fraction)")
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
@@ -223,7 +226,11 @@ def main():
     idx, n, frac, model, desc = WORKLOADS[args.workload]
     if args.workload in EXTRA and world > 1:
         raise SystemExit("the SINR workloads run on one GPU in this round (sharded on-air list: host-record path only)")
-    if args.nodes > 0:
+    as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
+    if as_rank:
+        n = int(round(n * as_rank[1] ** 0.5))
+        desc += " -- compute of rank %d of %d (weak scaling: %d nodes), no collective" % (as_rank[0], as_rank[1], n)
+    elif args.nodes > 0:
         n = args.nodes
         desc += " -- node count overridden: %d" % n
     elif world > 1 and args.scaling == "weak":
@@ -254,6 +261,10 @@ def main():
     # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
     lo = (n * rank) // world
     hi = (n * (rank + 1)) // world
+    if as_rank:
+        lo, hi = (n * as_rank[0]) // as_rank[1], (n * (as_rank[0] + 1)) // as_rank[1]
+        for e in engines:
+            e.set_partition(lo, hi - lo)
 
     ticks = args.warmup + args.steps
     base_seed = 0xC0FFEE00 + idx
@@ -361,7 +372,7 @@ def main():
     else:
         heard_total = float(heard)
 
-    links_per_tick = t_per_tick * (n - 1)
+    links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * (hi - lo)
     value = links_per_tick * args.steps / elapsed
     if stateful:
         # every frame on the air is swept against every receiver each tick

@@ -1522,7 +1522,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
     const uint32_t n_own = min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
     constexpr bool kRegScan = (SEG == 3 || SEG == 4);
     SmallCounts<scan_per(SEG)> pre{};
-    if (kRegScan && (PACKED || blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
+    if (kRegScan && !PACKED && (blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
     const int lane = threadIdx.x & 63;
@@ -1544,6 +1544,10 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
         n_chunks = uniform_u(s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
         if (threadIdx.x == 0) s_cs[PACKED ? kShards : 0] = n_chunks;
         __syncthreads();
+        // a workgroup without a chunk leaves before touching the per-frame counts (a receiver
+        // partition has few candidates per tick: most of the grid); the publisher stays for seg_off
+        if (blockIdx.x >= n_chunks && !publisher) return;
+        if (kRegScan) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
     }
     auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) {
         const uint32_t i = it + threadIdx.x;
@@ -2515,7 +2519,10 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
         }
 #undef RM_EXB
     } else {
-        const dim3 grid(max(1, min(2048, (max_new + 3) / 4)), 1, n), block(256);
+        // one frame per wave; a receiver partition hears 1/share of a frame's links, so its waves take
+        // several frames each (every workgroup redoes the scan of the per-frame counts first)
+        const int fpw = max(1, min(8, nd.n_rx > 0 ? nd.n / nd.n_rx : 1));
+        const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
         if (cfg.stochastic) {
             if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
             else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
