@@ -223,3 +223,50 @@ def test_sharded_batch_equals_global(rsa, O, world):
     finally:
         for eng in engines:
             eng.close()
+
+
+def test_batch_capacity_handling_and_unsorted_media(engine, rsa, O):
+    """A link capacity too small for one tick of the batch is reported for that tick only; raising
+    the capacity re-allocates the slots; media without geometry (N2N: unsorted table, no batched
+    kernels) go through the same API."""
+    n = 4000
+    nd = _layout(O, n, seed=13)
+    configure_engine(engine, nd, "udgm", {})
+    mdl = oracle_model(O, "udgm", {})
+    srcs = [np.arange(0, 40, dtype=np.int32), np.arange(0, n, 2, dtype=np.int32), np.arange(100, 140, dtype=np.int32)]
+    dev = [DeviceArray(s) for s in srcs]
+    tb = [0, 1000, 2000]
+    args = (tb, [1000, 2000, 3000], [d.ptr.value for d in dev], [len(s) for s in srcs], tb, [AIR] * 3)
+    engine.set_link_capacity(1 << 14)            # tick 1 (2000 frames x ~20 links) does not fit, ticks 0 and 2 do
+    engine.batch_run_sources_device(*args)
+    for b in (0, 2):
+        assert_same(engine.batch_result_copy(b, len(srcs[b])), O.tick(mdl, nd, nd.packets(srcs[b], tb[b], AIR)), "tick %d" % b)
+    assert engine.batch_result_count(1)[1] == 1                     # dropped flag
+    with pytest.raises(rsa.RadioMediumError) as e:
+        engine.batch_result_copy(1, len(srcs[1]))
+    assert e.value.code == -4
+    engine.set_link_capacity(1 << 18)
+    engine.batch_run_sources_device(*args)
+    for b in range(3):
+        assert_same(engine.batch_result_copy(b, len(srcs[b])), O.tick(mdl, nd, nd.packets(srcs[b], tb[b], AIR)), "tick %d" % b)
+    # N2N matrix medium over 300 nodes
+    m = 300
+    nd2 = random_nodes(O, m, 100.0, seed=2)
+    mat = np.random.default_rng(4).uniform(0.0, 1.0, (m, m))
+    mat[mat < 0.7] = 0.0
+    configure_engine(engine, nd2, "n2n", {}, matrix=mat)
+    engine.set_link_capacity(1 << 22)            # dense medium: a candidate shard must hold a whole (slab, tile) block
+    engine.seed(9)
+    state = O.lib().orc_jrandom_seed(9)
+    mdl2 = oracle_model(O, "n2n", {}, matrix=mat)
+    s2 = [np.arange(5 * b, 5 * b + 12, dtype=np.int32) for b in range(4)]
+    dev2 = [DeviceArray(s) for s in s2]
+    tb2 = [0, 1000, 2000, 3000]
+    engine.batch_run_sources_device(tb2, [t + 1000 for t in tb2], [d.ptr.value for d in dev2], [12] * 4, tb2, [AIR] * 4)
+    for b in range(4):
+        cpu = O.tick(mdl2, nd2, nd2.packets(s2[b], tb2[b], AIR), rng_state=state)
+        state = cpu.rng_state
+        assert_same(engine.batch_result_copy(b, 12), cpu, "n2n tick %d" % b)
+    assert engine.rng_state == state
+    for d in dev + dev2:
+        d.free()
