@@ -90,9 +90,8 @@ const char *model_name(int kind)
 struct TickSlot {
     DevBuf<rm_tx_record> d_tx;   // records uploaded by the host / built from source indices
     DevBuf<float4> d_p_txf;      // per-frame pre-filter records
-    DevBuf<int32_t> d_p_ch, d_p_src, d_near_list;
+    DevBuf<int32_t> d_p_ch, d_p_src;
     DevBuf<float> d_p_inv;
-    DevBuf<uint32_t> d_near_cnt, d_work;
 
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
     DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
@@ -222,8 +221,8 @@ struct rm_context : TickSlot {
 
 void TickSlot::release_all()
 {
-    d_tx.release(); d_p_txf.release(); d_p_ch.release(); d_p_src.release(); d_near_list.release(); d_p_inv.release();
-    d_near_cnt.release(); d_work.release(); d_cnt.release(); d_off.release(); d_slot_tot.release(); d_slot_off.release();
+    d_tx.release(); d_p_txf.release(); d_p_ch.release(); d_p_src.release(); d_p_inv.release();
+    d_cnt.release(); d_off.release(); d_slot_tot.release(); d_slot_off.release();
     d_counters.release(); d_shards.release(); d_cursor.release(); d_cand_tot.release(); d_seg_off.release(); d_a_e.release();
     d_st_pkt.release(); d_st_dst.release(); d_st_next.release(); d_head.release(); d_st_blk.release(); d_st_aux.release();
     d_st_lin.release(); d_st_sinr.release(); d_st_prob.release(); d_st_orig.release(); d_st_flags.release(); d_st_coll.release();
@@ -670,7 +669,6 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     ts.zero_len = std::max(ts.zero_len, std::max(t.n_cnt, 0));
     t.zero_len = ts.zero_len;
     t.a_e = ts.d_a_e.p;
-    t.n_wg = (rx_count + rm::kGroup * 16 - 1) / (rm::kGroup * 16);
     if (filter_mode != rm::kFilterGrid) { // per-frame pre-filter records
         RM_HIP(ts.d_p_txf.ensure(std::max(n_eval, 1)));
         RM_HIP(ts.d_p_ch.ensure(std::max(n_eval, 1)));
@@ -680,17 +678,6 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
         t.p_ch = ts.d_p_ch.p;
         t.p_src = ts.d_p_src.p;
         t.p_inv = ts.d_p_inv.p;
-    }
-    if (filter_mode == rm::kFilterList) { // large-grid path: near lists, work queue
-        if (size_t(t.n_wg) + 2 > ts.d_near_cnt.n) {
-            RM_HIP(ts.d_near_cnt.ensure(size_t(t.n_wg) + 2));
-            RM_HIP(hipMemsetAsync(ts.d_near_cnt.p, 0, ts.d_near_cnt.n * sizeof(uint32_t), c->stream));
-        }
-        RM_HIP(ts.d_near_list.ensure(size_t(t.n_wg) * rm::kNearCap));
-        RM_HIP(ts.d_work.ensure(size_t(t.n_wg) * (rm::kNearCap / 64)));
-        t.near_cnt = ts.d_near_cnt.p;
-        t.near_list = ts.d_near_list.p;
-        t.work = ts.d_work.p;
     }
     t.st_pkt = ts.d_st_pkt.p;
     t.st_dst = ts.d_st_dst.p;

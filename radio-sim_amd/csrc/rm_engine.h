@@ -16,8 +16,7 @@ constexpr int kGroup = 64;          // receivers per bounding-box group (one per
 constexpr int kShards = 256;        // append counters of the candidate list (one word sustains only ~88 atomics/us)
 constexpr int kShadowBins = 256;    // bins over rho = d^2 / cut^2 of the shadowing table
 constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
-constexpr int kNearCap = 4096;      // near frames one workgroup (1024 receivers) can list per tick (large-grid path)
-enum { kFilterGrid = 0, kFilterList = 1, kFilterWg = 2 }; // TickDev::filter_mode (plan_filter)
+enum { kFilterGrid = 0, kFilterWg = 2 }; // TickDev::filter_mode (plan_filter)
 constexpr int kShardStride = 32;
 constexpr int kMaxBatch = RM_MAX_BATCH; // ticks per batched launch (descriptors in device memory)    // u32 words between shard counters: one 128-byte line each
 
@@ -100,7 +99,7 @@ struct TickDev {
     int n_rx;               // receivers of the partition
     int rpt;                // receiver groups per wave in the filter kernel
     int n_slabs;            // ceil(n_rx / (64*rpt))
-    int filter_mode;        // kFilterGrid / kFilterList / kFilterWg
+    int filter_mode;        // kFilterGrid / kFilterWg
     // per (slot, slab) heard counts / offsets (off is relative to the frame's first link), layout [(chunk*n_slabs + slab)*64 + lane]
     uint32_t *cnt, *off;
     uint32_t *slot_tot;     // [n_cnt] heard links per frame slot
@@ -121,14 +120,10 @@ struct TickDev {
     uint32_t *cand_tot_next; // the other parity, zeroed by k_filter for the next tick
     uint32_t *seg_off;      // [n_cnt + 1] exclusive scan of cand_tot: the frame's segment in the A records
     int zero_len;           // slots of cursor / cand_tot_next that k_filter has to zero
-    // large-grid path: per-frame pre-filter records, per-workgroup lists of near frames, work queue
+    // two-level filter (k_tick_prep + k_filter_wg): per-frame pre-filter records
     float4 *p_txf;          // [n_eval]
     int32_t *p_ch, *p_src;  // [n_eval]
     float *p_inv;           // [n_eval]
-    uint32_t *near_cnt;     // [n_wg] (+ [n_wg]: n_work, [n_wg+1]: overflow flag)
-    int32_t *near_list;     // [n_wg * kNearCap] eval-relative frame indices
-    uint32_t *work;         // [n_wg * kNearCap / 64] items (workgroup << 6 | chunk of 64 near frames)
-    int n_wg;
     int32_t *a_e;           // [..] link-entry index of an A record (SINR results are looked up through it)
     int32_t *st_pkt;        // eval-relative frame index
     int32_t *st_dst;        // receiver engine position

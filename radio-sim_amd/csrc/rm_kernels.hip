@@ -753,239 +753,6 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
     }
 }
 
-// ============================================================================ large-grid path
-// Beyond a few thousand (workgroup, tile) pairs the 2-D grid of k_filter is mostly short-lived
-// workgroups that find nothing.  Then: k_near_pairs tests every frame against the box of every
-// filter workgroup (one wave per frame, one workgroup box per lane), appends the frame to the near
-// lists of the workgroups it can reach and opens a work item per started chunk of 64 near frames;
-// k_filter_list, a persistent grid, runs the same two-pass filter as k_filter over those items only.
-
-__global__ void __launch_bounds__(256) k_near_pairs(const NodesDev nd, const ModelDev m, const TickDev t)
-{
-    const int lane = threadIdx.x & 63;
-    const int n_eval = t.n_active - t.first_eval;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < 8) t.next_counters[threadIdx.x] = 0u;
-        t.next_shard_count[threadIdx.x * kShardStride] = 0u;
-    }
-    if (!t.use_matrix)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.zero_len; i += gridDim.x * blockDim.x) {
-            t.cursor[i] = 0u;
-            t.cand_tot_next[i] = 0u;
-        }
-    const int e = blockIdx.x * 4 + wave_index();
-    if (e >= n_eval) return;
-    const int abs_i = t.first_eval + e;
-    rm_tx_record tx;
-    if (t.src_list && abs_i >= t.first_new) {
-        tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
-        if (lane == 0) t.tx_build[abs_i] = tx;
-    } else {
-        tx = t.tx[abs_i];
-    }
-    float4 f;
-    double thr64;
-    tx_prefilter(m, tx, f, thr64);
-    if (lane == 0) {
-        float inv = 0.f;
-        if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) {
-            const double cut = sqrt(double(f.w));
-            if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
-        }
-        t.p_txf[e] = f;
-        t.p_ch[e] = tx.channel;
-        t.p_src[e] = tx.src;
-        t.p_inv[e] = inv;
-    }
-    for (int b0 = 0; b0 < t.n_wg; b0 += 64) {
-        const int b = b0 + lane;
-        if (b >= t.n_wg) continue;
-        const float4 q = nd.wg_box_xy[b];
-        const float2 qz = nd.wg_box_z[b];
-        const float dx = fmaxf(fmaxf(q.x - f.x, f.x - q.z), 0.f);
-        const float dy = fmaxf(fmaxf(q.y - f.y, f.y - q.w), 0.f);
-        const float dz = fmaxf(fmaxf(qz.x - f.z, f.z - qz.y), 0.f);
-        if (!(dist2_f32(dx, dy, dz) <= f.w)) continue;
-        const uint32_t pos = atomicAdd(&t.near_cnt[b], 1u);
-        if (pos >= uint32_t(kNearCap)) {
-            t.near_cnt[t.n_wg + 1] = 1u; // overflow: reported as a capacity error
-            continue;
-        }
-        t.near_list[size_t(b) * kNearCap + pos] = e;
-        if ((pos & 63u) == 0u) t.work[atomicAdd(&t.near_cnt[t.n_wg], 1u)] = (uint32_t(b) << 6) | (pos >> 6);
-    }
-}
-
-template <bool SHADOW>
-__global__ void __launch_bounds__(kBlock, 6) k_filter_list(const NodesDev nd, const ModelDev m, const TickDev t)
-{
-    constexpr int RPT = 4;
-    __shared__ float4 s_txf[kTxChunk];
-    __shared__ int s_ch[kTxChunk];
-    __shared__ int s_e[kTxChunk];
-    __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT];
-    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
-    __shared__ float s_inv[SHADOW ? kTxChunk : 1];
-    __shared__ int s_src[SHADOW ? kTxChunk : 1];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = wave_index();
-    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
-    const uint32_t n_work = uniform_u(t.near_cnt[t.n_wg]);
-
-    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) { // block-uniform; nothing is carried over
-        const uint32_t item = uniform_u(t.work[w]);
-        const int b = int(item >> 6), k = int(item & 63u);
-        const int cnt = uniform_i(int(min(t.near_cnt[b], uint32_t(kNearCap))));
-        const int nt = min(kTxChunk, cnt - k * kTxChunk);
-        const int slab = b * kWavesPerBlock + wave;
-        const int jbase = slab * (kGroup * RPT);
-        const bool live = slab < t.n_slabs;
-        if (w != blockIdx.x) __syncthreads(); // the previous item's LDS records are no longer read
-
-        float fx[RPT], fy[RPT], fz[RPT];
-        int fch[RPT], forig[RPT];
-        float4 bxy[RPT];
-        float2 bz[RPT];
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int j = jbase + r * kGroup + lane;
-            fx[r] = fy[r] = fz[r] = __builtin_nanf("");
-            fch[r] = 0;
-            forig[r] = 0;
-            if (live && j < t.n_rx) {
-                const float4 v = nd.rxf[j];
-                fx[r] = v.x;
-                fy[r] = v.y;
-                fz[r] = v.z;
-                fch[r] = __float_as_int(v.w);
-                if (SHADOW) forig[r] = nd.orig[j];
-            }
-            const int g = slab * RPT + r;
-            const bool ok = live && g * kGroup < t.n_rx;
-            bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-            bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
-        }
-        if (threadIdx.x < kTxChunk) {
-            float4 f = make_float4(0.f, 0.f, 0.f, -1.f);
-            int ch = 0, e = 0, src_id = -1;
-            float inv = 0.f;
-            if (int(threadIdx.x) < nt) {
-                e = t.near_list[size_t(b) * kNearCap + k * kTxChunk + threadIdx.x];
-                f = t.p_txf[e];
-                ch = t.p_ch[e];
-                if (SHADOW) {
-                    inv = t.p_inv[e];
-                    src_id = t.p_src[e];
-                }
-            }
-            s_txf[threadIdx.x] = f;
-            s_ch[threadIdx.x] = ch;
-            s_e[threadIdx.x] = e;
-            if (SHADOW) {
-                s_inv[threadIdx.x] = inv;
-                s_src[threadIdx.x] = src_id;
-            }
-        }
-        __syncthreads();
-        if (!live) continue;
-
-        uint64_t near[RPT];
-        uint64_t todo = 0;
-        {
-            const float4 tf = s_txf[lane];
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                near[r] = 0;
-                if ((slab * RPT + r) * kGroup < t.n_rx) {
-                    const float dx = fmaxf(fmaxf(bxy[r].x - tf.x, tf.x - bxy[r].z), 0.f);
-                    const float dy = fmaxf(fmaxf(bxy[r].y - tf.y, tf.y - bxy[r].w), 0.f);
-                    const float dz = fmaxf(fmaxf(bz[r].x - tf.z, tf.z - bz[r].y), 0.f);
-                    near[r] = ballot64(dist2_f32(dx, dy, dz) <= tf.w);
-                }
-                todo |= near[r];
-            }
-        }
-        uint32_t my_total = 0;
-        uint64_t walk = todo;
-        while (walk) {
-            const int ti = __ffsll((long long)walk) - 1;
-            walk &= walk - 1;
-            const float4 tf = s_txf[ti];
-            const int tch = s_ch[ti];
-            uint64_t mask[RPT];
-            uint32_t total = 0;
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                mask[r] = 0;
-                if ((near[r] >> ti) & 1ull) {
-                    const float s2 = dist2_f32(fx[r] - tf.x, fy[r] - tf.y, fz[r] - tf.z);
-                    bool hit = (s2 <= tf.w) && (fch[r] == tch);
-                    if (SHADOW && hit) {
-                        const int bin = min(kShadowBins - 1, int(s2 * s_inv[ti]));
-                        const uint32_t a = uint32_t(s_src[ti]), bb = uint32_t(forig[r]);
-                        const uint64_t key = (uint64_t(a < bb ? a : bb) << 32) | uint64_t(a < bb ? bb : a);
-                        hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
-                    }
-                    mask[r] = ballot64(hit);
-                    total += uint32_t(__popcll(mask[r]));
-                }
-            }
-            if (total) {
-                if (lane == ti) my_total = total;
-                if (lane < RPT) {
-                    uint64_t v = mask[0];
-#pragma unroll
-                    for (int r = 1; r < RPT; ++r) v = (lane == r) ? mask[r] : v;
-                    s_mask[wave][ti][lane] = v;
-                }
-            }
-        }
-        const uint64_t have = ballot64(my_total != 0u);
-        if (have == 0) continue;
-        const int my_e = s_e[lane];
-        if (!t.use_matrix && my_total != 0u && t.first_eval + my_e >= t.first_new)
-            atomicAdd(&t.cand_tot[my_e - t.cnt_base], my_total);
-        uint32_t inc = my_total;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
-        }
-        const uint32_t wave_total = __shfl(inc, 63);
-        const uint32_t shard = (uint32_t(b) * 4u + uint32_t(wave) + w * 37u) & t.shard_mask; // per wave: items are heavy
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base + wave_total > t.seg_cap) {
-            if (lane == 0) t.stage_count[1] = 1u;
-            continue;
-        }
-        const uint32_t my_base = shard * t.seg_cap + base + inc - my_total;
-        walk = have;
-        while (walk) {
-            const int ti = __ffsll((long long)walk) - 1;
-            walk &= walk - 1;
-            const uint32_t fbase = __shfl(my_base, ti);
-            const int e = s_e[ti];
-            uint32_t pre = 0;
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const uint64_t mk = s_mask[wave][ti][r];
-                if (mk == 0) continue;
-                if ((mk >> lane) & 1ull) {
-                    const uint32_t idx = fbase + pre + lane_prefix(mk);
-                    t.st_pkt[idx] = e;
-                    t.st_dst[idx] = jbase + r * kGroup + lane;
-                    t.st_blk[idx] = fbase;
-                }
-                pre += uint32_t(__popcll(mk));
-            }
-        }
-    }
-}
-
-
 // ============================================================================ two-level filter
 // k_tick_prep: one thread per swept frame -- builds the frame's on-air record (build mode) and its
 // pre-filter record once per tick, and zeroes the counters later kernels add to.
@@ -1777,7 +1544,7 @@ __global__ void __launch_bounds__(1024) k_slot_scan(TickDev t)
     if (threadIdx.x == 0) {
         t.slot_off[t.n_cnt] = carry;
         t.out_count[0] = carry < t.cap ? carry : t.cap;
-        t.out_count[1] = (carry > t.cap || t.stage_count[1] != 0u || (t.near_cnt && t.near_cnt[t.n_wg + 1] != 0u)) ? 1u : 0u;
+        t.out_count[1] = (carry > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
         t.out_count[2] = carry;
     }
 }
@@ -1929,20 +1696,15 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                                                        publisher ? &vmax : nullptr);
         if (publisher && threadIdx.x == 0) {
             t.out_count[0] = total < t.cap ? total : t.cap;
-            t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u || (t.near_cnt && t.near_cnt[t.n_wg + 1] != 0u)) ? 1u : 0u;
+            t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
             t.out_count[2] = total;
             t.out_count[3] = vmax;
         }
     } else if (publisher && threadIdx.x == 0) {
         const uint32_t total = t.slot_off[t.n_cnt];
         t.out_count[0] = total < t.cap ? total : t.cap;
-        t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u || (t.near_cnt && t.near_cnt[t.n_wg + 1] != 0u)) ? 1u : 0u;
+        t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
         t.out_count[2] = total;
-    }
-
-    if (publisher && t.near_cnt) { // large-grid path: the near counters of the next tick start at zero
-        __syncthreads();           // thread 0 has read the overflow flag above
-        for (int i = threadIdx.x; i < t.n_wg + 2; i += blockDim.x) t.near_cnt[i] = 0u;
     }
 
     for (int q = q0; q < n_new; q += gridDim.x * 4) { // wave-uniform
@@ -2232,7 +1994,6 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
 
 // Chooses the filter variant for this tick and fixes the receiver tiling (t.rpt, t.n_slabs):
 //  kFilterGrid: k_filter on a (slab, tile) grid -- the general variant (fp64 frame, unsorted tables);
-//  kFilterList: k_near_pairs + persistent k_filter_list (RM_FILTER=list);
 //  kFilterWg:   k_tick_prep + k_filter_wg, two-level cull inside one workgroup per 4*rpt groups.
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
 {
@@ -2245,10 +2006,11 @@ int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
     int mode = kFilterGrid;
     if (cfg.bbox && !cfg.f64_filter) {
         const long pairs = long((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8) * n_chunks;
-        if (t.rpt == 4 && pairs > 8192 && t.n_slabs >= 4 * 256) mode = kFilterList;
+        // beyond a few thousand (workgroup, tile) pairs the 2-D grid of k_filter is mostly short-lived
+        // workgroups that find nothing (1 M nodes, or thousands of frames on the air)
+        if (t.rpt == 4 && pairs > 8192 && t.n_slabs >= 4 * 256) mode = kFilterWg;
         if (const char *e = getenv("RM_FILTER")) {
             if (!strcmp(e, "grid")) mode = kFilterGrid;
-            else if (!strcmp(e, "list")) mode = (t.rpt == 4) ? kFilterList : kFilterGrid;
             else if (!strcmp(e, "wg")) mode = kFilterWg;
         }
         if (want_wg) mode = kFilterWg;
@@ -2283,13 +2045,6 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
             if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<1, true>), grid, block, 0, s, nd, m, t);
             else hipLaunchKernelGGL((k_filter_wg<1, false>), grid, block, 0, s, nd, m, t);
         }
-        return hipGetLastError();
-    }
-    if (t.filter_mode == kFilterList) {
-        // near_cnt is all zero here: zero-filled at allocation, re-zeroed by every tick's k_reorder
-        hipLaunchKernelGGL(k_near_pairs, dim3(cdiv(n_eval, 4)), dim3(256), 0, s, nd, m, t);
-        if (cfg.shadow) hipLaunchKernelGGL(k_filter_list<true>, dim3(1536), dim3(kBlock), 0, s, nd, m, t);
-        else hipLaunchKernelGGL(k_filter_list<false>, dim3(1536), dim3(kBlock), 0, s, nd, m, t);
         return hipGetLastError();
     }
     // XCD-aware launch: workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest),
