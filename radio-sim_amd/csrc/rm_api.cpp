@@ -184,6 +184,7 @@ struct rm_context : TickSlot {
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
     rm::TransmitResult *h_transmit = nullptr; // host-mapped result block of rm_transmit
+    uint32_t transmit_seq = 0;
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
     // larger batches upload them with one copy from pinned host memory (two staging buffers, each
     // guarded by an event: it is rewritten only after the copy that read it has completed)
@@ -1334,9 +1335,47 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
     c->in_tick = false;
     c->pending.clear();
     c->onair.clear();
-    if (!c->h_transmit)
+    if (!c->h_transmit) {
         RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_transmit), sizeof(rm::TransmitResult), hipHostMallocMapped));
+        std::memset(c->h_transmit, 0, sizeof(rm::TransmitResult));
+    }
     const rm_tx_record rec = make_record(c, src, start_us, rm_air_time_us(hex_length), txpower, channel);
+    // Geometric media on a sorted table: the whole packet in one launch of one workgroup.
+    RM_TRY(prepare_nodes(c));
+    {
+        const rm::ModelDev m = model_dev(c);
+        const bool f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
+        if (is_geometric(c) && c->rx_sorted && !f64_filter && c->n_rx > 0 && std::getenv("RM_NO_ONE_LAUNCH") == nullptr) {
+            if (!c->d_rng.p) RM_TRY(rm_seed(c, 0));
+            c->have_result = false; // the links go to the caller only
+            const uint32_t seq = ++c->transmit_seq;
+            RM_HIP(rm::launch_transmit_one(c->stream, nodes_dev(c), m, rec, c->d_rng.p, c->h_transmit, seq));
+            // The kernel publishes `seq` in the host-mapped block after everything else: polling it for
+            // the ~10 us the kernel takes beats the wake-up latency of a stream synchronisation; a stream
+            // synchronisation still bounds the wait.
+            {
+                volatile const uint32_t *flag = &c->h_transmit->seq;
+                bool seen = false;
+                for (int spin = 0; spin < 200000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+                if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+            }
+            const rm::TransmitResult &r1 = *c->h_transmit;
+            if (r1.total != rm::kTransmitFallback) {
+                if (count) *count = r1.total;
+                if (interference) *interference = uint8_t(r1.interference);
+                const uint32_t k1 = std::min(r1.stored, cap);
+                if (k1) {
+                    if (dst) std::memcpy(dst, r1.dst, k1 * sizeof(int32_t));
+                    if (verdict) std::memcpy(verdict, r1.verdict, k1);
+                    if (rssi) std::memcpy(rssi, r1.rssi, k1 * sizeof(double));
+                    if (sinr) std::memcpy(sinr, r1.sinr, k1 * sizeof(double));
+                }
+                if (r1.total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
+                return RM_OK;
+            }
+            // the kernel declined (unbounded range or more links than its LDS lists hold) and changed nothing
+        }
+    }
     RM_HIP(c->d_tx.ensure(1));
     RM_HIP(rm::launch_store_record(c->stream, rec, c->d_tx.p));
     RM_TRY(run_tick(c, c->d_tx.p, 1, 0));

@@ -158,6 +158,8 @@ struct TickDev {
 constexpr int kTransmitMax = 2048;
 struct TransmitResult {
     uint32_t stored, dropped, total, interference;
+    uint32_t seq;                 // k_transmit_one: the call's sequence number, written after everything else
+    uint32_t pad[3];
     int32_t dst[kTransmitMax];
     double rssi[kTransmitMax];
     double sinr[kTransmitMax];
@@ -180,6 +182,9 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
                                 const int64_t *start_us, int64_t air_us, rm_tx_record *out);
 hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst);
 hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped);
+hipError_t launch_transmit_one(hipStream_t s, const NodesDev &nd, const ModelDev &m, const rm_tx_record &tx,
+                               uint64_t *rng_state, TransmitResult *host_mapped, uint32_t seq);
+constexpr uint32_t kTransmitFallback = 0xFFFFFFFFu; // TransmitResult::total when k_transmit_one declined
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);
