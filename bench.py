@@ -1,29 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- Tx->Rx link evaluations per second of the MI355X radio-medium engine.
 
-On one GPU `--inflight` ticks (default 3) are in flight at once, each on its own engine context and
-stream: the benchmarked medium carries no state from tick to tick (no on-air list, no random draws
-with the reference's default probabilities), a tick of this size is a ~34 us chain of dependent
-kernel launches that leaves the device mostly idle, and independent ticks hide each other's
-latencies.  The strictly sequential rate (one tick at a time, what a closed-loop simulation sees)
-is measured in the same run and printed as "sequential_ticks".
-
 A "step" is one simulated tick: T = 1% of N nodes transmit a 127-byte frame; the engine
 evaluates all T x (N-1) links (log-distance path loss + log-normal shadowing, BASELINE.json
 configs[2]: 100k nodes, 1% concurrent Tx) and leaves the ordered heard-link records
-(receiver, rssi, verdict) in HBM.  Inputs (node state, the tick's source lists) are resident
-in HBM before the timed region starts.
+(receiver, rssi, verdict) in HBM, one result slot per tick.  Inputs (node state, every tick's
+source list) are resident in HBM before the timed region starts.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|udgm]
+The benchmarked medium carries no state from tick to tick (no on-air list, no random draws with
+the reference's default probabilities; RadioMedium.transmit treats every packet on its own), and a
+lone tick of this size is a ~30 us chain of three dependent launches on a mostly idle device.
+So `--batch` ticks (default 64) go through ONE launch sequence (rm_batch_run_sources_device), and
+`--inflight` contexts (default 2), each with its own stream, take the batches in turn.  The
+strictly sequential rate (one tick at a time, what a closed-loop simulation sees) is measured in
+the same run and printed as "sequential_ticks".
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|udgm|m1|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: receivers are range-partitioned over the ranks; every tick each rank packs the Tx records of
-the transmitters it owns and the ranks all-gather them over RCCL/xGMI (packing + all-gather of
-tick t+1 overlap the sweep of tick t on a second stream).  Default scaling is WEAK: the link
-evaluations per GPU and tick stay those of the 1-GPU config (T x N_loc = 1e8), i.e. the node
-count grows as 100k x sqrt(N) at constant density and Tx fraction -- one tick of the 100k-node
-config is ~34 us of dependent kernel launches on ONE GPU, so splitting it further (--scaling
-strong) only adds a collective to a latency floor.  Rank 0 prints ONE JSON line.
+N > 1: receivers are range-partitioned over the ranks; per batch each rank packs the Tx records of
+the transmitters it owns for all ticks of the batch, the ranks all-gather them over RCCL/xGMI (ONE
+collective per batch, on the context's own stream and process group; the other context's sweep runs
+under it) and every rank sweeps the gathered frames against its receivers.  Default scaling is
+WEAK: the link evaluations per GPU and tick stay those of the 1-GPU config (T x N_loc = 1e8), i.e.
+the node count grows as 100k x sqrt(N) at constant density and Tx fraction (`--scaling strong`
+splits the 100k nodes instead; `--as-rank R:W` runs one rank's share of a W-GPU run on one GPU,
+without the collective).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
