@@ -2461,9 +2461,9 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
         }
 #undef RM_EXB
     } else {
-        // one frame per wave; a receiver partition hears 1/share of a frame's links, so its waves take
-        // several frames each (every workgroup redoes the scan of the per-frame counts first)
-        const int fpw = max(1, min(8, nd.n_rx > 0 ? nd.n / nd.n_rx : 1));
+        // two frames per wave (every workgroup redoes the scan of the per-frame counts first: fewer, longer
+        // workgroups); a receiver partition hears 1/share of a frame's links, so its waves take more
+        const int fpw = max(2, min(8, nd.n_rx > 0 ? nd.n / nd.n_rx : 1));
         const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
         if (cfg.stochastic) {
             if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
