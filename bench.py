@@ -126,7 +126,7 @@ def cpu_baseline(wl, nodes, sources, cpu_ticks):
     return out, mt
 
 
-def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=192, warm=48):
+def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=384, warm=96):
     """The same medium at 1M nodes / 1000 frames per tick (38 MB of algorithmic traffic per tick): where
     the sweep stops being launch-latency-bound.  Same measurement rules as the main run."""
     idx, n, frac, model, desc = WORKLOADS["m1"]
