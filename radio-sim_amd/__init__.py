@@ -6,6 +6,7 @@ delivery-verdict pass, behind the reference's RadioMedium plug-in contract.
   engine.py  thin object wrapper over one rm_context
   host/radiomedium.hpp  C++ host-side mirror of the reference's RadioMedium / Simulator / Node API
   workload.py  synthetic inputs of SURVEY.md section 8d
+  trace.py   pcap (the reference's dialect) and compact replay traces; ticks of a trace as rm_tx_record arrays
   dist.py    receiver-sharded multi-GPU tick (torch.distributed all-gather of Tx records)
 
 There is no CPU fallback anywhere in this package.

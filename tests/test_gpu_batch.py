@@ -270,3 +270,36 @@ def test_batch_capacity_handling_and_unsorted_media(engine, rsa, O):
     assert engine.rng_state == state
     for d in dev + dev2:
         d.free()
+
+
+def test_trace_replay_through_a_batch(engine, rsa, O, tmp_path):
+    """A compact packet trace (radio_sim_amd.trace) cut into ticks and replayed
+    through rm_batch_run_device: every tick equals the oracle's answer for those packets, with the
+    trace's per-packet rf-power and start times."""
+    import os
+    from radio_sim_amd import trace as T
+    n = 4000
+    nd = _layout(O, n, seed=3)
+    rng = np.random.default_rng(2)
+    rows = np.zeros(900, dtype=T.TRACE_DTYPE)
+    rows["time_us"] = np.sort(rng.integers(0, 12000, 900))
+    rows["src"], rows["hex_length"] = rng.integers(0, n, 900), 2 * rng.integers(5, 127, 900)
+    rows["txpower"], rows["channel"] = rng.uniform(-5.0, 0.0, 900), 26
+    path = os.path.join(str(tmp_path), "replay.rmt")
+    T.write_trace(path, rows)
+    ticks = T.ticks_of(T.read_trace(path), 1000)
+    assert len(ticks) == 12
+    params = dict(ld_sigma_db=4.0, ld_seed=8)
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    recs = [T.records_of(part, nd) for _, part in ticks]
+    dev = [DeviceArray(r) for r in recs]
+    tb = [t0 for t0, _ in ticks]
+    engine.batch_run_device(tb, [t + 1000 for t in tb], [d.ptr.value for d in dev], [len(r) for r in recs])
+    for b, r in enumerate(recs):
+        pk = np.zeros(len(r), dtype=O.PACKET_DTYPE)
+        for f in ("src", "channel", "x", "y", "z", "txpower", "txprob", "start_us", "air_us"):
+            pk[f] = r[f]
+        assert_same(engine.batch_result_copy(b, len(r)), O.tick(mdl, nd, pk), "trace tick %d" % b)
+    for d in dev:
+        d.free()
