@@ -79,7 +79,7 @@ def ticks_of(rows, tick_us=1000):
 
 
 def records_of(rows, nodes):
-    """rm_tx_record array for trace rows; `nodes` has x, y, z, txprob arrays (oracle/workload NodeTable)."""
+    """rm_tx_record array for trace rows; `nodes` has x, y, z, txprob arrays (e.g. workload.NodeTable)."""
     r = np.zeros(len(rows), dtype=TX_RECORD_DTYPE)
     src = rows["src"]
     r["x"], r["y"], r["z"] = nodes.x[src], nodes.y[src], nodes.z[src]
