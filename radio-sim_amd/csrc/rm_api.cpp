@@ -2,7 +2,7 @@
 // device-resident node state, on-air list, the per-tick launch sequence.  Compiled by hipcc.
 //
 // There is deliberately no CPU fallback in this file: every evaluation goes through the gfx950
-// kernels of rm_kernels.hip, and rm_create fails when no HIP device can be used.
+// kernels of rm_filter / rm_exact / rm_reorder / rm_transmit .hip, and rm_create fails when no HIP device can be used.
 //
 // Reference paths: /root/reference/radio-medium/java/se/sics/emul8/radiomedium/.
 

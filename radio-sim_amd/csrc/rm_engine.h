@@ -1,5 +1,26 @@
 // rm_engine.h -- internal interface between the C-ABI host code (rm_api.cpp) and the
-// gfx950 kernels (rm_kernels.hip).  Not part of the public boundary (include/radiomedium_hip.h).
+// gfx950 kernels (rm_*.hip).  Not part of the public boundary (include/radiomedium_hip.h).
+//
+// The gfx950 (CDNA4, wave64) kernels of the radio-medium engine, in short:
+//
+// k_filter sweeps every (frame on the air) x (receiver of this rank's partition) link: one
+// receiver per lane (RPT groups of 64 per wave, resident in registers), transmitter tiles of 64
+// frames staged in LDS, a bounding-box test of the tile against each spatially sorted receiver
+// group (one frame per lane, one ballot), then a conservative fp32 (or fp64) geometric pre-filter
+// on the near frames whose ballots append candidate links to a compact list (one atomic per wave
+// step).  k_exact evaluates the candidates with full lanes: the reference's fp64 arithmetic in the
+// reference's operation order.  Everything after that is O(heard links): offsets from the
+// (frame, slab) cell counts, SINR over per-receiver lists, ordered scatter, per-packet reorder to
+// node-index order, Java-RNG draws.
+//
+// Build: hipcc --offload-arch=gfx950 -ffp-contract=off (no fast-math): the exact path relies
+// on every fp64 operation being one IEEE-754 rounding, as in Java.
+//
+// Reference paths: /root/reference/radio-medium/java/se/sics/emul8/radiomedium/.
+//
+// Files: rm_math.hpp (exact arithmetic: E-math, link hash, Q80, java.util.Random), rm_device.hpp
+// (shared device code: wave helpers, pre-filter records, eval_link, fused scans), rm_filter.hip,
+// rm_exact.hip, rm_reorder.hip, rm_transmit.hip (kernels + their launchers), rm_api.cpp (C ABI).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -174,7 +195,7 @@ struct LaunchCfg {
     bool shadow;      // second-level shadowing filter (table lookup on the link hash)
 };
 
-// kernels' host launchers (rm_kernels.hip)
+// kernels' host launchers (rm_filter.hip, rm_exact.hip, rm_reorder.hip, rm_transmit.hip)
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m);
 hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n, int64_t start_us,
                           int64_t air_us, rm_tx_record *out);
@@ -190,6 +211,12 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
 hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDev *dev_ticks);
+hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                               const TickDev *dev_ticks, const LaunchCfg &cfg);
+hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                              const TickDev *dev_ticks, const LaunchCfg &cfg);
+hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                                const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
@@ -205,7 +232,7 @@ hipError_t launch_draws_scan(hipStream_t s, const TickDev &t);
 hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
                               int rank);
 
-// host-side mirrors of device math used for constants (rm_kernels.hip, __host__ __device__)
+// host-side mirrors of device math used for constants (rm_math.hpp, exported by rm_transmit.hip)
 double host_det_pow10(double y);
 uint64_t host_mix64(uint64_t z);
 void host_lcg_jump_map(uint64_t steps, uint64_t *A, uint64_t *C);

@@ -1,0 +1,442 @@
+// rm_exact.hip -- exact evaluation of the candidates, SINR, and the ordered scatter of unsorted tables
+// (part of libradiomedium_hip.so; gfx950 only, -ffp-contract=off, no fast-math; overview at the top of rm_engine.h)
+#include "rm_device.hpp"
+
+namespace rm {
+
+// One lane per candidate link (full waves): the reference's fp64 arithmetic.
+// SEG 0: unsorted table, heard links are counted per (frame, slab) cell (ordered scatter later).
+// SEG 1/2: sorted table, heard links go straight into the frame's segment of the A records (any
+// order inside it); the segment offsets are the scan of the per-frame candidate counts, redone in
+// LDS by every workgroup (1; 3 / 4 = the same for at most kSmallScan / kMediumScan frames) or read from k_scan_counts' output (2).
+// PACKED: a 1-D grid whose workgroups walk the started 256-entry chunks of all shards (no workgroup
+// without entries); otherwise blockIdx.y is the shard and blockIdx.x strides over its entries.
+template <int MODEL, bool SINR, bool STOCH, int SEG, bool PACKED = false>
+RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
+{
+    __shared__ uint32_t s_seg[scan_lds(SEG)];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_cs[PACKED ? kShards + 1 : 1]; // exclusive scan of the shards' chunk counts
+    __shared__ uint32_t s_sn[PACKED ? kShards : 1];     // entries per shard
+    const bool publisher = (blockIdx.x == 0 && blockIdx.y == 0);
+    bool scanned = false; // the scan is only needed by the scatter: it runs after the first evaluation
+    const uint32_t n_own = min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
+    constexpr bool kRegScan = (SEG == 3 || SEG == 4);
+    SmallCounts<scan_per(SEG)> pre{};
+    if (kRegScan && !PACKED && (blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const int per_slab = kGroup * t.rpt;
+    const int lane = threadIdx.x & 63;
+    uint32_t n_chunks = 0;
+    if (PACKED) {
+        const uint32_t mine = (n_own + 255u) >> 8;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) s_wave[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine;
+        for (int w = 0; w < int(threadIdx.x >> 6); ++w) run += s_wave[w];
+        s_cs[threadIdx.x] = run;
+        s_sn[threadIdx.x] = n_own;
+        n_chunks = uniform_u(s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+        if (threadIdx.x == 0) s_cs[PACKED ? kShards : 0] = n_chunks;
+        __syncthreads();
+        // a workgroup without a chunk leaves before touching the per-frame counts (a receiver
+        // partition has few candidates per tick: most of the grid); the publisher stays for seg_off
+        if (blockIdx.x >= n_chunks && !publisher) return;
+        if (kRegScan) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
+    }
+    auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) {
+        const uint32_t i = it + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t idx = shard * t.seg_cap + i;
+        bool wanted = false;
+        int slot = -1, key = -1;
+        uint8_t fl = 0;
+        double rssi = 0.0, prob = 1.0;
+        int orig = 0;
+        if (valid) {
+            const int erel = t.st_pkt[idx];
+            const int pos = t.st_dst[idx];
+            const rm_tx_record tx = t.tx[t.first_eval + erel];
+            const bool is_new = (t.first_eval + erel) >= t.first_new;
+            const RxRecord rx_ = nd.rec[pos];
+            const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, rx_, is_new);
+            fl = ev.append ? ev.flags : uint8_t(0);
+            if (ev.append && MODEL != RM_MODEL_NULL && MODEL != RM_MODEL_UDGM_CONST && tx_success(m, tx) <= 0.0) fl |= kFlagTxDead;
+            t.st_flags[idx] = fl;
+            if (ev.append) {
+                orig = rx_.orig;
+                if (MODEL == RM_MODEL_LOGDIST) {
+                    rssi = ev.aux;
+                    prob = rx_.rxprob;
+                } else {
+                    rssi = tx.txpower; // reference media hand the packet's transmit power through
+                    prob = (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_N2N) ? ev.aux : 1.0;
+                }
+                if (SEG == 0 || SINR) { // the ordered scatter / the SINR pass read these from the entry
+                    t.st_orig[idx] = orig;
+                    t.st_aux[idx] = rssi;
+                    t.st_prob[idx] = prob;
+                }
+                if (SINR) {
+                    t.st_lin[idx] = ev.lin;
+                    t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
+                }
+                wanted = ev.wanted;
+            }
+            slot = erel - t.cnt_base;
+            key = (SEG == 0) ? int((size_t(slot >> 6) * t.n_slabs + pos / per_slab) * 64 + (slot & 63)) : slot;
+        }
+        if (SEG == 1 && !scanned) { // block-uniform
+            block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
+            scanned = true;
+        }
+        if (kRegScan && !scanned) {
+            small_scan(pre, t.n_cnt, s_seg, s_wave, publisher ? t.seg_off : nullptr, nullptr);
+            scanned = true;
+        }
+        // one atomic per run of same-frame (same-cell) entries
+        const RunInfo ri = run_prefix(key, wanted, lane);
+        if (SEG == 0) {
+            if (valid && lane == ri.start && ri.total) atomicAdd(&t.cnt[key], ri.total);
+        } else {
+            uint32_t base = 0;
+            if (valid && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total);
+            base = __shfl(base, ri.start);
+            if (wanted) {
+                const uint32_t o = ((SEG == 1 || kRegScan) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
+                t.a_dst[o] = orig;
+                t.a_rssi[o] = rssi;
+                if (SINR) t.a_e[o] = int(idx);
+                if (STOCH) {
+                    t.a_prob[o] = prob;
+                    t.a_verdict[o] = uint8_t(0); // pending: k_apply_draws decides
+                } else {
+                    t.a_verdict[o] = (fl & kFlagTxDead) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+                }
+            }
+        }
+    };
+    if (PACKED) {
+        for (uint32_t u = blockIdx.x; u < n_chunks; u += gridDim.x) { // block-uniform
+            uint32_t lo = 0, hi = kShards; // the shard whose chunk range holds u: s_cs[lo] <= u < s_cs[lo + 1]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (uniform_u(s_cs[mid]) <= u) lo = mid; else hi = mid;
+            }
+            entries(lo, (u - uniform_u(s_cs[lo])) << 8, uniform_u(s_sn[lo]));
+        }
+    } else {
+        for (uint32_t it = blockIdx.x * blockDim.x; it < n_own; it += stride) entries(blockIdx.y, it, n_own); // block-uniform trip count
+    }
+    if (SEG == 1 && !scanned && publisher) // seg_off is published even if this shard was empty
+        block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
+    if (kRegScan && !scanned && publisher) small_scan(pre, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
+}
+
+template <int MODEL, bool SINR, bool STOCH, int SEG>
+__global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    exact_body<MODEL, SINR, STOCH, SEG>(nd, m, t);
+}
+
+template <int MODEL, bool STOCH, int SCAN>
+__global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
+{
+    exact_body<MODEL, false, STOCH, SCAN, true>(nd, m, ticks[blockIdx.z]);
+}
+
+// half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
+__global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_eval = t.n_active - t.first_eval;
+    if (e >= n_eval) return;
+    const int src = t.tx[t.first_eval + e].src;
+    if (src < nd.rx_first || src >= nd.rx_first + nd.n_rx) return;
+    const int pos = nd.pos_of[src - nd.rx_first];
+    const uint32_t shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) & t.shard_mask;
+    const uint32_t local = atomicAdd(&t.shard_count[shard * kShardStride], 1u);
+    if (local >= t.seg_cap) {
+        t.stage_count[1] = 1u;
+        return;
+    }
+    const uint32_t idx = shard * t.seg_cap + local;
+    t.st_pkt[idx] = e;
+    t.st_dst[idx] = pos;
+    t.st_blk[idx] = idx;
+    t.st_flags[idx] = kFlagSelf;
+    t.st_aux[idx] = 0.0;
+    t.st_prob[idx] = 0.0;
+    t.st_orig[idx] = src;
+    t.st_lin[idx] = 0.0;
+    t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
+}
+
+// off[cell] = heard links of the same frame in lower slabs; slot_tot[slot] = heard links of the
+// frame.  One 1024-thread workgroup per tile of 64 frames: lane = frame, each wave owns a
+// contiguous range of slabs (coalesced 256-byte rows).
+__global__ void __launch_bounds__(1024) k_cell_off(TickDev t)
+{
+    __shared__ uint32_t s_part[16][64];
+    const int cc = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (t.n_slabs + 15) / 16;
+    const int s0 = min(t.n_slabs, wave * per), s1 = min(t.n_slabs, s0 + per);
+    const size_t row0 = size_t(cc) * t.n_slabs;
+    uint32_t sum = 0;
+    for (int s = s0; s < s1; ++s) sum += t.cnt[(row0 + s) * 64 + lane];
+    s_part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t x = s_part[w][lane];
+        if (w < wave) run += x;
+        total += x;
+    }
+    for (int s = s0; s < s1; ++s) {
+        const size_t c = (row0 + s) * 64 + lane;
+        t.off[c] = run;
+        run += t.cnt[c];
+    }
+    if (wave == 0) t.slot_tot[cc * 64 + lane] = total;
+}
+
+// slot_off = exclusive scan over frames of their heard-link totals; publishes the link count
+__global__ void __launch_bounds__(1024) k_slot_scan(TickDev t)
+{
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    uint32_t vmax = 0;
+    for (int base = 0; base < t.n_cnt; base += 1024) {
+        const int slot = base + threadIdx.x;
+        const uint32_t v = (slot < t.n_cnt) ? t.slot_tot[slot] : 0u;
+        vmax = max(vmax, v);
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (slot < t.n_cnt) t.slot_off[slot] = carry + ex;
+        carry += total;
+    }
+    for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), d)));
+    if ((threadIdx.x & 63) == 0 && vmax) atomicMax(&t.out_count[3], vmax);
+    if (threadIdx.x == 0) {
+        t.slot_off[t.n_cnt] = carry;
+        t.out_count[0] = carry < t.cap ? carry : t.cap;
+        t.out_count[1] = (carry > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+        t.out_count[2] = carry;
+    }
+}
+
+// ============================================================================ SINR (O(heard links))
+
+RM_D bool frames_overlap(const rm_tx_record &w, const rm_tx_record &k)
+{
+    return k.start_us < w.start_us + w.air_us && k.start_us + k.air_us > w.start_us;
+}
+
+// one thread per link entry that is a heard link of a new frame: walk the receiver's list,
+// sum the co-channel, time-overlapping interferers exactly (Q80), apply capture + half duplex
+__global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t)
+{
+    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t e = blockIdx.y * t.seg_cap + i;
+        if (!(t.st_flags[e] & kFlagHeardNew)) continue;
+        const int pos = t.st_dst[e];
+        const rm_tx_record w = t.tx[t.first_eval + t.st_pkt[e]];
+        U128 acc = {0, 0};
+        bool half_duplex = false;
+        for (int idx = t.head[pos]; idx >= 0; idx = t.st_next[idx]) {
+            if (uint32_t(idx) == e) continue;
+            const rm_tx_record k = t.tx[t.first_eval + t.st_pkt[idx]];
+            if (!frames_overlap(w, k)) continue;
+            const uint8_t fl = t.st_flags[idx];
+            if (fl & kFlagSelf) {
+                half_duplex = true;
+                continue;
+            }
+            if (!(fl & kFlagInterferer)) continue;
+            acc = u128_add(acc, q80_from_double(t.st_lin[idx]));
+        }
+        const double I = q80_to_double(acc);
+        const double denom = I + m.ld_noise_lin;
+        const double sinr = t.st_aux[e] - 10.0 * det_log10(denom);
+        t.st_sinr[e] = sinr;
+        t.st_coll[e] = (half_duplex || !(sinr >= m.ld_capture)) ? 1 : 0;
+    }
+}
+
+// ============================================================================ ordered scatter
+
+// frames beyond what the fused scans hold: seg_off / slot_off from a one-workgroup scan kernel
+__global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t *cnt, uint32_t *off, int n)
+{
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < n) ? cnt[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (i < n) off[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) off[n] = carry;
+}
+
+// Unsorted tables (Null / N2N media): link entry -> cell offset + rank inside the (frame, slab)
+// block -- directly the final (packet, node index) order; verdict for everything that needs no draw.
+template <bool STOCH>
+__global__ void __launch_bounds__(256) k_finalize(ModelDev m, TickDev t)
+{
+    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const int per_slab = kGroup * t.rpt;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t e = blockIdx.y * t.seg_cap + i;
+        const uint8_t fl = t.st_flags[e];
+        if (!(fl & kFlagHeardNew)) continue;
+        const int slot = t.st_pkt[e] - t.cnt_base;
+        const int slab = t.st_dst[e] / per_slab;
+        uint32_t rank = 0;
+        for (uint32_t k = t.st_blk[e]; k < e; ++k) rank += (t.st_flags[k] & kFlagHeardNew) ? 1u : 0u;
+        const uint32_t o = t.slot_off[slot] + t.off[(size_t(slot >> 6) * t.n_slabs + slab) * 64 + (slot & 63)] + rank;
+        if (o >= t.cap) continue;
+        t.out_pkt[o] = slot - t.shift;
+        t.out_dst[o] = t.st_orig[e];
+        t.out_rssi[o] = t.st_aux[e];
+        const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
+        t.out_sinr[o] = sinr ? t.st_sinr[e] : 0.0;
+        const bool collided = sinr && t.st_coll[e];
+        if (STOCH) {
+            t.out_prob[o] = t.st_prob[e];
+            t.out_verdict[o] = collided ? uint8_t(RM_INTERFERED) : uint8_t(0); // 0 = pending
+        } else {
+            t.out_verdict[o] = ((fl & kFlagTxDead) || collided) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+        }
+    }
+}
+
+// ============================================================================ launchers
+
+template <int MODEL, bool SINR>
+static void launch_exact_m(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
+{
+    const dim3 grid(4, kShards), block(256);
+    const int seg = t.use_matrix ? 0 : scan_variant(t.n_cnt);
+#define RM_EX(ST, SG) hipLaunchKernelGGL((k_exact<MODEL, SINR, ST, SG>), grid, block, 0, s, nd, m, t)
+    if (cfg.stochastic) {
+        if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else if (seg == 3) RM_EX(true, 3); else if (seg == 4) RM_EX(true, 4); else RM_EX(true, 2);
+    } else {
+        if (seg == 0) RM_EX(false, 0); else if (seg == 1) RM_EX(false, 1); else if (seg == 3) RM_EX(false, 3); else if (seg == 4) RM_EX(false, 4); else RM_EX(false, 2);
+    }
+#undef RM_EX
+}
+
+hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
+{
+    switch (m.kind) {
+    case RM_MODEL_NULL: launch_exact_m<RM_MODEL_NULL, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_UDGM: launch_exact_m<RM_MODEL_UDGM, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_UDGM_CONST: launch_exact_m<RM_MODEL_UDGM_CONST, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_N2N: launch_exact_m<RM_MODEL_N2N, false>(s, nd, m, t, cfg); break;
+    case RM_MODEL_LOGDIST:
+        if (m.flags & RM_LD_SINR) launch_exact_m<RM_MODEL_LOGDIST, true>(s, nd, m, t, cfg);
+        else launch_exact_m<RM_MODEL_LOGDIST, false>(s, nd, m, t, cfg);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// sorted tables with more frames than the fused scans hold: seg_off before k_exact
+hipError_t launch_seg_scan(hipStream_t s, const TickDev &t)
+{
+    if (!t.use_matrix && t.n_cnt > kFusedScanMax)
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cand_tot, t.seg_off, t.n_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t)
+{
+    const int n_eval = t.n_active - t.first_eval;
+    if (n_eval <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_self_entries, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, t);
+    return hipGetLastError();
+}
+
+// unsorted tables: cell offsets + frame scan; sorted tables with very many frames: slot_off
+hipError_t launch_offsets(hipStream_t s, const TickDev &t)
+{
+    if (t.use_matrix) {
+        if (t.n_cnt > 0 && t.n_slabs > 0) hipLaunchKernelGGL(k_cell_off, dim3(t.n_cnt / 64), dim3(1024), 0, s, t);
+        hipLaunchKernelGGL(k_slot_scan, dim3(1), dim3(1024), 0, s, t);
+    } else if (t.n_cnt > kFusedScanMax) {
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cursor, t.slot_off, t.n_cnt);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t)
+{
+    hipLaunchKernelGGL(k_sinr, dim3(4, kShards), dim3(256), 0, s, m, t);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_pkt_interference(ModelDev m, TickDev t)
+{
+    write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// unsorted tables only
+hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
+                           const LaunchCfg &cfg)
+{
+    (void)nd;
+    const dim3 grid(4, kShards), block(256);
+    if (cfg.stochastic) {
+        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, s, m, t);
+    } else {
+        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, s, m, t);
+        hipLaunchKernelGGL(k_pkt_interference, dim3(8), dim3(256), 0, s, m, t);
+    }
+    return hipGetLastError();
+}
+
+// rm_batch_*, stage 1
+hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n, const TickDev *b,
+                              const LaunchCfg &cfg)
+{
+    const int scan = batch_scan_variant(ticks, n);
+    const dim3 grid(kShards, 1, n), block(256); // packed: one started chunk of 256 entries per workgroup at the bench sizes
+#define RM_EXB(MODEL)                                                                                                \
+do {                                                                                                             \
+    if (cfg.stochastic) {                                                                                        \
+        if (scan == 3) hipLaunchKernelGGL((k_exact_batch<MODEL, true, 3>), grid, block, 0, s, nd, m, b);         \
+        else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<MODEL, true, 4>), grid, block, 0, s, nd, m, b);    \
+        else hipLaunchKernelGGL((k_exact_batch<MODEL, true, 1>), grid, block, 0, s, nd, m, b);                   \
+    } else {                                                                                                     \
+        if (scan == 3) hipLaunchKernelGGL((k_exact_batch<MODEL, false, 3>), grid, block, 0, s, nd, m, b);        \
+        else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<MODEL, false, 4>), grid, block, 0, s, nd, m, b);   \
+        else hipLaunchKernelGGL((k_exact_batch<MODEL, false, 1>), grid, block, 0, s, nd, m, b);                  \
+    }                                                                                                            \
+} while (0)
+    switch (m.kind) {
+    case RM_MODEL_NULL: RM_EXB(RM_MODEL_NULL); break;
+    case RM_MODEL_UDGM: RM_EXB(RM_MODEL_UDGM); break;
+    case RM_MODEL_UDGM_CONST: RM_EXB(RM_MODEL_UDGM_CONST); break;
+    case RM_MODEL_N2N: RM_EXB(RM_MODEL_N2N); break;
+    case RM_MODEL_LOGDIST: RM_EXB(RM_MODEL_LOGDIST); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef RM_EXB
+    return hipGetLastError();
+}
+
+} // namespace rm

@@ -1,0 +1,793 @@
+// rm_filter.hip -- receiver pre-filter records, Tx packing, the all-pairs filter (grid and two-level variants)
+// (part of libradiomedium_hip.so; gfx950 only, -ffp-contract=off, no fast-math; overview at the top of rm_engine.h)
+#include "rm_device.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace rm {
+
+// Pre-filter record per receiver: (fx, fy, fz, channel bits) in the fp32 frame; a disabled radio
+// gets a NaN position so that the geometric test can never pass (Transciever.isEnabled(),
+// UDGMRadioMedium.java:102).  One wave per group of 64 receivers; the group's bounding box is the
+// min/max of exactly these fp32 coordinates, so the box test is conservative w.r.t. the
+// per-receiver test by monotonicity of fp32 rounding.
+__global__ void __launch_bounds__(64) k_prep_rx(NodesDev nd, ModelDev m)
+{
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = g * kGroup + lane;
+    const bool geometric = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_UDGM_CONST || m.kind == RM_MODEL_LOGDIST);
+    const float nanf_ = __builtin_nanf("");
+    const float inf_ = __builtin_inff();
+    float4 r;
+    r.x = r.y = r.z = nanf_;
+    r.w = 0.f;
+    if (i < nd.n_rx) {
+        if (nd.enabled[i]) {
+            if (geometric) {
+                r.x = float(nd.x[i] - m.org_x);
+                r.y = float(nd.y[i] - m.org_y);
+                r.z = float(nd.z[i] - m.org_z);
+            } else {
+                r.x = r.y = r.z = 0.f;
+            }
+        }
+        r.w = __int_as_float(nd.channel[i]);
+        nd.rxf[i] = r;
+    }
+    const bool ok = (r.x == r.x);
+    const float lox = wave_min(ok ? r.x : inf_), hix = wave_max(ok ? r.x : -inf_);
+    const float loy = wave_min(ok ? r.y : inf_), hiy = wave_max(ok ? r.y : -inf_);
+    const float loz = wave_min(ok ? r.z : inf_), hiz = wave_max(ok ? r.z : -inf_);
+    if (lane == 0) {
+        nd.bbox_xy[g] = make_float4(lox, loy, hix, hiy);
+        nd.bbox_z[g] = make_float2(loz, hiz);
+    }
+}
+
+// union of the 16 group boxes of one filter workgroup (4 waves x 4 groups = 1024 receivers)
+__global__ void __launch_bounds__(256) k_wg_boxes(NodesDev nd, int n_wg)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_wg) return;
+    const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
+    const float inf_ = __builtin_inff();
+    float4 xy = make_float4(inf_, inf_, -inf_, -inf_);
+    float2 z = make_float2(inf_, -inf_);
+    for (int g = b * 16; g < min(n_groups, b * 16 + 16); ++g) {
+        const float4 q = nd.bbox_xy[g];
+        const float2 qz = nd.bbox_z[g];
+        xy.x = fminf(xy.x, q.x);
+        xy.y = fminf(xy.y, q.y);
+        xy.z = fmaxf(xy.z, q.z);
+        xy.w = fmaxf(xy.w, q.w);
+        z.x = fminf(z.x, qz.x);
+        z.y = fmaxf(z.y, qz.y);
+    }
+    nd.wg_box_xy[b] = xy;
+    nd.wg_box_z[b] = z;
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_us, rm_tx_record *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rm_tx_record r = make_tx_record(nd, src[i], start_us, air_us);
+    out[i] = r;
+}
+
+struct PackStarts {
+    int64_t start_us[kMaxBatch];
+};
+
+__global__ void __launch_bounds__(256)
+k_pack_tx_batch(NodesDev nd, const int32_t *src, int n, PackStarts st, int64_t air_us, rm_tx_record *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = size_t(blockIdx.y) * n + i;
+    const rm_tx_record r = make_tx_record(nd, src[o], st.start_us[blockIdx.y], air_us);
+    out[o] = r;
+}
+
+template <int RPT, bool F64, bool BBOX, bool SHADOW>
+__global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    __shared__ float4 s_txf[kTxChunk];
+    __shared__ int s_ch[kTxChunk];
+    __shared__ double s_td[F64 ? kTxChunk * 4 : 1];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT]; // candidate ballots of the near frames
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
+    __shared__ float s_inv[SHADOW ? kTxChunk : 1]; // bins / thr of the frame (0: table not usable for it)
+    __shared__ int s_src[SHADOW ? kTxChunk : 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    const int slab = blockIdx.x * kWavesPerBlock + wave;
+    const int chunk = blockIdx.y;
+    const int n_eval = t.n_active - t.first_eval;
+    const int e0 = chunk * kTxChunk; // eval-relative index of the tile's first frame
+    const int nt = min(kTxChunk, n_eval - e0);
+    const int jbase = slab * (kGroup * RPT);
+
+    // the next tick's counters (other parity) are zeroed here: nothing touches them during this tick
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x < 8) t.next_counters[threadIdx.x] = 0u;
+        t.next_shard_count[threadIdx.x * kShardStride] = 0u; // kBlock == kShards
+    }
+
+    // receivers of this lane (coalesced 16-byte loads), resident in registers for the whole tile;
+    // issued before the tile is staged so that both round trips overlap
+    float fx[RPT], fy[RPT], fz[RPT];
+    int fch[RPT];
+    int forig[RPT];
+    double gx[RPT], gy[RPT], gz[RPT];
+    float4 bxy[RPT];
+    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x]; // kBlock == kShadowBins
+    float2 bz[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int j = jbase + r * kGroup + lane;
+        fx[r] = fy[r] = fz[r] = __builtin_nanf("");
+        fch[r] = 0;
+        forig[r] = 0;
+        if (F64) gx[r] = gy[r] = gz[r] = u2f(0x7FF8000000000000ull);
+        if (j < t.n_rx) {
+            const float4 v = nd.rxf[j];
+            fx[r] = v.x;
+            fy[r] = v.y;
+            fz[r] = v.z;
+            fch[r] = __float_as_int(v.w);
+            if (SHADOW) forig[r] = nd.orig[j];
+            if (F64 && v.x == v.x) {
+                gx[r] = nd.x[j];
+                gy[r] = nd.y[j];
+                gz[r] = nd.z[j];
+            }
+        }
+        if (BBOX) {
+            const int g = slab * RPT + r;
+            const bool ok = g * kGroup < t.n_rx;
+            bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
+        }
+    }
+
+    // stage the transmitter tile in LDS: one frame per lane of wave 0, pre-filter record computed
+    // on the fly from the on-air record
+    if (threadIdx.x < kTxChunk) {
+        float4 f = make_float4(0.f, 0.f, 0.f, -1.f);
+        double thr64 = -1.0;
+        int ch = 0;
+        int src_id = -1;
+        double px = 0, py = 0, pz = 0;
+        if (int(threadIdx.x) < nt) {
+            rm_tx_record tx;
+            const int abs_i = t.first_eval + e0 + int(threadIdx.x);
+            if (t.src_list && abs_i >= t.first_new) { // build mode: a new frame's record comes from the source table
+                tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
+                if (blockIdx.x == 0) t.tx_build[abs_i] = tx;
+            } else { // a frame already on the air (or records given by the caller)
+                tx = t.tx[abs_i];
+            }
+            tx_prefilter(m, tx, f, thr64);
+            ch = tx.channel;
+            src_id = tx.src;
+            px = tx.x;
+            py = tx.y;
+            pz = tx.z;
+        }
+        s_txf[threadIdx.x] = f;
+        s_ch[threadIdx.x] = ch;
+        if (SHADOW) {
+            // the table is indexed by rho = s2 / thr; usable if the fp32 frame error is small against
+            // the distances where it decides anything (d > 0.15 cut), else bin 0 (always pass)
+            float inv = 0.f;
+            if (f.w > 0.f && f.w < __builtin_inff()) {
+                const double cut = sqrt(double(f.w));
+                if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
+            }
+            s_inv[threadIdx.x] = inv;
+            s_src[threadIdx.x] = src_id;
+        }
+        if (F64) {
+            s_td[threadIdx.x * 4 + 0] = px;
+            s_td[threadIdx.x * 4 + 1] = py;
+            s_td[threadIdx.x * 4 + 2] = pz;
+            s_td[threadIdx.x * 4 + 3] = thr64;
+        }
+    }
+    __syncthreads();
+    if (slab >= t.n_slabs) return;
+
+    // counters that later kernels of this tick (cursor) or the next tick's filter (candidate
+    // totals, other parity) add to start at zero
+    if (t.use_matrix) {
+        if (e0 >= t.cnt_base) t.cnt[(size_t((e0 - t.cnt_base) / kTxChunk) * t.n_slabs + slab) * 64 + lane] = 0u;
+    } else if (blockIdx.x == 0) {
+        for (int i = blockIdx.y * kBlock + threadIdx.x; i < t.zero_len; i += gridDim.y * kBlock) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
+        }
+    }
+
+    // which frames of the tile can reach which receiver group: one frame per lane against the
+    // group's bounding box, one ballot per group
+    uint64_t near[RPT];
+    uint64_t todo = 0;
+    if (BBOX) {
+        const float4 tf = s_txf[lane];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            near[r] = 0;
+            if ((slab * RPT + r) * kGroup < t.n_rx) {
+                const float dx = fmaxf(fmaxf(bxy[r].x - tf.x, tf.x - bxy[r].z), 0.f);
+                const float dy = fmaxf(fmaxf(bxy[r].y - tf.y, tf.y - bxy[r].w), 0.f);
+                const float dz = fmaxf(fmaxf(bz[r].x - tf.z, tf.z - bz[r].y), 0.f);
+                near[r] = ballot64(dist2_f32(dx, dy, dz) <= tf.w);
+            }
+            todo |= near[r];
+        }
+    } else {
+        todo = (nt >= 64) ? ~0ull : ((1ull << nt) - 1ull);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) near[r] = todo;
+    }
+
+    // pass 1: per near frame, the candidate ballots of the RPT groups; lane ti keeps frame ti's count
+    uint32_t my_total = 0;
+    uint64_t walk = todo;
+    while (walk) {
+        const int ti = __ffsll((long long)walk) - 1; // wave-uniform
+        walk &= walk - 1;
+        const float4 tf = s_txf[ti];
+        const int tch = s_ch[ti];
+        uint64_t mask[RPT];
+        uint32_t total = 0;
+        if (F64) {
+            const double px = s_td[ti * 4 + 0], py = s_td[ti * 4 + 1], pz = s_td[ti * 4 + 2], thr = s_td[ti * 4 + 3];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const double dx = px - gx[r], dy = py - gy[r], dz = pz - gz[r];
+                const double s2 = dx * dx + dy * dy + dz * dz;
+                mask[r] = ballot64((s2 <= thr) && (fch[r] == tch));
+                total += uint32_t(__popcll(mask[r]));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                mask[r] = 0;
+                if ((near[r] >> ti) & 1ull) { // wave-uniform
+                    const float s2 = dist2_f32(fx[r] - tf.x, fy[r] - tf.y, fz[r] - tf.z);
+                    bool hit = (s2 <= tf.w) && (fch[r] == tch);
+                    if (SHADOW && hit) {
+                        // second level: with this link's shadowing deviate, can it still reach the
+                        // level?  Conservative table of the largest hash that can, per bin of d^2/cut^2.
+                        const int bin = min(kShadowBins - 1, int(s2 * s_inv[ti]));
+                        const uint32_t a = uint32_t(s_src[ti]), b = uint32_t(forig[r]);
+                        const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
+                        hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                    }
+                    mask[r] = ballot64(hit);
+                    total += uint32_t(__popcll(mask[r]));
+                }
+            }
+        }
+        if (total) {
+            if (lane == ti) my_total = total;
+            if (lane < RPT) {
+                uint64_t v = mask[0];
+#pragma unroll
+                for (int r = 1; r < RPT; ++r) v = (lane == r) ? mask[r] : v;
+                s_mask[wave][ti][lane] = v;
+            }
+        }
+    }
+    const uint64_t have = ballot64(my_total != 0u);
+    if (have == 0) return; // the common case: far from every transmitter of the tile
+
+    // candidate links per frame (frames that get verdicts only): sizes the frame's segment
+    if (!t.use_matrix && my_total != 0u && t.first_eval + e0 + lane >= t.first_new)
+        atomicAdd(&t.cand_tot[e0 + lane - t.cnt_base], my_total);
+
+    // one atomic reserves the contiguous run of candidate entries of this (tile, slab); the frames'
+    // blocks follow each other inside it in frame order
+    uint32_t inc = my_total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    const uint32_t wave_total = __shfl(inc, 63);
+    const uint32_t shard = (blockIdx.x + blockIdx.y * gridDim.x) & t.shard_mask;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + wave_total > t.seg_cap) { // the shard is full: drop the run, flag the tick
+        if (lane == 0) t.stage_count[1] = 1u;
+        return;
+    }
+    const uint32_t my_base = shard * t.seg_cap + base + inc - my_total;
+
+    // pass 2: fill the blocks in receiver order
+    walk = have;
+    while (walk) {
+        const int ti = __ffsll((long long)walk) - 1;
+        walk &= walk - 1;
+        const uint32_t fbase = __shfl(my_base, ti);
+        uint32_t pre = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const uint64_t mk = s_mask[wave][ti][r];
+            if (mk == 0) continue;
+            if ((mk >> lane) & 1ull) {
+                const uint32_t idx = fbase + pre + lane_prefix(mk);
+                t.st_pkt[idx] = e0 + ti;
+                t.st_dst[idx] = jbase + r * kGroup + lane;
+                t.st_blk[idx] = fbase;
+            }
+            pre += uint32_t(__popcll(mk));
+        }
+    }
+}
+
+// ============================================================================ two-level filter
+// k_tick_prep: one thread per swept frame -- builds the frame's on-air record (build mode) and its
+// pre-filter record once per tick, and zeroes the counters later kernels add to.
+// k_filter_wg: one workgroup per 4*RPT receiver groups.  Phase A: every thread tests frames
+// against the union box of the workgroup's receivers and the near ones are compacted into LDS
+// (a few dozen of a thousand at the bench densities).  Phase B: each wave runs the two-pass
+// filter of k_filter over chunks of 64 near frames for its own RPT groups.
+
+constexpr int kNearLds = 512; // near-frame records held in LDS between two phase-B rounds
+
+RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
+{
+    const int n_eval = t.n_active - t.first_eval;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 8) t.next_counters[threadIdx.x] = 0u;
+        t.next_shard_count[threadIdx.x * kShardStride] = 0u; // kBlock == kShards
+    }
+    if (!t.use_matrix)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.zero_len; i += gridDim.x * blockDim.x) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
+        }
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_eval) return;
+    const int abs_i = t.first_eval + e;
+    rm_tx_record tx;
+    if (t.src_list && abs_i >= t.first_new) {
+        tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
+        t.tx_build[abs_i] = tx;
+    } else {
+        tx = t.tx[abs_i];
+    }
+    float4 f;
+    double thr64;
+    tx_prefilter(m, tx, f, thr64);
+    float inv = 0.f;
+    if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) {
+        const double cut = sqrt(double(f.w));
+        if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
+    }
+    t.p_txf[e] = f;
+    t.p_ch[e] = tx.channel;
+    t.p_src[e] = tx.src;
+    t.p_inv[e] = inv;
+}
+
+__global__ void __launch_bounds__(256) k_tick_prep(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    tick_prep_body(nd, m, t);
+}
+
+template <int RPT, bool SHADOW>
+RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
+{
+    __shared__ float4 s_txf[kNearLds];
+    __shared__ int s_ch[kNearLds];
+    __shared__ int s_e[kNearLds];
+    __shared__ float s_inv[SHADOW ? kNearLds : 1];
+    __shared__ int s_src[SHADOW ? kNearLds : 1];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT];
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
+    __shared__ uint32_t s_n;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    const int wg = blockIdx.x;
+    const int slab = wg * kWavesPerBlock + wave;
+    const int jbase = slab * (kGroup * RPT);
+    const bool live = slab < t.n_slabs;
+    const int n_eval = t.n_active - t.first_eval;
+    const int n_groups = (t.n_rx + kGroup - 1) / kGroup;
+
+    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
+    if (threadIdx.x == 0) s_n = 0u;
+
+    // phase A works on kUnrollA x 256 frames at a time: their records are requested together (one
+    // exposed round trip per 1024 frames), the first ones before anything else
+    constexpr int kUnrollA = 4;
+    float4 af[kUnrollA];
+    int ach[kUnrollA], asrc[kUnrollA];
+    float ainv[kUnrollA];
+    auto request = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < kUnrollA; ++u) {
+            const int e = g0 + u * kBlock + int(threadIdx.x);
+            af[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+            ach[u] = 0;
+            asrc[u] = -1;
+            ainv[u] = 0.f;
+            if (e < n_eval) {
+                af[u] = t.p_txf[e];
+                ach[u] = t.p_ch[e];
+                if (SHADOW) {
+                    ainv[u] = t.p_inv[e];
+                    asrc[u] = t.p_src[e];
+                }
+            }
+        }
+    };
+    request(0);
+
+    // this wave's receivers, resident in registers for the whole tick
+    float fx[RPT], fy[RPT], fz[RPT];
+    int fch[RPT], forig[RPT];
+    float4 bxy[RPT];
+    float2 bz[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int j = jbase + r * kGroup + lane;
+        fx[r] = fy[r] = fz[r] = __builtin_nanf("");
+        fch[r] = 0;
+        forig[r] = 0;
+        if (live && j < t.n_rx) {
+            const float4 v = nd.rxf[j];
+            fx[r] = v.x;
+            fy[r] = v.y;
+            fz[r] = v.z;
+            fch[r] = __float_as_int(v.w);
+            if (SHADOW) forig[r] = nd.orig[j];
+        }
+        const int g = slab * RPT + r;
+        const bool ok = live && g * kGroup < t.n_rx;
+        bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
+    }
+
+    // union box of the workgroup's 4*RPT groups
+    float4 wxy;
+    float2 wz;
+    if (RPT == 4) {
+        wxy = nd.wg_box_xy[wg];
+        wz = nd.wg_box_z[wg];
+    } else {
+        const float inf_ = __builtin_inff();
+        wxy = make_float4(inf_, inf_, -inf_, -inf_);
+        wz = make_float2(inf_, -inf_);
+        for (int g = wg * kWavesPerBlock * RPT; g < min(n_groups, (wg + 1) * kWavesPerBlock * RPT); ++g) { // uniform
+            const float4 q = nd.bbox_xy[g];
+            const float2 qz = nd.bbox_z[g];
+            wxy.x = fminf(wxy.x, q.x);
+            wxy.y = fminf(wxy.y, q.y);
+            wxy.z = fmaxf(wxy.z, q.z);
+            wxy.w = fmaxf(wxy.w, q.w);
+            wz.x = fminf(wz.x, qz.x);
+            wz.y = fmaxf(wz.y, qz.y);
+        }
+    }
+    __syncthreads();
+
+    uint32_t round = 0;
+    for (int g0 = 0; g0 < n_eval; g0 += kUnrollA * kBlock) { // block-uniform
+    if (g0) request(g0);
+#pragma unroll 1
+    for (int u = 0; u < kUnrollA; ++u) { // rolled: one copy of phase B; the records are selected, not indexed
+        const int f0 = g0 + u * kBlock;
+        if (f0 >= n_eval) break; // block-uniform
+        // phase A: this thread's frame against the workgroup box
+        const int e = f0 + int(threadIdx.x);
+        float4 tfa = af[0];
+        int cha = ach[0], srca = asrc[0];
+        float inva = ainv[0];
+#pragma unroll
+        for (int k = 1; k < kUnrollA; ++k) {
+            tfa.x = (u == k) ? af[k].x : tfa.x;
+            tfa.y = (u == k) ? af[k].y : tfa.y;
+            tfa.z = (u == k) ? af[k].z : tfa.z;
+            tfa.w = (u == k) ? af[k].w : tfa.w;
+            cha = (u == k) ? ach[k] : cha;
+            srca = (u == k) ? asrc[k] : srca;
+            inva = (u == k) ? ainv[k] : inva;
+        }
+        bool hit = false;
+        if (e < n_eval) {
+            const float dx = fmaxf(fmaxf(wxy.x - tfa.x, tfa.x - wxy.z), 0.f);
+            const float dy = fmaxf(fmaxf(wxy.y - tfa.y, tfa.y - wxy.w), 0.f);
+            const float dz = fmaxf(fmaxf(wz.x - tfa.z, tfa.z - wz.y), 0.f);
+            hit = dist2_f32(dx, dy, dz) <= tfa.w;
+        }
+        const uint64_t hm = ballot64(hit);
+        if (hm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, uint32_t(__popcll(hm)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const uint32_t k = base + lane_prefix(hm);
+                s_txf[k] = tfa;
+                s_ch[k] = cha;
+                s_e[k] = e;
+                if (SHADOW) {
+                    s_inv[k] = inva;
+                    s_src[k] = srca;
+                }
+            }
+        }
+        __syncthreads();
+        const int n_near = uniform_i(int(s_n));
+        const bool last = f0 + kBlock >= n_eval;
+        if (!last && n_near + kBlock <= kNearLds) continue; // room for another 256 frames
+
+        // phase B: chunks of 64 near frames, every wave for its own groups
+        if (live) {
+            for (int c0 = 0; c0 < n_near; c0 += kTxChunk) {
+                const int nt = min(kTxChunk, n_near - c0);
+                uint64_t near[RPT];
+                uint64_t todo = 0;
+                {
+                    const float4 tf = s_txf[c0 + min(lane, nt - 1)];
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        near[r] = 0;
+                        if ((slab * RPT + r) * kGroup < t.n_rx) {
+                            const float dx = fmaxf(fmaxf(bxy[r].x - tf.x, tf.x - bxy[r].z), 0.f);
+                            const float dy = fmaxf(fmaxf(bxy[r].y - tf.y, tf.y - bxy[r].w), 0.f);
+                            const float dz = fmaxf(fmaxf(bz[r].x - tf.z, tf.z - bz[r].y), 0.f);
+                            near[r] = ballot64(lane < nt && dist2_f32(dx, dy, dz) <= tf.w);
+                        }
+                        todo |= near[r];
+                    }
+                }
+                uint32_t my_total = 0;
+                uint64_t walk = todo;
+                while (walk) {
+                    const int ti = __ffsll((long long)walk) - 1; // wave-uniform
+                    walk &= walk - 1;
+                    const float4 tf = s_txf[c0 + ti];
+                    const int tch = s_ch[c0 + ti];
+                    uint64_t mask[RPT];
+                    uint32_t total = 0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        mask[r] = 0;
+                        if ((near[r] >> ti) & 1ull) {
+                            const float s2 = dist2_f32(fx[r] - tf.x, fy[r] - tf.y, fz[r] - tf.z);
+                            bool h = (s2 <= tf.w) && (fch[r] == tch);
+                            if (SHADOW && h) {
+                                const int bin = min(kShadowBins - 1, int(s2 * s_inv[c0 + ti]));
+                                const uint32_t a = uint32_t(s_src[c0 + ti]), bb = uint32_t(forig[r]);
+                                const uint64_t key = (uint64_t(a < bb ? a : bb) << 32) | uint64_t(a < bb ? bb : a);
+                                h = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                            }
+                            mask[r] = ballot64(h);
+                            total += uint32_t(__popcll(mask[r]));
+                        }
+                    }
+                    if (total) {
+                        if (lane == ti) my_total = total;
+                        if (lane < RPT) {
+                            uint64_t v = mask[0];
+#pragma unroll
+                            for (int r = 1; r < RPT; ++r) v = (lane == r) ? mask[r] : v;
+                            s_mask[wave][ti][lane] = v;
+                        }
+                    }
+                }
+                const uint64_t have = ballot64(my_total != 0u);
+                if (have == 0) continue;
+                const int my_e = s_e[c0 + min(lane, nt - 1)];
+                if (!t.use_matrix && my_total != 0u && t.first_eval + my_e >= t.first_new)
+                    atomicAdd(&t.cand_tot[my_e - t.cnt_base], my_total);
+                uint32_t inc = my_total;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d);
+                    if (lane >= d) inc += o;
+                }
+                const uint32_t wave_total = __shfl(inc, 63);
+                const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + blockIdx.z * 101u) & t.shard_mask;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + wave_total > t.seg_cap) { // the shard is full: drop the run, flag the tick
+                    if (lane == 0) t.stage_count[1] = 1u;
+                    continue;
+                }
+                const uint32_t my_base = shard * t.seg_cap + base + inc - my_total;
+                walk = have;
+                while (walk) {
+                    const int ti = __ffsll((long long)walk) - 1;
+                    walk &= walk - 1;
+                    const uint32_t fbase = __shfl(my_base, ti);
+                    const int e_ti = s_e[c0 + ti];
+                    uint32_t pre = 0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const uint64_t mk = s_mask[wave][ti][r];
+                        if (mk == 0) continue;
+                        if ((mk >> lane) & 1ull) {
+                            const uint32_t idx = fbase + pre + lane_prefix(mk);
+                            t.st_pkt[idx] = e_ti;
+                            t.st_dst[idx] = jbase + r * kGroup + lane;
+                            t.st_blk[idx] = fbase;
+                        }
+                        pre += uint32_t(__popcll(mk));
+                    }
+                }
+            }
+        }
+        round += uint32_t(kNearLds / kTxChunk);
+        if (!last) {
+            __syncthreads(); // every wave is done with the LDS records
+            if (threadIdx.x == 0) s_n = 0u;
+            __syncthreads();
+        }
+    }
+    }
+}
+
+template <int RPT, bool SHADOW>
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6)) k_filter_wg(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    filter_wg_body<RPT, SHADOW>(nd, m, t);
+}
+
+__global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
+{
+    tick_prep_body(nd, m, ticks[blockIdx.z]);
+}
+
+template <int RPT, bool SHADOW>
+__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6))
+k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
+{
+    filter_wg_body<RPT, SHADOW>(nd, m, ticks[blockIdx.z]);
+}
+
+// ============================================================================ launchers
+
+hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m)
+{
+    if (nd.n_rx <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_rx, dim3(cdiv(nd.n_rx, kGroup)), dim3(64), 0, s, nd, m);
+    const int n_wg = cdiv(nd.n_rx, kGroup * 16);
+    hipLaunchKernelGGL(k_wg_boxes, dim3(cdiv(n_wg, 256)), dim3(256), 0, s, nd, n_wg);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n, int64_t start_us,
+                          int64_t air_us, rm_tx_record *out)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_tx, dim3(cdiv(n, 256)), dim3(256), 0, s, nd, dev_src, n, start_us, air_us, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
+                                const int64_t *start_us, int64_t air_us, rm_tx_record *out)
+{
+    if (n <= 0 || n_ticks <= 0) return hipSuccess;
+    if (n_ticks > kMaxBatch) return hipErrorInvalidValue;
+    PackStarts st{};
+    for (int b = 0; b < n_ticks; ++b) st.start_us[b] = start_us[b];
+    hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), n_ticks), dim3(256), 0, s, nd, dev_src, n, st, air_us, out);
+    return hipGetLastError();
+}
+
+// Chooses the filter variant for this tick and fixes the receiver tiling (t.rpt, t.n_slabs):
+//  kFilterGrid: k_filter on a (slab, tile) grid -- the general variant (fp64 frame, unsorted tables);
+//  kFilterWg:   k_tick_prep + k_filter_wg, two-level cull inside one workgroup per 4*rpt groups.
+int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
+{
+    const int n_eval = t.n_active - t.first_eval;
+    const int n_chunks = cdiv(max(n_eval, 1), kTxChunk);
+    const long waves4 = long(cdiv(t.n_rx, 256)) * n_chunks;
+    // enough waves to fill 256 CUs x 4 SIMDs several times over, else one group per wave
+    t.rpt = (waves4 >= 4096) ? 4 : 1;
+    t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
+    int mode = kFilterGrid;
+    if (cfg.bbox && !cfg.f64_filter) {
+        const long pairs = long((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8) * n_chunks;
+        // beyond a few thousand (workgroup, tile) pairs the 2-D grid of k_filter is mostly short-lived
+        // workgroups that find nothing (1 M nodes, or thousands of frames on the air)
+        if (t.rpt == 4 && pairs > 8192 && t.n_slabs >= 4 * 256) mode = kFilterWg;
+        if (const char *e = getenv("RM_FILTER")) {
+            if (!strcmp(e, "grid")) mode = kFilterGrid;
+            else if (!strcmp(e, "wg")) mode = kFilterWg;
+        }
+        if (want_wg) mode = kFilterWg;
+        if (mode == kFilterWg) {
+            // batches bring their own parallelism (workgroups x ticks): the coarse tiling halves the frame x
+            // workgroup-box tests of phase A twice over; a lone tick needs the workgroups
+            int rpt = (t.n_rx > 400000 || (want_wg && t.n_rx >= 16384)) ? 4 : 1;
+            if (const char *e = getenv("RM_WG_RPT")) rpt = (atoi(e) == 4) ? 4 : (atoi(e) == 2 ? 2 : 1);
+            t.rpt = rpt;
+            t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
+        }
+    }
+    t.filter_mode = mode;
+    return mode;
+}
+
+hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
+                         const LaunchCfg &cfg)
+{
+    const int n_eval = t.n_active - t.first_eval;
+    if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
+    if (t.filter_mode == kFilterWg) {
+        hipLaunchKernelGGL(k_tick_prep, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, m, t);
+        const dim3 grid(cdiv(t.n_slabs, kWavesPerBlock)), block(kBlock);
+        if (t.rpt == 4) {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<4, true>), grid, block, 0, s, nd, m, t);
+            else hipLaunchKernelGGL((k_filter_wg<4, false>), grid, block, 0, s, nd, m, t);
+        } else if (t.rpt == 2) {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<2, true>), grid, block, 0, s, nd, m, t);
+            else hipLaunchKernelGGL((k_filter_wg<2, false>), grid, block, 0, s, nd, m, t);
+        } else {
+            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<1, true>), grid, block, 0, s, nd, m, t);
+            else hipLaunchKernelGGL((k_filter_wg<1, false>), grid, block, 0, s, nd, m, t);
+        }
+        return hipGetLastError();
+    }
+    // XCD-aware launch: workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest),
+    // so with gridDim.x a multiple of 8 every tile-workgroup of one receiver slab has the same
+    // blockIdx.x % 8 -- one XCD, one L2 -- and the slab's records leave HBM once per tick, not once
+    // per XCD (placement is a speed matter only; the padding workgroups exit at once)
+    const dim3 grid((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8, cdiv(n_eval, kTxChunk));
+    const dim3 block(kBlock);
+#define RM_LAUNCH(RPT, F64, BBOX, SH) hipLaunchKernelGGL((k_filter<RPT, F64, BBOX, SH>), grid, block, 0, s, nd, m, t)
+    if (t.rpt == 4) {
+        if (cfg.f64_filter) RM_LAUNCH(4, true, false, false);
+        else if (cfg.bbox && cfg.shadow) RM_LAUNCH(4, false, true, true);
+        else if (cfg.bbox) RM_LAUNCH(4, false, true, false);
+        else if (cfg.shadow) RM_LAUNCH(4, false, false, true);
+        else RM_LAUNCH(4, false, false, false);
+    } else {
+        if (cfg.f64_filter) RM_LAUNCH(1, true, false, false);
+        else if (cfg.bbox && cfg.shadow) RM_LAUNCH(1, false, true, true);
+        else if (cfg.bbox) RM_LAUNCH(1, false, true, false);
+        else if (cfg.shadow) RM_LAUNCH(1, false, false, true);
+        else RM_LAUNCH(1, false, false, false);
+    }
+#undef RM_LAUNCH
+    return hipGetLastError();
+}
+
+// rm_batch_*, stage 0: every tick's pre-pass and two-level filter (blockIdx.z = tick); `ticks` are the host
+// copies of the descriptors (grid sizes), `b` the same descriptors in device memory
+hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n, const TickDev *b,
+                               const LaunchCfg &cfg)
+{
+    int max_eval = 0;
+    for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
+    const TickDev &t0 = ticks[0];
+    hipLaunchKernelGGL(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
+    const dim3 grid(cdiv(t0.n_slabs, kWavesPerBlock), 1, n), block(kBlock);
+    if (t0.rpt == 4) {
+        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b);
+        else hipLaunchKernelGGL((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b);
+    } else if (t0.rpt == 2) {
+        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<2, true>), grid, block, 0, s, nd, m, b);
+        else hipLaunchKernelGGL((k_filter_wg_batch<2, false>), grid, block, 0, s, nd, m, b);
+    } else {
+        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b);
+        else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b);
+    }
+    return hipGetLastError();
+}
+
+} // namespace rm

@@ -1,0 +1,359 @@
+// rm_reorder.hip -- per-frame reorder to node-index order and the java.util.Random draw kernels
+// (part of libradiomedium_hip.so; gfx950 only, -ffp-contract=off, no fast-math; overview at the top of rm_engine.h)
+#include "rm_device.hpp"
+
+namespace rm {
+
+// Sorted tables: the heard links of a frame sit unordered in the frame's segment of the A
+// records.  One wave per frame ranks them by node index -- the order the reference's loop visits
+// receivers in (UDGMRadioMedium.java:99) -- and writes them to their final, compact place.
+// A segment of up to 64 links sits one per lane and is ranked with a readlane loop, longer ones by
+// counting through memory.  MODE 1: the scan of the per-frame heard counts is redone in every
+// workgroup (LDS); MODE 2: slot_off comes from k_scan_counts.
+template <bool STOCH, bool SINR, int MODE>
+RM_D void reorder_body(const ModelDev &m, const TickDev &t)
+{
+    __shared__ uint32_t s_off[scan_lds(MODE)];
+    __shared__ uint32_t s_wave[4];
+    const bool publisher = blockIdx.x == 0;
+    const int lane = threadIdx.x & 63;
+    const int n_new = t.n_active - t.first_new;
+    constexpr bool kRegScan = (MODE == 3 || MODE == 4);
+    SmallCounts<scan_per(MODE)> pre{};
+    if (kRegScan) pre = small_scan_load<scan_per(MODE)>(t.cursor, t.n_cnt);
+
+    // the first frame of this wave: its records are requested before the scan below, so that the
+    // scan's round trip and the records' overlap
+    const int q0 = blockIdx.x * 4 + wave_index();
+    uint32_t src0 = 0, len = 0;
+    int mine = 0x7fffffff, in_e = 0;
+    double in_rssi = 0.0, in_prob = 1.0;
+    uint8_t v = 0;
+    if (q0 < n_new) {
+        src0 = uniform_u(t.seg_off[q0 + t.shift]);
+        len = uniform_u(t.cursor[q0 + t.shift]);
+        if (uint32_t(lane) < len) {
+            const uint32_t o = src0 + lane;
+            mine = t.a_dst[o];
+            in_rssi = t.a_rssi[o];
+            v = t.a_verdict[o];
+            if (STOCH) in_prob = t.a_prob[o];
+            if (SINR) in_e = t.a_e[o];
+        }
+    }
+
+    if (MODE == 1 || kRegScan) {
+        uint32_t vmax = 0;
+        const uint32_t total = kRegScan
+                                   ? small_scan(pre, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr, publisher ? &vmax : nullptr)
+                                   : block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, publisher ? t.slot_off : nullptr,
+                                                       publisher ? &vmax : nullptr);
+        if (publisher && threadIdx.x == 0) {
+            t.out_count[0] = total < t.cap ? total : t.cap;
+            t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+            t.out_count[2] = total;
+            t.out_count[3] = vmax;
+        }
+    } else if (publisher && threadIdx.x == 0) {
+        const uint32_t total = t.slot_off[t.n_cnt];
+        t.out_count[0] = total < t.cap ? total : t.cap;
+        t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+        t.out_count[2] = total;
+    }
+
+    for (int q = q0; q < n_new; q += gridDim.x * 4) { // wave-uniform
+        const int slot = q + t.shift;
+        if (q != q0) {
+            src0 = uniform_u(t.seg_off[slot]);
+            len = uniform_u(t.cursor[slot]);
+        }
+        const uint32_t dst0 = uniform_u((MODE == 1 || kRegScan) ? s_off[slot] : t.slot_off[slot]);
+        for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+            const uint32_t o = src0 + c0 + lane;
+            const bool valid = c0 + lane < len;
+            if (q != q0 || c0 != 0) { // everything but the prefetched first chunk
+                mine = valid ? t.a_dst[o] : 0x7fffffff;
+                in_rssi = valid ? t.a_rssi[o] : 0.0;
+                v = valid ? t.a_verdict[o] : uint8_t(0);
+                in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
+                in_e = (SINR && valid) ? t.a_e[o] : 0;
+            }
+            uint32_t rank = 0;
+            if (len <= 64) {
+                for (uint32_t i = 0; i < len; ++i) rank += (__builtin_amdgcn_readlane(mine, int(i)) < mine) ? 1u : 0u;
+            } else if (valid) {
+                for (uint32_t k = 0; k < len; ++k) rank += (t.a_dst[src0 + k] < mine) ? 1u : 0u;
+            }
+            const uint32_t d = dst0 + rank;
+            if (valid && d < t.cap) {
+                t.out_pkt[d] = q;
+                t.out_dst[d] = mine;
+                t.out_rssi[d] = in_rssi;
+                uint8_t vv = v;
+                if (SINR) {
+                    t.out_sinr[d] = t.st_sinr[in_e];
+                    if (t.st_coll[in_e]) vv = RM_INTERFERED;
+                } else {
+                    t.out_sinr[d] = 0.0;
+                }
+                t.out_verdict[d] = vv;
+                if (STOCH) t.out_prob[d] = in_prob;
+            }
+        }
+    }
+    if (!STOCH) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+template <bool STOCH, bool SINR, int MODE>
+__global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
+{
+    reorder_body<STOCH, SINR, MODE>(m, t);
+}
+
+template <bool STOCH, int SCAN>
+__global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickDev *__restrict__ ticks)
+{
+    reorder_body<STOCH, false, SCAN>(m, ticks[blockIdx.z]);
+}
+
+// ============================================================================ Java-RNG draws
+
+constexpr int kScanTile = 2048; // 256 threads x 8
+
+RM_D uint32_t draw_flag(const TickDev &t, uint32_t pos)
+{
+    return (t.out_verdict[pos] == 0 && t.out_prob[pos] < 1.0) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_draw_tile_sums(TickDev t)
+{
+    __shared__ uint32_t s_part[4];
+    const uint32_t n = t.out_count[0];
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= n) return;
+    uint32_t v = 0;
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t pos = base + i * 256 + threadIdx.x;
+        if (pos < n) v += draw_flag(t, pos);
+    }
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) t.scan_block[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ void __launch_bounds__(1024) k_draw_tile_scan(TickDev t)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t n = t.out_count[0];
+    const int n_tiles = int((n + kScanTile - 1) / kScanTile);
+    uint32_t carry = 0;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < n_tiles) ? t.scan_block[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (i < n_tiles) t.scan_block[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) t.draw_scan[n] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_draw_scan(TickDev t)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n = t.out_count[0];
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= n) return;
+    // thread owns 8 consecutive positions
+    const uint32_t p0 = base + threadIdx.x * 8;
+    uint32_t f[8];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f[i] = (p0 + i < n) ? draw_flag(t, p0 + i) : 0u;
+        sum += f[i];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(sum, lane);
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t off = t.scan_block[blockIdx.x] + inc - sum;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (p0 + i < n) t.draw_scan[p0 + i] = off;
+        off += f[i];
+    }
+}
+
+// per-packet number of receiver draws this rank would consume (if the packet's Tx does not fail)
+__global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t)
+{
+    const int n_new = t.n_active - t.first_new;
+    const uint32_t n = t.out_count[0];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_new) return;
+    const uint32_t b = min(t.slot_off[q + t.shift], n);
+    const uint32_t e = min(t.slot_off[q + t.shift + 1], n);
+    t.pkt_draw_cnt[q] = t.draw_scan[e] - t.draw_scan[b];
+}
+
+// The only sequential part: the shared generator is consumed packet after packet
+// (Simulator.getRandom(); UDGMRadioMedium.java:85-92,106).  One workgroup: the per-packet jump
+// maps are built in parallel, then one lane walks the packets.  Receiver-sharded ranks all run
+// the same chain on the all-gathered per-(rank, packet) draw counts `all_cnt[world][n_new]`: a
+// packet's receivers are visited in node order = rank order, so this rank's first draw of packet q
+// comes after the draws of the lower ranks, and the generator moves on by the sum over all ranks.
+__global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const uint32_t *all_cnt, int world, int rank)
+{
+    __shared__ uint64_t s_A[1024], s_C[1024], s_Ab[1024], s_Cb[1024];
+    __shared__ double s_txs[1024];
+    __shared__ uint64_t s_state;
+    const int n_new = t.n_active - t.first_new;
+    if (threadIdx.x == 0) s_state = *t.rng_state & kLcgMask;
+    __syncthreads();
+    for (int base = 0; base < n_new; base += 1024) {
+        const int q = base + threadIdx.x;
+        if (q < n_new) {
+            uint64_t total = 0, before = 0;
+            if (all_cnt) {
+                for (int r = 0; r < world; ++r) {
+                    const uint32_t v = all_cnt[size_t(r) * n_new + q];
+                    if (r < rank) before += v;
+                    total += v;
+                }
+            } else {
+                total = t.pkt_draw_cnt[q];
+            }
+            uint64_t A, C;
+            lcg_jump_map(2ull * total, A, C);
+            s_A[threadIdx.x] = A;
+            s_C[threadIdx.x] = C;
+            lcg_jump_map(2ull * before, A, C);
+            s_Ab[threadIdx.x] = A;
+            s_Cb[threadIdx.x] = C;
+            s_txs[threadIdx.x] = tx_success(m, t.tx[t.first_new + q]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t s = s_state;
+            const int cnt = min(1024, n_new - base);
+            for (int i = 0; i < cnt; ++i) {
+                const double txs = s_txs[i];
+                bool interference = false;
+                if (txs <= 0.0) {
+                    interference = true;
+                } else if (txs < 1.0) {
+                    if (lcg_next_double(s) > txs) interference = true;
+                }
+                t.pkt_interference[base + i] = interference ? 1 : 0;
+                t.pkt_rng[base + i] = (s_Ab[i] * s + s_Cb[i]) & kLcgMask; // this rank's first receiver draw
+                if (!interference) s = (s_A[i] * s + s_C[i]) & kLcgMask;
+            }
+            s_state = s;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *t.rng_state = s_state;
+}
+
+__global__ void __launch_bounds__(256) k_apply_draws(TickDev t)
+{
+    const uint32_t n = t.out_count[0];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += stride) {
+        const int q = t.out_pkt[pos];
+        uint8_t v = t.out_verdict[pos];
+        if (t.pkt_interference[q]) {
+            v = RM_INTERFERED; // UDGMRadioMedium.java:106: no draw once the Tx failed
+        } else if (v == 0) {
+            const double p = t.out_prob[pos];
+            if (p < 1.0) {
+                const uint32_t first = min(t.slot_off[q + t.shift], n);
+                const uint32_t k = t.draw_scan[pos] - t.draw_scan[first];
+                uint64_t A, C;
+                lcg_jump_map(2ull * k, A, C);
+                uint64_t s = (A * t.pkt_rng[q] + C) & kLcgMask;
+                v = (lcg_next_double(s) > p) ? RM_INTERFERED : RM_DELIVERED;
+            } else {
+                v = RM_DELIVERED;
+            }
+        }
+        t.out_verdict[pos] = v;
+    }
+}
+
+// ============================================================================ launchers
+
+// sorted tables only
+hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
+{
+    const int n_new = t.n_active - t.first_new;
+    const dim3 grid(max(1, min(2048, (n_new + 3) / 4))), block(256);
+    const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
+    const int mode = scan_variant(t.n_cnt);
+#define RM_RE(ST, SI, MO) hipLaunchKernelGGL((k_reorder<ST, SI, MO>), grid, block, 0, s, m, t)
+    if (mode == 3) {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 3); else RM_RE(true, false, 3); }
+        else { if (sinr) RM_RE(false, true, 3); else RM_RE(false, false, 3); }
+    } else if (mode == 4) {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 4); else RM_RE(true, false, 4); }
+        else { if (sinr) RM_RE(false, true, 4); else RM_RE(false, false, 4); }
+    } else if (mode == 1) {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 1); else RM_RE(true, false, 1); }
+        else { if (sinr) RM_RE(false, true, 1); else RM_RE(false, false, 1); }
+    } else {
+        if (cfg.stochastic) { if (sinr) RM_RE(true, true, 2); else RM_RE(true, false, 2); }
+        else { if (sinr) RM_RE(false, true, 2); else RM_RE(false, false, 2); }
+    }
+#undef RM_RE
+    return hipGetLastError();
+}
+
+// rm_batch_*, stage 2
+hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n, const TickDev *b,
+                                const LaunchCfg &cfg)
+{
+    const int scan = batch_scan_variant(ticks, n);
+    int max_new = 0;
+    for (int i = 0; i < n; ++i) max_new = max(max_new, ticks[i].n_active - ticks[i].first_new);
+    // two frames per wave (every workgroup redoes the scan of the per-frame counts first: fewer, longer
+    // workgroups); a receiver partition hears 1/share of a frame's links, so its waves take more
+    const int fpw = max(2, min(8, nd.n_rx > 0 ? nd.n / nd.n_rx : 1));
+    const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
+    if (cfg.stochastic) {
+        if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
+        else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
+        else hipLaunchKernelGGL((k_reorder_batch<true, 1>), grid, block, 0, s, m, b);
+    } else {
+        if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<false, 3>), grid, block, 0, s, m, b);
+        else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<false, 4>), grid, block, 0, s, m, b);
+        else hipLaunchKernelGGL((k_reorder_batch<false, 1>), grid, block, 0, s, m, b);
+    }
+    return hipGetLastError();
+}
+
+// draws, part 1: which ordered records need a draw, and how many per packet
+hipError_t launch_draws_scan(hipStream_t s, const TickDev &t)
+{
+    const int tiles = cdiv(int(t.cap), kScanTile);
+    const int n_new = t.n_active - t.first_new;
+    hipLaunchKernelGGL(k_draw_tile_sums, dim3(tiles), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_draw_tile_scan, dim3(1), dim3(1024), 0, s, t);
+    hipLaunchKernelGGL(k_draw_scan, dim3(tiles), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_pkt_draw_counts, dim3(max(1, cdiv(n_new, 256))), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
+// draws, part 2: walk the generator over the packets, then every flagged record draws at its place
+hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
+                              int rank)
+{
+    hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, rank);
+    hipLaunchKernelGGL(k_apply_draws, dim3(1024), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
+
+} // namespace rm
