@@ -47,6 +47,8 @@ WORKLOADS = {
     "c2": (2, 10_000, 0.01, "logdist", "10k nodes, 1% concurrent-Tx, log-distance path loss"),
     "c3": (3, 100_000, 0.01, "logdist_shadow", "100k nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),
     "udgm": (3, 100_000, 0.01, "udgm", "100k nodes, 1% concurrent-Tx, reference UDGM (unit disc)"),
+    "udgm_lossy": (3, 100_000, 0.01, "udgm_lossy", "100k nodes, 1% concurrent-Tx, reference UDGM with successRatioRx = 0.9 "
+                                                   "(every heard link consumes a java.util.Random draw)"),
     "c3x6": (3, 100_000, 0.06, "logdist_shadow", "100k nodes, 6% concurrent-Tx (six ticks' worth of frames in one pass)"),
     "m1": (5, 1_000_000, 0.001, "logdist_shadow", "1M nodes, 0.1% concurrent-Tx, log-distance + log-normal shadowing"),
     "m1x": (5, 1_000_000, 0.01, "logdist_shadow", "1M nodes, 1% concurrent-Tx, log-distance + log-normal shadowing"),

@@ -207,8 +207,13 @@ __global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t)
 // comes after the draws of the lower ranks, and the generator moves on by the sum over all ranks.
 __global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const uint32_t *all_cnt, int world, int rank)
 {
-    __shared__ uint64_t s_A[1024], s_C[1024], s_Ab[1024], s_Cb[1024];
-    __shared__ double s_txs[1024];
+    // Per block of 1024 packets: (1) every thread builds its packet's jump maps, (2) ONE lane walks the
+    // generator over the packets -- the only sequential part of the engine: whether a packet's
+    // receivers draw at all depends on the value of its own Tx draw -- with the next packet's
+    // operands already in registers and nothing but LDS in the loop, (3) every thread publishes its
+    // packet's Tx-failure flag and the state its receivers' draws start from.
+    __shared__ uint64_t s_A[1024], s_C[1024], s_Ab[1024], s_Cb[1024], s_start[1024];
+    __shared__ double s_txs[1024]; // in: txSuccess; out of the walk: < 0 marks a failed Tx
     __shared__ uint64_t s_state;
     const int n_new = t.n_active - t.first_new;
     if (threadIdx.x == 0) s_state = *t.rng_state & kLcgMask;
@@ -239,19 +244,31 @@ __global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const
         if (threadIdx.x == 0) {
             uint64_t s = s_state;
             const int cnt = min(1024, n_new - base);
+            double txs = s_txs[0];
+            uint64_t A = s_A[0], C = s_C[0];
             for (int i = 0; i < cnt; ++i) {
-                const double txs = s_txs[i];
+                const int nx = min(i + 1, cnt - 1); // the next packet's operands are requested before this one's chain
+                const double txs_n = s_txs[nx];
+                const uint64_t A_n = s_A[nx], C_n = s_C[nx];
                 bool interference = false;
                 if (txs <= 0.0) {
                     interference = true;
                 } else if (txs < 1.0) {
                     if (lcg_next_double(s) > txs) interference = true;
                 }
-                t.pkt_interference[base + i] = interference ? 1 : 0;
-                t.pkt_rng[base + i] = (s_Ab[i] * s + s_Cb[i]) & kLcgMask; // this rank's first receiver draw
-                if (!interference) s = (s_A[i] * s + s_C[i]) & kLcgMask;
+                s_start[i] = s; // after the Tx draw: where the packet's receiver draws begin
+                s_txs[i] = interference ? -1.0 : 0.0;
+                if (!interference) s = (A * s + C) & kLcgMask;
+                txs = txs_n;
+                A = A_n;
+                C = C_n;
             }
             s_state = s;
+        }
+        __syncthreads();
+        if (q < n_new) {
+            t.pkt_interference[q] = (s_txs[threadIdx.x] < 0.0) ? 1 : 0;
+            t.pkt_rng[q] = (s_Ab[threadIdx.x] * s_start[threadIdx.x] + s_Cb[threadIdx.x]) & kLcgMask; // this rank's first receiver draw
         }
         __syncthreads();
     }

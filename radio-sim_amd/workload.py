@@ -106,6 +106,8 @@ def model_kwargs(name, seed=0xC0FFEE):
         return "udgm_const", {}
     if name == "udgm":
         return "udgm", {}
+    if name == "udgm_lossy":      # the reference's UDGM with successRatioRx < 1: every heard link draws
+        return "udgm", dict(udgm_success_ratio_rx=0.9)
     if name == "logdist":
         return "logdist", {}
     if name == "logdist_shadow":
