@@ -205,70 +205,175 @@ __global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t)
 // the same chain on the all-gathered per-(rank, packet) draw counts `all_cnt[world][n_new]`: a
 // packet's receivers are visited in node order = rank order, so this rank's first draw of packet q
 // comes after the draws of the lower ranks, and the generator moves on by the sum over all ranks.
+// The packet walk of java.util.Random.  A packet's step is
+//   sure success (txSuccess >= 1): s -> R(s),   R = the jump over its receivers' draws;
+//   sure failure (txSuccess <= 0): s -> s;
+//   a Tx draw (0 < txSuccess < 1): s1 = J(s) (one nextDouble = two LCG steps), and s -> R(s1) if the
+//   drawn value is <= txSuccess, else s -> s1 (UDGMRadioMedium.java:85-92, :106).
+// Only the last case depends on the state, and it fails rarely.  So the walk is speculated a wave at a
+// time: assuming every Tx draw succeeds, each packet is an affine map mod 2^48 and the state before
+// packet l of a chunk of 64 is P_l(v), P_l = the exclusive prefix composition (a wave scan, done
+// for all 16 chunks in parallel).  One wave then checks a chunk's 64 draws at once; at the first
+// packet f whose draw fails the packets before it are final, f itself becomes s -> J(s_f), and
+// the rest of the chunk is re-based without a new scan: v' = P_{f+1}^{-1}(J(s_f)).  The comparison
+// nextDouble() > txSuccess is done on integers: nextDouble = k * 2^-53 with k < 2^53, so it is
+// k > floor(txSuccess * 2^53) (the scaling by 2^53 is exact).
+struct Affine {
+    uint64_t a, c;
+};
+RM_D Affine affine_after(Affine later, Affine earlier) // later o earlier
+{
+    Affine r;
+    r.a = (later.a * earlier.a) & kLcgMask;
+    r.c = (later.a * earlier.c + later.c) & kLcgMask;
+    return r;
+}
+RM_D uint64_t inv_mod_2_48(uint64_t a) // a odd
+{
+    uint64_t x = a; // 3 correct bits
+    for (int i = 0; i < 4; ++i) x = x * (2ull - a * x); // 6, 12, 24, 48
+    return x & kLcgMask;
+}
+RM_D uint64_t shfl_u64(uint64_t v, int src)
+{
+    const uint32_t lo = uint32_t(__shfl(int(uint32_t(v)), src)), hi = uint32_t(__shfl(int(uint32_t(v >> 32)), src));
+    return (uint64_t(hi) << 32) | lo;
+}
+RM_D uint64_t shfl_up_u64(uint64_t v, int d)
+{
+    const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(v)), d)), hi = uint32_t(__shfl_up(int(uint32_t(v >> 32)), d));
+    return (uint64_t(hi) << 32) | lo;
+}
+RM_D uint64_t first_lane_u64(uint64_t v)
+{
+    return (uint64_t(uniform_u(uint32_t(v >> 32))) << 32) | uniform_u(uint32_t(v));
+}
+RM_D uint64_t read_lane_u64(uint64_t v, int src) // src wave-uniform
+{
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v)), src));
+    const uint32_t hi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v >> 32)), src));
+    return (uint64_t(hi) << 32) | lo;
+}
+
 __global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const uint32_t *all_cnt, int world, int rank)
 {
-    // Per block of 1024 packets: (1) every thread builds its packet's jump maps, (2) ONE lane walks the
-    // generator over the packets -- the only sequential part of the engine: whether a packet's
-    // receivers draw at all depends on the value of its own Tx draw -- with the next packet's
-    // operands already in registers and nothing but LDS in the loop, (3) every thread publishes its
-    // packet's Tx-failure flag and the state its receivers' draws start from.
-    __shared__ uint64_t s_A[1024], s_C[1024], s_Ab[1024], s_Cb[1024], s_start[1024];
-    __shared__ double s_txs[1024]; // in: txSuccess; out of the walk: < 0 marks a failed Tx
+    __shared__ uint64_t s_pa[1024], s_pc[1024];   // exclusive prefix map of the packet inside its chunk
+    __shared__ uint64_t s_pinv[1024];             // s_pa^-1 mod 2^48 (re-basing after a failed draw)
+    __shared__ uint64_t s_thr[1024];              // floor(txSuccess * 2^53) of a drawing packet
+    __shared__ uint64_t s_ab[1024], s_cb[1024];   // jump over the lower ranks' receiver draws
+    __shared__ uint64_t s_start[1024];            // state where the packet's receiver draws begin
+    __shared__ uint64_t s_ta[16], s_tc[16];       // a chunk's whole map
+    __shared__ uint8_t s_kind[1024], s_fail[1024];
     __shared__ uint64_t s_state;
+    enum { kSure = 0, kDraw = 1, kDead = 2 };
     const int n_new = t.n_active - t.first_new;
+    const int lane = threadIdx.x & 63, wave = wave_index();
+    Affine two; // one nextDouble
+    two.a = (kLcgA * kLcgA) & kLcgMask;
+    two.c = ((kLcgA + 1) * kLcgC) & kLcgMask;
     if (threadIdx.x == 0) s_state = *t.rng_state & kLcgMask;
     __syncthreads();
     for (int base = 0; base < n_new; base += 1024) {
+        // (1) every packet's maps, every chunk's prefix composition
         const int q = base + threadIdx.x;
+        Affine mq = {1ull, 0ull};
+        uint8_t kind = kSure;
+        uint64_t thr = 0;
+        Affine before = {1ull, 0ull};
         if (q < n_new) {
-            uint64_t total = 0, before = 0;
+            uint64_t total = 0, nb = 0;
             if (all_cnt) {
                 for (int r = 0; r < world; ++r) {
                     const uint32_t v = all_cnt[size_t(r) * n_new + q];
-                    if (r < rank) before += v;
+                    if (r < rank) nb += v;
                     total += v;
                 }
             } else {
                 total = t.pkt_draw_cnt[q];
             }
-            uint64_t A, C;
-            lcg_jump_map(2ull * total, A, C);
-            s_A[threadIdx.x] = A;
-            s_C[threadIdx.x] = C;
-            lcg_jump_map(2ull * before, A, C);
-            s_Ab[threadIdx.x] = A;
-            s_Cb[threadIdx.x] = C;
-            s_txs[threadIdx.x] = tx_success(m, t.tx[t.first_new + q]);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t s = s_state;
-            const int cnt = min(1024, n_new - base);
-            double txs = s_txs[0];
-            uint64_t A = s_A[0], C = s_C[0];
-            for (int i = 0; i < cnt; ++i) {
-                const int nx = min(i + 1, cnt - 1); // the next packet's operands are requested before this one's chain
-                const double txs_n = s_txs[nx];
-                const uint64_t A_n = s_A[nx], C_n = s_C[nx];
-                bool interference = false;
-                if (txs <= 0.0) {
-                    interference = true;
-                } else if (txs < 1.0) {
-                    if (lcg_next_double(s) > txs) interference = true;
-                }
-                s_start[i] = s; // after the Tx draw: where the packet's receiver draws begin
-                s_txs[i] = interference ? -1.0 : 0.0;
-                if (!interference) s = (A * s + C) & kLcgMask;
-                txs = txs_n;
-                A = A_n;
-                C = C_n;
+            Affine recv;
+            lcg_jump_map(2ull * total, recv.a, recv.c);
+            lcg_jump_map(2ull * nb, before.a, before.c);
+            const double txs = tx_success(m, t.tx[t.first_new + q]);
+            if (txs <= 0.0) {
+                kind = kDead;
+            } else if (txs < 1.0) {
+                kind = kDraw;
+                thr = uint64_t(txs * 0x1.0p53);
+                mq = affine_after(recv, two);
+            } else {
+                mq = recv;
             }
-            s_state = s;
+        }
+        Affine inc = mq; // inclusive prefix: packets 0..lane of the chunk, applied in packet order
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Affine prev;
+            prev.a = shfl_up_u64(inc.a, d);
+            prev.c = shfl_up_u64(inc.c, d);
+            if (lane >= d) inc = affine_after(inc, prev);
+        }
+        Affine exc; // exclusive
+        exc.a = shfl_up_u64(inc.a, 1);
+        exc.c = shfl_up_u64(inc.c, 1);
+        if (lane == 0) exc = {1ull, 0ull};
+        s_pa[threadIdx.x] = exc.a;
+        s_pc[threadIdx.x] = exc.c;
+        s_pinv[threadIdx.x] = inv_mod_2_48(exc.a);
+        s_thr[threadIdx.x] = thr;
+        s_ab[threadIdx.x] = before.a;
+        s_cb[threadIdx.x] = before.c;
+        s_kind[threadIdx.x] = kind;
+        if (lane == 63) {
+            s_ta[wave] = inc.a;
+            s_tc[wave] = inc.c;
         }
         __syncthreads();
+        // (2) one wave walks the chunks
+        if (wave == 0) {
+            uint64_t s0 = s_state; // the true state before the chunk's first packet
+            const int chunks = (min(1024, n_new - base) + 63) >> 6;
+            for (int c = 0; c < chunks; ++c) {
+                const int idx = c * 64 + lane;
+                const uint64_t pa = s_pa[idx], pc = s_pc[idx], pinv = s_pinv[idx], th = s_thr[idx];
+                const int kd = s_kind[idx];
+                uint64_t v = s0; // virtual start: the state before packet l is P_l(v) for the lanes >= lo
+                int lo = 0;
+                bool done = false;
+                while (!done) { // wave-uniform; at most 64 rounds
+                    const uint64_t sl = (pa * v + pc) & kLcgMask;
+                    const uint64_t s1 = (sl * kLcgA + kLcgC) & kLcgMask;
+                    const uint64_t s2 = (s1 * kLcgA + kLcgC) & kLcgMask;
+                    const uint64_t k = ((s1 >> 22) << 27) + (s2 >> 21);
+                    const bool fails = (lane >= lo) && (kd == kDraw) && (k > th);
+                    const uint64_t fm = ballot64(fails);
+                    const int f = fm ? (__ffsll((long long)fm) - 1) : 64; // wave-uniform
+                    if (lane >= lo && lane <= f) { // final now
+                        s_start[idx] = (kd == kDraw) ? s2 : sl;
+                        s_fail[idx] = (kd == kDead || lane == f) ? 1 : 0;
+                    }
+                    if (f >= 64) {
+                        s0 = (first_lane_u64(s_ta[c]) * v + first_lane_u64(s_tc[c])) & kLcgMask;
+                        done = true;
+                    } else {
+                        const uint64_t y = read_lane_u64(s2, f); // the failed packet consumed its Tx draw only
+                        if (f == 63) {
+                            s0 = y;
+                            done = true;
+                        } else { // re-base the rest of the chunk: P_{f+1}(v') = y
+                            v = (read_lane_u64(pinv, f + 1) * ((y - read_lane_u64(pc, f + 1)) & kLcgMask)) & kLcgMask;
+                            lo = f + 1;
+                        }
+                    }
+                }
+            }
+            if (lane == 0) s_state = s0;
+        }
+        __syncthreads();
+        // (3) every packet's Tx-failure flag and the state its receivers' draws start from on this rank
         if (q < n_new) {
-            t.pkt_interference[q] = (s_txs[threadIdx.x] < 0.0) ? 1 : 0;
-            t.pkt_rng[q] = (s_Ab[threadIdx.x] * s_start[threadIdx.x] + s_Cb[threadIdx.x]) & kLcgMask; // this rank's first receiver draw
+            t.pkt_interference[q] = s_fail[threadIdx.x];
+            t.pkt_rng[q] = (s_ab[threadIdx.x] * s_start[threadIdx.x] + s_cb[threadIdx.x]) & kLcgMask;
         }
         __syncthreads();
     }

@@ -218,3 +218,31 @@ def test_device_resident_paths(engine, rsa, O):
         assert engine.result_count() == (cpu.count, 0)
     src_dev.free()
     rec_dev.free()
+
+
+def test_generator_walk_over_thousands_of_packets(engine, rsa, O):
+    """k_rng_chain walks java.util.Random over the packets a wave at a time, speculating that Tx draws
+    succeed: 2500 frames in one tick (three blocks of 1024, chunks of 64) with every kind of packet --
+    Tx probability 0 (no draw, receivers skipped), fractional at several failure rates, 1 with
+    successRatioRx 1 elsewhere -- must leave every verdict and the generator state as the serial
+    Java loop does, tick after tick."""
+    n, t = 20000, 2500
+    rng = np.random.default_rng(77)
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=78)
+    nd.txprob[:] = rng.choice([0.0, 0.05, 0.3, 0.6, 0.97, 1.0], n, p=[0.05, 0.1, 0.2, 0.25, 0.3, 0.1])
+    nd.rxprob[:] = rng.choice([0.0, 0.5, 0.9, 1.0], n, p=[0.02, 0.3, 0.3, 0.38])
+    for ratio in (1.0, 0.85):
+        params = dict(udgm_success_ratio_rx=ratio)
+        configure_engine(engine, nd, "udgm", params)
+        mdl = oracle_model(O, "udgm", params)
+        engine.seed(2024)
+        state = O.lib().orc_jrandom_seed(2024)
+        for k in range(2):
+            srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+            pk = nd.packets(srcs, start_us=1000 * k, air_us=8128)
+            cpu = O.tick(mdl, nd, pk, rng_state=state)
+            state = cpu.rng_state
+            gpu = engine.tick(to_tx_records(rsa, pk))
+            assert_same(gpu, cpu, "ratio %.2f tick %d" % (ratio, k))
+            assert engine.rng_state == state
+            assert 0 < int(cpu.pkt_interference.sum()) < t
