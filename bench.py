@@ -75,11 +75,13 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="ticks in flight on one GPU (one engine context + stream each; ticks are independent "
-                         "for the media without an on-air list)")
-    ap.add_argument("--batch", type=int, default=64,
-                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 128); 1 = one tick per sequence")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="engine contexts per GPU, each with its own stream, taking the batches in turn (ticks are "
+                         "independent for the media without an on-air list); default 2, 3 with several GPUs")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 128); 1 = one tick per sequence; "
+                         "default 64, 128 with several GPUs (one all-gather per batch: fewer, larger collectives, and "
+                         "the stream hand-over around a collective is amortised over more ticks)")
     ap.add_argument("--as-rank", default="", metavar="R:W",
                     help="one process, no collective: sweep the weak-scaling workload of W ranks against the receiver "
                          "range of rank R only (what one GPU of a W-GPU run computes per tick)")
@@ -201,6 +203,10 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.inflight <= 0:
+        args.inflight = 2 if world == 1 else 3
+    if args.batch <= 0:
+        args.batch = 64 if world == 1 else 128
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
