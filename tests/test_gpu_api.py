@@ -161,17 +161,25 @@ def test_one_launch_transmit_against_the_oracle(engine, rsa, O, kind, params):
         np.testing.assert_array_equal(got.rssi, want.rssi)
         assert bool(got.pkt_interference[0]) == bool(want.pkt_interference[0])
     assert engine.rng_state == state
-    # a receiver partition hears its share of the same links (the draws need the per-rank exchange and
-    # go through the general path: only the heard sets are compared here)
+    # A receiver partition.  With probabilistic links the per-rank draw exchange is needed first, and the
+    # per-packet call says so; without them (probabilities 0 or 1 only) the partition hears exactly its
+    # share of the oracle's links, through the one-launch kernel.
     engine.set_partition(1000, 3000)
+    if kind != "udgm_const":                  # the constant-loss medium never draws (UDGMConstantLossRadioMedium.java:16-36)
+        with pytest.raises(rsa.RadioMediumError) as e:
+            engine.transmit(5, hex_length=100)
+        assert e.value.code == -5
+    nd.rxprob[:] = np.where(nd.rxprob < 1.0, 0.0, 1.0)
+    nd.txprob[:] = np.where(nd.txprob < 1.0, 0.0, 1.0)
+    plain = {k: v for k, v in params.items() if k != "udgm_success_ratio_rx"}
+    configure_engine(engine, nd, kind, plain)
+    engine.set_partition(1000, 3000)
+    mdl = oracle_model(O, kind, plain)
     for src in (5, 1500, 3999, 5999):
+        got = engine.transmit(src, hex_length=100)
         want = O.tick(mdl, nd, nd.packets([src], 0, 3200))
         keep = (want.dst >= 1000) & (want.dst < 4000)
-        if engine.draws_pending():
-            break
-        try:
-            got = engine.transmit(src, hex_length=100)
-        except rsa.RadioMediumError as e:       # partition + draws: rm_tick_finish_draws is needed first
-            assert e.code == -5
-            break
         np.testing.assert_array_equal(got.dst, want.dst[keep])
+        np.testing.assert_array_equal(got.verdict, want.verdict[keep])
+        np.testing.assert_array_equal(got.rssi, want.rssi[keep])
+        assert bool(got.pkt_interference[0]) == bool(want.pkt_interference[0])
