@@ -422,6 +422,7 @@ def main():
         pass_s = sum(per_stage_us.values()) * 1e-6
         achieved = b_tick / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
         traffic = None
+        valu = None
         pmc_note = "no PMC pass on file for this workload"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -430,6 +431,13 @@ def main():
             if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
                 traffic = ent["hbm_bytes_per_launch"]
                 pmc_note = ent["source"]
+                if "valu_issue_us_per_launch" in ent and kern_avg_s > 0:
+                    # SURVEY.md section 8(d) asks for the vector-ALU side next to the HBM side: issue time of the
+                    # stage's vector instructions on the whole chip (PMC, one context) over the stage's duration here
+                    valu = {"issue_us_per_launch": ent["valu_issue_us_per_launch"],
+                            "share_of_kernel_time": ent["valu_issue_us_per_launch"] / (kern_avg_s * 1e6),
+                            "instructions_per_launch": ent.get("valu_instructions_per_launch"),
+                            "source": "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU pass of tools/collect_profiles.sh (profiles/pmc_traffic.json)"}
         except (OSError, ValueError):
             pass
         out = {
@@ -454,7 +462,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
                          "algorithmic_bytes_per_launch": b_tick, "traffic_source": pmc_note,
-                         "stages_avg_us": per_stage_us, "event_bracket_us": bracket_us,
+                         "stages_avg_us": per_stage_us, "event_bracket_us": bracket_us, "valu": valu,
                          "whole_pass": {"gpu_us": pass_s * 1e6,
                                         "achieved": b_tick / pass_s / 1e9 if pass_s > 0 else 0.0,
                                         "frac": (b_tick / pass_s / 1e9 / HBM_PEAK_GBS) if pass_s > 0 else 0.0},

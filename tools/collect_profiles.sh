@@ -14,16 +14,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq -- python $
 echo "sequential stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 640 --warmup 128 > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 640 --warmup 128 > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 640 --warmup 128 > $O/pmc_sq.log 2>&1
 echo "pmc c3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m1_stats -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --batch 16 --steps 384 --warmup 96 > $O/m1_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/m1_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 192 --warmup 48 > $O/m1_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/m1_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 192 --warmup 48 > $O/m1_write.log 2>&1
 echo "m1 done"
 cd $R
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/r01_c3_pmc.csv $O/pmc_traffic.json
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/r01_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
 python tools/pmc_traffic.py $O/m1_fetch $O/m1_write m1 16 $O/r01_m1_pmc.csv $O/pmc_traffic.json
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/r01_c3_kernel_stats.csv
 cp $(find $O/stats_seq -name "*kernel_stats.csv" | head -1) $O/r01_c3_sequential_kernel_stats.csv
 cp $(find $O/m1_stats -name "*kernel_stats.csv" | head -1) $O/r01_m1_kernel_stats.csv
-rm -rf $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/m1_stats $O/m1_fetch $O/m1_write
+rm -rf $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/m1_stats $O/m1_fetch $O/m1_write
 echo "all done"

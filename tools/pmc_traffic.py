@@ -1,7 +1,11 @@
 """HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one counter group per
 pass -- TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ticks_per_launch> <out_csv> <out_json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ticks_per_launch> <out_csv> <out_json> [<sq_dir>]
+
+<sq_dir>: a third pass with --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY: the stages' vector
+issue time.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md), so
+issue time on the whole chip = 4 * count / 1024 SIMDs / 2.4 GHz (tools/clockprobe.hip: 2.4 GHz held).
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes
 (MI355X_MICROARCH.md section HBM), both counters are in KiB.  Kernels are grouped into the stages
@@ -35,7 +39,18 @@ def read(path, counter):
 
 def main():
     fetch_dir, write_dir, workload, tpl, out_csv, out_json = sys.argv[1:7]
+    sq_dir = sys.argv[7] if len(sys.argv) > 7 else None
     fetch, write = read(fetch_dir, "FETCH_SIZE"), read(write_dir, "WRITE_SIZE")
+    valu = read(sq_dir, "SQ_ACTIVE_INST_VALU") if sq_dir else {}
+    insts = read(sq_dir, "SQ_INSTS_VALU") if sq_dir else {}
+    valu_stage = collections.defaultdict(lambda: [0.0, 0.0])
+    for k in valu:
+        if len(valu[k]) > 8:
+            for prefix, stage in STAGE:
+                if k.startswith(prefix):
+                    valu_stage[stage][0] += sum(valu[k]) / len(valu[k])
+                    valu_stage[stage][1] += sum(insts.get(k, [0])) / max(1, len(insts.get(k, [0])))
+                    break
     rows, stages = [], collections.defaultdict(lambda: [0.0, 0.0])
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
@@ -65,6 +80,10 @@ def main():
     for stage, (f, w) in stages.items():
         out[workload][stage] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_size_kb_raw": round(f, 1),
                                 "write_size_kb": round(w, 1), "source": src}
+    for stage, (quad, n_inst) in valu_stage.items():
+        if stage in out[workload]:
+            out[workload][stage]["valu_issue_us_per_launch"] = round(4.0 * quad / 1024.0 / 2400.0, 2)
+            out[workload][stage]["valu_instructions_per_launch"] = int(n_inst)
     json.dump(out, open(out_json, "w"), indent=1)
     print(json.dumps(out[workload], indent=1))
 
