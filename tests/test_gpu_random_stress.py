@@ -82,3 +82,59 @@ def test_randomized_scenarios(engine, rsa, O, block):
         assert engine.rng_state == cpu.rng_state
         checked += cpu.count
     assert checked > 0
+
+
+@pytest.mark.parametrize("block", range(16))
+def test_randomized_scenarios_through_batches_and_single_packets(engine, rsa, O, block):
+    """The same awkward scenarios through the other two entry points: the tick's packets split over the
+    ticks of an rm_batch_run_device call (batched kernels where they apply, one launch sequence per
+    tick where they do not), and one rm_transmit per packet (k_transmit_one or its hand-over to the
+    general path).  Without the SINR extension every packet is evaluated on its own, so both must give
+    the oracle's per-packet answers and consume the generator exactly as the one-tick run does."""
+    from util import DeviceArray
+    rng = np.random.default_rng(5000 + block)
+    checked = 0
+    for it in range(10):
+        nd, kind, params, matrix, pk = _scenario(O, rng)
+        if params.get("ld_flags"):
+            continue
+        mdl = oracle_model(O, kind, params, matrix)
+        seed = int(rng.integers(0, 2 ** 31))
+        what = "block %d it %d %s %s n=%d t=%d" % (block, it, kind, params, nd.n, len(pk))
+        # -- a batch: the packets cut into up to 5 ticks (some possibly empty)
+        cuts = np.sort(rng.integers(0, len(pk) + 1, int(rng.integers(0, 5))))
+        parts = np.split(pk, cuts)
+        configure_engine(engine, nd, kind, params, matrix)
+        engine.seed(seed)
+        recs = [to_tx_records(rsa, p) for p in parts]
+        dev = [DeviceArray(r) if len(r) else DeviceArray(nbytes=64) for r in recs]
+        tb = [1000 * b for b in range(len(parts))]
+        engine.batch_run_device(tb, [t + 1000 for t in tb], [d.ptr.value for d in dev], [len(r) for r in recs])
+        state = O.lib().orc_jrandom_seed(seed)
+        for b, p in enumerate(parts):
+            cpu = O.tick(mdl, nd, p, rng_state=state)
+            state = cpu.rng_state
+            assert_same(engine.batch_result_copy(b, len(p)), cpu, what + " batch tick %d" % b)
+            checked += cpu.count
+        assert engine.rng_state == state
+        for d in dev:
+            d.free()
+        # -- one call per packet (the packet's own rf-power / channel as overrides)
+        engine.seed(seed)
+        state = O.lib().orc_jrandom_seed(seed)
+        for i in range(min(len(pk), 12)):
+            one = pk[i:i + 1]
+            hexlen = int(one["air_us"][0] // 32)
+            got = engine.transmit(int(one["src"][0]), start_us=int(one["start_us"][0]), hex_length=hexlen,
+                                  txpower=float(one["txpower"][0]), channel=int(one["channel"][0]))
+            one = one.copy()
+            one["air_us"] = hexlen * 32
+            cpu = O.tick(mdl, nd, one, rng_state=state)
+            state = cpu.rng_state
+            assert got.count == cpu.count, what + " packet %d" % i
+            np.testing.assert_array_equal(got.dst, cpu.dst, err_msg=what)
+            np.testing.assert_array_equal(got.verdict, cpu.verdict, err_msg=what)
+            np.testing.assert_array_equal(got.rssi, cpu.rssi, err_msg=what)
+            assert bool(got.pkt_interference[0]) == bool(cpu.pkt_interference[0]), what
+            assert engine.rng_state == state, what
+    assert checked > 0
