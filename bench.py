@@ -359,14 +359,25 @@ def main():
     fence()
     run_range(0, args.warmup)
     fence()
-    eng.profile_enable(args.profile_every if batch == 1 else max(1, args.profile_every // 4))
+    # HIP-event brackets on every n-th launch sequence of every context; few launches: all of them
+    launches = -(-args.steps // batch)
+    every = args.profile_every if batch == 1 else max(1, args.profile_every // 4)
+    if launches <= 4 * inflight:
+        every = 1
+    for e in engines:
+        e.profile_enable(every)
     t_start = time.perf_counter()
     links_done[0] = 0
     run_range(args.warmup, ticks)
     fence()
     elapsed = time.perf_counter() - t_start
-    n_samples, stage_ms = eng.profile_read()
-    eng.profile_enable(0)
+    n_samples, stage_ms = 0, {}
+    for e in engines:
+        ns, ms = e.profile_read()
+        e.profile_enable(0)
+        n_samples += ns
+        for k, v in ms.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
     heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
     if dropped:
         raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
@@ -411,7 +422,9 @@ def main():
         # largest share.  Algorithmic bytes per launch = N_loc*37 + T_act*56 + H_loc*25.
         n_loc = hi - lo
         h_loc = heard
-        b_tick = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * batch   # per launch: `batch` ticks
+        # per launch: the ticks it sweeps (`batch`, fewer when the K steps do not fill the launches)
+        ticks_per_launch = args.steps / launches if every == 1 else batch   # every launch sampled: their mean size
+        b_tick = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
         raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
         # an event pair with nothing between it measures the bracketing itself (a few us on this
         # runtime): subtracted from every stage so that the durations are the kernels'
