@@ -281,3 +281,52 @@ def test_large_grid_path_with_draws_and_partitions(rsa, O):
     finally:
         for e in engines:
             e.close()
+
+
+def test_c3_full_size_batch_of_64_ticks(rsa, O):
+    """The bench's launch shape: 64 ticks of 1000 frames over 100k nodes in one rm_batch_run_sources_device
+    call.  Four whole ticks are compared with the oracle bit for bit, the others through their link counts
+    against a second, one-tick-at-a-time run of the engine, and every tick's structure is checked
+    (packet-major, receivers ascending, offsets consistent)."""
+    from util import DeviceArray
+    params = {"ld_sigma_db": 4.0, "ld_seed": 0xC0FFEE}
+    nd, eng, W = _setup(rsa, O, 100_000, 3, "logdist", params)
+    try:
+        eng.set_link_capacity(1 << 20)
+        n_ticks = 64
+        srcs = [W.choose_sources(100_000, 1000, 0xC0FFEE03, 100 + k) for k in range(n_ticks)]
+        dev = [DeviceArray(s) for s in srcs]
+        t0 = np.arange(n_ticks, dtype=np.int64) * 1000
+        eng.batch_run_sources_device(t0, t0 + 1000, [d.ptr.value for d in dev], [1000] * n_ticks, t0, [W.AIR_US] * n_ticks)
+        counts = [eng.batch_result_count(b) for b in range(n_ticks)]
+        assert all(drop == 0 for _, drop in counts) and all(30_000 < c < 60_000 for c, _ in counts)
+        mdl = oracle_model(O, "logdist", params)
+        for b in (0, 21, 42, 63):
+            gpu = eng.batch_result_copy(b, 1000, cap=1 << 20)
+            cpu = O.tick(mdl, nd, nd.packets(srcs[b], int(t0[b]), W.AIR_US), cap=1 << 20)
+            assert gpu.count == cpu.count
+            np.testing.assert_array_equal(gpu.pkt, cpu.pkt)
+            np.testing.assert_array_equal(gpu.dst, cpu.dst)
+            np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+            np.testing.assert_array_equal(gpu.rssi, cpu.rssi)
+        for b in range(0, n_ticks, 5):
+            gpu = eng.batch_result_copy(b, 1000, cap=1 << 20)
+            assert np.all(np.diff(gpu.pkt) >= 0)
+            assert np.all(np.diff(gpu.dst)[np.diff(gpu.pkt) == 0] > 0)
+            assert gpu.pkt_offset[0] == 0 and gpu.pkt_offset[-1] == gpu.count
+            np.testing.assert_array_equal(np.diff(gpu.pkt_offset.astype(np.int64)), np.bincount(gpu.pkt, minlength=1000))
+        # the same ticks one at a time on a second context: identical link counts tick by tick
+        single = rsa.Engine(0)
+        try:
+            single.upload_table(nd)
+            single.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            single.set_link_capacity(1 << 20)
+            for b in range(n_ticks):
+                single.tick_run_sources_device(int(t0[b]), int(t0[b]) + 1000, dev[b].ptr.value, 1000, int(t0[b]), W.AIR_US)
+                assert single.result_count() == counts[b]
+        finally:
+            single.close()
+        for d in dev:
+            d.free()
+    finally:
+        eng.close()
