@@ -250,7 +250,8 @@ def main():
     t_per_tick = int(round(frac * n))
     extra = EXTRA.get(args.workload, {})
     tick_us = extra.get("tick_us", W.TICK_US)
-    stateful = model in ("logdist_sinr16", "logdist_sinr_overlap")   # on-air list: ticks are chained
+    # the SINR extension looks at every frame on the air: ticks are chained unless no frame outlives its tick
+    stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > tick_us
     nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
     kind_name, kw = W.model_kwargs(model)
     kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
@@ -301,20 +302,22 @@ def main():
     ctx_rr = [0]
     _bargs = {}
 
-    def batch_args(k, nb):
-        """arguments of one rm_batch_run_sources_device call for ticks k .. k+nb-1 (built once)"""
-        if (k, nb) not in _bargs:
-            t0 = np.arange(k, k + nb, dtype=np.int64) * tick_us
-            _bargs[(k, nb)] = (t0, t0 + tick_us, np.array([src_dev[kk].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
-                               np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
-        return _bargs[(k, nb)]
+    clock = [0]   # simulated ticks issued so far: simulated time never runs backwards (the SINR medium keeps frames on the air)
+
+    def batch_args(k, nb, tk):
+        """arguments of one rm_batch_run_sources_device call for the source lists k .. k+nb-1 at simulated ticks tk .."""
+        if (k, nb, tk) not in _bargs:
+            t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
+            _bargs[(k, nb, tk)] = (t0, t0 + tick_us, np.array([src_dev[kk].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
+                                   np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
+        return _bargs[(k, nb, tk)]
 
     def run_range(k0, k1):
         """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
         with torch.cuda.stream(stream if sharded is None else sharded.comm):
             if sharded is None and batch > 1:
                 for k in range(k0, k1, batch):
-                    a = batch_args(k, min(batch, k1 - k))
+                    a = batch_args(k, min(batch, k1 - k), clock[0] + k - k0)
                     g = ctx_rr[0] % inflight       # contexts take the batches in turn
                     ctx_rr[0] += 1
                     engines[g].batch_run_sources_device(*a)
@@ -329,7 +332,7 @@ def main():
                     last_run[:] = [engines[g], len(t_b) - 1]
             elif sharded is None:
                 for k in range(k0, k1):
-                    t0 = k * tick_us
+                    t0 = (clock[0] + k - k0) * tick_us
                     # one call: the frames' Tx records are built from the resident node state inside the sweep
                     engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k].data_ptr(), t_per_tick,
                                                                   t0, W.AIR_US)
@@ -343,6 +346,7 @@ def main():
                     if k + 1 < k1:
                         sharded.stage(src_dev[k + 1].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
                     sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
+        clock[0] += k1 - k0
 
     def fence():
         for st in streams:
@@ -408,8 +412,8 @@ def main():
         t_seq = time.perf_counter()
         with torch.cuda.stream(stream):
             for k in range(args.warmup, ticks):
-                t0 = k * W.TICK_US
-                eng.tick_run_sources_device(t0, t0 + W.TICK_US, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+                t0 = (clock[0] + k - args.warmup) * tick_us
+                eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
         fence()
         el = time.perf_counter() - t_seq
         sequential = {"ticks_in_flight": 1, "value": links_per_tick * args.steps / el, "unit": "links/s",

@@ -218,8 +218,11 @@ int rm_sync(rm_context *ctx);
  * launches of a few microseconds each).  Tick b's results live in result slot b of the context
  * (slot 0 is also what rm_result_* read) until the next rm_batch_* / rm_tick_* call.  The
  * java.util.Random draws are consumed tick by tick in slot order, i.e. exactly as n_ticks
- * single rm_tick_run_sources_device calls would.  Media that carry state from tick to tick
- * (RM_LD_SINR: the on-air list) and partitioned contexts whose links draw are refused with
+ * single rm_tick_run_sources_device calls would.  The RM_LD_SINR extension looks at every frame
+ * on the air, so it is batched only when the ticks are self-contained -- frames given as source
+ * indices, no frame of an earlier call or of an earlier tick of the batch still on the air when a
+ * tick begins (air time <= tick length); the last tick's frames stay on the air for the calls that
+ * follow.  Anything else of it, and partitioned contexts whose links draw, are refused with
  * RM_ERR_STATE -- run those one tick at a time. */
 #define RM_MAX_BATCH 128
 int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,

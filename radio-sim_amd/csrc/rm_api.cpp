@@ -1656,6 +1656,10 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, dev_ticks, cfg));
     RM_TRY(stage(RM_STAGE_EXACT));
     RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, dev_ticks, cfg));
+    if (plans[0].sinr) {
+        RM_TRY(stage(RM_STAGE_SINR));
+        RM_HIP(rm::launch_batch_stage(s, 3, nd, m, ticks, n, dev_ticks, cfg));
+    }
     RM_TRY(stage(RM_STAGE_REORDER));
     RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, dev_ticks, cfg));
     if (cfg.stochastic) {
@@ -1682,9 +1686,29 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         if (n_per[b] < 0 || (n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
             (dev_src && air_us[b] < 0))
             return fail(RM_ERR_INVALID, "bad arguments");
-    if (is_sinr(c))
-        return fail(RM_ERR_STATE, "the SINR medium carries its on-air list from tick to tick: run it one tick at a time");
     RM_HIP(hipSetDevice(c->device));
+    const bool sinr = is_sinr(c);
+    if (sinr) {
+        // The SINR extension looks at every frame on the air.  A batch is accepted when its ticks are
+        // self-contained: nothing of an earlier call and nothing of an earlier tick of the batch is
+        // still on the air when a tick begins (e.g. air time <= tick length).  The time spans must be
+        // known here, so the frames have to come as source indices.
+        if (!dev_src)
+            return fail(RM_ERR_STATE, "SINR batches take the frames as source indices (rm_batch_run_sources_device)");
+        for (const auto &bt : c->air_batches)
+            if (bt.end_us > t_begin_us[0])
+                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
+        for (const auto &r : c->onair)
+            if (still_on_air(r, t_begin_us[0]))
+                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
+        for (int b = 0; b + 1 < n_ticks; ++b)
+            if (n_per[b] > 0 && start_us[b] + air_us[b] > t_begin_us[b + 1])
+                return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run "
+                                          "overlapping ticks one at a time");
+        c->onair.clear();
+        c->air_batches.clear();
+        c->air_head = c->air_tail = 0;
+    }
     if (maybe_draws(c) && part_count(c) != c->n)
         return fail(RM_ERR_STATE, "a receiver partition whose links draw needs rm_tick_finish_draws per tick: run it one "
                                   "tick at a time");
@@ -1696,7 +1720,12 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         TickSlot &ts = *slot_of(c, b);
         slots[b] = &ts;
         const rm_tx_record *tx = nullptr;
-        if (dev_src) {
+        if (dev_src && sinr && b == n_ticks - 1) {
+            // the last tick's frames may outlive the batch: they are built where the on-air list of the
+            // one-tick-at-a-time path lives
+            RM_HIP(c->d_air.ensure(std::max<size_t>(size_t(n_per[b]), 1 << 16)));
+            tx = c->d_air.p;
+        } else if (dev_src) {
             RM_HIP(ts.d_tx.ensure(std::max(n_per[b], 1)));
             tx = ts.d_tx.p;
         } else {
@@ -1709,7 +1738,15 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
     }
     c->t_begin = t_begin_us[0];
     c->t_end = t_end_us[n_ticks - 1];
-    if (batched) return launch_batch(c, slots, plans, n_ticks);
+    if (sinr && n_per[n_ticks - 1] > 0) {
+        c->air_tail = size_t(n_per[n_ticks - 1]);
+        c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1]});
+    }
+    if (batched) {
+        if (sinr)
+            for (int b = 0; b < n_ticks; ++b) plans[b].t.reset_heads = 1;
+        return launch_batch(c, slots, plans, n_ticks);
+    }
     // configurations the batched kernels do not cover (fp64 frame, unsorted table, very many frames,
     // empty ticks): the same ticks, one launch sequence each
     for (int b = 0; b < n_ticks; ++b) RM_TRY(launch_tick(c, *slots[b], plans[b]));

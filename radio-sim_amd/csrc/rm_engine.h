@@ -121,6 +121,7 @@ struct TickDev {
     int rpt;                // receiver groups per wave in the filter kernel
     int n_slabs;            // ceil(n_rx / (64*rpt))
     int filter_mode;        // kFilterGrid / kFilterWg
+    int reset_heads;        // k_tick_prep empties the per-receiver link lists (SINR ticks of a batch)
     // per (slot, slab) heard counts / offsets (off is relative to the frame's first link), layout [(chunk*n_slabs + slab)*64 + lane]
     uint32_t *cnt, *off;
     uint32_t *slot_tot;     // [n_cnt] heard links per frame slot
@@ -215,6 +216,8 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
                                const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
+hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                             const TickDev *dev_ticks);
 hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                                 const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,

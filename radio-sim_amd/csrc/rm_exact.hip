@@ -145,14 +145,14 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
     exact_body<MODEL, SINR, STOCH, SEG>(nd, m, t);
 }
 
-template <int MODEL, bool STOCH, int SCAN>
+template <int MODEL, bool STOCH, int SCAN, bool SINR = false>
 __global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    exact_body<MODEL, false, STOCH, SCAN, true>(nd, m, ticks[blockIdx.z]);
+    exact_body<MODEL, SINR, STOCH, SCAN, true>(nd, m, ticks[blockIdx.z]);
 }
 
 // half duplex (SINR mode): every frame on the air leaves a SELF entry in its source's list
-__global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t)
+RM_D void self_entries_body(const NodesDev &nd, const TickDev &t)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_eval = t.n_active - t.first_eval;
@@ -176,6 +176,13 @@ __global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t)
     t.st_orig[idx] = src;
     t.st_lin[idx] = 0.0;
     t.st_next[idx] = atomicExch(&t.head[pos], int(idx));
+}
+
+__global__ void __launch_bounds__(256) k_self_entries(NodesDev nd, TickDev t) { self_entries_body(nd, t); }
+
+__global__ void __launch_bounds__(256) k_self_entries_batch(const NodesDev nd, const TickDev *__restrict__ ticks)
+{
+    self_entries_body(nd, ticks[blockIdx.z]);
 }
 
 // off[cell] = heard links of the same frame in lower slabs; slot_tot[slot] = heard links of the
@@ -242,7 +249,7 @@ RM_D bool frames_overlap(const rm_tx_record &w, const rm_tx_record &k)
 
 // one thread per link entry that is a heard link of a new frame: walk the receiver's list,
 // sum the co-channel, time-overlapping interferers exactly (Q80), apply capture + half duplex
-__global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t)
+RM_D void sinr_body(const ModelDev &m, const TickDev &t)
 {
     const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -270,6 +277,13 @@ __global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t)
         t.st_sinr[e] = sinr;
         t.st_coll[e] = (half_duplex || !(sinr >= m.ld_capture)) ? 1 : 0;
     }
+}
+
+__global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t) { sinr_body(m, t); }
+
+__global__ void __launch_bounds__(256) k_sinr_batch(const ModelDev m, const TickDev *__restrict__ ticks)
+{
+    sinr_body(m, ticks[blockIdx.z]);
 }
 
 // ============================================================================ ordered scatter
@@ -427,6 +441,12 @@ do {                                                                            
         else hipLaunchKernelGGL((k_exact_batch<MODEL, false, 1>), grid, block, 0, s, nd, m, b);                  \
     }                                                                                                            \
 } while (0)
+    if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) { // self-contained ticks of the SINR extension (no draws)
+        if (scan == 3) hipLaunchKernelGGL((k_exact_batch<RM_MODEL_LOGDIST, false, 3, true>), grid, block, 0, s, nd, m, b);
+        else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<RM_MODEL_LOGDIST, false, 4, true>), grid, block, 0, s, nd, m, b);
+        else hipLaunchKernelGGL((k_exact_batch<RM_MODEL_LOGDIST, false, 1, true>), grid, block, 0, s, nd, m, b);
+        return hipGetLastError();
+    }
     switch (m.kind) {
     case RM_MODEL_NULL: RM_EXB(RM_MODEL_NULL); break;
     case RM_MODEL_UDGM: RM_EXB(RM_MODEL_UDGM); break;
@@ -436,6 +456,16 @@ do {                                                                            
     default: return hipErrorInvalidValue;
     }
 #undef RM_EXB
+    return hipGetLastError();
+}
+
+// rm_batch_*, SINR stage: every on-air frame's SELF entry, then the interference sums
+hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n, const TickDev *b)
+{
+    int max_eval = 0;
+    for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
+    hipLaunchKernelGGL(k_self_entries_batch, dim3(cdiv(max(max_eval, 1), 256), 1, n), dim3(256), 0, s, nd, b);
+    hipLaunchKernelGGL(k_sinr_batch, dim3(4, kShards, n), dim3(256), 0, s, m, b);
     return hipGetLastError();
 }
 

@@ -355,6 +355,8 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
             t.cursor[i] = 0u;
             t.cand_tot_next[i] = 0u;
         }
+    if (t.reset_heads) // SINR tick of a batch: every receiver's link list starts empty
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n_rx; i += gridDim.x * blockDim.x) t.head[i] = -1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_eval) return;
     const int abs_i = t.first_eval + e;

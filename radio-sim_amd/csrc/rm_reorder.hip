@@ -110,10 +110,10 @@ __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
     reorder_body<STOCH, SINR, MODE>(m, t);
 }
 
-template <bool STOCH, int SCAN>
+template <bool STOCH, int SCAN, bool SINR = false>
 __global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickDev *__restrict__ ticks)
 {
-    reorder_body<STOCH, false, SCAN>(m, ticks[blockIdx.z]);
+    reorder_body<STOCH, SINR, SCAN>(m, ticks[blockIdx.z]);
 }
 
 // ============================================================================ Java-RNG draws
@@ -444,7 +444,11 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     // workgroups); a receiver partition hears 1/share of a frame's links, so its waves take more
     const int fpw = max(2, min(8, nd.n_rx > 0 ? nd.n / nd.n_rx : 1));
     const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
-    if (cfg.stochastic) {
+    if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
+        if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<false, 3, true>), grid, block, 0, s, m, b);
+        else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<false, 4, true>), grid, block, 0, s, m, b);
+        else hipLaunchKernelGGL((k_reorder_batch<false, 1, true>), grid, block, 0, s, m, b);
+    } else if (cfg.stochastic) {
         if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
         else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
         else hipLaunchKernelGGL((k_reorder_batch<true, 1>), grid, block, 0, s, m, b);

@@ -259,8 +259,8 @@ hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *h
 
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
 {
-    const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
-    return cfg.sorted && cfg.bbox && !cfg.f64_filter && !sinr && !t.use_matrix && t.n_cnt <= kFusedScanMax &&
+    (void)m; // the SINR extension is batched as well (self-contained ticks only: rm_api.cpp checks that)
+    return cfg.sorted && cfg.bbox && !cfg.f64_filter && !t.use_matrix && t.n_cnt <= kFusedScanMax &&
            t.filter_mode == kFilterWg && t.n_active > t.first_new && t.n_rx > 0;
 }
 
@@ -276,13 +276,15 @@ hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDe
 }
 
 // rm_batch_*: n independent ticks (sorted table, fp32 frame, no SINR, <= kFusedScanMax frames each) in four
-// launches (+ the descriptor upload).  stage 0: k_tick_prep + k_filter_wg, 1: k_exact, 2: k_reorder.
+// launches (+ the descriptor upload).  stage 0: k_tick_prep + k_filter_wg, 1: k_exact, 2: k_reorder,
+// 3 (SINR, between 1 and 2): k_self_entries + k_sinr.
 hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *b, const LaunchCfg &cfg)
 {
     if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
     if (stage == 0) return launch_filter_batch(s, nd, m, ticks, n, b, cfg);
     if (stage == 1) return launch_exact_batch(s, nd, m, ticks, n, b, cfg);
+    if (stage == 3) return launch_sinr_batch(s, nd, m, ticks, n, b);
     return launch_reorder_batch(s, nd, m, ticks, n, b, cfg);
 }
 

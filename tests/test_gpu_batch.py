@@ -147,9 +147,13 @@ def test_batch_refusals(engine, rsa, O):
     configure_engine(engine, nd, "logdist", dict(ld_flags=1))
     src = DeviceArray(np.arange(10, dtype=np.int32))
     args = ([0], [1000], [src.ptr.value], [10], [0], [AIR])
-    with pytest.raises(rsa.RadioMediumError) as e:
-        engine.batch_run_sources_device(*args)
-    assert e.value.code == _lib.RM_ERR_STATE                       # SINR carries an on-air list
+    recs = DeviceArray(to_tx_records(rsa, nd.packets(np.arange(10), 0, 320)))
+    with pytest.raises(rsa.RadioMediumError) as e:                 # SINR: the frames' time spans must be known
+        engine.batch_run_device([0], [1000], [recs.ptr.value], [10])
+    assert e.value.code == _lib.RM_ERR_STATE
+    with pytest.raises(rsa.RadioMediumError) as e:                 # SINR: tick 0's frames (8128 us) outlive their tick
+        engine.batch_run_sources_device([0, 1000], [1000, 2000], [src.ptr.value] * 2, [10, 10], [0, 1000], [AIR, AIR])
+    assert e.value.code == _lib.RM_ERR_STATE
     configure_engine(engine, nd, "udgm", dict(udgm_success_ratio_rx=0.5))
     engine.set_partition(0, n // 2)
     with pytest.raises(rsa.RadioMediumError) as e:
@@ -165,6 +169,48 @@ def test_batch_refusals(engine, rsa, O):
     engine.batch_run_sources_device(*args)
     assert engine.batch_result_copy(0, 10).count > 0
     src.free()
+    recs.free()
+
+
+def test_sinr_batch_of_self_contained_ticks(engine, rsa, O):
+    """The SINR extension in a batch: allowed when no frame outlives its tick (air time <= tick length),
+    every tick then equals the oracle's answer for its own frames; the last tick's frames stay on the
+    air for the one-tick-at-a-time calls that follow; an earlier call's frames still on the air make
+    the next batch be refused."""
+    from radio_sim_amd import _lib
+    n = 6000
+    nd = _layout(O, n, seed=41)
+    rng = np.random.default_rng(12)
+    nd.channel[:] = 11 + rng.integers(0, 3, n)
+    params = dict(ld_flags=1, ld_sigma_db=4.0, ld_seed=17, ld_capture_db=3.0)
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    n_ticks = 7
+    srcs = _ticks(n, n_ticks, 260, seed=5, ragged=True)
+    airs = [960, 320, 1000, 640, 960, 32, 8128]                    # the last one outlives the batch
+    dev = [DeviceArray(s) for s in srcs]
+    tb = np.arange(n_ticks, dtype=np.int64) * 1000
+    engine.batch_run_sources_device(tb, tb + 1000, [d.ptr.value for d in dev], [len(s) for s in srcs], tb, airs)
+    interfered = 0
+    for b in range(n_ticks):
+        cpu = O.tick(mdl, nd, nd.packets(srcs[b], int(tb[b]), airs[b]))
+        assert_same(engine.batch_result_copy(b, len(srcs[b])), cpu, "sinr batch tick %d" % b)
+        interfered += int((cpu.verdict == O.INTERFERED).sum())
+    assert interfered > 50
+    # the frames of tick 6 (start 6000, air 8128) are still on the air at t = 7000
+    onair = nd.packets(srcs[-1], int(tb[-1]), airs[-1])
+    more = np.sort(rng.choice(n, 120, replace=False)).astype(np.int32)
+    d_more = DeviceArray(more)
+    engine.tick_run_sources_device(7000, 8000, d_more.ptr.value, len(more), 7000, 2048)
+    cpu = O.tick(mdl, nd, np.concatenate([onair, nd.packets(more, 7000, 2048)]), first_new=len(onair))
+    assert_same(engine.result_copy(len(more)), cpu, "one tick after the batch, with the batch's last frames on the air")
+    with pytest.raises(rsa.RadioMediumError) as e:                 # ... and a batch starting at 8000 would miss them
+        engine.batch_run_sources_device([8000], [9000], [d_more.ptr.value], [len(more)], [8000], [320])
+    assert e.value.code == _lib.RM_ERR_STATE
+    engine.batch_run_sources_device([20000], [21000], [d_more.ptr.value], [len(more)], [20000], [320])   # all expired
+    assert_same(engine.batch_result_copy(0, len(more)), O.tick(mdl, nd, nd.packets(more, 20000, 320)), "batch after expiry")
+    for d in dev + [d_more]:
+        d.free()
 
 
 @pytest.mark.parametrize("world", [2, 3])
