@@ -64,7 +64,7 @@ def build_library(force=False):
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "radiomedium_hip.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _CSRC, "-s", "libradiomedium_hip.so"])
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "-j4", "libradiomedium_hip.so"])
     return _SO
 
 
