@@ -234,8 +234,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     idx, n, frac, model, desc = WORKLOADS[args.workload]
-    if args.workload in EXTRA and world > 1:
-        raise SystemExit("the SINR workloads run on one GPU in this round (sharded on-air list: host-record path only)")
+    extra0 = EXTRA.get(args.workload, {})
+    if model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > extra0.get("tick_us", W.TICK_US) and world > 1:
+        raise SystemExit("frames that outlive their tick (SINR on-air list) are sharded through the host-record path only")
     as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
     if as_rank:
         n = int(round(n * as_rank[1] ** 0.5))
@@ -325,10 +326,10 @@ def main():
             elif batch > 1:
                 # sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream
                 for k in range(k0, k1, batch):
-                    t_b = np.arange(k, min(k + batch, k1), dtype=np.int64) * W.TICK_US
+                    t_b = (clock[0] - k0 + np.arange(k, min(k + batch, k1), dtype=np.int64)) * tick_us
                     g = ctx_rr[0] % inflight
                     ctx_rr[0] += 1
-                    sharded.run_batch(g, src_dev[k].data_ptr(), t_b, W.AIR_US, W.TICK_US)
+                    sharded.run_batch(g, src_dev[k].data_ptr(), t_b, W.AIR_US, tick_us)
                     last_run[:] = [engines[g], len(t_b) - 1]
             elif sharded is None:
                 for k in range(k0, k1):

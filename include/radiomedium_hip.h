@@ -219,11 +219,14 @@ int rm_sync(rm_context *ctx);
  * (slot 0 is also what rm_result_* read) until the next rm_batch_* / rm_tick_* call.  The
  * java.util.Random draws are consumed tick by tick in slot order, i.e. exactly as n_ticks
  * single rm_tick_run_sources_device calls would.  The RM_LD_SINR extension looks at every frame
- * on the air, so it is batched only when the ticks are self-contained -- frames given as source
- * indices, no frame of an earlier call or of an earlier tick of the batch still on the air when a
- * tick begins (air time <= tick length); the last tick's frames stay on the air for the calls that
- * follow.  Anything else of it, and partitioned contexts whose links draw, are refused with
- * RM_ERR_STATE -- run those one tick at a time. */
+ * on the air, so it is batched only when the ticks are self-contained: no frame of an earlier
+ * call or of an earlier tick of the batch still on the air when a tick begins (air time <= tick
+ * length).  With source indices the time spans are in the arguments, and the last tick's frames
+ * stay on the air for the calls that follow; with records (rm_batch_run_device, e.g. the gathered
+ * records of a multi-GPU batch) the ticks [t_begin, t_end] must not overlap and every frame has to
+ * lie inside its tick -- verified on the device, a violation is reported as RM_ERR_STATE when
+ * the tick's result is read.  Anything else of it, and partitioned contexts whose links draw,
+ * are refused with RM_ERR_STATE -- run those one tick at a time. */
 #define RM_MAX_BATCH 128
 int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,
                                 const int64_t *t_end_us, const int32_t *const *dev_src /* device int32[n_src[b]] each */,

@@ -1247,9 +1247,10 @@ static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uin
         return fail(RM_ERR_STATE, "this rank's verdicts wait for the other ranks' draw counts: exchange "
                                   "rm_draw_counts_device and call rm_tick_finish_draws first");
     hipStream_t s = c->stream;
-    uint32_t oc[3] = {0, 0, 0};
+    uint32_t oc[5] = {0, 0, 0, 0, 0}; // [4]: a SINR tick of a batch held a frame outside its [t_begin, t_end]
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
     RM_HIP(hipStreamSynchronize(s));
+    if (oc[4]) return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
     if (count) *count = oc[2];
     const uint32_t k = std::min(oc[0], cap);
     if (k) {
@@ -1582,9 +1583,10 @@ static int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *
 {
     if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
-    uint32_t oc[3];
+    uint32_t oc[5];
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
+    if (oc[4]) return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
     if (count) *count = oc[2];
     if (dropped) *dropped = oc[1];
     return RM_OK;
@@ -1691,17 +1693,21 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
     if (sinr) {
         // The SINR extension looks at every frame on the air.  A batch is accepted when its ticks are
         // self-contained: nothing of an earlier call and nothing of an earlier tick of the batch is
-        // still on the air when a tick begins (e.g. air time <= tick length).  The time spans must be
-        // known here, so the frames have to come as source indices.
+        // still on the air when a tick begins (e.g. air time <= tick length).  Frames given as source
+        // indices carry their time span in the arguments; records given by the caller (the gathered
+        // records of a multi-GPU batch) are verified on the device: every frame of tick b has to lie
+        // inside [t_begin[b], t_end[b]], and the ticks must not overlap.
         if (!dev_src)
-            return fail(RM_ERR_STATE, "SINR batches take the frames as source indices (rm_batch_run_sources_device)");
+            for (int b = 0; b < n_ticks; ++b)
+                if (t_end_us[b] < t_begin_us[b] || (b + 1 < n_ticks && t_end_us[b] > t_begin_us[b + 1]))
+                    return fail(RM_ERR_STATE, "SINR batches of records need ticks [t_begin, t_end] that do not overlap");
         for (const auto &bt : c->air_batches)
             if (bt.end_us > t_begin_us[0])
                 return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
         for (const auto &r : c->onair)
             if (still_on_air(r, t_begin_us[0]))
                 return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
-        for (int b = 0; b + 1 < n_ticks; ++b)
+        for (int b = 0; dev_src && b + 1 < n_ticks; ++b)
             if (n_per[b] > 0 && start_us[b] + air_us[b] > t_begin_us[b + 1])
                 return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run "
                                           "overlapping ticks one at a time");
@@ -1738,7 +1744,13 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
     }
     c->t_begin = t_begin_us[0];
     c->t_end = t_end_us[n_ticks - 1];
-    if (sinr && n_per[n_ticks - 1] > 0) {
+    if (sinr && !dev_src)
+        for (int b = 0; b < n_ticks; ++b) {
+            plans[b].t.check_span = 1;
+            plans[b].t.span_begin = t_begin_us[b];
+            plans[b].t.span_end = t_end_us[b];
+        }
+    if (sinr && dev_src && n_per[n_ticks - 1] > 0) {
         c->air_tail = size_t(n_per[n_ticks - 1]);
         c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1]});
     }

@@ -367,6 +367,8 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     } else {
         tx = t.tx[abs_i];
     }
+    if (t.check_span && tx.src >= 0 && (tx.start_us < t.span_begin || tx.start_us + tx.air_us > t.span_end))
+        t.stage_count[6] = 1u; // reported as RM_ERR_STATE when the tick's result is read
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);

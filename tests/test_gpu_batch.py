@@ -148,9 +148,15 @@ def test_batch_refusals(engine, rsa, O):
     src = DeviceArray(np.arange(10, dtype=np.int32))
     args = ([0], [1000], [src.ptr.value], [10], [0], [AIR])
     recs = DeviceArray(to_tx_records(rsa, nd.packets(np.arange(10), 0, 320)))
-    with pytest.raises(rsa.RadioMediumError) as e:                 # SINR: the frames' time spans must be known
-        engine.batch_run_device([0], [1000], [recs.ptr.value], [10])
+    with pytest.raises(rsa.RadioMediumError) as e:                 # SINR records: overlapping ticks are refused at once
+        engine.batch_run_device([0, 500], [1000, 1500], [recs.ptr.value] * 2, [10, 10])
     assert e.value.code == _lib.RM_ERR_STATE
+    engine.batch_run_device([0], [200], [recs.ptr.value], [10])    # frames of 320 us in a tick of 200 us: found on the device,
+    with pytest.raises(rsa.RadioMediumError) as e:                 # reported when the tick is read
+        engine.batch_result_copy(0, 10)
+    assert e.value.code == _lib.RM_ERR_STATE
+    engine.batch_run_device([0], [320], [recs.ptr.value], [10])
+    assert engine.batch_result_count(0)[1] == 0
     with pytest.raises(rsa.RadioMediumError) as e:                 # SINR: tick 0's frames (8128 us) outlive their tick
         engine.batch_run_sources_device([0, 1000], [1000, 2000], [src.ptr.value] * 2, [10, 10], [0, 1000], [AIR, AIR])
     assert e.value.code == _lib.RM_ERR_STATE
@@ -214,7 +220,8 @@ def test_sinr_batch_of_self_contained_ticks(engine, rsa, O):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_batch_equals_global(rsa, O, world):
+@pytest.mark.parametrize("sinr", [False, True])
+def test_sharded_batch_equals_global(rsa, O, world, sinr):
     """The multi-GPU batch sequence on one GPU: every 'rank' packs its own transmitters of all ticks with
     rm_pack_tx_batch_device_on, the 'all-gather' + transposition to tick-major order is done on the
     host, every rank sweeps the gathered ticks against its receiver range with rm_batch_run_device;
@@ -224,6 +231,11 @@ def test_sharded_batch_equals_global(rsa, O, world):
     n, n_ticks = 5000, 5
     params = {"ld_sigma_db": 4.0, "ld_seed": 5}
     nd = _layout(O, n, seed=31)
+    air = AIR
+    if sinr:          # the SINR extension: ticks whose frames end with the tick (BASELINE configs[3] shape), 3 channels
+        params.update(ld_flags=1, ld_capture_db=3.0)
+        nd.channel[:] = 11 + np.random.default_rng(3).integers(0, 3, n)
+        air = 1000
     mdl = oracle_model(O, "logdist", params)
     srcs = _ticks(n, n_ticks, 120, seed=7, ragged=True)
     slots = D.slots_needed(n, world, srcs)
@@ -240,7 +252,7 @@ def test_sharded_batch_equals_global(rsa, O, world):
             eng.set_partition(lo, hi - lo)
             padded = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in srcs])     # [ticks][slots]
             d_src, d_out = DeviceArray(padded), DeviceArray(nbytes=n_ticks * slots * 64)
-            eng.pack_tx_batch_device_on(0, d_src.ptr.value, n_ticks, slots, starts, AIR, d_out.ptr.value)
+            eng.pack_tx_batch_device_on(0, d_src.ptr.value, n_ticks, slots, starts, air, d_out.ptr.value)
             mine_bytes.append(DeviceArray.read(d_out.ptr.value, np.uint8, n_ticks * slots * 64).reshape(n_ticks, slots * 64))
             d_src.free()
             d_out.free()
@@ -255,16 +267,19 @@ def test_sharded_batch_equals_global(rsa, O, world):
             for eng in engines:
                 res = eng.batch_result_copy(b, per_tick)
                 shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
-            pkt, dst, verdict, rssi, _ = D.merge_shard_links(shards, per_tick)
+            pkt, dst, verdict, rssi, sinr_db = D.merge_shard_links(shards, per_tick)
             gathered = D.records_from_bytes(tick_major[b].reshape(-1))
             valid, slot_idx = D.drop_padding(gathered)
             np.testing.assert_array_equal(valid["src"], srcs[b])                                  # canonical order survives
-            ref = O.tick(mdl, nd, nd.packets(srcs[b], start_us=int(starts[b]), air_us=AIR))
+            ref = O.tick(mdl, nd, nd.packets(srcs[b], start_us=int(starts[b]), air_us=air))
             assert ref.count > 100 and len(pkt) == ref.count
             np.testing.assert_array_equal(pkt, slot_idx[ref.pkt])
             np.testing.assert_array_equal(dst, ref.dst)
             np.testing.assert_array_equal(verdict, ref.verdict)
             np.testing.assert_array_equal(rssi, ref.rssi)
+            np.testing.assert_array_equal(sinr_db, ref.sinr)
+            if sinr:
+                assert (ref.verdict == O.INTERFERED).any()
         d_all.free()
     finally:
         for eng in engines:
