@@ -72,3 +72,23 @@ def test_pure_helpers(rsa):
     L.rm_model_defaults(C.byref(p), 1)
     assert (p.udgm_transmission_range, p.udgm_interference_range, p.const_range) == (50.0, 100.0, 100.0)
     assert (p.udgm_success_ratio_rx, p.udgm_success_ratio_tx) == (1.0, 1.0)
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 (and C++11) on its own, and a C caller links
+    against the library's symbols."""
+    import subprocess
+    import tempfile
+    hdr = os.path.join(ROOT, "include", "radiomedium_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    src = ('#include "radiomedium_hip.h"\n'
+           "int main(void) { rm_model_params p; rm_model_defaults(&p, RM_MODEL_UDGM);\n"
+           "  return (rm_abi_version() == RM_ABI_VERSION && rm_air_time_us(10) == 320 && p.udgm_transmission_range == 50.0) ? 0 : 1; }\n")
+    with tempfile.TemporaryDirectory() as tmp:
+        c_file, exe = os.path.join(tmp, "caller.c"), os.path.join(tmp, "caller")
+        open(c_file, "w").write(src)
+        lib = os.path.join(ROOT, "radio-sim_amd", "csrc")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), c_file, "-L" + lib,
+                               "-lradiomedium_hip", "-Wl,-rpath," + lib, "-o", exe])
+        assert subprocess.run([exe], timeout=60).returncode == 0   # host-only entry points: no GPU needed
