@@ -1665,12 +1665,9 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     RM_TRY(stage(RM_STAGE_REORDER));
     RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, dev_ticks, cfg));
     if (cfg.stochastic) {
-        // the shared generator is walked tick by tick, in slot order
+        // the shared generator is walked tick by tick, in slot order, inside one launch
         RM_TRY(stage(RM_STAGE_DRAWS));
-        for (int b = 0; b < n; ++b) {
-            RM_HIP(rm::launch_draws_scan(s, ticks[b]));
-            RM_HIP(rm::launch_draws_apply(s, m, ticks[b], nullptr, 1, 0));
-        }
+        RM_HIP(rm::launch_draws_batch(s, m, ticks, n, dev_ticks));
     }
     if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
     for (int b = 0; b < n; ++b) slots[b]->have_result = true;

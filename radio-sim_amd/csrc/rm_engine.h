@@ -234,6 +234,7 @@ hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m,
 hipError_t launch_seg_scan(hipStream_t s, const TickDev &t);
 hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_draws_scan(hipStream_t s, const TickDev &t);
+hipError_t launch_draws_batch(hipStream_t s, const ModelDev &m, const TickDev *ticks, int n, const TickDev *dev_ticks);
 hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
                               int rank);
 

@@ -125,24 +125,31 @@ RM_D uint32_t draw_flag(const TickDev &t, uint32_t pos)
     return (t.out_verdict[pos] == 0 && t.out_prob[pos] < 1.0) ? 1u : 0u;
 }
 
-__global__ void __launch_bounds__(256) k_draw_tile_sums(TickDev t)
+// (the tile kernels walk the tiles with a grid stride: the grid is sized for the records there are, not
+// for the link capacity, and the batched variants share it between the ticks of a batch)
+RM_D void draw_tile_sums_body(const TickDev &t)
 {
     __shared__ uint32_t s_part[4];
     const uint32_t n = t.out_count[0];
-    const uint32_t base = blockIdx.x * kScanTile;
-    if (base >= n) return;
-    uint32_t v = 0;
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t pos = base + i * 256 + threadIdx.x;
-        if (pos < n) v += draw_flag(t, pos);
+    for (uint32_t tile = blockIdx.x; tile * kScanTile < n; tile += gridDim.x) { // block-uniform
+        const uint32_t base = tile * kScanTile;
+        uint32_t v = 0;
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t pos = base + i * 256 + threadIdx.x;
+            if (pos < n) v += draw_flag(t, pos);
+        }
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) t.scan_block[tile] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
     }
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) t.scan_block[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
-__global__ void __launch_bounds__(1024) k_draw_tile_scan(TickDev t)
+__global__ void __launch_bounds__(256) k_draw_tile_sums(TickDev t) { draw_tile_sums_body(t); }
+__global__ void __launch_bounds__(256) k_draw_tile_sums_batch(const TickDev *__restrict__ ticks) { draw_tile_sums_body(ticks[blockIdx.z]); }
+
+RM_D void draw_tile_scan_body(const TickDev &t)
 {
     __shared__ uint32_t s_wave[16];
     const uint32_t n = t.out_count[0];
@@ -159,12 +166,15 @@ __global__ void __launch_bounds__(1024) k_draw_tile_scan(TickDev t)
     if (threadIdx.x == 0) t.draw_scan[n] = carry;
 }
 
-__global__ void __launch_bounds__(256) k_draw_scan(TickDev t)
+__global__ void __launch_bounds__(1024) k_draw_tile_scan(TickDev t) { draw_tile_scan_body(t); }
+__global__ void __launch_bounds__(1024) k_draw_tile_scan_batch(const TickDev *__restrict__ ticks) { draw_tile_scan_body(ticks[blockIdx.z]); }
+
+RM_D void draw_scan_body(const TickDev &t)
 {
     __shared__ uint32_t s_wave[4];
     const uint32_t n = t.out_count[0];
-    const uint32_t base = blockIdx.x * kScanTile;
-    if (base >= n) return;
+    for (uint32_t tile = blockIdx.x; tile * kScanTile < n; tile += gridDim.x) { // block-uniform
+    const uint32_t base = tile * kScanTile;
     // thread owns 8 consecutive positions
     const uint32_t p0 = base + threadIdx.x * 8;
     uint32_t f[8];
@@ -178,17 +188,22 @@ __global__ void __launch_bounds__(256) k_draw_scan(TickDev t)
     const uint32_t inc = wave_inclusive_scan(sum, lane);
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t off = t.scan_block[blockIdx.x] + inc - sum;
+    uint32_t off = t.scan_block[tile] + inc - sum;
     for (int w = 0; w < wave; ++w) off += s_wave[w];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (p0 + i < n) t.draw_scan[p0 + i] = off;
         off += f[i];
     }
+    __syncthreads();
+    }
 }
 
+__global__ void __launch_bounds__(256) k_draw_scan(TickDev t) { draw_scan_body(t); }
+__global__ void __launch_bounds__(256) k_draw_scan_batch(const TickDev *__restrict__ ticks) { draw_scan_body(ticks[blockIdx.z]); }
+
 // per-packet number of receiver draws this rank would consume (if the packet's Tx does not fail)
-__global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t)
+RM_D void pkt_draw_counts_body(const TickDev &t)
 {
     const int n_new = t.n_active - t.first_new;
     const uint32_t n = t.out_count[0];
@@ -198,6 +213,9 @@ __global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t)
     const uint32_t e = min(t.slot_off[q + t.shift + 1], n);
     t.pkt_draw_cnt[q] = t.draw_scan[e] - t.draw_scan[b];
 }
+
+__global__ void __launch_bounds__(256) k_pkt_draw_counts(TickDev t) { pkt_draw_counts_body(t); }
+__global__ void __launch_bounds__(256) k_pkt_draw_counts_batch(const TickDev *__restrict__ ticks) { pkt_draw_counts_body(ticks[blockIdx.z]); }
 
 // The only sequential part: the shared generator is consumed packet after packet
 // (Simulator.getRandom(); UDGMRadioMedium.java:85-92,106).  One workgroup: the per-packet jump
@@ -255,7 +273,7 @@ RM_D uint64_t read_lane_u64(uint64_t v, int src) // src wave-uniform
     return (uint64_t(hi) << 32) | lo;
 }
 
-__global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const uint32_t *all_cnt, int world, int rank)
+RM_D void rng_chain_body(const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world, int rank)
 {
     __shared__ uint64_t s_pa[1024], s_pc[1024];   // exclusive prefix map of the packet inside its chunk
     __shared__ uint64_t s_pinv[1024];             // s_pa^-1 mod 2^48 (re-basing after a failed draw)
@@ -378,9 +396,21 @@ __global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const
         __syncthreads();
     }
     if (threadIdx.x == 0) *t.rng_state = s_state;
+    __syncthreads(); // the generator state is in memory before a next tick of the same launch reads it
 }
 
-__global__ void __launch_bounds__(256) k_apply_draws(TickDev t)
+__global__ void __launch_bounds__(1024) k_rng_chain(ModelDev m, TickDev t, const uint32_t *all_cnt, int world, int rank)
+{
+    rng_chain_body(m, t, all_cnt, world, rank);
+}
+
+// the ticks of a batch share the generator: one workgroup walks them in slot order
+__global__ void __launch_bounds__(1024) k_rng_chain_batch(const ModelDev m, const TickDev *__restrict__ ticks, int n)
+{
+    for (int b = 0; b < n; ++b) rng_chain_body(m, ticks[b], nullptr, 1, 0);
+}
+
+RM_D void apply_draws_body(const TickDev &t)
 {
     const uint32_t n = t.out_count[0];
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -405,6 +435,9 @@ __global__ void __launch_bounds__(256) k_apply_draws(TickDev t)
         t.out_verdict[pos] = v;
     }
 }
+
+__global__ void __launch_bounds__(256) k_apply_draws(TickDev t) { apply_draws_body(t); }
+__global__ void __launch_bounds__(256) k_apply_draws_batch(const TickDev *__restrict__ ticks) { apply_draws_body(ticks[blockIdx.z]); }
 
 // ============================================================================ launchers
 
@@ -463,7 +496,7 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
 // draws, part 1: which ordered records need a draw, and how many per packet
 hipError_t launch_draws_scan(hipStream_t s, const TickDev &t)
 {
-    const int tiles = cdiv(int(t.cap), kScanTile);
+    const int tiles = min(256, cdiv(int(t.cap), kScanTile)); // grid-stride over the tiles that hold records
     const int n_new = t.n_active - t.first_new;
     hipLaunchKernelGGL(k_draw_tile_sums, dim3(tiles), dim3(256), 0, s, t);
     hipLaunchKernelGGL(k_draw_tile_scan, dim3(1), dim3(1024), 0, s, t);
@@ -477,7 +510,23 @@ hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t
                               int rank)
 {
     hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, rank);
-    hipLaunchKernelGGL(k_apply_draws, dim3(1024), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_apply_draws, dim3(256), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
+// rm_batch_*: the draw stage of all ticks of a batch in six launches; the generator is walked over the
+// ticks in slot order inside ONE launch of k_rng_chain_batch (full table only: no per-rank exchange)
+hipError_t launch_draws_batch(hipStream_t s, const ModelDev &m, const TickDev *ticks, int n, const TickDev *b)
+{
+    int max_new = 0;
+    for (int i = 0; i < n; ++i) max_new = max(max_new, ticks[i].n_active - ticks[i].first_new);
+    const int tiles = min(64, cdiv(int(ticks[0].cap), kScanTile));
+    hipLaunchKernelGGL(k_draw_tile_sums_batch, dim3(tiles, 1, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_draw_tile_scan_batch, dim3(1, 1, n), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(k_draw_scan_batch, dim3(tiles, 1, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_pkt_draw_counts_batch, dim3(max(1, cdiv(max_new, 256)), 1, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_rng_chain_batch, dim3(1), dim3(1024), 0, s, m, b, n);
+    hipLaunchKernelGGL(k_apply_draws_batch, dim3(32, 1, n), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
