@@ -183,3 +183,18 @@ def test_one_launch_transmit_against_the_oracle(engine, rsa, O, kind, params):
         np.testing.assert_array_equal(got.verdict, want.verdict[keep])
         np.testing.assert_array_equal(got.rssi, want.rssi[keep])
         assert bool(got.pkt_interference[0]) == bool(want.pkt_interference[0])
+
+
+def test_plain_c_example(tmp_path):
+    """examples/udgm_transmit.c: the ABI driven from plain C (K2's boundary case through rm_transmit)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "radio-sim_amd", "csrc")
+    exe = os.path.join(str(tmp_path), "udgm_transmit")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "udgm_transmit.c"), "-L" + lib, "-lradiomedium_hip",
+                           "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "UDGM Radio Medium: 1 heard, Tx ok" in out.stdout and "node 1: delivered, rssi 0.0" in out.stdout
