@@ -24,6 +24,7 @@ def O():
 def rsa():
     """The product package (radio-sim_amd/)."""
     import radio_sim_amd
+    radio_sim_amd.build_library()      # hipcc cross-compiles without a GPU; a no-op when the library is current
     return radio_sim_amd
 
 
