@@ -60,7 +60,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h", ".hpp")) or f == "Makefile"]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "radiomedium_hip.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
