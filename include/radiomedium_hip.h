@@ -131,8 +131,18 @@ int rm_nodes_upload(rm_context *ctx, int32_t n,
                     const double *txpower, const int32_t *channel, const uint8_t *enabled,
                     const double *rxprob, const double *txprob,
                     const int32_t *int_id /* Node.getIdAsInteger(); NULL = index+1 */);
+/* One changed node (node-config-set, SimulatorJSONHandler.java:105-143: position, rf-power,
+ * wireless-channel, rx-loss, tx-loss, radio-state).  Written in place on the device by one small
+ * launch, no synchronisation; the receiver table is sorted again only after enough receivers have
+ * left the box their group of 64 had (results never depend on that order). */
 int rm_node_update(rm_context *ctx, int32_t node, double x, double y, double z, double txpower,
                    int32_t channel, uint8_t enabled, double rxprob, double txprob);
+/* New positions of `count` nodes in one call (Position.set, Position.java:44-52); z may be NULL
+ * (z = 0, as Position.set(x, y) does).  The shim's "dirty list" flushed at the start of a tick. */
+int rm_nodes_move(rm_context *ctx, int32_t count, const int32_t *nodes, const double *x, const double *y,
+                  const double *z);
+/* how often the receiver table has been (re)built and spatially sorted so far (observability) */
+int64_t rm_receiver_table_builds(const rm_context *ctx);
 int rm_node_count(const rm_context *ctx);
 /* receiver range owned by this context (multi-GPU range partitioning); default = all */
 int rm_set_partition(rm_context *ctx, int32_t first, int32_t count);

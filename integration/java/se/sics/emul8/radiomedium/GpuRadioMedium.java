@@ -47,6 +47,8 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private static native int nSeed(long ctx, long seed);
     private static native int nNodesUpload(long ctx, int n, double[] x, double[] y, double[] z, double[] txpower,
             int[] channel, byte[] enabled, double[] rxprob, double[] txprob, int[] intId);
+    private static native int nNodeUpdate(long ctx, int node, double x, double y, double z, double txpower, int channel,
+            boolean enabled, double rxprob, double txprob);
     private static native int nSetTime(long ctx, long currentTime);
     /** returns the number of heard links (negative = rm error); dst/verdict/rssi are filled in node order */
     private static native int nTransmit(long ctx, int src, long startUs, long hexLength, boolean hasPower, double txpower,
@@ -57,6 +59,7 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private long ctx;
     private Node[] uploaded;          // the Simulator.getNodes() snapshot the device currently mirrors
     private java.util.IdentityHashMap<Node, Integer> index = new java.util.IdentityHashMap<Node, Integer>();
+    private final java.util.ArrayList<Node> changed = new java.util.ArrayList<Node>(); // the dirty list
     private int[] dst = new int[0];
     private byte[] verdict = new byte[0];
     private double[] rssi = new double[0], sinr = new double[0];
@@ -77,9 +80,20 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     }
 
     private void syncNodes(Node[] nodes) {
-        if (nodes == uploaded) {
-            return; // copy-on-write array (Simulator.java:274): same array == same node set
+        if (nodes == uploaded) { // copy-on-write array (Simulator.java:274): same array == same node set
+            for (Node nd : changed) { // the dirty list: rm_node_update writes these nodes in place on the device
+                Integer i = index.get(nd);
+                Transciever r = nd.getRadio();
+                if (i != null && nNodeUpdate(ctx, i, nd.getPosition().x, nd.getPosition().y, nd.getPosition().z,
+                        r.getTransmitPower(), r.getWirelessChannel(), r.isEnabled(), r.getRxProbability(),
+                        r.getTxProbability()) != 0) {
+                    log.error("node update failed: {}", nLastError());
+                }
+            }
+            changed.clear();
+            return;
         }
+        changed.clear(); // covered by the snapshot below
         int n = nodes.length;
         double[] x = new double[n], y = new double[n], z = new double[n], tp = new double[n], rp = new double[n], xp = new double[n];
         int[] ch = new int[n], id = new int[n];
@@ -102,7 +116,15 @@ public class GpuRadioMedium extends AbstractRadioMedium {
         }
     }
 
-    /** call after node-config-set changed fields of existing nodes (no hook exists in the reference) */
+    /** call after node-config-set changed fields of an existing node (no hook exists in the reference,
+     *  SimulatorJSONHandler.java:105-143): only this node is written to the device before the next packet */
+    public void nodeChanged(Node node) {
+        synchronized (lock) {
+            changed.add(node);
+        }
+    }
+
+    /** anything may have changed: the next packet uploads a fresh snapshot */
     public void invalidateNodes() {
         synchronized (lock) {
             uploaded = null;

@@ -110,6 +110,13 @@ JNIEXPORT jint JFN(nNodesUpload)(JNIEnv *env, jclass cls, jlong ctx, jint n, jdo
     return rc;
 }
 
+JNIEXPORT jint JFN(nNodeUpdate)(JNIEnv *env, jclass cls, jlong ctx, jint node, jdouble x, jdouble y, jdouble z,
+                                jdouble txpower, jint channel, jboolean enabled, jdouble rxprob, jdouble txprob)
+{
+    (void)env; (void)cls;
+    return rm_node_update((rm_context *)(intptr_t)ctx, node, x, y, z, txpower, channel, enabled ? 1 : 0, rxprob, txprob);
+}
+
 JNIEXPORT jint JFN(nTransmit)(JNIEnv *env, jclass cls, jlong ctx, jint src, jlong startUs, jlong hexLength,
                               jboolean hasPower, jdouble txpower, jboolean hasChannel, jint channel, jintArray dst,
                               jbyteArray verdict, jdoubleArray rssi, jdoubleArray sinr, jbyteArray interference)

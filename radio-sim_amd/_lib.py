@@ -91,6 +91,8 @@ SIGNATURES = {
     "rm_nodes_upload": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 9),
     "rm_node_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_int32, C.c_uint8, C.c_double, C.c_double]),
+    "rm_receiver_table_builds": (C.c_int64, [C.c_void_p]),
+    "rm_nodes_move": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rm_node_count": (C.c_int, [C.c_void_p]),
     "rm_set_partition": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rm_set_link_capacity": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <memory>
 #include <vector>
 
@@ -155,6 +156,16 @@ struct rm_context : TickSlot {
     bool shadow_tbl_valid = false;
     int n_rx = 0;            // receivers in the table
     bool rx_sorted = false;  // engine order != node-index order
+    // changed nodes are written in place while the engine order is still a good spatial order
+    struct GroupBox {
+        double lo[3], hi[3];
+    };
+    std::vector<int32_t> h_pos_of;  // node index - rx_first -> engine position (host copy of d_pos_of)
+    std::vector<GroupBox> g_box;    // per group of 64: its box when the table was sorted
+    std::vector<uint8_t> g_escaped; // bit 0 / 1: a receiver of this group has left the box by more than 1/8 / 1/2 of its extent
+    int drifted_groups = 0, escaped_groups = 0;
+    int64_t table_sorts = 0;        // times the receiver table was (re)built
+    DevBuf<rm::NodePatch> d_patch;
 
     int frac_probs = -1;         // cached: any rx/tx probability strictly between 0 and 1 (-1 = unknown)
     bool rx_dirty = true;        // receiver table has to be rebuilt (positions / partition / model class)
@@ -371,31 +382,51 @@ bool is_geometric(const rm_context *c)
     return k == RM_MODEL_UDGM || k == RM_MODEL_UDGM_CONST || k == RM_MODEL_LOGDIST;
 }
 
-// k-d split of perm[lo, hi) down to groups of 64: the left part always holds a multiple of 64
-// receivers, so every group of 64 consecutive engine positions is one leaf (a compact box)
-void kd_split(const rm_context *c, std::vector<int32_t> &perm, int lo, int hi)
+// k-d split of items[lo, hi) down to groups of 64: the left part always holds a multiple of 64
+// receivers, so every group of 64 consecutive engine positions is one leaf (a compact box).
+// The items carry their coordinates (no indirection in the comparisons); ties are broken by the node
+// index, so the leaves do not depend on how the work is spread over threads: the first levels hand
+// their right halves to new threads.
+struct KdItem {
+    double v[3];
+    int32_t idx;
+    int32_t pad;
+};
+
+void kd_split(KdItem *items, int lo, int hi, int spawn_levels)
 {
     const int cnt = hi - lo;
     if (cnt <= rm::kGroup) return;
-    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-    for (int i = lo; i < hi; ++i) {
-        const int k = perm[i];
-        const double v[3] = {c->x[k], c->y[k], c->z[k]};
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) mn[a] = mx[a] = items[lo].v[a];
+    for (int i = lo + 1; i < hi; ++i)
         for (int a = 0; a < 3; ++a) {
-            if (i == lo || v[a] < mn[a]) mn[a] = v[a];
-            if (i == lo || v[a] > mx[a]) mx[a] = v[a];
+            mn[a] = std::min(mn[a], items[i].v[a]);
+            mx[a] = std::max(mx[a], items[i].v[a]);
         }
-    }
     int axis = 0;
     for (int a = 1; a < 3; ++a)
         if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
-    const std::vector<double> &coord = axis == 0 ? c->x : (axis == 1 ? c->y : c->z);
     const int groups = (cnt + rm::kGroup - 1) / rm::kGroup;
     const int mid = lo + ((groups + 1) / 2) * rm::kGroup;
-    std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi,
-                     [&](int32_t a, int32_t b) { return coord[a] < coord[b] || (coord[a] == coord[b] && a < b); });
-    kd_split(c, perm, lo, mid);
-    kd_split(c, perm, mid, hi);
+    std::nth_element(items + lo, items + mid, items + hi, [axis](const KdItem &a, const KdItem &b) {
+        return a.v[axis] < b.v[axis] || (a.v[axis] == b.v[axis] && a.idx < b.idx);
+    });
+    if (spawn_levels > 0 && cnt > 8192) {
+        std::thread right;
+        bool spawned = true;
+        try {
+            right = std::thread(kd_split, items, mid, hi, spawn_levels - 1);
+        } catch (...) { // no thread to be had: this one does both halves
+            spawned = false;
+        }
+        kd_split(items, lo, mid, spawn_levels - 1);
+        if (spawned) right.join();
+        else kd_split(items, mid, hi, 0);
+    } else {
+        kd_split(items, lo, mid, 0);
+        kd_split(items, mid, hi, 0);
+    }
 }
 
 template <typename T> int upload_gather(DevBuf<T> &d, const std::vector<T> &src, const std::vector<int32_t> &perm,
@@ -417,7 +448,13 @@ int rebuild_receivers(rm_context *c)
     for (int i = 0; i < count; ++i) perm[i] = first + i;
     c->rx_sorted = false;
     if (is_geometric(c) && count > rm::kGroup) {
-        kd_split(c, perm, 0, count);
+        std::vector<KdItem> items(static_cast<size_t>(count));
+        for (int i = 0; i < count; ++i) {
+            const int k = first + i;
+            items[size_t(i)] = KdItem{{c->x[k], c->y[k], c->z[k]}, k, 0};
+        }
+        kd_split(items.data(), 0, count, 3); // up to 8 threads
+        for (int i = 0; i < count; ++i) perm[size_t(i)] = items[size_t(i)].idx;
         c->rx_sorted = true;
     }
     std::vector<double> td;
@@ -460,9 +497,94 @@ int rebuild_receivers(rm_context *c)
             RM_HIP(hipStreamSynchronize(c->stream));
         }
     }
+    c->h_pos_of.swap(pos_of);
+    const int groups = (count + rm::kGroup - 1) / rm::kGroup;
+    c->g_box.assign(size_t(groups), rm_context::GroupBox{});
+    for (int g = 0; g < groups; ++g) {
+        rm_context::GroupBox &b = c->g_box[size_t(g)];
+        for (int i = g * rm::kGroup; i < std::min(count, (g + 1) * rm::kGroup); ++i) {
+            const int k = perm[i];
+            const double v[3] = {c->x[k], c->y[k], c->z[k]};
+            for (int a = 0; a < 3; ++a) {
+                if (i == g * rm::kGroup || v[a] < b.lo[a]) b.lo[a] = v[a];
+                if (i == g * rm::kGroup || v[a] > b.hi[a]) b.hi[a] = v[a];
+            }
+        }
+    }
+    c->g_escaped.assign(size_t(groups), 0);
+    c->table_sorts++;
+    c->escaped_groups = 0;
+    c->drifted_groups = 0;
     c->n_rx = count;
     c->rx_dirty = false;
     c->prefilter_dirty = true;
+    return RM_OK;
+}
+
+// Changed nodes (host mirror already updated) go to the device in place: one launch, no
+// synchronisation for a single node.  The receiver table keeps its engine order -- any permutation
+// is correct, the order only decides how tight the groups' boxes are -- and is sorted again once
+// enough receivers have left the box their group had when it was sorted.
+int patch_nodes(rm_context *c, const int32_t *nodes, int count)
+{
+    if (count <= 0) return RM_OK;
+    const int first = part_first(c), pcount = part_count(c);
+    static const long resort_after = [] {
+        const char *e = std::getenv("RM_RESORT_AFTER"); // escaped groups that trigger a new sort (0: every change)
+        return e ? std::atol(e) : -1L;
+    }();
+    const int groups = int(c->g_box.size());
+    const long limit = resort_after >= 0 ? resort_after : std::max(2, groups / 128);
+    std::vector<rm::NodePatch> list(static_cast<size_t>(count));
+    bool frame_changed = false;
+    for (int k = 0; k < count; ++k) {
+        const int i = nodes[k];
+        rm::NodePatch &p = list[size_t(k)];
+        p.node = i;
+        p.pos = -1;
+        p.x = c->x[i]; p.y = c->y[i]; p.z = c->z[i];
+        p.txpower = c->txpower[i]; p.txprob = c->txprob[i]; p.rxprob = c->rxprob[i];
+        p.channel = c->channel[i];
+        p.enabled = c->enabled[i];
+        const double dv[3] = {p.x - c->org[0], p.y - c->org[1], p.z - c->org[2]};
+        if (std::fabs(dv[0]) > c->coord_bound || std::fabs(dv[1]) > c->coord_bound || std::fabs(dv[2]) > c->coord_bound)
+            frame_changed = true;
+        if (c->rx_dirty || i < first || i >= first + pcount) continue;
+        p.pos = c->h_pos_of[size_t(i - first)];
+        if (!c->rx_sorted) continue;
+        const int g = p.pos / rm::kGroup;
+        const rm_context::GroupBox &b = c->g_box[size_t(g)];
+        const double ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
+        const double v[3] = {p.x, p.y, p.z};
+        bool near = false, far = false;
+        for (int a = 0; a < 3; ++a) {
+            near = near || v[a] < b.lo[a] - 0.125 * ext || v[a] > b.hi[a] + 0.125 * ext;
+            far = far || v[a] < b.lo[a] - 0.5 * ext || v[a] > b.hi[a] + 0.5 * ext;
+        }
+        uint8_t &flag = c->g_escaped[size_t(g)];
+        if (near && !(flag & 1)) {
+            flag |= 1;
+            c->drifted_groups++;
+        }
+        if (far && !(flag & 2)) {
+            flag |= 2;
+            c->escaped_groups++;
+        }
+    }
+    const rm::NodesDev nd = nodes_dev(c);
+    if (count == 1) {
+        RM_HIP(rm::launch_patch_nodes(c->stream, nd, nullptr, 1, list[0]));
+    } else {
+        RM_HIP(c->d_patch.ensure(size_t(count)));
+        RM_HIP(hipMemcpyAsync(c->d_patch.p, list.data(), size_t(count) * sizeof(rm::NodePatch), hipMemcpyHostToDevice, c->stream));
+        RM_HIP(rm::launch_patch_nodes(c->stream, nd, c->d_patch.p, count, list[0]));
+        RM_HIP(hipStreamSynchronize(c->stream)); // the host list goes away
+    }
+    if (frame_changed) recompute_frame(c);
+    c->prefilter_dirty = true;
+    // a far-flung receiver makes its group a candidate for many frames; many slightly grown boxes cost as much
+    if (c->rx_sorted && !c->rx_dirty && (c->escaped_groups > limit || (resort_after < 0 && c->drifted_groups > groups / 4)))
+        c->rx_dirty = true; // sorted again before the next tick
     return RM_OK;
 }
 
@@ -970,6 +1092,7 @@ void rm_destroy(rm_context *c)
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
+    c->d_patch.release();
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();
     for (int g = 0; g < 2; ++g) {
@@ -1141,29 +1264,46 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     return RM_OK;
 }
 
+// keep the cached "can a draw happen" answer across a node change where that is possible
+static void note_probabilities(rm_context *c, double old_rx, double old_tx, double new_rx, double new_tx)
+{
+    if (c->frac_probs < 0) return;
+    const bool was = frac(old_rx) || frac(old_tx), is = frac(new_rx) || frac(new_tx);
+    if (is) c->frac_probs = 1;
+    else if (was && c->frac_probs == 1) c->frac_probs = -1; // it may have been the only one: scan again
+}
+
 int rm_node_update(rm_context *c, int32_t i, double x, double y, double z, double txpower, int32_t channel,
                    uint8_t enabled, double rxprob, double txprob)
 {
     if (!c || i < 0 || i >= c->n) return fail(RM_ERR_INVALID, "node index out of range");
     if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return fail(RM_ERR_INVALID, "position must be finite");
     RM_HIP(hipSetDevice(c->device));
+    note_probabilities(c, c->rxprob[i], c->txprob[i], rxprob, txprob);
     c->x[i] = x; c->y[i] = y; c->z[i] = z; c->txpower[i] = txpower; c->channel[i] = channel;
     c->enabled[i] = enabled; c->rxprob[i] = rxprob; c->txprob[i] = txprob;
-    hipStream_t s = c->stream;
-    RM_HIP(hipMemcpyAsync(c->d_x.p + i, &c->x[i], 8, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_y.p + i, &c->y[i], 8, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_z.p + i, &c->z[i], 8, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_txpower.p + i, &c->txpower[i], 8, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_txprob.p + i, &c->txprob[i], 8, hipMemcpyHostToDevice, s));
-    RM_HIP(hipMemcpyAsync(c->d_channel.p + i, &c->channel[i], 4, hipMemcpyHostToDevice, s));
-    RM_HIP(hipStreamSynchronize(s));
-    const double dv[3] = {x - c->org[0], y - c->org[1], z - c->org[2]};
-    if (std::fabs(dv[0]) > c->coord_bound || std::fabs(dv[1]) > c->coord_bound || std::fabs(dv[2]) > c->coord_bound)
-        recompute_frame(c);
-    c->rx_dirty = true; // the receiver table is rebuilt (and re-sorted) before the next tick
-    c->frac_probs = -1;
-    return RM_OK;
+    return patch_nodes(c, &i, 1);
 }
+
+int rm_nodes_move(rm_context *c, int32_t count, const int32_t *nodes, const double *x, const double *y, const double *z)
+{
+    if (!c || count < 0 || (count > 0 && (!nodes || !x || !y))) return fail(RM_ERR_INVALID, "bad arguments");
+    for (int k = 0; k < count; ++k) {
+        if (nodes[k] < 0 || nodes[k] >= c->n) return fail(RM_ERR_INVALID, "node index out of range");
+        if (!std::isfinite(x[k]) || !std::isfinite(y[k]) || (z && !std::isfinite(z[k])))
+            return fail(RM_ERR_INVALID, "position must be finite");
+    }
+    RM_HIP(hipSetDevice(c->device));
+    for (int k = 0; k < count; ++k) {
+        const int i = nodes[k];
+        c->x[i] = x[k];
+        c->y[i] = y[k];
+        c->z[i] = z ? z[k] : 0.0; // Position.java:44-46: set(x, y) puts z at 0
+    }
+    return patch_nodes(c, nodes, count);
+}
+
+int64_t rm_receiver_table_builds(const rm_context *c) { return c ? c->table_sorts : 0; }
 
 int rm_node_count(const rm_context *c) { return c ? c->n : fail(RM_ERR_INVALID, "ctx is NULL"); }
 

@@ -86,6 +86,15 @@ struct alignas(64) RxRecord {
     double pad[2];
 };
 
+// One changed node (node-config-set, SimulatorJSONHandler.java:102-143): its new state for the source
+// table and, when it is a receiver of this partition with a current table, its engine position.
+struct NodePatch {
+    int32_t node;     // node index
+    int32_t pos;      // engine position in the receiver table, -1 = not a receiver here / table stale
+    double x, y, z, txpower, txprob, rxprob;
+    int32_t channel, enabled;
+};
+
 struct NodesDev {
     int n;                                   // nodes in the simulator
     const double *sx, *sy, *sz, *stxpower, *stxprob;
@@ -200,6 +209,7 @@ struct LaunchCfg {
 
 // kernels' host launchers (rm_filter.hip, rm_exact.hip, rm_reorder.hip, rm_transmit.hip)
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m);
+hipError_t launch_patch_nodes(hipStream_t s, const NodesDev &nd, const NodePatch *dev_list, int n, const NodePatch &one);
 hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n, int64_t start_us,
                           int64_t air_us, rm_tx_record *out);
 hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,

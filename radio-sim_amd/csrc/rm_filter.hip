@@ -69,6 +69,36 @@ __global__ void __launch_bounds__(256) k_wg_boxes(NodesDev nd, int n_wg)
     nd.wg_box_z[b] = z;
 }
 
+// Changed nodes written in place: the source table by node index, the receiver table (SoA arrays
+// and the exact-path record) at the node's engine position.  The engine order stays as it is --
+// it only has to be a permutation; k_prep_rx recomputes the pre-filter records and boxes afterwards.
+__global__ void __launch_bounds__(256) k_patch_nodes(NodesDev nd, const NodePatch *list, int n, NodePatch one)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const NodePatch p = list ? list[i] : one;
+    const_cast<double *>(nd.sx)[p.node] = p.x;
+    const_cast<double *>(nd.sy)[p.node] = p.y;
+    const_cast<double *>(nd.sz)[p.node] = p.z;
+    const_cast<double *>(nd.stxpower)[p.node] = p.txpower;
+    const_cast<double *>(nd.stxprob)[p.node] = p.txprob;
+    const_cast<int32_t *>(nd.schannel)[p.node] = p.channel;
+    if (p.pos < 0) return;
+    const_cast<double *>(nd.x)[p.pos] = p.x;
+    const_cast<double *>(nd.y)[p.pos] = p.y;
+    const_cast<double *>(nd.z)[p.pos] = p.z;
+    const_cast<double *>(nd.rxprob)[p.pos] = p.rxprob;
+    const_cast<int32_t *>(nd.channel)[p.pos] = p.channel;
+    const_cast<uint8_t *>(nd.enabled)[p.pos] = uint8_t(p.enabled);
+    RxRecord *r = const_cast<RxRecord *>(nd.rec) + p.pos;
+    r->x = p.x;
+    r->y = p.y;
+    r->z = p.z;
+    r->rxprob = p.rxprob;
+    r->channel = p.channel;
+    r->enabled = p.enabled;
+}
+
 __global__ void __launch_bounds__(256)
 k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_us, rm_tx_record *out)
 {
@@ -663,6 +693,13 @@ k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict
 }
 
 // ============================================================================ launchers
+
+hipError_t launch_patch_nodes(hipStream_t s, const NodesDev &nd, const NodePatch *dev_list, int n, const NodePatch &one)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_patch_nodes, dim3(cdiv(n, 256)), dim3(256), 0, s, nd, dev_list, n, one);
+    return hipGetLastError();
+}
 
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m)
 {

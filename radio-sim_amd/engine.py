@@ -108,6 +108,17 @@ class Engine:
     def update_node(self, i, x, y, z, txpower, channel, enabled, rxprob, txprob):
         check(self._L.rm_node_update(self._h, i, x, y, z, txpower, channel, enabled, rxprob, txprob))
 
+    def move_nodes(self, nodes, x, y, z=None):
+        """New positions of several nodes in one call (rm_nodes_move)."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        z = None if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        check(self._L.rm_nodes_move(self._h, len(nodes), _ptr(nodes), _ptr(x), _ptr(y), _ptr(z)))
+
+    def receiver_table_builds(self):
+        return int(self._L.rm_receiver_table_builds(self._h))
+
     def set_partition(self, first, count):
         check(self._L.rm_set_partition(self._h, first, count))
 

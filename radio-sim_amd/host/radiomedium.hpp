@@ -201,6 +201,15 @@ public:
     const std::vector<Node *> &getNodes() const { return nodes_; }
     uint64_t nodesVersion() const { return version_; }
     void nodesChanged() { ++version_; } // call after changing fields of existing nodes (no hook in the reference)
+    // the finer hook: one node's fields changed (node-config-set, SimulatorJSONHandler.java:105-143);
+    // the medium writes just these nodes to the device before its next evaluation (rm_node_update)
+    void nodeChanged(const Node *n) { if (n) dirty_.push_back(n->index); }
+    std::vector<int> takeChangedNodes()
+    {
+        std::vector<int> d;
+        d.swap(dirty_);
+        return d;
+    }
     Node *addNode(const std::string &id)
     {
         if (Node *n = getNode(id)) return n; // already handled
@@ -235,6 +244,7 @@ private:
     std::vector<Node *> nodes_;
     std::unordered_map<std::string, Node *> table_;
     uint64_t version_ = 0;
+    std::vector<int> dirty_;
 };
 
 // The receiver-side state machine the verdicts drive (events/ReceptionEvent.java:12-46,
@@ -366,7 +376,20 @@ protected:
 private:
     bool sync(Simulator *sim, const std::vector<Node *> &nodes)
     {
-        if (uploaded_ == sim->nodesVersion()) return true;
+        if (uploaded_ == sim->nodesVersion()) {
+            for (int i : sim->takeChangedNodes()) { // the dirty list: only these nodes go to the device
+                Node &nd = *nodes[size_t(i)];
+                if (rm_node_update(ctx_, i, nd.getPosition().x, nd.getPosition().y, nd.getPosition().z,
+                                   nd.getRadio().getTransmitPower(), nd.getRadio().getWirelessChannel(),
+                                   nd.getRadio().isEnabled(), nd.getRadio().getRxProbability(),
+                                   nd.getRadio().getTxProbability()) != RM_OK) {
+                    lastError = rm_last_error();
+                    return false;
+                }
+            }
+            return true;
+        }
+        (void)sim->takeChangedNodes(); // covered by the snapshot
         const size_t n = nodes.size();
         std::vector<double> x(n), y(n), z(n), tp(n), rp(n), xp(n);
         std::vector<int32_t> ch(n), id(n);

@@ -72,7 +72,18 @@ int main(int argc, char **argv)
         std::string id, hex;
         long long start, now;
         int has_override;
-        in >> id >> start >> now >> hex >> has_override;
+        in >> id;
+        if (id == "@move") { // node-config-set with a new position between two packets
+            std::string who;
+            double x, y, z;
+            in >> who >> x >> y >> z;
+            Node *nd = sim.getNode(who);
+            nd->getPosition().set(x, y, z);
+            sim.nodeChanged(nd);
+            packets.emplace_back(nullptr);
+            continue;
+        }
+        in >> start >> now >> hex >> has_override;
         Node *src = sim.getNode(id);
         if (!src) { std::printf("error could not find source node\n"); continue; } // SimulatorJSONHandler.java:75-77
         packets.emplace_back(new RadioPacket(src, start, hex == "-" ? std::string() : hex));

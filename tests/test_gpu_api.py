@@ -36,6 +36,101 @@ def test_node_update_moves_a_receiver_and_resorts(engine, rsa, O):
         assert_same(gpu, cpu, "after update %d" % step)
 
 
+@pytest.mark.parametrize("kind,params", [("udgm", {}), ("logdist", dict(ld_sigma_db=4.0, ld_seed=9))])
+def test_moved_nodes_are_written_in_place_and_the_table_is_sorted_again_when_it_pays(engine, rsa, O, kind, params):
+    """Mobility: node-config-set with a new position per node (rm_node_update) or the shim's dirty list in
+    one call (rm_nodes_move).  Small moves keep the receiver table's order; results never depend on it."""
+    n = 20000
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd = random_nodes(O, n, side, seed=11)
+    configure_engine(engine, nd, kind, params)
+    mdl = oracle_model(O, kind, params)
+    rng = np.random.default_rng(5)
+    srcs = np.sort(rng.choice(n, 200, replace=False))
+    engine.tick(to_tx_records(rsa, nd.packets(srcs)))
+    builds0 = engine.receiver_table_builds()
+    assert builds0 == 1
+    for step in range(4):
+        # a random walk of 300 nodes (a few metres), flushed in one call; z == None keeps the plane z = 0
+        who = rng.choice(n, 300, replace=False).astype(np.int32)
+        nd.x[who] += rng.normal(0, 3.0, who.size)
+        nd.y[who] += rng.normal(0, 3.0, who.size)
+        engine.move_nodes(who, nd.x[who], nd.y[who])
+        # and some single updates, transmitters among them
+        for i in list(rng.choice(n, 5, replace=False)) + [int(srcs[step])]:
+            nd.x[i] += rng.normal(0, 3.0)
+            nd.channel[i] = 26 if rng.random() < 0.7 else 25
+            engine.update_node(int(i), nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]),
+                               nd.rxprob[i], nd.txprob[i])
+        pk = nd.packets(srcs)
+        assert_same(engine.tick(to_tx_records(rsa, pk)), O.tick(mdl, nd, pk), "random walk %d" % step)
+    assert engine.receiver_table_builds() == builds0, "small moves must not sort the table again"
+    # teleports across the field: correct at once, and after enough of them the table is sorted again
+    for step in range(3):
+        who = rng.choice(n, 40, replace=False).astype(np.int32)
+        nd.x[who] = rng.uniform(0, side, who.size)
+        nd.y[who] = rng.uniform(0, side, who.size)
+        nd.z[who] = rng.uniform(0, 5.0, who.size)
+        engine.move_nodes(who, nd.x[who], nd.y[who], nd.z[who])
+        pk = nd.packets(srcs)
+        assert_same(engine.tick(to_tx_records(rsa, pk)), O.tick(mdl, nd, pk), "teleport %d" % step)
+    assert engine.receiver_table_builds() > builds0
+    # the per-packet call sees the same table
+    i = int(srcs[7])
+    one = engine.transmit(i, 0, 254)
+    ref = O.tick(mdl, nd, nd.packets(np.array([i])))
+    np.testing.assert_array_equal(one.dst, ref.dst)
+    np.testing.assert_array_equal(one.verdict, ref.verdict)
+
+
+def test_moved_nodes_with_a_receiver_partition_and_probabilities(engine, rsa, O):
+    n = 6000
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=12)
+    configure_engine(engine, nd, "udgm", {})
+    mdl = oracle_model(O, "udgm", {})
+    engine.set_partition(2000, 3000)
+    rng = np.random.default_rng(6)
+    srcs = np.sort(rng.choice(n, 120, replace=False))
+    for step in range(3):
+        who = rng.choice(n, 200, replace=False).astype(np.int32)   # receivers of this partition and of others, sources
+        nd.x[who] += rng.normal(0, 10.0, who.size)
+        nd.y[who] += rng.normal(0, 10.0, who.size)
+        engine.move_nodes(who, nd.x[who], nd.y[who])
+        pk = nd.packets(srcs)
+        gpu = engine.tick(to_tx_records(rsa, pk))
+        cpu = O.tick(mdl, nd, pk)
+        keep = (cpu.dst >= 2000) & (cpu.dst < 5000)
+        np.testing.assert_array_equal(gpu.pkt, cpu.pkt[keep])
+        np.testing.assert_array_equal(gpu.dst, cpu.dst[keep])
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict[keep])
+    # rx-loss on one node makes the medium draw; taking it away again stops the draws (the cached answer follows)
+    engine.set_partition(0, n)
+    engine.seed(42)
+    i = int(srcs[3]) + 1
+    nd.rxprob[i] = 0.5
+    engine.update_node(i, nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]), nd.rxprob[i], nd.txprob[i])
+    pk = nd.packets(srcs)
+    cpu = O.tick(mdl, nd, pk, rng_state=O.lib().orc_jrandom_seed(42))
+    assert_same(engine.tick(to_tx_records(rsa, pk)), cpu, "after rx-loss")
+    assert engine.rng_state == cpu.rng_state
+    nd.rxprob[i] = 1.0
+    engine.update_node(i, nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]), nd.rxprob[i], nd.txprob[i])
+    before = engine.rng_state
+    assert_same(engine.tick(to_tx_records(rsa, pk)), O.tick(mdl, nd, pk), "rx-loss removed")
+    assert engine.rng_state == before
+
+
+def test_nodes_move_rejects_bad_input(engine, rsa, O):
+    from radio_sim_amd import _lib
+    nd = random_nodes(O, 100, 300.0, seed=2)
+    configure_engine(engine, nd, "udgm", {})
+    with pytest.raises(_lib.RadioMediumError):
+        engine.move_nodes([100], [0.0], [0.0])
+    with pytest.raises(_lib.RadioMediumError):
+        engine.move_nodes([3], [float("nan")], [0.0])
+    engine.move_nodes(np.zeros(0, np.int32), np.zeros(0), np.zeros(0))   # an empty dirty list
+
+
 def test_error_codes_and_call_sequence(engine, rsa, O):
     from radio_sim_amd import _lib
     L = _lib.lib()

@@ -37,6 +37,9 @@ def _scenario(tmp_path, O, model, nd, ids, packets, extra, seed):
     lines.append(extra)
     lines.append(str(len(packets)))
     for p in packets:
+        if "move" in p:
+            lines.append("@move %s %.17g %.17g %.17g" % ((ids[p["move"]],) + tuple(p["to"])))
+            continue
         o = (" 1 %.17g %d" % (p["txpower"], p["channel"])) if "txpower" in p else " 0"
         lines.append("%s %d %d %s%s" % (p["id"], p["start"], p["now"], p["hex"] or "-", o))
     path = os.path.join(str(tmp_path), "scenario.txt")
@@ -92,6 +95,9 @@ def test_mirror_makes_the_reference_calls(tmp_path, O, model):
         if k % 5 == 0:
             p["txpower"], p["channel"] = -3.5, 26 if k % 10 else 25
         packets.append(p)
+        if k % 4 == 1:     # node-config-set between packets: a neighbour of the next source moves next to it
+            nxt = int(rng.integers(0, n))
+            packets.append({"move": nxt, "to": (nd.x[s] + 3.0, nd.y[s] - 2.0, 0.5)})
     packets.append({"id": "nobody", "start": 0, "now": 0, "hex": "00"})       # unknown source
     packets.append({"id": ids[3], "src": 3, "start": 99000, "now": 0, "hex": ""})   # zero-length payload
 
@@ -109,6 +115,9 @@ def test_mirror_makes_the_reference_calls(tmp_path, O, model):
     state = O.lib().orc_jrandom_seed(seed)
     expected = []
     for k, p in enumerate(packets):
+        if "move" in p:
+            nd.x[p["move"]], nd.y[p["move"]], nd.z[p["move"]] = p["to"]
+            continue
         if "src" not in p:
             continue
         pk = nd.packet(p["src"], p["start"], 32 * len(p["hex"]), txpower=p.get("txpower"), channel=p.get("channel"))
