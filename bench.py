@@ -201,6 +201,11 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=384, 
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner
+    # on the first communicator), so everything but the result line goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.inflight <= 0:
@@ -225,9 +230,12 @@ def main():
     torch.cuda.set_device(device_ordinal)
     dev = torch.device("cuda", device_ordinal)
     dist = None
-    if world > 1:
+    # RM_DIST_SINGLE=1 with --force-sharded: a one-rank process group, so that the collectives of the
+    # sharded driver go through RCCL itself on a box with one GPU
+    if world > 1 or (args.force_sharded and os.environ.get("RM_DIST_SINGLE") == "1"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -497,11 +505,11 @@ def main():
             st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
             out["cpu_baseline"] = st
             out["cpu_baseline_all_cores"] = mt
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
         sys.stdout.flush()
     for e in engines:
         e.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -133,7 +133,7 @@ class ShardedTick:
         self.tick_major = ([torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device)
                             for _ in range(ring)] if batch > 1 else None)
         # one process group (RCCL communicator) per context: their collectives are independent
-        self.groups = ([dist.new_group() for _ in self.engines] if (batch > 1 and world > 1) else None)
+        self.groups = ([dist.new_group() for _ in self.engines] if (batch > 1 and dist is not None) else None)
         self.ready = [torch.cuda.Event() for _ in range(ring)]  # gathered records of the buffer are complete
         self.done = [torch.cuda.Event() for _ in range(ring)]   # the sweep that read the buffer has finished
         self.used = [False] * ring
@@ -155,7 +155,7 @@ class ShardedTick:
             self.comm.wait_event(self.done[b])         # the sweep that last read this buffer
         eng.pack_tx_device_on(self.comm.cuda_stream, dev_src_ptr, self.slots, t_begin, air_us,
                               self.mine[b].data_ptr())
-        if self.world > 1:
+        if self.dist is not None:
             all_gather_records(self.dist, self.mine[b], self.world, self.all[b])
         else:
             self.all[b].copy_(self.mine[b], non_blocking=True)
@@ -181,7 +181,7 @@ class ShardedTick:
                 self.cnt_all = torch.empty(self.world * n_new, dtype=torch.int32, device=self.all[b].device)
             with torch.cuda.stream(stream):
                 eng.draw_counts_to(self.cnt_mine.data_ptr())
-                if self.world > 1:
+                if self.dist is not None:
                     self.dist.all_gather_into_tensor(self.cnt_all, self.cnt_mine)
                 else:
                     self.cnt_all.copy_(self.cnt_mine, non_blocking=True)
@@ -203,7 +203,7 @@ class ShardedTick:
             eng.pack_tx_batch_device_on(stream.cuda_stream, dev_src_ptr, nb, self.slots, t_begins, air_us,
                                         self.mine[ctx].data_ptr())
             src = self.mine[ctx]
-            if self.world > 1:
+            if self.dist is not None:
                 mine, gathered = self.mine[ctx][: nb * row], self.all[ctx][: self.world * nb * row]
                 all_gather_records(self.dist, mine, self.world, gathered, group=self.groups[ctx])
                 # [rank][tick][slot] -> [tick][rank][slot]: a tick's frames in canonical (rank = source range) order

@@ -147,3 +147,26 @@ def test_pipelined_sharded_driver_on_one_gpu():
         outs.append(json.loads(line))
     assert outs[0]["config"]["heard_links_last_tick"] == outs[1]["config"]["heard_links_last_tick"] > 0
     assert outs[1]["value"] > 0
+
+
+def test_batched_sharded_driver_through_rccl_with_one_rank():
+    """The batched multi-GPU tick driver with a real process group: backend "nccl" (= RCCL) with one
+    rank, so that packing, the all-gather on the context's own communicator, the transposition and
+    the batched sweep run on one stream exactly as they do with 8 ranks.  stdout must hold the
+    result line and nothing else (RCCL prints a banner on its first communicator)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra, env in (([], {}), (["--force-sharded", "--inflight", "3", "--batch", "16"], {"RM_DIST_SINGLE": "1"})):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "96",
+                            "--warmup", "16", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MASTER_PORT="29547", **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = p.stdout.splitlines()
+        assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[:500]
+        outs.append(json.loads(lines[0]))
+    assert outs[0]["config"]["heard_links_last_tick"] == outs[1]["config"]["heard_links_last_tick"] > 0
+    assert outs[1]["config"]["ticks_per_launch"] == 16 and outs[1]["value"] > 0
