@@ -177,6 +177,21 @@ int rm_tick_flush(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict,
                   uint8_t *pkt_interference /* [n_new] or NULL */,
                   uint32_t *pkt_offset /* [n_new+1] or NULL */);
 
+/* The same without the copy: the engine's last kernel writes the tick's result into pinned,
+ * host-mapped memory the context owns, and the caller reads it in place (a JNI shim wraps the
+ * arrays in direct ByteBuffers).  The pointers stay valid until the next call that evaluates
+ * anything on this context.  `count` records are there; an error is reported as by rm_tick_flush. */
+typedef struct rm_host_result {
+    uint32_t count;                  /* heard links */
+    uint32_t n_packets;              /* frames of this tick */
+    const uint32_t *pkt_offset;      /* [n_packets + 1] first link of every packet */
+    const uint8_t *pkt_interference; /* [n_packets] Tx-failure flag (UDGMRadioMedium.java:88-92) */
+    const int32_t *pkt, *dst;        /* [count] packet, receiver node index (ascending per packet) */
+    const uint8_t *verdict;          /* [count] RM_INTERFERED / RM_DELIVERED */
+    const double *rssi, *sinr;       /* [count] */
+} rm_host_result;
+int rm_tick_flush_view(rm_context *ctx, rm_host_result *out);
+
 /* evaluate the enqueued tick without copying anything out (then rm_result_copy / rm_result_device) */
 int rm_tick_run(rm_context *ctx);
 

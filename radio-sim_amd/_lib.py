@@ -54,6 +54,12 @@ class DeviceResult(C.Structure):
                 ("verdict", C.c_void_p), ("rssi", C.c_void_p), ("sinr", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class HostResult(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("n_packets", C.c_uint32), ("pkt_offset", C.c_void_p),
+                ("pkt_interference", C.c_void_p), ("pkt", C.c_void_p), ("dst", C.c_void_p), ("verdict", C.c_void_p),
+                ("rssi", C.c_void_p), ("sinr", C.c_void_p)]
+
+
 def library_path():
     return _SO
 
@@ -108,6 +114,7 @@ SIGNATURES = {
     "rm_enqueue_tx_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rm_tick_flush": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
+    "rm_tick_flush_view": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rm_tick_run": (C.c_int, [C.c_void_p]),
     "rm_draws_pending": (C.c_int, [C.c_void_p]),
     "rm_draw_counts_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),

@@ -195,6 +195,16 @@ struct rm_context : TickSlot {
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
     rm::TransmitResult *h_transmit = nullptr; // host-mapped result block of rm_transmit
+    // host-mapped result block of rm_tick_flush*: the last kernel of a flushed tick writes header,
+    // offsets and records there, the host waits for the header's sequence number
+    char *h_stage = nullptr;
+    uint32_t stage_links = 0, stage_packets = 0, stage_seq = 0;
+    DevBuf<uint32_t> d_pack_done;
+    // pinned staging of the Tx records of rm_tick_begin / rm_enqueue_tx* (two buffers, each guarded by an event)
+    rm_tx_record *h_tx[2] = {nullptr, nullptr};
+    size_t h_tx_n[2] = {0, 0};
+    hipEvent_t h_tx_ev[2] = {nullptr, nullptr};
+    int h_tx_gen = 0;
     uint32_t transmit_seq = 0;
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
     // larger batches upload them with one copy from pinned host memory (two staging buffers, each
@@ -1100,6 +1110,12 @@ void rm_destroy(rm_context *c)
         if (c->h_ticks[g]) (void)hipHostFree(c->h_ticks[g]);
     }
     if (c->h_transmit) (void)hipHostFree(c->h_transmit);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->d_pack_done.release();
+    for (int g = 0; g < 2; ++g) {
+        if (c->h_tx_ev[g]) (void)hipEventDestroy(c->h_tx_ev[g]);
+        if (c->h_tx[g]) (void)hipHostFree(c->h_tx[g]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1416,6 +1432,78 @@ static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uin
     return RM_OK;
 }
 
+// ---- a flushed tick's result in host-mapped memory --------------------------------------------------
+
+static size_t pad64(size_t v) { return (v + 63) & ~size_t(63); }
+
+static rm::HostView stage_view(char *base, uint32_t links, uint32_t packets, size_t *bytes)
+{
+    rm::HostView v{};
+    size_t o = 0;
+    v.hdr = reinterpret_cast<rm::HostHeader *>(base + o); o += pad64(sizeof(rm::HostHeader));
+    v.pkt_offset = reinterpret_cast<uint32_t *>(base + o); o += pad64((size_t(packets) + 1) * 4);
+    v.pkt_interference = reinterpret_cast<uint8_t *>(base + o); o += pad64(size_t(packets) + 1);
+    v.pkt = reinterpret_cast<int32_t *>(base + o); o += pad64(size_t(links) * 4);
+    v.dst = reinterpret_cast<int32_t *>(base + o); o += pad64(size_t(links) * 4);
+    v.rssi = reinterpret_cast<double *>(base + o); o += pad64(size_t(links) * 8);
+    v.sinr = reinterpret_cast<double *>(base + o); o += pad64(size_t(links) * 8);
+    v.verdict = reinterpret_cast<uint8_t *>(base + o); o += pad64(size_t(links) + 1);
+    v.links = links;
+    v.packets = packets;
+    if (bytes) *bytes = o;
+    return v;
+}
+
+static int ensure_stage(rm_context *c, uint32_t links, uint32_t packets)
+{
+    if (c->h_stage && links <= c->stage_links && packets <= c->stage_packets) return RM_OK;
+    links = std::max(links, std::max(c->stage_links, 1u << 16));
+    packets = std::max(packets, std::max(c->stage_packets, 1u << 12));
+    size_t bytes = 0;
+    (void)stage_view(nullptr, links, packets, &bytes);
+    RM_HIP(hipStreamSynchronize(c->stream)); // nothing may still write the old block
+    if (c->h_stage) RM_HIP(hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->stage_links = c->stage_packets = 0;
+    RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_stage), bytes, hipHostMallocMapped));
+    std::memset(c->h_stage, 0, pad64(sizeof(rm::HostHeader)));
+    c->stage_links = links;
+    c->stage_packets = packets;
+    if (!c->d_pack_done.p) {
+        RM_HIP(c->d_pack_done.ensure(1));
+        RM_HIP(hipMemsetAsync(c->d_pack_done.p, 0, sizeof(uint32_t), c->stream));
+    }
+    return RM_OK;
+}
+
+// pack the evaluated tick of slot `ts` into the host-mapped block and wait for it
+static int pack_to_stage(rm_context *c, TickSlot &ts, rm::HostView *view)
+{
+    if (ts.draws_pending)
+        return fail(RM_ERR_STATE, "this rank's verdicts wait for the other ranks' draw counts: exchange "
+                                  "rm_draw_counts_device and call rm_tick_finish_draws first");
+    const int n_new = std::max(ts.last_n_new, 0);
+    const int have_offsets = (n_new > 0 && part_count(c) > 0) ? 1 : 0;
+    RM_TRY(ensure_stage(c, 0, uint32_t(n_new)));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const rm::HostView v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
+        const uint32_t seq = ++c->stage_seq;
+        RM_HIP(rm::launch_pack_tick(c->stream, ts.last, n_new, have_offsets, v, c->d_pack_done.p, seq));
+        // poll the sequence number (the kernel publishes it after everything else); a stream
+        // synchronisation bounds the wait
+        volatile const uint32_t *flag = &v.hdr->seq;
+        bool seen = false;
+        for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+        if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+        if (v.hdr->total <= v.links || v.hdr->dropped) {
+            *view = v;
+            return RM_OK;
+        }
+        RM_TRY(ensure_stage(c, std::max(v.hdr->total, 2u * v.links), uint32_t(n_new))); // more links than the block held
+    }
+    return fail(RM_ERR_HIP, "result block could not be sized");
+}
+
 static int tick_run_host(rm_context *c);
 
 int rm_tick_run(rm_context *c)
@@ -1424,12 +1512,55 @@ int rm_tick_run(rm_context *c)
     return tick_run_host(c);
 }
 
+static int stage_status(const rm::HostView &v)
+{
+    if (v.hdr->span_flag)
+        return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
+    if (v.hdr->dropped) return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    return RM_OK;
+}
+
+int rm_tick_flush_view(rm_context *c, rm_host_result *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    RM_TRY(tick_run_host(c));
+    rm::HostView v{};
+    RM_TRY(pack_to_stage(c, *c, &v));
+    out->count = v.hdr->stored;
+    out->n_packets = v.hdr->n_packets;
+    out->pkt_offset = v.pkt_offset;
+    out->pkt_interference = v.pkt_interference;
+    out->pkt = v.pkt;
+    out->dst = v.dst;
+    out->verdict = v.verdict;
+    out->rssi = v.rssi;
+    out->sinr = v.sinr;
+    return stage_status(v);
+}
+
 int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
                   uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     RM_TRY(tick_run_host(c));
-    return copy_out(c, *c, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+    rm::HostView v{};
+    RM_TRY(pack_to_stage(c, *c, &v));
+    if (v.hdr->span_flag) return stage_status(v);
+    if (count) *count = v.hdr->total;
+    const uint32_t k = std::min(v.hdr->stored, cap);
+    if (k) {
+        if (pkt) std::memcpy(pkt, v.pkt, k * sizeof(int32_t));
+        if (dst) std::memcpy(dst, v.dst, k * sizeof(int32_t));
+        if (verdict) std::memcpy(verdict, v.verdict, k);
+        if (rssi) std::memcpy(rssi, v.rssi, k * sizeof(double));
+        if (sinr) std::memcpy(sinr, v.sinr, k * sizeof(double));
+    }
+    const uint32_t np = v.hdr->n_packets;
+    if (pkt_interference && np) std::memcpy(pkt_interference, v.pkt_interference, np);
+    if (pkt_offset) std::memcpy(pkt_offset, v.pkt_offset, (size_t(np) + 1) * sizeof(uint32_t));
+    RM_TRY(stage_status(v));
+    if (v.hdr->total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
+    return RM_OK;
 }
 
 // evaluate the tick enqueued with rm_tick_begin / rm_enqueue_tx* (results stay on the device)
@@ -1440,17 +1571,30 @@ static int tick_run_host(rm_context *c)
     RM_HIP(hipSetDevice(c->device));
     c->in_tick = false;
     const int first_new = int(c->onair.size());
-    std::vector<rm_tx_record> all;
-    all.reserve(c->onair.size() + c->pending.size());
-    all.insert(all.end(), c->onair.begin(), c->onair.end());
-    all.insert(all.end(), c->pending.begin(), c->pending.end());
-    RM_HIP(c->d_tx.ensure(std::max<size_t>(all.size(), 1)));
-    if (!all.empty())
-        RM_HIP(hipMemcpyAsync(c->d_tx.p, all.data(), all.size() * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
-    // the host vector must outlive the async copy
-    RM_HIP(hipStreamSynchronize(c->stream));
-    RM_TRY(run_tick(c, c->d_tx.p, int(all.size()), first_new));
-    if (is_sinr(c)) c->onair.swap(all);
+    const size_t total = c->onair.size() + c->pending.size();
+    RM_HIP(c->d_tx.ensure(std::max<size_t>(total, 1)));
+    if (total) {
+        // through pinned staging: the copy is asynchronous, the buffer is reused only after its copy has completed
+        const int g = c->h_tx_gen;
+        c->h_tx_gen ^= 1;
+        if (!c->h_tx_ev[g]) RM_HIP(hipEventCreateWithFlags(&c->h_tx_ev[g], hipEventDisableTiming));
+        else RM_HIP(hipEventSynchronize(c->h_tx_ev[g]));
+        if (c->h_tx_n[g] < total) {
+            if (c->h_tx[g]) RM_HIP(hipHostFree(c->h_tx[g]));
+            c->h_tx[g] = nullptr;
+            c->h_tx_n[g] = 0;
+            const size_t want = std::max<size_t>(total + total / 2, 1024);
+            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_tx[g]), want * sizeof(rm_tx_record), hipHostMallocDefault));
+            c->h_tx_n[g] = want;
+        }
+        if (!c->onair.empty()) std::memcpy(c->h_tx[g], c->onair.data(), c->onair.size() * sizeof(rm_tx_record));
+        if (!c->pending.empty())
+            std::memcpy(c->h_tx[g] + c->onair.size(), c->pending.data(), c->pending.size() * sizeof(rm_tx_record));
+        RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipEventRecord(c->h_tx_ev[g], c->stream));
+    }
+    RM_TRY(run_tick(c, c->d_tx.p, int(total), first_new));
+    if (is_sinr(c)) c->onair.insert(c->onair.end(), c->pending.begin(), c->pending.end());
     c->pending.clear();
     return RM_OK;
 }

@@ -199,6 +199,27 @@ struct TransmitResult {
     uint8_t verdict[kTransmitMax];
 };
 
+// A tick's result in host-mapped memory (rm_tick_flush*): header, then the arrays at the offsets the
+// host computed for `links` records and `packets` packets.
+struct HostHeader {
+    uint32_t stored;      // records written (min(total, links))
+    uint32_t dropped;     // the context's link capacity was exceeded
+    uint32_t total;       // heard links of the tick
+    uint32_t span_flag;   // a SINR tick held a frame outside its span
+    uint32_t n_packets;
+    uint32_t seq;         // written last
+    uint32_t pad[10];
+};
+struct HostView {
+    HostHeader *hdr;
+    uint32_t *pkt_offset;       // [packets + 1]
+    uint8_t *pkt_interference;  // [packets]
+    int32_t *pkt, *dst;
+    double *rssi, *sinr;
+    uint8_t *verdict;
+    uint32_t links, packets;    // room
+};
+
 struct LaunchCfg {
     bool f64_filter;  // fp32 frame too coarse: filter in fp64, no bounding boxes
     bool stochastic;  // java.util.Random draws may be consumed
@@ -215,6 +236,8 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
 hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
                                 const int64_t *start_us, int64_t air_us, rm_tx_record *out);
 hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst);
+hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int pkt_shift_valid, const HostView &v, uint32_t *done_counter,
+                            uint32_t seq);
 hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped);
 hipError_t launch_transmit_one(hipStream_t s, const NodesDev &nd, const ModelDev &m, const rm_tx_record &tx,
                                uint64_t *rng_state, TransmitResult *host_mapped, uint32_t seq);

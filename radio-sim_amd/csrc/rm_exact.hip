@@ -20,7 +20,10 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
     __shared__ uint32_t s_sn[PACKED ? kShards : 1];     // entries per shard
     const bool publisher = (blockIdx.x == 0 && blockIdx.y == 0);
     bool scanned = false; // the scan is only needed by the scatter: it runs after the first evaluation
-    const uint32_t n_own = min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
+    // A tick whose candidates did not fit the link capacity is reported as RM_ERR_CAPACITY; its shards
+    // hold gaps where runs were dropped, so none of its entries is touched (no link of it is reported).
+    const bool dropped = t.stage_count[1] != 0u;
+    const uint32_t n_own = dropped ? 0u : min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
     constexpr bool kRegScan = (SEG == 3 || SEG == 4);
     SmallCounts<scan_per(SEG)> pre{};
     if (kRegScan && !PACKED && (blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
@@ -251,7 +254,7 @@ RM_D bool frames_overlap(const rm_tx_record &w, const rm_tx_record &k)
 // sum the co-channel, time-overlapping interferers exactly (Q80), apply capture + half duplex
 RM_D void sinr_body(const ModelDev &m, const TickDev &t)
 {
-    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    const uint32_t n = t.stage_count[1] ? 0u : min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap); // nothing of a dropped tick
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t e = blockIdx.y * t.seg_cap + i;
         if (!(t.st_flags[e] & kFlagHeardNew)) continue;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t *cnt, uint3
 template <bool STOCH>
 __global__ void __launch_bounds__(256) k_finalize(ModelDev m, TickDev t)
 {
-    const uint32_t n = min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap);
+    const uint32_t n = t.stage_count[1] ? 0u : min(t.shard_count[blockIdx.y * kShardStride], t.seg_cap); // nothing of a dropped tick
     const uint32_t stride = gridDim.x * blockDim.x;
     const int per_slab = kGroup * t.rpt;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

@@ -56,6 +56,41 @@ __global__ void __launch_bounds__(256) k_pack_result(TickDev t, TransmitResult *
     }
 }
 
+// The tick's records, offsets and per-packet flags written straight into host-mapped memory; the
+// workgroup that finishes last publishes the sequence number the host waits for.
+__global__ void __launch_bounds__(256)
+k_pack_tick(TickDev t, int n_new, int have_offsets, HostView v, uint32_t *done_counter, uint32_t seq)
+{
+    const uint32_t total = t.out_count[2];
+    const uint32_t n = min(min(t.out_count[0], total), v.links);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    for (uint32_t i = tid; i < n; i += step) {
+        v.pkt[i] = t.out_pkt[i];
+        v.dst[i] = t.out_dst[i];
+        v.verdict[i] = t.out_verdict[i];
+        v.rssi[i] = t.out_rssi[i];
+        v.sinr[i] = t.out_sinr[i];
+    }
+    const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
+    for (uint32_t i = tid; i < np; i += step) v.pkt_interference[i] = t.pkt_interference[i];
+    for (uint32_t i = tid; i <= np; i += step) v.pkt_offset[i] = have_offsets ? t.slot_off[t.shift + i] : 0u;
+    __threadfence_system();
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        *done_counter = 0u;
+        v.hdr->stored = n;
+        v.hdr->dropped = t.out_count[1];
+        v.hdr->total = total;
+        v.hdr->span_flag = t.out_count[4];
+        v.hdr->n_packets = uint32_t(max(n_new, 0));
+        __threadfence_system();
+        __hip_atomic_store(&v.hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One packet in ONE launch of ONE workgroup (geometric media on a sorted table): the frame is tested
 // against the boxes of 1024 receivers (one per thread), the group boxes of the near ones, then the
 // receivers of the near groups (one wave per group); the few hits are evaluated exactly on the
@@ -248,6 +283,14 @@ hipError_t launch_transmit_one(hipStream_t s, const NodesDev &nd, const ModelDev
     case RM_MODEL_LOGDIST: hipLaunchKernelGGL(k_transmit_one<RM_MODEL_LOGDIST>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int have_offsets, const HostView &v, uint32_t *done_counter,
+                            uint32_t seq)
+{
+    // enough workgroups to keep the PCIe writes streaming, few enough for a short tail
+    hipLaunchKernelGGL(k_pack_tick, dim3(64), dim3(256), 0, s, t, n_new, have_offsets, v, done_counter, seq);
     return hipGetLastError();
 }
 

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ModelParams, DeviceResult, TX_RECORD_DTYPE, check
+from ._lib import ModelParams, DeviceResult, HostResult, TX_RECORD_DTYPE, check
 
 
 def _ptr(a):
@@ -180,6 +180,24 @@ class Engine:
                                     sinr.ctypes.data, cap, C.byref(cnt), pint.ctypes.data, poff.ctypes.data))
         k = cnt.value
         return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
+
+    def tick_flush_view(self):
+        """Evaluate the enqueued tick; the result stays in the engine's pinned host block and is wrapped,
+        not copied (valid until the next evaluating call on this engine)."""
+        n_new = self._n_new
+        r = HostResult()
+        check(self._L.rm_tick_flush_view(self._h, C.byref(r)))
+
+        def arr(ptr, dtype, count):
+            if count == 0 or not ptr:
+                return np.empty(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count)
+        k = r.count
+        assert r.n_packets == n_new
+        return TickResult(k, arr(r.pkt, np.int32, k), arr(r.dst, np.int32, k), arr(r.verdict, np.uint8, k),
+                          arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k), arr(r.pkt_interference, np.uint8, n_new),
+                          arr(r.pkt_offset, np.uint32, n_new + 1))
 
     def tick_run(self):
         """Evaluate the enqueued tick; results stay on the device (result_copy / result_device)."""

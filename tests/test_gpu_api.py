@@ -131,6 +131,54 @@ def test_nodes_move_rejects_bad_input(engine, rsa, O):
     engine.move_nodes(np.zeros(0, np.int32), np.zeros(0), np.zeros(0))   # an empty dirty list
 
 
+@pytest.mark.parametrize("kind,params,n,t", [
+    ("udgm", {}, 3000, 10),
+    ("udgm", {"udgm_success_ratio_rx": 0.8}, 20000, 300),          # draws
+    ("logdist", dict(ld_sigma_db=4.0, ld_seed=3), 20000, 5000),     # more links and packets than the first block holds
+    ("logdist", dict(ld_sigma_db=4.0, ld_seed=3, ld_flags=1), 5000, 200),   # SINR
+    ("null", {}, 300, 3),                                           # unsorted table
+])
+def test_flush_into_the_pinned_block_equals_the_oracle(engine, rsa, O, kind, params, n, t):
+    """rm_tick_flush_view: the result is read in place from the engine's host-mapped block;
+    rm_tick_flush copies from the same block."""
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=n + t)
+    configure_engine(engine, nd, kind, params)
+    mdl = oracle_model(O, kind, params)
+    rng = np.random.default_rng(t)
+    state = O.lib().orc_jrandom_seed(5)
+    engine.seed(5)
+    for step in range(3):
+        srcs = np.sort(rng.choice(n, t, replace=False))
+        pk = nd.packets(srcs, 1000 * step, 320)
+        cpu = O.tick(mdl, nd, pk, rng_state=state)
+        state = cpu.rng_state
+        engine.tick_begin(1000 * step, 1000 * step + 1000)
+        engine.enqueue_records(to_tx_records(rsa, pk))
+        gpu = engine.tick_flush_view() if step != 1 else engine.tick_flush()
+        assert_same(gpu, cpu, "step %d" % step)
+        np.testing.assert_array_equal(gpu.pkt_interference, cpu.pkt_interference)
+        np.testing.assert_array_equal(np.diff(gpu.pkt_offset.astype(np.int64)), np.bincount(cpu.pkt, minlength=t))
+        assert engine.rng_state == state
+    # an empty tick
+    engine.tick_begin(9000, 10000)
+    empty = engine.tick_flush_view()
+    assert empty.count == 0 and len(empty.pkt_offset) == 1 and empty.pkt_offset[0] == 0
+
+
+def test_flush_view_reports_capacity_like_the_copying_flush(engine, rsa, O):
+    from radio_sim_amd import _lib
+    n = 4000
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=8)
+    configure_engine(engine, nd, "udgm", {})
+    engine.set_link_capacity(256)
+    pk = nd.packets(np.arange(0, n, 4))
+    engine.tick_begin(0, 1000)
+    engine.enqueue_records(to_tx_records(rsa, pk))
+    with pytest.raises(_lib.RadioMediumError) as e:
+        engine.tick_flush_view()
+    assert e.value.code == _lib.RM_ERR_CAPACITY
+
+
 def test_error_codes_and_call_sequence(engine, rsa, O):
     from radio_sim_amd import _lib
     L = _lib.lib()

@@ -23,3 +23,32 @@ for name, kind, kw in (("udgm", rsa.MODEL_UDGM, {}), ("logdist_shadow", rsa.MODE
     dt = (time.perf_counter() - t0) / 250
     print("%-15s N=%d  rm_transmit: %.1f us per packet (%.1f heard links each)" % (name, n, dt * 1e6, heard / 250))
     eng.close()
+
+# one tick through host buffers: records in (rm_enqueue_tx_records), heard links out (rm_tick_flush)
+eng = rsa.Engine(0)
+eng.upload_table(nodes)
+eng.set_model(rsa.MODEL_LOGDIST, **W.model_kwargs("logdist_shadow")[1])
+for T in (10, 100, 1000):
+    srcs = np.sort(np.random.default_rng(2).choice(n, T, replace=False))
+    recs = np.zeros(T, dtype=rsa.TX_RECORD_DTYPE)
+    recs["x"], recs["y"], recs["z"] = nodes.x[srcs], nodes.y[srcs], nodes.z[srcs]
+    recs["txpower"], recs["txprob"], recs["channel"] = nodes.txpower[srcs], nodes.txprob[srcs], nodes.channel[srcs]
+    recs["src"], recs["air_us"] = srcs, W.AIR_US
+    for _ in range(5):
+        res = eng.tick(recs, 0, 1000, cap=1 << 17)
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = eng.tick(recs, 0, 1000, cap=1 << 17)
+    dt = (time.perf_counter() - t0) / reps
+    print("rm_tick_flush       N=%d  T=%-5d %.1f us per tick, host buffers in and out (%d heard links, %.2f MB out) = %.2e links/s"
+          % (n, T, dt * 1e6, res.count, res.count * 25 / 1e6, T * (n - 1) / dt))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.tick_begin(0, 1000)
+        eng.enqueue_records(recs)
+        res = eng.tick_flush_view()
+    dt = (time.perf_counter() - t0) / reps
+    print("rm_tick_flush_view  N=%d  T=%-5d %.1f us per tick, records in, result read in place = %.2e links/s"
+          % (n, T, dt * 1e6, T * (n - 1) / dt))
+eng.close()
