@@ -264,6 +264,11 @@ int rm_batch_result_count(rm_context *ctx, int32_t slot, uint32_t *count, uint32
 int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,
                          double *sinr, uint32_t cap, uint32_t *count, uint8_t *pkt_interference,
                          uint32_t *pkt_offset);
+/* The results of slots 0 .. n_slots-1 in the context's pinned, host-mapped block: one packing
+ * launch, one wait; out[b] points into the block (valid until the next evaluating call).
+ * status (may be NULL) gets every slot's own RM_OK / RM_ERR_CAPACITY / RM_ERR_STATE; the return
+ * value is the first of them that is not RM_OK. */
+int rm_batch_result_view(rm_context *ctx, int32_t n_slots, rm_host_result *out, int32_t *status);
 
 /* Per-stage timing on the context's stream: on every `every_n`-th tick each stage of the launch
  * sequence is bracketed by HIP events (0 = off; an event costs microseconds of stream time on

@@ -114,6 +114,7 @@ SIGNATURES = {
     "rm_enqueue_tx_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rm_tick_flush": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
+    "rm_batch_result_view": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rm_tick_flush_view": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rm_tick_run": (C.c_int, [C.c_void_p]),
     "rm_draws_pending": (C.c_int, [C.c_void_p]),

@@ -200,6 +200,8 @@ struct rm_context : TickSlot {
     char *h_stage = nullptr;
     uint32_t stage_links = 0, stage_packets = 0, stage_seq = 0;
     DevBuf<uint32_t> d_pack_done;
+    DevBuf<rm::PackSlot> d_pack;    // descriptors of rm_batch_result_view
+    rm::PackSlot *h_pack = nullptr; // their pinned staging
     // pinned staging of the Tx records of rm_tick_begin / rm_enqueue_tx* (two buffers, each guarded by an event)
     rm_tx_record *h_tx[2] = {nullptr, nullptr};
     size_t h_tx_n[2] = {0, 0};
@@ -1111,6 +1113,8 @@ void rm_destroy(rm_context *c)
     }
     if (c->h_transmit) (void)hipHostFree(c->h_transmit);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
+    c->d_pack.release();
     c->d_pack_done.release();
     for (int g = 0; g < 2; ++g) {
         if (c->h_tx_ev[g]) (void)hipEventDestroy(c->h_tx_ev[g]);
@@ -1441,6 +1445,7 @@ static rm::HostView stage_view(char *base, uint32_t links, uint32_t packets, siz
     rm::HostView v{};
     size_t o = 0;
     v.hdr = reinterpret_cast<rm::HostHeader *>(base + o); o += pad64(sizeof(rm::HostHeader));
+    o += pad64(sizeof(rm::BatchCounts) * RM_MAX_BATCH); // per-slot counts of rm_batch_result_view (stage_counts)
     v.pkt_offset = reinterpret_cast<uint32_t *>(base + o); o += pad64((size_t(packets) + 1) * 4);
     v.pkt_interference = reinterpret_cast<uint8_t *>(base + o); o += pad64(size_t(packets) + 1);
     v.pkt = reinterpret_cast<int32_t *>(base + o); o += pad64(size_t(links) * 4);
@@ -1453,6 +1458,8 @@ static rm::HostView stage_view(char *base, uint32_t links, uint32_t packets, siz
     if (bytes) *bytes = o;
     return v;
 }
+
+static rm::BatchCounts *stage_counts(char *base) { return reinterpret_cast<rm::BatchCounts *>(base + pad64(sizeof(rm::HostHeader))); }
 
 static int ensure_stage(rm_context *c, uint32_t links, uint32_t packets)
 {
@@ -2086,6 +2093,68 @@ int rm_batch_result_copy(rm_context *c, int32_t slot, int32_t *pkt, int32_t *dst
     if (!ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
     return copy_out(c, *ts, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+}
+
+int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, int32_t *status)
+{
+    if (!c || !out || n_slots < 1 || n_slots > RM_MAX_BATCH) return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    if (!c->h_pack) RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pack), sizeof(rm::PackSlot) * RM_MAX_BATCH, hipHostMallocDefault));
+    RM_HIP(c->d_pack.ensure(RM_MAX_BATCH));
+    uint32_t packets = 0;
+    for (int b = 0; b < n_slots; ++b) {
+        TickSlot *ts = slot_of(c, b);
+        if (!ts || !ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick in this result slot");
+        if (ts->draws_pending) return fail(RM_ERR_STATE, "a slot's verdicts wait for rm_tick_finish_draws");
+        rm::PackSlot &ps = c->h_pack[b];
+        ps.t = ts->last;
+        ps.n_new = std::max(ts->last_n_new, 0);
+        ps.have_offsets = (ps.n_new > 0 && part_count(c) > 0) ? 1 : 0;
+        ps.pkt_base = packets;
+        ps.pad = 0;
+        packets += uint32_t(ps.n_new);
+    }
+    RM_TRY(ensure_stage(c, 0, packets + uint32_t(n_slots)));
+    RM_HIP(hipMemcpyAsync(c->d_pack.p, c->h_pack, sizeof(rm::PackSlot) * size_t(n_slots), hipMemcpyHostToDevice, c->stream));
+    rm::HostView v{};
+    rm::BatchCounts *counts = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
+        counts = stage_counts(c->h_stage);
+        const uint32_t seq = ++c->stage_seq;
+        RM_HIP(rm::launch_pack_batch(c->stream, c->d_pack.p, n_slots, v, counts, c->d_pack_done.p, seq));
+        volatile const uint32_t *flag = &v.hdr->seq;
+        bool seen = false;
+        for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+        if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+        const uint64_t need = uint64_t(counts[n_slots - 1].link_base) + counts[n_slots - 1].stored;
+        if (need <= v.links) break;
+        if (attempt) return fail(RM_ERR_HIP, "result block could not be sized");
+        RM_TRY(ensure_stage(c, uint32_t(std::min<uint64_t>(need + need / 4, 0xFFFFFFFFu)), packets + uint32_t(n_slots)));
+    }
+    int first_error = RM_OK;
+    for (int b = 0; b < n_slots; ++b) {
+        const rm::BatchCounts &bc = counts[b];
+        const rm::PackSlot &ps = c->h_pack[b];
+        rm_host_result &r = out[b];
+        r.count = bc.stored;
+        r.n_packets = uint32_t(ps.n_new);
+        r.pkt_offset = v.pkt_offset + ps.pkt_base + uint32_t(b);
+        r.pkt_interference = v.pkt_interference + ps.pkt_base;
+        r.pkt = v.pkt + bc.link_base;
+        r.dst = v.dst + bc.link_base;
+        r.verdict = v.verdict + bc.link_base;
+        r.rssi = v.rssi + bc.link_base;
+        r.sinr = v.sinr + bc.link_base;
+        int st = RM_OK;
+        if (bc.span_flag)
+            st = fail(RM_ERR_STATE, "a frame of a SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
+        else if (bc.dropped)
+            st = fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+        if (status) status[b] = st;
+        if (st != RM_OK && first_error == RM_OK) first_error = st;
+    }
+    return first_error;
 }
 
 int rm_sync(rm_context *c)

@@ -220,6 +220,17 @@ struct HostView {
     uint32_t links, packets;    // room
 };
 
+// rm_batch_result_view: the results of several slots packed back to back into the host-mapped block.
+struct PackSlot {
+    TickDev t;
+    int n_new, have_offsets;
+    uint32_t pkt_base;      // first packet of this slot in the block's packet arrays (offsets: pkt_base + slot index)
+    uint32_t pad;
+};
+struct BatchCounts {        // per slot, in the host-mapped block
+    uint32_t stored, dropped, total, span_flag, link_base, pad[3];
+};
+
 struct LaunchCfg {
     bool f64_filter;  // fp32 frame too coarse: filter in fp64, no bounding boxes
     bool stochastic;  // java.util.Random draws may be consumed
@@ -238,6 +249,8 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
 hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst);
 hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int pkt_shift_valid, const HostView &v, uint32_t *done_counter,
                             uint32_t seq);
+hipError_t launch_pack_batch(hipStream_t s, const PackSlot *dev_slots, int n_slots, const HostView &v, BatchCounts *host_counts,
+                             uint32_t *done_counter, uint32_t seq);
 hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped);
 hipError_t launch_transmit_one(hipStream_t s, const NodesDev &nd, const ModelDev &m, const rm_tx_record &tx,
                                uint64_t *rng_state, TransmitResult *host_mapped, uint32_t seq);

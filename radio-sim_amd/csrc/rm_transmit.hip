@@ -91,6 +91,61 @@ k_pack_tick(TickDev t, int n_new, int have_offsets, HostView v, uint32_t *done_c
     }
 }
 
+// The same for the slots of a batch: blockIdx.y = slot; the slots' records are packed back to back
+// (a slot's first record = the sum of the records of the slots before it, recomputed by every
+// workgroup from the slots' counters), the packet arrays at the bases the host computed.
+__global__ void __launch_bounds__(256)
+k_pack_batch(const PackSlot *__restrict__ slots, int n_slots, HostView v, BatchCounts *counts, uint32_t *done_counter, uint32_t seq)
+{
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_last;
+    const int b = blockIdx.y;
+    uint32_t before = 0;
+    for (int a = threadIdx.x; a < b; a += blockDim.x) {
+        const uint32_t *oc = slots[a].t.out_count;
+        before += min(oc[0], oc[2]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) before += uint32_t(__shfl_xor(int(before), d));
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const uint32_t link_base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    const PackSlot &ps = slots[b];
+    const TickDev &t = ps.t;
+    const uint32_t total = t.out_count[2];
+    const uint32_t stored = min(t.out_count[0], total);
+    const uint32_t n = (link_base + stored <= v.links) ? stored : 0u; // no room: the host grows the block and packs again
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    for (uint32_t i = tid; i < n; i += step) {
+        const uint32_t o = link_base + i;
+        v.pkt[o] = t.out_pkt[i];
+        v.dst[o] = t.out_dst[i];
+        v.verdict[o] = t.out_verdict[i];
+        v.rssi[o] = t.out_rssi[i];
+        v.sinr[o] = t.out_sinr[i];
+    }
+    const uint32_t np = uint32_t(max(ps.n_new, 0));
+    for (uint32_t i = tid; i < np; i += step) v.pkt_interference[ps.pkt_base + i] = t.pkt_interference[i];
+    for (uint32_t i = tid; i <= np; i += step) v.pkt_offset[ps.pkt_base + uint32_t(b) + i] = ps.have_offsets ? t.slot_off[t.shift + i] : 0u;
+    if (tid == 0) {
+        BatchCounts c{};
+        c.stored = stored;
+        c.dropped = t.out_count[1];
+        c.total = total;
+        c.span_flag = t.out_count[4];
+        c.link_base = link_base;
+        counts[b] = c;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        *done_counter = 0u;
+        __threadfence_system();
+        __hip_atomic_store(&v.hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One packet in ONE launch of ONE workgroup (geometric media on a sorted table): the frame is tested
 // against the boxes of 1024 receivers (one per thread), the group boxes of the near ones, then the
 // receivers of the near groups (one wave per group); the few hits are evaluated exactly on the
@@ -291,6 +346,14 @@ hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int have
 {
     // enough workgroups to keep the PCIe writes streaming, few enough for a short tail
     hipLaunchKernelGGL(k_pack_tick, dim3(64), dim3(256), 0, s, t, n_new, have_offsets, v, done_counter, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_batch(hipStream_t s, const PackSlot *dev_slots, int n_slots, const HostView &v, BatchCounts *host_counts,
+                             uint32_t *done_counter, uint32_t seq)
+{
+    if (n_slots < 1 || n_slots > kMaxBatch) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack_batch, dim3(16, n_slots), dim3(256), 0, s, dev_slots, n_slots, v, host_counts, done_counter, seq);
     return hipGetLastError();
 }
 

@@ -181,23 +181,36 @@ class Engine:
         k = cnt.value
         return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
 
+    @staticmethod
+    def _wrap_host_result(r):
+        def arr(ptr, dtype, count):
+            if count == 0 or not ptr:
+                return np.empty(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count)
+        k, p = r.count, r.n_packets
+        return TickResult(k, arr(r.pkt, np.int32, k), arr(r.dst, np.int32, k), arr(r.verdict, np.uint8, k),
+                          arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k), arr(r.pkt_interference, np.uint8, p),
+                          arr(r.pkt_offset, np.uint32, p + 1))
+
+    def batch_result_view(self, n_slots, raise_on_error=True):
+        """Results of slots 0..n_slots-1 of the last batch, wrapped in place in the engine's pinned host
+        block (one packing launch, one wait).  Returns (results, status per slot)."""
+        res = (HostResult * n_slots)()
+        status = (C.c_int32 * n_slots)()
+        rc = self._L.rm_batch_result_view(self._h, n_slots, res, status)
+        if rc != 0 and (raise_on_error or all(s == 0 for s in status)):
+            check(rc)
+        return [self._wrap_host_result(r) for r in res], list(status)
+
     def tick_flush_view(self):
         """Evaluate the enqueued tick; the result stays in the engine's pinned host block and is wrapped,
         not copied (valid until the next evaluating call on this engine)."""
         n_new = self._n_new
         r = HostResult()
         check(self._L.rm_tick_flush_view(self._h, C.byref(r)))
-
-        def arr(ptr, dtype, count):
-            if count == 0 or not ptr:
-                return np.empty(0, dtype=dtype)
-            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dtype, count=count)
-        k = r.count
         assert r.n_packets == n_new
-        return TickResult(k, arr(r.pkt, np.int32, k), arr(r.dst, np.int32, k), arr(r.verdict, np.uint8, k),
-                          arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k), arr(r.pkt_interference, np.uint8, n_new),
-                          arr(r.pkt_offset, np.uint32, n_new + 1))
+        return self._wrap_host_result(r)
 
     def tick_run(self):
         """Evaluate the enqueued tick; results stay on the device (result_copy / result_device)."""

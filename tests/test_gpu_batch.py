@@ -52,6 +52,8 @@ def test_batch_matches_the_oracle_tick_by_tick(engine, rsa, O, kind, params, los
     starts = [1000 * b for b in range(n_ticks)]
     engine.batch_run_sources_device(starts, [s + 1000 for s in starts], [d.ptr.value for d in dev],
                                     [len(s) for s in srcs], starts, [AIR] * n_ticks)
+    views, status = engine.batch_result_view(n_ticks)      # all slots through the pinned host block, one launch
+    assert status == [0] * n_ticks
     for b in range(n_ticks):
         pk = nd.packets(srcs[b], start_us=starts[b], air_us=AIR)
         cpu = O.tick(mdl, nd, pk, rng_state=state)
@@ -59,6 +61,9 @@ def test_batch_matches_the_oracle_tick_by_tick(engine, rsa, O, kind, params, los
         gpu = engine.batch_result_copy(b, len(srcs[b]))
         assert cpu.count > 0
         assert_same(gpu, cpu, "%s tick %d of %d" % (kind, b, n_ticks))
+        assert_same(views[b], cpu, "%s tick %d of %d in the host block" % (kind, b, n_ticks))
+        np.testing.assert_array_equal(views[b].pkt_interference, cpu.pkt_interference)
+        np.testing.assert_array_equal(views[b].pkt_offset, gpu.pkt_offset)
         assert engine.batch_result_count(b) == (cpu.count, 0)
     assert engine.rng_state == state
     for d in dev:
@@ -306,6 +311,10 @@ def test_batch_capacity_handling_and_unsorted_media(engine, rsa, O):
     with pytest.raises(rsa.RadioMediumError) as e:
         engine.batch_result_copy(1, len(srcs[1]))
     assert e.value.code == -4
+    views, status = engine.batch_result_view(3, raise_on_error=False)     # the other slots stay usable
+    assert status == [0, -4, 0]
+    for b in (0, 2):
+        assert_same(views[b], O.tick(mdl, nd, nd.packets(srcs[b], tb[b], AIR)), "tick %d in the host block" % b)
     engine.set_link_capacity(1 << 18)
     engine.batch_run_sources_device(*args)
     for b in range(3):
@@ -328,6 +337,7 @@ def test_batch_capacity_handling_and_unsorted_media(engine, rsa, O):
         cpu = O.tick(mdl2, nd2, nd2.packets(s2[b], tb2[b], AIR), rng_state=state)
         state = cpu.rng_state
         assert_same(engine.batch_result_copy(b, 12), cpu, "n2n tick %d" % b)
+        assert_same(engine.batch_result_view(4)[0][b], cpu, "n2n tick %d in the host block" % b)
     assert engine.rng_state == state
     for d in dev + dev2:
         d.free()

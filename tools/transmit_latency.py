@@ -52,3 +52,34 @@ for T in (10, 100, 1000):
     print("rm_tick_flush_view  N=%d  T=%-5d %.1f us per tick, records in, result read in place = %.2e links/s"
           % (n, T, dt * 1e6, T * (n - 1) / dt))
 eng.close()
+
+# a batch of ticks with the results brought to the host: rm_batch_run_sources_device + rm_batch_result_view
+import ctypes as C
+hip = C.CDLL("libamdhip64.so.7")
+eng = rsa.Engine(0)
+eng.upload_table(nodes)
+eng.set_model(rsa.MODEL_LOGDIST, **W.model_kwargs("logdist_shadow")[1])
+eng.set_link_capacity(1 << 21)
+T, NB = n // 100, 64
+ptrs = []
+for b in range(NB):
+    srcs = np.sort(np.random.default_rng(100 + b).choice(n, T, replace=False)).astype(np.int32)
+    d = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d), C.c_size_t(srcs.nbytes)) == 0
+    assert hip.hipMemcpy(d, C.c_void_p(srcs.ctypes.data), C.c_size_t(srcs.nbytes), 1) == 0
+    ptrs.append(d.value)
+tb = [1000 * b for b in range(NB)]
+te = [t + 1000 for t in tb]
+for _ in range(3):
+    eng.batch_run_sources_device(tb, te, ptrs, [T] * NB, tb, [W.AIR_US] * NB)
+    views, _ = eng.batch_result_view(NB)
+reps = 10
+t0 = time.perf_counter()
+for _ in range(reps):
+    eng.batch_run_sources_device(tb, te, ptrs, [T] * NB, tb, [W.AIR_US] * NB)
+    views, _ = eng.batch_result_view(NB)
+dt = (time.perf_counter() - t0) / reps
+links = sum(v.count for v in views)
+print("batch of %d ticks + rm_batch_result_view  N=%d T=%d: %.1f us per tick with all results on the host (%.1f MB per batch) = %.2e links/s"
+      % (NB, n, T, dt / NB * 1e6, links * 25 / 1e6, NB * T * (n - 1) / dt))
+eng.close()
