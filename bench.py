@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- Tx->Rx link evaluations per second of the MI355X radio-medium engine.
 
-A "step" is one simulated tick: T = 1% of N nodes transmit a 127-byte frame; the engine
-evaluates all T x (N-1) links (log-distance path loss + log-normal shadowing, BASELINE.json
-configs[2]: 100k nodes, 1% concurrent Tx) and leaves the ordered heard-link records
-(receiver, rssi, verdict) in HBM, one result slot per tick.  Inputs (node state, every tick's
-source list) are resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch sequence that
+sweeps `ticks_per_step` simulated ticks (64 on one GPU, 128 per rank on several; `--batch`).  In
+every tick T = 1% of N nodes transmit a 127-byte frame; the engine evaluates all T x (N-1) links
+(log-distance path loss + log-normal shadowing, BASELINE.json configs[2]: 100k nodes, 1% concurrent
+Tx) and leaves the ordered heard-link records (receiver, rssi, verdict) in HBM, one result slot per
+tick.  Inputs (node state, every tick's source list) are resident in HBM before the timed region
+starts.  `value` = link evaluations of the K timed steps / their wall time, whatever K is.
 
 The benchmarked medium carries no state from tick to tick (no on-air list, no random draws with
 the reference's default probabilities; RadioMedium.transmit treats every packet on its own), and a
@@ -70,8 +72,8 @@ def baseline_metric():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1920)
-    ap.add_argument("--warmup", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (launch sequences of --batch ticks); default: 1920 ticks' worth")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps before them; default: 192 ticks' worth")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
@@ -286,13 +288,19 @@ def main():
         for e in engines:
             e.set_partition(lo, hi - lo)
 
-    ticks = args.warmup + args.steps
-    base_seed = 0xC0FFEE00 + idx
-    sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(ticks)]
-
     from radio_sim_amd import dist as D
     use_sharded = world > 1 or args.force_sharded
     batch = 1 if stateful else max(1, min(args.batch, rsa.MAX_BATCH))
+    tps = batch                          # ticks per step: a step is one launch sequence
+    if args.steps <= 0:
+        args.steps = -(-1920 // tps)
+    if args.warmup < 0:
+        args.warmup = -(-192 // tps)
+    warm_ticks, ticks = args.warmup * tps, (args.warmup + args.steps) * tps
+    base_seed = 0xC0FFEE00 + idx
+    # synthetic input: a pool of distinct ticks (a multiple of the batch), reused in turn by longer runs
+    pool = min(ticks, -(-2112 // tps) * tps)
+    sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(pool)]
     with torch.cuda.stream(stream):
         if not use_sharded:
             src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
@@ -317,7 +325,7 @@ def main():
         """arguments of one rm_batch_run_sources_device call for the source lists k .. k+nb-1 at simulated ticks tk .."""
         if (k, nb, tk) not in _bargs:
             t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
-            _bargs[(k, nb, tk)] = (t0, t0 + tick_us, np.array([src_dev[kk].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
+            _bargs[(k, nb, tk)] = (t0, t0 + tick_us, np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
                                    np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
         return _bargs[(k, nb, tk)]
 
@@ -337,23 +345,23 @@ def main():
                     t_b = (clock[0] - k0 + np.arange(k, min(k + batch, k1), dtype=np.int64)) * tick_us
                     g = ctx_rr[0] % inflight
                     ctx_rr[0] += 1
-                    sharded.run_batch(g, src_dev[k].data_ptr(), t_b, W.AIR_US, tick_us)
+                    sharded.run_batch(g, src_dev[k % pool].data_ptr(), t_b, W.AIR_US, tick_us)
                     last_run[:] = [engines[g], len(t_b) - 1]
             elif sharded is None:
                 for k in range(k0, k1):
                     t0 = (clock[0] + k - k0) * tick_us
                     # one call: the frames' Tx records are built from the resident node state inside the sweep
-                    engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k].data_ptr(), t_per_tick,
+                    engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick,
                                                                   t0, W.AIR_US)
                     if stateful:
                         links_done[0] += engines[0].last_link_evaluations()
             else:
                 if k1 > k0:
-                    sharded.stage(src_dev[k0].data_ptr(), k0 * W.TICK_US, W.AIR_US)
+                    sharded.stage(src_dev[k0 % pool].data_ptr(), k0 * W.TICK_US, W.AIR_US)
                 for k in range(k0, k1):
                     cur = sharded.staged
                     if k + 1 < k1:
-                        sharded.stage(src_dev[k + 1].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
+                        sharded.stage(src_dev[(k + 1) % pool].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
                     sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
         clock[0] += k1 - k0
 
@@ -370,10 +378,10 @@ def main():
     for _ in range(inflight):
         run_range(0, min(ticks, batch))
     fence()
-    run_range(0, args.warmup)
+    run_range(0, warm_ticks)
     fence()
     # HIP-event brackets on every n-th launch sequence of every context; few launches: all of them
-    launches = -(-args.steps // batch)
+    launches = args.steps
     every = args.profile_every if batch == 1 else max(1, args.profile_every // 4)
     if launches <= 4 * inflight:
         every = 1
@@ -381,7 +389,7 @@ def main():
         e.profile_enable(every)
     t_start = time.perf_counter()
     links_done[0] = 0
-    run_range(args.warmup, ticks)
+    run_range(warm_ticks, ticks)
     fence()
     elapsed = time.perf_counter() - t_start
     n_samples, stage_ms = 0, {}
@@ -407,26 +415,28 @@ def main():
         heard_total = float(heard)
 
     links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * (hi - lo)
-    value = links_per_tick * args.steps / elapsed
+    timed_ticks = args.steps * tps
+    value = links_per_tick * timed_ticks / elapsed
     if stateful:
         # every frame on the air is swept against every receiver each tick
         value = links_done[0] / elapsed
 
     sequential = None
     if stateful:
-        desc += " -- %.2e link evaluations per tick incl. the frames still on the air" % (links_done[0] / args.steps)
+        desc += " -- %.2e link evaluations per tick incl. the frames still on the air" % (links_done[0] / timed_ticks)
     if (inflight > 1 or batch > 1) and sharded is None:
         # the same ticks again, one at a time on one context
         fence()
         t_seq = time.perf_counter()
         with torch.cuda.stream(stream):
-            for k in range(args.warmup, ticks):
-                t0 = (clock[0] + k - args.warmup) * tick_us
-                eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k].data_ptr(), t_per_tick, t0, W.AIR_US)
+            seq_ticks = min(timed_ticks, 1920)
+            for k in range(warm_ticks, warm_ticks + seq_ticks):
+                t0 = (clock[0] + k - warm_ticks) * tick_us
+                eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick, t0, W.AIR_US)
         fence()
         el = time.perf_counter() - t_seq
-        sequential = {"ticks_in_flight": 1, "value": links_per_tick * args.steps / el, "unit": "links/s",
-                      "ms_per_step": el / args.steps * 1e3}
+        sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
+                      "ms_per_tick": el / seq_ticks * 1e3}
 
     if rank == 0:
         # Roofline of the dominant kernel on this rank.  Per-stage durations
@@ -436,7 +446,7 @@ def main():
         n_loc = hi - lo
         h_loc = heard
         # per launch: the ticks it sweeps (`batch`, fewer when the K steps do not fill the launches)
-        ticks_per_launch = args.steps / launches if every == 1 else batch   # every launch sampled: their mean size
+        ticks_per_launch = batch
         b_tick = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
         raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
         # an event pair with nothing between it measures the bracketing itself (a few us on this
@@ -474,13 +484,15 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_tick": elapsed / timed_ticks * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight * batch,
-                       "ticks_per_launch": batch, "contexts": inflight,
+                       "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
+                       "step": "one launch sequence sweeping ticks_per_step simulated ticks",
                        "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total,
                        "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per tick, "
                                     "overlapped with the previous tick's sweep" % world) if world > 1 else "none"},

@@ -141,7 +141,7 @@ def test_pipelined_sharded_driver_on_one_gpu():
     outs = []
     for extra in ([], ["--force-sharded"]):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "40",
-                            "--warmup", "5", "--no-cpu-baseline", "--inflight", "1"] + extra, capture_output=True, text=True, timeout=600)
+                            "--warmup", "5", "--no-cpu-baseline", "--inflight", "1", "--batch", "1"] + extra, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
         outs.append(json.loads(line))
@@ -160,9 +160,9 @@ def test_batched_sharded_driver_through_rccl_with_one_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for extra, env in (([], {}), (["--force-sharded", "--inflight", "3", "--batch", "16"], {"RM_DIST_SINGLE": "1"})):
-        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "96",
-                            "--warmup", "16", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600,
+    for extra, env in ((["--batch", "16"], {}), (["--force-sharded", "--inflight", "3", "--batch", "16"], {"RM_DIST_SINGLE": "1"})):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "8",
+                            "--warmup", "2", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, MASTER_PORT="29547", **env))
         assert p.returncode == 0, p.stderr[-2000:]
         lines = p.stdout.splitlines()

@@ -12,13 +12,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/be
 echo "stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --batch 1 --steps 400 --warmup 40 > $O/stats_seq.log 2>&1
 echo "sequential stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 640 --warmup 128 > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 640 --warmup 128 > $O/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 640 --warmup 128 > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 10 --warmup 2 > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 10 --warmup 2 > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 10 --warmup 2 > $O/pmc_sq.log 2>&1
 echo "pmc c3 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/m1_stats -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --batch 16 --steps 384 --warmup 96 > $O/m1_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/m1_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 192 --warmup 48 > $O/m1_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/m1_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 192 --warmup 48 > $O/m1_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/m1_stats -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --batch 16 --steps 24 --warmup 6 > $O/m1_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/m1_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3 > $O/m1_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/m1_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3 > $O/m1_write.log 2>&1
 echo "m1 done"
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/r01_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
