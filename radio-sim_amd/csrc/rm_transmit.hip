@@ -365,9 +365,12 @@ hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *h
 
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
 {
-    (void)m; // the SINR extension is batched as well (self-contained ticks only: rm_api.cpp checks that)
+    // the SINR extension is batched as well (self-contained ticks only: rm_api.cpp checks that) -- but not together
+    // with java.util.Random draws: the batched SINR kernels carry no pending verdicts, such ticks take one
+    // launch sequence each
+    const bool sinr = m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR);
     return cfg.sorted && cfg.bbox && !cfg.f64_filter && !t.use_matrix && t.n_cnt <= kFusedScanMax &&
-           t.filter_mode == kFilterWg && t.n_active > t.first_new && t.n_rx > 0;
+           t.filter_mode == kFilterWg && t.n_active > t.first_new && t.n_rx > 0 && !(sinr && cfg.stochastic);
 }
 
 hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDev *dev_ticks)

@@ -224,6 +224,33 @@ def test_sinr_batch_of_self_contained_ticks(engine, rsa, O):
         d.free()
 
 
+def test_sinr_batch_with_lossy_links_draws_from_the_shared_generator(engine, rsa, O):
+    """SINR capture and java.util.Random draws in the same medium (rx-loss / tx-loss on some nodes): the
+    ticks of such a batch take one launch sequence each (the batched SINR kernels carry no pending
+    verdicts); verdicts and the generator must follow the oracle from tick to tick."""
+    n = 5000
+    nd = _layout(O, n, seed=43, lossy=True)
+    params = dict(ld_flags=1, ld_sigma_db=4.0, ld_seed=3, ld_capture_db=3.0)
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    engine.seed(2025)
+    state = O.lib().orc_jrandom_seed(2025)
+    n_ticks = 4
+    srcs = _ticks(n, n_ticks, 200, seed=8, ragged=True)
+    dev = [DeviceArray(s) for s in srcs]
+    tb = np.arange(n_ticks, dtype=np.int64) * 1000
+    engine.batch_run_sources_device(tb, tb + 1000, [d.ptr.value for d in dev], [len(s) for s in srcs], tb, [640] * n_ticks)
+    drawn = 0
+    for b in range(n_ticks):
+        cpu = O.tick(mdl, nd, nd.packets(srcs[b], int(tb[b]), 640), rng_state=state)
+        drawn += int(cpu.rng_state != state)
+        state = cpu.rng_state
+        assert_same(engine.batch_result_copy(b, len(srcs[b])), cpu, "lossy sinr batch tick %d" % b)
+    assert drawn == n_ticks and engine.rng_state == state
+    for d in dev:
+        d.free()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("sinr", [False, True])
 def test_sharded_batch_equals_global(rsa, O, world, sinr):

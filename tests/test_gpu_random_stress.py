@@ -138,3 +138,82 @@ def test_randomized_scenarios_through_batches_and_single_packets(engine, rsa, O,
             assert bool(got.pkt_interference[0]) == bool(cpu.pkt_interference[0]), what
             assert engine.rng_state == state, what
     # (some blocks draw only scenarios without a single heard link: nothing to require of `checked` here)
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_randomized_scenarios_with_node_changes_between_ticks(engine, rsa, O, block):
+    """node-config-set between ticks on the same awkward scenarios: single updates of every field and
+    lists of moved nodes (a few metres, and teleports that make the table sort again), results read in
+    place from the pinned block (rm_tick_flush_view) and through rm_batch_result_view."""
+    from util import DeviceArray
+    rng = np.random.default_rng(9000 + block)
+    for it in range(8):
+        nd, kind, params, matrix, pk = _scenario(O, rng)
+        sinr = bool(params.get("ld_flags"))
+        if sinr and (len(pk) * nd.n > 60_000):
+            pk = pk[:40]
+        pk["start_us"], pk["air_us"] = 0, 320          # self-contained ticks: nothing stays on the air
+        configure_engine(engine, nd, kind, params, matrix)
+        mdl = oracle_model(O, kind, params, matrix)
+        seed = int(rng.integers(0, 2 ** 31))
+        engine.seed(seed)
+        state = O.lib().orc_jrandom_seed(seed)
+        what = "block %d it %d %s %s n=%d t=%d" % (block, it, kind, params, nd.n, len(pk))
+        n = nd.n
+        for step in range(4):
+            # single updates: any field
+            for i in rng.choice(n, min(n, 3), replace=False):
+                i = int(i)
+                if rng.random() < 0.7:
+                    nd.x[i] += rng.normal(0, 20.0)
+                    nd.y[i] += rng.normal(0, 20.0)
+                if rng.random() < 0.3:
+                    nd.channel[i] = int(rng.choice([26, 11]))
+                if rng.random() < 0.3:
+                    nd.enabled[i] = int(rng.random() < 0.7)
+                if rng.random() < 0.3:
+                    nd.rxprob[i] = float(rng.choice([1.0, 0.4, 0.0]))
+                    nd.txprob[i] = float(rng.choice([1.0, 0.7]))
+                if rng.random() < 0.2:
+                    nd.txpower[i] = float(rng.choice([0.0, -10.0, 7.0]))
+                engine.update_node(i, nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]),
+                                   nd.rxprob[i], nd.txprob[i])
+            # a list of moved nodes (z given or not)
+            k = int(min(n, rng.choice([0, 1, 5, 70])))
+            who = rng.choice(n, k, replace=False).astype(np.int32)
+            if rng.random() < 0.3:
+                nd.x[who], nd.y[who] = rng.uniform(-2000, 2000, k), rng.uniform(-2000, 2000, k)      # teleports
+            else:
+                nd.x[who] += rng.normal(0, 3.0, k)
+                nd.y[who] += rng.normal(0, 3.0, k)
+            if rng.random() < 0.5:
+                nd.z[who] = 0.0
+                engine.move_nodes(who, nd.x[who], nd.y[who])
+            else:
+                nd.z[who] = rng.uniform(0, 30.0, k)
+                engine.move_nodes(who, nd.x[who], nd.y[who], nd.z[who])
+            # the packets take the sources' current state
+            cur = nd.packets(pk["src"], 1000 * step, 320)
+            cpu = O.tick(mdl, nd, cur, rng_state=state)
+            state = cpu.rng_state
+            engine.tick_begin(1000 * step, 1000 * step + 1000)
+            engine.enqueue_records(to_tx_records(rsa, cur))
+            assert_same(engine.tick_flush_view(), cpu, what + " step %d" % step)
+            assert engine.rng_state == state, what
+        # the final state once more through a batch of two ticks and the batch view
+        cur = nd.packets(pk["src"], 10000, 320)
+        half = len(cur) // 2
+        parts = [cur[:half], cur[half:]]
+        parts[1]["start_us"] = 11000
+        recs = [to_tx_records(rsa, p) for p in parts]
+        dev = [DeviceArray(r) if len(r) else DeviceArray(nbytes=64) for r in recs]
+        engine.batch_run_device([10000, 11000], [11000, 12000], [d.ptr.value for d in dev], [len(r) for r in recs])
+        views, status = engine.batch_result_view(2)
+        assert status == [0, 0], what
+        for b in range(2):
+            cpu = O.tick(mdl, nd, parts[b], rng_state=state)
+            state = cpu.rng_state
+            assert_same(views[b], cpu, what + " batch view %d" % b)
+        assert engine.rng_state == state, what
+        for d in dev:
+            d.free()
