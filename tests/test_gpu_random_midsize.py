@@ -1,0 +1,129 @@
+"""Seeded randomized parity at sizes where every code path is taken for real (thousands of nodes:
+spatially sorted table, bounding boxes, the shadowing table, medium scans, several shards), with the
+state an application builds up over time: frames that stay on the air across ticks (SINR), lossy
+links drawing from the shared java.util.Random, node changes between ticks, a receiver partition.
+Each run is a short random "session" against the oracle, tick by tick."""
+import numpy as np
+import pytest
+
+from util import configure_engine, oracle_model, to_tx_records, assert_same, DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _session(O, rng):
+    n = int(rng.choice([3000, 8000, 20000]))
+    k = float(rng.choice([8.0, 20.0, 45.0]))                      # expected neighbours in 50 m
+    side = 50.0 * np.sqrt(np.pi * n / k)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    if rng.random() < 0.3:
+        nd.z = rng.uniform(0, 40.0, n)
+    if rng.random() < 0.5:
+        nd.channel[:] = rng.choice([26, 25, 11], n, p=[0.7, 0.2, 0.1])
+    nd.enabled[rng.random(n) < 0.03] = 0
+    nd.txpower[:] = rng.choice([0.0, -5.0, 3.0], n)
+    lossy = rng.random() < 0.5
+    if lossy:
+        nd.rxprob[rng.random(n) < 0.2] = float(rng.choice([0.5, 0.9]))
+        nd.txprob[rng.random(n) < 0.05] = 0.6
+    kind = str(rng.choice(["udgm", "udgm_const", "logdist", "logdist_shadow", "logdist_sinr"]))
+    if kind == "udgm":
+        params = {"udgm_transmission_range": float(rng.choice([50.0, 80.0])),
+                  "udgm_success_ratio_rx": float(rng.choice([1.0, 0.85]))}
+    elif kind == "udgm_const":
+        params = {"const_range": float(rng.choice([100.0, 60.0]))}
+    else:
+        params = {"ld_exponent": float(rng.choice([3.0, 2.5, 4.0])), "ld_seed": int(rng.integers(0, 2 ** 40)),
+                  "ld_sigma_db": 0.0 if kind == "logdist" else float(rng.choice([4.0, 8.0])),
+                  "ld_sensitivity_dbm": float(rng.choice([-95.0, -90.0]))}
+        if kind == "logdist_sinr":
+            params.update({"ld_flags": 1, "ld_capture_db": float(rng.choice([3.0, 6.0])), "ld_ifloor_dbm": float(rng.choice([-110.0, -100.0]))})
+        kind = "logdist"
+    return nd, kind, params, lossy
+
+
+@pytest.mark.parametrize("block", range(int(__import__("os").environ.get("RM_STRESS_BLOCKS", "12"))))
+def test_random_sessions(engine, rsa, O, block):
+    rng = np.random.default_rng(77000 + block)
+    nd, kind, params, lossy = _session(O, rng)
+    n = nd.n
+    sinr = bool(params.get("ld_flags"))
+    configure_engine(engine, nd, kind, params)
+    mdl = oracle_model(O, kind, params)
+    seed = int(rng.integers(0, 2 ** 31))
+    engine.seed(seed)
+    state = O.lib().orc_jrandom_seed(seed)
+    part = None
+    if rng.random() < 0.3 and not (lossy or (kind == "udgm" and params["udgm_success_ratio_rx"] < 1.0)):
+        lo = int(rng.integers(0, n // 2))
+        part = (lo, int(rng.integers(n // 4, n - lo)))
+        engine.set_partition(*part)
+    what = "block %d %s %s n=%d lossy=%s part=%s" % (block, kind, params, n, lossy, part)
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    heard = 0
+    # the SINR medium keeps its on-air list where the frames came from (host records or device-resident
+    # source lists): a session stays with one of the two
+    sinr_host = sinr and (part is not None or rng.random() < 0.5)
+    for step in range(6):
+        t0 = 1000 * step
+        # node changes between ticks
+        if rng.random() < 0.6:
+            who = rng.choice(n, int(rng.choice([1, 20, 300])), replace=False).astype(np.int32)
+            far = rng.random() < 0.2
+            nd.x[who] = rng.uniform(0, nd.x.max(), who.size) if far else nd.x[who] + rng.normal(0, 4.0, who.size)
+            nd.y[who] = rng.uniform(0, nd.y.max(), who.size) if far else nd.y[who] + rng.normal(0, 4.0, who.size)
+            engine.move_nodes(who, nd.x[who], nd.y[who], nd.z[who])
+        if rng.random() < 0.4:
+            i = int(rng.integers(0, n))
+            nd.channel[i] = int(rng.choice([26, 25]))
+            nd.enabled[i] = int(rng.random() < 0.8)
+            if lossy:
+                nd.rxprob[i] = float(rng.choice([1.0, 0.5]))
+            engine.update_node(i, nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]),
+                               nd.rxprob[i], nd.txprob[i])
+        t = int(rng.choice([1, 40, 300, 700]))
+        srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+        air = int(rng.choice([320, 960, 2500, 8128])) if sinr else 320
+        new = nd.packets(srcs, t0, air)
+        if sinr:
+            onair = onair[onair["start_us"] + onair["air_us"] > t0]
+        active = np.concatenate([onair, new]) if sinr else new
+        cpu = O.tick(mdl, nd, active, first_new=len(active) - len(new), rng_state=state)
+        state = cpu.rng_state
+        mode = int(rng.integers(0, 3))
+        if sinr:
+            mode = 0 if sinr_host else int(rng.integers(1, 3))
+        if mode == 0:
+            engine.tick_begin(t0, t0 + 1000)
+            engine.enqueue_records(to_tx_records(rsa, new))
+            gpu = engine.tick_flush_view()
+        elif mode == 1:
+            d = DeviceArray(srcs)
+            engine.tick_run_sources_device(t0, t0 + 1000, d.ptr.value, t, t0, air)
+            gpu = engine.result_copy(t)
+            d.free()
+        else:
+            d = DeviceArray(srcs)
+            try:
+                engine.batch_run_sources_device([t0], [t0 + 1000], [d.ptr.value], [t], [t0], [air])
+                gpu = engine.batch_result_view(1)[0][0]
+            except rsa.RadioMediumError as e:      # frames of earlier ticks still on the air: a batch is refused
+                assert sinr and e.code == -5, what
+                engine.tick_run_sources_device(t0, t0 + 1000, d.ptr.value, t, t0, air)
+                gpu = engine.result_copy(t)
+            d.free()
+        if sinr:
+            onair = active
+        if part is not None:
+            keep = (cpu.dst >= part[0]) & (cpu.dst < part[0] + part[1])
+            assert gpu.count == int(keep.sum()), what + " step %d" % step
+            np.testing.assert_array_equal(gpu.pkt, cpu.pkt[keep], err_msg=what)
+            np.testing.assert_array_equal(gpu.dst, cpu.dst[keep], err_msg=what)
+            np.testing.assert_array_equal(gpu.verdict, cpu.verdict[keep], err_msg=what)
+            np.testing.assert_array_equal(gpu.rssi, cpu.rssi[keep], err_msg=what)
+        else:
+            assert_same(gpu, cpu, what + " step %d mode %d" % (step, mode))
+            assert engine.rng_state == state, what + " step %d" % step
+        heard += cpu.count
+    assert heard > 0, what

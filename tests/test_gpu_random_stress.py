@@ -65,7 +65,7 @@ def _scenario(O, rng):
     return nd, kind, params, matrix, pk
 
 
-@pytest.mark.parametrize("block", range(8))
+@pytest.mark.parametrize("block", range(int(__import__("os").environ.get("RM_STRESS_BLOCKS", "8"))))
 def test_randomized_scenarios(engine, rsa, O, block):
     rng = np.random.default_rng(1000 + block)
     checked = 0
@@ -84,7 +84,7 @@ def test_randomized_scenarios(engine, rsa, O, block):
     assert checked > 0
 
 
-@pytest.mark.parametrize("block", range(16))
+@pytest.mark.parametrize("block", range(int(__import__("os").environ.get("RM_STRESS_BLOCKS", "16"))))
 def test_randomized_scenarios_through_batches_and_single_packets(engine, rsa, O, block):
     """The same awkward scenarios through the other two entry points: the tick's packets split over the
     ticks of an rm_batch_run_device call (batched kernels where they apply, one launch sequence per
@@ -140,7 +140,7 @@ def test_randomized_scenarios_through_batches_and_single_packets(engine, rsa, O,
     # (some blocks draw only scenarios without a single heard link: nothing to require of `checked` here)
 
 
-@pytest.mark.parametrize("block", range(8))
+@pytest.mark.parametrize("block", range(int(__import__("os").environ.get("RM_STRESS_BLOCKS", "8"))))
 def test_randomized_scenarios_with_node_changes_between_ticks(engine, rsa, O, block):
     """node-config-set between ticks on the same awkward scenarios: single updates of every field and
     lists of moved nodes (a few metres, and teleports that make the table sort again), results read in
