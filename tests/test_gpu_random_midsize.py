@@ -126,4 +126,34 @@ def test_random_sessions(engine, rsa, O, block):
             assert_same(gpu, cpu, what + " step %d mode %d" % (step, mode))
             assert engine.rng_state == state, what + " step %d" % step
         heard += cpu.count
+        if sinr or part is not None:
+            continue
+        # a few single packets (rm_transmit: one launch of one workgroup where the links fit its lists) ...
+        if rng.random() < 0.5:
+            for i in rng.choice(n, 3, replace=False):
+                one = nd.packets(np.array([int(i)]), t0 + 500, 64 * 32)
+                cpu1 = O.tick(mdl, nd, one, rng_state=state)
+                state = cpu1.rng_state
+                got = engine.transmit(int(i), start_us=t0 + 500, hex_length=64)
+                assert got.count == cpu1.count, what + " transmit %d" % i
+                np.testing.assert_array_equal(got.dst, cpu1.dst, err_msg=what)
+                np.testing.assert_array_equal(got.verdict, cpu1.verdict, err_msg=what)
+                np.testing.assert_array_equal(got.rssi, cpu1.rssi, err_msg=what)
+                assert engine.rng_state == state, what
+        # ... and several ticks in one launch sequence, ragged sizes
+        if rng.random() < 0.5:
+            nb = int(rng.integers(2, 6))
+            lists = [np.sort(rng.choice(n, int(rng.choice([1, 60, 400])), replace=False)).astype(np.int32) for _ in range(nb)]
+            dev = [DeviceArray(a) for a in lists]
+            tb = [t0 + 100 * b for b in range(nb)]
+            engine.batch_run_sources_device(tb, [v + 100 for v in tb], [d.ptr.value for d in dev], [len(a) for a in lists], tb, [96] * nb)
+            views, status = engine.batch_result_view(nb)
+            assert status == [0] * nb, what
+            for b in range(nb):
+                cpub = O.tick(mdl, nd, nd.packets(lists[b], tb[b], 96), rng_state=state)
+                state = cpub.rng_state
+                assert_same(views[b], cpub, what + " step %d batch tick %d of %d" % (step, b, nb))
+            assert engine.rng_state == state, what
+            for d in dev:
+                d.free()
     assert heard > 0, what
