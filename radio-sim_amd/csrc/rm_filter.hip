@@ -230,17 +230,18 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
         }
     }
     __syncthreads();
-    if (slab >= t.n_slabs) return;
-
     // counters that later kernels of this tick (cursor) or the next tick's filter (candidate
-    // totals, other parity) add to start at zero
-    if (t.use_matrix) {
-        if (e0 >= t.cnt_base) t.cnt[(size_t((e0 - t.cnt_base) / kTxChunk) * t.n_slabs + slab) * 64 + lane] = 0u;
-    } else if (blockIdx.x == 0) {
+    // totals, other parity) add to start at zero.  Every thread of the x = 0 workgroups takes part,
+    // also the waves without a slab (a table of fewer than four slabs): they leave only afterwards.
+    if (!t.use_matrix && blockIdx.x == 0) {
         for (int i = blockIdx.y * kBlock + threadIdx.x; i < t.zero_len; i += gridDim.y * kBlock) {
             t.cursor[i] = 0u;
             t.cand_tot_next[i] = 0u;
         }
+    }
+    if (slab >= t.n_slabs) return;
+    if (t.use_matrix) {
+        if (e0 >= t.cnt_base) t.cnt[(size_t((e0 - t.cnt_base) / kTxChunk) * t.n_slabs + slab) * 64 + lane] = 0u;
     }
 
     // which frames of the tile can reach which receiver group: one frame per lane against the

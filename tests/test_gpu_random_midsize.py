@@ -157,3 +157,87 @@ def test_random_sessions(engine, rsa, O, block):
             for d in dev:
                 d.free()
     assert heard > 0, what
+
+
+@pytest.mark.parametrize("block", range(int(__import__("os").environ.get("RM_STRESS_BLOCKS", "6"))))
+def test_random_sharded_sessions(rsa, O, block):
+    """The same kind of session on W contexts that each own an uneven range of the receivers (what W
+    ranks hold): every context sees the tick's records, the per-packet draw counts are exchanged where
+    links can draw, node changes go to every context; the merged links equal the one-process oracle."""
+    from radio_sim_amd import dist as D
+    from util import KINDS, _PARAM_MAP
+    rng = np.random.default_rng(88000 + block)
+    nd, kind, params, lossy = _session(O, rng)
+    n = nd.n
+    sinr = bool(params.get("ld_flags"))
+    world = int(rng.integers(2, 5))
+    cuts = np.sort(rng.choice(np.arange(1, n), world - 1, replace=False))
+    bounds = np.concatenate([[0], cuts, [n]])
+    mdl = oracle_model(O, kind, params)
+    what = "block %d %s %s n=%d lossy=%s world=%d bounds=%s" % (block, kind, params, n, lossy, world, bounds)
+    engines = []
+    try:
+        for r in range(world):
+            eng = rsa.Engine(0)
+            eng.upload_table(nd)
+            eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            eng.set_partition(int(bounds[r]), int(bounds[r + 1] - bounds[r]))
+            eng.seed(31 + block)
+            engines.append(eng)
+        state = O.lib().orc_jrandom_seed(31 + block)
+        onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+        drew = 0
+        for step in range(5):
+            t0 = 1000 * step
+            if rng.random() < 0.6:
+                who = rng.choice(n, int(rng.choice([1, 30, 200])), replace=False).astype(np.int32)
+                nd.x[who] += rng.normal(0, 5.0, who.size)
+                nd.y[who] += rng.normal(0, 5.0, who.size)
+                for eng in engines:
+                    eng.move_nodes(who, nd.x[who], nd.y[who], nd.z[who])
+            t = int(rng.choice([1, 50, 400]))
+            srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+            air = int(rng.choice([320, 2500, 8128])) if sinr else 320
+            new = nd.packets(srcs, t0, air)
+            if sinr:
+                onair = onair[onair["start_us"] + onair["air_us"] > t0]
+            active = np.concatenate([onair, new]) if sinr else new
+            ref = O.tick(mdl, nd, active, first_new=len(active) - len(new), rng_state=state)
+            drew += int(ref.rng_state != state)
+            state = ref.rng_state
+            recs = to_tx_records(rsa, new)
+            counts, pending = [], False
+            for eng in engines:
+                eng.tick_begin(t0, t0 + 1000)
+                eng.enqueue_records(recs)
+                eng.tick_run()
+                pending = pending or eng.draws_pending()
+            if pending:
+                for eng in engines:
+                    assert eng.draws_pending(), what
+                    ptr, n_new = eng.draw_counts_device()
+                    counts.append(DeviceArray.read(ptr, np.uint32, n_new))
+                allc = np.stack(counts)
+                for r, eng in enumerate(engines):
+                    eng.finish_draws(allc, world, r)
+            shards = []
+            for eng in engines:
+                res = eng.result_copy(t)
+                shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
+            merged = D.merge_shard_links(shards, t)
+            if sinr:
+                onair = active
+            assert len(merged[0]) == ref.count, what + " step %d" % step
+            np.testing.assert_array_equal(merged[0], ref.pkt, err_msg=what)
+            np.testing.assert_array_equal(merged[1], ref.dst, err_msg=what)
+            np.testing.assert_array_equal(merged[2], ref.verdict, err_msg=what)
+            np.testing.assert_array_equal(merged[3], ref.rssi, err_msg=what)
+            if sinr:
+                np.testing.assert_array_equal(merged[4], ref.sinr, err_msg=what)
+            if pending:
+                for eng in engines:
+                    assert eng.rng_state == state, what
+        assert drew > 0 or not lossy or kind == "udgm_const", what
+    finally:
+        for eng in engines:
+            eng.close()

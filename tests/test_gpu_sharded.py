@@ -170,3 +170,35 @@ def test_batched_sharded_driver_through_rccl_with_one_rank():
         outs.append(json.loads(lines[0]))
     assert outs[0]["config"]["heard_links_last_tick"] == outs[1]["config"]["heard_links_last_tick"] > 0
     assert outs[1]["config"]["ticks_per_launch"] == 16 and outs[1]["value"] > 0
+
+
+@pytest.mark.parametrize("kind,params", [("udgm", {}), ("logdist", {"ld_sigma_db": 4.0, "ld_seed": 5})])
+def test_small_partition_with_many_frames_over_several_ticks(rsa, O, kind, params):
+    """A rank that owns fewer than four slabs of receivers (151 here) while every tick carries hundreds
+    of frames: the per-frame counters have to be clean again for every tick, also the slots that only
+    the slab-less waves of the sweep's first workgroup would clear."""
+    n = 8000
+    rng = np.random.default_rng(1)
+    nd = O.NodeTable(n)
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    mdl = oracle_model(O, kind, params)
+    for lo, cnt in ((7849, 151), (3000, 70), (10, 200)):
+        eng = rsa.Engine(0)
+        try:
+            eng.upload_table(nd)
+            eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            eng.set_partition(lo, cnt)
+            for step, t in enumerate((400, 50, 1, 400, 400)):
+                srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+                pk = nd.packets(srcs, 1000 * step, 320)
+                ref = O.tick(mdl, nd, pk)
+                keep = (ref.dst >= lo) & (ref.dst < lo + cnt)
+                res = eng.tick(to_tx_records(rsa, pk), 1000 * step, 1000 * step + 1000)
+                assert res.count == int(keep.sum()), "partition %s tick %d" % ((lo, cnt), step)
+                np.testing.assert_array_equal(res.pkt, ref.pkt[keep])
+                np.testing.assert_array_equal(res.dst, ref.dst[keep])
+                np.testing.assert_array_equal(res.verdict, ref.verdict[keep])
+                np.testing.assert_array_equal(res.rssi, ref.rssi[keep])
+        finally:
+            eng.close()
