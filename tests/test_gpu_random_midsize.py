@@ -19,6 +19,9 @@ def _session(O, rng):
     nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
     if rng.random() < 0.3:
         nd.z = rng.uniform(0, 40.0, n)
+    if rng.random() < 0.15:      # far from the origin: the fp32 frame is too coarse, the sweep filters in fp64
+        nd.x += 4.0e7
+        nd.y -= 9.0e7
     if rng.random() < 0.5:
         nd.channel[:] = rng.choice([26, 25, 11], n, p=[0.7, 0.2, 0.1])
     nd.enabled[rng.random(n) < 0.03] = 0
@@ -50,6 +53,7 @@ def test_random_sessions(engine, rsa, O, block):
     n = nd.n
     sinr = bool(params.get("ld_flags"))
     configure_engine(engine, nd, kind, params)
+    engine.set_link_capacity(1 << 24)          # dense layouts with 8 dB of shadowing: millions of candidates per tick
     mdl = oracle_model(O, kind, params)
     seed = int(rng.integers(0, 2 ** 31))
     engine.seed(seed)
@@ -71,8 +75,8 @@ def test_random_sessions(engine, rsa, O, block):
         if rng.random() < 0.6:
             who = rng.choice(n, int(rng.choice([1, 20, 300])), replace=False).astype(np.int32)
             far = rng.random() < 0.2
-            nd.x[who] = rng.uniform(0, nd.x.max(), who.size) if far else nd.x[who] + rng.normal(0, 4.0, who.size)
-            nd.y[who] = rng.uniform(0, nd.y.max(), who.size) if far else nd.y[who] + rng.normal(0, 4.0, who.size)
+            nd.x[who] = rng.uniform(nd.x.min(), nd.x.max(), who.size) if far else nd.x[who] + rng.normal(0, 4.0, who.size)
+            nd.y[who] = rng.uniform(nd.y.min(), nd.y.max(), who.size) if far else nd.y[who] + rng.normal(0, 4.0, who.size)
             engine.move_nodes(who, nd.x[who], nd.y[who], nd.z[who])
         if rng.random() < 0.4:
             i = int(rng.integers(0, n))
@@ -94,6 +98,17 @@ def test_random_sessions(engine, rsa, O, block):
         mode = int(rng.integers(0, 3))
         if sinr:
             mode = 0 if sinr_host else int(rng.integers(1, 3))
+        if not sinr and cpu.count > 300 and rng.random() < 0.25:
+            # a tick over the link capacity is reported, leaves nothing behind, and the same tick is right afterwards
+            before = engine.rng_state
+            engine.set_link_capacity(256)
+            with pytest.raises(rsa.RadioMediumError) as e:
+                engine.tick_begin(t0, t0 + 1000)
+                engine.enqueue_records(to_tx_records(rsa, new))
+                engine.tick_flush_view()
+            assert e.value.code == -4, what
+            engine.set_link_capacity(1 << 24)
+            engine.rng_state = before
         if mode == 0:
             engine.tick_begin(t0, t0 + 1000)
             engine.enqueue_records(to_tx_records(rsa, new))
@@ -237,6 +252,33 @@ def test_random_sharded_sessions(rsa, O, block):
             if pending:
                 for eng in engines:
                     assert eng.rng_state == state, what
+            draws_possible = lossy or (kind == "udgm" and params["udgm_success_ratio_rx"] < 1.0)
+            if not sinr and not draws_possible and rng.random() < 0.5:
+                # several ticks of gathered records in one launch sequence on every context (what a rank does
+                # with the all-gathered batch)
+                nb = int(rng.integers(2, 5))
+                lists = [np.sort(rng.choice(n, int(rng.choice([1, 80, 500])), replace=False)).astype(np.int32) for _ in range(nb)]
+                tb = [t0 + 100 * b for b in range(nb)]
+                recs_b = [to_tx_records(rsa, nd.packets(a, tb[b], 96)) for b, a in enumerate(lists)]
+                dev = [DeviceArray(r) for r in recs_b]
+                per_tick = [[] for _ in range(nb)]
+                for eng in engines:
+                    eng.batch_run_device(tb, [v + 100 for v in tb], [d.ptr.value for d in dev], [len(a) for a in lists])
+                    views, status = eng.batch_result_view(nb)
+                    assert status == [0] * nb, what
+                    for b in range(nb):
+                        v = views[b]
+                        per_tick[b].append((v.pkt.copy(), v.dst.copy(), v.verdict.copy(), v.rssi.copy(), v.sinr.copy()))
+                for b in range(nb):
+                    refb = O.tick(mdl, nd, nd.packets(lists[b], tb[b], 96))
+                    mb = D.merge_shard_links(per_tick[b], len(lists[b]))
+                    assert len(mb[0]) == refb.count, what + " step %d batch tick %d" % (step, b)
+                    np.testing.assert_array_equal(mb[0], refb.pkt, err_msg=what)
+                    np.testing.assert_array_equal(mb[1], refb.dst, err_msg=what)
+                    np.testing.assert_array_equal(mb[2], refb.verdict, err_msg=what)
+                    np.testing.assert_array_equal(mb[3], refb.rssi, err_msg=what)
+                for d in dev:
+                    d.free()
         assert drew > 0 or not lossy or kind == "udgm_const", what
     finally:
         for eng in engines:
