@@ -6,7 +6,7 @@ Each run is a short random "session" against the oracle, tick by tick."""
 import numpy as np
 import pytest
 
-from util import configure_engine, oracle_model, to_tx_records, assert_same, DeviceArray
+from util import configure_engine, oracle_model, to_tx_records, assert_same, DeviceArray, KINDS, _PARAM_MAP
 
 pytestmark = pytest.mark.gpu
 
@@ -86,6 +86,22 @@ def test_random_sessions(engine, rsa, O, block):
                 nd.rxprob[i] = float(rng.choice([1.0, 0.5]))
             engine.update_node(i, nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]),
                                nd.rxprob[i], nd.txprob[i])
+        # the medium's parameters change between ticks (setters of the reference's media / a new propagation option)
+        if not sinr and rng.random() < 0.25:
+            if kind == "udgm":
+                params = dict(params, udgm_transmission_range=float(rng.choice([40.0, 50.0, 90.0])))
+            elif kind == "udgm_const":
+                params = dict(params, const_range=float(rng.choice([50.0, 100.0, 130.0])))
+            else:
+                params = dict(params, ld_sensitivity_dbm=float(rng.choice([-95.0, -92.0, -88.0])),
+                              ld_sigma_db=float(rng.choice([0.0, 4.0, 6.0])), ld_exponent=float(rng.choice([2.5, 3.0, 3.5])))
+            engine.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            mdl = oracle_model(O, kind, params)
+        # ... and so does the receiver range this context owns
+        if part is not None and rng.random() < 0.3:
+            lo = int(rng.integers(0, n // 2))
+            part = (lo, int(rng.integers(1, n - lo)))
+            engine.set_partition(*part)
         t = int(rng.choice([1, 40, 300, 700]))
         srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
         air = int(rng.choice([320, 960, 2500, 8128])) if sinr else 320
