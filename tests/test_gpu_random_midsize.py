@@ -157,6 +157,34 @@ def test_random_sessions(engine, rsa, O, block):
             assert_same(gpu, cpu, what + " step %d mode %d" % (step, mode))
             assert engine.rng_state == state, what + " step %d" % step
         heard += cpu.count
+        if sinr and not sinr_host and part is None and rng.random() < 0.5:
+            # several short SINR ticks in one call: accepted when nothing is on the air at their start and no
+            # frame but the last tick's outlives its tick; refused (RM_ERR_STATE) otherwise -> one tick at a time
+            nb = int(rng.integers(2, 5))
+            lists = [np.sort(rng.choice(n, int(rng.choice([1, 50, 300])), replace=False)).astype(np.int32) for _ in range(nb)]
+            tb = [t0 + 400 + 100 * b for b in range(nb)]
+            airs = [int(rng.choice([32, 96])) for _ in range(nb - 1)] + [int(rng.choice([64, 900, 5000]))]
+            dev = [DeviceArray(a) for a in lists]
+            try:
+                engine.batch_run_sources_device(tb, [v + 100 for v in tb], [d.ptr.value for d in dev], [len(a) for a in lists], tb, airs)
+                got = [engine.batch_result_copy(b, len(lists[b])) for b in range(nb)]
+            except rsa.RadioMediumError as e:
+                assert e.code == -5, what
+                got = []
+                for b in range(nb):
+                    engine.tick_run_sources_device(tb[b], tb[b] + 100, dev[b].ptr.value, len(lists[b]), tb[b], airs[b])
+                    got.append(engine.result_copy(len(lists[b])))
+            for b in range(nb):
+                onair = onair[onair["start_us"] + onair["air_us"] > tb[b]]
+                newb = nd.packets(lists[b], tb[b], airs[b])
+                act = np.concatenate([onair, newb])
+                cpub = O.tick(mdl, nd, act, first_new=len(onair), rng_state=state)
+                state = cpub.rng_state
+                onair = act
+                assert_same(got[b], cpub, what + " step %d short tick %d of %d" % (step, b, nb))
+            assert engine.rng_state == state, what
+            for d in dev:
+                d.free()
         if sinr or part is not None:
             continue
         # a few single packets (rm_transmit: one launch of one workgroup where the links fit its lists) ...
