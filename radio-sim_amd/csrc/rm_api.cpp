@@ -209,8 +209,8 @@ struct rm_context : TickSlot {
     int h_tx_gen = 0;
     uint32_t transmit_seq = 0;
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
-    // larger batches upload them with one copy from pinned host memory (two staging buffers, each
-    // guarded by an event: it is rewritten only after the copy that read it has completed)
+    // larger batches: k_fetch_ticks reads them from pinned, host-mapped memory (two staging buffers, each
+    // guarded by an event: it is rewritten only after the kernel that read it has completed)
     rm::TickDev *h_ticks[2] = {nullptr, nullptr};
     hipEvent_t h_ticks_ev[2] = {nullptr, nullptr};
     int h_ticks_gen = 0;
@@ -1907,18 +1907,18 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     // batch's kernels, which read the same array)
     RM_HIP(c->d_ticks.ensure(RM_MAX_BATCH));
     rm::TickDev *dev_ticks = c->d_ticks.p;
-    const bool by_copy = n > 2 * 6; // beyond two k_store_ticks launches one pinned copy is cheaper
+    const bool by_copy = n > 2 * 6; // beyond two k_store_ticks launches: one fetch from pinned, host-mapped memory
     if (by_copy) {
         const int g = c->h_ticks_gen;
         c->h_ticks_gen ^= 1;
         if (!c->h_ticks[g]) {
-            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ticks[g]), sizeof(rm::TickDev) * RM_MAX_BATCH, hipHostMallocDefault));
+            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ticks[g]), sizeof(rm::TickDev) * RM_MAX_BATCH, hipHostMallocMapped));
             RM_HIP(hipEventCreateWithFlags(&c->h_ticks_ev[g], hipEventDisableTiming));
         } else {
             RM_HIP(hipEventSynchronize(c->h_ticks_ev[g]));
         }
         std::memcpy(c->h_ticks[g], ticks, sizeof(rm::TickDev) * size_t(n));
-        RM_HIP(hipMemcpyAsync(dev_ticks, c->h_ticks[g], sizeof(rm::TickDev) * size_t(n), hipMemcpyHostToDevice, c->stream));
+        RM_HIP(rm::launch_fetch_ticks(c->stream, c->h_ticks[g], n, dev_ticks)); // the device reads the mapped block itself
         RM_HIP(hipEventRecord(c->h_ticks_ev[g], c->stream));
     }
     const rm::ModelDev m = model_dev(c);

@@ -249,6 +249,7 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
 hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst);
 hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int pkt_shift_valid, const HostView &v, uint32_t *done_counter,
                             uint32_t seq);
+hipError_t launch_fetch_ticks(hipStream_t s, const TickDev *host_mapped, int n, TickDev *dev_ticks);
 hipError_t launch_pack_batch(hipStream_t s, const PackSlot *dev_slots, int n_slots, const HostView &v, BatchCounts *host_counts,
                              uint32_t *done_counter, uint32_t seq);
 hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped);

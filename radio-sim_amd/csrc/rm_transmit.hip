@@ -27,6 +27,22 @@ __global__ void __launch_bounds__(64) k_store_ticks(const TickGroup g, TickDev *
     for (int i = threadIdx.x; i < int(sizeof(TickDev) / 4); i += blockDim.x) out[i] = src[i];
 }
 
+// larger batches: the descriptors are read from pinned, host-mapped memory by the device itself (no copy
+// engine between two kernels of the stream)
+__global__ void __launch_bounds__(64) k_fetch_ticks(const TickDev *__restrict__ host_mapped, TickDev *dst, int n)
+{
+    if (int(blockIdx.x) >= n) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(host_mapped + blockIdx.x);
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst + blockIdx.x);
+    for (int i = threadIdx.x; i < int(sizeof(TickDev) / 4); i += blockDim.x) out[i] = src[i];
+}
+
+hipError_t launch_fetch_ticks(hipStream_t s, const TickDev *host_mapped, int n, TickDev *dev_ticks)
+{
+    hipLaunchKernelGGL(k_fetch_ticks, dim3(n), dim3(64), 0, s, host_mapped, dev_ticks, n);
+    return hipGetLastError();
+}
+
 // ============================================================================ per-packet call
 // rm_transmit (one RadioMedium.transmit): the packet's record travels in the kernel arguments, and
 // its heard links come back through ONE block of host-mapped memory (header + up to kTransmitMax
