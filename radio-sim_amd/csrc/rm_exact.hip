@@ -2,6 +2,8 @@
 // (part of libradiomedium_hip.so; gfx950 only, -ffp-contract=off, no fast-math; overview at the top of rm_engine.h)
 #include "rm_device.hpp"
 
+#include <stdlib.h>
+
 namespace rm {
 
 // One lane per candidate link (full waves): the reference's fp64 arithmetic.
@@ -53,21 +55,44 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
         if (blockIdx.x >= n_chunks && !publisher) return;
         if (kRegScan) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
     }
-    auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) {
+    // an entry's inputs, requested ahead of its evaluation (PACKED walks request the next chunk's before
+    // they evaluate the current one: the gathers of one chunk fly under the arithmetic of the other)
+    struct Loaded {
+        uint32_t idx;
+        bool valid;
+        int erel, pos;
+        rm_tx_record tx;
+        RxRecord rx;
+    };
+    auto load = [&](const uint32_t shard, const uint32_t it, const uint32_t n) -> Loaded {
+        Loaded L;
         const uint32_t i = it + threadIdx.x;
-        const bool valid = i < n;
-        const uint32_t idx = shard * t.seg_cap + i;
+        L.valid = i < n;
+        L.idx = shard * t.seg_cap + i;
+        L.erel = 0;
+        L.pos = 0;
+        if (L.valid) {
+            L.erel = t.st_pkt[L.idx];
+            L.pos = t.st_dst[L.idx];
+            L.tx = t.tx[t.first_eval + L.erel];
+            L.rx = nd.rec[L.pos];
+        }
+        return L;
+    };
+    auto finish = [&](const Loaded &L) {
+        const bool valid = L.valid;
+        const uint32_t idx = L.idx;
         bool wanted = false;
         int slot = -1, key = -1;
         uint8_t fl = 0;
         double rssi = 0.0, prob = 1.0;
         int orig = 0;
         if (valid) {
-            const int erel = t.st_pkt[idx];
-            const int pos = t.st_dst[idx];
-            const rm_tx_record tx = t.tx[t.first_eval + erel];
+            const int erel = L.erel;
+            const int pos = L.pos;
+            const rm_tx_record &tx = L.tx;
             const bool is_new = (t.first_eval + erel) >= t.first_new;
-            const RxRecord rx_ = nd.rec[pos];
+            const RxRecord &rx_ = L.rx;
             const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, rx_, is_new);
             fl = ev.append ? ev.flags : uint8_t(0);
             if (ev.append && MODEL != RM_MODEL_NULL && MODEL != RM_MODEL_UDGM_CONST && tx_success(m, tx) <= 0.0) fl |= kFlagTxDead;
@@ -125,14 +150,31 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             }
         }
     };
+    auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) { finish(load(shard, it, n)); };
     if (PACKED) {
-        for (uint32_t u = blockIdx.x; u < n_chunks; u += gridDim.x) { // block-uniform
+        auto load_chunk = [&](const uint32_t u) -> Loaded {
             uint32_t lo = 0, hi = kShards; // the shard whose chunk range holds u: s_cs[lo] <= u < s_cs[lo + 1]
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (uniform_u(s_cs[mid]) <= u) lo = mid; else hi = mid;
             }
-            entries(lo, (u - uniform_u(s_cs[lo])) << 8, uniform_u(s_sn[lo]));
+            return load(lo, (u - uniform_u(s_cs[lo])) << 8, uniform_u(s_sn[lo]));
+        };
+        uint32_t u = blockIdx.x;
+        if (u < n_chunks) {
+            Loaded cur = load_chunk(u);
+            for (;;) { // block-uniform
+                const uint32_t un = u + gridDim.x;
+                if (un < n_chunks) {
+                    const Loaded nxt = load_chunk(un); // requested before the current chunk is evaluated
+                    finish(cur);
+                    cur = nxt;
+                    u = un;
+                } else {
+                    finish(cur);
+                    break;
+                }
+            }
         }
     } else {
         for (uint32_t it = blockIdx.x * blockDim.x; it < n_own; it += stride) entries(blockIdx.y, it, n_own); // block-uniform trip count
@@ -431,7 +473,12 @@ hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev 
                               const LaunchCfg &cfg)
 {
     const int scan = batch_scan_variant(ticks, n);
-    const dim3 grid(kShards, 1, n), block(256); // packed: one started chunk of 256 entries per workgroup at the bench sizes
+    // packed walk: a workgroup takes every gridDim.x-th started chunk of 256 entries and requests the next
+    // chunk's records before it evaluates the current one, so it wants several chunks: about one
+    // workgroup per CU and tick slot in flight (1024 in all), the ticks of the batch bring the rest
+    int gx = max(8, min(int(kShards), 1024 / n));
+    if (const char *e = getenv("RM_EXACT_GRID")) gx = max(1, min(int(kShards), atoi(e)));
+    const dim3 grid(gx, 1, n), block(256);
 #define RM_EXB(MODEL)                                                                                                \
 do {                                                                                                             \
     if (cfg.stochastic) {                                                                                        \
