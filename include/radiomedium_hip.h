@@ -98,7 +98,7 @@ typedef struct rm_device_result {
     const int32_t *dst;         /* [count] receiver node index */
     const uint8_t *verdict;     /* [count] RM_INTERFERED / RM_DELIVERED */
     const double *rssi;         /* [count] */
-    const double *sinr;         /* [count] (logdist+SINR only, else 0) */
+    const double *sinr;         /* [count] with the SINR extension, else NULL (host copies deliver 0) */
     uint32_t capacity;
 } rm_device_result;
 

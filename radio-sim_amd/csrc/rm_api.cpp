@@ -623,7 +623,6 @@ int ensure_link_buffers(rm_context *c, TickSlot &ts, int feat)
         RM_HIP(ts.d_out_dst.ensure(cap));
         RM_HIP(ts.d_out_verdict.ensure(cap));
         RM_HIP(ts.d_out_rssi.ensure(cap));
-        RM_HIP(ts.d_out_sinr.ensure(cap));
         RM_HIP(ts.d_a_pkt.ensure(cap));
         RM_HIP(ts.d_a_dst.ensure(cap));
         RM_HIP(ts.d_a_verdict.ensure(cap));
@@ -642,6 +641,7 @@ int ensure_link_buffers(rm_context *c, TickSlot &ts, int feat)
         RM_HIP(ts.d_st_sinr.ensure(cap));
         RM_HIP(ts.d_st_coll.ensure(cap));
         RM_HIP(ts.d_a_sinr.ensure(cap));
+        RM_HIP(ts.d_out_sinr.ensure(cap));
         RM_HIP(ts.d_a_e.ensure(cap));
     }
     if (feat & kFeatDraws) {
@@ -831,7 +831,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.out_dst = ts.d_out_dst.p;
     t.out_verdict = ts.d_out_verdict.p;
     t.out_rssi = ts.d_out_rssi.p;
-    t.out_sinr = ts.d_out_sinr.p;
+    t.out_sinr = sinr ? ts.d_out_sinr.p : nullptr; // only the SINR extension writes it: 8 of a record's 25 bytes
     t.out_prob = ts.d_out_prob.p;
     if (cfg.sorted) {
         t.a_pkt = ts.d_a_pkt.p;
@@ -1418,7 +1418,8 @@ static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uin
         if (dst) RM_HIP(hipMemcpyAsync(dst, ts.d_out_dst.p, k * 4ull, hipMemcpyDeviceToHost, s));
         if (verdict) RM_HIP(hipMemcpyAsync(verdict, ts.d_out_verdict.p, k, hipMemcpyDeviceToHost, s));
         if (rssi) RM_HIP(hipMemcpyAsync(rssi, ts.d_out_rssi.p, k * 8ull, hipMemcpyDeviceToHost, s));
-        if (sinr) RM_HIP(hipMemcpyAsync(sinr, ts.d_out_sinr.p, k * 8ull, hipMemcpyDeviceToHost, s));
+        if (sinr && ts.last.out_sinr) RM_HIP(hipMemcpyAsync(sinr, ts.last.out_sinr, k * 8ull, hipMemcpyDeviceToHost, s));
+        else if (sinr) std::memset(sinr, 0, k * 8ull);
     }
     const int n_new = ts.last_n_new;
     if (pkt_interference && n_new > 0)
@@ -1811,7 +1812,7 @@ static int result_device(rm_context *c, TickSlot &ts, rm_device_result *out)
     out->dst = ts.d_out_dst.p;
     out->verdict = ts.d_out_verdict.p;
     out->rssi = ts.d_out_rssi.p;
-    out->sinr = ts.d_out_sinr.p;
+    out->sinr = ts.last.out_sinr; // NULL without the SINR extension
     out->capacity = c->cap;
     return RM_OK;
 }

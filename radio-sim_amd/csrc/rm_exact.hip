@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) k_finalize(ModelDev m, TickDev t)
         t.out_dst[o] = t.st_orig[e];
         t.out_rssi[o] = t.st_aux[e];
         const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
-        t.out_sinr[o] = sinr ? t.st_sinr[e] : 0.0;
+        if (t.out_sinr) t.out_sinr[o] = sinr ? t.st_sinr[e] : 0.0;
         const bool collided = sinr && t.st_coll[e];
         if (STOCH) {
             t.out_prob[o] = t.st_prob[e];

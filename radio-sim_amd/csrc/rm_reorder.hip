@@ -93,9 +93,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 if (SINR) {
                     t.out_sinr[d] = t.st_sinr[in_e];
                     if (t.st_coll[in_e]) vv = RM_INTERFERED;
-                } else {
-                    t.out_sinr[d] = 0.0;
-                }
+                } // no SINR extension: the record carries no sinr (the array is not even allocated; readers give 0)
                 t.out_verdict[d] = vv;
                 if (STOCH) t.out_prob[d] = in_prob;
             }
