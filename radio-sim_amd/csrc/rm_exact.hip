@@ -96,7 +96,7 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, rx_, is_new);
             fl = ev.append ? ev.flags : uint8_t(0);
             if (ev.append && MODEL != RM_MODEL_NULL && MODEL != RM_MODEL_UDGM_CONST && tx_success(m, tx) <= 0.0) fl |= kFlagTxDead;
-            t.st_flags[idx] = fl;
+            if (SEG == 0 || SINR) t.st_flags[idx] = fl; // read by the ordered scatter / the SINR pass only
             if (ev.append) {
                 orig = rx_.orig;
                 if (MODEL == RM_MODEL_LOGDIST) {

@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
                 const uint32_t idx = fbase + pre + lane_prefix(mk);
                 t.st_pkt[idx] = e0 + ti;
                 t.st_dst[idx] = jbase + r * kGroup + lane;
-                t.st_blk[idx] = fbase;
+                if (t.use_matrix) t.st_blk[idx] = fbase; // the run's base: only the ordered scatter of unsorted tables ranks inside it
             }
             pre += uint32_t(__popcll(mk));
         }
@@ -658,7 +658,7 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
                             const uint32_t idx = fbase + pre + lane_prefix(mk);
                             t.st_pkt[idx] = e_ti;
                             t.st_dst[idx] = jbase + r * kGroup + lane;
-                            t.st_blk[idx] = fbase;
+                            if (t.use_matrix) t.st_blk[idx] = fbase; // the run's base: only the ordered scatter of unsorted tables ranks inside it
                         }
                         pre += uint32_t(__popcll(mk));
                     }
