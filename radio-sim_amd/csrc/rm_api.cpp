@@ -147,6 +147,7 @@ struct rm_context : TickSlot {
     DevBuf<int32_t> d_rx_channel, d_rx_int_id, d_rx_orig, d_pos_of;
     DevBuf<uint8_t> d_rx_enabled;
     DevBuf<rm::RxRecord> d_rx_rec;
+    DevBuf<rm::RxCompact> d_rx_rec32;
     DevBuf<float4> d_rxf, d_bbox_xy, d_wg_box_xy;
     DevBuf<float2> d_wg_box_z;
     DevBuf<float2> d_bbox_z;
@@ -378,6 +379,8 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.orig = c->d_rx_orig.p;
     nd.enabled = c->d_rx_enabled.p;
     nd.rec = c->d_rx_rec.p;
+    static const bool no_rec32 = std::getenv("RM_NO_REC32") != nullptr;
+    nd.rec32 = no_rec32 ? nullptr : c->d_rx_rec32.p;
     nd.pos_of = c->d_pos_of.p;
     nd.rx_first = part_first(c);
     nd.rxf = c->d_rxf.p;
@@ -503,6 +506,19 @@ int rebuild_receivers(rm_context *c)
             r.channel = c->channel[k];
             r.enabled = c->enabled[k];
         }
+        std::vector<rm::RxCompact> small(count);
+        for (int i = 0; i < count; ++i) {
+            const int k = perm[i];
+            rm::RxCompact &r = small[i];
+            r.x = c->x[k];
+            r.y = c->y[k];
+            r.z = c->z[k];
+            r.orig = k;
+            r.flags = (c->rxprob[k] != 1.0) ? 1u : 0u;
+        }
+        RM_HIP(c->d_rx_rec32.ensure(std::max(count, 1)));
+        if (count)
+            RM_HIP(hipMemcpyAsync(c->d_rx_rec32.p, small.data(), size_t(count) * sizeof(rm::RxCompact), hipMemcpyHostToDevice, c->stream));
         RM_HIP(c->d_rx_rec.ensure(std::max(count, 1)));
         if (count) {
             RM_HIP(hipMemcpyAsync(c->d_rx_rec.p, recs.data(), size_t(count) * sizeof(rm::RxRecord), hipMemcpyHostToDevice, c->stream));
@@ -1101,7 +1117,7 @@ void rm_destroy(rm_context *c)
     c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release();
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
-    c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rxf.release(); c->d_bbox_xy.release();
+    c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rx_rec32.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
     c->d_patch.release();

@@ -95,6 +95,17 @@ struct NodePatch {
     int32_t channel, enabled;
 };
 
+// The same receiver for the exact stage of the spatially sorted media, in 32 bytes: every candidate of
+// those media passed the sweep's exact channel test and its "radio enabled" test (a disabled radio has NaN
+// pre-filter coordinates), so the record carries neither; a reception probability other than 1.0 is
+// flagged and read from the rxprob column.  Half the bytes per gathered candidate, and the table of
+// 100 k receivers (3.2 MB) fits one XCD's L2.
+struct alignas(32) RxCompact {
+    double x, y, z;
+    int32_t orig;     // node index (registration order)
+    uint32_t flags;   // bit 0: rxprob != 1.0
+};
+
 struct NodesDev {
     int n;                                   // nodes in the simulator
     const double *sx, *sy, *sz, *stxpower, *stxprob;
@@ -103,7 +114,8 @@ struct NodesDev {
     const double *x, *y, *z, *rxprob;
     const int32_t *channel, *int_id, *orig;
     const uint8_t *enabled;
-    const RxRecord *rec;                     // [n_rx] the same data as one record per receiver (k_exact)
+    const RxRecord *rec;                     // [n_rx] the same data as one record per receiver (k_exact, unsorted tables; k_transmit_one)
+    const RxCompact *rec32;                  // [n_rx] 32-byte form for the exact stage of sorted tables
     const int32_t *pos_of;                   // [rx_count] node index - rx_first -> engine position
     int rx_first;
     float4 *rxf;                             // pre-filter record: (fx, fy, fz, channel bits); NaN = never a candidate

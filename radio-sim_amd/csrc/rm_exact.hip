@@ -75,7 +75,19 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             L.erel = t.st_pkt[L.idx];
             L.pos = t.st_dst[L.idx];
             L.tx = t.tx[t.first_eval + L.erel];
-            L.rx = nd.rec[L.pos];
+            if (SEG == 0 || nd.rec32 == nullptr) {
+                L.rx = nd.rec[L.pos];
+            } else { // sorted table: the 32-byte record; channel and radio state were tested by the sweep
+                const RxCompact c = nd.rec32[L.pos];
+                L.rx.x = c.x;
+                L.rx.y = c.y;
+                L.rx.z = c.z;
+                L.rx.orig = c.orig;
+                L.rx.int_id = 0;
+                L.rx.channel = L.tx.channel;
+                L.rx.enabled = 1;
+                L.rx.rxprob = (c.flags & 1u) ? nd.rxprob[L.pos] : 1.0;
+            }
         }
         return L;
     };

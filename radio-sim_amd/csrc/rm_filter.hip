@@ -97,6 +97,12 @@ __global__ void __launch_bounds__(256) k_patch_nodes(NodesDev nd, const NodePatc
     r->rxprob = p.rxprob;
     r->channel = p.channel;
     r->enabled = p.enabled;
+    if (!nd.rec32) return;
+    RxCompact *c = const_cast<RxCompact *>(nd.rec32) + p.pos;
+    c->x = p.x;
+    c->y = p.y;
+    c->z = p.z;
+    c->flags = (p.rxprob != 1.0) ? 1u : 0u;
 }
 
 __global__ void __launch_bounds__(256)
