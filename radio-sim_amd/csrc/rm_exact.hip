@@ -162,7 +162,6 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             }
         }
     };
-    auto entries = [&](const uint32_t shard, const uint32_t it, const uint32_t n) { finish(load(shard, it, n)); };
     if (PACKED) {
         auto load_chunk = [&](const uint32_t u) -> Loaded {
             uint32_t lo = 0, hi = kShards; // the shard whose chunk range holds u: s_cs[lo] <= u < s_cs[lo + 1]
@@ -189,7 +188,22 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             }
         }
     } else {
-        for (uint32_t it = blockIdx.x * blockDim.x; it < n_own; it += stride) entries(blockIdx.y, it, n_own); // block-uniform trip count
+        uint32_t it = blockIdx.x * blockDim.x; // block-uniform trip count; pipelined like the packed walk
+        if (it < n_own) {
+            Loaded cur = load(blockIdx.y, it, n_own);
+            for (;;) {
+                const uint32_t nx = it + stride;
+                if (nx < n_own) {
+                    const Loaded nxt = load(blockIdx.y, nx, n_own);
+                    finish(cur);
+                    cur = nxt;
+                    it = nx;
+                } else {
+                    finish(cur);
+                    break;
+                }
+            }
+        }
     }
     if (SEG == 1 && !scanned && publisher) // seg_off is published even if this shard was empty
         block_scan_counts(t.cand_tot, t.n_cnt, s_seg, s_wave, t.seg_off, nullptr);
