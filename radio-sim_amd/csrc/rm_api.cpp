@@ -922,9 +922,30 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         }
         return RM_OK;
     };
+    // frames per tick up to which a lone tick takes the one-frame-per-workgroup path (RM_FRAME_TICK=0: never)
+    static const int frame_tick_max = [] {
+        const char *e = std::getenv("RM_FRAME_TICK");
+        return e ? std::atoi(e) : 4096;
+    }();
+    const int seg_len = (t.n_active - t.first_new <= frame_tick_max) ? rm::frame_tick_segment(t, cfg, m) : 0;
     auto sequence = [&]() -> int {
         if (sinr) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
         if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
+        if (seg_len > 0) {
+            // the closed-loop tick: filter + exact evaluation of a frame inside one workgroup (rm_tick.hip),
+            // then the per-frame reorder -- two dependent launches instead of three
+            RM_TRY(stage(RM_STAGE_FILTER));
+            RM_HIP(rm::launch_tick_frames(s, nd, m, t, cfg, seg_len));
+            RM_TRY(stage(RM_STAGE_REORDER));
+            RM_HIP(rm::launch_reorder(s, m, t, cfg));
+            if (stochastic) {
+                RM_TRY(stage(RM_STAGE_DRAWS));
+                RM_HIP(rm::launch_draws_scan(s, t));
+                if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
+            }
+            if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+            return RM_OK;
+        }
         RM_TRY(stage(RM_STAGE_FILTER));
         RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
         RM_TRY(stage(RM_STAGE_EXACT));
@@ -968,7 +989,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         mix(&nd, sizeof(nd));
         mix(&m, sizeof(m));
         mix(&t, sizeof(t));
-        const int bits[7] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, cfg.shadow, partitioned};
+        const int bits[8] = {cfg.f64_filter, cfg.stochastic, cfg.sorted, cfg.bbox, sinr, cfg.shadow, partitioned, seg_len};
         mix(bits, sizeof(bits));
         hipGraphExec_t exec = nullptr;
         for (auto &g : c->graphs)

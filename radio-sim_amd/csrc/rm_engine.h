@@ -20,7 +20,7 @@
 //
 // Files: rm_math.hpp (exact arithmetic: E-math, link hash, Q80, java.util.Random), rm_device.hpp
 // (shared device code: wave helpers, pre-filter records, eval_link, fused scans), rm_filter.hip,
-// rm_exact.hip, rm_reorder.hip, rm_transmit.hip (kernels + their launchers), rm_api.cpp (C ABI).
+// rm_exact.hip, rm_reorder.hip, rm_transmit.hip, rm_tick.hip (kernels + their launchers), rm_api.cpp (C ABI).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -39,6 +39,7 @@ constexpr int kShadowBins = 256;    // bins over rho = d^2 / cut^2 of the shadow
 constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
 enum { kFilterGrid = 0, kFilterWg = 2 }; // TickDev::filter_mode (plan_filter)
 constexpr int kShardStride = 32;
+constexpr int kFrameSegMax = 512;   // heard links of one frame kept in LDS by k_tick_frames (rm_tick.hip) = its fixed segment of the A records
 constexpr int kMaxBatch = RM_MAX_BATCH; // ticks per batched launch (descriptors in device memory)    // u32 words between shard counters: one 128-byte line each
 
 // link-entry flags
@@ -285,6 +286,10 @@ hipError_t launch_batch_stage(hipStream_t s, int stage, const NodesDev &nd, cons
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                         const LaunchCfg &cfg);
+// the closed-loop tick (rm_tick.hip): one frame per workgroup, filter + exact evaluation in one launch
+int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
+hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg,
+                              int seg_len);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);
 hipError_t launch_offsets(hipStream_t s, const TickDev &t);
 hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t);
