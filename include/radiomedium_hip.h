@@ -188,7 +188,8 @@ typedef struct rm_host_result {
     const uint8_t *pkt_interference; /* [n_packets] Tx-failure flag (UDGMRadioMedium.java:88-92) */
     const int32_t *pkt, *dst;        /* [count] packet, receiver node index (ascending per packet) */
     const uint8_t *verdict;          /* [count] RM_INTERFERED / RM_DELIVERED */
-    const double *rssi, *sinr;       /* [count] */
+    const double *rssi;              /* [count] */
+    const double *sinr;              /* [count] with the SINR extension, else NULL (as rm_device_result.sinr) */
 } rm_host_result;
 int rm_tick_flush_view(rm_context *ctx, rm_host_result *out);
 

@@ -122,6 +122,11 @@ struct TickSlot {
     int last_n_new = 0;
     bool have_result = false;
     int64_t last_links = 0;
+    // the closed-loop tick (rm_tick.hip) leaves per-frame ordered segments; the compact packet-major
+    // arrays of rm_device_result are produced (k_reorder) when somebody asks for them
+    bool compact_pending = false;
+    rm::ModelDev last_model{};
+    rm::LaunchCfg last_cfg{};
 
     void release_all();
 };
@@ -729,6 +734,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
 {
     const int n_new = n_active - first_new;
     ts.have_result = false;
+    ts.compact_pending = false;
     ts.last_n_new = n_new;
     RM_TRY(prepare_nodes(c));
 
@@ -932,13 +938,13 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         if (sinr) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
         if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         if (seg_len > 0) {
-            // the closed-loop tick: filter + exact evaluation of a frame inside one workgroup (rm_tick.hip),
-            // then the per-frame reorder -- two dependent launches instead of three
+            // the closed-loop tick: filter, exact evaluation and node order of a frame inside one workgroup
+            // (rm_tick.hip) -- ONE launch; the compact arrays only for the draw kernels, or on demand
             RM_TRY(stage(RM_STAGE_FILTER));
             RM_HIP(rm::launch_tick_frames(s, nd, m, t, cfg, seg_len));
-            RM_TRY(stage(RM_STAGE_REORDER));
-            RM_HIP(rm::launch_reorder(s, m, t, cfg));
             if (stochastic) {
+                RM_TRY(stage(RM_STAGE_REORDER));
+                RM_HIP(rm::launch_reorder(s, m, t, cfg));
                 RM_TRY(stage(RM_STAGE_DRAWS));
                 RM_HIP(rm::launch_draws_scan(s, t));
                 if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
@@ -1028,7 +1034,19 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         ts.draws_pending = true;
         ts.pending_model = m;
     }
+    ts.compact_pending = seg_len > 0 && !stochastic;
+    ts.last_model = m;
+    ts.last_cfg = cfg;
     ts.have_result = true;
+    return RM_OK;
+}
+
+// the compact packet-major arrays of a tick that so far only has its per-frame segments
+int materialize(rm_context *c, TickSlot &ts)
+{
+    if (!ts.compact_pending) return RM_OK;
+    RM_HIP(rm::launch_reorder(c->stream, ts.last_model, ts.last, ts.last_cfg));
+    ts.compact_pending = false;
     return RM_OK;
 }
 
@@ -1443,6 +1461,7 @@ static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uin
     if (ts.draws_pending)
         return fail(RM_ERR_STATE, "this rank's verdicts wait for the other ranks' draw counts: exchange "
                                   "rm_draw_counts_device and call rm_tick_finish_draws first");
+    RM_TRY(materialize(c, ts));
     hipStream_t s = c->stream;
     uint32_t oc[5] = {0, 0, 0, 0, 0}; // [4]: a SINR tick of a batch held a frame outside its [t_begin, t_end]
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
@@ -1533,7 +1552,10 @@ static int pack_to_stage(rm_context *c, TickSlot &ts, rm::HostView *view)
     for (int attempt = 0; attempt < 2; ++attempt) {
         const rm::HostView v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
         const uint32_t seq = ++c->stage_seq;
-        RM_HIP(rm::launch_pack_tick(c->stream, ts.last, n_new, have_offsets, v, c->d_pack_done.p, seq));
+        if (ts.compact_pending) // straight from the frames' segments: no compact arrays in between
+            RM_HIP(rm::launch_pack_frames(c->stream, ts.last_model, ts.last, n_new, v, c->d_pack_done.p, seq));
+        else
+            RM_HIP(rm::launch_pack_tick(c->stream, ts.last, n_new, have_offsets, v, c->d_pack_done.p, seq));
         // poll the sequence number (the kernel publishes it after everything else); a stream
         // synchronisation bounds the wait
         volatile const uint32_t *flag = &v.hdr->seq;
@@ -1579,7 +1601,7 @@ int rm_tick_flush_view(rm_context *c, rm_host_result *out)
     out->dst = v.dst;
     out->verdict = v.verdict;
     out->rssi = v.rssi;
-    out->sinr = v.sinr;
+    out->sinr = c->last.out_sinr ? v.sinr : nullptr; // written by the SINR extension only
     return stage_status(v);
 }
 
@@ -1598,7 +1620,8 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
         if (dst) std::memcpy(dst, v.dst, k * sizeof(int32_t));
         if (verdict) std::memcpy(verdict, v.verdict, k);
         if (rssi) std::memcpy(rssi, v.rssi, k * sizeof(double));
-        if (sinr) std::memcpy(sinr, v.sinr, k * sizeof(double));
+        if (sinr && c->last.out_sinr) std::memcpy(sinr, v.sinr, k * sizeof(double));
+        else if (sinr) std::memset(sinr, 0, k * sizeof(double));
     }
     const uint32_t np = v.hdr->n_packets;
     if (pkt_interference && np) std::memcpy(pkt_interference, v.pkt_interference, np);
@@ -1714,6 +1737,7 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
         if (interference) *interference = 0;
         return RM_OK;
     }
+    RM_TRY(materialize(c, *c));
     RM_HIP(rm::launch_pack_result(c->stream, c->last, c->h_transmit));
     RM_HIP(hipStreamSynchronize(c->stream));
     const rm::TransmitResult &r = *c->h_transmit;
@@ -1843,6 +1867,8 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
 static int result_device(rm_context *c, TickSlot &ts, rm_device_result *out)
 {
     if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(materialize(c, ts));
     out->count = ts.last.out_count;
     out->pkt_offset = ts.d_slot_off.p + ts.last.shift;
     out->pkt = ts.d_out_pkt.p;
@@ -1912,6 +1938,7 @@ static int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *
 {
     if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(materialize(c, ts));
     uint32_t oc[5];
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
@@ -1999,7 +2026,10 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
         RM_HIP(rm::launch_draws_batch(s, m, ticks, n, dev_ticks));
     }
     if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
-    for (int b = 0; b < n; ++b) slots[b]->have_result = true;
+    for (int b = 0; b < n; ++b) {
+        slots[b]->have_result = true;
+        slots[b]->compact_pending = false;
+    }
     return RM_OK;
 }
 
@@ -2144,6 +2174,7 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
         TickSlot *ts = slot_of(c, b);
         if (!ts || !ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick in this result slot");
         if (ts->draws_pending) return fail(RM_ERR_STATE, "a slot's verdicts wait for rm_tick_finish_draws");
+        RM_TRY(materialize(c, *ts));
         rm::PackSlot &ps = c->h_pack[b];
         ps.t = ts->last;
         ps.n_new = std::max(ts->last_n_new, 0);
@@ -2183,7 +2214,7 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
         r.dst = v.dst + bc.link_base;
         r.verdict = v.verdict + bc.link_base;
         r.rssi = v.rssi + bc.link_base;
-        r.sinr = v.sinr + bc.link_base;
+        r.sinr = ps.t.out_sinr ? v.sinr + bc.link_base : nullptr;
         int st = RM_OK;
         if (bc.span_flag)
             st = fail(RM_ERR_STATE, "a frame of a SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");

@@ -1,45 +1,81 @@
-// rm_tick.hip -- the closed-loop tick: ONE frame per workgroup, filter + exact evaluation in one launch
+// rm_tick.hip -- the closed-loop tick: ONE frame per workgroup, filter + exact evaluation + node order in one launch
 // (part of libradiomedium_hip.so; gfx950 only, -ffp-contract=off, no fast-math; overview at the top of rm_engine.h)
 //
 // A lone tick is what the reference's call pattern produces: the emulators step, their transmit()
 // calls are evaluated, the events are consumed in emulatorTimeStepDone (Simulator.java:155-165), and
 // only then does the next tick begin.  Its few MB of work cannot fill the chip, so what it costs is
-// the chain of dependent launches and memory round trips.  The sweep kernels (rm_filter / rm_exact)
-// need three dependent launches because the candidate list crosses workgroups; here a frame's whole
+// the chain of dependent launches and memory round trips (a kernel of this runtime cannot finish in
+// less than 3-4 us, whatever it does).  The sweep kernels (rm_filter / rm_exact / rm_reorder) are
+// three dependent launches because the candidate list crosses workgroups; here a frame's whole
 // evaluation stays inside one workgroup, as k_transmit_one (rm_transmit.hip) does for one packet:
 //
-//   level 1   the frame against the boxes of 1024 receivers (one box per thread)        -> LDS list
-//   level 2   the frame against the group boxes (64 receivers) of the near ones          -> LDS list
-//   level 3   the receivers of the near groups: fp32 pre-filter, exact channel test      -> LDS candidates
-//   exact     the candidates with full lanes: the reference's fp64 arithmetic (eval_link)
-//             UDGMRadioMedium.java:99-111, UDGMConstantLossRadioMedium.java:25-33          -> LDS links
-//   write     the frame's heard links into its own fixed segment of the A records
+//   boxes     the frame against the boxes of 16 receiver groups (1024 receivers), then the group boxes
+//             (64 receivers) of the near ones; small tables test every group box directly              -> LDS lists
+//   filter    the receivers of the near groups: fp32 pre-filter, exact channel test, and for the
+//             shadowed medium the sweep's second-level test on the link hash                         -> LDS candidates
+//   exact     the candidates with full lanes: the reference's fp64 arithmetic (eval_link),
+//             UDGMRadioMedium.java:99-111, UDGMConstantLossRadioMedium.java:25-33                     -> LDS links
+//   order     rank by node index -- the order the reference's loop visits receivers in
+//             (UDGMRadioMedium.java:99) -- and write the frame's links into its own segment of the A records
 //
-// k_reorder (rm_reorder.hip) then ranks every frame's links by node index and compacts them: two
-// launches per tick instead of three, no candidate list, no atomics on global memory.  Every level
-// works in rounds, so nothing is bounded by the LDS lists: a frame with more heard links than its
-// segment holds takes its room from an overflow allocator and evaluates its candidates a second time.
+// The result of the tick is then complete: per frame an ordered list (seg_off, cursor = count) in HBM.
+// Consumers that walk it frame by frame (the host-mapped pack k_pack_frames below, the reception
+// stage) read the segments as they are; the compact packet-major arrays of rm_device_result are
+// produced by k_reorder only when somebody asks for them (rm_result_device / rm_result_copy), and
+// before the java.util.Random kernels, which scan the compact records.  No candidate list, no
+// atomics on global memory.  Every level works in rounds, so nothing is bounded by the LDS lists:
+// a frame with more heard links than its segment holds takes its room from an overflow allocator,
+// evaluates its candidates a second time and sorts its links through global memory.
 #include "rm_device.hpp"
+
+#include <stdlib.h>
 
 namespace rm {
 
-constexpr int kFrBoxes = 1024; // level-1 boxes tested per round (4 per thread)
-constexpr int kFrGroups = 1024; // level-2 group boxes tested per round
-constexpr int kFrRound = 16;   // near groups per level-3 round: at most 1024 candidates
+constexpr int kFrBoxes = 1024;      // level-1 boxes tested per round (4 per thread)
+constexpr int kFrGroups = 2048;     // group boxes tested per round (8 per thread)
+constexpr int kFrFlatGroups = 256;  // up to here every group box is tested directly (no level 1)
+constexpr int kFrRound = 16;        // near groups per filter round: at most 1024 candidates
 constexpr int kFrCand = kFrRound * kGroup;
 
-template <int MODEL, bool STOCH>
+RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
+{
+    const float dx = fmaxf(fmaxf(qb.x - f.x, f.x - qb.z), 0.f);
+    const float dy = fmaxf(fmaxf(qb.y - f.y, f.y - qb.w), 0.f);
+    const float dz = fmaxf(fmaxf(qz.x - f.z, f.z - qz.y), 0.f);
+    return dist2_f32(dx, dy, dz) <= f.w;
+}
+
+template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
 __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
 {
-    __shared__ int s_l1[kFrBoxes], s_l2[kFrGroups], s_cand[kFrCand];
+    __shared__ int s_l1[FLAT ? 1 : kFrBoxes], s_l2[kFrGroups], s_cand[kFrCand];
     __shared__ int s_orig[kFrameSegMax];
     __shared__ double s_rssi[kFrameSegMax];
     __shared__ double s_prob[STOCH ? kFrameSegMax : 1];
     __shared__ uint32_t s_n1[2], s_n2[2], s_nc[2], s_nres, s_base; // the lists' fill counts, by round parity
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
     const int slot = blockIdx.x;
     const int n_new = t.n_active - t.first_new;
+    const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
+    const int n_boxes = (n_groups + 15) / 16;
+
+    // the first round's boxes do not depend on the frame: requested before its record
+    constexpr int kPre = FLAT ? kFrGroups / 256 : kFrBoxes / 256;
+    float4 pre_xy[kPre];
+    float2 pre_z[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int b = k * 256 + tid;
+        pre_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pre_z[k] = make_float2(0.f, 0.f);
+        if (b < (FLAT ? n_groups : n_boxes)) {
+            pre_xy[k] = FLAT ? nd.bbox_xy[b] : nd.wg_box_xy[b];
+            pre_z[k] = FLAT ? nd.bbox_z[b] : nd.wg_box_z[b];
+        }
+    }
 
     // what the sweep's first kernel does for the tick after this one (rm_filter.hip, tick_prep_body)
     if (blockIdx.x == 0) {
@@ -67,14 +103,22 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);
+    // shadowed medium: can the link still reach the level with its own deviate?  The sweep's second-level
+    // filter (rm_filter.hip): conservative table of the largest link hash that can, per bin of d^2 / cut^2
+    float shadow_inv = 0.f;
+    if (SHADOW) {
+        s_tbl[tid] = m.shadow_tbl[tid]; // kBlock == kShadowBins
+        if (f.w > 0.f && f.w < __builtin_inff()) {
+            const double cut = sqrt(double(f.w));
+            if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) shadow_inv = float(kShadowBins) / f.w;
+        }
+    }
     if (tid == 0) s_n1[0] = s_n1[1] = s_n2[0] = s_n2[1] = s_nc[0] = s_nc[1] = s_nres = s_base = 0u;
     __syncthreads();
     // A list's fill count of one round is cleared while the next round's -- the other parity -- is in use: every
-    // reuse of a list or a count is separated from its last reader by a barrier without extra barriers for the clearing.
+    // reuse of a list or a count is separated from its last reader by a barrier, without barriers for the clearing.
     int r1 = 0, r2 = 0, rc = 0;
 
-    const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
-    const int n_boxes = (n_groups + 15) / 16;
     const bool dead = (MODEL != RM_MODEL_UDGM_CONST) && tx_success(m, tx) <= 0.0; // UDGMRadioMedium.java:88
     const uint32_t seg = uint32_t(seg_len);
     const uint32_t fixed_base = uint32_t(slot) * seg;
@@ -83,48 +127,44 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     // and writes them straight to the room it got from the overflow allocator
     for (int pass = 0; pass < 2; ++pass) { // block-uniform
         if (f.w >= 0.f) {
-            for (int b0 = 0; b0 < n_boxes; b0 += kFrBoxes) {
-                // level 1
+            for (int b0 = 0; b0 < (FLAT ? 1 : n_boxes); b0 += kFrBoxes) {
+                int n1 = 0;
+                if (!FLAT) {
+                    // level 1: the boxes of 16 groups
 #pragma unroll
-                for (int k = 0; k < kFrBoxes / 256; ++k) {
-                    const int b = b0 + k * 256 + tid;
-                    bool hit = false;
-                    if (b < n_boxes) {
-                        const float4 qb = nd.wg_box_xy[b];
-                        const float2 qz = nd.wg_box_z[b];
-                        const float dx = fmaxf(fmaxf(qb.x - f.x, f.x - qb.z), 0.f);
-                        const float dy = fmaxf(fmaxf(qb.y - f.y, f.y - qb.w), 0.f);
-                        const float dz = fmaxf(fmaxf(qz.x - f.z, f.z - qz.y), 0.f);
-                        hit = dist2_f32(dx, dy, dz) <= f.w;
+                    for (int k = 0; k < kFrBoxes / 256; ++k) {
+                        const int b = b0 + k * 256 + tid;
+                        bool hit = false;
+                        if (b < n_boxes) {
+                            if (b0 == 0 && pass == 0) hit = box_near(pre_xy[k], pre_z[k], f);
+                            else hit = box_near(nd.wg_box_xy[b], nd.wg_box_z[b], f);
+                        }
+                        const uint64_t hm = ballot64(hit);
+                        if (hm) {
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&s_n1[r1 & 1], uint32_t(__popcll(hm)));
+                            base = uniform_u(base);
+                            if (hit) s_l1[base + lane_prefix(hm)] = b;
+                        }
                     }
-                    const uint64_t hm = ballot64(hit);
-                    if (hm) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&s_n1[r1 & 1], uint32_t(__popcll(hm)));
-                        base = uniform_u(base);
-                        if (hit) s_l1[base + lane_prefix(hm)] = b;
-                    }
+                    __syncthreads();
+                    n1 = uniform_i(int(s_n1[r1 & 1]));
+                    if (tid == 0) s_n1[(r1 + 1) & 1] = 0u;
+                    ++r1;
                 }
-                __syncthreads();
-                const int n1 = uniform_i(int(s_n1[r1 & 1]));
-                if (tid == 0) s_n1[(r1 + 1) & 1] = 0u;
-                ++r1;
-                for (int i0 = 0; i0 < n1 * 16; i0 += kFrGroups) {
-                    // level 2
+                const int n_l2 = FLAT ? n_groups : n1 * 16;
+                for (int i0 = 0; i0 < n_l2; i0 += kFrGroups) {
+                    // level 2: the group boxes
 #pragma unroll
                     for (int k = 0; k < kFrGroups / 256; ++k) {
                         const int i = i0 + k * 256 + tid;
                         bool hit = false;
                         int g = 0;
-                        if (i < n1 * 16) {
-                            g = s_l1[i >> 4] * 16 + (i & 15);
+                        if (i < n_l2) {
+                            g = FLAT ? i : s_l1[i >> 4] * 16 + (i & 15);
                             if (g < n_groups) {
-                                const float4 qb = nd.bbox_xy[g];
-                                const float2 qz = nd.bbox_z[g];
-                                const float dx = fmaxf(fmaxf(qb.x - f.x, f.x - qb.z), 0.f);
-                                const float dy = fmaxf(fmaxf(qb.y - f.y, f.y - qb.w), 0.f);
-                                const float dz = fmaxf(fmaxf(qz.x - f.z, f.z - qz.y), 0.f);
-                                hit = dist2_f32(dx, dy, dz) <= f.w;
+                                if (FLAT && i0 == 0 && pass == 0) hit = box_near(pre_xy[k < kPre ? k : 0], pre_z[k < kPre ? k : 0], f);
+                                else hit = box_near(nd.bbox_xy[g], nd.bbox_z[g], f);
                             }
                         }
                         const uint64_t hm = ballot64(hit);
@@ -140,26 +180,34 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                     if (tid == 0) s_n2[(r2 + 1) & 1] = 0u;
                     ++r2;
                     for (int gi0 = 0; gi0 < n2; gi0 += kFrRound) {
-                        // level 3: every wave takes four of the round's groups, their records requested together
+                        // filter: every wave takes four of the round's groups, their records requested together
                         float4 v[kFrRound / 4];
-                        int jj[kFrRound / 4];
+                        int jj[kFrRound / 4], oo[kFrRound / 4];
 #pragma unroll
                         for (int k = 0; k < kFrRound / 4; ++k) {
                             const int gi = gi0 + k * 4 + wave;
                             jj[k] = -1;
+                            oo[k] = 0;
                             v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (gi < n2) {
                                 const int j = s_l2[gi] * kGroup + lane;
                                 if (j < nd.n_rx) {
                                     jj[k] = j;
                                     v[k] = nd.rxf[j];
+                                    if (SHADOW) oo[k] = nd.orig[j];
                                 }
                             }
                         }
 #pragma unroll
                         for (int k = 0; k < kFrRound / 4; ++k) {
                             const float s2 = dist2_f32(v[k].x - f.x, v[k].y - f.y, v[k].z - f.z);
-                            const bool hit = jj[k] >= 0 && s2 <= f.w && __float_as_int(v[k].w) == tx.channel;
+                            bool hit = jj[k] >= 0 && s2 <= f.w && __float_as_int(v[k].w) == tx.channel;
+                            if (SHADOW && hit) {
+                                const int bin = min(kShadowBins - 1, int(s2 * shadow_inv));
+                                const uint32_t a = uint32_t(tx.src), b = uint32_t(oo[k]);
+                                const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
+                                hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                            }
                             const uint64_t hm = ballot64(hit);
                             if (hm) {
                                 uint32_t base = 0;
@@ -184,15 +232,15 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                                 if (nd.rec32 == nullptr) {
                                     rx_ = nd.rec[pos];
                                 } else { // the 32-byte record: channel and radio state were tested above
-                                    const RxCompact rc = nd.rec32[pos];
-                                    rx_.x = rc.x;
-                                    rx_.y = rc.y;
-                                    rx_.z = rc.z;
-                                    rx_.orig = rc.orig;
+                                    const RxCompact rc32 = nd.rec32[pos];
+                                    rx_.x = rc32.x;
+                                    rx_.y = rc32.y;
+                                    rx_.z = rc32.z;
+                                    rx_.orig = rc32.orig;
                                     rx_.int_id = 0;
                                     rx_.channel = tx.channel;
                                     rx_.enabled = 1;
-                                    rx_.rxprob = (rc.flags & 1u) ? nd.rxprob[pos] : 1.0;
+                                    rx_.rxprob = (rc32.flags & 1u) ? nd.rxprob[pos] : 1.0;
                                 }
                                 const LinkEval ev = eval_link<MODEL, false>(m, nd, tx, rx_, true);
                                 if (ev.wanted) {
@@ -220,16 +268,11 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                                             s_rssi[k] = rssi;
                                             if (STOCH) s_prob[k] = prob;
                                         }
-                                    } else {
+                                    } else { // unordered, behind the fixed segments; sorted below
                                         const uint32_t o = s_base + k;
                                         t.a_dst[o] = orig;
                                         t.a_rssi[o] = rssi;
-                                        if (STOCH) {
-                                            t.a_prob[o] = prob;
-                                            t.a_verdict[o] = uint8_t(0); // pending: k_apply_draws decides
-                                        } else {
-                                            t.a_verdict[o] = dead ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
-                                        }
+                                        if (STOCH) t.a_prob[o] = prob;
                                     }
                                 }
                             }
@@ -241,11 +284,48 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
         }
         __syncthreads();
         const uint32_t total = s_nres;
-        if (pass == 1) break;
+        if (pass == 1) {
+            // the frame's links sit unordered at s_base: rank by node index through LDS tiles of keys, permute into
+            // the (so far unused) compact arrays of the same range, copy back
+            const uint32_t base = s_base;
+            for (uint32_t i0 = 0; i0 < total; i0 += 256) { // block-uniform
+                const uint32_t i = i0 + tid;
+                const int mine = (i < total) ? t.a_dst[base + i] : 0x7fffffff;
+                uint32_t rank = 0;
+                for (uint32_t k0 = 0; k0 < total; k0 += kFrCand) {
+                    __syncthreads();
+                    for (uint32_t k = tid; k < uint32_t(kFrCand) && k0 + k < total; k += 256) s_cand[k] = t.a_dst[base + k0 + k];
+                    __syncthreads();
+                    const uint32_t nk = min(uint32_t(kFrCand), total - k0);
+                    for (uint32_t k = 0; k < nk; ++k) rank += (s_cand[k] < mine) ? 1u : 0u;
+                }
+                if (i < total) {
+                    t.out_dst[base + rank] = mine;
+                    t.out_rssi[base + rank] = t.a_rssi[base + i];
+                    if (STOCH) t.out_prob[base + rank] = t.a_prob[base + i];
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < total; i += 256) {
+                t.a_dst[base + i] = t.out_dst[base + i];
+                t.a_rssi[base + i] = t.out_rssi[base + i];
+                if (STOCH) {
+                    t.a_prob[base + i] = t.out_prob[base + i];
+                    t.a_verdict[base + i] = uint8_t(0); // pending: k_apply_draws decides
+                } else {
+                    t.a_verdict[base + i] = dead ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+                }
+            }
+            break;
+        }
         if (total <= seg) {
+            // node order: rank inside LDS, every link written to its final place of the segment
             for (uint32_t i = tid; i < total; i += blockDim.x) {
-                const uint32_t o = fixed_base + i;
-                t.a_dst[o] = s_orig[i];
+                const int mine = s_orig[i];
+                uint32_t rank = 0;
+                for (uint32_t k = 0; k < total; ++k) rank += (s_orig[k] < mine) ? 1u : 0u;
+                const uint32_t o = fixed_base + rank;
+                t.a_dst[o] = mine;
                 t.a_rssi[o] = s_rssi[i];
                 if (STOCH) {
                     t.a_prob[o] = s_prob[i];
@@ -283,6 +363,66 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The tick's result written straight from the frames' segments into the host-mapped block of
+// rm_tick_flush* (header, packet offsets, Tx-failure flags, records): every workgroup redoes the scan
+// of the per-frame counts in LDS, a wave copies a frame's links to their compact place, the workgroup
+// that finishes last publishes the sequence number the host polls.  Same layout as k_pack_tick
+// (rm_transmit.hip) writes from the compact arrays.
+template <int SCAN>
+__global__ void __launch_bounds__(256)
+k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t *done_counter, uint32_t seq)
+{
+    __shared__ uint32_t s_off[scan_lds(SCAN)];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_last;
+    const int lane = threadIdx.x & 63;
+    constexpr bool kRegScan = (SCAN == 3 || SCAN == 4);
+    SmallCounts<scan_per(SCAN)> pre{};
+    if (kRegScan) pre = small_scan_load<scan_per(SCAN)>(t.cursor, t.n_cnt);
+    const uint32_t total = kRegScan ? small_scan(pre, t.n_cnt, s_off, s_wave, nullptr, nullptr)
+                                    : block_scan_counts(t.cursor, t.n_cnt, s_off, s_wave, nullptr, nullptr);
+    const uint32_t dropped = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+    const uint32_t room = dropped ? 0u : v.links;
+    const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
+    const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
+    for (uint32_t q = blockIdx.x * 4 + wave_index(); q < np; q += gridDim.x * 4) { // wave-uniform
+        const int slot = int(q) + t.shift;
+        const uint32_t src0 = uniform_u(t.seg_off[slot]);
+        const uint32_t len = uniform_u(t.cursor[slot]);
+        const uint32_t dst0 = uniform_u(s_off[slot]);
+        for (uint32_t c = lane; c < len; c += 64) {
+            const uint32_t d = dst0 + c;
+            if (d < room) {
+                v.pkt[d] = int(q);
+                v.dst[d] = t.a_dst[src0 + c];
+                v.rssi[d] = t.a_rssi[src0 + c];
+                v.verdict[d] = t.a_verdict[src0 + c]; // (this path has no SINR extension: no sinr column)
+            }
+        }
+        if (lane == 0) {
+            v.pkt_offset[q] = dst0;
+            v.pkt_interference[q] = (draws_possible && tx_success(m, t.tx[t.first_new + int(q)]) <= 0.0) ? 1 : 0;
+            if (q + 1 == np) v.pkt_offset[np] = total;
+        }
+    }
+    if (np == 0 && blockIdx.x == 0 && threadIdx.x == 0) v.pkt_offset[0] = 0u;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        *done_counter = 0u;
+        v.hdr->stored = dropped ? 0u : min(total, v.links);
+        v.hdr->dropped = dropped;
+        v.hdr->total = total;
+        v.hdr->span_flag = 0u;
+        v.hdr->n_packets = uint32_t(max(n_new, 0));
+        __threadfence_system();
+        __hip_atomic_store(&v.hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // the largest per-frame segment the A records (capacity `cap`) allow for n_cnt frame slots, 0 = not this path
 int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m)
 {
@@ -299,18 +439,44 @@ int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m
 hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg, int seg_len)
 {
     const dim3 grid(t.n_cnt), block(256);
-#define RM_FR(MODEL)                                                                                             \
-    do {                                                                                                         \
-        if (cfg.stochastic) hipLaunchKernelGGL((k_tick_frames<MODEL, true>), grid, block, 0, s, nd, m, t, seg_len); \
-        else hipLaunchKernelGGL((k_tick_frames<MODEL, false>), grid, block, 0, s, nd, m, t, seg_len);             \
+    const int n_groups = cdiv(nd.n_rx, kGroup);
+    static const int flat_max = [] {
+        const char *e = getenv("RM_FR_FLAT_MAX");
+        return e ? max(0, min(kFrGroups * 2, atoi(e))) : kFrFlatGroups;
+    }();
+#define RM_FR2(MODEL, ST, SH)                                                                                          \
+    do {                                                                                                               \
+        if (n_groups <= flat_max) hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, m, t, seg_len); \
+        else hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, m, t, seg_len);          \
     } while (0)
+#define RM_FR(MODEL, SH)                                                                                               \
+    do {                                                                                                               \
+        if (cfg.stochastic) RM_FR2(MODEL, true, SH);                                                                   \
+        else RM_FR2(MODEL, false, SH);                                                                                 \
+    } while (0)
+    static const bool no_shadow = getenv("RM_FR_NO_SHADOW") != nullptr;
     switch (m.kind) {
-    case RM_MODEL_UDGM: RM_FR(RM_MODEL_UDGM); break;
-    case RM_MODEL_UDGM_CONST: RM_FR(RM_MODEL_UDGM_CONST); break;
-    case RM_MODEL_LOGDIST: RM_FR(RM_MODEL_LOGDIST); break;
+    case RM_MODEL_UDGM: RM_FR(RM_MODEL_UDGM, false); break;
+    case RM_MODEL_UDGM_CONST: RM_FR(RM_MODEL_UDGM_CONST, false); break;
+    case RM_MODEL_LOGDIST:
+        if (cfg.shadow && m.shadow_tbl && !no_shadow) RM_FR(RM_MODEL_LOGDIST, true);
+        else RM_FR(RM_MODEL_LOGDIST, false);
+        break;
     default: return hipErrorInvalidValue;
     }
 #undef RM_FR
+#undef RM_FR2
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t, int n_new, const HostView &v, uint32_t *done_counter,
+                              uint32_t seq)
+{
+    const dim3 grid(64), block(256);
+    const int scan = scan_variant(t.n_cnt);
+    if (scan == 3) hipLaunchKernelGGL(k_pack_frames<3>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
+    else if (scan == 4) hipLaunchKernelGGL(k_pack_frames<4>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
+    else hipLaunchKernelGGL(k_pack_frames<1>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
     return hipGetLastError();
 }
 

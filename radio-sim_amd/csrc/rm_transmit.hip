@@ -85,7 +85,7 @@ k_pack_tick(TickDev t, int n_new, int have_offsets, HostView v, uint32_t *done_c
         v.dst[i] = t.out_dst[i];
         v.verdict[i] = t.out_verdict[i];
         v.rssi[i] = t.out_rssi[i];
-        v.sinr[i] = t.out_sinr ? t.out_sinr[i] : 0.0;
+        if (t.out_sinr) v.sinr[i] = t.out_sinr[i]; // no SINR extension: no sinr column crosses the link (8 of 25 bytes)
     }
     const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
     for (uint32_t i = tid; i < np; i += step) v.pkt_interference[i] = t.pkt_interference[i];
@@ -137,7 +137,7 @@ k_pack_batch(const PackSlot *__restrict__ slots, int n_slots, HostView v, BatchC
         v.dst[o] = t.out_dst[i];
         v.verdict[o] = t.out_verdict[i];
         v.rssi[o] = t.out_rssi[i];
-        v.sinr[o] = t.out_sinr ? t.out_sinr[i] : 0.0;
+        if (t.out_sinr) v.sinr[o] = t.out_sinr[i];
     }
     const uint32_t np = uint32_t(max(ps.n_new, 0));
     for (uint32_t i = tid; i < np; i += step) v.pkt_interference[ps.pkt_base + i] = t.pkt_interference[i];

@@ -190,7 +190,7 @@ class Engine:
             return np.frombuffer(buf, dtype=dtype, count=count)
         k, p = r.count, r.n_packets
         return TickResult(k, arr(r.pkt, np.int32, k), arr(r.dst, np.int32, k), arr(r.verdict, np.uint8, k),
-                          arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k), arr(r.pkt_interference, np.uint8, p),
+                          arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k) if r.sinr else np.zeros(k), arr(r.pkt_interference, np.uint8, p),
                           arr(r.pkt_offset, np.uint32, p + 1))
 
     def batch_result_view(self, n_slots, raise_on_error=True):
