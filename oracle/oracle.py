@@ -18,7 +18,7 @@ LD_SINR = 1
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("rm_oracle.c", "rm_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("rm_oracle.c", "rm_events.c", "rm_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "librm_oracle.so"])
@@ -102,8 +102,136 @@ def lib():
         L.orc_shadow_hash.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_shadow_gauss.restype = C.c_double
         L.orc_shadow_gauss.argtypes = [C.POINTER(Model), C.c_uint32, C.c_uint32]
+        # serial replay of the event queue / tick-end drain / receiver state machine (rm_events.c)
+        L.orc_sim_create.restype = C.c_void_p
+        L.orc_sim_create.argtypes = [C.c_int32]
+        L.orc_sim_destroy.argtypes = [C.c_void_p]
+        for name in ("orc_sim_time", "orc_sim_move_tops", "orc_sim_top_start", "orc_sim_pending"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_sim_error.restype = C.c_int32
+        L.orc_sim_error.argtypes = [C.c_void_p]
+        L.orc_sim_transmission_events.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
+        L.orc_sim_reception_events.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_int32]
+        L.orc_sim_step.restype = C.c_int64
+        L.orc_sim_step.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.orc_sim_rssi.restype = C.c_double
+        L.orc_sim_rssi.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+        L.orc_sim_receiving_state.restype = C.c_int32
+        L.orc_sim_receiving_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.orc_sim_receiving_packet.restype = C.c_int32
+        L.orc_sim_receiving_packet.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_sim_sending_packet.restype = C.c_int32
+        L.orc_sim_sending_packet.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_evq_replay.restype = C.c_int64
+        L.orc_evq_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         _lib = L
     return _lib
+
+
+EV_RX_START, EV_RX_END_INTERFERENCE, EV_RX_END_DELIVERY, EV_TX_START, EV_TX_END = range(5)
+EVENT_DTYPE = np.dtype([("time", "<i8"), ("node", "<i4"), ("pkt", "<i4"), ("kind", "<i4"), ("pad", "<i4"), ("rssi", "<f8")])
+assert EVENT_DTYPE.itemsize == 32
+
+
+class Sim:
+    """Serial replay of what consumes the verdicts: the reference's ladder queue (EventQueue.java, literal),
+    Simulator.generate*Events / processAllEvents and the Transciever state machine (oracle/rm_events.c)."""
+
+    def __init__(self, n_nodes):
+        self._L = lib()
+        self.n = n_nodes
+        self._h = C.c_void_p(self._L.orc_sim_create(n_nodes))
+
+    def close(self):
+        if self._h:
+            self._L.orc_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def time(self):
+        return self._L.orc_sim_time(self._h)
+
+    @property
+    def error(self):
+        return self._L.orc_sim_error(self._h)
+
+    @property
+    def move_tops(self):
+        return self._L.orc_sim_move_tops(self._h)
+
+    @property
+    def top_start(self):
+        return self._L.orc_sim_top_start(self._h)
+
+    @property
+    def pending(self):
+        return self._L.orc_sim_pending(self._h)
+
+    def transmission_events(self, pkt, src, start_us, air_us):
+        self._L.orc_sim_transmission_events(self._h, pkt, src, start_us, air_us)
+
+    def reception_events(self, pkt, dst, start_us, air_us, rssi, deliver):
+        self._L.orc_sim_reception_events(self._h, pkt, dst, start_us, air_us, float(rssi), 1 if deliver else 0)
+
+    def medium_calls(self, res, packets, pkt_base=0, const_loss=False):
+        """What a reference medium does with one evaluated tick `res` (oracle TickResult) of `packets`, in the
+        reference's order: per packet generateTransmissionEvents, then generateReceptionEvents per heard receiver in
+        node order (UDGMRadioMedium.java:97-111).  Returns the immediate deliveries of the constant-loss medium
+        (UDGMConstantLossRadioMedium.java:30: deliverRadioPacket, no events)."""
+        immediate = []
+        k = 0
+        for q in range(len(packets)):
+            p = packets[q]
+            if not const_loss:
+                self.transmission_events(pkt_base + q, int(p["src"]), int(p["start_us"]), int(p["air_us"]))
+            while k < res.count and res.pkt[k] == q:
+                if const_loss:
+                    immediate.append((pkt_base + q, int(res.dst[k]), float(res.rssi[k])))
+                else:
+                    self.reception_events(pkt_base + q, int(res.dst[k]), int(p["start_us"]), int(p["air_us"]),
+                                          res.rssi[k], res.verdict[k] == DELIVERED)
+                k += 1
+        return immediate
+
+    def step(self, time_us, cap=None):
+        """emulatorTimeStepDone: currentTime = time; processAllEvents(time).  Executed events in pop order."""
+        if cap is None:
+            cap = max(1, self.pending)
+        ev = np.zeros(cap, dtype=EVENT_DTYPE)
+        n = self._L.orc_sim_step(self._h, time_us, ev.ctypes.data, cap)
+        assert n <= cap
+        return ev[:n]
+
+    def rssi(self, node, base_rssi=-100.0):
+        return self._L.orc_sim_rssi(self._h, node, base_rssi)
+
+    def receiving_state(self, node, enabled=True):
+        return self._L.orc_sim_receiving_state(self._h, node, 1 if enabled else 0)
+
+    def node_info(self, nodes=None, base_rssi=-100.0, enabled=None):
+        idx = range(self.n) if nodes is None else nodes
+        rssi = np.array([self.rssi(i, base_rssi) for i in idx])
+        st = np.array([self.receiving_state(i, True if enabled is None else bool(enabled[i])) for i in idx], dtype=np.int32)
+        return rssi, st
+
+
+def evq_replay(ops):
+    """ops: list of ('add', time) / ('pop', time).  Returns the popped events' insertion numbers in pop order."""
+    t = np.array([o[1] for o in ops], dtype=np.int64)
+    k = np.array([0 if o[0] == "add" else 1 for o in ops], dtype=np.int32)
+    n_add = int((k == 0).sum())
+    out = np.zeros(max(1, n_add), dtype=np.int64)
+    n = lib().orc_evq_replay(t.ctypes.data, k.ctypes.data, len(ops), out.ctypes.data, len(out))
+    if n < 0:
+        raise RuntimeError("the Java queue would have thrown (code %d)" % -n)
+    return out[:n]
 
 
 class JavaRandom:

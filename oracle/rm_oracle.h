@@ -151,13 +151,47 @@ double orc_fixed_roundtrip(double lin); /* to Q80 fixed point and back (test hoo
  * TransmissionEvent.java:18-26, Transciever.java:52-113, Simulator.java:213-228 and the
  * equal-timestamp pop order of com/botbox/scheduler/EventQueue.java:206-244).
  */
+enum {
+    ORC_EV_RX_START = 0,            /* ReceptionMode.start */
+    ORC_EV_RX_END_INTERFERENCE = 1, /* ReceptionMode.interference */
+    ORC_EV_RX_END_DELIVERY = 2,     /* ReceptionMode.delivery: simulator.deliverRadioPacket on the end flank */
+    ORC_EV_TX_START = 3,            /* TransmissionEvent isStart */
+    ORC_EV_TX_END = 4
+};
+
 typedef struct {
     int64_t time;
     int32_t node;       /* destination (reception) or source (transmission) */
     int32_t pkt;        /* caller's packet id */
-    int32_t kind;       /* 0 rx start, 1 rx end interfered, 2 rx end delivery, 3 tx start, 4 tx end */
+    int32_t kind;       /* ORC_EV_* */
     double rssi;
 } orc_event_t;
+
+/* Serial replay (oracle/rm_events.c): the reference's ladder queue (EventQueue.java, literal), the
+ * simulator's event generation and tick-end drain, the Transciever state machine. */
+typedef struct orc_sim orc_sim_t;
+orc_sim_t *orc_sim_create(int32_t n_nodes);
+void orc_sim_destroy(orc_sim_t *s);
+int64_t orc_sim_time(const orc_sim_t *s);
+int32_t orc_sim_error(const orc_sim_t *s);      /* != 0: the Java queue would have thrown */
+int64_t orc_sim_move_tops(const orc_sim_t *s);  /* times EventQueue.moveTop ran (test hook) */
+int64_t orc_sim_top_start(const orc_sim_t *s);  /* EventQueue.topStart (test hook) */
+int64_t orc_sim_pending(const orc_sim_t *s);    /* events still queued */
+/* Simulator.generateTransmissionEvents :337-350 / generateReceptionEvents :321-335 (event time = max(start, currentTime)) */
+void orc_sim_transmission_events(orc_sim_t *s, int32_t pkt, int32_t src, int64_t start_us, int64_t air_us);
+void orc_sim_reception_events(orc_sim_t *s, int32_t pkt, int32_t dst, int64_t start_us, int64_t air_us, double rssi,
+                              int32_t do_deliver);
+/* Simulator.emulatorTimeStepDone :155-165: currentTime = time; processAllEvents(time).  The executed events in
+ * pop order (at most cap stored); deliveries are the ORC_EV_RX_END_DELIVERY entries.  Returns their number. */
+int64_t orc_sim_step(orc_sim_t *s, int64_t time, orc_event_t *out_events, int64_t cap);
+/* Transciever.getRSSI :52-61 / getReceivingState :67-78 */
+double orc_sim_rssi(const orc_sim_t *s, int32_t node, double base_rssi);
+int32_t orc_sim_receiving_state(const orc_sim_t *s, int32_t node, int32_t enabled);
+int32_t orc_sim_receiving_packet(const orc_sim_t *s, int32_t node);
+int32_t orc_sim_sending_packet(const orc_sim_t *s, int32_t node);
+/* bare queue: op_kind 0 = addEvent(op_time), 1 = pop everything with time < op_time; returns the popped
+ * events' insertion numbers in pop order (or -error) */
+int64_t orc_evq_replay(const int64_t *op_time, const int32_t *op_kind, int64_t n_ops, int64_t *out_id, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                     // level 2: the group boxes
 #pragma unroll
                     for (int k = 0; k < kFrGroups / 256; ++k) {
+                        if (i0 + k * 256 >= n_l2) break; // block-uniform
                         const int i = i0 + k * 256 + tid;
                         bool hit = false;
                         int g = 0;
@@ -319,11 +320,25 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
             break;
         }
         if (total <= seg) {
-            // node order: rank inside LDS, every link written to its final place of the segment
+            // node order: every link is written to its final place of the segment.  Up to 64 links (the usual
+            // frame) sit one per lane of the first wave and are ranked with a readlane loop; more by counting in LDS.
             for (uint32_t i = tid; i < total; i += blockDim.x) {
                 const int mine = s_orig[i];
                 uint32_t rank = 0;
-                for (uint32_t k = 0; k < total; ++k) rank += (s_orig[k] < mine) ? 1u : 0u;
+                if (total <= 64u) {
+                    const int n = uniform_i(int(total));
+                    for (int k = 0; k < n; ++k) rank += (__builtin_amdgcn_readlane(mine, k) < mine) ? 1u : 0u;
+                } else {
+                    uint32_t k = 0;
+                    for (; k + 8u <= total; k += 8u) { // eight independent LDS reads in flight
+                        int v8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v8[u] = s_orig[k + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) rank += (v8[u] < mine) ? 1u : 0u;
+                    }
+                    for (; k < total; ++k) rank += (s_orig[k] < mine) ? 1u : 0u;
+                }
                 const uint32_t o = fixed_base + rank;
                 t.a_dst[o] = mine;
                 t.a_rssi[o] = s_rssi[i];
