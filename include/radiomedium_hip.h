@@ -292,10 +292,53 @@ int rm_profile_read(rm_context *ctx, uint32_t *samples, double *stage_ms /* [RM_
 /* number of Tx->Rx link evaluations resolved by the last tick ( T * (N_loc) minus self links ) */
 int64_t rm_last_link_evaluations(const rm_context *ctx);
 
+/* ---- reception stage: what the reference does with the verdicts, on the device -------------------------
+ * SURVEY.md section 8f-1 / 8f-3.  After rm_events_enable every evaluated tick (rm_transmit, rm_tick_flush*,
+ * rm_tick_run*, not rm_batch_*) also hands its packets and heard links to the event stage, exactly as the
+ * reference's media call Simulator.generateTransmissionEvents / generateReceptionEvents (Simulator.java:321-350)
+ * per packet and heard link: event times max(start, rm_set_time value) and + air time.  The constant-loss
+ * medium queues nothing and delivers synchronously (UDGMConstantLossRadioMedium.java:30): its links come
+ * out of the next rm_events_process call first, in call order.
+ *
+ * rm_events_process(t) is Simulator.emulatorTimeStepDone (:155-165): currentTime = t; processAllEvents(t)
+ * pops every event with time < t (strict, :213-228) in the order of the reference's ladder queue
+ * (com/botbox/scheduler/EventQueue.java; equal timestamps included, see csrc/rm_evorder.hpp) and executes
+ * it (events/ReceptionEvent.java:35-46, events/TransmissionEvent.java:18-26, Transciever.java:80-113).  The
+ * deliveries -- the Simulator.deliverRadioPacket(packet, destination, rssi) calls of that drain, in call
+ * order -- are returned in pinned, host-mapped memory (valid until the next rm_events_process).  Packets are
+ * numbered in the order they were handed in since rm_events_enable (rm_events_next_packet tells the number
+ * the next one gets; every record of a tick counts, padding records too).
+ *
+ * rm_node_info gives the per-node fields of a time-step message (net/JSONClientConnection.java:331-341):
+ * Transciever.getRSSI (:52-61), getReceivingState (:67-78: 0 listening, 1 transmitting, 2 receiving,
+ * 3 disabled) and the wireless channel, from the device-resident radio state; nodes == NULL: nodes 0..n-1.
+ * On a receiver partition (rm_set_partition) a context keeps the events of its own nodes only. */
+typedef struct rm_delivery_view {
+    uint32_t count;            /* deliveries of this drain */
+    uint32_t pending_packets;  /* packets with events still queued */
+    const int64_t *packet;     /* [count] packet number */
+    const int32_t *dst;        /* [count] destination node index */
+    const double *rssi;        /* [count] */
+} rm_delivery_view;
+int rm_events_enable(rm_context *ctx, uint32_t max_pending_packets, uint32_t max_pending_links); /* 0, 0: defaults */
+int rm_events_disable(rm_context *ctx);
+int64_t rm_events_next_packet(rm_context *ctx);
+int rm_events_process(rm_context *ctx, int64_t time_us, rm_delivery_view *out);
+int rm_node_info(rm_context *ctx, const int32_t *nodes, int32_t n, double *rssi, int32_t *receiving, int32_t *channel);
+
 /* ---- host-side helpers exported for tests ------------------------------------------------- */
 /* java.util.Random LCG: state after `steps` next() calls */
 uint64_t rm_lcg_jump(uint64_t state48, uint64_t steps);
 double rm_lcg_next_double(uint64_t *state48);
+/* the pop order of the reference's event queue as a sort key (csrc/rm_evorder.hpp; no device needed):
+ * rm_evq_add returns the ladder of an event added now with time t, rm_evq_drain is processAllEvents(t) */
+typedef struct rm_evq_order {
+    int64_t top_start, top_max;
+    int32_t ladders, top_nonempty;
+} rm_evq_order;
+void rm_evq_init(rm_evq_order *o);
+int32_t rm_evq_add(rm_evq_order *o, int64_t time_us);
+void rm_evq_drain(rm_evq_order *o, int64_t time_us);
 
 #ifdef __cplusplus
 }

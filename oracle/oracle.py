@@ -123,6 +123,8 @@ def lib():
         L.orc_sim_receiving_packet.argtypes = [C.c_void_p, C.c_int32]
         L.orc_sim_sending_packet.restype = C.c_int32
         L.orc_sim_sending_packet.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_sim_medium_calls.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int32]
         L.orc_evq_replay.restype = C.c_int64
         L.orc_evq_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         _lib = L
@@ -185,20 +187,16 @@ class Sim:
         reference's order: per packet generateTransmissionEvents, then generateReceptionEvents per heard receiver in
         node order (UDGMRadioMedium.java:97-111).  Returns the immediate deliveries of the constant-loss medium
         (UDGMConstantLossRadioMedium.java:30: deliverRadioPacket, no events)."""
-        immediate = []
-        k = 0
-        for q in range(len(packets)):
-            p = packets[q]
-            if not const_loss:
-                self.transmission_events(pkt_base + q, int(p["src"]), int(p["start_us"]), int(p["air_us"]))
-            while k < res.count and res.pkt[k] == q:
-                if const_loss:
-                    immediate.append((pkt_base + q, int(res.dst[k]), float(res.rssi[k])))
-                else:
-                    self.reception_events(pkt_base + q, int(res.dst[k]), int(p["start_us"]), int(p["air_us"]),
-                                          res.rssi[k], res.verdict[k] == DELIVERED)
-                k += 1
-        return immediate
+        packets = np.ascontiguousarray(np.atleast_1d(packets), dtype=PACKET_DTYPE)
+        pkt = np.ascontiguousarray(res.pkt, dtype=np.int32)
+        dst = np.ascontiguousarray(res.dst, dtype=np.int32)
+        verdict = np.ascontiguousarray(res.verdict, dtype=np.uint8)
+        rssi = np.ascontiguousarray(res.rssi, dtype=np.float64)
+        self._L.orc_sim_medium_calls(self._h, packets.ctypes.data, len(packets), pkt_base, len(pkt), pkt.ctypes.data,
+                                     dst.ctypes.data, verdict.ctypes.data, rssi.ctypes.data, 1 if const_loss else 0)
+        if const_loss:
+            return [(pkt_base + int(q), int(d), float(r)) for q, d, r in zip(pkt, dst, rssi)]
+        return []
 
     def step(self, time_us, cap=None):
         """emulatorTimeStepDone: currentTime = time; processAllEvents(time).  Executed events in pop order."""

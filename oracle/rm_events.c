@@ -448,6 +448,27 @@ int64_t orc_sim_step(orc_sim_t *s, int64_t time, orc_event_t *out_events, int64_
 
 int64_t orc_sim_pending(const orc_sim_t *s) { return s->live; }
 
+/* What a reference medium does with one evaluated pass (orc_tick's output), in the reference's order: per
+ * packet generateTransmissionEvents (UDGMRadioMedium.java:97, N2NRadioMedium.java:53, NullRadioMedium.java:59),
+ * then generateReceptionEvents per heard receiver in node order (:99-111).  The constant-loss medium queues
+ * nothing (UDGMConstantLossRadioMedium.java:25-33: deliverRadioPacket at once); its links are returned as they are. */
+void orc_sim_medium_calls(orc_sim_t *s, const orc_packet_t *packets, int32_t n_packets, int32_t pkt_base, int64_t n_links,
+                          const int32_t *out_pkt, const int32_t *out_dst, const uint8_t *out_verdict, const double *out_rssi,
+                          int32_t const_loss)
+{
+    int64_t k = 0;
+    for (int32_t q = 0; q < n_packets; ++q) {
+        const orc_packet_t *p = &packets[q];
+        if (!const_loss) orc_sim_transmission_events(s, pkt_base + q, p->src, p->start_us, p->air_us);
+        while (k < n_links && out_pkt[k] == q) {
+            if (!const_loss)
+                orc_sim_reception_events(s, pkt_base + q, out_dst[k], p->start_us, p->air_us, out_rssi[k],
+                                         out_verdict[k] == ORC_DELIVERED);
+            k++;
+        }
+    }
+}
+
 /* Transciever.getRSSI :52-61 (medium present: its base RSSI) */
 double orc_sim_rssi(const orc_sim_t *s, int32_t node, double base_rssi)
 {

@@ -181,6 +181,9 @@ int64_t orc_sim_pending(const orc_sim_t *s);    /* events still queued */
 void orc_sim_transmission_events(orc_sim_t *s, int32_t pkt, int32_t src, int64_t start_us, int64_t air_us);
 void orc_sim_reception_events(orc_sim_t *s, int32_t pkt, int32_t dst, int64_t start_us, int64_t air_us, double rssi,
                               int32_t do_deliver);
+void orc_sim_medium_calls(orc_sim_t *s, const orc_packet_t *packets, int32_t n_packets, int32_t pkt_base, int64_t n_links,
+                          const int32_t *out_pkt, const int32_t *out_dst, const uint8_t *out_verdict, const double *out_rssi,
+                          int32_t const_loss);
 /* Simulator.emulatorTimeStepDone :155-165: currentTime = time; processAllEvents(time).  The executed events in
  * pop order (at most cap stored); deliveries are the ORC_EV_RX_END_DELIVERY entries.  Returns their number. */
 int64_t orc_sim_step(orc_sim_t *s, int64_t time, orc_event_t *out_events, int64_t cap);

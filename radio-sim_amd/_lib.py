@@ -60,6 +60,15 @@ class HostResult(C.Structure):
                 ("rssi", C.c_void_p), ("sinr", C.c_void_p)]
 
 
+class DeliveryView(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("pending_packets", C.c_uint32), ("packet", C.c_void_p), ("dst", C.c_void_p),
+                ("rssi", C.c_void_p)]
+
+
+class EvqOrder(C.Structure):
+    _fields_ = [("top_start", C.c_int64), ("top_max", C.c_int64), ("ladders", C.c_int32), ("top_nonempty", C.c_int32)]
+
+
 def library_path():
     return _SO
 
@@ -143,6 +152,14 @@ SIGNATURES = {
     "rm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
     "rm_last_link_evaluations": (C.c_int64, [C.c_void_p]),
+    "rm_events_enable": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rm_events_disable": (C.c_int, [C.c_void_p]),
+    "rm_events_next_packet": (C.c_int64, [C.c_void_p]),
+    "rm_events_process": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "rm_node_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rm_evq_init": (None, [C.c_void_p]),
+    "rm_evq_add": (C.c_int32, [C.c_void_p, C.c_int64]),
+    "rm_evq_drain": (None, [C.c_void_p, C.c_int64]),
     "rm_lcg_jump": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "rm_lcg_next_double": (C.c_double, [C.POINTER(C.c_uint64)]),
 }

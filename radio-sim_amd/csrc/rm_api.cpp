@@ -7,6 +7,7 @@
 // Reference paths: /root/reference/radio-medium/java/se/sics/emul8/radiomedium/.
 
 #include "rm_engine.h"
+#include "rm_evorder.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -172,6 +173,31 @@ struct rm_context : TickSlot {
     int drifted_groups = 0, escaped_groups = 0;
     int64_t table_sorts = 0;        // times the receiver table was (re)built
     DevBuf<rm::NodePatch> d_patch;
+
+    // reception stage (rm_events.hip): pending packets + their links, radio state per node, delivery list block
+    struct Events {
+        bool on = false;
+        uint32_t pk_cap = 0, pool_cap = 0, g_cap = 0;
+        DevBuf<rm::EvState> d_st;
+        DevBuf<rm::EvPacket> d_pk;
+        DevBuf<int32_t> d_ldst;
+        DevBuf<double> d_lrssi;
+        DevBuf<uint8_t> d_lverdict;
+        DevBuf<int64_t> d_gtime;
+        DevBuf<uint64_t> d_gmeta;
+        DevBuf<uint32_t> d_gref, d_grank, d_cnt, d_off;
+        DevBuf<unsigned long long> d_recv_key, d_send_key;
+        DevBuf<uint8_t> d_receiving, d_sending;
+        DevBuf<double> d_latched;
+        int state_n = 0;          // nodes the radio-state arrays hold
+        char *h_out = nullptr;    // host-mapped: EvHeader + packet / dst / rssi arrays of pool_cap entries
+        char *h_info = nullptr;   // host-mapped: node-info answers
+        int info_n = 0;
+        uint32_t seq = 0, info_seq = 0;
+        DevBuf<int32_t> d_info_nodes;
+        int64_t next_packet = 0;  // host mirror of EvState::gseq_next
+    } ev;
+    DevBuf<uint8_t> d_enabled;   // Transciever.isEnabled by node index
 
     int frac_probs = -1;         // cached: any rx/tx probability strictly between 0 and 1 (-1 = unknown)
     bool rx_dirty = true;        // receiver table has to be rebuilt (positions / partition / model class)
@@ -374,6 +400,7 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.stxprob = c->d_txprob.p;
     nd.schannel = c->d_channel.p;
     nd.sint_id = c->d_int_id.p;
+    nd.senabled = c->d_enabled.p;
     nd.n_rx = c->n_rx;
     nd.x = c->d_rx_x.p;
     nd.y = c->d_rx_y.p;
@@ -1050,12 +1077,107 @@ int materialize(rm_context *c, TickSlot &ts)
     return RM_OK;
 }
 
+rm::EvDev ev_dev(rm_context *c)
+{
+    rm::EvDev e{};
+    rm_context::Events &v = c->ev;
+    e.st = v.d_st.p;
+    e.pk = v.d_pk.p;
+    e.pk_mask = v.pk_cap - 1u;
+    e.l_dst = v.d_ldst.p;
+    e.l_rssi = v.d_lrssi.p;
+    e.l_verdict = v.d_lverdict.p;
+    e.pool_mask = v.pool_cap - 1u;
+    e.g_time = v.d_gtime.p;
+    e.g_meta = v.d_gmeta.p;
+    e.g_ref = v.d_gref.p;
+    e.g_rank = v.d_grank.p;
+    e.cnt_by_rank = v.d_cnt.p;
+    e.off_by_rank = v.d_off.p;
+    e.g_cap = v.g_cap;
+    e.recv_key = v.d_recv_key.p;
+    e.send_key = v.d_send_key.p;
+    e.receiving = v.d_receiving.p;
+    e.sending = v.d_sending.p;
+    e.latched = v.d_latched.p;
+    e.n_nodes = v.state_n;
+    e.own_first = part_first(c);
+    e.own_count = part_count(c);
+    return e;
+}
+
+// radio-state arrays for c->n nodes; what they hold for the nodes already known is kept
+int ev_ensure_nodes(rm_context *c)
+{
+    rm_context::Events &v = c->ev;
+    const int n = std::max(c->n, 1);
+    if (v.state_n >= c->n && v.d_receiving.p) return RM_OK;
+    const size_t old_n = size_t(v.state_n);
+    RM_HIP(v.d_recv_key.ensure(size_t(n), true, c->stream));
+    RM_HIP(v.d_send_key.ensure(size_t(n), true, c->stream));
+    RM_HIP(v.d_receiving.ensure(size_t(n), true, c->stream));
+    RM_HIP(v.d_sending.ensure(size_t(n), true, c->stream));
+    RM_HIP(v.d_latched.ensure(size_t(n), true, c->stream));
+    // DevBuf grows geometrically: clear everything behind the nodes that were there
+    RM_HIP(hipMemsetAsync(v.d_recv_key.p + old_n, 0, (v.d_recv_key.n - old_n) * sizeof(unsigned long long), c->stream));
+    RM_HIP(hipMemsetAsync(v.d_send_key.p + old_n, 0, (v.d_send_key.n - old_n) * sizeof(unsigned long long), c->stream));
+    RM_HIP(hipMemsetAsync(v.d_receiving.p + old_n, 0, v.d_receiving.n - old_n, c->stream));
+    RM_HIP(hipMemsetAsync(v.d_sending.p + old_n, 0, v.d_sending.n - old_n, c->stream));
+    RM_HIP(hipMemsetAsync(v.d_latched.p + old_n, 0, (v.d_latched.n - old_n) * sizeof(double), c->stream));
+    v.state_n = c->n;
+    return RM_OK;
+}
+
+// hand the evaluated tick of slot `ts` to the reception stage (Simulator.generate*Events for every packet / heard link)
+int ev_append(rm_context *c, TickSlot &ts)
+{
+    if (!c->ev.on || !ts.have_result || ts.last_n_new <= 0) {
+        return RM_OK;
+    }
+    RM_TRY(ev_ensure_nodes(c));
+    const rm::TickDev &t = ts.last;
+    rm::EvLinkSrc ls{};
+    const uint32_t *dropped = nullptr;
+    if (part_count(c) <= 0) { // no receivers here: the packets still count (and their transmission events, elsewhere)
+        static_assert(sizeof(uint32_t) == 4, "");
+    }
+    if (ts.compact_pending) {
+        ls.dst = t.a_dst;
+        ls.rssi = t.a_rssi;
+        ls.verdict = t.a_verdict;
+        ls.off = t.seg_off + t.shift;
+        ls.cnt = t.cursor + t.shift;
+        ls.n_scan = ts.last_n_new;
+        dropped = t.stage_count + 1;
+    } else {
+        ls.dst = t.out_dst;
+        ls.rssi = t.out_rssi;
+        ls.verdict = t.out_verdict;
+        ls.off = t.slot_off + t.shift;
+        ls.cnt = nullptr;
+        ls.n_scan = 0;
+        dropped = t.out_count + 1;
+    }
+    const int immediate = (c->params.kind == RM_MODEL_UDGM_CONST) ? 1 : 0;
+    RM_HIP(rm::launch_ev_append(c->stream, ev_dev(c), ls, t.tx + t.first_new, ts.last_n_new, c->current_time, immediate, dropped));
+    c->ev.next_packet += ts.last_n_new;
+    return RM_OK;
+}
+
 int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
              int64_t src_start_us = 0, int64_t src_air_us = 0)
 {
     TickPlan plan;
     RM_TRY(prepare_tick(c, *c, plan, false, tx, n_active, first_new, src_list, src_start_us, src_air_us));
-    return launch_tick(c, *c, plan);
+    RM_TRY(launch_tick(c, *c, plan));
+    if (c->ev.on && !c->draws_pending) {
+        if (plan.empty && c->last_n_new > 0) {
+            // a tick without receivers on this rank: its packets exist all the same (slot_off of an empty tick is not written)
+            RM_HIP(hipMemsetAsync(c->d_slot_off.p, 0, (size_t(std::max(c->last.n_cnt, 0)) + 2) * sizeof(uint32_t), c->stream));
+        }
+        RM_TRY(ev_append(c, *c));
+    }
+    return RM_OK;
 }
 
 int drain_profile(rm_context *c)
@@ -1160,6 +1282,8 @@ void rm_destroy(rm_context *c)
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
     c->d_patch.release();
+    c->d_enabled.release();
+    (void)rm_events_disable(c);
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();
     for (int g = 0; g < 2; ++g) {
@@ -1323,7 +1447,9 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     RM_TRY(upload(c->d_txprob, c->txprob, c->stream));
     RM_TRY(upload(c->d_channel, c->channel, c->stream));
     RM_TRY(upload(c->d_int_id, c->int_id, c->stream));
+    RM_TRY(upload(c->d_enabled, c->enabled, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
+    if (c->ev.on) RM_TRY(ev_ensure_nodes(c));
     recompute_frame(c);
     c->rx_dirty = true;
     c->frac_probs = -1;
@@ -1698,7 +1824,8 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
     {
         const rm::ModelDev m = model_dev(c);
         const bool f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
-        if (is_geometric(c) && c->rx_sorted && !f64_filter && c->n_rx > 0 && std::getenv("RM_NO_ONE_LAUNCH") == nullptr) {
+        // (with the reception stage on, the packet's links have to stay on the device: the tick path)
+        if (is_geometric(c) && c->rx_sorted && !f64_filter && c->n_rx > 0 && !c->ev.on && std::getenv("RM_NO_ONE_LAUNCH") == nullptr) {
             if (!c->d_rng.p) RM_TRY(rm_seed(c, 0));
             c->have_result = false; // the links go to the caller only
             const uint32_t seq = ++c->transmit_seq;
@@ -1922,6 +2049,7 @@ int rm_tick_finish_draws(rm_context *c, const uint32_t *all_counts, int32_t worl
     }
     RM_HIP(rm::launch_draws_apply(c->stream, c->pending_model, c->last, dev, world, rank));
     c->draws_pending = false;
+    if (c->ev.on) RM_TRY(ev_append(c, *c)); // the verdicts are final now
     return RM_OK;
 }
 
@@ -2224,6 +2352,188 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
         if (st != RM_OK && first_error == RM_OK) first_error = st;
     }
     return first_error;
+}
+
+// ---- reception stage ------------------------------------------------------------------------------------
+
+static size_t ev_out_bytes(uint32_t cap)
+{
+    return pad64(sizeof(rm::EvHeader)) + pad64(size_t(cap) * 8) + pad64(size_t(cap) * 4) + pad64(size_t(cap) * 8);
+}
+
+static rm::EvOut ev_out(rm_context *c)
+{
+    rm::EvOut o{};
+    char *b = c->ev.h_out;
+    const uint32_t cap = c->ev.pool_cap;
+    size_t off = 0;
+    o.hdr = reinterpret_cast<rm::EvHeader *>(b + off); off += pad64(sizeof(rm::EvHeader));
+    o.pkt = reinterpret_cast<int64_t *>(b + off); off += pad64(size_t(cap) * 8);
+    o.dst = reinterpret_cast<int32_t *>(b + off); off += pad64(size_t(cap) * 4);
+    o.rssi = reinterpret_cast<double *>(b + off);
+    o.cap = cap;
+    return o;
+}
+
+static uint32_t pow2_at_least(uint32_t v)
+{
+    uint32_t p = 64;
+    while (p < v && p < (1u << 30)) p <<= 1;
+    return p;
+}
+
+int rm_events_disable(rm_context *c)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    rm_context::Events &v = c->ev;
+    if (v.on || v.h_out) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    v.d_st.release(); v.d_pk.release(); v.d_ldst.release(); v.d_lrssi.release(); v.d_lverdict.release();
+    v.d_gtime.release(); v.d_gmeta.release(); v.d_gref.release(); v.d_grank.release(); v.d_cnt.release(); v.d_off.release();
+    v.d_recv_key.release(); v.d_send_key.release(); v.d_receiving.release(); v.d_sending.release(); v.d_latched.release();
+    v.d_info_nodes.release();
+    if (v.h_out) (void)hipHostFree(v.h_out);
+    if (v.h_info) (void)hipHostFree(v.h_info);
+    v.h_out = v.h_info = nullptr;
+    v.info_n = 0;
+    v.state_n = 0;
+    v.on = false;
+    v.next_packet = 0;
+    return RM_OK;
+}
+
+int rm_events_enable(rm_context *c, uint32_t max_pending_packets, uint32_t max_pending_links)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (max_pending_links > (1u << 29)) return fail(RM_ERR_INVALID, "at most 2^29 pending links");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(rm_events_disable(c));
+    rm_context::Events &v = c->ev;
+    v.pk_cap = pow2_at_least(max_pending_packets ? max_pending_packets : (1u << 16));
+    v.pool_cap = pow2_at_least(max_pending_links ? max_pending_links : (1u << 21));
+    v.g_cap = 2u * v.pk_cap;
+    RM_HIP(v.d_st.ensure(1));
+    RM_HIP(v.d_pk.ensure(v.pk_cap));
+    RM_HIP(v.d_ldst.ensure(v.pool_cap));
+    RM_HIP(v.d_lrssi.ensure(v.pool_cap));
+    RM_HIP(v.d_lverdict.ensure(v.pool_cap));
+    RM_HIP(v.d_gtime.ensure(v.g_cap));
+    RM_HIP(v.d_gmeta.ensure(v.g_cap));
+    RM_HIP(v.d_gref.ensure(v.g_cap));
+    RM_HIP(v.d_grank.ensure(v.g_cap));
+    RM_HIP(v.d_cnt.ensure(v.g_cap));
+    RM_HIP(v.d_off.ensure(v.g_cap));
+    rm::EvState st{};
+    st.top_max = int64_t(0x8000000000000000ull); // the top list is empty
+    RM_HIP(hipMemcpyAsync(v.d_st.p, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&v.h_out), ev_out_bytes(v.pool_cap), hipHostMallocMapped));
+    std::memset(v.h_out, 0, pad64(sizeof(rm::EvHeader)));
+    v.seq = 0;
+    v.on = true;
+    v.next_packet = 0;
+    RM_TRY(ev_ensure_nodes(c));
+    return RM_OK;
+}
+
+int64_t rm_events_next_packet(rm_context *c) { return (c && c->ev.on) ? c->ev.next_packet : -1; }
+
+int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!c->ev.on) return fail(RM_ERR_STATE, "rm_events_enable first");
+    if (c->draws_pending) return fail(RM_ERR_STATE, "the last tick waits for rm_tick_finish_draws");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_ensure_nodes(c));
+    const rm::EvOut o = ev_out(c);
+    const uint32_t seq = ++c->ev.seq;
+    RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq));
+    c->current_time = time_us; // Simulator.java:156
+    volatile const uint32_t *flag = &o.hdr->seq;
+    bool seen = false;
+    for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+    if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+    out->count = o.hdr->count;
+    out->pending_packets = o.hdr->pending_packets;
+    out->packet = o.pkt;
+    out->dst = o.dst;
+    out->rssi = o.rssi;
+    if (o.hdr->err & 8u) return fail(RM_ERR_CAPACITY, "a tick's heard links exceeded the link capacity (rm_set_link_capacity): its events are missing");
+    if (o.hdr->err) return fail(RM_ERR_CAPACITY, "the reception stage ran out of room for pending packets / links (rm_events_enable)");
+    if (o.hdr->total > o.hdr->count) return fail(RM_ERR_CAPACITY, "more deliveries than the delivery block holds");
+    return RM_OK;
+}
+
+int rm_node_info(rm_context *c, const int32_t *nodes, int32_t n, double *rssi, int32_t *receiving, int32_t *channel)
+{
+    if (!c || n < 0) return fail(RM_ERR_INVALID, "bad arguments");
+    if (!c->ev.on) return fail(RM_ERR_STATE, "rm_events_enable first");
+    if (n == 0) return RM_OK;
+    if (!nodes && n > c->n) return fail(RM_ERR_INVALID, "more nodes than the table holds");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_ensure_nodes(c));
+    rm_context::Events &v = c->ev;
+    if (v.info_n < n) {
+        RM_HIP(hipStreamSynchronize(c->stream));
+        if (v.h_info) RM_HIP(hipHostFree(v.h_info));
+        v.h_info = nullptr;
+        const int want = std::max(n + n / 2, 1024);
+        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&v.h_info), 64 + pad64(size_t(want) * 8) + 2 * pad64(size_t(want) * 4), hipHostMallocMapped));
+        std::memset(v.h_info, 0, 64);
+        v.info_n = want;
+    }
+    rm::NodeInfoOut o{};
+    o.seq = reinterpret_cast<uint32_t *>(v.h_info);
+    o.rssi = reinterpret_cast<double *>(v.h_info + 64);
+    o.receiving = reinterpret_cast<int32_t *>(v.h_info + 64 + pad64(size_t(v.info_n) * 8));
+    o.channel = reinterpret_cast<int32_t *>(v.h_info + 64 + pad64(size_t(v.info_n) * 8) + pad64(size_t(v.info_n) * 4));
+    const int32_t *dev_nodes = nullptr;
+    if (nodes) {
+        RM_HIP(v.d_info_nodes.ensure(size_t(n)));
+        RM_HIP(hipMemcpyAsync(v.d_info_nodes.p, nodes, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
+        dev_nodes = v.d_info_nodes.p;
+    }
+    const uint32_t seq = ++v.info_seq;
+    RM_HIP(rm::launch_node_info(c->stream, ev_dev(c), nodes_dev(c), dev_nodes, n, c->base_rssi, o, seq));
+    volatile const uint32_t *flag = o.seq;
+    bool seen = false;
+    for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+    if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+    if (rssi) std::memcpy(rssi, o.rssi, size_t(n) * 8);
+    if (receiving) std::memcpy(receiving, o.receiving, size_t(n) * 4);
+    if (channel) std::memcpy(channel, o.channel, size_t(n) * 4);
+    return RM_OK;
+}
+
+void rm_evq_init(rm_evq_order *o)
+{
+    if (!o) return;
+    o->top_start = 0; // EventQueue.java:51
+    o->top_max = 0;
+    o->ladders = 0;
+    o->top_nonempty = 0;
+}
+
+int32_t rm_evq_add(rm_evq_order *o, int64_t time_us)
+{
+    rm::EvOrder e{o->top_start, o->top_max, o->ladders, o->top_nonempty};
+    const int32_t lad = rm::ev_ladder(e, time_us);
+    rm::ev_note_top(e, time_us);
+    o->top_max = e.top_max;
+    o->top_nonempty = e.top_nonempty;
+    return lad;
+}
+
+void rm_evq_drain(rm_evq_order *o, int64_t time_us)
+{
+    rm::EvOrder e{o->top_start, o->top_max, o->ladders, o->top_nonempty};
+    rm::ev_drain(e, time_us);
+    o->top_start = e.top_start;
+    o->top_max = e.top_max;
+    o->ladders = e.ladders;
+    o->top_nonempty = e.top_nonempty;
 }
 
 int rm_sync(rm_context *c)

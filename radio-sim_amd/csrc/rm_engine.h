@@ -20,7 +20,8 @@
 //
 // Files: rm_math.hpp (exact arithmetic: E-math, link hash, Q80, java.util.Random), rm_device.hpp
 // (shared device code: wave helpers, pre-filter records, eval_link, fused scans), rm_filter.hip,
-// rm_exact.hip, rm_reorder.hip, rm_transmit.hip, rm_tick.hip (kernels + their launchers), rm_api.cpp (C ABI).
+// rm_exact.hip, rm_reorder.hip, rm_transmit.hip, rm_tick.hip, rm_events.hip (kernels + their launchers),
+// rm_evorder.hpp (the reference event queue's pop order as a sort key), rm_api.cpp (C ABI).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -111,6 +112,7 @@ struct NodesDev {
     int n;                                   // nodes in the simulator
     const double *sx, *sy, *sz, *stxpower, *stxprob;
     const int32_t *schannel, *sint_id;
+    const uint8_t *senabled;                 // Transciever.isEnabled by node index (node-info)
     int n_rx;                                // receivers of this partition
     const double *x, *y, *z, *rxprob;
     const int32_t *channel, *int_id, *orig;
@@ -244,6 +246,89 @@ struct BatchCounts {        // per slot, in the host-mapped block
     uint32_t stored, dropped, total, span_flag, link_base, pad[3];
 };
 
+// ---- reception stage (rm_events.hip): Simulator.generate*Events + processAllEvents + Transciever state on the device
+// One transmitted packet whose events are still (partly) queued.  The pending packets form a window
+// [pk_head, pk_tail) of a ring in transmission order; a packet's heard links sit contiguously in the link pool ring.
+struct alignas(64) EvPacket {
+    int64_t t0, t1;      // event times: max(start, currentTime at transmit), + air time (Simulator.java:323-333)
+    int64_t gseq;        // packet number since rm_events_enable: its events' insertion order
+    uint32_t link_off;   // first link in the pool (monotone counter, index = value & pool_mask)
+    uint32_t link_cnt;
+    int32_t src;
+    int32_t lad0, lad1;  // ladder of its start / end events (rm_evorder.hpp)
+    uint32_t flags;      // kEvStartDone | kEvDone | kEvImmediate | kEvNoTx
+    uint32_t pad[4];
+};
+constexpr uint32_t kEvStartDone = 1, kEvDone = 2, kEvImmediate = 4, kEvNoTx = 8;
+enum { kEvRxStart = 0, kEvRxEnd = 1, kEvTxStart = 2, kEvTxEnd = 3 };
+
+struct EvState {
+    int64_t top_start, top_max; // rm_evorder.hpp (top_max == INT64_MIN: the top list is empty)
+    int64_t t_prev;             // time of the last drain
+    int64_t gseq_next;
+    int32_t ladders, pad0;
+    uint32_t pk_head, pk_tail, pool_head, pool_tail; // monotone counters
+    uint32_t n_groups;          // fired (packet, phase) groups of the running drain
+    uint32_t n_deliv;
+    uint32_t err;               // sticky: 1 packet ring full, 2 link pool full, 4 group list full, 8 a tick was dropped for capacity
+    uint32_t done_a, done_b;    // "last workgroup" counters
+    uint32_t pad1[3];
+};
+
+struct EvDev {
+    EvState *st;
+    EvPacket *pk;
+    uint32_t pk_mask;
+    int32_t *l_dst;
+    double *l_rssi;
+    uint8_t *l_verdict;
+    uint32_t pool_mask;
+    int64_t *g_time;      // fired groups: sort key (time, meta) ...
+    uint64_t *g_meta;
+    uint32_t *g_ref;      // ... packet ring index << 1 | phase (0 end, 1 start)
+    uint32_t *g_rank, *cnt_by_rank, *off_by_rank;
+    uint32_t g_cap;
+    unsigned long long *recv_key, *send_key; // [n] last writer of the node's receivingPacket / sendingPacket in the running drain
+    uint8_t *receiving, *sending;            // [n] Transciever.receivingPacket / sendingPacket != null
+    double *latched;                         // [n] Transciever.receivingRSSI
+    int n_nodes;
+    int own_first, own_count;                // nodes whose Tx / Rx events this context keeps (receiver partition)
+};
+
+// a tick's heard links, packet by packet: the frames' segments (rm_tick.hip) or the compact arrays
+struct EvLinkSrc {
+    const int32_t *dst;
+    const double *rssi;
+    const uint8_t *verdict;
+    const uint32_t *off;   // [n_new] first link of packet q (compact arrays: [n_new + 1], cnt == nullptr)
+    const uint32_t *cnt;   // [n_new] or nullptr
+    int n_scan;            // segments: entries of cnt to scan for the pool positions (n_cnt), 0 = off is the scan
+};
+
+// the delivery list of one drain in host-mapped memory
+struct EvHeader {
+    uint32_t count;      // deliveries written
+    uint32_t total;      // deliveries of the drain (count < total: the block was too small)
+    uint32_t err;
+    uint32_t pending_packets;
+    int64_t next_packet; // number the next transmitted packet gets
+    int64_t time;
+    uint32_t seq;        // written last
+    uint32_t pad[7];
+};
+struct EvOut {
+    EvHeader *hdr;
+    int64_t *pkt;
+    int32_t *dst;
+    double *rssi;
+    uint32_t cap;
+};
+struct NodeInfoOut {
+    uint32_t *seq;
+    double *rssi;
+    int32_t *receiving, *channel;
+};
+
 struct LaunchCfg {
     bool f64_filter;  // fp32 frame too coarse: filter in fp64, no bounding boxes
     bool stochastic;  // java.util.Random draws may be consumed
@@ -303,6 +388,13 @@ hipError_t launch_draws_scan(hipStream_t s, const TickDev &t);
 hipError_t launch_draws_batch(hipStream_t s, const ModelDev &m, const TickDev *ticks, int n, const TickDev *dev_ticks);
 hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
                               int rank);
+
+// reception stage (rm_events.hip)
+hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,
+                            int immediate, const uint32_t *dropped_flag);
+hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq);
+hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, const int32_t *dev_nodes, int n, double base_rssi,
+                            const NodeInfoOut &out, uint32_t seq);
 
 // host-side mirrors of device math used for constants (rm_math.hpp, exported by rm_transmit.hip)
 double host_det_pow10(double y);

@@ -1,0 +1,480 @@
+// rm_events.hip -- the reception stage: what the reference does with the verdicts after RadioMedium.transmit
+// (part of libradiomedium_hip.so; gfx950 only; overview at the top of rm_engine.h)
+//
+// Reference (paths relative to /root/reference/radio-medium/java/se/sics/emul8/radiomedium/):
+//   Simulator.generateTransmissionEvents / generateReceptionEvents (Simulator.java:321-350): two queued events
+//     per packet and per heard link, at max(start, currentTime) and + air time -- 2 allocations and 2 locked
+//     ladder-queue inserts per heard link, the reference's real bottleneck;
+//   Simulator.emulatorTimeStepDone -> processAllEvents (:155-165, :213-228): at the end of a tick every
+//     event with time < currentTime is popped and executed;
+//   events/ReceptionEvent.java:35-46, events/TransmissionEvent.java:18-26, Transciever.java:52-113: the start
+//     flank latches packet + rssi (and clears "sending"), the end flank clears the reception and, in
+//     delivery mode, calls Simulator.deliverRadioPacket; setSending clears the reception.
+//
+// Here the packets of the evaluated ticks stay on the device (a ring of EvPacket + a ring of their heard
+// links) and a drain is a handful of data-parallel kernels instead of a queue:
+//   * the pop order of the reference's queue is a sort key (rm_evorder.hpp), constant per (packet, flank):
+//     a drain ranks the few thousand fired (packet, flank) groups, not the events;
+//   * deliveries do not depend on the radio state (a delivery-mode end flank always delivers): the
+//     delivery list is the delivered links of the fired end groups, group by group in rank order, inside
+//     a group in reverse node order (reverse insertion);
+//   * every event ASSIGNS the radio fields it touches (receiving <- true / false, sending <- true / false,
+//     rssi <- r), so a node's state after the drain is decided by the LAST event that touched the field:
+//     one 64-bit atomicMax per event on (rank, event) keys, then the winners write the state.
+// Nothing is approximated: tests/test_gpu_events.py compares delivery lists and node states with a literal
+// serial replay of the Java queue kept with the tests, ties included.
+#include "rm_device.hpp"
+#include "rm_evorder.hpp"
+
+namespace rm {
+
+constexpr int64_t kI64Min = int64_t(0x8000000000000000ull);
+
+RM_D void amax_i64(int64_t *p, int64_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RM_D unsigned long long ev_key(uint32_t rank, uint32_t kind, uint32_t ref)
+{
+    return ((unsigned long long)(rank + 1u) << 32) | ((unsigned long long)kind << 29) | (unsigned long long)(ref & 0x1FFFFFFFu);
+}
+RM_D void amax_key(unsigned long long *p, unsigned long long k) { (void)__hip_atomic_fetch_max(p, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RM_D bool owned(const EvDev &e, int node) { return node >= e.own_first && node < e.own_first + e.own_count; }
+
+// ============================================================================ append
+// One evaluated tick handed to the event stage: per packet an EvPacket (event times, ladders, packet
+// number) and a copy of its heard links.  What Simulator.generate*Events does per call, for the whole tick.
+template <bool SEG>
+__global__ void __launch_bounds__(256)
+k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ tx, int n_new, int64_t now, int immediate,
+            const uint32_t *dropped_flag)
+{
+    __shared__ uint32_t s_off[SEG ? kFusedScanMax + 1 : 1];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_last;
+    EvState &st = *e.st;
+    const uint32_t pk_head = st.pk_head, pk_tail = st.pk_tail, pool_head = st.pool_head, pool_tail = st.pool_tail;
+    const int64_t gseq0 = st.gseq_next;
+    EvOrder ord;
+    ord.top_start = st.top_start;
+    ord.ladders = st.ladders;
+    ord.top_max = 0;
+    ord.top_nonempty = 0;
+    uint32_t total;
+    if (SEG) total = block_scan_counts(ls.cnt, ls.n_scan, s_off, s_wave, nullptr, nullptr);
+    else total = ls.off[n_new];
+    uint32_t err = 0;
+    if (dropped_flag && *dropped_flag != 0u) err |= 8u; // the tick itself overflowed the link capacity: it has no links
+    if (pk_tail - pk_head + uint32_t(n_new) > e.pk_mask + 1u) err |= 1u;
+    if (pool_tail - pool_head + total > e.pool_mask + 1u) err |= 2u;
+    const int lane = threadIdx.x & 63;
+    if (!err) {
+        for (int q = blockIdx.x * 4 + wave_index(); q < n_new; q += gridDim.x * 4) { // wave-uniform
+            const rm_tx_record r = tx[q];
+            const uint32_t cnt = uniform_u(SEG ? ls.cnt[q] : (ls.off[q + 1] - ls.off[q]));
+            const uint32_t src0 = uniform_u(ls.off[q]);
+            const uint32_t dst0 = pool_tail + uniform_u(SEG ? s_off[q] : ls.off[q]);
+            for (uint32_t j = lane; j < cnt; j += 64) {
+                const uint32_t o = (dst0 + j) & e.pool_mask;
+                e.l_dst[o] = ls.dst[src0 + j];
+                e.l_rssi[o] = ls.rssi[src0 + j];
+                e.l_verdict[o] = ls.verdict[src0 + j];
+            }
+            if (lane == 0) {
+                EvPacket p;
+                int64_t t0 = r.start_us;           // Simulator.java:323-326
+                if (t0 < now) t0 = now;
+                p.t0 = t0;
+                p.t1 = t0 + r.air_us;
+                p.gseq = gseq0 + q;
+                p.link_off = dst0;
+                p.link_cnt = cnt;
+                p.src = r.src;
+                p.lad0 = ev_ladder(ord, p.t0);
+                p.lad1 = ev_ladder(ord, p.t1);
+                p.flags = 0u;
+                if (immediate) p.flags |= kEvImmediate | kEvNoTx;          // UDGMConstantLossRadioMedium.java:30: no events at all
+                else if (r.src < 0 || !owned(e, r.src)) p.flags |= kEvNoTx; // the source's Transciever lives on another rank
+                if (r.src < 0) p.flags |= kEvStartDone | kEvDone;           // a padding record is no packet
+                p.pad[0] = p.pad[1] = p.pad[2] = p.pad[3] = 0u;
+                e.pk[(pk_tail + uint32_t(q)) & e.pk_mask] = p;
+                // every packet's transmission events sit in the reference's (one, global) queue, whoever owns the source
+                if (!immediate && r.src >= 0) {
+                    if (p.t0 >= ord.top_start) amax_i64(&st.top_max, p.t0);
+                    if (p.t1 >= ord.top_start) amax_i64(&st.top_max, p.t1);
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&st.done_a, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        st.done_a = 0u;
+        if (err) {
+            st.err |= err;
+        } else {
+            st.pk_tail = pk_tail + uint32_t(n_new);
+            st.pool_tail = pool_tail + total;
+        }
+        st.gseq_next = gseq0 + n_new; // the packets were transmitted, kept or not
+    }
+}
+
+// ============================================================================ drain
+// k_ev_select: which (packet, flank) groups fire in processAllEvents(T)?  Sort key = (time, meta).
+RM_D uint64_t ev_meta(uint32_t lad_rel, uint32_t order, uint32_t phase) { return (uint64_t(lad_rel) << 40) | (uint64_t(order) << 1) | phase; }
+
+__global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
+{
+    EvState &st = *e.st;
+    const uint32_t head = st.pk_head, w = st.pk_tail - head;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x * blockDim.x >= ((w + 63u) & ~63u)) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t idx = (head + i) & e.pk_mask;
+    EvPacket p{};
+    bool valid = false;
+    if (i < w) {
+        p = e.pk[idx];
+        valid = !(p.flags & kEvDone);
+    }
+    const int64_t gseq_head = e.pk[head & e.pk_mask].gseq;
+    const uint32_t rel = uint32_t(p.gseq - gseq_head);
+    const int32_t lb = st.ladders;
+    const bool imm = (p.flags & kEvImmediate) != 0u;
+    const bool fire_start = valid && !imm && !(p.flags & kEvStartDone) && p.t0 < T;
+    const bool fire_end = valid && (imm || p.t1 < T);
+    for (int ph = 0; ph < 2; ++ph) { // 0 end, 1 start
+        const bool fire = ph ? fire_start : fire_end;
+        const uint64_t hm = ballot64(fire);
+        if (hm == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&st.n_groups, uint32_t(__popcll(hm)));
+        base = uniform_u(base);
+        if (base + uint32_t(__popcll(hm)) > e.g_cap) {
+            if (lane == 0) st.err |= 4u;
+            continue;
+        }
+        if (fire) {
+            const uint32_t k = base + lane_prefix(hm);
+            if (imm) { // synchronous deliveries: before anything queued, in call order
+                e.g_time[k] = kI64Min;
+                e.g_meta[k] = ev_meta(0u, rel, 0u);
+            } else {
+                e.g_time[k] = ph ? p.t0 : p.t1;
+                e.g_meta[k] = ev_meta(uint32_t((ph ? p.lad0 : p.lad1) - lb), 0xFFFFFFFFu - rel, uint32_t(ph));
+            }
+            e.g_ref[k] = (idx << 1) | uint32_t(ph);
+        }
+    }
+}
+
+// k_ev_rank: a group's rank = the number of groups with a smaller key (keys are unique); an end group
+// also counts its delivered links.
+constexpr int kEvTile = 1024;
+__global__ void __launch_bounds__(256) k_ev_rank(const EvDev e)
+{
+    __shared__ int64_t s_time[kEvTile];
+    __shared__ uint64_t s_meta[kEvTile];
+    const uint32_t G = min(e.st->n_groups, e.g_cap);
+    if (blockIdx.x * blockDim.x >= G) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = i < G;
+    const int64_t ti = mine ? e.g_time[i] : 0;
+    const uint64_t mi = mine ? e.g_meta[i] : 0;
+    uint32_t rank = 0;
+    for (uint32_t k0 = 0; k0 < G; k0 += kEvTile) { // block-uniform
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < uint32_t(kEvTile) && k0 + k < G; k += blockDim.x) {
+            s_time[k] = e.g_time[k0 + k];
+            s_meta[k] = e.g_meta[k0 + k];
+        }
+        __syncthreads();
+        const uint32_t nk = min(uint32_t(kEvTile), G - k0);
+        for (uint32_t k = 0; k < nk; ++k) {
+            const int64_t tk = s_time[k];
+            const uint64_t mk = s_meta[k];
+            rank += (tk < ti || (tk == ti && mk < mi)) ? 1u : 0u;
+        }
+    }
+    if (!mine) return;
+    uint32_t cnt = 0;
+    const uint32_t ref = e.g_ref[i];
+    if ((ref & 1u) == 0u) { // end group
+        const EvPacket &p = e.pk[ref >> 1];
+        for (uint32_t j = 0; j < p.link_cnt; ++j) cnt += (e.l_verdict[(p.link_off + j) & e.pool_mask] == RM_DELIVERED) ? 1u : 0u;
+    }
+    e.g_rank[i] = rank;
+    e.cnt_by_rank[rank] = cnt;
+}
+
+// k_ev_scan: first delivery of every group, in rank order
+__global__ void __launch_bounds__(1024) k_ev_scan(const EvDev e)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t G = min(e.st->n_groups, e.g_cap);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < G; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < G) ? e.cnt_by_rank[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (i < G) e.off_by_rank[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) e.st->n_deliv = carry;
+}
+
+// k_ev_emit: one wave per fired group: the deliveries of an end group to their places of the delivery
+// list, and every event's (rank, event) key to the fields of the node it touches.
+__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out)
+{
+    const uint32_t G = min(e.st->n_groups, e.g_cap);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
+        const uint32_t ref = uniform_u(e.g_ref[g]);
+        const uint32_t r = uniform_u(e.g_rank[g]);
+        const EvPacket &p = e.pk[ref >> 1];
+        const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
+        const int src = uniform_i(p.src);
+        const bool start = (ref & 1u) != 0u;
+        const bool imm = (fl & kEvImmediate) != 0u;
+        if (start) {
+            // ReceptionEvent start flank: setReceiving = clearSending + latch (Transciever.java:80-84)
+            for (uint32_t j = lane; j < cnt; j += 64) {
+                const uint32_t o = (off0 + j) & e.pool_mask;
+                const unsigned long long k = ev_key(r, kEvRxStart, o);
+                const int d = e.l_dst[o];
+                amax_key(&e.recv_key[d], k);
+                amax_key(&e.send_key[d], k);
+            }
+            // TransmissionEvent start: setSending = clearReceiving + sendingPacket (Transciever.java:106-109)
+            if (lane == 0 && !(fl & kEvNoTx)) {
+                const unsigned long long k = ev_key(r, kEvTxStart, 0u);
+                amax_key(&e.send_key[src], k);
+                amax_key(&e.recv_key[src], k);
+            }
+        } else {
+            const uint32_t n_del = uniform_u(e.cnt_by_rank[r]), first = uniform_u(e.off_by_rank[r]);
+            const int64_t gseq = p.gseq;
+            uint32_t seen = 0;
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 64) { // wave-uniform
+                const uint32_t j = j0 + lane;
+                bool deliver = false;
+                uint32_t o = 0;
+                if (j < cnt) {
+                    o = (off0 + j) & e.pool_mask;
+                    deliver = e.l_verdict[o] == RM_DELIVERED;
+                    if (!imm) amax_key(&e.recv_key[e.l_dst[o]], ev_key(r, kEvRxEnd, o)); // end flank: clearReceiving, whichever packet
+                }
+                const uint64_t dm = ballot64(deliver);
+                if (deliver) {
+                    const uint32_t nth = seen + lane_prefix(dm); // n-th delivered link of the packet in node order
+                    // queued end events pop in reverse insertion order = reverse node order; the constant-loss
+                    // medium delivers synchronously in node order
+                    const uint32_t pos = first + (imm ? nth : (n_del - 1u - nth));
+                    if (pos < out.cap) {
+                        out.pkt[pos] = gseq;
+                        out.dst[pos] = e.l_dst[o];
+                        out.rssi[pos] = e.l_rssi[o];
+                    }
+                }
+                seen += uint32_t(__popcll(dm));
+            }
+            if (lane == 0 && !(fl & kEvNoTx)) amax_key(&e.send_key[src], ev_key(r, kEvTxEnd, 0u)); // clearSending
+        }
+    }
+}
+
+// k_ev_apply: the last writer of a field writes it (and clears its key); the groups' packets are marked; the
+// workgroup that finishes last moves the ring heads, runs the queue's ladder rule for this drain
+// (rm_evorder.hpp) and publishes the delivery list's header.
+__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out, int64_t T, uint32_t seq)
+{
+    __shared__ uint32_t s_last;
+    EvState &st = *e.st;
+    const uint32_t G = min(st.n_groups, e.g_cap);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
+        const uint32_t ref = uniform_u(e.g_ref[g]);
+        const uint32_t r = uniform_u(e.g_rank[g]);
+        EvPacket &p = e.pk[ref >> 1];
+        const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
+        const int src = uniform_i(p.src);
+        const bool start = (ref & 1u) != 0u;
+        const bool imm = (fl & kEvImmediate) != 0u;
+        if (start) {
+            for (uint32_t j = lane; j < cnt; j += 64) {
+                const uint32_t o = (off0 + j) & e.pool_mask;
+                const unsigned long long k = ev_key(r, kEvRxStart, o);
+                const int d = e.l_dst[o];
+                if (e.recv_key[d] == k) {
+                    e.receiving[d] = 1;
+                    e.latched[d] = e.l_rssi[o];
+                    e.recv_key[d] = 0ull;
+                }
+                if (e.send_key[d] == k) {
+                    e.sending[d] = 0;
+                    e.send_key[d] = 0ull;
+                }
+            }
+            if (lane == 0 && !(fl & kEvNoTx)) {
+                const unsigned long long k = ev_key(r, kEvTxStart, 0u);
+                if (e.send_key[src] == k) {
+                    e.sending[src] = 1;
+                    e.send_key[src] = 0ull;
+                }
+                if (e.recv_key[src] == k) {
+                    e.receiving[src] = 0;
+                    e.recv_key[src] = 0ull;
+                }
+            }
+        } else {
+            if (!imm) {
+                for (uint32_t j = lane; j < cnt; j += 64) {
+                    const uint32_t o = (off0 + j) & e.pool_mask;
+                    const unsigned long long k = ev_key(r, kEvRxEnd, o);
+                    const int d = e.l_dst[o];
+                    if (e.recv_key[d] == k) {
+                        e.receiving[d] = 0;
+                        e.recv_key[d] = 0ull;
+                    }
+                }
+                if (lane == 0 && !(fl & kEvNoTx)) {
+                    const unsigned long long k = ev_key(r, kEvTxEnd, 0u);
+                    if (e.send_key[src] == k) {
+                        e.sending[src] = 0;
+                        e.send_key[src] = 0ull;
+                    }
+                }
+            }
+        }
+    }
+    // the flags are read by every wave above (a packet's two groups may sit in different workgroups): set them
+    // only after all of them are done -- by the last workgroup
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&st.done_b, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) {
+        const uint32_t ref = e.g_ref[g];
+        atomicOr(&e.pk[ref >> 1].flags, (ref & 1u) ? kEvStartDone : (kEvDone | kEvStartDone));
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    // ring heads: past every packet whose end has fired
+    uint32_t head = st.pk_head;
+    const uint32_t tail = st.pk_tail;
+    while (head != tail) { // wave-uniform
+        const uint32_t i = head + lane;
+        bool done = false;
+        if (int32_t(tail - i) > 0) done = (__hip_atomic_load(&e.pk[i & e.pk_mask].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kEvDone) != 0u;
+        const uint64_t keep = ~ballot64(done);
+        const uint32_t run = keep ? uint32_t(__ffsll((long long)keep) - 1) : 64u;
+        const uint32_t left = tail - head;
+        head += min(run, left);
+        if (run < 64u || left <= 64u) break;
+    }
+    if (lane == 0) {
+        st.pk_head = head;
+        st.pool_head = (head == tail) ? st.pool_tail : __hip_atomic_load(&e.pk[head & e.pk_mask].link_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        EvOrder o;
+        o.top_start = st.top_start;
+        o.top_max = st.top_max;
+        o.ladders = st.ladders;
+        o.top_nonempty = (st.top_max != kI64Min) ? 1 : 0;
+        ev_drain(o, T);
+        st.top_start = o.top_start;
+        st.ladders = o.ladders;
+        if (!o.top_nonempty) st.top_max = kI64Min;
+        st.t_prev = T;
+        const uint32_t total = st.n_deliv;
+        if (st.n_groups > e.g_cap) st.err |= 4u;
+        st.n_groups = 0u;
+        st.done_b = 0u;
+        out.hdr->count = min(total, out.cap);
+        out.hdr->total = total;
+        out.hdr->err = st.err;
+        out.hdr->pending_packets = tail - head;
+        out.hdr->next_packet = st.gseq_next;
+        out.hdr->time = T;
+        __threadfence_system();
+        __hip_atomic_store(&out.hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ============================================================================ node-info
+// The per-node fields of a time-step message (net/JSONClientConnection.java:331-341): Transciever.getRSSI
+// (:52-61: the latched rssi while receiving, else the medium's base RSSI), getReceivingState (:67-78),
+// getWirelessChannel -- from the device-resident radio state.
+__global__ void __launch_bounds__(256)
+k_node_info(const EvDev e, const NodesDev nd, const int32_t *__restrict__ nodes, int n, double base_rssi, NodeInfoOut out, uint32_t seq,
+            uint32_t *done_counter)
+{
+    __shared__ uint32_t s_last;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int i = nodes ? nodes[k] : k;
+        double rssi = base_rssi;
+        int state = 0, ch = 0;
+        if (i >= 0 && i < e.n_nodes) {
+            const bool rx = e.receiving[i] != 0;
+            if (rx) rssi = e.latched[i];
+            state = !nd.senabled[i] ? 3 : (rx ? 2 : (e.sending[i] ? 1 : 0)); // DISABLED / RECEIVING / TRANSMITTING / LISTENING
+            ch = nd.schannel[i];
+        }
+        out.rssi[k] = rssi;
+        out.receiving[k] = state;
+        out.channel[k] = ch;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        *done_counter = 0u;
+        __threadfence_system();
+        __hip_atomic_store(out.seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ============================================================================ launchers
+
+hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,
+                            int immediate, const uint32_t *dropped_flag)
+{
+    if (n_new <= 0) return hipSuccess;
+    const dim3 grid(max(1, min(256, cdiv(n_new, 4)))), block(256);
+    if (ls.n_scan > 0) {
+        if (ls.n_scan > kFusedScanMax) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_ev_append<true>, grid, block, 0, s, e, ls, tx, n_new, now, immediate, dropped_flag);
+    } else {
+        hipLaunchKernelGGL(k_ev_append<false>, grid, block, 0, s, e, ls, tx, n_new, now, immediate, dropped_flag);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq)
+{
+    const uint32_t pk_cap = e.pk_mask + 1u;
+    hipLaunchKernelGGL(k_ev_select, dim3(cdiv(int(pk_cap), 256)), dim3(256), 0, s, e, time_us);
+    hipLaunchKernelGGL(k_ev_rank, dim3(cdiv(int(e.g_cap), 256)), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(k_ev_scan, dim3(1), dim3(1024), 0, s, e);
+    hipLaunchKernelGGL(k_ev_emit, dim3(512), dim3(256), 0, s, e, out);
+    hipLaunchKernelGGL(k_ev_apply, dim3(512), dim3(256), 0, s, e, out, time_us, seq);
+    return hipGetLastError();
+}
+
+static uint32_t *g_dummy = nullptr;
+
+hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, const int32_t *dev_nodes, int n, double base_rssi,
+                            const NodeInfoOut &out, uint32_t seq)
+{
+    (void)g_dummy;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_node_info, dim3(max(1, min(256, cdiv(n, 256)))), dim3(256), 0, s, e, nd, dev_nodes, n, base_rssi, out, seq,
+                       &e.st->done_a);
+    return hipGetLastError();
+}
+
+} // namespace rm

@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) k_patch_nodes(NodesDev nd, const NodePatc
     const_cast<double *>(nd.stxpower)[p.node] = p.txpower;
     const_cast<double *>(nd.stxprob)[p.node] = p.txprob;
     const_cast<int32_t *>(nd.schannel)[p.node] = p.channel;
+    const_cast<uint8_t *>(nd.senabled)[p.node] = uint8_t(p.enabled);
     if (p.pos < 0) return;
     const_cast<double *>(nd.x)[p.pos] = p.x;
     const_cast<double *>(nd.y)[p.pos] = p.y;

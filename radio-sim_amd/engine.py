@@ -335,6 +335,45 @@ class Engine:
         check(self._L.rm_result_count(self._h, C.byref(cnt), C.byref(dropped)))
         return cnt.value, dropped.value
 
+    # ---- reception stage (Simulator.generate*Events + processAllEvents + Transciever state on the device)
+    def events_enable(self, max_packets=0, max_links=0):
+        check(self._L.rm_events_enable(self._h, max_packets, max_links))
+
+    def events_disable(self):
+        check(self._L.rm_events_disable(self._h))
+
+    def events_next_packet(self):
+        return self._L.rm_events_next_packet(self._h)
+
+    def events_process(self, time_us):
+        """Simulator.emulatorTimeStepDone: currentTime = time; processAllEvents(time).  Returns the deliveries of
+        the drain in call order: (packet numbers, destination node indices, rssi), copied out of the pinned block."""
+        from ._lib import DeliveryView
+        v = DeliveryView()
+        check(self._L.rm_events_process(self._h, int(time_us), C.byref(v)))
+        k = v.count
+
+        def arr(ptr, dtype):
+            if k == 0:
+                return np.empty(0, dtype=dtype)
+            buf = (C.c_char * (k * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=k).copy()
+        return arr(v.packet, np.int64), arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets
+
+    def node_info(self, nodes=None, n=None):
+        """(rssi, receiving state, channel) per node: the node-info of a time-step message."""
+        if nodes is not None:
+            nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+            n = len(nodes)
+        elif n is None:
+            n = self._L.rm_node_count(self._h)
+        rssi = np.empty(n, dtype=np.float64)
+        rx = np.empty(n, dtype=np.int32)
+        ch = np.empty(n, dtype=np.int32)
+        check(self._L.rm_node_info(self._h, nodes.ctypes.data if nodes is not None else None, n, rssi.ctypes.data,
+                                   rx.ctypes.data, ch.ctypes.data))
+        return rssi, rx, ch
+
     def sync(self):
         check(self._L.rm_sync(self._h))
 

@@ -49,3 +49,44 @@ def test_expected_neighbours(rsa):
     d2 = (nd.x[i, None] - nd.x[None, :]) ** 2 + (nd.y[i, None] - nd.y[None, :]) ** 2
     k = (d2 <= 2500).sum(1).mean() - 1
     assert 17 < k < 21
+
+
+def _product_order(ops):
+    """pop order of every ('pop', T) of `ops` with the product's order rule (csrc/rm_evorder.hpp through rm_evq_*):
+    sort by (time, ladder, -insertion)."""
+    from radio_sim_amd import _lib
+    L = _lib.lib()
+    o = _lib.EvqOrder()
+    L.rm_evq_init(C.byref(o))
+    pending, out, nid = [], [], 0
+    for kind, t in ops:
+        if kind == "add":
+            pending.append((t, L.rm_evq_add(C.byref(o), t), -nid))
+            nid += 1
+        else:
+            L.rm_evq_drain(C.byref(o), t)
+            pending.sort()
+            k = 0
+            while k < len(pending) and pending[k][0] < t:
+                out.append(-pending[k][2])
+                k += 1
+            pending = pending[k:]
+    return out
+
+
+def test_event_order_rule_equals_the_reference_queue(rsa, O):
+    """The sort key the reception stage uses instead of a queue (time, ladder, reverse insertion) against the
+    literal restatement of com/botbox/scheduler/EventQueue.java, ties and the moveTop boundary included."""
+    kat = [("add", 10), ("add", 50), ("add", 50), ("pop", 20), ("add", 50), ("add", 50), ("add", 30), ("pop", 100)]
+    assert _product_order(kat) == list(O.evq_replay(kat)) == [0, 5, 2, 1, 4, 3]
+    for seed in range(120):
+        rng = np.random.default_rng(1000 + seed)
+        now, ops = 0, []
+        for _ in range(int(rng.integers(3, 25))):
+            for _ in range(int(rng.integers(0, 80))):
+                pick = [now, now, now + 320, now + 8128, now + int(rng.integers(0, 1000)), now + 1000, now + 2000]
+                ops.append(("add", int(pick[int(rng.integers(0, len(pick)))])))
+            now += int(rng.choice([1000, 1000, 1, 10, 5000]))
+            ops.append(("pop", now))
+        ops.append(("pop", now + 10 ** 9))
+        assert _product_order(ops) == list(O.evq_replay(ops)), seed
