@@ -51,6 +51,7 @@ def random_session(O, rsa, eng, seed, kind, params, n=1500, ticks=14, per_tick=3
     configure_engine(eng, nodes, kind, params, matrix)
     eng.seed(seed)
     eng.events_enable()
+    eng.set_time(0)        # a new Simulator starts at time 0 (the engine may have served another session)
     mdl = oracle_model(O, kind, params, matrix)
     state = O.lib().orc_jrandom_seed(seed)
     sim = O.Sim(n)
