@@ -170,6 +170,8 @@ int rm_transmit(rm_context *ctx, int32_t src, int64_t start_us, int64_t hex_leng
 int rm_tick_begin(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us);
 int rm_enqueue_tx(rm_context *ctx, int32_t src, int64_t start_us, int64_t air_us,
                   const double *txpower, const int32_t *channel);
+/* records built by the caller: a record's txprob decides the packet's Tx draw (UDGMRadioMedium.java:87-92), also
+ * where it differs from the node table */
 int rm_enqueue_tx_records(rm_context *ctx, const rm_tx_record *recs, int32_t n);
 /* evaluates the tick and copies the heard links (packet-major, receiver ascending) out */
 int rm_tick_flush(rm_context *ctx, int32_t *pkt, int32_t *dst, uint8_t *verdict,
@@ -220,7 +222,9 @@ int rm_pack_tx_device_on(rm_context *ctx, void *hip_stream, const int32_t *dev_s
  * starts at start_us[b] (host array) -- feeds one RCCL all-gather per batch of ticks */
 int rm_pack_tx_batch_device_on(rm_context *ctx, void *hip_stream, const int32_t *dev_src, int32_t n_ticks, int32_t n,
                                const int64_t *start_us, int64_t air_us, rm_tx_record *dev_out);
-/* evaluate one tick whose new frames are `dev_new[0..n_new)` (device memory, canonical order) */
+/* evaluate one tick whose new frames are `dev_new[0..n_new)` (device memory, canonical order).  Records in device
+ * memory are not inspected by the host: their txprob has to be the source node's (as rm_pack_tx_device builds
+ * them) -- whether a java.util.Random draw can happen is decided from the node table and the model. */
 int rm_tick_run_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
                        const rm_tx_record *dev_new, int32_t n_new);
 /* the same with the new frames given as source node indices (device int32[n], -1 = padding): the

@@ -200,6 +200,7 @@ struct rm_context : TickSlot {
     DevBuf<uint8_t> d_enabled;   // Transciever.isEnabled by node index
 
     int frac_probs = -1;         // cached: any rx/tx probability strictly between 0 and 1 (-1 = unknown)
+    bool tick_frac_records = false; // a host record of the running tick has 0 < txprob < 1 (rm_enqueue_tx_records)
     bool rx_dirty = true;        // receiver table has to be rebuilt (positions / partition / model class)
     bool prefilter_dirty = true; // pre-filter records have to be recomputed
     double org[3] = {0, 0, 0};
@@ -306,6 +307,7 @@ bool maybe_draws(rm_context *c)
     const int k = c->params.kind;
     if (k == RM_MODEL_NULL || k == RM_MODEL_UDGM_CONST) return false;
     if (k == RM_MODEL_N2N) return true;
+    if (c->tick_frac_records) return true; // a record of this tick carries its own fractional txProbability
     if (k == RM_MODEL_UDGM && c->params.udgm_success_ratio_rx != 1.0) return true;
     if (c->frac_probs < 0) {
         c->frac_probs = 0;
@@ -1547,6 +1549,7 @@ int rm_tick_begin(rm_context *c, int64_t t_begin_us, int64_t t_end_us)
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
     c->pending.clear();
+    c->tick_frac_records = false;
     if (is_sinr(c)) {
         size_t k = 0;
         for (size_t i = 0; i < c->onair.size(); ++i)
@@ -1576,6 +1579,8 @@ int rm_enqueue_tx_records(rm_context *c, const rm_tx_record *recs, int32_t n)
     if (!c->in_tick) return fail(RM_ERR_STATE, "rm_enqueue_tx_records outside a tick");
     for (int i = 0; i < n; ++i) {
         if (recs[i].src >= c->n) return fail(RM_ERR_INVALID, "record source out of range");
+        // the Tx draw of UDGMRadioMedium.java:87-92 follows the RECORD's txProbability, whatever the node table says
+        if (frac(recs[i].txprob)) c->tick_frac_records = true;
         c->pending.push_back(recs[i]);
     }
     return RM_OK;
@@ -1787,7 +1792,9 @@ static int tick_run_host(rm_context *c)
         RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
         RM_HIP(hipEventRecord(c->h_tx_ev[g], c->stream));
     }
-    RM_TRY(run_tick(c, c->d_tx.p, int(total), first_new));
+    const int rc = run_tick(c, c->d_tx.p, int(total), first_new);
+    c->tick_frac_records = false;
+    if (rc != RM_OK) return rc;
     if (is_sinr(c)) c->onair.insert(c->onair.end(), c->pending.begin(), c->pending.end());
     c->pending.clear();
     return RM_OK;

@@ -19,11 +19,22 @@
 //                       rm_transmit call, and the heard links -- returned in node order -- become exactly the
 //                       Simulator calls the reference's loops make.
 //
+// Two more modes of the media, for hosts that batch (the reference consumes a tick's events only in
+// emulatorTimeStepDone -> processAllEvents, Simulator.java:155-165, so nothing forces one evaluation per packet):
+//   setTickMode(true)      transmit() only queues the packet; Simulator::emulatorTimeStepDone flushes the queue in
+//                          ONE evaluation (rm_tick_begin / rm_enqueue_tx / rm_tick_flush_view) before the time moves,
+//                          and the medium then makes the very calls of the per-packet mode, in arrival x node order.
+//   setDeviceEvents(true)  the events never reach the host: the engine keeps packets, heard links and every
+//                          node's radio state on the device (rm_events_*), Simulator::emulatorTimeStepDone hands
+//                          out the drain's deliveries in the reference queue's order, nodeInfo() the time-step
+//                          message's per-node fields.
+//
 // There is no CPU evaluation in this file: without a gfx950 device the medium's constructor throws.
 #pragma once
 
 #include <cstdint>
 #include <cstdlib>
+#include <deque>
 #include <memory>
 #include <cstdio>
 #include <stdexcept>
@@ -155,6 +166,9 @@ public:
     virtual void setSimulator(Simulator *sim) = 0;
     virtual void transmit(RadioPacket &packet) = 0;
     virtual double getBaseRSSI(Node &node) = 0;
+    // hooks of Simulator::emulatorTimeStepDone (not in the reference's interface; no-ops for a plain medium)
+    virtual void flush() {}                       // evaluate the transmit() calls queued since the last tick end
+    virtual void processEvents(int64_t /*time*/) {} // the tick-end drain, when the medium keeps the events itself
 };
 
 // what the medium hands back to the simulation core, recorded in call order
@@ -220,6 +234,15 @@ public:
         table_[id] = n;
         ++version_;
         return n;
+    }
+    // Simulator.emulatorTimeStepDone (Simulator.java:155-165): currentTime = stepTime; processAllEvents(currentTime).
+    // A medium in tick mode evaluates its queued transmit() calls first -- while currentTime is still the old one,
+    // which is what the event times of those packets were computed with in the reference (:323-326).
+    void emulatorTimeStepDone(int64_t stepTime)
+    {
+        if (medium_) medium_->flush();
+        currentTime_ = stepTime;
+        if (medium_) medium_->processEvents(stepTime);
     }
     void generateTransmissionEvents(RadioPacket &p) { record(MediumCall::TRANSMISSION_EVENTS, p, nullptr, 0.0, false); }
     void generateReceptionEvents(RadioPacket &p, Node *dst, double rssi, bool doDeliver)
@@ -337,9 +360,96 @@ public:
         rm_set_base_rssi(ctx_, rssi);
     }
 
+    // ---- batching modes (see the top of this file)
+    void setTickMode(bool on) { tickMode_ = on; }
+    bool getTickMode() const { return tickMode_; }
+    void setDeviceEvents(bool on)
+    {
+        if (on == deviceEvents_) return;
+        if ((on ? rm_events_enable(ctx_, 0, 0) : rm_events_disable(ctx_)) != RM_OK) throw std::runtime_error(rm_last_error());
+        deviceEvents_ = on;
+        inFlight_.clear();
+        firstInFlight_ = on ? rm_events_next_packet(ctx_) : 0;
+    }
+    bool getDeviceEvents() const { return deviceEvents_; }
+
+    // the transmit() calls queued in tick mode, in ONE evaluation; then the calls the per-packet mode makes
+    void flush() override
+    {
+        if (queue_.empty()) return;
+        lastError.clear();
+        Simulator *sim = simulator;
+        std::vector<RadioPacket *> q;
+        q.swap(queue_);
+        if (!sim) { lastError = "No simulator"; return; }
+        const std::vector<Node *> &nodes = sim->getNodes();
+        if (!sync(sim, nodes)) return;
+        rm_set_time(ctx_, sim->getTime());
+        int rc = rm_tick_begin(ctx_, sim->getTime(), sim->getTime());
+        for (size_t k = 0; k < q.size() && rc == RM_OK; ++k) {
+            const double txp = q[k]->getTransmitPower();
+            const int32_t ch = q[k]->getWirelessChannel();
+            rc = rm_enqueue_tx(ctx_, q[k]->getSource()->index, q[k]->getStartTime(), q[k]->getPacketAirTime(), &txp, &ch);
+        }
+        if (rc != RM_OK) { lastError = rm_last_error(); return; }
+        if (deviceEvents_) { // nothing comes back: packets, links and events stay on the device
+            if (rm_tick_run(ctx_) != RM_OK) { lastError = rm_last_error(); return; }
+            for (RadioPacket *p : q) inFlight_.push_back(p);
+            return;
+        }
+        rm_host_result r{};
+        if (rm_tick_flush_view(ctx_, &r) != RM_OK) { lastError = rm_last_error(); return; }
+        for (uint32_t k = 0; k < r.n_packets; ++k) { // arrival order, then node order: the per-packet calls
+            RadioPacket &packet = *q[k];
+            if (kind_ != RM_MODEL_UDGM_CONST) sim->generateTransmissionEvents(packet);
+            for (uint32_t i = r.pkt_offset[k]; i < r.pkt_offset[k + 1]; ++i) {
+                Node *node = nodes[size_t(r.dst[i])];
+                if (kind_ == RM_MODEL_UDGM_CONST) sim->deliverRadioPacket(packet, node, r.rssi[i]);
+                else sim->generateReceptionEvents(packet, node, r.rssi[i], r.verdict[i] == RM_DELIVERED);
+            }
+        }
+    }
+
+    // device events: Simulator.processAllEvents(time) as one drain on the device; the deliveries come back in the
+    // order the reference's queue pops them and become Simulator.deliverRadioPacket calls (ReceptionEvent.java:41-44)
+    void processEvents(int64_t time) override
+    {
+        if (!deviceEvents_) return;
+        Simulator *sim = simulator;
+        rm_delivery_view v{};
+        if (rm_events_process(ctx_, time, &v) != RM_OK) { lastError = rm_last_error(); return; }
+        const std::vector<Node *> &nodes = sim->getNodes();
+        for (uint32_t i = 0; i < v.count; ++i) {
+            RadioPacket *p = inFlight_[size_t(v.packet[i] - firstInFlight_)];
+            sim->deliverRadioPacket(*p, nodes[size_t(v.dst[i])], v.rssi[i]);
+        }
+        // packets whose last event has fired are forgotten
+        const int64_t oldest = rm_events_next_packet(ctx_) - int64_t(v.pending_packets);
+        while (firstInFlight_ < oldest && !inFlight_.empty()) {
+            inFlight_.pop_front();
+            ++firstInFlight_;
+        }
+    }
+
+    // the per-node fields of a time-step message (net/JSONClientConnection.java:331-341) from the device's radio state
+    bool nodeInfo(const std::vector<int32_t> &nodes, std::vector<double> &rssi, std::vector<int32_t> &receiving,
+                  std::vector<int32_t> &channel)
+    {
+        rssi.resize(nodes.size()); receiving.resize(nodes.size()); channel.resize(nodes.size());
+        if (rm_node_info(ctx_, nodes.data(), int32_t(nodes.size()), rssi.data(), receiving.data(), channel.data()) != RM_OK) {
+            lastError = rm_last_error();
+            return false;
+        }
+        return true;
+    }
+
     // transmit(): never throws (the reference's returns void); failures are reported through lastError
     void transmit(RadioPacket &packet) override
     {
+        if (tickMode_) { // evaluated at the end of the tick, with everything else that was sent in it
+            queue_.push_back(&packet);
+            return;
+        }
         lastError.clear();
         Simulator *sim = simulator;
         if (!sim) { lastError = "No simulator"; return; }
@@ -355,6 +465,10 @@ public:
                                    rssi_.data(), sinr_.data(), uint32_t(dst_.size()), &heard, &interference);
         if (rc != RM_OK) { lastError = rm_last_error(); return; }
         lastInterference = interference != 0;
+        if (deviceEvents_) { // the engine queued the packet's events itself
+            inFlight_.push_back(&packet);
+            return;
+        }
         if (kind_ != RM_MODEL_UDGM_CONST) sim->generateTransmissionEvents(packet);
         for (uint32_t i = 0; i < heard; ++i) { // node order, as the reference's for (Node node : nodes)
             Node *node = nodes[dst_[i]];
@@ -411,6 +525,10 @@ private:
         return true;
     }
     int kind_;
+    bool tickMode_ = false, deviceEvents_ = false;
+    std::vector<RadioPacket *> queue_;   // tick mode: transmit() calls since the last flush
+    std::deque<RadioPacket *> inFlight_; // device events: packets with events still queued, by packet number
+    int64_t firstInFlight_ = 0;
     uint64_t uploaded_ = ~0ull;
     std::vector<int32_t> dst_;
     std::vector<uint8_t> verdict_;

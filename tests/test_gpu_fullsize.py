@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from util import to_tx_records, KINDS, _PARAM_MAP, oracle_model
+from util import to_tx_records, KINDS, _PARAM_MAP, oracle_model, assert_same
 
 pytestmark = pytest.mark.gpu
 
@@ -197,6 +197,82 @@ def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
                 _sampled_sinr_check(O, oracle_model(O, "logdist", params), nd, onair, new, gpu, np.arange(0, t, 67))
             onair = np.concatenate([onair, new])
     finally:
+        eng.close()
+
+
+def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
+    """BASELINE configs[4] at its steady state: 8128 us frames over 1000 us ticks keep ~9 ticks of frames (8000-9000)
+    on the air.  Eleven ticks; the last two are checked -- 17 sampled new frames each against the oracle with
+    the FULL on-air list (8000+ frames) as interferers."""
+    from radio_sim_amd import workload as W
+    n, t = 1_000_000, 1000
+    src_nd = W.make_nodes(n, 5)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = src_nd.x, src_nd.y
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 11}
+    eng = rsa.Engine(0)
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+        eng.set_link_capacity(1 << 25)      # ~3.6 M candidate links per tick with 9000 frames on the air
+        rng = np.random.default_rng(6)
+        onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+        mdl = oracle_model(O, "logdist", params)
+        for tick in range(11):
+            t0 = tick * 1000
+            onair = onair[onair["start_us"] + onair["air_us"] > t0]
+            srcs = W.choose_sources(n, t, 0xC0FFEE05, tick)
+            new = nd.packets(srcs, 0, W.AIR_US)
+            new["start_us"] = t0 + rng.integers(0, 1000, t)
+            eng.tick_begin(t0, t0 + 1000)
+            eng.enqueue_records(to_tx_records(rsa, new))
+            gpu = eng.tick_flush(cap=1 << 20)
+            assert gpu.count > 30_000
+            if tick >= 9:
+                assert len(onair) >= 8000, len(onair)
+                cpu = _sampled_sinr_check(O, mdl, nd, onair, new, gpu, np.arange(tick, t, 59))
+                assert (cpu.verdict == O.INTERFERED).sum() > 0      # the overlap does interfere
+            onair = np.concatenate([onair, new])
+    finally:
+        eng.close()
+
+
+def test_c2_full_tick_equals_oracle(rsa, O):
+    """BASELINE configs[1] at its own size: 10 000 nodes, 100 concurrent frames, log-distance path loss (sigma = 0),
+    seed 0xC0FFEE02 -- the WHOLE tick bit for bit against the oracle, through the host-buffer tick, the
+    device-resident tick and one batch."""
+    from radio_sim_amd import workload as W
+    from util import DeviceArray
+    n, t = 10_000, 100
+    src_nd = W.make_nodes(n, 2)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = src_nd.x, src_nd.y
+    eng = rsa.Engine(0)
+    devs = []
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"])
+        mdl = oracle_model(O, "logdist", {})
+        ticks = [W.choose_sources(n, t, 0xC0FFEE02, k) for k in range(3)]
+        want = []
+        for k, srcs in enumerate(ticks):
+            pk = nd.packets(srcs, k * W.TICK_US, W.AIR_US)
+            cpu = O.tick(mdl, nd, pk)
+            assert cpu.count > 3000
+            want.append(cpu)
+            assert_same(eng.tick(to_tx_records(rsa, pk), k * W.TICK_US, (k + 1) * W.TICK_US), cpu, "c2 host-buffer tick %d" % k)
+            d = DeviceArray(srcs)
+            devs.append(d)
+            eng.tick_run_sources_device(k * W.TICK_US, (k + 1) * W.TICK_US, d.ptr.value, t, k * W.TICK_US, W.AIR_US)
+            assert_same(eng.result_copy(t), cpu, "c2 device-resident tick %d" % k)
+        starts = [k * W.TICK_US for k in range(3)]
+        eng.batch_run_sources_device(starts, [s + W.TICK_US for s in starts], [d.ptr.value for d in devs], [t] * 3, starts,
+                                     [W.AIR_US] * 3)
+        for k in range(3):
+            assert_same(eng.batch_result_copy(k, t), want[k], "c2 batch slot %d" % k)
+    finally:
+        for d in devs:
+            d.free()
         eng.close()
 
 

@@ -136,6 +136,30 @@ def test_single_transmit_api(engine, rsa, O):
         engine.transmit(500)
 
 
+def test_records_with_their_own_tx_probability(engine, rsa, O):
+    """A caller's record may carry a txProbability the node table does not have (every node at 1.0, successRatioRx
+    1.0: no draw can come from the table).  The reference draws random.nextDouble() > txSuccess for it all the same
+    (UDGMRadioMedium.java:87-92): the frame may fail, and the generator moves."""
+    nd = random_nodes(O, 900, 400.0, seed=31)
+    for kind, params in (("udgm", {}), ("logdist", {})):
+        configure_engine(engine, nd, kind, params)
+        mdl = oracle_model(O, kind, params)
+        pk = nd.packets(np.arange(0, 900, 9), 0, 320)
+        pk["txprob"][::2] = 0.5
+        pk["txprob"][5] = 0.0
+        engine.seed(7)
+        cpu = O.tick(mdl, nd, pk, rng_state=O.lib().orc_jrandom_seed(7))
+        assert cpu.pkt_draws.sum() >= 40 and 0 < cpu.pkt_interference.sum() < len(pk)
+        gpu = engine.tick(to_tx_records(rsa, pk))
+        assert_same(gpu, cpu, kind + " records with their own txprob")
+        assert engine.rng_state == cpu.rng_state
+        # and the next tick, from the table again, takes the draw-free path
+        pk2 = nd.packets(np.arange(1, 900, 9), 1000, 320)
+        cpu2 = O.tick(mdl, nd, pk2, rng_state=cpu.rng_state)
+        assert_same(engine.tick(to_tx_records(rsa, pk2)), cpu2, kind + " next tick")
+        assert engine.rng_state == cpu.rng_state == cpu2.rng_state
+
+
 def test_empty_and_ragged(engine, rsa, O):
     nd = random_nodes(O, 130, 100.0, seed=2)      # not a multiple of 64
     configure_engine(engine, nd, "udgm", {})
