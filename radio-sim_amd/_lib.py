@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "libradiomedium_hip.so")
+_SO = os.environ.get("RM_LIBRARY") or os.path.join(_CSRC, "libradiomedium_hip.so")  # RM_LIBRARY: a diagnostic build (make stamps)
 
 MODEL_NULL, MODEL_UDGM, MODEL_UDGM_CONST, MODEL_N2N, MODEL_LOGDIST = range(5)
 UNHEARD, INTERFERED, DELIVERED = 0, 1, 2

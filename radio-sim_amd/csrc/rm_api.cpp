@@ -374,6 +374,7 @@ rm::ModelDev model_dev(const rm_context *c)
     m.ld_ifloor = p.ld_ifloor_dbm;
     m.ld_noise_lin = rm::host_det_pow10(p.ld_noise_dbm / 10.0);
     m.ld_level = p.ld_sensitivity_dbm;
+    m.ld_cut_scale = (p.ld_exponent > 0.0) ? 3.3219280948873622 / (10.0 * p.ld_exponent) : 0.0;
     if ((p.flags & RM_LD_SINR) && p.ld_ifloor_dbm < m.ld_level) m.ld_level = p.ld_ifloor_dbm;
     m.org_x = c->org[0];
     m.org_y = c->org[1];

@@ -48,7 +48,7 @@ RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, dou
             cut = inf;
         } else {
             // hardware fp32 exp2 (relative error ~1e-6 at these arguments) with a 1e-4 pad
-            cut = m.ld_d0 * double(__builtin_amdgcn_exp2f(float(margin / (10.0 * m.ld_exp) * 3.3219280948873622))) * (1.0 + 1e-4);
+            cut = m.ld_d0 * double(__builtin_amdgcn_exp2f(float(margin * m.ld_cut_scale))) * (1.0 + 1e-4);
             if (cut < m.ld_d0) cut = m.ld_d0;
         }
     } else {

@@ -63,6 +63,7 @@ struct ModelDev {
     double ld_sens, ld_noise, ld_capture, ld_ifloor;
     double ld_noise_lin;      // det_pow10(noise/10)
     double ld_level;          // candidate level L = sens, or min(sens, ifloor) with SINR
+    double ld_cut_scale;      // log2(10) / (10 n): margin [dB] -> log2 of the cut-off distance ratio (pre-filter only)
     // pre-filter
     double org_x, org_y, org_z; // origin of the fp32 frame
     double coord_bound;         // max |coord - origin| the fp32 slack was computed for

@@ -74,21 +74,23 @@ RM_HD double det_normal(double u)
                  c4 = -2.549732539343734e+00, c5 = 4.374664141464968e+00, c6 = 2.938163982698783e+00;
     const double d1 = 7.784695709041462e-03, d2 = 3.224671290700398e-01, d3 = 2.445134137142996e+00,
                  d4 = 3.754408661907416e+00;
-    // The two tails are one code path (a wave almost always holds lanes of both, and divergent
-    // branches are issued one after the other): the upper tail is the lower tail's expression on
-    // 1 - u with the sign flipped -- operation for operation what the extension spec writes as two cases.
+    // Branch-free: the central expression and the tail expression are both evaluated and one is selected --
+    // operation for operation what the extension spec writes as three cases (the upper tail is the lower
+    // tail's expression on 1 - u with the sign flipped).  A wave almost always holds lanes of the centre AND
+    // of a tail (4.85 % of the deviates are tail values), so divergent branches would be issued one after
+    // the other anyway; as one basic block the two dependent chains (and the caller's distance logarithm)
+    // interleave, which is what a latency-bound evaluation -- one frame per workgroup, rm_tick.hip -- needs.
     const bool lower = u < 0.02425;
-    if (lower || !(u <= 0.97575)) {
-        const double t = lower ? u : 1.0 - u;
-        const double q = sqrt(-2.0 * (det_log2(t) * 0.6931471805599453));
-        const double r = (((((c1 * q + c2) * q + c3) * q + c4) * q + c5) * q + c6) /
-                         ((((d1 * q + d2) * q + d3) * q + d4) * q + 1.0);
-        return lower ? r : -r;
-    }
+    const bool tail = lower || !(u <= 0.97575);
+    const double t = tail ? (lower ? u : 1.0 - u) : 0.5; // (any value with a finite logarithm for the lanes that discard it)
+    const double qt = sqrt(-2.0 * (det_log2(t) * 0.6931471805599453));
+    const double rt = (((((c1 * qt + c2) * qt + c3) * qt + c4) * qt + c5) * qt + c6) /
+                      ((((d1 * qt + d2) * qt + d3) * qt + d4) * qt + 1.0);
     const double q = u - 0.5;
     const double r = q * q;
-    return (((((a1 * r + a2) * r + a3) * r + a4) * r + a5) * r + a6) * q /
-           (((((b1 * r + b2) * r + b3) * r + b4) * r + b5) * r + 1.0);
+    const double rc = (((((a1 * r + a2) * r + a3) * r + a4) * r + a5) * r + a6) * q /
+                      (((((b1 * r + b2) * r + b3) * r + b4) * r + b5) * r + 1.0);
+    return tail ? (lower ? rt : -rt) : rc;
 }
 
 RM_HD uint64_t mix64(uint64_t z)

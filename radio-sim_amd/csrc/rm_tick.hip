@@ -38,6 +38,19 @@ constexpr int kFrFlatGroups = 256;  // up to here every group box is tested dire
 constexpr int kFrRound = 16;        // near groups per filter round: at most 1024 candidates
 constexpr int kFrCand = kFrRound * kGroup;
 
+// Diagnostic build only (make stamps; never the shipped library): s_memtime at the phase boundaries of
+// k_tick_frames, written to the unused tail of the compact rssi array (tools/tick_stamps.py reads them).
+#ifdef RM_STAMPS
+#define RM_STAMP(k)                                                                                          \
+    do {                                                                                                     \
+        if (threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();                                      \
+    } while (0)
+#else
+#define RM_STAMP(k)                                                                                          \
+    do {                                                                                                     \
+    } while (0)
+#endif
+
 RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
 {
     const float dx = fmaxf(fmaxf(qb.x - f.x, f.x - qb.z), 0.f);
@@ -61,20 +74,54 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     const int n_new = t.n_active - t.first_new;
     const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
     const int n_boxes = (n_groups + 15) / 16;
+#ifdef RM_STAMPS
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(t.out_rssi + (size_t(t.cap) - 16u * (size_t(slot) + 1u)));
+    if (threadIdx.x == 0) stamps[15] = __builtin_amdgcn_s_memrealtime();
+#endif
+    RM_STAMP(0);
 
-    // the first round's boxes do not depend on the frame: requested before its record
+    // Program order = issue order: the frame's record first (two dependent round trips when it is built from a
+    // source index), then everything that does not depend on it, so that it all flies under those round trips.
+    const int q = slot - t.shift;
+    const bool real = q >= 0 && q < n_new;
+    const int abs_i = t.first_new + (real ? q : 0);
+    const bool build = t.src_list != nullptr;
+    rm_tx_record tx;
+    int s_idx = -1;
+    if (build) s_idx = t.src_list[real ? q : 0];
+    else tx = t.tx[abs_i];
+
+    // the first round's boxes do not depend on the frame (branch-free: the index is clamped, validity is tested at use)
     constexpr int kPre = FLAT ? kFrGroups / 256 : kFrBoxes / 256;
     float4 pre_xy[kPre];
     float2 pre_z[kPre];
+    {
+        const int nb = max(FLAT ? n_groups : n_boxes, 1);
+        const float4 *__restrict__ bxy = FLAT ? nd.bbox_xy : nd.wg_box_xy;
+        const float2 *__restrict__ bz = FLAT ? nd.bbox_z : nd.wg_box_z;
 #pragma unroll
-    for (int k = 0; k < kPre; ++k) {
-        const int b = k * 256 + tid;
-        pre_xy[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pre_z[k] = make_float2(0.f, 0.f);
-        if (b < (FLAT ? n_groups : n_boxes)) {
-            pre_xy[k] = FLAT ? nd.bbox_xy[b] : nd.wg_box_xy[b];
-            pre_z[k] = FLAT ? nd.bbox_z[b] : nd.wg_box_z[b];
+        for (int k = 0; k < kPre; ++k) {
+            const int b = min(k * 256 + tid, nb - 1);
+            pre_xy[k] = bxy[b];
+            pre_z[k] = bz[b];
         }
+    }
+    uint32_t tbl_word = 0u;
+    if (SHADOW) tbl_word = m.shadow_tbl[tid]; // kBlock == kShadowBins; needed by the filter phase only
+
+    if (build) { // RadioPacket(node, time, data) copies txpower / channel from its source, RadioPacket.java:46-52
+        const bool pad = s_idx < 0 || s_idx >= nd.n;
+        const int sc = pad ? 0 : s_idx;
+        tx.x = nd.sx[sc];
+        tx.y = nd.sy[sc];
+        tx.z = nd.sz[sc];
+        tx.txpower = nd.stxpower[sc];
+        tx.txprob = nd.stxprob[sc];
+        tx.channel = nd.schannel[sc];
+        tx.start_us = t.src_start_us;
+        tx.air_us = t.src_air_us;
+        tx.src = s_idx;
+        if (pad) tx = make_tx_record(nd, -1, t.src_start_us, t.src_air_us);
     }
 
     // what the sweep's first kernel does for the tick after this one (rm_filter.hip, tick_prep_body)
@@ -84,33 +131,29 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     }
     for (int i = blockIdx.x * blockDim.x + tid; i < t.zero_len; i += gridDim.x * blockDim.x) t.cand_tot_next[i] = 0u;
 
-    const int q = slot - t.shift;
-    if (q < 0 || q >= n_new) { // padding slot of the per-frame counters
+    if (!real) { // padding slot of the per-frame counters
         if (tid == 0) {
             t.cursor[slot] = 0u;
             t.seg_off[slot] = uint32_t(slot) * uint32_t(seg_len);
         }
         return;
     }
-    rm_tx_record tx;
-    const int abs_i = t.first_new + q;
-    if (t.src_list) { // RadioPacket(node, time, data) copies txpower / channel from its source, RadioPacket.java:46-52
-        tx = make_tx_record(nd, t.src_list[q], t.src_start_us, t.src_air_us);
-        if (tid == 0) t.tx_build[abs_i] = tx;
-    } else {
-        tx = t.tx[abs_i];
-    }
+    if (build && tid == 0) t.tx_build[abs_i] = tx;
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);
+    RM_STAMP(1); // the frame's record is there
     // shadowed medium: can the link still reach the level with its own deviate?  The sweep's second-level
     // filter (rm_filter.hip): conservative table of the largest link hash that can, per bin of d^2 / cut^2
     float shadow_inv = 0.f;
     if (SHADOW) {
-        s_tbl[tid] = m.shadow_tbl[tid]; // kBlock == kShadowBins
+        s_tbl[tid] = tbl_word;
         if (f.w > 0.f && f.w < __builtin_inff()) {
-            const double cut = sqrt(double(f.w));
-            if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) shadow_inv = float(kShadowBins) / f.w;
+            // is the fp32 frame error small against the distances where the table decides anything (d > 0.15 cut)?
+            // Otherwise bin 0 (always pass).  An fp32 evaluation with a 1 % margin: the test only chooses between
+            // two conservative filters.
+            const float cut = __builtin_sqrtf(f.w);
+            if (1.01f * (2.0f * float(m.f32_slack)) / (0.15f * cut) + 1e-5f <= float(kShadowPad)) shadow_inv = float(kShadowBins) / f.w;
         }
     }
     if (tid == 0) s_n1[0] = s_n1[1] = s_n2[0] = s_n2[1] = s_nc[0] = s_nc[1] = s_nres = s_base = 0u;
@@ -148,6 +191,7 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                         }
                     }
                     __syncthreads();
+                    RM_STAMP(2); // level 1 done
                     n1 = uniform_i(int(s_n1[r1 & 1]));
                     if (tid == 0) s_n1[(r1 + 1) & 1] = 0u;
                     ++r1;
@@ -177,6 +221,7 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                         }
                     }
                     __syncthreads();
+                    RM_STAMP(3); // level 2 done
                     const int n2 = uniform_i(int(s_n2[r2 & 1]));
                     if (tid == 0) s_n2[(r2 + 1) & 1] = 0u;
                     ++r2;
@@ -199,6 +244,8 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                                 }
                             }
                         }
+                        uint64_t hms[kFrRound / 4];
+                        uint32_t wave_hits = 0;
 #pragma unroll
                         for (int k = 0; k < kFrRound / 4; ++k) {
                             const float s2 = dist2_f32(v[k].x - f.x, v[k].y - f.y, v[k].z - f.z);
@@ -209,15 +256,21 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                                 const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
                                 hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
                             }
-                            const uint64_t hm = ballot64(hit);
-                            if (hm) {
-                                uint32_t base = 0;
-                                if (lane == 0) base = atomicAdd(&s_nc[rc & 1], uint32_t(__popcll(hm)));
-                                base = uniform_u(base);
-                                if (hit) s_cand[base + lane_prefix(hm)] = jj[k];
+                            hms[k] = ballot64(hit);
+                            wave_hits += uint32_t(__popcll(hms[k]));
+                        }
+                        if (wave_hits) { // one LDS atomic per wave and round
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&s_nc[rc & 1], wave_hits);
+                            base = uniform_u(base);
+#pragma unroll
+                            for (int k = 0; k < kFrRound / 4; ++k) {
+                                if ((hms[k] >> lane) & 1ull) s_cand[base + lane_prefix(hms[k])] = jj[k];
+                                base += uint32_t(__popcll(hms[k]));
                             }
                         }
                         __syncthreads();
+                        RM_STAMP(4); // filter done
                         // exact: full lanes over the round's candidates
                         const int nc = uniform_i(int(s_nc[rc & 1]));
                         if (tid == 0) s_nc[(rc + 1) & 1] = 0u;
@@ -279,6 +332,7 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                             }
                         }
                         __syncthreads(); // the candidates are overwritten by the next round
+                        RM_STAMP(5); // exact done
                     }
                 }
             }
@@ -322,13 +376,36 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
         if (total <= seg) {
             // node order: every link is written to its final place of the segment.  Up to 64 links (the usual
             // frame) sit one per lane of the first wave and are ranked with a readlane loop; more by counting in LDS.
-            for (uint32_t i = tid; i < total; i += blockDim.x) {
+            if (total <= 64u && tid < 64) {
+                // every lane of the first wave takes part (lanes without a link hold the largest key), so that the
+                // loop can be unrolled: eight independent readlanes in flight instead of one SALU -> VALU round trip each
+                const bool have = uint32_t(tid) < total;
+                const int mine = have ? s_orig[tid] : 0x7fffffff;
+                uint32_t rank = 0;
+                const int n8 = uniform_i(int((total + 7u) & ~7u));
+                for (int k0 = 0; k0 < n8; k0 += 8) {
+                    int v8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v8[u] = __builtin_amdgcn_readlane(mine, k0 + u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rank += (v8[u] < mine) ? 1u : 0u;
+                }
+                if (have) {
+                    const uint32_t o = fixed_base + rank;
+                    t.a_dst[o] = mine;
+                    t.a_rssi[o] = s_rssi[tid];
+                    if (STOCH) {
+                        t.a_prob[o] = s_prob[tid];
+                        t.a_verdict[o] = uint8_t(0);
+                    } else {
+                        t.a_verdict[o] = dead ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+                    }
+                }
+            }
+            for (uint32_t i = tid; total > 64u && i < total; i += blockDim.x) {
                 const int mine = s_orig[i];
                 uint32_t rank = 0;
-                if (total <= 64u) {
-                    const int n = uniform_i(int(total));
-                    for (int k = 0; k < n; ++k) rank += (__builtin_amdgcn_readlane(mine, k) < mine) ? 1u : 0u;
-                } else {
+                {
                     uint32_t k = 0;
                     for (; k + 8u <= total; k += 8u) { // eight independent LDS reads in flight
                         int v8[8];
@@ -353,6 +430,10 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
                 t.cursor[slot] = total;
                 t.seg_off[slot] = fixed_base;
             }
+            RM_STAMP(6); // ordered and written
+#ifdef RM_STAMPS
+            if (threadIdx.x == 0) stamps[14] = __builtin_amdgcn_s_memrealtime();
+#endif
             break;
         }
         // more links than the segment holds: room behind the fixed segments, then the candidates once more

@@ -436,6 +436,7 @@ public:
                   std::vector<int32_t> &channel)
     {
         rssi.resize(nodes.size()); receiving.resize(nodes.size()); channel.resize(nodes.size());
+        if (simulator && !sync(simulator, simulator->getNodes())) return false; // the device mirrors the node table first
         if (rm_node_info(ctx_, nodes.data(), int32_t(nodes.size()), rssi.data(), receiving.data(), channel.data()) != RM_OK) {
             lastError = rm_last_error();
             return false;
