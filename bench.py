@@ -24,10 +24,11 @@ N > 1: receivers are range-partitioned over the ranks; per batch each rank packs
 the transmitters it owns for all ticks of the batch, the ranks all-gather them over RCCL/xGMI (ONE
 collective per batch, on the context's own stream and process group; the other context's sweep runs
 under it) and every rank sweeps the gathered frames against its receivers.  Default scaling is
-WEAK: the link evaluations per GPU and tick stay those of the 1-GPU config (T x N_loc = 1e8), i.e.
-the node count grows as 100k x sqrt(N) at constant density and Tx fraction (`--scaling strong`
-splits the 100k nodes instead; `--as-rank R:W` runs one rank's share of a W-GPU run on one GPU,
-without the collective).  Rank 0 prints ONE JSON line.
+STRONG: the BASELINE config itself (100k nodes for configs[2]; `--workload c4` for the 8-GPU config),
+its receivers split over the ranks.  `--scaling weak` grows the node count as 100k x sqrt(N) at constant
+density and Tx fraction instead, so that the link evaluations per GPU and tick stay those of the 1-GPU
+config; `--as-rank R:W` runs one rank's share of a W-GPU weak-scaling run on one GPU, without the
+collective.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -88,9 +89,12 @@ def parse():
                     help="one process, no collective: sweep the weak-scaling workload of W ranks against the receiver "
                          "range of rank R only (what one GPU of a W-GPU run computes per tick)")
     ap.add_argument("--nodes", type=int, default=0, help="override the workload's node count (same density and Tx fraction)")
+    ap.add_argument("--no-host-transfer", action="store_true", help="skip the PCIe-inclusive legs (with_host_transfer)")
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="several GPUs: strong (default) = the BASELINE config itself, receivers split over the ranks; "
+                         "weak = node count grown as sqrt(GPUs) so that the link evaluations per GPU stay fixed")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the pipelined multi-GPU tick driver even on one GPU (testing)")
     ap.add_argument("--profile-every", type=int, default=16,
@@ -195,10 +199,118 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=384, 
         e.close()
     return {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "ticks_in_flight": inflight * batch,
             "ticks_per_launch": batch, "contexts": inflight,
-            "value": t_per_tick * (n - 1) / per_tick, "unit": "links/s", "ms_per_step": per_tick * 1e3,
-            "algorithmic_bytes_per_tick": b_tick, "dominant_kernel": dominant, "stages_avg_us": stages,
-            "hbm_frac_dominant_kernel": b_tick * batch / (stages[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "value": t_per_tick * (n - 1) / per_tick, "unit": "links/s", "ms_per_tick": per_tick * 1e3,
+            "ms_per_step": per_tick * batch * 1e3,
+            "algorithmic_bytes_per_tick": b_tick, "dominant_kernel": dominant, "stages_avg_us_per_launch": stages,
             "hbm_frac_whole_tick": b_tick / per_tick / 1e9 / HBM_PEAK_GBS, "dropped": bool(dropped)}
+
+
+def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick, tick_us, src_dev, pool, batch):
+    """The same ticks with the data crossing PCIe, driver-timed like everything else in this file (SURVEY.md 8(d):
+    "report separately with/without host<->device transfers"; never the headline `value`):
+      tick_flush_view    the closed loop a JNI tick mode sees: records in (rm_enqueue_tx_records), ONE evaluation, the
+                         heard links read in place from the context's pinned block (rm_tick_flush_view)
+      tick_events        the same loop with the reception stage on the device: nothing but the drain's deliveries
+                         crosses the link (rm_tick_run + rm_events_process)
+      batch_result_view  `batch` ticks per launch sequence, all their records brought to the host in one packing launch"""
+    import ctypes as C
+    out = {}
+    recs = []
+    for s in sources[:16]:
+        r = np.zeros(len(s), dtype=rsa.TX_RECORD_DTYPE)
+        r["x"], r["y"], r["z"] = nodes.x[s], nodes.y[s], nodes.z[s]
+        r["txpower"], r["txprob"], r["channel"] = nodes.txpower[s], nodes.txprob[s], nodes.channel[s]
+        r["src"], r["air_us"] = s, W.AIR_US
+        recs.append(r)
+    links_per_tick = t_per_tick * (n - 1)
+
+    def flush_loop(k0, k1):
+        got = 0
+        for k in range(k0, k1):
+            eng.tick_begin(k * tick_us, (k + 1) * tick_us)
+            eng.enqueue_records(recs[k % len(recs)])
+            got += eng.tick_flush_view().count
+        return got
+    with torch.cuda.stream(stream):
+        flush_loop(0, 16)
+        reps = 200
+        t0 = time.perf_counter()
+        got = flush_loop(16, 16 + reps)
+        el = time.perf_counter() - t0
+    out["tick_flush_view"] = {"us_per_tick": el / reps * 1e6, "value": links_per_tick * reps / el, "unit": "links/s",
+                              "bytes_out_per_tick": got / reps * 17, "bytes_in_per_tick": t_per_tick * 64}
+    # the reception stage on: frames of 8128 us over 1000 us ticks, ~9 ticks of packets pending at any time
+    with torch.cuda.stream(stream):
+        eng.events_enable(1 << 16, 1 << 21)
+        eng.set_time(0)
+
+        def ev_loop(k0, k1):
+            got = 0
+            for k in range(k0, k1):
+                eng.tick_run_sources_device(k * tick_us, (k + 1) * tick_us, src_dev[k % pool].data_ptr(), t_per_tick, k * tick_us, W.AIR_US)
+                got += len(eng.events_process((k + 1) * tick_us)[0])
+            return got
+        ev_loop(0, 24)
+        t0 = time.perf_counter()
+        got = ev_loop(24, 24 + reps)
+        el = time.perf_counter() - t0
+        eng.events_disable()
+    out["tick_events"] = {"us_per_tick": el / reps * 1e6, "value": links_per_tick * reps / el, "unit": "links/s",
+                          "deliveries_per_tick": got / reps, "bytes_out_per_tick": got / reps * 20,
+                          "what": "rm_tick_run_sources_device + rm_events_process per tick: Simulator.generate*Events, "
+                                  "processAllEvents and the Transciever state on the device, the deliveries on the host"}
+    if batch > 1:
+        nb = min(batch, pool)
+        t_b = np.arange(nb, dtype=np.int64) * tick_us
+        ptrs = np.array([src_dev[k].data_ptr() for k in range(nb)], dtype=np.uint64)
+        cnt = np.full(nb, t_per_tick, dtype=np.int32)
+        air = np.full(nb, W.AIR_US, dtype=np.int64)
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                eng.batch_run_sources_device(t_b, t_b + tick_us, ptrs, cnt, t_b, air)
+                views, _ = eng.batch_result_view(nb)
+            reps_b = 8
+            t0 = time.perf_counter()
+            for _ in range(reps_b):
+                eng.batch_run_sources_device(t_b, t_b + tick_us, ptrs, cnt, t_b, air)
+                views, _ = eng.batch_result_view(nb)
+            el = time.perf_counter() - t0
+        links = sum(v.count for v in views)
+        out["batch_result_view"] = {"us_per_tick": el / (reps_b * nb) * 1e6, "value": links_per_tick * reps_b * nb / el,
+                                    "unit": "links/s", "ticks_per_launch": nb, "bytes_out_per_tick": links / nb * 17}
+    return out
+
+
+def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=12):
+    """A layout the spatial cull cannot help: 20k nodes inside one transmission range (the reference UDGM medium with
+    range >= the square's diagonal), every frame heard by every node -- the rate when ALL T x (N-1) links are
+    evaluated exactly and 4 M records per tick are ordered and written.  One tick at a time."""
+    nodes = W.make_nodes(n, 3)
+    side = W.side_length(n)
+    e = rsa.Engine(device_ordinal)
+    st = torch.cuda.Stream(device=dev)
+    e.set_stream(st.cuda_stream)
+    e.upload_table(nodes)
+    e.set_model(rsa.MODEL_UDGM, udgm_transmission_range=float(side * 1.5))
+    e.set_link_capacity(1 << 24)
+    srcs = [W.choose_sources(n, t, 0xC0FFEE0D, k) for k in range(4)]
+    with torch.cuda.stream(st):
+        src_dev = torch.from_numpy(np.stack(srcs)).to(dev)
+        st.synchronize()
+        for k in range(2):
+            e.tick_run_sources_device(k * 1000, k * 1000 + 1000, src_dev[k % 4].data_ptr(), t, k * 1000, W.AIR_US)
+        heard, dropped = e.result_count()
+        st.synchronize()
+        t0 = time.perf_counter()
+        for k in range(ticks):
+            e.tick_run_sources_device(k * 1000, k * 1000 + 1000, src_dev[k % 4].data_ptr(), t, k * 1000, W.AIR_US)
+        heard, dropped = e.result_count()       # includes ordering the last tick's records into the compact arrays
+        st.synchronize()
+        el = time.perf_counter() - t0
+    e.close()
+    return {"workload": "20k nodes, 200 frames per tick, reference UDGM with everyone in range (nothing to cull)", "nodes": n,
+            "tx_per_tick": t, "heard_links_per_tick": int(heard), "ms_per_tick": el / ticks * 1e3,
+            "value": t * (n - 1) / (el / ticks), "unit": "links/s", "dropped": bool(dropped)}
 
 
 def main():
@@ -237,7 +349,11 @@ def main():
     if world > 1 or (args.force_sharded and os.environ.get("RM_DIST_SINGLE") == "1"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:      # the launcher (torchrun) normally supplies it; a one-rank rehearsal picks a free one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -436,18 +552,31 @@ def main():
         fence()
         el = time.perf_counter() - t_seq
         sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
-                      "ms_per_tick": el / seq_ticks * 1e3}
+                      "ms_per_tick": el / seq_ticks * 1e3,
+                      "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
+                              "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
 
     if rank == 0:
-        # Roofline of the dominant kernel on this rank.  Per-stage durations
-        # come from HIP events recorded on the engine's stream around every stage of each
-        # `profile_every`-th tick of the timed region; the dominant kernel is the stage with the
-        # largest share.  Algorithmic bytes per launch = N_loc*37 + T_act*56 + H_loc*25.
+        # Roofline.  Per-stage durations come from HIP events recorded on the engine's
+        # stream around every stage of each `profile_every`-th launch of the timed region.  Every stage is priced
+        # with ITS OWN algorithmic bytes:
+        #   filter   N_loc*16 (pre-filter records) + T*28 (frame pre-filter records) + cand*12 (candidate entries written)
+        #   exact    cand*(12 + 32) (entries + 32-byte receiver records) + H*13 (staged link records written)
+        #   reorder  H*13 read + H*17 written (pkt 4, dst 4, rssi 8, verdict 1)
+        # The dominant stage's bound is named for what binds it: vector issue slots for these integer / fp32 / fp64
+        # sweeps (PMC: profiles/pmc_traffic.json), its HBM fraction is reported next to it; the HBM figure of the
+        # whole step is section 8(d)'s bytes (N_loc*37 + T*56 + H*25 per tick) over the DRIVER-timed ms_per_step.
         n_loc = hi - lo
         h_loc = heard
-        # per launch: the ticks it sweeps (`batch`, fewer when the K steps do not fill the launches)
         ticks_per_launch = batch
-        b_tick = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
+        try:
+            cand, _ = (last_run[0].slot_stats(last_run[1]) if batch > 1 else eng.slot_stats(0))
+        except Exception:
+            cand = 0
+        b_step = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
+        stage_bytes = {"k_filter": (n_loc * 16 + t_per_tick * 28 + cand * 12) * ticks_per_launch,
+                       "k_exact": (cand * 44 + h_loc * 13) * ticks_per_launch,
+                       "k_reorder": (h_loc * 30) * ticks_per_launch}
         raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
         # an event pair with nothing between it measures the bracketing itself (a few us on this
         # runtime): subtracted from every stage so that the durations are the kernels'
@@ -455,10 +584,17 @@ def main():
         per_stage_us = {k: max(v - bracket_us, 0.0) for k, v in raw_us.items()}
         dominant = max(per_stage_us, key=per_stage_us.get) if per_stage_us else "k_filter"
         kern_avg_s = per_stage_us.get(dominant, 0.0) * 1e-6
-        pass_s = sum(per_stage_us.values()) * 1e-6
-        achieved = b_tick / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
+        stages = {}
+        for k, us in per_stage_us.items():
+            b = stage_bytes.get(k)
+            stages[k] = {"us": us, "algorithmic_bytes": b,
+                         "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
+                         "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
+        dom_bytes = stage_bytes.get(dominant, b_step)
+        achieved = dom_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
         traffic = None
         valu = None
+        bound = "hbm"
         pmc_note = "no PMC pass on file for this workload"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -466,16 +602,19 @@ def main():
             ent = wl.get(dominant)
             if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
                 traffic = ent["hbm_bytes_per_launch"]
-                pmc_note = ent["source"]
+                pmc_note = ent["source"] + " (commit %s)" % wl.get("commit", "unrecorded")
                 if "valu_issue_us_per_launch" in ent and kern_avg_s > 0:
-                    # SURVEY.md section 8(d) asks for the vector-ALU side next to the HBM side: issue time of the
-                    # stage's vector instructions on the whole chip (PMC, one context) over the stage's duration here
-                    valu = {"issue_us_per_launch": ent["valu_issue_us_per_launch"],
-                            "share_of_kernel_time": ent["valu_issue_us_per_launch"] / (kern_avg_s * 1e6),
+                    # vector-issue time of the stage's instructions on the whole chip (PMC, one context) over the
+                    # stage's duration here: the binding resource of the sweep
+                    share = ent["valu_issue_us_per_launch"] / (kern_avg_s * 1e6)
+                    valu = {"issue_us_per_launch": ent["valu_issue_us_per_launch"], "frac": share,
                             "instructions_per_launch": ent.get("valu_instructions_per_launch"),
                             "source": "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU pass of tools/collect_profiles.sh (profiles/pmc_traffic.json)"}
+                    if share > achieved / HBM_PEAK_GBS:
+                        bound = "valu"
         except (OSError, ValueError):
             pass
+        step_s = elapsed / args.steps
         out = {
             "metric": baseline_metric(),
             "value": value,
@@ -483,36 +622,41 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "ms_per_tick": elapsed / timed_ticks * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
+            "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight * batch,
                        "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
                        "step": "one launch sequence sweeping ticks_per_step simulated ticks",
-                       "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total,
-                       "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per tick, "
-                                    "overlapped with the previous tick's sweep" % world) if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
+                       "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per batch of ticks"
+                                    % world) if world > 1 else "none"},
+            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (valu["frac"] if (bound == "valu" and valu) else achieved / HBM_PEAK_GBS),
+                         "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
-                         "algorithmic_bytes_per_launch": b_tick, "traffic_source": pmc_note,
-                         "stages_avg_us": per_stage_us, "event_bracket_us": bracket_us, "valu": valu,
-                         "whole_pass": {"gpu_us": pass_s * 1e6,
-                                        "achieved": b_tick / pass_s / 1e9 if pass_s > 0 else 0.0,
-                                        "frac": (b_tick / pass_s / 1e9 / HBM_PEAK_GBS) if pass_s > 0 else 0.0},
-                         "note": "one launch sweeps `ticks_per_launch` ticks; durations are HIP-event brackets on the "
-                                 "context's stream while the other contexts' launches share the device; the sweep is "
-                                 "integer/fp32 VALU work, its HBM traffic is far below the HBM roofline by construction "
-                                 "(DESIGN.md section 5, profiles/README.md)"},
+                         "algorithmic_bytes_per_launch": dom_bytes, "traffic_source": pmc_note,
+                         "stages": stages, "event_bracket_us": bracket_us, "valu": valu,
+                         "whole_step": {"algorithmic_bytes": b_step, "ms_per_step": step_s * 1e3,
+                                        "achieved": b_step / step_s / 1e9, "frac": b_step / step_s / 1e9 / HBM_PEAK_GBS,
+                                        "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step"},
+                         "note": "`frac` is the fraction of the BINDING resource: with bound = valu the share of the dominant "
+                                 "kernel's time its vector instructions need to issue (hbm_frac: the same kernel's own "
+                                 "algorithmic bytes against 8 TB/s); one launch sweeps `ticks_per_launch` ticks; durations are "
+                                 "HIP-event brackets on the context's stream while the other contexts' launches share the device"},
         }
         if sequential is not None:
             out["sequential_ticks"] = sequential
+        if world == 1 and not stateful and not as_rank and not args.no_host_transfer:
+            out["with_host_transfer"] = host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick, tick_us,
+                                                           src_dev, pool, batch)
         if world == 1 and args.workload == "c3" and not args.no_scale_probe:
             out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch)
+            out["dense_layout"] = dense_probe(rsa, W, torch, dev, device_ordinal)
         if world == 1 and not args.no_cpu_baseline:
             st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
             out["cpu_baseline"] = st

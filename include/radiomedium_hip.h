@@ -295,6 +295,9 @@ int rm_profile_enable(rm_context *ctx, int every_n);
 int rm_profile_read(rm_context *ctx, uint32_t *samples, double *stage_ms /* [RM_PROFILE_STAGES] */);
 /* number of Tx->Rx link evaluations resolved by the last tick ( T * (N_loc) minus self links ) */
 int64_t rm_last_link_evaluations(const rm_context *ctx);
+/* observability (synchronises): the candidate links the sweep's conservative filter handed to the exact stage for the
+ * tick of result slot `slot` (0 on the one-launch tick path, which keeps no candidate list) and its heard links */
+int rm_slot_stats(rm_context *ctx, int32_t slot, uint64_t *candidates, uint64_t *heard);
 
 /* ---- reception stage: what the reference does with the verdicts, on the device -------------------------
  * SURVEY.md section 8f-1 / 8f-3.  After rm_events_enable every evaluated tick (rm_transmit, rm_tick_flush*,

@@ -152,6 +152,7 @@ SIGNATURES = {
     "rm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
     "rm_last_link_evaluations": (C.c_int64, [C.c_void_p]),
+    "rm_slot_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_events_enable": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rm_events_disable": (C.c_int, [C.c_void_p]),
     "rm_events_next_packet": (C.c_int64, [C.c_void_p]),

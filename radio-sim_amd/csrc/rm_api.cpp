@@ -974,7 +974,9 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
             RM_HIP(rm::launch_tick_frames(s, nd, m, t, cfg, seg_len));
             if (stochastic) {
                 RM_TRY(stage(RM_STAGE_REORDER));
-                RM_HIP(rm::launch_reorder(s, m, t, cfg));
+                rm::TickDev tr = t;
+                tr.seg_ordered = 1;
+                RM_HIP(rm::launch_reorder(s, m, tr, cfg));
                 RM_TRY(stage(RM_STAGE_DRAWS));
                 RM_HIP(rm::launch_draws_scan(s, t));
                 if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
@@ -1065,6 +1067,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         ts.pending_model = m;
     }
     ts.compact_pending = seg_len > 0 && !stochastic;
+    ts.last.seg_ordered = (seg_len > 0) ? 1 : 0;
     ts.last_model = m;
     ts.last_cfg = cfg;
     ts.have_result = true;
@@ -2577,6 +2580,26 @@ int rm_profile_read(rm_context *c, uint32_t *samples, double *stage_ms)
 }
 
 int64_t rm_last_link_evaluations(const rm_context *c) { return c ? c->last_links : 0; }
+
+int rm_slot_stats(rm_context *c, int32_t slot, uint64_t *candidates, uint64_t *heard)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts || !ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick in this result slot");
+    RM_HIP(hipSetDevice(c->device));
+    uint32_t count = 0, dropped = 0;
+    RM_TRY(result_count(c, *ts, &count, &dropped));
+    if (heard) *heard = count;
+    if (candidates) {
+        std::vector<uint32_t> sh(size_t(rm::kShards) * rm::kShardStride);
+        RM_HIP(hipMemcpyAsync(sh.data(), ts->last.shard_count, sh.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+        uint64_t sum = 0;
+        for (int k = 0; k < rm::kShards; ++k) sum += sh[size_t(k) * rm::kShardStride];
+        *candidates = sum;
+    }
+    return RM_OK;
+}
 
 uint64_t rm_lcg_jump(uint64_t state48, uint64_t steps)
 {

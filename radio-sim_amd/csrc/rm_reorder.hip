@@ -81,7 +81,9 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 in_e = (SINR && valid) ? t.a_e[o] : 0;
             }
             uint32_t rank = 0;
-            if (len <= 64) {
+            if (t.seg_ordered) {
+                rank = c0 + lane;
+            } else if (len <= 64) {
                 for (uint32_t i = 0; i < len; ++i) rank += (__builtin_amdgcn_readlane(mine, int(i)) < mine) ? 1u : 0u;
             } else if (valid) {
                 for (uint32_t k = 0; k < len; ++k) rank += (t.a_dst[src0 + k] < mine) ? 1u : 0u;

@@ -390,5 +390,11 @@ class Engine:
         check(self._L.rm_profile_read(self._h, C.byref(n), ms))
         return n.value, {name: ms[i] for i, name in enumerate(self.STAGES)}
 
+    def slot_stats(self, slot=0):
+        """(candidate links of the sweep's filter, heard links) of result slot `slot`; synchronises"""
+        cand, heard = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.rm_slot_stats(self._h, slot, C.byref(cand), C.byref(heard)))
+        return cand.value, heard.value
+
     def last_link_evaluations(self):
         return self._L.rm_last_link_evaluations(self._h)

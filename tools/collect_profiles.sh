@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round evidence, run on the GPU box from the repository root:  bash tools/collect_profiles.sh
-# Writes under gpurun_out/r01/; the summaries to be judged are then copied into profiles/.
+# Round evidence, run on the GPU box from the repository root:  RM_COMMIT=<commit> ROUND=r02 bash tools/collect_profiles.sh
+# Writes under gpurun_out/$ROUND/; the summaries to be judged are then copied into profiles/.
 set -e -o pipefail
 R=$PWD
-O=$R/gpurun_out/r01
+ROUND=${ROUND:-r02}
+O=$R/gpurun_out/$ROUND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
@@ -21,10 +22,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/m1_fetch -- 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/m1_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3 > $O/m1_write.log 2>&1
 echo "m1 done"
 cd $R
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/r01_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
-python tools/pmc_traffic.py $O/m1_fetch $O/m1_write m1 16 $O/r01_m1_pmc.csv $O/pmc_traffic.json
-cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/r01_c3_kernel_stats.csv
-cp $(find $O/stats_seq -name "*kernel_stats.csv" | head -1) $O/r01_c3_sequential_kernel_stats.csv
-cp $(find $O/m1_stats -name "*kernel_stats.csv" | head -1) $O/r01_m1_kernel_stats.csv
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/${ROUND}_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
+python tools/pmc_traffic.py $O/m1_fetch $O/m1_write m1 16 $O/${ROUND}_m1_pmc.csv $O/pmc_traffic.json
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_kernel_stats.csv
+cp $(find $O/stats_seq -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_sequential_kernel_stats.csv
+cp $(find $O/m1_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_m1_kernel_stats.csv
+for f in $O/${ROUND}_c3_kernel_stats.csv $O/${ROUND}_c3_sequential_kernel_stats.csv $O/${ROUND}_m1_kernel_stats.csv; do echo "# commit ${RM_COMMIT:-unrecorded}" >> $f; done
 rm -rf $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/m1_stats $O/m1_fetch $O/m1_write
 echo "all done"

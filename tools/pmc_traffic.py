@@ -3,6 +3,8 @@ pass -- TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2, MI355X_MICROARCH.m
 
     python tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ticks_per_launch> <out_csv> <out_json> [<sq_dir>]
 
+RM_COMMIT=<id> stamps the commit the counters were collected for into the JSON (the GPU box has no .git).
+
 <sq_dir>: a third pass with --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY: the stages' vector
 issue time.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md), so
 issue time on the whole chip = 4 * count / 1024 SIMDs / 2.4 GHz (tools/clockprobe.hip: 2.4 GHz held).
@@ -18,7 +20,7 @@ import json
 import os
 import sys
 
-STAGE = (("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
+STAGE = (("k_tick_frames", "k_tick_frames"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
          ("k_reorder", "k_reorder"), ("k_self_entries", "k_self_entries"), ("k_sinr", "k_sinr"),
          ("k_cell_off", "k_cell_off+k_slot_scan"), ("k_slot_scan", "k_cell_off+k_slot_scan"), ("k_finalize", "k_finalize"))
 
@@ -76,7 +78,7 @@ def main():
     src = ("%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --inflight 1, %s ticks per "
            "launch), (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads half of a wide "
            "coalesced stream)" % (os.path.relpath(out_csv), tpl))
-    out[workload] = {"ticks_per_launch": int(tpl)}
+    out[workload] = {"ticks_per_launch": int(tpl), "commit": os.environ.get("RM_COMMIT", "unrecorded")}
     for stage, (f, w) in stages.items():
         out[workload][stage] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_size_kb_raw": round(f, 1),
                                 "write_size_kb": round(w, 1), "source": src}
