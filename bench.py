@@ -248,7 +248,7 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
             got = 0
             for k in range(k0, k1):
                 eng.tick_run_sources_device(k * tick_us, (k + 1) * tick_us, src_dev[k % pool].data_ptr(), t_per_tick, k * tick_us, W.AIR_US)
-                got += len(eng.events_process((k + 1) * tick_us)[0])
+                got += len(eng.events_process((k + 1) * tick_us, copy=False)[0])   # read in place, as rm_tick_flush_view's records
             return got
         ev_loop(0, 24)
         t0 = time.perf_counter()

@@ -195,7 +195,8 @@ struct rm_context : TickSlot {
         int info_n = 0;
         uint32_t seq = 0, info_seq = 0;
         DevBuf<int32_t> d_info_nodes;
-        int64_t next_packet = 0;  // host mirror of EvState::gseq_next
+        int64_t next_packet = 0;  // host mirror of EvTails::gseq_next
+        int par = 0;              // which EvState::tails are current (flips with every appended tick)
     } ev;
     DevBuf<uint8_t> d_enabled;   // Transciever.isEnabled by node index
 
@@ -1109,6 +1110,7 @@ rm::EvDev ev_dev(rm_context *c)
     e.n_nodes = v.state_n;
     e.own_first = part_first(c);
     e.own_count = part_count(c);
+    e.par = v.par;
     return e;
 }
 
@@ -1166,6 +1168,7 @@ int ev_append(rm_context *c, TickSlot &ts)
     }
     const int immediate = (c->params.kind == RM_MODEL_UDGM_CONST) ? 1 : 0;
     RM_HIP(rm::launch_ev_append(c->stream, ev_dev(c), ls, t.tx + t.first_new, ts.last_n_new, c->current_time, immediate, dropped));
+    c->ev.par ^= 1; // the launch wrote the other set of tails
     c->ev.next_packet += ts.last_n_new;
     return RM_OK;
 }
@@ -2438,13 +2441,16 @@ int rm_events_enable(rm_context *c, uint32_t max_pending_packets, uint32_t max_p
     RM_HIP(v.d_off.ensure(v.g_cap));
     rm::EvState st{};
     st.top_max = int64_t(0x8000000000000000ull); // the top list is empty
+    st.first_live = 0xFFFFFFFFu;
     RM_HIP(hipMemcpyAsync(v.d_st.p, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
     RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&v.h_out), ev_out_bytes(v.pool_cap), hipHostMallocMapped));
+
     std::memset(v.h_out, 0, pad64(sizeof(rm::EvHeader)));
     v.seq = 0;
     v.on = true;
     v.next_packet = 0;
+    v.par = 0;
     RM_TRY(ev_ensure_nodes(c));
     return RM_OK;
 }

@@ -259,22 +259,34 @@ struct alignas(64) EvPacket {
     int32_t src;
     int32_t lad0, lad1;  // ladder of its start / end events (rm_evorder.hpp)
     uint32_t flags;      // kEvStartDone | kEvDone | kEvImmediate | kEvNoTx
-    uint32_t pad[4];
+    uint32_t n_deliver;  // heard links with a delivery-mode end flank
+    uint32_t pad[3];
 };
 constexpr uint32_t kEvStartDone = 1, kEvDone = 2, kEvImmediate = 4, kEvNoTx = 8;
 enum { kEvRxStart = 0, kEvRxEnd = 1, kEvTxStart = 2, kEvTxEnd = 3 };
 
+// The ring tails move with every appended tick.  They are kept twice: an append reads the set `par` (a kernel
+// argument) and ONE thread writes the other one at its end -- no workgroup of the launch reads what another
+// writes, so the launch needs no hand-off; the next launch is told the other parity.
+struct EvTails {
+    int64_t gseq_next;
+    uint32_t pk_tail, pool_tail; // monotone counters
+    uint32_t err;                // sticky: 1 packet ring full, 2 link pool full, 8 a tick was dropped for capacity
+    uint32_t pad;
+};
 struct EvState {
     int64_t top_start, top_max; // rm_evorder.hpp (top_max == INT64_MIN: the top list is empty)
     int64_t t_prev;             // time of the last drain
-    int64_t gseq_next;
     int32_t ladders, pad0;
-    uint32_t pk_head, pk_tail, pool_head, pool_tail; // monotone counters
+    uint32_t pk_head, pool_head; // monotone counters
     uint32_t n_groups;          // fired (packet, phase) groups of the running drain
     uint32_t n_deliv;
-    uint32_t err;               // sticky: 1 packet ring full, 2 link pool full, 4 group list full, 8 a tick was dropped for capacity
-    uint32_t done_a, done_b;    // "last workgroup" counters
-    uint32_t pad1[3];
+    uint32_t err;               // sticky: 4 group list full
+    uint32_t done_a;            // "last workgroup" counter (node-info)
+    uint32_t pad1[2];
+    EvTails tails[2];
+    // (its own 128-byte line: k_ev_select's workgroups add to n_groups and take minima here at the same time)
+    alignas(128) uint32_t first_live; // window index of the oldest packet with events still queued (0xFFFFFFFF: none)
 };
 
 struct EvDev {
@@ -295,6 +307,7 @@ struct EvDev {
     double *latched;                         // [n] Transciever.receivingRSSI
     int n_nodes;
     int own_first, own_count;                // nodes whose Tx / Rx events this context keeps (receiver partition)
+    int par;                                 // which EvState::tails are current
 };
 
 // a tick's heard links, packet by packet: the frames' segments (rm_tick.hip) or the compact arrays

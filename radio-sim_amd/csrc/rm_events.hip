@@ -48,10 +48,11 @@ k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ 
 {
     __shared__ uint32_t s_off[SEG ? kFusedScanMax + 1 : 1];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_last;
+    __shared__ int64_t s_top[4];
     EvState &st = *e.st;
-    const uint32_t pk_head = st.pk_head, pk_tail = st.pk_tail, pool_head = st.pool_head, pool_tail = st.pool_tail;
-    const int64_t gseq0 = st.gseq_next;
+    const EvTails tl = st.tails[e.par];
+    const uint32_t pk_head = st.pk_head, pk_tail = tl.pk_tail, pool_head = st.pool_head, pool_tail = tl.pool_tail;
+    const int64_t gseq0 = tl.gseq_next;
     EvOrder ord;
     ord.top_start = st.top_start;
     ord.ladders = st.ladders;
@@ -65,17 +66,26 @@ k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ 
     if (pk_tail - pk_head + uint32_t(n_new) > e.pk_mask + 1u) err |= 1u;
     if (pool_tail - pool_head + total > e.pool_mask + 1u) err |= 2u;
     const int lane = threadIdx.x & 63;
+    int64_t wave_top = kI64Min; // latest event of this wave's packets that waits in the queue's top list
     if (!err) {
         for (int q = blockIdx.x * 4 + wave_index(); q < n_new; q += gridDim.x * 4) { // wave-uniform
             const rm_tx_record r = tx[q];
             const uint32_t cnt = uniform_u(SEG ? ls.cnt[q] : (ls.off[q + 1] - ls.off[q]));
             const uint32_t src0 = uniform_u(ls.off[q]);
             const uint32_t dst0 = pool_tail + uniform_u(SEG ? s_off[q] : ls.off[q]);
-            for (uint32_t j = lane; j < cnt; j += 64) {
-                const uint32_t o = (dst0 + j) & e.pool_mask;
-                e.l_dst[o] = ls.dst[src0 + j];
-                e.l_rssi[o] = ls.rssi[src0 + j];
-                e.l_verdict[o] = ls.verdict[src0 + j];
+            uint32_t n_deliver = 0;
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 64) { // wave-uniform
+                const uint32_t j = j0 + lane;
+                bool deliver = false;
+                if (j < cnt) {
+                    const uint32_t o = (dst0 + j) & e.pool_mask;
+                    const uint8_t v = ls.verdict[src0 + j];
+                    e.l_dst[o] = ls.dst[src0 + j];
+                    e.l_rssi[o] = ls.rssi[src0 + j];
+                    e.l_verdict[o] = v;
+                    deliver = v == RM_DELIVERED;
+                }
+                n_deliver += uint32_t(__popcll(ballot64(deliver)));
             }
             if (lane == 0) {
                 EvPacket p;
@@ -93,29 +103,36 @@ k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ 
                 if (immediate) p.flags |= kEvImmediate | kEvNoTx;          // UDGMConstantLossRadioMedium.java:30: no events at all
                 else if (r.src < 0 || !owned(e, r.src)) p.flags |= kEvNoTx; // the source's Transciever lives on another rank
                 if (r.src < 0) p.flags |= kEvStartDone | kEvDone;           // a padding record is no packet
-                p.pad[0] = p.pad[1] = p.pad[2] = p.pad[3] = 0u;
+                p.n_deliver = n_deliver;
+                p.pad[0] = p.pad[1] = p.pad[2] = 0u;
                 e.pk[(pk_tail + uint32_t(q)) & e.pk_mask] = p;
                 // every packet's transmission events sit in the reference's (one, global) queue, whoever owns the source
                 if (!immediate && r.src >= 0) {
-                    if (p.t0 >= ord.top_start) amax_i64(&st.top_max, p.t0);
-                    if (p.t1 >= ord.top_start) amax_i64(&st.top_max, p.t1);
+                    if (p.t0 >= ord.top_start && p.t0 > wave_top) wave_top = p.t0;
+                    if (p.t1 >= ord.top_start && p.t1 > wave_top) wave_top = p.t1;
                 }
             }
         }
     }
-    __threadfence();
+    // one atomic per workgroup (a single word takes ~88 atomics per microsecond: one per packet would cost more
+    // than everything else in this kernel)
+    if (lane == 0) s_top[wave_index()] = wave_top;
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&st.done_a, 1u) == gridDim.x - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        st.done_a = 0u;
-        if (err) {
-            st.err |= err;
-        } else {
-            st.pk_tail = pk_tail + uint32_t(n_new);
-            st.pool_tail = pool_tail + total;
+    if (threadIdx.x == 0) {
+        int64_t m4 = s_top[0];
+        for (int w = 1; w < 4; ++w) m4 = s_top[w] > m4 ? s_top[w] : m4;
+        if (m4 != kI64Min) amax_i64(&st.top_max, m4);
+    }
+    // the tails after this tick, for the next launch (see EvTails): every workgroup computed the same values
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        EvTails nt = tl;
+        nt.err = tl.err | err;
+        if (!err) {
+            nt.pk_tail = pk_tail + uint32_t(n_new);
+            nt.pool_tail = pool_tail + total;
         }
-        st.gseq_next = gseq0 + n_new; // the packets were transmitted, kept or not
+        nt.gseq_next = gseq0 + n_new; // the packets were transmitted, kept or not
+        st.tails[e.par ^ 1] = nt;
     }
 }
 
@@ -126,16 +143,28 @@ RM_D uint64_t ev_meta(uint32_t lad_rel, uint32_t order, uint32_t phase) { return
 __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
 {
     EvState &st = *e.st;
-    const uint32_t head = st.pk_head, w = st.pk_tail - head;
+    const uint32_t head = st.pk_head, w = st.tails[e.par].pk_tail - head;
     const int lane = threadIdx.x & 63;
     if (blockIdx.x * blockDim.x >= ((w + 63u) & ~63u)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2u * i + 1u < e.g_cap) e.g_rank[2u * i] = e.g_rank[2u * i + 1u] = 0u; // at most 2 w groups fire: k_ev_rank adds into these
     const uint32_t idx = (head + i) & e.pk_mask;
     EvPacket p{};
     bool valid = false;
     if (i < w) {
         p = e.pk[idx];
         valid = !(p.flags & kEvDone);
+    }
+    // the oldest packet with events still queued BEFORE this drain: k_ev_finish moves the ring heads up to it (the
+    // packets this drain finishes are passed over by the next one -- a window scan per drain costs more than it frees)
+    {
+        __shared__ uint32_t s_live;
+        if (threadIdx.x == 0) s_live = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint64_t live = ballot64(valid);
+        if (live && lane == 0) atomicMin(&s_live, (i & ~63u) + uint32_t(__ffsll((long long)live) - 1));
+        __syncthreads();
+        if (threadIdx.x == 0 && s_live != 0xFFFFFFFFu) atomicMin(&st.first_live, s_live); // one per workgroup
     }
     const int64_t gseq_head = e.pk[head & e.pk_mask].gseq;
     const uint32_t rel = uint32_t(p.gseq - gseq_head);
@@ -164,47 +193,51 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
                 e.g_meta[k] = ev_meta(uint32_t((ph ? p.lad0 : p.lad1) - lb), 0xFFFFFFFFu - rel, uint32_t(ph));
             }
             e.g_ref[k] = (idx << 1) | uint32_t(ph);
+            // a node that starts to send in this drain: reception starts on it must take part in the "sending"
+            // field's last-writer contest (k_ev_emit skips that for every other idle node)
+            if (ph && !(p.flags & kEvNoTx)) e.send_key[p.src] = 1ull;
         }
     }
 }
 
-// k_ev_rank: a group's rank = the number of groups with a smaller key (keys are unique); an end group
-// also counts its delivered links.
-constexpr int kEvTile = 1024;
+// k_ev_rank: a group's rank = the number of groups with a smaller key (keys are unique).  The G x G comparisons
+// are cut into tiles of 64 groups x 512 keys; the workgroups take the tiles in turn (the host does not know G).
+// Inside a tile every lane owns a group, the four waves each scan a quarter of the keys from LDS (eight reads
+// in flight) and add their partial counts to the group's rank.
+constexpr int kEvTile = 512;
 __global__ void __launch_bounds__(256) k_ev_rank(const EvDev e)
 {
     __shared__ int64_t s_time[kEvTile];
     __shared__ uint64_t s_meta[kEvTile];
     const uint32_t G = min(e.st->n_groups, e.g_cap);
-    if (blockIdx.x * blockDim.x >= G) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = i < G;
-    const int64_t ti = mine ? e.g_time[i] : 0;
-    const uint64_t mi = mine ? e.g_meta[i] : 0;
-    uint32_t rank = 0;
-    for (uint32_t k0 = 0; k0 < G; k0 += kEvTile) { // block-uniform
+    const uint32_t ni = (G + 63u) / 64u, nj = (G + uint32_t(kEvTile) - 1u) / uint32_t(kEvTile);
+    const int lane = threadIdx.x & 63, part = wave_index();
+    for (uint32_t tile = blockIdx.x; tile < ni * nj; tile += gridDim.x) { // block-uniform
+        const uint32_t i = (tile % ni) * 64u + uint32_t(lane), k0 = (tile / ni) * uint32_t(kEvTile);
+        const bool mine = i < G;
+        const int64_t ti = mine ? e.g_time[i] : 0;
+        const uint64_t mi = mine ? e.g_meta[i] : 0;
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < uint32_t(kEvTile) && k0 + k < G; k += blockDim.x) {
-            s_time[k] = e.g_time[k0 + k];
-            s_meta[k] = e.g_meta[k0 + k];
+        for (uint32_t k = threadIdx.x; k < uint32_t(kEvTile); k += blockDim.x) {
+            const bool ok = k0 + k < G;
+            s_time[k] = ok ? e.g_time[k0 + k] : int64_t(0x7FFFFFFFFFFFFFFFll); // padding keys are larger than every key
+            s_meta[k] = ok ? e.g_meta[k0 + k] : ~0ull;
         }
         __syncthreads();
-        const uint32_t nk = min(uint32_t(kEvTile), G - k0);
-        for (uint32_t k = 0; k < nk; ++k) {
-            const int64_t tk = s_time[k];
-            const uint64_t mk = s_meta[k];
-            rank += (tk < ti || (tk == ti && mk < mi)) ? 1u : 0u;
+        uint32_t rank = 0;
+        for (uint32_t k = uint32_t(part) * uint32_t(kEvTile / 4); k < uint32_t(part + 1) * uint32_t(kEvTile / 4); k += 8u) {
+            int64_t tk[8];
+            uint64_t mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                tk[u] = s_time[k + u];
+                mk[u] = s_meta[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (tk[u] < ti || (tk[u] == ti && mk[u] < mi)) ? 1u : 0u;
         }
+        if (mine && rank) atomicAdd(&e.g_rank[i], rank);
     }
-    if (!mine) return;
-    uint32_t cnt = 0;
-    const uint32_t ref = e.g_ref[i];
-    if ((ref & 1u) == 0u) { // end group
-        const EvPacket &p = e.pk[ref >> 1];
-        for (uint32_t j = 0; j < p.link_cnt; ++j) cnt += (e.l_verdict[(p.link_off + j) & e.pool_mask] == RM_DELIVERED) ? 1u : 0u;
-    }
-    e.g_rank[i] = rank;
-    e.cnt_by_rank[rank] = cnt;
 }
 
 // k_ev_scan: first delivery of every group, in rank order
@@ -212,6 +245,11 @@ __global__ void __launch_bounds__(1024) k_ev_scan(const EvDev e)
 {
     __shared__ uint32_t s_wave[16];
     const uint32_t G = min(e.st->n_groups, e.g_cap);
+    for (uint32_t g = threadIdx.x; g < G; g += 1024) { // an end group delivers its packet's delivery-mode links
+        const uint32_t ref = e.g_ref[g];
+        e.cnt_by_rank[e.g_rank[g]] = ((ref & 1u) == 0u) ? e.pk[ref >> 1].n_deliver : 0u;
+    }
+    __syncthreads();
     uint32_t carry = 0;
     for (uint32_t base = 0; base < G; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -245,7 +283,9 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out)
                 const unsigned long long k = ev_key(r, kEvRxStart, o);
                 const int d = e.l_dst[o];
                 amax_key(&e.recv_key[d], k);
-                amax_key(&e.send_key[d], k);
+                // clearSending only matters on a node that is sending or starts to in this drain (marked by k_ev_select)
+                if (e.sending[d] || __hip_atomic_load(&e.send_key[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)
+                    amax_key(&e.send_key[d], k);
             }
             // TransmissionEvent start: setSending = clearReceiving + sendingPacket (Transciever.java:106-109)
             if (lane == 0 && !(fl & kEvNoTx)) {
@@ -285,14 +325,10 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out)
     }
 }
 
-// k_ev_apply: the last writer of a field writes it (and clears its key); the groups' packets are marked; the
-// workgroup that finishes last moves the ring heads, runs the queue's ladder rule for this drain
-// (rm_evorder.hpp) and publishes the delivery list's header.
-__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out, int64_t T, uint32_t seq)
+// k_ev_apply: the last writer of a field writes it (and clears its key).
+__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e)
 {
-    __shared__ uint32_t s_last;
-    EvState &st = *e.st;
-    const uint32_t G = min(st.n_groups, e.g_cap);
+    const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
     for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
         const uint32_t ref = uniform_u(e.g_ref[g]);
@@ -349,59 +385,53 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out
             }
         }
     }
-    // the flags are read by every wave above (a packet's two groups may sit in different workgroups): set them
-    // only after all of them are done -- by the last workgroup
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&st.done_b, 1u) == gridDim.x - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
+}
+
+// k_ev_finish (one workgroup, after k_ev_apply): the fired groups' packets are marked, the ring heads move, the
+// queue's ladder rule for this drain (rm_evorder.hpp) is applied and the delivery list's header is published.
+__global__ void __launch_bounds__(1024) k_ev_finish(const EvDev e, const EvOut out, int64_t T, uint32_t seq)
+{
+    EvState &st = *e.st;
+    const uint32_t G = min(st.n_groups, e.g_cap);
+    const EvTails tl = st.tails[e.par];
+    const uint32_t head = st.pk_head, tail = tl.pk_tail;
     for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) {
         const uint32_t ref = e.g_ref[g];
         atomicOr(&e.pk[ref >> 1].flags, (ref & 1u) ? kEvStartDone : (kEvDone | kEvStartDone));
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    // ring heads: past every packet whose end has fired
-    uint32_t head = st.pk_head;
-    const uint32_t tail = st.pk_tail;
-    while (head != tail) { // wave-uniform
-        const uint32_t i = head + lane;
-        bool done = false;
-        if (int32_t(tail - i) > 0) done = (__hip_atomic_load(&e.pk[i & e.pk_mask].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kEvDone) != 0u;
-        const uint64_t keep = ~ballot64(done);
-        const uint32_t run = keep ? uint32_t(__ffsll((long long)keep) - 1) : 64u;
-        const uint32_t left = tail - head;
-        head += min(run, left);
-        if (run < 64u || left <= 64u) break;
-    }
-    if (lane == 0) {
-        st.pk_head = head;
-        st.pool_head = (head == tail) ? st.pool_tail : __hip_atomic_load(&e.pk[head & e.pk_mask].link_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        EvOrder o;
-        o.top_start = st.top_start;
-        o.top_max = st.top_max;
-        o.ladders = st.ladders;
-        o.top_nonempty = (st.top_max != kI64Min) ? 1 : 0;
-        ev_drain(o, T);
-        st.top_start = o.top_start;
-        st.ladders = o.ladders;
-        if (!o.top_nonempty) st.top_max = kI64Min;
-        st.t_prev = T;
-        const uint32_t total = st.n_deliv;
-        if (st.n_groups > e.g_cap) st.err |= 4u;
-        st.n_groups = 0u;
-        st.done_b = 0u;
-        out.hdr->count = min(total, out.cap);
-        out.hdr->total = total;
-        out.hdr->err = st.err;
-        out.hdr->pending_packets = tail - head;
-        out.hdr->next_packet = st.gseq_next;
-        out.hdr->time = T;
-        __threadfence_system();
-        __hip_atomic_store(&out.hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x != 0) return;
+    // ring heads: up to the oldest packet that still had events queued when this drain began (k_ev_select)
+    const uint32_t live = st.first_live;
+    st.first_live = 0xFFFFFFFFu;
+    const uint32_t new_head = head + min(live, tail - head);
+    st.pk_head = new_head;
+    st.pool_head = (new_head == tail) ? tl.pool_tail
+                                      : __hip_atomic_load(&e.pk[new_head & e.pk_mask].link_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    EvOrder o;
+    o.top_start = st.top_start;
+    o.top_max = st.top_max;
+    o.ladders = st.ladders;
+    o.top_nonempty = (st.top_max != kI64Min) ? 1 : 0;
+    ev_drain(o, T);
+    st.top_start = o.top_start;
+    st.ladders = o.ladders;
+    if (!o.top_nonempty) st.top_max = kI64Min;
+    st.t_prev = T;
+    const uint32_t total = st.n_deliv;
+    if (st.n_groups > e.g_cap) st.err |= 4u;
+    st.n_groups = 0u;
+    // The header lives in host-mapped memory: write-through stores, drained, then the sequence number the host
+    // polls.  (A system-scope release fence here would also write back every dirty line the drain's kernels left in
+    // this XCD's L2 -- microseconds, and nothing the host reads: the delivery records were stored by an earlier
+    // launch.)
+    __hip_atomic_store(&out.hdr->count, min(total, out.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out.hdr->total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out.hdr->err, st.err | tl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out.hdr->pending_packets, tail - new_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out.hdr->next_packet, tl.gseq_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out.hdr->time, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&out.hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ============================================================================ node-info
@@ -427,9 +457,12 @@ k_node_info(const EvDev e, const NodesDev nd, const int32_t *__restrict__ nodes,
         out.receiving[k] = state;
         out.channel[k] = ch;
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         *done_counter = 0u;
@@ -458,10 +491,11 @@ hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int6
 {
     const uint32_t pk_cap = e.pk_mask + 1u;
     hipLaunchKernelGGL(k_ev_select, dim3(cdiv(int(pk_cap), 256)), dim3(256), 0, s, e, time_us);
-    hipLaunchKernelGGL(k_ev_rank, dim3(cdiv(int(e.g_cap), 256)), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(k_ev_rank, dim3(256), dim3(256), 0, s, e);
     hipLaunchKernelGGL(k_ev_scan, dim3(1), dim3(1024), 0, s, e);
     hipLaunchKernelGGL(k_ev_emit, dim3(512), dim3(256), 0, s, e, out);
-    hipLaunchKernelGGL(k_ev_apply, dim3(512), dim3(256), 0, s, e, out, time_us, seq);
+    hipLaunchKernelGGL(k_ev_apply, dim3(256), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(k_ev_finish, dim3(1), dim3(1024), 0, s, e, out, time_us, seq);
     return hipGetLastError();
 }
 

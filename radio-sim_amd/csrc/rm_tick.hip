@@ -503,9 +503,12 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
         }
     }
     if (np == 0 && blockIdx.x == 0 && threadIdx.x == 0) v.pkt_offset[0] = 0u;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its stores, ...
+    __syncthreads();                                  // ... the workgroup meets, one lane releases them to the host
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         *done_counter = 0u;

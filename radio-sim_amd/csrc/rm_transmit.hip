@@ -90,10 +90,13 @@ k_pack_tick(TickDev t, int n_new, int have_offsets, HostView v, uint32_t *done_c
     const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
     for (uint32_t i = tid; i < np; i += step) v.pkt_interference[i] = t.pkt_interference[i];
     for (uint32_t i = tid; i <= np; i += step) v.pkt_offset[i] = have_offsets ? t.slot_off[t.shift + i] : 0u;
-    __threadfence_system();
     __shared__ uint32_t s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its stores, ...
+    __syncthreads();                                  // ... the workgroup meets, one lane releases them to the host
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         *done_counter = 0u;
@@ -151,9 +154,12 @@ k_pack_batch(const PackSlot *__restrict__ slots, int n_slots, HostView v, BatchC
         c.link_base = link_base;
         counts[b] = c;
     }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its stores, ...
+    __syncthreads();                                  // ... the workgroup meets, one lane releases them to the host
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        s_last = (atomicAdd(done_counter, 1u) == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
+    }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         *done_counter = 0u;

@@ -345,9 +345,10 @@ class Engine:
     def events_next_packet(self):
         return self._L.rm_events_next_packet(self._h)
 
-    def events_process(self, time_us):
+    def events_process(self, time_us, copy=True):
         """Simulator.emulatorTimeStepDone: currentTime = time; processAllEvents(time).  Returns the deliveries of
-        the drain in call order: (packet numbers, destination node indices, rssi), copied out of the pinned block."""
+        the drain in call order: (packet numbers, destination node indices, rssi), copied out of the pinned block
+        (copy=False: wrapped in place, valid until the next call)."""
         from ._lib import DeliveryView
         v = DeliveryView()
         check(self._L.rm_events_process(self._h, int(time_us), C.byref(v)))
@@ -357,7 +358,8 @@ class Engine:
             if k == 0:
                 return np.empty(0, dtype=dtype)
             buf = (C.c_char * (k * np.dtype(dtype).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dtype, count=k).copy()
+            a = np.frombuffer(buf, dtype=dtype, count=k)
+            return a.copy() if copy else a
         return arr(v.packet, np.int64), arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets
 
     def node_info(self, nodes=None, n=None):
