@@ -62,12 +62,20 @@ RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
 template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
 __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
 {
-    __shared__ int s_l1[FLAT ? 1 : kFrBoxes], s_l2[kFrGroups], s_cand[kFrCand];
-    __shared__ int s_orig[kFrameSegMax];
-    __shared__ double s_rssi[kFrameSegMax];
-    __shared__ double s_prob[STOCH ? kFrameSegMax : 1];
+    // one LDS block, carved by hand: the lists are dead when a frame that outgrew its segment orders its links,
+    // and that ordering wants all of it for a bitmap over the node indices (below)
+    constexpr int kWl1 = FLAT ? 0 : kFrBoxes, kWprob = STOCH ? 2 * kFrameSegMax : 0, kWtbl = SHADOW ? kShadowBins : 0;
+    constexpr int kWords = kWl1 + kFrGroups + kFrCand + kFrameSegMax + 2 * kFrameSegMax + kWprob + kWtbl;
+    static_assert((kWl1 + kFrGroups + kFrCand + kFrameSegMax) % 2 == 0, "the doubles behind the lists are 8-byte aligned");
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kWords];
+    int *const s_l1 = reinterpret_cast<int *>(s_mem);
+    int *const s_l2 = s_l1 + kWl1;
+    int *const s_cand = s_l2 + kFrGroups;
+    int *const s_orig = s_cand + kFrCand;
+    double *const s_rssi = reinterpret_cast<double *>(s_orig + kFrameSegMax);
+    double *const s_prob = s_rssi + kFrameSegMax; // (STOCH only)
+    uint32_t *const s_tbl = s_mem + (kWords - kWtbl); // (SHADOW only)
     __shared__ uint32_t s_n1[2], s_n2[2], s_nc[2], s_nres, s_base; // the lists' fill counts, by round parity
-    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
     const int slot = blockIdx.x;
@@ -340,10 +348,53 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
         __syncthreads();
         const uint32_t total = s_nres;
         if (pass == 1) {
-            // the frame's links sit unordered at s_base: rank by node index through LDS tiles of keys, permute into
-            // the (so far unused) compact arrays of the same range, copy back
+            // the frame's links sit unordered at s_base: rank by node index, permute into the (so far unused) compact
+            // arrays of the same range, copy back.
             const uint32_t base = s_base;
-            for (uint32_t i0 = 0; i0 < total; i0 += 256) { // block-uniform
+            // Node indices are unique inside a frame: a bitmap over the partition's nodes in LDS ranks all of them in
+            // O(links + nodes / 32): rank(j) = bits set below j = prefix of its 256-bit block + the words before it.
+            const uint32_t n_bits = uint32_t(nd.n_rx), nw = (n_bits + 31u) >> 5, nblk = (nw + 7u) >> 3;
+            const bool bitmap = nw + nblk + 8u <= uint32_t(kWords);
+            if (bitmap) {
+                uint32_t *const bits = s_mem, *const bpre = s_mem + ((nw + 7u) & ~7u);
+                __syncthreads();
+                for (uint32_t w = tid; w < ((nw + 7u) & ~7u) + nblk; w += 256) s_mem[w] = 0u;
+                __syncthreads();
+                for (uint32_t i = tid; i < total; i += 256) {
+                    const uint32_t j = uint32_t(t.a_dst[base + i] - nd.rx_first);
+                    atomicOr(&bits[j >> 5], 1u << (j & 31u));
+                }
+                __syncthreads();
+                for (uint32_t b = tid; b < nblk; b += 256) { // bits per block of eight words
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) c += uint32_t(__popc(bits[b * 8u + w]));
+                    bpre[b] = c;
+                }
+                __syncthreads();
+                if (tid < 64) { // exclusive scan of the block counts by one wave
+                    uint32_t carry = 0;
+                    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) { // wave-uniform
+                        const uint32_t b = b0 + lane;
+                        const uint32_t v = (b < nblk) ? bpre[b] : 0u;
+                        const uint32_t inc = wave_inclusive_scan(v, lane);
+                        if (b < nblk) bpre[b] = carry + inc - v;
+                        carry += uint32_t(__shfl(int(inc), 63));
+                    }
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < total; i += 256) {
+                    const int node = t.a_dst[base + i];
+                    const uint32_t j = uint32_t(node - nd.rx_first);
+                    uint32_t rank = bpre[j >> 8];
+                    for (uint32_t w = (j >> 8) << 3; w < (j >> 5); ++w) rank += uint32_t(__popc(bits[w]));
+                    rank += uint32_t(__popc(bits[j >> 5] & ((1u << (j & 31u)) - 1u)));
+                    t.out_dst[base + rank] = node;
+                    t.out_rssi[base + rank] = t.a_rssi[base + i];
+                    if (STOCH) t.out_prob[base + rank] = t.a_prob[base + i];
+                }
+            }
+            for (uint32_t i0 = 0; !bitmap && i0 < total; i0 += 256) { // block-uniform: tables too large for the bitmap
                 const uint32_t i = i0 + tid;
                 const int mine = (i < total) ? t.a_dst[base + i] : 0x7fffffff;
                 uint32_t rank = 0;

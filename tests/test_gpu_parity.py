@@ -160,6 +160,37 @@ def test_records_with_their_own_tx_probability(engine, rsa, O):
         assert engine.rng_state == cpu.rng_state == cpu2.rng_state
 
 
+@pytest.mark.parametrize("lossy", [False, True])
+def test_frames_heard_by_everybody(engine, rsa, O, lossy):
+    """Nothing to cull: a transmission range that covers the whole layout, so every frame is heard by every node --
+    far more links than a frame's LDS segment of the one-launch tick holds (rm_tick.hip: second pass, room from the
+    overflow allocator, node order from a bitmap over the node indices).  With and without java.util.Random draws."""
+    n = 3000
+    nd = random_nodes(O, n, 400.0, seed=41)
+    rng = np.random.default_rng(41)
+    if lossy:
+        nd.rxprob[:] = np.where(rng.random(n) < 0.6, 1.0, rng.uniform(0, 1, n))
+    nd.enabled[rng.choice(n, 30, replace=False)] = 0
+    params = {"udgm_transmission_range": 5000.0}
+    engine.set_link_capacity(1 << 20)
+    pk = nd.packets(rng.choice(n, 40, replace=False), 0, 320)
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", params, pk, seed=3)
+    assert cpu.count > 40 * 2900
+    assert_same(gpu, cpu, "everybody in range")
+    assert engine.rng_state == cpu.rng_state
+
+
+def test_frames_heard_by_everybody_large_table(engine, rsa, O):
+    """the same on a table too large for the LDS bitmap (170 000 nodes): the frame's links are ordered by counting"""
+    n = 170_000
+    nd = random_nodes(O, n, 3000.0, seed=42)
+    engine.set_link_capacity(1 << 20)
+    pk = nd.packets([5, 99_999], 0, 320)
+    gpu, cpu = run_both(O, rsa, engine, nd, "udgm", {"udgm_transmission_range": 1e5}, pk)
+    assert cpu.count == 2 * (n - 1)
+    assert_same(gpu, cpu, "everybody in range, large table")
+
+
 def test_empty_and_ragged(engine, rsa, O):
     nd = random_nodes(O, 130, 100.0, seed=2)      # not a multiple of 64
     configure_engine(engine, nd, "udgm", {})
