@@ -337,6 +337,11 @@ int rm_node_info(rm_context *ctx, const int32_t *nodes, int32_t n, double *rssi,
 /* java.util.Random LCG: state after `steps` next() calls */
 uint64_t rm_lcg_jump(uint64_t state48, uint64_t steps);
 double rm_lcg_next_double(uint64_t *state48);
+/* the exact-arithmetic layer of the extension spec as the HOST compiler builds it from the kernels' header
+ * (csrc/rm_math.hpp; no device needed): fn 0 det_log2, 1 det_exp2, 2 det_log10, 3 det_pow10, 4 det_normal,
+ * 5 Q80 truncation and back; the per-link shadowing hash and its uniform deviate */
+double rm_det_math(int32_t fn, double x);
+uint64_t rm_link_hash(uint64_t seed, uint32_t a, uint32_t b, double *u);
 /* the pop order of the reference's event queue as a sort key (csrc/rm_evorder.hpp; no device needed):
  * rm_evq_add returns the ladder of an event added now with time t, rm_evq_drain is processAllEvents(t) */
 typedef struct rm_evq_order {

@@ -2524,6 +2524,10 @@ int rm_node_info(rm_context *c, const int32_t *nodes, int32_t n, double *rssi, i
     return RM_OK;
 }
 
+double rm_det_math(int32_t fn, double x) { return rm::host_det_math(fn, x); }
+
+uint64_t rm_link_hash(uint64_t seed, uint32_t a, uint32_t b, double *u) { return rm::host_link_hash(seed, a, b, u); }
+
 void rm_evq_init(rm_evq_order *o)
 {
     if (!o) return;

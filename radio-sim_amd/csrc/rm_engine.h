@@ -413,6 +413,8 @@ hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, c
 
 // host-side mirrors of device math used for constants (rm_math.hpp, exported by rm_transmit.hip)
 double host_det_pow10(double y);
+double host_det_math(int fn, double x);                                  // rm_det_math (test hook)
+uint64_t host_link_hash(uint64_t seed, uint32_t a, uint32_t b, double *u); // rm_link_hash (test hook)
 uint64_t host_mix64(uint64_t z);
 void host_lcg_jump_map(uint64_t steps, uint64_t *A, uint64_t *C);
 

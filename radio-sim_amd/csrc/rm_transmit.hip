@@ -5,6 +5,25 @@
 namespace rm {
 
 double host_det_pow10(double y) { return det_pow10(y); }
+double host_det_math(int fn, double x)
+{
+    switch (fn) {
+    case 0: return det_log2(x);
+    case 1: return det_exp2(x);
+    case 2: return det_log10(x);
+    case 3: return det_pow10(x);
+    case 4: return det_normal(x);
+    case 5: return q80_to_double(q80_from_double(x));
+    default: return 0.0;
+    }
+}
+uint64_t host_link_hash(uint64_t seed, uint32_t a, uint32_t b, double *u)
+{
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const uint64_t h = mix64(mix64(seed + 0x9E3779B97F4A7C15ull) ^ ((uint64_t(lo) << 32) | uint64_t(hi)));
+    if (u) *u = (double(h >> 12) + 0.5) * 0x1.0p-52;
+    return h;
+}
 uint64_t host_mix64(uint64_t z) { return mix64(z); }
 void host_lcg_jump_map(uint64_t steps, uint64_t *A, uint64_t *C) { lcg_jump_map(steps, *A, *C); }
 

@@ -50,6 +50,33 @@ def test_detmath_golden_bits(O):
     np.testing.assert_array_equal(h, z["hash_h"])
 
 
+def test_detmath_against_the_rational_arithmetic_fixture(O, rsa):
+    """tests/golden/detmath_mp.npz comes from a third, structurally different evaluation of the extension spec
+    (tests/golden/make_detmath_mp.py: exact rational arithmetic, one rounding per operation, constants derived with
+    mpmath, accuracy checked against the true functions).  Both C texts must agree with it bit for bit: the oracle,
+    and the kernels' own header as the host compiler builds it (rm_det_math / rm_link_hash, no device needed)."""
+    import ctypes as C
+    from radio_sim_amd import _lib
+    z = np.load(os.path.join(GOLDEN, "detmath_mp.npz"))
+    L, P = O.lib(), _lib.lib()
+    cases = (("log2_x", "log2_y", L.orc_det_log2, 0, 1.0), ("log2_x", "log10_y", L.orc_det_log10, 2, 1.0),
+             ("exp2_x", "exp2_y", L.orc_det_exp2, 1, 1.0), ("exp2_x", "pow10_y", L.orc_det_pow10, 3, 0.1),
+             ("normal_u", "normal_g", L.orc_det_normal, 4, 1.0), ("fixed_x", "fixed_y", L.orc_fixed_roundtrip, 5, 1.0))
+    for xk, yk, ofn, pfn, scale in cases:
+        xs = z[xk] * scale if scale == 1.0 else z[xk] / 10.0
+        want = z[yk].view(np.uint64)
+        got_o = np.array([ofn(float(v)) for v in xs]).view(np.uint64)
+        got_p = np.array([P.rm_det_math(pfn, float(v)) for v in xs]).view(np.uint64)
+        np.testing.assert_array_equal(got_o, want, err_msg="oracle " + yk)
+        np.testing.assert_array_equal(got_p, want, err_msg="engine header " + yk)
+    seed = int(z["hash_seed"])
+    u = C.c_double(0.0)
+    for (a, b), h, uu in zip(z["hash_pairs"], z["hash_h"], z["hash_u"]):
+        assert L.orc_shadow_hash(seed, int(a), int(b)) == int(h)
+        assert P.rm_link_hash(seed, int(a), int(b), C.byref(u)) == int(h) and u.value == float(uu)
+        assert P.rm_link_hash(seed, int(b), int(a), None) == int(h)       # symmetric per link
+
+
 def test_detmath_accuracy(O):
     """E-math of the extension spec against libm / scipy: a few ulp, not bit-exactness."""
     from scipy.stats import norm
