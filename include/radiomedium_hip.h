@@ -299,6 +299,41 @@ int64_t rm_last_link_evaluations(const rm_context *ctx);
  * tick of result slot `slot` (0 on the one-launch tick path, which keeps no candidate list) and its heard links */
 int rm_slot_stats(rm_context *ctx, int32_t slot, uint64_t *candidates, uint64_t *heard);
 
+/* ---- several devices behind one caller --------------------------------------------------------------
+ * The reference host is ONE process (Main.java:65-73): a group drives n contexts from one host thread, one
+ * per device (an ordinal may repeat: several partitions on one GPU).  Receivers are range-partitioned by
+ * node index over the members (rm_set_partition); a tick's Tx records are on the host already, so they are
+ * simply handed to every member -- no all-gather; every member evaluates them against its receivers, the
+ * launches of all members are enqueued before any result is waited for, and the heard links are merged
+ * packet-major / node ascending (member order = node order).  Probabilistic links: the per-packet draw
+ * counts are exchanged through the host and every member places its draws behind the lower members'
+ * (rm_tick_finish_draws), so verdicts, Tx-failure flags and the java.util.Random state are those of one
+ * context.  Everything else of a member (reception stage, node-info, device-resident results) is reached
+ * through rm_group_context. */
+typedef struct rm_group rm_group;
+int rm_group_create(int32_t n_members, const int32_t *device_ordinals, rm_group **out);
+void rm_group_destroy(rm_group *g);
+int rm_group_size(const rm_group *g);
+rm_context *rm_group_context(rm_group *g, int32_t member);
+int rm_group_set_model(rm_group *g, const rm_model_params *p);
+int rm_group_set_n2n_matrix(rm_group *g, int32_t m, const double *row_major);
+int rm_group_seed(rm_group *g, int64_t seed);
+int rm_group_get_rng_state(rm_group *g, uint64_t *state48);
+int rm_group_set_link_capacity(rm_group *g, uint32_t max_links_per_member);
+int rm_group_nodes_upload(rm_group *g, int32_t n, const double *x, const double *y, const double *z,
+                          const double *txpower, const int32_t *channel, const uint8_t *enabled,
+                          const double *rxprob, const double *txprob, const int32_t *int_id);
+int rm_group_node_update(rm_group *g, int32_t node, double x, double y, double z, double txpower,
+                         int32_t channel, uint8_t enabled, double rxprob, double txprob);
+int rm_group_set_time(rm_group *g, int64_t current_time_us);
+int rm_group_tick_begin(rm_group *g, int64_t t_begin_us, int64_t t_end_us);
+int rm_group_enqueue_tx(rm_group *g, int32_t src, int64_t start_us, int64_t air_us, const double *txpower,
+                        const int32_t *channel);
+int rm_group_enqueue_tx_records(rm_group *g, const rm_tx_record *recs, int32_t n);
+/* as rm_tick_flush, over all members */
+int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
+                        uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset);
+
 /* ---- reception stage: what the reference does with the verdicts, on the device -------------------------
  * SURVEY.md section 8f-1 / 8f-3.  After rm_events_enable every evaluated tick (rm_transmit, rm_tick_flush*,
  * rm_tick_run*, not rm_batch_*) also hands its packets and heard links to the event stage, exactly as the

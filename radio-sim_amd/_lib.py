@@ -153,6 +153,25 @@ SIGNATURES = {
     "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
     "rm_last_link_evaluations": (C.c_int64, [C.c_void_p]),
     "rm_slot_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rm_group_create": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rm_group_destroy": (None, [C.c_void_p]),
+    "rm_group_size": (C.c_int, [C.c_void_p]),
+    "rm_group_context": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "rm_group_set_model": (C.c_int, [C.c_void_p, C.POINTER(ModelParams)]),
+    "rm_group_set_n2n_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "rm_group_seed": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rm_group_get_rng_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rm_group_set_link_capacity": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rm_group_nodes_upload": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 9),
+    "rm_group_node_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                       C.c_int32, C.c_uint8, C.c_double, C.c_double]),
+    "rm_group_set_time": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rm_group_tick_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    "rm_group_enqueue_tx": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int32)]),
+    "rm_group_enqueue_tx_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "rm_group_tick_flush": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rm_events_enable": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rm_events_disable": (C.c_int, [C.c_void_p]),
     "rm_events_next_packet": (C.c_int64, [C.c_void_p]),

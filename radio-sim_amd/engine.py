@@ -400,3 +400,79 @@ class Engine:
 
     def last_link_evaluations(self):
         return self._L.rm_last_link_evaluations(self._h)
+
+
+class Group:
+    """n engine contexts behind one caller (rm_group_*): receivers range-partitioned over the members, a tick's Tx
+    records handed to every member from the host, results merged in node order."""
+
+    def __init__(self, devices):
+        self._L = _lib.lib()
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self._L.rm_group_create(len(devices), devs, C.byref(h)))
+        self._h = h
+        self._n_new = 0
+
+    def close(self):
+        if self._h:
+            self._L.rm_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self._L.rm_group_size(self._h)
+
+    def set_model(self, kind, **kw):
+        p = Engine.default_params(kind)
+        for k, v in kw.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        check(self._L.rm_group_set_model(self._h, C.byref(p)))
+
+    def seed(self, seed):
+        check(self._L.rm_group_seed(self._h, seed))
+
+    @property
+    def rng_state(self):
+        st = C.c_uint64(0)
+        check(self._L.rm_group_get_rng_state(self._h, C.byref(st)))
+        return st.value
+
+    def set_link_capacity(self, cap):
+        check(self._L.rm_group_set_link_capacity(self._h, cap))
+
+    def upload_table(self, nd):
+        def arr(a, dt):
+            return np.ascontiguousarray(a, dtype=dt)
+        self._keep = [arr(nd.x, np.float64), arr(nd.y, np.float64), arr(nd.z, np.float64), arr(nd.txpower, np.float64),
+                      arr(nd.channel, np.int32), arr(nd.enabled, np.uint8), arr(nd.rxprob, np.float64),
+                      arr(nd.txprob, np.float64), arr(nd.int_id, np.int32)]
+        check(self._L.rm_group_nodes_upload(self._h, nd.n, *[a.ctypes.data for a in self._keep]))
+        self._n = nd.n
+
+    def tick(self, recs, t_begin=0, t_end=0, cap=None):
+        recs = np.ascontiguousarray(recs, dtype=TX_RECORD_DTYPE)
+        n_new = len(recs)
+        check(self._L.rm_group_tick_begin(self._h, t_begin, t_end))
+        check(self._L.rm_group_enqueue_tx_records(self._h, recs.ctypes.data, n_new))
+        if cap is None:
+            cap = max(1, n_new) * max(1, self._n)
+        pkt = np.empty(cap, dtype=np.int32)
+        dst = np.empty(cap, dtype=np.int32)
+        verdict = np.empty(cap, dtype=np.uint8)
+        rssi = np.empty(cap, dtype=np.float64)
+        sinr = np.empty(cap, dtype=np.float64)
+        pint = np.zeros(max(1, n_new), dtype=np.uint8)
+        poff = np.zeros(n_new + 1, dtype=np.uint32)
+        cnt = C.c_uint32(0)
+        check(self._L.rm_group_tick_flush(self._h, pkt.ctypes.data, dst.ctypes.data, verdict.ctypes.data, rssi.ctypes.data,
+                                          sinr.ctypes.data, cap, C.byref(cnt), pint.ctypes.data, poff.ctypes.data))
+        k = cnt.value
+        return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
