@@ -19,7 +19,23 @@
  *   threading               transmit() is entered from per-socket reader threads
  *                           (net/JSONClientConnection.java:118-131): one lock per context.
  *   errors                  transmit() returns void and must not throw: failures are logged and
- *                           the packet reaches no receiver.
+ *                           the packet reaches no receiver (its transmission events are generated all
+ *                           the same, as every reference medium does first thing).
+ *
+ * Batching modes (the reference consumes a tick's events only in emulatorTimeStepDone ->
+ * processAllEvents, Simulator.java:155-165, so nothing forces one evaluation per packet):
+ *   setTickMode(true)       transmit() only queues the packet.  flush() -- ONE call a maintainer adds at
+ *                           the top of Simulator.emulatorTimeStepDone, before `currentTime = stepTime` --
+ *                           evaluates the queue in one pass (nTickBegin / nEnqueue / nTickFlushView) and
+ *                           makes exactly the per-packet mode's generate*Events calls, in arrival x node
+ *                           order.  12-13 us of GPU time per tick of 1000 frames at 100k nodes instead of
+ *                           1000 x 22 us.
+ *   setDeviceEvents(true)   the events never reach the JVM: the engine keeps packets, heard links and
+ *                           every node's radio state on the device (rm_events_*).  processEvents(time) --
+ *                           called INSTEAD of processAllEvents(currentTime) -- returns the drain's
+ *                           deliveries in the order the reference's ladder queue pops them and turns them
+ *                           into Simulator.deliverRadioPacket calls; nodeInfo() serves the per-node fields
+ *                           of the time-step message (net/JSONClientConnection.java:331-341).
  */
 package se.sics.emul8.radiomedium;
 
@@ -54,8 +70,26 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private static native int nTransmit(long ctx, int src, long startUs, long hexLength, boolean hasPower, double txpower,
             boolean hasChannel, int channel, int[] dst, byte[] verdict, double[] rssi, double[] sinr, byte[] interference);
 
+    /* tick mode: the queued transmit() calls in one evaluation; the result is read in place from direct buffers
+     * over the context's pinned block (rm_tick_flush_view); views = {pktOffset, pktInterference, dst, verdict, rssi} */
+    private static native int nTickBegin(long ctx, long tBegin, long tEnd);
+    private static native int nEnqueue(long ctx, int src, long startUs, long airUs, double txpower, int channel);
+    private static native int nTickRun(long ctx);
+    private static native int nTickFlushView(long ctx, java.nio.ByteBuffer[] views, int[] counts /* links, packets */);
+    /* reception stage on the device */
+    private static native int nEventsEnable(long ctx, int maxPackets, int maxLinks);
+    private static native long nEventsNextPacket(long ctx);
+    private static native int nEventsProcess(long ctx, long timeUs, java.nio.ByteBuffer[] views /* packet, dst, rssi */,
+            int[] counts /* deliveries, pending packets */);
+    private static native int nNodeInfo(long ctx, int[] nodes, double[] rssi, int[] receiving, int[] channel);
+
     private final Object lock = new Object();
     private final int kind;
+    private boolean tickMode, deviceEvents;
+    private final java.util.ArrayList<RadioPacket> queue = new java.util.ArrayList<RadioPacket>();
+    private final java.util.ArrayDeque<RadioPacket> inFlight = new java.util.ArrayDeque<RadioPacket>();
+    private long firstInFlight;
+    private double[] params; // the double fields of rm_model_params, udgm_success_ratio_tx first (nSetModel)
     private long ctx;
     private Node[] uploaded;          // the Simulator.getNodes() snapshot the device currently mirrors
     private java.util.IdentityHashMap<Node, Integer> index = new java.util.IdentityHashMap<Node, Integer>();
@@ -71,7 +105,53 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             throw new IllegalStateException("no MI355X radio medium: " + nLastError());
         }
         nSetModel(ctx, kind, 0, null);
-        nSeed(ctx, randomSeed); // a seeded Simulator(Random) (Simulator.java:87-89) must use the same seed
+        // The engine keeps the generator on the device and consumes exactly the draws the Java loop would.  A run is
+        // reproducible only with a seeded Simulator(new Random(seed)) (Simulator.java:87-89) and the same seed here;
+        // simulator.getRandom() itself is never advanced by this medium.
+        nSeed(ctx, randomSeed);
+    }
+
+    /* the reference media's setters (UDGMRadioMedium.java:31-61, N2NRadioMedium.java:11) */
+    private void param(int index, double v) {
+        synchronized (lock) {
+            if (params == null) {
+                params = new double[] {1.0, 1.0, 50.0, 100.0, 100.0}; // UDGMRadioMedium.java:18-24, UDGMConstantLossRadioMedium.java:8
+            }
+            params[index] = v;
+            if (nSetModel(ctx, kind, 0, params) != 0) {
+                log.error("radio medium: {}", nLastError());
+            }
+        }
+    }
+    public void setSuccessRatioTx(double v) { param(0, v); }   // declared by the reference, never used by it
+    public void setSuccessRatioRx(double v) { param(1, v); }
+    public void setTransmissionRange(double v) { param(2, v); }
+    public void setInterferenceRange(double v) { param(3, v); } // declared by the reference, never read by it
+    public void setMatrix(double[][] m) {                       // N2NRadioMedium(double[][]): rows x longest row
+        int cols = 0;
+        for (double[] row : m) cols = Math.max(cols, row.length);
+        int dim = Math.max(m.length, cols);
+        double[] flat = new double[dim * dim];
+        for (int i = 0; i < m.length; i++) System.arraycopy(m[i], 0, flat, i * dim, m[i].length);
+        synchronized (lock) {
+            if (nSetN2NMatrix(ctx, dim, flat) != 0) {
+                log.error("radio medium: {}", nLastError());
+            }
+        }
+    }
+
+    public void setTickMode(boolean on) { synchronized (lock) { tickMode = on; } }
+
+    public void setDeviceEvents(boolean on) {
+        synchronized (lock) {
+            if (nEventsEnable(ctx, on ? 1 << 16 : 0, on ? 1 << 21 : 0) != 0) {
+                log.error("radio medium: {}", nLastError());
+                return;
+            }
+            deviceEvents = on;
+            inFlight.clear();
+            firstInFlight = on ? nEventsNextPacket(ctx) : 0;
+        }
     }
 
     @Override
@@ -143,6 +223,10 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             return;
         }
         synchronized (lock) {
+            if (tickMode) { // evaluated in flush(), with everything else that is sent in this tick
+                queue.add(packet);
+                return;
+            }
             syncNodes(nodes);
             Integer src = index.get(packet.getSource());
             if (src == null) {
@@ -154,12 +238,17 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             int heard = nTransmit(ctx, src, packet.getStartTime(), packet.getPacketDataAsHex() == null ? 0
                     : packet.getPacketDataAsHex().length(), true, packet.getTransmitPower(), true,
                     packet.getWirelessChannel(), dst, verdict, rssi, sinr, interference);
-            if (heard < 0) {
-                log.error("radio medium: {}", nLastError());
+            if (deviceEvents) { // the engine queued the packet's events itself
+                if (heard < 0) log.error("radio medium: {}", nLastError());
+                inFlight.add(packet);
                 return;
             }
             if (kind != MODEL_UDGM_CONST) {
-                sim.generateTransmissionEvents(packet); // UDGMRadioMedium.java:97
+                sim.generateTransmissionEvents(packet); // UDGMRadioMedium.java:97 -- whatever the native call said
+            }
+            if (heard < 0) {
+                log.error("radio medium: {}", nLastError());
+                return;
             }
             for (int i = 0; i < heard; i++) { // node order, as the reference's loop (:99)
                 Node node = nodes[dst[i]];
@@ -169,6 +258,86 @@ public class GpuRadioMedium extends AbstractRadioMedium {
                     sim.generateReceptionEvents(packet, node, rssi[i], verdict[i] == DELIVERED);
                 }
             }
+        }
+    }
+
+    /** Tick mode: call at the top of Simulator.emulatorTimeStepDone, before `this.currentTime = stepTime`
+     *  (Simulator.java:156): the event times of the queued packets are max(start, OLD currentTime), :323-326. */
+    public void flush() {
+        Simulator sim = this.simulator;
+        synchronized (lock) {
+            if (queue.isEmpty() || sim == null) {
+                queue.clear();
+                return;
+            }
+            Node[] nodes = sim.getNodes();
+            syncNodes(nodes);
+            nSetTime(ctx, sim.getTime());
+            int rc = nTickBegin(ctx, sim.getTime(), sim.getTime());
+            for (RadioPacket p : queue) {
+                Integer src = index.get(p.getSource());
+                if (rc == 0 && src != null) {
+                    rc = nEnqueue(ctx, src, p.getStartTime(), p.getPacketAirTime(), p.getTransmitPower(), p.getWirelessChannel());
+                }
+            }
+            if (deviceEvents) {
+                if (rc == 0) rc = nTickRun(ctx);
+                if (rc != 0) log.error("radio medium: {}", nLastError());
+                inFlight.addAll(queue);
+                queue.clear();
+                return;
+            }
+            java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[5];
+            int[] counts = new int[2];
+            if (rc == 0) rc = nTickFlushView(ctx, v, counts);
+            if (rc != 0) log.error("radio medium: {}", nLastError());
+            java.nio.IntBuffer off = rc == 0 ? v[0].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer() : null;
+            java.nio.IntBuffer d = rc == 0 ? v[2].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer() : null;
+            java.nio.DoubleBuffer r = rc == 0 ? v[4].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer() : null;
+            for (int k = 0; k < queue.size(); k++) { // arrival order, then node order: the per-packet calls
+                RadioPacket p = queue.get(k);
+                if (kind != MODEL_UDGM_CONST) sim.generateTransmissionEvents(p);
+                for (int i = rc == 0 ? off.get(k) : 0; rc == 0 && i < off.get(k + 1); i++) {
+                    Node node = nodes[d.get(i)];
+                    if (kind == MODEL_UDGM_CONST) sim.deliverRadioPacket(p, node, r.get(i));
+                    else sim.generateReceptionEvents(p, node, r.get(i), v[3].get(i) == DELIVERED);
+                }
+            }
+            queue.clear();
+        }
+    }
+
+    /** Device events: call INSTEAD of processAllEvents(currentTime) in Simulator.emulatorTimeStepDone (:161). */
+    public void processEvents(long time) {
+        Simulator sim = this.simulator;
+        synchronized (lock) {
+            if (!deviceEvents || sim == null) return;
+            java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[3];
+            int[] counts = new int[2];
+            if (nEventsProcess(ctx, time, v, counts) != 0) {
+                log.error("radio medium: {}", nLastError());
+                return;
+            }
+            Node[] nodes = sim.getNodes();
+            java.nio.LongBuffer pk = v[0].order(java.nio.ByteOrder.nativeOrder()).asLongBuffer();
+            java.nio.IntBuffer d = v[1].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer();
+            java.nio.DoubleBuffer r = v[2].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer();
+            RadioPacket[] live = inFlight.toArray(new RadioPacket[0]);
+            for (int i = 0; i < counts[0]; i++) { // ReceptionEvent.java:41-44, in the queue's pop order
+                sim.deliverRadioPacket(live[(int) (pk.get(i) - firstInFlight)], nodes[d.get(i)], r.get(i));
+            }
+            long oldest = nEventsNextPacket(ctx) - counts[1]; // packets whose last event has fired are forgotten
+            while (firstInFlight < oldest && !inFlight.isEmpty()) {
+                inFlight.poll();
+                firstInFlight++;
+            }
+        }
+    }
+
+    /** the node-info fields of a time-step message for `nodes` (indices into Simulator.getNodes()) */
+    public boolean nodeInfo(int[] nodes, double[] rssi, int[] receiving, int[] channel) {
+        synchronized (lock) {
+            return nNodeInfo(ctx, nodes, rssi, receiving, channel) == 0;
         }
     }
 

@@ -140,6 +140,87 @@ JNIEXPORT jint JFN(nTransmit)(JNIEnv *env, jclass cls, jlong ctx, jint src, jlon
     (*env)->ReleaseByteArrayElements(env, interference, pi, 0);
     return rc == RM_OK ? (jint)count : (jint)rc;
 }
+
+/* ---- tick mode ------------------------------------------------------------------------------------ */
+JNIEXPORT jint JFN(nTickBegin)(JNIEnv *env, jclass cls, jlong ctx, jlong t0, jlong t1)
+{
+    (void)env; (void)cls;
+    return rm_tick_begin((rm_context *)(intptr_t)ctx, t0, t1);
+}
+
+JNIEXPORT jint JFN(nEnqueue)(JNIEnv *env, jclass cls, jlong ctx, jint src, jlong startUs, jlong airUs, jdouble txpower, jint channel)
+{
+    (void)env; (void)cls;
+    double tp = txpower;
+    int32_t ch = channel;
+    return rm_enqueue_tx((rm_context *)(intptr_t)ctx, src, startUs, airUs, &tp, &ch);
+}
+
+JNIEXPORT jint JFN(nTickRun)(JNIEnv *env, jclass cls, jlong ctx)
+{
+    (void)env; (void)cls;
+    return rm_tick_run((rm_context *)(intptr_t)ctx);
+}
+
+/* the result is not copied: direct ByteBuffers over the context's pinned, host-mapped block */
+JNIEXPORT jint JFN(nTickFlushView)(JNIEnv *env, jclass cls, jlong ctx, jobjectArray views, jintArray counts)
+{
+    (void)cls;
+    rm_host_result r;
+    int rc = rm_tick_flush_view((rm_context *)(intptr_t)ctx, &r);
+    if (rc != RM_OK) return rc;
+    jint c[2] = {(jint)r.count, (jint)r.n_packets};
+    (*env)->SetIntArrayRegion(env, counts, 0, 2, c);
+    void *ptr[5] = {(void *)r.pkt_offset, (void *)r.pkt_interference, (void *)r.dst, (void *)r.verdict, (void *)r.rssi};
+    jlong len[5] = {((jlong)r.n_packets + 1) * 4, (jlong)r.n_packets, (jlong)r.count * 4, (jlong)r.count, (jlong)r.count * 8};
+    for (int i = 0; i < 5; i++)
+        (*env)->SetObjectArrayElement(env, views, i, (*env)->NewDirectByteBuffer(env, ptr[i], len[i] > 0 ? len[i] : 0));
+    return RM_OK;
+}
+
+/* ---- reception stage on the device ------------------------------------------------------------------ */
+JNIEXPORT jint JFN(nEventsEnable)(JNIEnv *env, jclass cls, jlong ctx, jint maxPackets, jint maxLinks)
+{
+    (void)env; (void)cls;
+    if (maxPackets == 0 && maxLinks == 0) return rm_events_disable((rm_context *)(intptr_t)ctx);
+    return rm_events_enable((rm_context *)(intptr_t)ctx, (uint32_t)maxPackets, (uint32_t)maxLinks);
+}
+
+JNIEXPORT jlong JFN(nEventsNextPacket)(JNIEnv *env, jclass cls, jlong ctx)
+{
+    (void)env; (void)cls;
+    return rm_events_next_packet((rm_context *)(intptr_t)ctx);
+}
+
+JNIEXPORT jint JFN(nEventsProcess)(JNIEnv *env, jclass cls, jlong ctx, jlong timeUs, jobjectArray views, jintArray counts)
+{
+    (void)cls;
+    rm_delivery_view v;
+    int rc = rm_events_process((rm_context *)(intptr_t)ctx, timeUs, &v);
+    if (rc != RM_OK) return rc;
+    jint c[2] = {(jint)v.count, (jint)v.pending_packets};
+    (*env)->SetIntArrayRegion(env, counts, 0, 2, c);
+    void *ptr[3] = {(void *)v.packet, (void *)v.dst, (void *)v.rssi};
+    jlong len[3] = {(jlong)v.count * 8, (jlong)v.count * 4, (jlong)v.count * 8};
+    for (int i = 0; i < 3; i++) (*env)->SetObjectArrayElement(env, views, i, (*env)->NewDirectByteBuffer(env, ptr[i], len[i]));
+    return RM_OK;
+}
+
+JNIEXPORT jint JFN(nNodeInfo)(JNIEnv *env, jclass cls, jlong ctx, jintArray nodes, jdoubleArray rssi, jintArray receiving,
+                              jintArray channel)
+{
+    (void)cls;
+    jsize n = (*env)->GetArrayLength(env, nodes);
+    jint *pn = (*env)->GetIntArrayElements(env, nodes, NULL);
+    jdouble *pr = (*env)->GetDoubleArrayElements(env, rssi, NULL);
+    jint *px = (*env)->GetIntArrayElements(env, receiving, NULL), *pc = (*env)->GetIntArrayElements(env, channel, NULL);
+    int rc = rm_node_info((rm_context *)(intptr_t)ctx, (const int32_t *)pn, n, pr, (int32_t *)px, (int32_t *)pc);
+    (*env)->ReleaseIntArrayElements(env, nodes, pn, JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, rssi, pr, 0);
+    (*env)->ReleaseIntArrayElements(env, receiving, px, 0);
+    (*env)->ReleaseIntArrayElements(env, channel, pc, 0);
+    return rc;
+}
 #else
 /* no JDK on this machine: nothing to build (the C ABI is exercised through ctypes and C++ instead) */
 typedef int rm_jni_unavailable;

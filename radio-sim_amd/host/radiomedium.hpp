@@ -32,6 +32,7 @@
 // There is no CPU evaluation in this file: without a gfx950 device the medium's constructor throws.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <deque>
@@ -567,10 +568,14 @@ public:
     }
     void setMatrix(const std::vector<std::vector<double>> &m)
     {
-        const size_t n = m.size();
+        // The reference bounds the source id by the number of rows and the destination id by THAT row's length
+        // (N2NRadioMedium.java:28-37), anything outside gives probability 0 = unheard: a jagged matrix is the square
+        // matrix of side max(rows, longest row) padded with zeros.
+        size_t n = m.size();
+        for (const auto &row : m) n = std::max(n, row.size());
         std::vector<double> flat(n * n, 0.0);
-        for (size_t i = 0; i < n; ++i)
-            for (size_t j = 0; j < n && j < m[i].size(); ++j) flat[i * n + j] = m[i][j];
+        for (size_t i = 0; i < m.size(); ++i)
+            for (size_t j = 0; j < m[i].size(); ++j) flat[i * n + j] = m[i][j];
         if (rm_set_n2n_matrix(ctx_, int32_t(n), flat.data()) != RM_OK) throw std::invalid_argument(rm_last_error());
     }
 };
