@@ -2152,6 +2152,26 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     };
     if (!by_copy) RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
     if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
+    // RM_BATCH_FRAMES=1: the batch through the one-frame-per-workgroup kernel of the closed-loop tick instead of the
+    // three sweep stages (one launch; the compact arrays on demand, per slot)
+    static const bool batch_frames = std::getenv("RM_BATCH_FRAMES") != nullptr;
+    if (batch_frames && !cfg.stochastic && !plans[0].sinr) {
+        int seg_len = rm::frame_tick_segment(ticks[0], cfg, m);
+        for (int b = 1; b < n && seg_len > 0; ++b) seg_len = std::min(seg_len, rm::frame_tick_segment(ticks[b], cfg, m));
+        if (seg_len > 0) {
+            RM_TRY(stage(RM_STAGE_FILTER));
+            RM_HIP(rm::launch_tick_frames_batch(s, nd, m, ticks, n, dev_ticks, cfg, seg_len));
+            if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+            for (int b = 0; b < n; ++b) {
+                slots[b]->have_result = true;
+                slots[b]->compact_pending = true;
+                slots[b]->last.seg_ordered = 1;
+                slots[b]->last_model = m;
+                slots[b]->last_cfg = cfg;
+            }
+            return RM_OK;
+        }
+    }
     RM_TRY(stage(RM_STAGE_FILTER));
     RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, dev_ticks, cfg));
     RM_TRY(stage(RM_STAGE_EXACT));

@@ -390,6 +390,8 @@ hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, co
 int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
 hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg,
                               int seg_len);
+hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                                    const TickDev *dev_ticks, const LaunchCfg &cfg, int seg_len);
 hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t, int n_new, const HostView &v, uint32_t *done_counter,
                               uint32_t seq);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);

@@ -60,7 +60,7 @@ RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
 }
 
 template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
-__global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
+RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev &t, const int seg_len)
 {
     // one LDS block, carved by hand: the lists are dead when a frame that outgrew its segment orders its links,
     // and that ordering wants all of it for a bitmap over the node indices (below)
@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     }
     for (int i = blockIdx.x * blockDim.x + tid; i < t.zero_len; i += gridDim.x * blockDim.x) t.cand_tot_next[i] = 0u;
 
-    if (!real) { // padding slot of the per-frame counters
-        if (tid == 0) {
+    if (!real) { // padding slot of the per-frame counters (a batch launches the largest tick's grid for every tick)
+        if (tid == 0 && slot < t.n_cnt) {
             t.cursor[slot] = 0u;
             t.seg_off[slot] = uint32_t(slot) * uint32_t(seg_len);
         }
@@ -510,6 +510,20 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     }
 }
 
+template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
+__global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
+{
+    tick_frames_body<MODEL, STOCH, SHADOW, FLAT>(nd, m, t, seg_len);
+}
+
+// the same for the ticks of a batch (blockIdx.z = tick; descriptors in device memory, as the sweep's batched kernels)
+template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
+__global__ void __launch_bounds__(256)
+k_tick_frames_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks, const int seg_len)
+{
+    tick_frames_body<MODEL, STOCH, SHADOW, FLAT>(nd, m, ticks[blockIdx.z], seg_len);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The tick's result written straight from the frames' segments into the host-mapped block of
 // rm_tick_flush* (header, packet offsets, Tx-failure flags, records): every workgroup redoes the scan
@@ -616,6 +630,32 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     }
 #undef RM_FR
 #undef RM_FR2
+    return hipGetLastError();
+}
+
+hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
+                                    const TickDev *dev_ticks, const LaunchCfg &cfg, int seg_len)
+{
+    int max_cnt = 0;
+    for (int i = 0; i < n; ++i) max_cnt = max(max_cnt, ticks[i].n_cnt);
+    const dim3 grid(max_cnt, 1, n), block(256);
+    const int n_groups = cdiv(nd.n_rx, kGroup);
+    const bool flat = n_groups <= kFrFlatGroups;
+#define RM_FRB(MODEL, SH)                                                                                              \
+    do {                                                                                                               \
+        if (flat) hipLaunchKernelGGL((k_tick_frames_batch<MODEL, false, SH, true>), grid, block, 0, s, nd, m, dev_ticks, seg_len); \
+        else hipLaunchKernelGGL((k_tick_frames_batch<MODEL, false, SH, false>), grid, block, 0, s, nd, m, dev_ticks, seg_len);     \
+    } while (0)
+    switch (m.kind) {
+    case RM_MODEL_UDGM: RM_FRB(RM_MODEL_UDGM, false); break;
+    case RM_MODEL_UDGM_CONST: RM_FRB(RM_MODEL_UDGM_CONST, false); break;
+    case RM_MODEL_LOGDIST:
+        if (cfg.shadow && m.shadow_tbl) RM_FRB(RM_MODEL_LOGDIST, true);
+        else RM_FRB(RM_MODEL_LOGDIST, false);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+#undef RM_FRB
     return hipGetLastError();
 }
 

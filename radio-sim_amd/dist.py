@@ -130,10 +130,10 @@ class ShardedTick:
         self.batch = batch
         self.mine = [torch.empty(batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
         self.all = [torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
-        self.tick_major = ([torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device)
-                            for _ in range(ring)] if batch > 1 else None)
+        # (also for batch == 1: run_batch may be called with a single tick)
+        self.tick_major = [torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
         # one process group (RCCL communicator) per context: their collectives are independent
-        self.groups = ([dist.new_group() for _ in self.engines] if (batch > 1 and dist is not None) else None)
+        self.groups = [dist.new_group() for _ in self.engines] if dist is not None else None
         self.ready = [torch.cuda.Event() for _ in range(ring)]  # gathered records of the buffer are complete
         self.done = [torch.cuda.Event() for _ in range(ring)]   # the sweep that read the buffer has finished
         self.used = [False] * ring
@@ -197,8 +197,15 @@ class ShardedTick:
         runtime an event wait between two streams costs far more than the collective it would hide,
         and with two contexts the other context's sweep runs under this one's all-gather anyway."""
         torch = self.torch
+        if self.may_draw and self.world > 1:
+            # a partitioned medium whose links draw needs the per-tick draw-count exchange (stage / sweep):
+            # rm_batch_run_device would refuse it with RM_ERR_STATE -- say so here, before anything is enqueued
+            raise ValueError("run_batch cannot place java.util.Random draws across ranks: use stage() / sweep() per tick "
+                             "(or construct ShardedTick with may_draw=False for media without draws)")
         eng, stream = self.engines[ctx], self.streams[ctx]
         nb, row = len(t_begins), self.slots * RECORD_BYTES
+        if nb > self.batch:
+            raise ValueError("run_batch: %d ticks, the buffers hold %d" % (nb, self.batch))
         with torch.cuda.stream(stream):
             eng.pack_tx_batch_device_on(stream.cuda_stream, dev_src_ptr, nb, self.slots, t_begins, air_us,
                                         self.mine[ctx].data_ptr())
