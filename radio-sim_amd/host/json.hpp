@@ -41,7 +41,14 @@ inline std::string java_double_to_string(double d)
     std::string digits;
     for (size_t i = 0; i < epos; ++i)
         if (sci[i] != '.') digits += sci[i];
-    const int exp10 = std::atoi(sci.c_str() + epos + 1);
+    int exp10 = std::atoi(sci.c_str() + epos + 1);
+    if (digits.size() == 1) { // Java always writes two digits, the pair closest to the exact value (4.9E-324, not 5.0E-324)
+        const auto r2 = std::to_chars(buf, buf + sizeof(buf), std::fabs(d), std::chars_format::scientific, 1);
+        const std::string two(buf, r2.ptr); // d.de[+-]XX
+        digits = std::string(1, two[0]);
+        if (two[2] != '0') digits += two[2];
+        exp10 = std::atoi(two.c_str() + 4);
+    }
     std::string out = std::signbit(d) ? "-" : "";
     const double a = std::fabs(d);
     if (a >= 1e-3 && a < 1e7) {

@@ -373,6 +373,9 @@ public:
         firstInFlight_ = on ? rm_events_next_packet(ctx_) : 0;
     }
     bool getDeviceEvents() const { return deviceEvents_; }
+    // packets the medium still refers to (queued, or with events pending on the device), oldest first: a host that
+    // owns the RadioPacket objects may drop all but the last inFlightCount() it handed to transmit()
+    size_t inFlightCount() const { return queue_.size() + inFlight_.size(); }
 
     // the transmit() calls queued in tick mode, in ONE evaluation; then the calls the per-packet mode makes
     void flush() override
