@@ -534,12 +534,15 @@ def main():
     timed_ticks = args.steps * tps
     value = links_per_tick * timed_ticks / elapsed
     if stateful:
-        # every frame on the air is swept against every receiver each tick
+        # the links the ticks resolved: the new frames against every receiver; the frames still on the air keep
+        # their entries in the per-receiver lists on the device and are not swept again
         value = links_done[0] / elapsed
 
     sequential = None
     if stateful:
-        desc += " -- %.2e link evaluations per tick incl. the frames still on the air" % (links_done[0] / timed_ticks)
+        inc, reb = engines[0].air_list_stats()
+        desc += (" -- %.2e link evaluations per tick (new frames only: the frames still on the air stay in the on-air lists on the "
+                 "device; %d ticks added to the lists, %d rebuilt them)" % (links_done[0] / timed_ticks, inc, reb))
     if (inflight > 1 or batch > 1) and sharded is None:
         # the same ticks again, one at a time on one context
         fence()

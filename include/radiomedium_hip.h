@@ -298,6 +298,10 @@ int64_t rm_last_link_evaluations(const rm_context *ctx);
 /* observability (synchronises): the candidate links the sweep's conservative filter handed to the exact stage for the
  * tick of result slot `slot` (0 on the one-launch tick path, which keeps no candidate list) and its heard links */
 int rm_slot_stats(rm_context *ctx, int32_t slot, uint64_t *candidates, uint64_t *heard);
+/* the SINR extension's on-air lists (build-defined, DESIGN.md "Extension spec" E4): how many ticks added only their new
+ * frames to the per-receiver interferer lists kept on the device, and how many rebuilt the lists from every frame on the
+ * air (first tick, after a node / model / partition / capacity change, after a dropped tick, when t_begin went back) */
+int rm_air_list_stats(const rm_context *ctx, uint64_t *incremental_ticks, uint64_t *rebuilt_ticks);
 
 /* ---- several devices behind one caller --------------------------------------------------------------
  * The reference host is ONE process (Main.java:65-73): a group drives n contexts from one host thread, one

@@ -222,10 +222,24 @@ struct rm_context : TickSlot {
     struct AirBatch {
         int count;
         int64_t end_us;
+        uint32_t tick; // AirLists::tick of the call that put the batch on the air
     };
     DevBuf<rm_tx_record> d_air;
     std::vector<AirBatch> air_batches;
     size_t air_head = 0, air_tail = 0;
+    // the per-receiver interferer lists of the frames on the air, alive on the device from tick to tick (rm::AirDev):
+    // a SINR tick evaluates its new frames only, as long as nothing the old entries were computed from has changed
+    struct AirLists {
+        DevBuf<rm::AirEntry> pool;
+        DevBuf<unsigned long long> head;
+        DevBuf<uint32_t> tail, mark, bad;
+        bool valid = false;       // the lists hold exactly the frames on the air
+        uint32_t tick = 0;        // number of the last tick that added entries (1 ..)
+        uint32_t sub_cap = 0;     // entries per sub-ring (a power of two)
+        int64_t last_t_begin = 0;
+        uint64_t rebuilds = 0, incremental = 0;
+    } air;
+    std::vector<uint32_t> onair_tick; // AirLists::tick per frame of `onair`
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
     rm::TransmitResult *h_transmit = nullptr; // host-mapped result block of rm_transmit
@@ -760,8 +774,34 @@ struct TickPlan {
 
 // Buffers and descriptor of one tick in result slot `ts`; `tx` is the on-air list in device memory
 // (build mode: where the records of the source indices `src_list` are written).
+enum { kAirNone = 0, kAirIncremental = 1, kAirRebuild = 2 };
+
+// Can the on-air lists on the device take this tick's new frames as they are?  `oldest` = AirLists::tick of the
+// oldest frame still on the air (0: none).  Anything an old entry was computed from -- the receivers' positions,
+// channels, the model -- shows up as a dirty receiver table or pre-filter.
+uint32_t air_sub_cap(const rm_context *c) // entries per sub-ring: the link capacity over the sub-rings, as a power of two
+{
+    size_t sub = 64;
+    while (sub * rm::kShards < size_t(c->cap)) sub <<= 1;
+    return uint32_t(sub);
+}
+
+bool air_lists_current(const rm_context *c, int64_t t_begin, uint32_t oldest)
+{
+    static const bool off = [] {
+        const char *e = std::getenv("RM_AIR_LISTS"); // 0: rebuild the lists from every frame on the air, every tick
+        return e && std::atoi(e) == 0;
+    }();
+    const rm_context::AirLists &a = c->air;
+    if (off || !a.valid || c->rx_dirty || c->prefilter_dirty || t_begin < a.last_t_begin) return false;
+    if (a.tick + 1 >= rm::kAirTickMax) return false;
+    if (oldest != 0 && (oldest > a.tick || a.tick + 1 - oldest >= rm::kAirTicks - 1)) return false;
+    return a.pool.p != nullptr && a.sub_cap == air_sub_cap(c) && a.head.n >= size_t(std::max(c->n_rx, 1));
+}
+
 int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, const rm_tx_record *tx, int n_active,
-                 int first_new, const int32_t *src_list = nullptr, int64_t src_start_us = 0, int64_t src_air_us = 0)
+                 int first_new, const int32_t *src_list = nullptr, int64_t src_start_us = 0, int64_t src_air_us = 0,
+                 int air_mode = kAirNone, uint32_t air_oldest = 0)
 {
     const int n_new = n_active - first_new;
     ts.have_result = false;
@@ -787,6 +827,43 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.n_active = n_active;
     t.first_new = first_new;
     t.first_eval = sinr ? 0 : first_new;
+    if (sinr && air_mode != kAirNone) {
+        // the lists that live across ticks: kAirIncremental -- `tx` holds the new frames only (first_new == 0);
+        // kAirRebuild -- `tx` holds every frame on the air and all of them leave their entries again
+        rm_context::AirLists &a = c->air;
+        const size_t sub = air_sub_cap(c);
+        if (a.sub_cap != sub || a.head.n < size_t(std::max(rx_count, 1)) || !a.pool.p) {
+            if (air_mode == kAirIncremental) return fail(RM_ERR_STATE, "internal: on-air lists not allocated");
+            RM_HIP(a.pool.ensure(sub * rm::kShards));
+            RM_HIP(a.head.ensure(std::max(rx_count, 1)));
+            RM_HIP(a.tail.ensure(size_t(rm::kShards) * rm::kShardStride));
+            RM_HIP(a.mark.ensure(size_t(rm::kAirTicks) * rm::kShards));
+            RM_HIP(a.bad.ensure(1));
+            a.sub_cap = uint32_t(sub);
+        }
+        if (air_mode == kAirRebuild) {
+            RM_HIP(hipMemsetAsync(a.head.p, 0, a.head.n * sizeof(unsigned long long), c->stream));
+            RM_HIP(hipMemsetAsync(a.tail.p, 0, a.tail.n * sizeof(uint32_t), c->stream));
+            RM_HIP(hipMemsetAsync(a.bad.p, 0, sizeof(uint32_t), c->stream));
+            a.tick = 0;
+            a.rebuilds++;
+        } else {
+            a.incremental++;
+        }
+        a.tick++;
+        a.valid = true;
+        a.last_t_begin = c->t_begin;
+        t.air.pool = a.pool.p;
+        t.air.head = a.head.p;
+        t.air.tail = a.tail.p;
+        t.air.mark = a.mark.p;
+        t.air.bad = a.bad.p;
+        t.air.sub_mask = a.sub_cap - 1u;
+        t.air.sub_shift = uint32_t(__builtin_ctz(a.sub_cap));
+        t.air.tick = a.tick;
+        t.air.wtick = (air_mode == kAirRebuild || air_oldest == 0) ? a.tick : air_oldest;
+        t.air.t_begin = c->t_begin;
+    }
     const int n_eval = n_active - t.first_eval;
     const int n_chunks = (n_eval + rm::kTxChunk - 1) / rm::kTxChunk;
     t.cnt_base = ((first_new - t.first_eval) / rm::kTxChunk) * rm::kTxChunk;
@@ -914,6 +991,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     plan.stochastic = stochastic;
     plan.partitioned = partitioned;
     plan.empty = (n_new <= 0 || rx_count <= 0);
+    if (plan.empty && air_mode == kAirRebuild) c->air.valid = false; // nothing is launched: the lists are rebuilt with the next frames
     if (plan.empty) {
         // nothing to sweep: publish an empty result in this parity's counters
         RM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), c->stream));
@@ -966,7 +1044,8 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
     }();
     const int seg_len = (t.n_active - t.first_new <= frame_tick_max) ? rm::frame_tick_segment(t, cfg, m) : 0;
     auto sequence = [&]() -> int {
-        if (sinr) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        if (sinr && t.air.pool) RM_HIP(rm::launch_air_begin(s, t));
+        else if (sinr) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
         if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         if (seg_len > 0) {
             // the closed-loop tick: filter, exact evaluation and node order of a frame inside one workgroup
@@ -1174,10 +1253,10 @@ int ev_append(rm_context *c, TickSlot &ts)
 }
 
 int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
-             int64_t src_start_us = 0, int64_t src_air_us = 0)
+             int64_t src_start_us = 0, int64_t src_air_us = 0, int air_mode = kAirNone, uint32_t air_oldest = 0)
 {
     TickPlan plan;
-    RM_TRY(prepare_tick(c, *c, plan, false, tx, n_active, first_new, src_list, src_start_us, src_air_us));
+    RM_TRY(prepare_tick(c, *c, plan, false, tx, n_active, first_new, src_list, src_start_us, src_air_us, air_mode, air_oldest));
     RM_TRY(launch_tick(c, *c, plan));
     if (c->ev.on && !c->draws_pending) {
         if (plan.empty && c->last_n_new > 0) {
@@ -1290,6 +1369,7 @@ void rm_destroy(rm_context *c)
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rx_rec32.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
+    c->air.pool.release(); c->air.head.release(); c->air.tail.release(); c->air.mark.release(); c->air.bad.release();
     c->d_patch.release();
     c->d_enabled.release();
     (void)rm_events_disable(c);
@@ -1359,6 +1439,8 @@ int rm_set_model(rm_context *c, const rm_model_params *p)
     c->air_batches.clear();
     c->air_head = c->air_tail = 0;
     c->onair.clear();
+    c->onair_tick.clear();
+    c->air.valid = false;
     c->pending.clear();
     return RM_OK;
 }
@@ -1465,6 +1547,8 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     c->air_batches.clear();
     c->air_head = c->air_tail = 0;
     c->onair.clear();
+    c->onair_tick.clear();
+    c->air.valid = false;
     c->pending.clear();
     if (c->rx_count >= 0 && c->rx_first + c->rx_count > n) {
         c->rx_first = 0;
@@ -1533,6 +1617,14 @@ int rm_set_link_capacity(rm_context *c, uint32_t max_links)
     return RM_OK;
 }
 
+int rm_air_list_stats(const rm_context *c, uint64_t *incremental_ticks, uint64_t *rebuilt_ticks)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    if (incremental_ticks) *incremental_ticks = c->air.incremental;
+    if (rebuilt_ticks) *rebuilt_ticks = c->air.rebuilds;
+    return RM_OK;
+}
+
 int rm_set_time(rm_context *c, int64_t t)
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
@@ -1559,11 +1651,18 @@ int rm_tick_begin(rm_context *c, int64_t t_begin_us, int64_t t_end_us)
     c->tick_frac_records = false;
     if (is_sinr(c)) {
         size_t k = 0;
+        c->onair_tick.resize(c->onair.size(), 0u);
         for (size_t i = 0; i < c->onair.size(); ++i)
-            if (still_on_air(c->onair[i], t_begin_us)) c->onair[k++] = c->onair[i];
+            if (still_on_air(c->onair[i], t_begin_us)) {
+                c->onair_tick[k] = c->onair_tick[i];
+                c->onair[k++] = c->onair[i];
+            }
         c->onair.resize(k);
+        c->onair_tick.resize(k);
     } else {
         c->onair.clear();
+        c->onair_tick.clear();
+        c->air.valid = false;
     }
     c->in_tick = true;
     return RM_OK;
@@ -1626,7 +1725,10 @@ static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uin
             for (int i = 0; i <= std::max(n_new, 0); ++i) pkt_offset[i] = 0;
     }
     RM_HIP(hipStreamSynchronize(s));
-    if (oc[1]) return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    if (oc[1]) {
+        c->air.valid = false; // a dropped SINR tick leaves the on-air lists incomplete
+        return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    }
     if (oc[2] > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
     return RM_OK;
 }
@@ -1717,11 +1819,14 @@ int rm_tick_run(rm_context *c)
     return tick_run_host(c);
 }
 
-static int stage_status(const rm::HostView &v)
+static int stage_status(rm_context *c, const rm::HostView &v)
 {
     if (v.hdr->span_flag)
         return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
-    if (v.hdr->dropped) return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    if (v.hdr->dropped) {
+        c->air.valid = false;
+        return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    }
     return RM_OK;
 }
 
@@ -1740,7 +1845,7 @@ int rm_tick_flush_view(rm_context *c, rm_host_result *out)
     out->verdict = v.verdict;
     out->rssi = v.rssi;
     out->sinr = c->last.out_sinr ? v.sinr : nullptr; // written by the SINR extension only
-    return stage_status(v);
+    return stage_status(c, v);
 }
 
 int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
@@ -1750,7 +1855,7 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
     RM_TRY(tick_run_host(c));
     rm::HostView v{};
     RM_TRY(pack_to_stage(c, *c, &v));
-    if (v.hdr->span_flag) return stage_status(v);
+    if (v.hdr->span_flag) return stage_status(c, v);
     if (count) *count = v.hdr->total;
     const uint32_t k = std::min(v.hdr->stored, cap);
     if (k) {
@@ -1764,7 +1869,7 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
     const uint32_t np = v.hdr->n_packets;
     if (pkt_interference && np) std::memcpy(pkt_interference, v.pkt_interference, np);
     if (pkt_offset) std::memcpy(pkt_offset, v.pkt_offset, (size_t(np) + 1) * sizeof(uint32_t));
-    RM_TRY(stage_status(v));
+    RM_TRY(stage_status(c, v));
     if (v.hdr->total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
     return RM_OK;
 }
@@ -1776,8 +1881,23 @@ static int tick_run_host(rm_context *c)
     if (!c->in_tick) return fail(RM_ERR_STATE, "rm_tick_flush without rm_tick_begin");
     RM_HIP(hipSetDevice(c->device));
     c->in_tick = false;
-    const int first_new = int(c->onair.size());
-    const size_t total = c->onair.size() + c->pending.size();
+    // SINR: the frames of earlier ticks have their entries in the lists on the device -- only the new frames go there
+    // (and are evaluated), unless the lists have to be rebuilt from everything on the air
+    const bool sinr = is_sinr(c);
+    int air_mode = kAirNone;
+    uint32_t oldest = 0;
+    if (sinr) {
+        for (const rm_tx_record &r : c->pending)
+            if (r.air_us < 0 || r.air_us > int64_t(UINT32_MAX))
+                return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
+        c->onair_tick.resize(c->onair.size(), 0u);
+        for (uint32_t k : c->onair_tick) oldest = (oldest == 0 || k < oldest) ? k : oldest;
+        const bool unknown = std::find(c->onair_tick.begin(), c->onair_tick.end(), 0u) != c->onair_tick.end();
+        air_mode = (!unknown && air_lists_current(c, c->t_begin, oldest)) ? kAirIncremental : kAirRebuild;
+    }
+    const size_t n_old = (air_mode == kAirIncremental) ? 0 : c->onair.size();
+    const int first_new = int(n_old);
+    const size_t total = n_old + c->pending.size();
     RM_HIP(c->d_tx.ensure(std::max<size_t>(total, 1)));
     if (total) {
         // through pinned staging: the copy is asynchronous, the buffer is reused only after its copy has completed
@@ -1793,16 +1913,22 @@ static int tick_run_host(rm_context *c)
             RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_tx[g]), want * sizeof(rm_tx_record), hipHostMallocDefault));
             c->h_tx_n[g] = want;
         }
-        if (!c->onair.empty()) std::memcpy(c->h_tx[g], c->onair.data(), c->onair.size() * sizeof(rm_tx_record));
-        if (!c->pending.empty())
-            std::memcpy(c->h_tx[g] + c->onair.size(), c->pending.data(), c->pending.size() * sizeof(rm_tx_record));
+        if (n_old) std::memcpy(c->h_tx[g], c->onair.data(), n_old * sizeof(rm_tx_record));
+        if (!c->pending.empty()) std::memcpy(c->h_tx[g] + n_old, c->pending.data(), c->pending.size() * sizeof(rm_tx_record));
         RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
         RM_HIP(hipEventRecord(c->h_tx_ev[g], c->stream));
     }
-    const int rc = run_tick(c, c->d_tx.p, int(total), first_new);
+    const int rc = run_tick(c, c->d_tx.p, int(total), first_new, nullptr, 0, 0, air_mode, oldest);
     c->tick_frac_records = false;
-    if (rc != RM_OK) return rc;
-    if (is_sinr(c)) c->onair.insert(c->onair.end(), c->pending.begin(), c->pending.end());
+    if (rc != RM_OK) {
+        c->air.valid = false;
+        return rc;
+    }
+    if (sinr) {
+        if (air_mode == kAirRebuild) std::fill(c->onair_tick.begin(), c->onair_tick.end(), c->air.tick);
+        c->onair.insert(c->onair.end(), c->pending.begin(), c->pending.end());
+        c->onair_tick.resize(c->onair.size(), c->air.tick);
+    }
     c->pending.clear();
     return RM_OK;
 }
@@ -1828,6 +1954,8 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
     c->in_tick = false;
     c->pending.clear();
     c->onair.clear();
+    c->onair_tick.clear();
+    c->air.valid = false;
     if (!c->h_transmit) {
         RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_transmit), sizeof(rm::TransmitResult), hipHostMallocMapped));
         std::memset(c->h_transmit, 0, sizeof(rm::TransmitResult));
@@ -1893,7 +2021,10 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
         if (rssi) std::memcpy(rssi, r.rssi, k * sizeof(double));
         if (sinr) std::memcpy(sinr, r.sinr, k * sizeof(double));
     }
-    if (r.dropped) return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    if (r.dropped) {
+        c->air.valid = false;
+        return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+    }
     if (r.total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
     return RM_OK;
 }
@@ -1997,11 +2128,26 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
         c->air_head = 0;
         c->air_tail = live;
     }
-    const int first_new = int(live);
-    const int rc = run_tick(c, c->d_air.p + c->air_head, first_new + n, first_new, dev_src, start_us, air_us);
-    if (rc != RM_OK) return rc;
+    if (air_us > int64_t(UINT32_MAX)) return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
+    uint32_t oldest = 0;
+    bool unknown = false;
+    for (const auto &bt : c->air_batches) {
+        unknown = unknown || bt.tick == 0;
+        oldest = (oldest == 0 || bt.tick < oldest) ? bt.tick : oldest;
+    }
+    const int air_mode = (!unknown && air_lists_current(c, t_begin_us, oldest)) ? kAirIncremental : kAirRebuild;
+    // the records of the new frames are built at the window's tail either way; an incremental tick sweeps only those
+    const int first_new = (air_mode == kAirIncremental) ? 0 : int(live);
+    const rm_tx_record *base = c->d_air.p + c->air_head + (air_mode == kAirIncremental ? live : 0);
+    const int rc = run_tick(c, base, first_new + n, first_new, dev_src, start_us, air_us, air_mode, oldest);
+    if (rc != RM_OK) {
+        c->air.valid = false;
+        return rc;
+    }
+    if (air_mode == kAirRebuild)
+        for (auto &bt : c->air_batches) bt.tick = c->air.tick;
     c->air_tail += size_t(n);
-    if (n > 0) c->air_batches.push_back({n, start_us + air_us});
+    if (n > 0) c->air_batches.push_back({n, start_us + air_us, c->air.tick});
     return RM_OK;
 }
 
@@ -2230,6 +2376,8 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
                 return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run "
                                           "overlapping ticks one at a time");
         c->onair.clear();
+        c->onair_tick.clear();
+        c->air.valid = false; // the ticks of a batch keep their lists to themselves
         c->air_batches.clear();
         c->air_head = c->air_tail = 0;
     }
@@ -2270,7 +2418,7 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         }
     if (sinr && dev_src && n_per[n_ticks - 1] > 0) {
         c->air_tail = size_t(n_per[n_ticks - 1]);
-        c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1]});
+        c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1], 0u});
     }
     if (batched) {
         if (sinr)
@@ -2543,7 +2691,7 @@ int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdic
         o.verdict = v.verdict;
         o.rssi = v.rssi;
         o.sinr = c->last.out_sinr ? v.sinr : nullptr;
-        const int st = stage_status(v);
+        const int st = stage_status(c, v);
         if (st != RM_OK && first_error == RM_OK) {
             first_error = st;
             first_msg = g_err;
@@ -2686,6 +2834,7 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
     out->packet = o.pkt;
     out->dst = o.dst;
     out->rssi = o.rssi;
+    if (o.hdr->err & 8u) c->air.valid = false;
     if (o.hdr->err & 8u) return fail(RM_ERR_CAPACITY, "a tick's heard links exceeded the link capacity (rm_set_link_capacity): its events are missing");
     if (o.hdr->err) return fail(RM_ERR_CAPACITY, "the reception stage ran out of room for pending packets / links (rm_events_enable)");
     if (o.hdr->total > o.hdr->count) return fail(RM_ERR_CAPACITY, "more deliveries than the delivery block holds");

@@ -129,7 +129,38 @@ struct NodesDev {
     float2 *wg_box_z;
 };
 
+// SINR across ticks: the frames on the air leave their significant links in per-receiver lists that live on the
+// device from tick to tick, so that a tick evaluates its NEW frames only.  An entry carries everything the interference
+// sum reads (one 32-byte load per hop).  Entries are allocated from kShards sub-rings in tick order; a tick's
+// allocations begin at mark[tick][sub], and everything older than the oldest tick that still has a frame on the air
+// (wtick) is free again.  Links are validated while walking: a head or next pointer is followed only while the ticks
+// do not increase along the list and stay >= wtick (an insertion stores the previous head only if it was live, so a
+// reclaimed slot can only come back with a newer tick than the entry that points to it).
+struct AirEntry {
+    int64_t start_us;
+    double lin;       // linear power at the receiver
+    uint32_t air_us;  // SINR frames are shorter than 2^32 us (checked when they are enqueued)
+    int32_t next;
+    uint32_t meta;    // tick << 2 | kAirSelf | kAirInterferer
+    uint32_t pad;
+};
+constexpr uint32_t kAirSelf = 1, kAirInterferer = 2;
+constexpr uint32_t kAirTicks = 1024;      // marks kept: a frame that stays longer makes the host rebuild the lists
+constexpr uint32_t kAirTickMax = (1u << 30) - 8;
+
+struct AirDev {
+    AirEntry *pool;            // nullptr: the lists are per tick (st_next / head; batches of self-contained ticks)
+    unsigned long long *head;  // [n_rx] tick << 32 | entry; 0 = empty (ticks start at 1)
+    uint32_t *tail;            // [kShards * kShardStride] entries ever allocated in the sub-ring
+    uint32_t *mark;            // [kAirTicks][kShards] tail when the tick began
+    uint32_t *bad;             // [1] an allocation ran over live entries: the lists are unusable until rebuilt
+    uint32_t sub_mask, sub_shift;
+    uint32_t tick, wtick;
+    int64_t t_begin;           // entries with start + air <= t_begin have left the air
+};
+
 struct TickDev {
+    AirDev air;
     const rm_tx_record *tx; // on-air list, canonical order [n_active]
     // build mode (single tick of new frames given as source indices): k_filter builds the records
     // from the source table while staging its tile and writes them to tx_build (== tx) for k_exact
@@ -395,6 +426,7 @@ hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const Mod
 hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t, int n_new, const HostView &v, uint32_t *done_counter,
                               uint32_t seq);
 hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev &t);
+hipError_t launch_air_begin(hipStream_t s, const TickDev &t);
 hipError_t launch_offsets(hipStream_t s, const TickDev &t);
 hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t);
 hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,

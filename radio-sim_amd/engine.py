@@ -398,6 +398,12 @@ class Engine:
         check(self._L.rm_slot_stats(self._h, slot, C.byref(cand), C.byref(heard)))
         return cand.value, heard.value
 
+    def air_list_stats(self):
+        """(ticks that only added their new frames to the on-air lists, ticks that rebuilt the lists) -- SINR extension"""
+        inc, reb = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.rm_air_list_stats(self._h, C.byref(inc), C.byref(reb)))
+        return inc.value, reb.value
+
     def last_link_evaluations(self):
         return self._L.rm_last_link_evaluations(self._h)
 

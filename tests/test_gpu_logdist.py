@@ -190,3 +190,116 @@ def test_sinr_device_resident_on_air_list(engine, rsa, O):
         interfered += int((cpu.verdict == O.INTERFERED).sum())
         onair = active
     assert interfered > 100
+
+
+def _overlap_run(engine, rsa, O, nd, mdl, rng, ticks, per_tick, airs, hook=None, t_of=None, what=""):
+    """ticks of new frames through the tick API against the oracle's tick over the full on-air list"""
+    n = nd.n
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    interfered = 0
+    for tick in range(ticks):
+        t0 = tick * 1000 if t_of is None else t_of(tick)
+        if hook is not None:
+            hook(tick)
+        onair = onair[onair["start_us"] + onair["air_us"] > t0]
+        k = int(per_tick(tick)) if callable(per_tick) else per_tick
+        src = np.sort(rng.choice(n, k, replace=False)) if k else np.zeros(0, dtype=np.int64)
+        new = nd.packets(src, 0, 0)
+        new["start_us"] = t0 + rng.integers(0, 1000, len(new))
+        new["air_us"] = rng.choice(airs, len(new))
+        active = np.concatenate([onair, new])
+        cpu = O.tick(mdl, nd, active, first_new=len(onair))
+        engine.tick_begin(t0, t0 + 1000)
+        engine.enqueue_records(to_tx_records(rsa, new))
+        try:
+            gpu = engine.tick_flush()
+        except rsa.RadioMediumError as e:
+            raise AssertionError("%s tick %d (%d new frames, %d on the air, lists %r): %s" % (
+                what, tick, len(new), len(onair), engine.air_list_stats(), e))
+        assert_same(gpu, cpu, "%s tick %d" % (what, tick))
+        interfered += int((cpu.verdict == O.INTERFERED).sum())
+        onair = active
+    return interfered
+
+
+def test_sinr_lists_live_across_ticks(engine, rsa, O):
+    """The per-receiver interferer lists stay on the device: a tick adds its new frames only.  A small link capacity
+    makes the entry rings wrap many times; frames of very different lengths leave the air out of order; empty ticks."""
+    n = 10000                                       # enough receiver groups to spread the candidates over the shards
+    nd = _layout(O, n, seed=41)
+    rng = np.random.default_rng(12)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    engine.set_link_capacity(1 << 19)               # 2048 entries per sub-ring: ~1M entries wrap them twice
+    mdl = oracle_model(O, "logdist", params)
+    inc0, reb0 = engine.air_list_stats()
+    got = _overlap_run(engine, rsa, O, nd, mdl, rng, 200, lambda t: 0 if t % 17 == 5 else rng.integers(1, 30),
+                       [320, 2048, 8128, 8128, 20000], what="rings")
+    inc, reb = engine.air_list_stats()
+    assert got > 100
+    assert (inc - inc0, reb - reb0) == (199, 1)     # one build, then only new frames
+
+
+def test_sinr_lists_rebuilt_when_something_changes(engine, rsa, O):
+    """Whatever an old entry was computed from may change while its frame is on the air: a receiver moves or changes
+    its channel, the model changes, the clock goes back.  The next tick rebuilds the lists from every frame on the
+    air (the oracle evaluates the full on-air list against the node table as it is now)."""
+    n = 2000
+    nd = _layout(O, n, seed=43)
+    rng = np.random.default_rng(13)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+
+    def hook(tick):
+        if tick in (4, 9):                          # a receiver in the middle of the traffic moves next to a sender
+            i = int(rng.integers(n))
+            nd.x[i], nd.y[i] = nd.x[(i + 1) % n] + 1.0, nd.y[(i + 1) % n]
+            if tick == 9:
+                nd.channel[i] = 11
+            engine.update_node(i, nd.x[i], nd.y[i], nd.z[i], nd.txpower[i], int(nd.channel[i]), int(nd.enabled[i]),
+                               nd.rxprob[i], nd.txprob[i])
+        if tick == 14:
+            engine.move_nodes(np.arange(5, dtype=np.int32), nd.x[:5] + 3.0, nd.y[:5])
+            nd.x[:5] += 3.0
+            nd.z[:5] = 0.0
+
+    inc0, reb0 = engine.air_list_stats()
+    # tick 12 begins before tick 11 did: frames that had left the air do not come back
+    t_of = lambda t: (t * 1000 if t != 12 else 9500)
+    got = _overlap_run(engine, rsa, O, nd, mdl, rng, 20, 35, [320, 2048, 8128], hook=hook, t_of=t_of, what="changes")
+    inc, reb = engine.air_list_stats()
+    assert got > 30
+    assert reb - reb0 == 5 and inc - inc0 == 15     # first tick, three node changes, the clock going back
+
+
+def test_sinr_lists_after_a_dropped_tick(engine, rsa, O):
+    """A tick whose links do not fit the capacity is reported and leaves the lists unusable; with more room the
+    next tick rebuilds them and is exact again."""
+    n = 10000
+    nd = _layout(O, n, seed=47)
+    rng = np.random.default_rng(14)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    engine.set_link_capacity(1 << 16)
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    failed = 0
+    for tick in range(8):
+        t0 = tick * 1000
+        onair = onair[onair["start_us"] + onair["air_us"] > t0]
+        src = np.sort(rng.choice(n, 900 if tick == 3 else 10, replace=False))
+        new = nd.packets(src, t0, 8128)
+        active = np.concatenate([onair, new])
+        cpu = O.tick(mdl, nd, active, first_new=len(onair))
+        engine.tick_begin(t0, t0 + 1000)
+        engine.enqueue_records(to_tx_records(rsa, new))
+        try:
+            gpu = engine.tick_flush()
+            assert_same(gpu, cpu, "after a dropped tick, tick %d" % tick)
+        except rsa.RadioMediumError as e:
+            assert "capacity" in str(e)
+            failed += 1
+            engine.set_link_capacity(1 << 22)
+        onair = active
+    assert failed == 1
