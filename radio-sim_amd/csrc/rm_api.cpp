@@ -827,7 +827,10 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.n_active = n_active;
     t.first_new = first_new;
     t.first_eval = sinr ? 0 : first_new;
-    if (sinr && air_mode != kAirNone) {
+    const bool nothing_to_sweep = (n_new <= 0 || rx_count <= 0); // no launch at all: the lists stay as they are
+    if (sinr && air_mode == kAirRebuild && nothing_to_sweep) c->air.valid = false; // rebuilt with the next frames
+    if (sinr && air_mode == kAirIncremental && nothing_to_sweep) c->air.last_t_begin = c->t_begin;
+    if (sinr && air_mode != kAirNone && !nothing_to_sweep) {
         // the lists that live across ticks: kAirIncremental -- `tx` holds the new frames only (first_new == 0);
         // kAirRebuild -- `tx` holds every frame on the air and all of them leave their entries again
         rm_context::AirLists &a = c->air;
@@ -845,6 +848,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
             RM_HIP(hipMemsetAsync(a.head.p, 0, a.head.n * sizeof(unsigned long long), c->stream));
             RM_HIP(hipMemsetAsync(a.tail.p, 0, a.tail.n * sizeof(uint32_t), c->stream));
             RM_HIP(hipMemsetAsync(a.bad.p, 0, sizeof(uint32_t), c->stream));
+            RM_HIP(hipMemsetAsync(a.mark.p + rm::kShards, 0, rm::kShards * sizeof(uint32_t), c->stream)); // tick 1 begins at 0
             a.tick = 0;
             a.rebuilds++;
         } else {
@@ -991,7 +995,6 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     plan.stochastic = stochastic;
     plan.partitioned = partitioned;
     plan.empty = (n_new <= 0 || rx_count <= 0);
-    if (plan.empty && air_mode == kAirRebuild) c->air.valid = false; // nothing is launched: the lists are rebuilt with the next frames
     if (plan.empty) {
         // nothing to sweep: publish an empty result in this parity's counters
         RM_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), c->stream));
@@ -1044,8 +1047,10 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
     }();
     const int seg_len = (t.n_active - t.first_new <= frame_tick_max) ? rm::frame_tick_segment(t, cfg, m) : 0;
     auto sequence = [&]() -> int {
-        if (sinr && t.air.pool) RM_HIP(rm::launch_air_begin(s, t));
-        else if (sinr) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        const bool air = sinr && t.air.pool != nullptr;
+        const bool air_in_prep = air && t.filter_mode == rm::kFilterWg; // k_tick_prep leaves the SELF entries and looks at the sticky flag
+        if (air && !air_in_prep) RM_HIP(rm::launch_air_begin(s, t));
+        else if (sinr && !air) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
         if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         if (seg_len > 0) {
             // the closed-loop tick: filter, exact evaluation and node order of a frame inside one workgroup
@@ -1069,7 +1074,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         RM_TRY(stage(RM_STAGE_EXACT));
         RM_HIP(rm::launch_seg_scan(s, t));
         RM_HIP(rm::launch_exact(s, nd, m, t, cfg));
-        if (sinr) {
+        if (sinr && !air_in_prep) {
             RM_TRY(stage(RM_STAGE_SELF));
             RM_HIP(rm::launch_self_entries(s, nd, t));
         }
@@ -1077,7 +1082,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
             RM_TRY(stage(RM_STAGE_OFFSETS));
             RM_HIP(rm::launch_offsets(s, t));
         }
-        if (sinr) {
+        if (sinr && !(air && cfg.sorted)) { // sorted tables with the cross-tick lists: k_reorder walks the lists itself
             RM_TRY(stage(RM_STAGE_SINR));
             RM_HIP(rm::launch_sinr(s, m, t));
         }

@@ -385,6 +385,93 @@ RM_D uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave /*[16]*/, u
 }
 
 // per-packet Tx-failure flag where no draw can happen (txSuccess <= 0 is the only way to fail)
+// ---- the on-air lists across ticks (AirDev, rm_engine.h)
+// room for the wanted lanes' entries in sub-ring `sub`: one atomic per wave.  Whole waves call this together.
+RM_D int air_alloc(const TickDev &t, bool want, uint32_t sub)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    const uint32_t cnt = uint32_t(__popcll(mask));
+    uint32_t base = 0;
+    if (lane == leader) {
+        base = atomicAdd(&t.air.tail[sub * kShardStride], cnt);
+        const uint32_t live0 = t.air.mark[(t.air.wtick & (kAirTicks - 1)) * kShards + sub];
+        if (base + cnt - live0 > t.air.sub_mask + 1u) { // would overwrite entries of frames still on the air
+            t.stage_count[1] = 1u;
+            t.air.bad[0] = 1u; // sticky: every later tick is dropped as well until the host has rebuilt the lists
+        }
+    }
+    base = uint32_t(__shfl(int(base), leader));
+    if (!want) return -1;
+    const uint32_t seq = base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+    return int((sub << t.air.sub_shift) | (seq & t.air.sub_mask));
+}
+
+RM_D uint32_t air_sub(const TickDev &t)
+{
+    return (blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 17u + t.air.tick * 61u) & uint32_t(kShards - 1);
+}
+
+// the entry becomes the head of its receiver's list; the old head is kept as `next` only if it is still live
+RM_D void air_link(const TickDev &t, int aidx, int pos, int64_t start_us, int64_t air_us, double lin, uint32_t flags)
+{
+    const unsigned long long mine = ((unsigned long long)t.air.tick << 32) | uint32_t(aidx);
+    const unsigned long long old = atomicExch(&t.air.head[pos], mine);
+    AirEntry e;
+    e.start_us = start_us;
+    e.lin = lin;
+    e.air_us = uint32_t(air_us);
+    e.next = (uint32_t(old >> 32) >= t.air.wtick) ? int(uint32_t(old)) : -1; // an empty head has tick 0
+    e.meta = (t.air.tick << 2) | flags;
+    e.pad = 0u;
+    t.air.pool[aidx] = e;
+}
+
+// The tick is over for the lists: the next tick's entries begin where the sub-rings' tails are now.  One workgroup of
+// kShards threads, after the last allocation of the tick (a later kernel than the one that evaluates the links).
+RM_D void air_end(const TickDev &t)
+{
+    if (threadIdx.x < uint32_t(kShards))
+        t.air.mark[((t.air.tick + 1u) & (kAirTicks - 1)) * kShards + threadIdx.x] = t.air.tail[threadIdx.x * kShardStride];
+}
+
+struct SinrOut {
+    double sinr;
+    bool collided;
+};
+
+// SINR of one heard link of a new frame (start w_start, length w_air) at the receiver in engine position `pos`: the
+// receiver's list holds every co-channel frame on the air that is significant there; the interferers that overlap the
+// frame in time are summed exactly (Q80: the order of the list does not matter), a SELF entry is half duplex.
+// `self` is the link's own entry.
+RM_D SinrOut air_sinr(const ModelDev &m, const TickDev &t, int pos, int self, int64_t w_start, int64_t w_air, double rssi)
+{
+    U128 acc = {0, 0};
+    bool half_duplex = false;
+    const int64_t w_end = w_start + w_air;
+    const unsigned long long h = t.air.head[pos];
+    uint32_t prev = uint32_t(h >> 32);
+    int idx = (prev >= t.air.wtick) ? int(uint32_t(h)) : -1;
+    for (int hops = 0; idx >= 0 && hops < (1 << 22); ++hops) {
+        const AirEntry k = t.air.pool[idx];
+        const uint32_t kt = k.meta >> 2;
+        if (kt > prev || kt < t.air.wtick) break; // a slot that was handed out again: the list ended before it
+        prev = kt;
+        const int64_t k_end = k.start_us + int64_t(k.air_us);
+        if (idx != self && k_end > t.air.t_begin && k.start_us < w_end && k_end > w_start) {
+            if (k.meta & kAirSelf) half_duplex = true;
+            else acc = u128_add(acc, q80_from_double(k.lin));
+        }
+        idx = k.next;
+    }
+    SinrOut r;
+    r.sinr = rssi - 10.0 * det_log10(q80_to_double(acc) + m.ld_noise_lin);
+    r.collided = half_duplex || !(r.sinr >= m.ld_capture);
+    return r;
+}
+
 RM_D void write_pkt_interference(const ModelDev &m, const TickDev &t, uint32_t first, uint32_t stride)
 {
     const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);

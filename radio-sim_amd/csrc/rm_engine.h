@@ -131,12 +131,15 @@ struct NodesDev {
 
 // SINR across ticks: the frames on the air leave their significant links in per-receiver lists that live on the
 // device from tick to tick, so that a tick evaluates its NEW frames only.  An entry carries everything the interference
-// sum reads (one 32-byte load per hop).  Entries are allocated from kShards sub-rings in tick order; a tick's
-// allocations begin at mark[tick][sub], and everything older than the oldest tick that still has a frame on the air
-// (wtick) is free again.  Links are validated while walking: a head or next pointer is followed only while the ticks
-// do not increase along the list and stay >= wtick (an insertion stores the previous head only if it was live, so a
-// reclaimed slot can only come back with a newer tick than the entry that points to it).
-struct AirEntry {
+// sum reads.  Entries are allocated from kShards sub-rings in tick order; a tick's allocations begin at
+// mark[tick][sub], and everything older than the oldest tick that still has a frame on the air (wtick) is free again.
+// Links are validated while walking: a head or a pointer is followed only while the ticks do not increase along the
+// list and stay >= wtick (an insertion stores the previous head only if it was live, so a reclaimed slot can only come
+// back with a newer tick than the entry that points to it).
+// One 32-byte entry = half a cache line, never straddling two.  (What a walk costs is the number of cache lines a
+// compute unit has to fetch at random, not the length of the chain: entries with four successor pointers, and copies of a
+// receiver's newest entries side by side, were both measured and made the walk no faster, the insertion slower.)
+struct alignas(32) AirEntry {
     int64_t start_us;
     double lin;       // linear power at the receiver
     uint32_t air_us;  // SINR frames are shorter than 2^32 us (checked when they are enqueued)
@@ -144,6 +147,7 @@ struct AirEntry {
     uint32_t meta;    // tick << 2 | kAirSelf | kAirInterferer
     uint32_t pad;
 };
+static_assert(sizeof(AirEntry) == 32, "half a cache line");
 constexpr uint32_t kAirSelf = 1, kAirInterferer = 2;
 constexpr uint32_t kAirTicks = 1024;      // marks kept: a frame that stays longer makes the host rebuild the lists
 constexpr uint32_t kAirTickMax = (1u << 30) - 8;

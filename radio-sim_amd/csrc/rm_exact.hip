@@ -6,53 +6,9 @@
 
 namespace rm {
 
-// ---- the on-air lists across ticks (AirDev, rm_engine.h)
-// room for the wanted lanes' entries in sub-ring `sub`: one atomic per wave.  Whole waves call this together.
-RM_D int air_alloc(const TickDev &t, bool want, uint32_t sub)
+// grid-filter ticks have no k_tick_prep: the sticky overflow flag is looked at here
+__global__ void __launch_bounds__(64) k_air_begin(TickDev t)
 {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return -1;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    const uint32_t cnt = uint32_t(__popcll(mask));
-    uint32_t base = 0;
-    if (lane == leader) {
-        base = atomicAdd(&t.air.tail[sub * kShardStride], cnt);
-        const uint32_t live0 = t.air.mark[(t.air.wtick & (kAirTicks - 1)) * kShards + sub];
-        if (base + cnt - live0 > t.air.sub_mask + 1u) { // would overwrite entries of frames still on the air
-            t.stage_count[1] = 1u;
-            t.air.bad[0] = 1u; // sticky: every later tick is dropped as well until the host has rebuilt the lists
-        }
-    }
-    base = uint32_t(__shfl(int(base), leader));
-    if (!want) return -1;
-    const uint32_t seq = base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-    return int((sub << t.air.sub_shift) | (seq & t.air.sub_mask));
-}
-
-RM_D uint32_t air_sub(const TickDev &t)
-{
-    return (blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 17u + t.air.tick * 61u) & uint32_t(kShards - 1);
-}
-
-// the entry becomes the head of its receiver's list; the old head is kept as `next` only if it is still live
-RM_D void air_link(const TickDev &t, int aidx, int pos, int64_t start_us, int64_t air_us, double lin, uint32_t flags)
-{
-    const unsigned long long mine = ((unsigned long long)t.air.tick << 32) | uint32_t(aidx);
-    const unsigned long long old = atomicExch(&t.air.head[pos], mine);
-    AirEntry e;
-    e.start_us = start_us;
-    e.lin = lin;
-    e.air_us = uint32_t(air_us);
-    e.next = (uint32_t(old >> 32) >= t.air.wtick) ? int(uint32_t(old)) : -1; // an empty head has tick 0
-    e.meta = (t.air.tick << 2) | flags;
-    e.pad = 0u;
-    t.air.pool[aidx] = e;
-}
-
-__global__ void __launch_bounds__(256) k_air_begin(TickDev t)
-{
-    t.air.mark[(t.air.tick & (kAirTicks - 1)) * kShards + threadIdx.x] = t.air.tail[threadIdx.x * kShardStride]; // kBlock == kShards
     if (threadIdx.x == 0 && t.air.bad[0]) t.stage_count[1] = 1u;
 }
 
@@ -404,25 +360,12 @@ RM_D void sinr_body(const ModelDev &m, const TickDev &t)
         const rm_tx_record w = t.tx[t.first_eval + t.st_pkt[e]];
         U128 acc = {0, 0};
         bool half_duplex = false;
-        if (t.air.pool != nullptr) { // the lists that live across ticks: one 32-byte entry per hop
-            const int self = t.st_next[e];
-            const unsigned long long h = t.air.head[pos];
-            uint32_t prev = uint32_t(h >> 32);
-            int idx = (prev >= t.air.wtick) ? int(uint32_t(h)) : -1;
-            const int64_t w_end = w.start_us + w.air_us;
-            for (int hops = 0; idx >= 0 && hops < (1 << 22); ++hops) {
-                const AirEntry k = t.air.pool[idx];
-                const uint32_t kt = k.meta >> 2;
-                if (kt > prev || kt < t.air.wtick) break; // a slot that was handed out again: the list ended before it
-                prev = kt;
-                const int64_t k_end = k.start_us + int64_t(k.air_us);
-                if (idx != self && k_end > t.air.t_begin && k.start_us < w_end && k_end > w.start_us) {
-                    if (k.meta & kAirSelf) half_duplex = true;
-                    else acc = u128_add(acc, q80_from_double(k.lin));
-                }
-                idx = k.next;
-            }
-        } else
+        if (t.air.pool != nullptr) { // the lists that live across ticks (unsorted tables: sorted ones do this in k_reorder)
+            const SinrOut so = air_sinr(m, t, pos, t.st_next[e], w.start_us, w.air_us, t.st_aux[e]);
+            t.st_sinr[e] = so.sinr;
+            t.st_coll[e] = so.collided ? 1 : 0;
+            continue;
+        }
         for (int idx = t.head[pos]; idx >= 0; idx = t.st_next[idx]) {
             if (uint32_t(idx) == e) continue;
             const rm_tx_record k = t.tx[t.first_eval + t.st_pkt[idx]];
@@ -443,7 +386,11 @@ RM_D void sinr_body(const ModelDev &m, const TickDev &t)
     }
 }
 
-__global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t) { sinr_body(m, t); }
+__global__ void __launch_bounds__(256) k_sinr(ModelDev m, TickDev t)
+{
+    sinr_body(m, t);
+    if (t.air.pool != nullptr && blockIdx.x == 0 && blockIdx.y == 0) air_end(t);
+}
 
 __global__ void __launch_bounds__(256) k_sinr_batch(const ModelDev m, const TickDev *__restrict__ ticks)
 {
@@ -543,7 +490,7 @@ hipError_t launch_seg_scan(hipStream_t s, const TickDev &t)
 
 hipError_t launch_air_begin(hipStream_t s, const TickDev &t)
 {
-    hipLaunchKernelGGL(k_air_begin, dim3(1), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(k_air_begin, dim3(1), dim3(64), 0, s, t);
     return hipGetLastError();
 }
 

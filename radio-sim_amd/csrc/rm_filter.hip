@@ -396,6 +396,23 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     if (t.reset_heads) // SINR tick of a batch: every receiver's link list starts empty
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n_rx; i += gridDim.x * blockDim.x) t.head[i] = -1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t.air.pool != nullptr) { // block-uniform.  SINR with the lists that live across ticks:
+        if (blockIdx.x == 0 && threadIdx.x == 0 && t.air.bad[0]) t.stage_count[1] = 1u; // the lists are broken until the host rebuilds them
+        // half duplex: every swept frame leaves a SELF entry in its source's list (whole waves allocate together)
+        bool want = false;
+        int pos = 0;
+        rm_tx_record txs{};
+        if (e < n_eval) {
+            const int ai = t.first_eval + e;
+            txs = (t.src_list && ai >= t.first_new) ? make_tx_record(nd, t.src_list[ai - t.first_new], t.src_start_us, t.src_air_us) : t.tx[ai];
+            if (txs.src >= nd.rx_first && txs.src < nd.rx_first + nd.n_rx) {
+                want = true;
+                pos = nd.pos_of[txs.src - nd.rx_first];
+            }
+        }
+        const int aidx = air_alloc(t, want, air_sub(t));
+        if (want) air_link(t, aidx, pos, txs.start_us, txs.air_us, 0.0, kAirSelf);
+    }
     if (e >= n_eval) return;
     const int abs_i = t.first_eval + e;
     rm_tx_record tx;

@@ -80,6 +80,11 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
                 in_e = (SINR && valid) ? t.a_e[o] : 0;
             }
+            SinrOut so = {0.0, false};
+            if (SINR && t.air.pool != nullptr && valid) { // the lists that live across ticks: the walk happens here, one lane per heard link
+                const rm_tx_record &w = t.tx[t.first_new + q];
+                so = air_sinr(m, t, t.st_dst[in_e], t.st_next[in_e], w.start_us, w.air_us, in_rssi);
+            }
             uint32_t rank = 0;
             if (t.seg_ordered) {
                 rank = c0 + lane;
@@ -94,7 +99,10 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 t.out_dst[d] = mine;
                 t.out_rssi[d] = in_rssi;
                 uint8_t vv = v;
-                if (SINR) {
+                if (SINR && t.air.pool != nullptr) {
+                    t.out_sinr[d] = so.sinr;
+                    if (so.collided) vv = RM_INTERFERED;
+                } else if (SINR) {
                     t.out_sinr[d] = t.st_sinr[in_e];
                     if (t.st_coll[in_e]) vv = RM_INTERFERED;
                 } // no SINR extension: the record carries no sinr (the array is not even allocated; readers give 0)
@@ -104,6 +112,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         }
     }
     if (!STOCH) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    if (SINR && t.air.pool != nullptr && publisher) air_end(t);
 }
 
 template <bool STOCH, bool SINR, int MODE>
