@@ -1070,7 +1070,8 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
             return RM_OK;
         }
         RM_TRY(stage(RM_STAGE_FILTER));
-        RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
+        if (rm::frames_cand_applies(t, cfg)) RM_HIP(rm::launch_frames_cand(s, nd, m, t, cfg)); // a frame finds its own receivers
+        else RM_HIP(rm::launch_filter(s, nd, m, t, cfg));
         RM_TRY(stage(RM_STAGE_EXACT));
         RM_HIP(rm::launch_seg_scan(s, t));
         RM_HIP(rm::launch_exact(s, nd, m, t, cfg));

@@ -423,6 +423,8 @@ hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, co
                         const LaunchCfg &cfg);
 // the closed-loop tick (rm_tick.hip): one frame per workgroup, filter + exact evaluation in one launch
 int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
+bool frames_cand_applies(const TickDev &t, const LaunchCfg &cfg);
+hipError_t launch_frames_cand(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg,
                               int seg_len);
 hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,

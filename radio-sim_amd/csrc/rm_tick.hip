@@ -525,6 +525,216 @@ k_tick_frames_batch(const NodesDev nd, const ModelDev m, const TickDev *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The sweep's candidate list, one frame per workgroup: for a lone tick over a table so large that the sweep's
+// filter tiles the receivers (k_tick_prep + k_filter_wg: every tile of 1024 receivers looks at every frame, then the
+// waves of a tile walk its near frames one after the other -- about 30 us at a million receivers however few the
+// frames).  Here a frame finds its own receivers through the two box levels, as k_tick_frames does, and appends them
+// to the candidate list k_exact walks.  Used by the SINR medium, whose links cross workgroups (the per-receiver
+// interferer lists), and does what k_tick_prep does besides: the frame's record in build mode, the counters of the
+// next tick, the SELF entry of the on-air lists.
+template <bool SHADOW>
+__global__ void __launch_bounds__(256) k_frames_cand(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    __shared__ int s_l1[kFrBoxes];
+    __shared__ int s_l2[kFrGroups];
+    constexpr int kRound = 32;                  // near groups per filter round: eight per wave, their records requested together
+    constexpr int kRoundCand = kRound * kGroup; // what a round can add at most
+    constexpr int kCandLds = 3 * kRoundCand;    // candidates gathered between two appends to the list
+    __shared__ int s_cand[kCandLds];
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
+    __shared__ uint32_t s_n1[2], s_n2[2], s_nc[2], s_base;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
+    const int e = blockIdx.x; // eval-relative frame
+    const int n_eval = t.n_active - t.first_eval;
+    const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
+    const int n_boxes = (n_groups + 15) / 16;
+    const int abs_i = t.first_eval + e;
+    const bool build = t.src_list != nullptr && abs_i >= t.first_new;
+    rm_tx_record tx;
+    int s_idx = -1;
+    if (build) s_idx = t.src_list[abs_i - t.first_new];
+    else tx = t.tx[abs_i];
+
+    // the first round's level-1 boxes do not depend on the frame: requested under the record's round trips
+    constexpr int kPre = kFrBoxes / 256;
+    float4 pre_xy[kPre];
+    float2 pre_z[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int b = min(k * 256 + tid, max(n_boxes, 1) - 1);
+        pre_xy[k] = nd.wg_box_xy[b];
+        pre_z[k] = nd.wg_box_z[b];
+    }
+    if (SHADOW) s_tbl[tid] = m.shadow_tbl[tid]; // kBlock == kShadowBins
+    if (build) tx = make_tx_record(nd, s_idx, t.src_start_us, t.src_air_us);
+
+    // what k_tick_prep does for the tick after this one
+    if (blockIdx.x == 0) {
+        if (tid < 8) t.next_counters[tid] = 0u;
+        t.next_shard_count[tid * kShardStride] = 0u; // kBlock == kShards
+        if (t.air.pool != nullptr && tid == 0 && t.air.bad[0]) t.stage_count[1] = 1u; // the lists are broken until rebuilt
+    }
+    for (int i = blockIdx.x * blockDim.x + tid; i < t.zero_len; i += gridDim.x * blockDim.x) {
+        t.cursor[i] = 0u;
+        t.cand_tot_next[i] = 0u;
+    }
+    if (build && tid == 0) t.tx_build[abs_i] = tx;
+    if (t.check_span && tid == 0 && tx.src >= 0 && (tx.start_us < t.span_begin || tx.start_us + tx.air_us > t.span_end))
+        t.stage_count[6] = 1u;
+    float4 f;
+    double thr64;
+    tx_prefilter(m, tx, f, thr64);
+    float shadow_inv = 0.f;
+    if (SHADOW && f.w > 0.f && f.w < __builtin_inff()) {
+        const float cut = __builtin_sqrtf(f.w);
+        if (1.01f * (2.0f * float(m.f32_slack)) / (0.15f * cut) + 1e-5f <= float(kShadowPad)) shadow_inv = float(kShadowBins) / f.w;
+    }
+    if (tid == 0) s_n1[0] = s_n1[1] = s_n2[0] = s_n2[1] = s_nc[0] = s_nc[1] = 0u;
+    __syncthreads();
+    int r1 = 0, r2 = 0, rc = 0;
+    uint32_t total = 0, flushes = 0;
+    const bool counted = abs_i >= t.first_new; // frames that get verdicts: their candidates size the frame's segment
+    int pending_rounds = 0;
+    // the gathered candidates join the list k_exact walks: one atomic reserves their run in a shard (block-uniform call)
+    auto flush = [&]() {
+        __syncthreads(); // the rounds' LDS writes
+        const int nc = uniform_i(int(s_nc[rc & 1]));
+        if (nc > 0) {
+            const uint32_t shard = (uint32_t(e) * 7u + flushes * 37u) & t.shard_mask;
+            if (tid == 0) {
+                s_base = atomicAdd(&t.shard_count[shard * kShardStride], uint32_t(nc));
+                s_nc[(rc + 1) & 1] = 0u;
+            }
+            __syncthreads();
+            const uint32_t base = uniform_u(s_base);
+            if (base + uint32_t(nc) > t.seg_cap) { // the shard is full: drop the run, flag the tick
+                if (tid == 0) t.stage_count[1] = 1u;
+            } else {
+                for (int c = tid; c < nc; c += 256) {
+                    const uint32_t idx = shard * t.seg_cap + base + uint32_t(c);
+                    t.st_pkt[idx] = e;
+                    t.st_dst[idx] = s_cand[c];
+                }
+                total += uint32_t(nc);
+            }
+            ++flushes;
+            ++rc;
+            __syncthreads(); // s_cand and s_base are reused
+        }
+    };
+
+    if (f.w >= 0.f) {
+        for (int b0 = 0; b0 < n_boxes; b0 += kFrBoxes) {
+            // level 1: the boxes of 16 groups
+#pragma unroll
+            for (int k = 0; k < kFrBoxes / 256; ++k) {
+                const int b = b0 + k * 256 + tid;
+                bool hit = false;
+                if (b < n_boxes) hit = (b0 == 0) ? box_near(pre_xy[k], pre_z[k], f) : box_near(nd.wg_box_xy[b], nd.wg_box_z[b], f);
+                const uint64_t hm = ballot64(hit);
+                if (hm) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n1[r1 & 1], uint32_t(__popcll(hm)));
+                    base = uniform_u(base);
+                    if (hit) s_l1[base + lane_prefix(hm)] = b;
+                }
+            }
+            __syncthreads();
+            const int n1 = uniform_i(int(s_n1[r1 & 1]));
+            if (tid == 0) s_n1[(r1 + 1) & 1] = 0u;
+            ++r1;
+            const int n_l2 = n1 * 16;
+            for (int i0 = 0; i0 < n_l2; i0 += kFrGroups) {
+                // level 2: the group boxes
+#pragma unroll
+                for (int k = 0; k < kFrGroups / 256; ++k) {
+                    if (i0 + k * 256 >= n_l2) break; // block-uniform
+                    const int i = i0 + k * 256 + tid;
+                    bool hit = false;
+                    int g = 0;
+                    if (i < n_l2) {
+                        g = s_l1[i >> 4] * 16 + (i & 15);
+                        if (g < n_groups) hit = box_near(nd.bbox_xy[g], nd.bbox_z[g], f);
+                    }
+                    const uint64_t hm = ballot64(hit);
+                    if (hm) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_n2[r2 & 1], uint32_t(__popcll(hm)));
+                        base = uniform_u(base);
+                        if (hit) s_l2[base + lane_prefix(hm)] = g;
+                    }
+                }
+                __syncthreads();
+                const int n2 = uniform_i(int(s_n2[r2 & 1]));
+                if (tid == 0) s_n2[(r2 + 1) & 1] = 0u;
+                ++r2;
+                for (int gi0 = 0; gi0 < n2; gi0 += kRound) {
+                    // filter: every wave takes eight of the round's groups, their records requested together
+                    float4 v[kRound / 4];
+                    int jj[kRound / 4], oo[kRound / 4];
+#pragma unroll
+                    for (int k = 0; k < kRound / 4; ++k) {
+                        const int gi = gi0 + k * 4 + wave;
+                        jj[k] = -1;
+                        oo[k] = 0;
+                        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (gi < n2) {
+                            const int j = s_l2[gi] * kGroup + lane;
+                            if (j < nd.n_rx) {
+                                jj[k] = j;
+                                v[k] = nd.rxf[j];
+                                if (SHADOW) oo[k] = nd.orig[j];
+                            }
+                        }
+                    }
+                    uint64_t hms[kRound / 4];
+                    uint32_t wave_hits = 0;
+#pragma unroll
+                    for (int k = 0; k < kRound / 4; ++k) {
+                        const float s2 = dist2_f32(v[k].x - f.x, v[k].y - f.y, v[k].z - f.z);
+                        bool hit = jj[k] >= 0 && s2 <= f.w && __float_as_int(v[k].w) == tx.channel;
+                        if (SHADOW && hit) {
+                            const int bin = min(kShadowBins - 1, int(s2 * shadow_inv));
+                            const uint32_t a = uint32_t(tx.src), b = uint32_t(oo[k]);
+                            const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
+                            hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                        }
+                        hms[k] = ballot64(hit);
+                        wave_hits += uint32_t(__popcll(hms[k]));
+                    }
+                    if (wave_hits) { // one LDS atomic per wave and round
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nc[rc & 1], wave_hits);
+                        base = uniform_u(base);
+#pragma unroll
+                        for (int k = 0; k < kRound / 4; ++k) {
+                            if ((hms[k] >> lane) & 1ull) s_cand[base + lane_prefix(hms[k])] = jj[k];
+                            base += uint32_t(__popcll(hms[k]));
+                        }
+                    }
+                    // no barrier between rounds: the waves stream through their groups; the candidates join the
+                    // list when another round might not fit any more (block-uniform: a round adds at most kRoundCand)
+                    if (++pending_rounds * kRoundCand + kRoundCand > kCandLds) {
+                        flush();
+                        pending_rounds = 0;
+                    }
+                }
+                // (the lists s_l2 / s_l1 are rewritten by the next chunk: everybody is done reading them)
+                __syncthreads();
+            }
+        }
+    }
+    flush();
+    if (counted && tid == 0 && total) t.cand_tot[e - t.cnt_base] = total; // (zeroed by the tick before; one workgroup per frame)
+    if (t.air.pool != nullptr && wave == 0) { // half duplex: the frame's SELF entry in its source's list (two atomics in a row: last)
+        const bool want = lane == 0 && tx.src >= nd.rx_first && tx.src < nd.rx_first + nd.n_rx;
+        const int aidx = air_alloc(t, want, air_sub(t));
+        if (want) air_link(t, aidx, nd.pos_of[tx.src - nd.rx_first], tx.start_us, tx.air_us, 0.0, kAirSelf);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The tick's result written straight from the frames' segments into the host-mapped block of
 // rm_tick_flush* (header, packet offsets, Tx-failure flags, records): every workgroup redoes the scan
 // of the per-frame counts in LDS, a wave copies a frame's links to their compact place, the workgroup
@@ -630,6 +840,26 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     }
 #undef RM_FR
 #undef RM_FR2
+    return hipGetLastError();
+}
+
+// is the per-frame candidate kernel the better filter for this tick?  (a lone tick over a table the sweep would tile)
+bool frames_cand_applies(const TickDev &t, const LaunchCfg &cfg)
+{
+    static const bool off = [] {
+        const char *e = getenv("RM_FRAMES_CAND");
+        return e && atoi(e) == 0;
+    }();
+    return !off && t.air.pool != nullptr && t.filter_mode == kFilterWg && cfg.sorted && cfg.bbox && !cfg.f64_filter && !t.use_matrix &&
+           !t.reset_heads;
+}
+
+hipError_t launch_frames_cand(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)
+{
+    const int n_eval = t.n_active - t.first_eval;
+    if (n_eval <= 0 || t.n_rx <= 0) return hipSuccess;
+    if (cfg.shadow && m.shadow_tbl) hipLaunchKernelGGL((k_frames_cand<true>), dim3(n_eval), dim3(256), 0, s, nd, m, t);
+    else hipLaunchKernelGGL((k_frames_cand<false>), dim3(n_eval), dim3(256), 0, s, nd, m, t);
     return hipGetLastError();
 }
 

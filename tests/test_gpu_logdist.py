@@ -303,3 +303,24 @@ def test_sinr_lists_after_a_dropped_tick(engine, rsa, O):
             engine.set_link_capacity(1 << 22)
         onair = active
     assert failed == 1
+
+
+def test_sinr_lists_with_the_per_frame_candidate_kernel(engine, rsa, O, monkeypatch):
+    """Tables large enough for the tiled filter take their candidates from k_frames_cand (one frame per workgroup);
+    RM_FILTER=wg selects that regime for a table of test size."""
+    monkeypatch.setenv("RM_FILTER", "wg")
+    n = 6000
+    nd = _layout(O, n, seed=53, z=3.0)
+    rng = np.random.default_rng(15)
+    nd.channel[:] = 11 + rng.integers(0, 3, n)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+
+    def hook(tick):
+        if tick == 7:                                   # a rebuild in the middle: every frame on the air is swept again
+            engine.move_nodes(np.arange(3, dtype=np.int32), nd.x[:3] + 1.0, nd.y[:3], nd.z[:3])
+            nd.x[:3] += 1.0
+
+    got = _overlap_run(engine, rsa, O, nd, mdl, rng, 16, lambda t: rng.integers(0, 60), [320, 2048, 8128], hook=hook, what="frames cand")
+    assert got > 30
