@@ -602,7 +602,9 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             wl = pmc.get(args.workload, {})
-            ent = wl.get(dominant)
+            if batch == 1 and wl.get("ticks_per_launch", 1) != 1:
+                wl = pmc.get(args.workload + "_tick", {})   # the one-launch tick has its own counter passes
+            ent = wl.get(dominant) or (wl.get("k_tick_frames") if dominant == "k_filter" else None)
             if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
                 traffic = ent["hbm_bytes_per_launch"]
                 pmc_note = ent["source"] + " (commit %s)" % wl.get("commit", "unrecorded")

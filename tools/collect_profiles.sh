@@ -21,12 +21,27 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/m1_stats -- python $R
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/m1_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3 > $O/m1_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/m1_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3 > $O/m1_write.log 2>&1
 echo "m1 done"
+# the closed-loop tick (one launch per tick): its own PMC passes, keyed by the workload name c3_tick
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tick_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --inflight 1 --batch 1 --steps 200 --warmup 20 > $O/tick_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tick_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --inflight 1 --batch 1 --steps 200 --warmup 20 > $O/tick_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/tick_sq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --inflight 1 --batch 1 --steps 200 --warmup 20 > $O/tick_sq.log 2>&1
+echo "tick pmc done"
+# configs[4]: the SINR medium with frames that stay on the air (lists kept on the device across ticks)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -- python $R/bench.py --no-cpu-baseline --no-host-transfer --workload c5 --steps 40 --warmup 12 > $O/c5_stats.log 2>&1
+# the reception stage (device events): tick + drain, deliveries to the host
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ev_stats -- python $R/tools/events_latency.py c3 100 > $O/ev_stats.log 2>&1
+echo "c5 / events done"
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/${ROUND}_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
 python tools/pmc_traffic.py $O/m1_fetch $O/m1_write m1 16 $O/${ROUND}_m1_pmc.csv $O/pmc_traffic.json
+python tools/pmc_traffic.py $O/tick_fetch $O/tick_write c3_tick 1 $O/${ROUND}_c3_tick_pmc.csv $O/pmc_traffic.json $O/tick_sq
+cp $(find $O/c5_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c5_kernel_stats.csv
+cp $(find $O/ev_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_events_kernel_stats.csv
+grep -h '"metric"' $O/c5_stats.log > $O/${ROUND}_c5_bench.json || true
+tail -1 $O/ev_stats.log > $O/${ROUND}_c3_events.json || true
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_kernel_stats.csv
 cp $(find $O/stats_seq -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_sequential_kernel_stats.csv
 cp $(find $O/m1_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_m1_kernel_stats.csv
-for f in $O/${ROUND}_c3_kernel_stats.csv $O/${ROUND}_c3_sequential_kernel_stats.csv $O/${ROUND}_m1_kernel_stats.csv; do echo "# commit ${RM_COMMIT:-unrecorded}" >> $f; done
-rm -rf $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/m1_stats $O/m1_fetch $O/m1_write
+for f in $O/${ROUND}_c3_kernel_stats.csv $O/${ROUND}_c3_sequential_kernel_stats.csv $O/${ROUND}_m1_kernel_stats.csv $O/${ROUND}_c5_kernel_stats.csv $O/${ROUND}_c3_events_kernel_stats.csv; do echo "# commit ${RM_COMMIT:-unrecorded}" >> $f; done
+rm -rf $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/m1_stats $O/m1_fetch $O/m1_write $O/tick_fetch $O/tick_write $O/tick_sq $O/c5_stats $O/ev_stats
 echo "all done"

@@ -20,7 +20,7 @@ import json
 import os
 import sys
 
-STAGE = (("k_tick_frames", "k_tick_frames"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
+STAGE = (("k_tick_frames", "k_tick_frames"), ("k_frames_cand", "k_filter"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
          ("k_reorder", "k_reorder"), ("k_self_entries", "k_self_entries"), ("k_sinr", "k_sinr"),
          ("k_cell_off", "k_cell_off+k_slot_scan"), ("k_slot_scan", "k_cell_off+k_slot_scan"), ("k_finalize", "k_finalize"))
 
