@@ -244,19 +244,27 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
         eng.events_enable(1 << 16, 1 << 21)
         eng.set_time(0)
 
+        split = [0.0, 0.0]   # host time inside the two calls (the drain call includes waiting for the device)
+
         def ev_loop(k0, k1):
             got = 0
             for k in range(k0, k1):
+                ta = time.perf_counter()
                 eng.tick_run_sources_device(k * tick_us, (k + 1) * tick_us, src_dev[k % pool].data_ptr(), t_per_tick, k * tick_us, W.AIR_US)
+                tb = time.perf_counter()
                 got += len(eng.events_process((k + 1) * tick_us, copy=False)[0])   # read in place, as rm_tick_flush_view's records
+                split[0] += tb - ta
+                split[1] += time.perf_counter() - tb
             return got
         ev_loop(0, 24)
+        split[:] = [0.0, 0.0]
         t0 = time.perf_counter()
         got = ev_loop(24, 24 + reps)
         el = time.perf_counter() - t0
         eng.events_disable()
     out["tick_events"] = {"us_per_tick": el / reps * 1e6, "value": links_per_tick * reps / el, "unit": "links/s",
                           "deliveries_per_tick": got / reps, "bytes_out_per_tick": got / reps * 20,
+                          "tick_call_us": split[0] / reps * 1e6, "drain_call_us": split[1] / reps * 1e6,
                           "what": "rm_tick_run_sources_device + rm_events_process per tick: Simulator.generate*Events, "
                                   "processAllEvents and the Transciever state on the device, the deliveries on the host"}
     if batch > 1:

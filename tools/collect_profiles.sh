@@ -38,7 +38,7 @@ python tools/pmc_traffic.py $O/tick_fetch $O/tick_write c3_tick 1 $O/${ROUND}_c3
 cp $(find $O/c5_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c5_kernel_stats.csv
 cp $(find $O/ev_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_events_kernel_stats.csv
 grep -h '"metric"' $O/c5_stats.log > $O/${ROUND}_c5_bench.json || true
-tail -1 $O/ev_stats.log > $O/${ROUND}_c3_events.json || true
+grep -o "{\"workload\".*}" $O/ev_stats.log > $O/${ROUND}_c3_events.json || true
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_kernel_stats.csv
 cp $(find $O/stats_seq -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_sequential_kernel_stats.csv
 cp $(find $O/m1_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_m1_kernel_stats.csv

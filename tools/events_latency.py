@@ -19,7 +19,14 @@ idx, n, frac, model = SHAPES[wl]
 t = int(round(n * frac))
 nodes = W.make_nodes(n, idx)
 kind_name, kw = W.model_kwargs(model)
+_stream = None
+if len(sys.argv) > 3 and sys.argv[3] == "torch":   # as bench.py drives it: the context on a torch stream
+    import torch
+    torch.cuda.set_device(0)
+    _stream = torch.cuda.Stream()
 eng = rsa.Engine(0)
+if _stream is not None:
+    eng.set_stream(_stream.cuda_stream)
 eng.upload_table(nodes)
 eng.set_model({"udgm": rsa.MODEL_UDGM, "logdist": rsa.MODEL_LOGDIST}[kind_name], **kw)
 eng.set_link_capacity(1 << 21)

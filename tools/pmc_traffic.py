@@ -80,6 +80,8 @@ def main():
            "coalesced stream)" % (os.path.relpath(out_csv), tpl))
     out[workload] = {"ticks_per_launch": int(tpl), "commit": os.environ.get("RM_COMMIT", "unrecorded")}
     for stage, (f, w) in stages.items():
+        if (stage == "k_tick_frames") != (int(tpl) == 1):
+            continue   # the one-launch tick belongs to the ticks_per_launch = 1 passes (the batch runs contain bench.py's sequential leg)
         out[workload][stage] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_size_kb_raw": round(f, 1),
                                 "write_size_kb": round(w, 1), "source": src}
     for stage, (quad, n_inst) in valu_stage.items():
