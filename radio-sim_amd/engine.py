@@ -11,6 +11,23 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+_CHAR_BLOCKS = {}
+
+
+def _wrap(ptr, dtype, count):
+    """`count` items of `dtype` at address `ptr`, wrapped in place.  ctypes builds (and keeps) a new array type for
+    every distinct length -- tens of microseconds each -- so the wrapper's byte length is rounded up to a power of two
+    (numpy only ever looks at the first `count` items)."""
+    if count == 0 or not ptr:
+        return np.empty(0, dtype=dtype)
+    nbytes = count * np.dtype(dtype).itemsize
+    size = 1 << max(6, (nbytes - 1).bit_length())
+    block = _CHAR_BLOCKS.get(size)
+    if block is None:
+        block = _CHAR_BLOCKS[size] = C.c_char * size
+    return np.frombuffer(block.from_address(ptr), dtype=dtype, count=count)
+
+
 class TickResult:
     """Heard links of one evaluated tick, packet-major / receiver ascending."""
 
@@ -183,11 +200,7 @@ class Engine:
 
     @staticmethod
     def _wrap_host_result(r):
-        def arr(ptr, dtype, count):
-            if count == 0 or not ptr:
-                return np.empty(0, dtype=dtype)
-            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dtype, count=count)
+        arr = _wrap
         k, p = r.count, r.n_packets
         return TickResult(k, arr(r.pkt, np.int32, k), arr(r.dst, np.int32, k), arr(r.verdict, np.uint8, k),
                           arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k) if r.sinr else np.zeros(k), arr(r.pkt_interference, np.uint8, p),
@@ -355,10 +368,7 @@ class Engine:
         k = v.count
 
         def arr(ptr, dtype):
-            if k == 0:
-                return np.empty(0, dtype=dtype)
-            buf = (C.c_char * (k * np.dtype(dtype).itemsize)).from_address(ptr)
-            a = np.frombuffer(buf, dtype=dtype, count=k)
+            a = _wrap(ptr, dtype, k)
             return a.copy() if copy else a
         return arr(v.packet, np.int64), arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets
 
