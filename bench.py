@@ -31,6 +31,7 @@ config; `--as-rank R:W` runs one rank's share of a W-GPU weak-scaling run on one
 collective.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -92,6 +93,7 @@ def parse():
     ap.add_argument("--no-host-transfer", action="store_true", help="skip the PCIe-inclusive legs (with_host_transfer)")
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
+    ap.add_argument("--no-weak-probe", action="store_true", help="several GPUs: skip the extra weak-scaling pass (key weak_scaling)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="several GPUs: strong (default) = the BASELINE config itself, receivers split over the ranks; "
                          "weak = node count grown as sqrt(GPUs) so that the link evaluations per GPU stay fixed")
@@ -367,317 +369,337 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    idx, n, frac, model, desc = WORKLOADS[args.workload]
-    extra0 = EXTRA.get(args.workload, {})
-    if model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > extra0.get("tick_us", W.TICK_US) and world > 1:
-        raise SystemExit("frames that outlive their tick (SINR on-air list) are sharded through the host-record path only")
-    as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
-    if as_rank:
-        n = int(round(n * as_rank[1] ** 0.5))
-        desc += " -- compute of rank %d of %d (weak scaling: %d nodes), no collective" % (as_rank[0], as_rank[1], n)
-    elif args.nodes > 0:
-        n = args.nodes
-        desc += " -- node count overridden: %d" % n
-    elif world > 1 and args.scaling == "weak":
-        # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
-        n = int(round(n * world ** 0.5))
-        desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
-    t_per_tick = int(round(frac * n))
-    extra = EXTRA.get(args.workload, {})
-    tick_us = extra.get("tick_us", W.TICK_US)
-    # the SINR extension looks at every frame on the air: ticks are chained unless no frame outlives its tick
-    stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > tick_us
-    nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
-    kind_name, kw = W.model_kwargs(model)
-    kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
+    def measure(args):
+        """one configuration through the whole bench; rank 0 gets the result line's dictionary"""
+        args = copy.copy(args)
+        result = None
+        idx, n, frac, model, desc = WORKLOADS[args.workload]
+        extra0 = EXTRA.get(args.workload, {})
+        if model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > extra0.get("tick_us", W.TICK_US) and world > 1:
+            raise SystemExit("frames that outlive their tick (SINR on-air list) are sharded through the host-record path only")
+        as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
+        if as_rank:
+            n = int(round(n * as_rank[1] ** 0.5))
+            desc += " -- compute of rank %d of %d (weak scaling: %d nodes), no collective" % (as_rank[0], as_rank[1], n)
+        elif args.nodes > 0:
+            n = args.nodes
+            desc += " -- node count overridden: %d" % n
+        elif world > 1 and args.scaling == "weak":
+            # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
+            n = int(round(n * world ** 0.5))
+            desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
+        t_per_tick = int(round(frac * n))
+        extra = EXTRA.get(args.workload, {})
+        tick_us = extra.get("tick_us", W.TICK_US)
+        # the SINR extension looks at every frame on the air: ticks are chained unless no frame outlives its tick
+        stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > tick_us
+        nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
+        kind_name, kw = W.model_kwargs(model)
+        kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
 
-    inflight = max(1, args.inflight) if not stateful else 1
-    engines, streams = [], []
-    for _ in range(inflight):
-        e = rsa.Engine(device_ordinal)
-        st = torch.cuda.Stream(device=dev)
-        e.set_stream(st.cuda_stream)
-        e.upload_table(nodes)
-        e.set_model(kind, **kw)
-        e.set_link_capacity(extra.get("link_capacity", 1 << 21))
-        engines.append(e)
-        streams.append(st)
-    eng, stream = engines[0], streams[0]
+        inflight = max(1, args.inflight) if not stateful else 1
+        engines, streams = [], []
+        for _ in range(inflight):
+            e = rsa.Engine(device_ordinal)
+            st = torch.cuda.Stream(device=dev)
+            e.set_stream(st.cuda_stream)
+            e.upload_table(nodes)
+            e.set_model(kind, **kw)
+            e.set_link_capacity(extra.get("link_capacity", 1 << 21))
+            engines.append(e)
+            streams.append(st)
+        eng, stream = engines[0], streams[0]
 
-    # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
-    lo = (n * rank) // world
-    hi = (n * (rank + 1)) // world
-    if as_rank:
-        lo, hi = (n * as_rank[0]) // as_rank[1], (n * (as_rank[0] + 1)) // as_rank[1]
-        for e in engines:
-            e.set_partition(lo, hi - lo)
+        # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
+        lo = (n * rank) // world
+        hi = (n * (rank + 1)) // world
+        if as_rank:
+            lo, hi = (n * as_rank[0]) // as_rank[1], (n * (as_rank[0] + 1)) // as_rank[1]
+            for e in engines:
+                e.set_partition(lo, hi - lo)
 
-    from radio_sim_amd import dist as D
-    use_sharded = world > 1 or args.force_sharded
-    batch = 1 if stateful else max(1, min(args.batch, rsa.MAX_BATCH))
-    tps = batch                          # ticks per step: a step is one launch sequence
-    if args.steps <= 0:
-        args.steps = -(-1920 // tps)
-    if args.warmup < 0:
-        args.warmup = -(-192 // tps)
-    warm_ticks, ticks = args.warmup * tps, (args.warmup + args.steps) * tps
-    base_seed = 0xC0FFEE00 + idx
-    # synthetic input: a pool of distinct ticks (a multiple of the batch), reused in turn by longer runs
-    pool = min(ticks, -(-2112 // tps) * tps)
-    sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(pool)]
-    with torch.cuda.stream(stream):
-        if not use_sharded:
-            src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
-            sharded = None
-        else:
-            # every rank packs the frames whose source it owns into a fixed number of slots
-            # (padded with src = -1), then the ranks all-gather the slots over RCCL
-            slots = D.slots_needed(n, world, sources)
-            pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
-            src_dev = torch.from_numpy(pad).to(dev)
-            sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch)
-    stream.synchronize()
-
-    links_done = [0]
-    last_run = [eng, 0]     # (context, result slot) of the last tick issued
-    ctx_rr = [0]
-    _bargs = {}
-
-    clock = [0]   # simulated ticks issued so far: simulated time never runs backwards (the SINR medium keeps frames on the air)
-
-    def batch_args(k, nb, tk):
-        """arguments of one rm_batch_run_sources_device call for the source lists k .. k+nb-1 at simulated ticks tk .."""
-        if (k, nb, tk) not in _bargs:
-            t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
-            _bargs[(k, nb, tk)] = (t0, t0 + tick_us, np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
-                                   np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
-        return _bargs[(k, nb, tk)]
-
-    def run_range(k0, k1):
-        """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
-        with torch.cuda.stream(stream if sharded is None else sharded.comm):
-            if sharded is None and batch > 1:
-                for k in range(k0, k1, batch):
-                    a = batch_args(k, min(batch, k1 - k), clock[0] + k - k0)
-                    g = ctx_rr[0] % inflight       # contexts take the batches in turn
-                    ctx_rr[0] += 1
-                    engines[g].batch_run_sources_device(*a)
-                    last_run[:] = [engines[g], min(batch, k1 - k) - 1]
-            elif batch > 1:
-                # sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream
-                for k in range(k0, k1, batch):
-                    t_b = (clock[0] - k0 + np.arange(k, min(k + batch, k1), dtype=np.int64)) * tick_us
-                    g = ctx_rr[0] % inflight
-                    ctx_rr[0] += 1
-                    sharded.run_batch(g, src_dev[k % pool].data_ptr(), t_b, W.AIR_US, tick_us)
-                    last_run[:] = [engines[g], len(t_b) - 1]
-            elif sharded is None:
-                for k in range(k0, k1):
-                    t0 = (clock[0] + k - k0) * tick_us
-                    # one call: the frames' Tx records are built from the resident node state inside the sweep
-                    engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick,
-                                                                  t0, W.AIR_US)
-                    if stateful:
-                        links_done[0] += engines[0].last_link_evaluations()
-            else:
-                if k1 > k0:
-                    sharded.stage(src_dev[k0 % pool].data_ptr(), k0 * W.TICK_US, W.AIR_US)
-                for k in range(k0, k1):
-                    cur = sharded.staged
-                    if k + 1 < k1:
-                        sharded.stage(src_dev[(k + 1) % pool].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
-                    sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
-        clock[0] += k1 - k0
-
-    def fence():
-        for st in streams:
-            st.synchronize()
-        torch.cuda.synchronize()   # includes the communication stream
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # set-up, not a step: every context sweeps one batch once, so that its result slots and link
-    # buffers exist before the warm-up (the W warm-up steps alone need not reach every context)
-    for _ in range(inflight):
-        run_range(0, min(ticks, batch))
-    fence()
-    run_range(0, warm_ticks)
-    fence()
-    # HIP-event brackets on every n-th launch sequence of every context; few launches: all of them
-    launches = args.steps
-    every = args.profile_every if batch == 1 else max(1, args.profile_every // 4)
-    if launches <= 4 * inflight:
-        every = 1
-    for e in engines:
-        e.profile_enable(every)
-    t_start = time.perf_counter()
-    links_done[0] = 0
-    run_range(warm_ticks, ticks)
-    fence()
-    elapsed = time.perf_counter() - t_start
-    n_samples, stage_ms = 0, {}
-    for e in engines:
-        ns, ms = e.profile_read()
-        e.profile_enable(0)
-        n_samples += ns
-        for k, v in ms.items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
-    heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
-    if dropped:
-        raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
-
-    if world > 1:
-        rdev = dev if backend == "nccl" else torch.device("cpu")
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        hsum = torch.tensor([heard], dtype=torch.float64, device=rdev)
-        dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
-        heard_total = float(hsum.item())
-    else:
-        heard_total = float(heard)
-
-    links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * (hi - lo)
-    timed_ticks = args.steps * tps
-    value = links_per_tick * timed_ticks / elapsed
-    if stateful:
-        # the links the ticks resolved: the new frames against every receiver; the frames still on the air keep
-        # their entries in the per-receiver lists on the device and are not swept again (SURVEY.md section 8d, C5)
-        value = links_done[0] / elapsed
-
-    sequential = None
-    if stateful:
-        inc, reb = engines[0].air_list_stats()
-        desc += (" -- %.2e link evaluations per tick (new frames only: the frames still on the air stay in the on-air lists on the "
-                 "device; %d ticks added to the lists, %d rebuilt them)" % (links_done[0] / timed_ticks, inc, reb))
-    if (inflight > 1 or batch > 1) and sharded is None:
-        # the same ticks again, one at a time on one context
-        fence()
-        t_seq = time.perf_counter()
+        from radio_sim_amd import dist as D
+        use_sharded = world > 1 or args.force_sharded
+        batch = 1 if stateful else max(1, min(args.batch, rsa.MAX_BATCH))
+        tps = batch                          # ticks per step: a step is one launch sequence
+        if args.steps <= 0:
+            args.steps = -(-1920 // tps)
+        if args.warmup < 0:
+            args.warmup = -(-192 // tps)
+        warm_ticks, ticks = args.warmup * tps, (args.warmup + args.steps) * tps
+        base_seed = 0xC0FFEE00 + idx
+        # synthetic input: a pool of distinct ticks (a multiple of the batch), reused in turn by longer runs
+        pool = min(ticks, -(-2112 // tps) * tps)
+        sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(pool)]
         with torch.cuda.stream(stream):
-            seq_ticks = min(timed_ticks, 1920)
-            for k in range(warm_ticks, warm_ticks + seq_ticks):
-                t0 = (clock[0] + k - warm_ticks) * tick_us
-                eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick, t0, W.AIR_US)
-        fence()
-        el = time.perf_counter() - t_seq
-        sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
-                      "ms_per_tick": el / seq_ticks * 1e3,
-                      "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
-                              "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
+            if not use_sharded:
+                src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
+                sharded = None
+            else:
+                # every rank packs the frames whose source it owns into a fixed number of slots
+                # (padded with src = -1), then the ranks all-gather the slots over RCCL
+                slots = D.slots_needed(n, world, sources)
+                pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
+                src_dev = torch.from_numpy(pad).to(dev)
+                sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch)
+        stream.synchronize()
 
-    if rank == 0:
-        # Roofline (SURVEY.md section 8(d)).  Per-stage durations come from HIP events recorded on the engine's
-        # stream around every stage of each `profile_every`-th launch of the timed region.  Every stage is priced
-        # with ITS OWN algorithmic bytes (DESIGN.md section 5):
-        #   filter   N_loc*16 (pre-filter records) + T*28 (frame pre-filter records) + cand*12 (candidate entries written)
-        #   exact    cand*(12 + 32) (entries + 32-byte receiver records) + H*13 (staged link records written)
-        #   reorder  H*13 read + H*17 written (pkt 4, dst 4, rssi 8, verdict 1)
-        # The dominant stage's bound is named for what binds it: vector issue slots for these integer / fp32 / fp64
-        # sweeps (PMC: profiles/pmc_traffic.json), its HBM fraction is reported next to it; the HBM figure of the
-        # whole step is section 8(d)'s bytes (N_loc*37 + T*56 + H*25 per tick) over the DRIVER-timed ms_per_step.
-        n_loc = hi - lo
-        h_loc = heard
-        ticks_per_launch = batch
-        try:
-            cand, _ = (last_run[0].slot_stats(last_run[1]) if batch > 1 else eng.slot_stats(0))
-        except Exception:
-            cand = 0
-        b_step = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
-        stage_bytes = {"k_filter": (n_loc * 16 + t_per_tick * 28 + cand * 12) * ticks_per_launch,
-                       "k_exact": (cand * 44 + h_loc * 13) * ticks_per_launch,
-                       "k_reorder": (h_loc * 30) * ticks_per_launch}
-        raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
-        # an event pair with nothing between it measures the bracketing itself (a few us on this
-        # runtime): subtracted from every stage so that the durations are the kernels'
-        bracket_us = raw_us.pop("empty bracket", 0.0)
-        per_stage_us = {k: max(v - bracket_us, 0.0) for k, v in raw_us.items()}
-        dominant = max(per_stage_us, key=per_stage_us.get) if per_stage_us else "k_filter"
-        kern_avg_s = per_stage_us.get(dominant, 0.0) * 1e-6
-        stages = {}
-        for k, us in per_stage_us.items():
-            b = stage_bytes.get(k)
-            stages[k] = {"us": us, "algorithmic_bytes": b,
-                         "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
-                         "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
-        dom_bytes = stage_bytes.get(dominant, b_step)
-        achieved = dom_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
-        traffic = None
-        valu = None
-        bound = "hbm"
-        pmc_note = "no PMC pass on file for this workload"
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            wl = pmc.get(args.workload, {})
-            if batch == 1 and wl.get("ticks_per_launch", 1) != 1:
-                wl = pmc.get(args.workload + "_tick", {})   # the one-launch tick has its own counter passes
-            ent = wl.get(dominant) or (wl.get("k_tick_frames") if dominant == "k_filter" else None)
-            if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
-                traffic = ent["hbm_bytes_per_launch"]
-                pmc_note = ent["source"] + " (commit %s)" % wl.get("commit", "unrecorded")
-                if "valu_issue_us_per_launch" in ent and kern_avg_s > 0:
-                    # vector-issue time of the stage's instructions on the whole chip (PMC, one context) over the
-                    # stage's duration here: the binding resource of the sweep
-                    share = ent["valu_issue_us_per_launch"] / (kern_avg_s * 1e6)
-                    valu = {"issue_us_per_launch": ent["valu_issue_us_per_launch"], "frac": share,
-                            "instructions_per_launch": ent.get("valu_instructions_per_launch"),
-                            "source": "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU pass of tools/collect_profiles.sh (profiles/pmc_traffic.json)"}
-                    if share > achieved / HBM_PEAK_GBS:
-                        bound = "valu"
-        except (OSError, ValueError):
-            pass
-        step_s = elapsed / args.steps
-        out = {
-            "metric": baseline_metric(),
-            "value": value,
-            "unit": "links/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": step_s * 1e3,
-            "ms_per_tick": elapsed / timed_ticks * 1e3,
-            "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight * batch,
-                       "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
-                       "step": "one launch sequence sweeping ticks_per_step simulated ticks",
-                       "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
-                       "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per batch of ticks"
-                                    % world) if world > 1 else "none"},
-            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (valu["frac"] if (bound == "valu" and valu) else achieved / HBM_PEAK_GBS),
-                         "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
-                         "algorithmic_bytes_per_launch": dom_bytes, "traffic_source": pmc_note,
-                         "stages": stages, "event_bracket_us": bracket_us, "valu": valu,
-                         "whole_step": {"algorithmic_bytes": b_step, "ms_per_step": step_s * 1e3,
-                                        "achieved": b_step / step_s / 1e9, "frac": b_step / step_s / 1e9 / HBM_PEAK_GBS,
-                                        "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step"},
-                         "note": "`frac` is the fraction of the BINDING resource: with bound = valu the share of the dominant "
-                                 "kernel's time its vector instructions need to issue (hbm_frac: the same kernel's own "
-                                 "algorithmic bytes against 8 TB/s); one launch sweeps `ticks_per_launch` ticks; durations are "
-                                 "HIP-event brackets on the context's stream while the other contexts' launches share the device"},
-        }
-        if sequential is not None:
-            out["sequential_ticks"] = sequential
-        if world == 1 and not stateful and not as_rank and not args.no_host_transfer:
-            out["with_host_transfer"] = host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick, tick_us,
-                                                           src_dev, pool, batch)
-        if world == 1 and args.workload == "c3" and not args.no_scale_probe:
-            out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch)
-            out["dense_layout"] = dense_probe(rsa, W, torch, dev, device_ordinal)
-        if world == 1 and not args.no_cpu_baseline:
-            st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
-            out["cpu_baseline"] = st
-            out["cpu_baseline_all_cores"] = mt
+        links_done = [0]
+        last_run = [eng, 0]     # (context, result slot) of the last tick issued
+        ctx_rr = [0]
+        _bargs = {}
+
+        clock = [0]   # simulated ticks issued so far: simulated time never runs backwards (the SINR medium keeps frames on the air)
+
+        def batch_args(k, nb, tk):
+            """arguments of one rm_batch_run_sources_device call for the source lists k .. k+nb-1 at simulated ticks tk .."""
+            if (k, nb, tk) not in _bargs:
+                t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
+                _bargs[(k, nb, tk)] = (t0, t0 + tick_us, np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
+                                       np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
+            return _bargs[(k, nb, tk)]
+
+        def run_range(k0, k1):
+            """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
+            with torch.cuda.stream(stream if sharded is None else sharded.comm):
+                if sharded is None and batch > 1:
+                    for k in range(k0, k1, batch):
+                        a = batch_args(k, min(batch, k1 - k), clock[0] + k - k0)
+                        g = ctx_rr[0] % inflight       # contexts take the batches in turn
+                        ctx_rr[0] += 1
+                        engines[g].batch_run_sources_device(*a)
+                        last_run[:] = [engines[g], min(batch, k1 - k) - 1]
+                elif batch > 1:
+                    # sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream
+                    for k in range(k0, k1, batch):
+                        t_b = (clock[0] - k0 + np.arange(k, min(k + batch, k1), dtype=np.int64)) * tick_us
+                        g = ctx_rr[0] % inflight
+                        ctx_rr[0] += 1
+                        sharded.run_batch(g, src_dev[k % pool].data_ptr(), t_b, W.AIR_US, tick_us)
+                        last_run[:] = [engines[g], len(t_b) - 1]
+                elif sharded is None:
+                    for k in range(k0, k1):
+                        t0 = (clock[0] + k - k0) * tick_us
+                        # one call: the frames' Tx records are built from the resident node state inside the sweep
+                        engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick,
+                                                                      t0, W.AIR_US)
+                        if stateful:
+                            links_done[0] += engines[0].last_link_evaluations()
+                else:
+                    if k1 > k0:
+                        sharded.stage(src_dev[k0 % pool].data_ptr(), k0 * W.TICK_US, W.AIR_US)
+                    for k in range(k0, k1):
+                        cur = sharded.staged
+                        if k + 1 < k1:
+                            sharded.stage(src_dev[(k + 1) % pool].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
+                        sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
+            clock[0] += k1 - k0
+
+        def fence():
+            for st in streams:
+                st.synchronize()
+            torch.cuda.synchronize()   # includes the communication stream
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        # set-up, not a step: every context sweeps one batch once, so that its result slots and link
+        # buffers exist before the warm-up (the W warm-up steps alone need not reach every context)
+        for _ in range(inflight):
+            run_range(0, min(ticks, batch))
+        fence()
+        run_range(0, warm_ticks)
+        fence()
+        # HIP-event brackets on every n-th launch sequence of every context; few launches: all of them
+        launches = args.steps
+        every = args.profile_every if batch == 1 else max(1, args.profile_every // 4)
+        if launches <= 4 * inflight:
+            every = 1
+        for e in engines:
+            e.profile_enable(every)
+        t_start = time.perf_counter()
+        links_done[0] = 0
+        run_range(warm_ticks, ticks)
+        fence()
+        elapsed = time.perf_counter() - t_start
+        n_samples, stage_ms = 0, {}
+        for e in engines:
+            ns, ms = e.profile_read()
+            e.profile_enable(0)
+            n_samples += ns
+            for k, v in ms.items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + v
+        heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
+        if dropped:
+            raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
+
+        if world > 1:
+            rdev = dev if backend == "nccl" else torch.device("cpu")
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            hsum = torch.tensor([heard], dtype=torch.float64, device=rdev)
+            dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
+            heard_total = float(hsum.item())
+        else:
+            heard_total = float(heard)
+
+        links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * (hi - lo)
+        timed_ticks = args.steps * tps
+        value = links_per_tick * timed_ticks / elapsed
+        if stateful:
+            # the links the ticks resolved: the new frames against every receiver; the frames still on the air keep
+            # their entries in the per-receiver lists on the device and are not swept again (SURVEY.md section 8d, C5)
+            value = links_done[0] / elapsed
+
+        sequential = None
+        if stateful:
+            inc, reb = engines[0].air_list_stats()
+            desc += (" -- %.2e link evaluations per tick (new frames only: the frames still on the air stay in the on-air lists on the "
+                     "device; %d ticks added to the lists, %d rebuilt them)" % (links_done[0] / timed_ticks, inc, reb))
+        if (inflight > 1 or batch > 1) and sharded is None:
+            # the same ticks again, one at a time on one context
+            fence()
+            t_seq = time.perf_counter()
+            with torch.cuda.stream(stream):
+                seq_ticks = min(timed_ticks, 1920)
+                for k in range(warm_ticks, warm_ticks + seq_ticks):
+                    t0 = (clock[0] + k - warm_ticks) * tick_us
+                    eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick, t0, W.AIR_US)
+            fence()
+            el = time.perf_counter() - t_seq
+            sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
+                          "ms_per_tick": el / seq_ticks * 1e3,
+                          "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
+                                  "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
+
+        if rank == 0:
+            # Roofline (SURVEY.md section 8(d)).  Per-stage durations come from HIP events recorded on the engine's
+            # stream around every stage of each `profile_every`-th launch of the timed region.  Every stage is priced
+            # with ITS OWN algorithmic bytes (DESIGN.md section 5):
+            #   filter   N_loc*16 (pre-filter records) + T*28 (frame pre-filter records) + cand*12 (candidate entries written)
+            #   exact    cand*(12 + 32) (entries + 32-byte receiver records) + H*13 (staged link records written)
+            #   reorder  H*13 read + H*17 written (pkt 4, dst 4, rssi 8, verdict 1)
+            # The dominant stage's bound is named for what binds it: vector issue slots for these integer / fp32 / fp64
+            # sweeps (PMC: profiles/pmc_traffic.json), its HBM fraction is reported next to it; the HBM figure of the
+            # whole step is section 8(d)'s bytes (N_loc*37 + T*56 + H*25 per tick) over the DRIVER-timed ms_per_step.
+            n_loc = hi - lo
+            h_loc = heard
+            ticks_per_launch = batch
+            try:
+                cand, _ = (last_run[0].slot_stats(last_run[1]) if batch > 1 else eng.slot_stats(0))
+            except Exception:
+                cand = 0
+            b_step = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
+            stage_bytes = {"k_filter": (n_loc * 16 + t_per_tick * 28 + cand * 12) * ticks_per_launch,
+                           "k_exact": (cand * 44 + h_loc * 13) * ticks_per_launch,
+                           "k_reorder": (h_loc * 30) * ticks_per_launch}
+            raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
+            # an event pair with nothing between it measures the bracketing itself (a few us on this
+            # runtime): subtracted from every stage so that the durations are the kernels'
+            bracket_us = raw_us.pop("empty bracket", 0.0)
+            per_stage_us = {k: max(v - bracket_us, 0.0) for k, v in raw_us.items()}
+            dominant = max(per_stage_us, key=per_stage_us.get) if per_stage_us else "k_filter"
+            kern_avg_s = per_stage_us.get(dominant, 0.0) * 1e-6
+            stages = {}
+            for k, us in per_stage_us.items():
+                b = stage_bytes.get(k)
+                stages[k] = {"us": us, "algorithmic_bytes": b,
+                             "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
+                             "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
+            dom_bytes = stage_bytes.get(dominant, b_step)
+            achieved = dom_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
+            traffic = None
+            valu = None
+            bound = "hbm"
+            pmc_note = "no PMC pass on file for this workload"
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                wl = pmc.get(args.workload, {})
+                if batch == 1 and wl.get("ticks_per_launch", 1) != 1:
+                    wl = pmc.get(args.workload + "_tick", {})   # the one-launch tick has its own counter passes
+                ent = wl.get(dominant) or (wl.get("k_tick_frames") if dominant == "k_filter" else None)
+                if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
+                    traffic = ent["hbm_bytes_per_launch"]
+                    pmc_note = ent["source"] + " (commit %s)" % wl.get("commit", "unrecorded")
+                    if "valu_issue_us_per_launch" in ent and kern_avg_s > 0:
+                        # vector-issue time of the stage's instructions on the whole chip (PMC, one context) over the
+                        # stage's duration here: the binding resource of the sweep
+                        share = ent["valu_issue_us_per_launch"] / (kern_avg_s * 1e6)
+                        valu = {"issue_us_per_launch": ent["valu_issue_us_per_launch"], "frac": share,
+                                "instructions_per_launch": ent.get("valu_instructions_per_launch"),
+                                "source": "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU pass of tools/collect_profiles.sh (profiles/pmc_traffic.json)"}
+                        if share > achieved / HBM_PEAK_GBS:
+                            bound = "valu"
+            except (OSError, ValueError):
+                pass
+            step_s = elapsed / args.steps
+            out = {
+                "metric": baseline_metric(),
+                "value": value,
+                "unit": "links/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": step_s * 1e3,
+                "ms_per_tick": elapsed / timed_ticks * 1e3,
+                "higher_is_better": True,
+                "scaling": args.scaling if world > 1 else "strong",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight * batch,
+                           "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
+                           "step": "one launch sequence sweeping ticks_per_step simulated ticks",
+                           "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
+                           "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per batch of ticks"
+                                        % world) if world > 1 else "none"},
+                "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": (valu["frac"] if (bound == "valu" and valu) else achieved / HBM_PEAK_GBS),
+                             "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
+                             "algorithmic_bytes_per_launch": dom_bytes, "traffic_source": pmc_note,
+                             "stages": stages, "event_bracket_us": bracket_us, "valu": valu,
+                             "whole_step": {"algorithmic_bytes": b_step, "ms_per_step": step_s * 1e3,
+                                            "achieved": b_step / step_s / 1e9, "frac": b_step / step_s / 1e9 / HBM_PEAK_GBS,
+                                            "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step"},
+                             "note": "`frac` is the fraction of the BINDING resource: with bound = valu the share of the dominant "
+                                     "kernel's time its vector instructions need to issue (hbm_frac: the same kernel's own "
+                                     "algorithmic bytes against 8 TB/s); one launch sweeps `ticks_per_launch` ticks; durations are "
+                                     "HIP-event brackets on the context's stream while the other contexts' launches share the device"},
+            }
+            if sequential is not None:
+                out["sequential_ticks"] = sequential
+            if world == 1 and not stateful and not as_rank and not args.no_host_transfer:
+                out["with_host_transfer"] = host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick, tick_us,
+                                                               src_dev, pool, batch)
+            if world == 1 and args.workload == "c3" and not args.no_scale_probe:
+                out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch)
+                out["dense_layout"] = dense_probe(rsa, W, torch, dev, device_ordinal)
+            if world == 1 and not args.no_cpu_baseline:
+                st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
+                out["cpu_baseline"] = st
+                out["cpu_baseline_all_cores"] = mt
+            result = out
+        for e in engines:
+            e.close()
+        return result
+
+    out = measure(args)
+    if world > 1 and args.scaling == "strong" and not args.no_weak_probe and not args.as_rank and args.nodes == 0:
+        # the same run once more with the node count grown as sqrt(GPUs) (constant link evaluations per GPU and tick):
+        # printed as an extra key, the headline stays the BASELINE config
+        a2 = copy.copy(args)
+        a2.scaling = "weak"
+        a2.steps = 8 if args.steps <= 0 else min(args.steps, 8)
+        a2.warmup = 2 if args.warmup < 0 else min(args.warmup, 2)
+        a2.no_cpu_baseline = True
+        w = measure(a2)
+        if out is not None and w is not None:
+            out["weak_scaling"] = {k: w[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_tick", "config")}
+    if out is not None:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         sys.stdout.flush()
-    for e in engines:
-        e.close()
     if dist is not None:
         dist.destroy_process_group()
 
