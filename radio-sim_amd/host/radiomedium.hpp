@@ -583,6 +583,117 @@ public:
     }
 };
 
+// The same contract over SEVERAL devices (or several partitions of one device): one rm_group behind one medium
+// object, because the reference host is one process (Main.java:65-73).  The receivers are range-partitioned over the
+// members; a packet is handed to every member, the members' heard links come back merged in node order, and the
+// medium makes the calls of the single-device media.
+class GroupRadioMedium : public AbstractRadioMedium {
+public:
+    GroupRadioMedium(int kind, const std::vector<int32_t> &devices) : kind_(kind)
+    {
+        if (rm_group_create(int32_t(devices.size()), devices.data(), &grp_) != RM_OK)
+            throw std::runtime_error(std::string("no MI355X radio medium group: ") + rm_last_error());
+        rm_model_defaults(&params_, kind);
+        apply();
+    }
+    ~GroupRadioMedium() override { rm_group_destroy(grp_); }
+    GroupRadioMedium(const GroupRadioMedium &) = delete;
+    GroupRadioMedium &operator=(const GroupRadioMedium &) = delete;
+
+    std::string getName() override { return rm_get_name(rm_group_context(grp_, 0)); }
+    void setSimulator(Simulator *sim) override
+    {
+        simulator = sim;
+        if (sim) rm_group_seed(grp_, sim->getRandomSeed());
+        uploaded_ = ~0ull;
+    }
+    rm_model_params &params() { return params_; } // change, then apply()
+    void apply()
+    {
+        if (rm_group_set_model(grp_, &params_) != RM_OK) throw std::invalid_argument(rm_last_error());
+    }
+    void setMatrix(const std::vector<std::vector<double>> &m) // N2NRadioMedium(double[][]): jagged rows as a zero-padded square
+    {
+        size_t side = m.size();
+        for (const auto &row : m) side = std::max(side, row.size());
+        std::vector<double> flat(side * side, 0.0);
+        for (size_t i = 0; i < m.size(); ++i)
+            for (size_t j = 0; j < m[i].size(); ++j) flat[i * side + j] = m[i][j];
+        if (rm_group_set_n2n_matrix(grp_, int32_t(side), flat.data()) != RM_OK) throw std::invalid_argument(rm_last_error());
+    }
+    void transmit(RadioPacket &packet) override
+    {
+        lastError.clear();
+        Simulator *sim = simulator;
+        if (!sim) { lastError = "No simulator"; return; }
+        const std::vector<Node *> &nodes = sim->getNodes();
+        if (!sync(sim, nodes)) return;
+        rm_group_set_time(grp_, sim->getTime());
+        const double txp = packet.getTransmitPower();
+        const int32_t ch = packet.getWirelessChannel();
+        uint32_t heard = 0;
+        uint8_t interference = 0;
+        int rc = rm_group_tick_begin(grp_, packet.getStartTime(), packet.getStartTime());
+        if (rc == RM_OK) rc = rm_group_enqueue_tx(grp_, packet.getSource()->index, packet.getStartTime(), packet.getPacketAirTime(), &txp, &ch);
+        if (rc == RM_OK)
+            rc = rm_group_tick_flush(grp_, nullptr, dst_.data(), verdict_.data(), rssi_.data(), nullptr, uint32_t(dst_.size()), &heard,
+                                     &interference, nullptr);
+        if (rc != RM_OK) { lastError = rm_last_error(); return; }
+        if (kind_ != RM_MODEL_UDGM_CONST) sim->generateTransmissionEvents(packet);
+        for (uint32_t i = 0; i < heard; ++i) {
+            Node *node = nodes[size_t(dst_[i])];
+            if (kind_ == RM_MODEL_UDGM_CONST) sim->deliverRadioPacket(packet, node, rssi_[i]);
+            else sim->generateReceptionEvents(packet, node, rssi_[i], verdict_[i] == RM_DELIVERED);
+        }
+    }
+    std::string lastError;
+
+private:
+    bool sync(Simulator *sim, const std::vector<Node *> &nodes)
+    {
+        if (uploaded_ == sim->nodesVersion()) {
+            for (int i : sim->takeChangedNodes()) {
+                Node &nd = *nodes[size_t(i)];
+                if (rm_group_node_update(grp_, i, nd.getPosition().x, nd.getPosition().y, nd.getPosition().z, nd.getRadio().getTransmitPower(),
+                                         nd.getRadio().getWirelessChannel(), nd.getRadio().isEnabled(), nd.getRadio().getRxProbability(),
+                                         nd.getRadio().getTxProbability()) != RM_OK) {
+                    lastError = rm_last_error();
+                    return false;
+                }
+            }
+            return true;
+        }
+        (void)sim->takeChangedNodes();
+        const size_t n = nodes.size();
+        std::vector<double> x(n), y(n), z(n), tp(n), rp(n), xp(n);
+        std::vector<int32_t> ch(n), id(n);
+        std::vector<uint8_t> en(n);
+        for (size_t i = 0; i < n; ++i) {
+            Node &nd = *nodes[i];
+            x[i] = nd.getPosition().x; y[i] = nd.getPosition().y; z[i] = nd.getPosition().z;
+            tp[i] = nd.getRadio().getTransmitPower(); ch[i] = nd.getRadio().getWirelessChannel();
+            en[i] = nd.getRadio().isEnabled(); rp[i] = nd.getRadio().getRxProbability();
+            xp[i] = nd.getRadio().getTxProbability(); id[i] = nd.getIdAsInteger();
+        }
+        if (rm_group_nodes_upload(grp_, int32_t(n), x.data(), y.data(), z.data(), tp.data(), ch.data(), en.data(), rp.data(), xp.data(),
+                                  id.data()) != RM_OK) {
+            lastError = rm_last_error();
+            return false;
+        }
+        dst_.resize(n + 1); verdict_.resize(n + 1); rssi_.resize(n + 1);
+        uploaded_ = sim->nodesVersion();
+        return true;
+    }
+    int kind_;
+    rm_group *grp_ = nullptr;
+    rm_model_params params_{};
+    uint64_t uploaded_ = ~0ull;
+    std::vector<int32_t> dst_;
+    std::vector<uint8_t> verdict_;
+    std::vector<double> rssi_;
+};
+
+
 // ---- packet traces ----------------------------------------------------
 // util/PcapExporter.java:47-91: classic pcap, every field written big-endian by DataOutputStream:
 // magic 0xa1b2c3d4, version 2.4, thiszone 0, sigfigs 0, snaplen 4096, network 195

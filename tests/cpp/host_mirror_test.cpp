@@ -35,8 +35,41 @@ int main(int argc, char **argv)
         nd->getRadio().setTxProbability(xp);
     }
     std::unique_ptr<RadioMedium> medium;
+    // "udgm@2": the same medium as a group of 2 members on device 0 (receivers split over two contexts)
+    int members = 0;
+    if (const size_t at = model.find('@'); at != std::string::npos) {
+        members = std::atoi(model.c_str() + at + 1);
+        model.resize(at);
+    }
     try {
-        if (model == "udgm") {
+        if (members > 0) {
+            const std::vector<int32_t> devices(size_t(members), 0);
+            if (model == "udgm") {
+                double ratioRx, range;
+                in >> ratioRx >> range;
+                auto *m = new GroupRadioMedium(RM_MODEL_UDGM, devices);
+                medium.reset(m);
+                m->params().udgm_success_ratio_rx = ratioRx;
+                m->params().udgm_transmission_range = range;
+                m->params().udgm_success_ratio_tx = 0.0;
+                m->apply();
+            } else if (model == "const") {
+                medium.reset(new GroupRadioMedium(RM_MODEL_UDGM_CONST, devices));
+            } else if (model == "null") {
+                medium.reset(new GroupRadioMedium(RM_MODEL_NULL, devices));
+            } else if (model == "n2n") {
+                int m;
+                in >> m;
+                std::vector<std::vector<double>> mat(m, std::vector<double>(m));
+                for (auto &row : mat)
+                    for (auto &v : row) in >> v;
+                auto *g = new GroupRadioMedium(RM_MODEL_N2N, devices);
+                medium.reset(g);
+                g->setMatrix(mat);
+            } else {
+                return 2;
+            }
+        } else if (model == "udgm") {
             double ratioRx, range;
             in >> ratioRx >> range;
             auto *m = new UDGMRadioMedium();
@@ -97,8 +130,11 @@ int main(int argc, char **argv)
         sim.setTime(now);
         const size_t before = sim.calls.size();
         medium->transmit(*packets.back());
-        auto *g = dynamic_cast<GpuRadioMedium *>(medium.get());
-        if (!g->lastError.empty()) std::printf("error %s\n", g->lastError.c_str());
+        if (auto *g = dynamic_cast<GpuRadioMedium *>(medium.get())) {
+            if (!g->lastError.empty()) std::printf("error %s\n", g->lastError.c_str());
+        } else if (auto *gg = dynamic_cast<GroupRadioMedium *>(medium.get())) {
+            if (!gg->lastError.empty()) std::printf("error %s\n", gg->lastError.c_str());
+        }
         for (size_t i = before; i < sim.calls.size(); ++i) {
             const MediumCall &c = sim.calls[i];
             std::printf("call %d %d %d %.17g %d %lld %lld\n", int(c.kind), p, c.destination ? c.destination->index : -1, c.rssi,

@@ -64,8 +64,12 @@ def _run(path):
     return name, base, calls, errors
 
 
-@pytest.mark.parametrize("model", ["udgm", "const", "null", "n2n"])
+@pytest.mark.parametrize("model", ["udgm", "const", "null", "n2n", "udgm@2", "n2n@3", "const@2"])
 def test_mirror_makes_the_reference_calls(tmp_path, O, model):
+    """`model@k`: the same medium as a GroupRadioMedium of k contexts on this GPU (rm_group_*: receivers split over the
+    members, draw counts through the host) -- the calls must be those of the single context, i.e. the oracle's."""
+    scenario_model = model
+    model = model.split("@")[0]
     n = 400
     rng = np.random.default_rng(21)
     nd = O.NodeTable(n)
@@ -101,7 +105,7 @@ def test_mirror_makes_the_reference_calls(tmp_path, O, model):
     packets.append({"id": "nobody", "start": 0, "now": 0, "hex": "00"})       # unknown source
     packets.append({"id": ids[3], "src": 3, "start": 99000, "now": 0, "hex": ""})   # zero-length payload
 
-    name, base, calls, errors = _run(_scenario(tmp_path, O, model, nd, ids, packets, extra, seed))
+    name, base, calls, errors = _run(_scenario(tmp_path, O, scenario_model, nd, ids, packets, extra, seed))
     assert base == (-100.0, -100.0)          # AbstractRadioMedium.java:38 ; Transciever.getRSSI() while idle
     assert name == {"udgm": "UDGM Radio Medium", "const": "UDGM Constant Loss Radio Medium",
                     "null": "Null radio medium - just forwards incoming packets to all other nodes",
