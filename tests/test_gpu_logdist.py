@@ -2,6 +2,8 @@
 capture, multi-tick overlap -- DESIGN.md "Extension spec") with the CPU oracle's independent
 implementation of the same text.  Verdicts / heard sets bit-exact; rssi and sinr are compared
 bit-exactly as well (tolerance of the north star: 1e-5 relative)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -237,7 +239,8 @@ def test_sinr_lists_live_across_ticks(engine, rsa, O):
                        [320, 2048, 8128, 8128, 20000], what="rings")
     inc, reb = engine.air_list_stats()
     assert got > 100
-    assert (inc - inc0, reb - reb0) == (187, 1)     # one build, then only new frames (12 ticks had none)
+    if os.environ.get("RM_AIR_LISTS") != "0":        # (the developer knob that rebuilds the lists every tick)
+        assert (inc - inc0, reb - reb0) == (187, 1) # one build, then only new frames (12 ticks had none)
 
 
 def test_sinr_lists_rebuilt_when_something_changes(engine, rsa, O):
@@ -270,7 +273,8 @@ def test_sinr_lists_rebuilt_when_something_changes(engine, rsa, O):
     got = _overlap_run(engine, rsa, O, nd, mdl, rng, 20, 35, [320, 2048, 8128], hook=hook, t_of=t_of, what="changes")
     inc, reb = engine.air_list_stats()
     assert got > 30
-    assert reb - reb0 == 5 and inc - inc0 == 15     # first tick, three node changes, the clock going back
+    if os.environ.get("RM_AIR_LISTS") != "0":
+        assert reb - reb0 == 5 and inc - inc0 == 15 # first tick, three node changes, the clock going back
 
 
 def test_sinr_lists_after_a_dropped_tick(engine, rsa, O):
