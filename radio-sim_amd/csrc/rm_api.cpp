@@ -751,6 +751,7 @@ int build_shadow_table(rm_context *c)
 
 int prepare_nodes(rm_context *c)
 {
+    if (c->rx_dirty || c->prefilter_dirty) c->air.valid = false; // whatever the SINR lists' entries were computed from has changed
     if (c->rx_dirty) RM_TRY(rebuild_receivers(c));
     if (!c->prefilter_dirty) return RM_OK;
     const int groups = (c->n_rx + rm::kGroup - 1) / rm::kGroup;

@@ -333,3 +333,28 @@ def test_json_number_text_and_parser(tmp_path):
             assert wire == (want[:-2] if want.endswith(".0") else want)     # cutOffPointZero
     for (k, a, want), got in zip(cases, out[len(xs):]):
         assert got == want, (k, a, got)
+
+
+def test_emulink_session_shapes(server):
+    """The messages the reference's own emulator client sends, member for member (mspsim-emulink EmuLink.java:97-231:
+    sendInit, sendPacket, serveForever's time-set, the reply to time-step with the id before the reply member, sendLog),
+    and what that client needs back: a greeting it can parse as JSON, time-step with "parameters"."time", the
+    controller's reply carrying its id, receive / error messages with a string "node-id"."""
+    emu = connect(server)
+    emu.raw('{"command":"node-config-set","parameters":{"node-id":1,"position":[10.0,20.0,0.0]}}\r\n')
+    emu.raw('{"command":"node-config-set","parameters":{"node-id":2,"position":[15.0,20.0,0.0]}}\r\n')
+    emu.raw('{"command":"time-set","parameters":{"time":1000},"id":1}\r\n')          # the emulator is the time controller too
+    step = json.loads(emu.line())
+    assert step["command"] == "time-step" and step["id"] == 1001 and step["parameters"]["time"] == 1000
+    assert [i["node-id"] for i in step["parameters"]["node-info"]] == ["1", "2"]
+    emu.raw('{"command":"transmit","node-id":1,"packet-data":"0A0B0C","time":0}\r\n')
+    # (this server runs without a medium: the reference answers a transmit it cannot evaluate with an error, id-less here)
+    assert emu.line() == b'{"reply":"error","reply-object":{"class":"command-error","description":"no radio medium available"}}'
+    emu.raw('{"id":1001,"reply":"OK"}\r\n')
+    assert emu.line() == b'{"reply":"OK","id":1}'
+    emu.raw('{"command":"log","parameters":{"node-id":1,"message":"booted"}}\r\n')
+    emu.raw('{"command":"time-set","parameters":{"time":2000},"id":2}\r\n')
+    assert json.loads(emu.line())["id"] == 1002
+    emu.raw('{"id":1002,"reply":"OK"}\r\n')
+    assert emu.line() == b'{"reply":"OK","id":2}'
+    emu.close()
