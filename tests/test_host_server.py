@@ -20,6 +20,8 @@ GREETING = b'{"radio-simulator":{"name":"RSIM 0.1","api-version":"0.6"},"status"
 
 
 def build_server(rsa, tmp_path):
+    if os.environ.get("RSIM_SERVER_EXE"):      # e.g. a sanitizer build of the same source
+        return os.environ["RSIM_SERVER_EXE"]
     lib = os.path.dirname(rsa.library_path())
     exe = os.path.join(str(tmp_path), "rsim_server")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe, os.path.join(HOST, "rsim_server.cpp"),
