@@ -232,7 +232,9 @@ def test_sinr_lists_live_across_ticks(engine, rsa, O):
     rng = np.random.default_rng(12)
     params = _sinr_params()
     configure_engine(engine, nd, "logdist", params)
-    engine.set_link_capacity(1 << 19)               # 2048 entries per sub-ring: ~1M entries wrap them twice
+    # 2048 entries per sub-ring: ~1M entries wrap them twice (without the shadowing table -- a developer knob -- the
+    # filter hands six times the candidates to the exact stage, and the candidate shards need the room instead)
+    engine.set_link_capacity(1 << 19 if not os.environ.get("RM_NO_SHADOW_TABLE") else 1 << 23)
     mdl = oracle_model(O, "logdist", params)
     inc0, reb0 = engine.air_list_stats()
     got = _overlap_run(engine, rsa, O, nd, mdl, rng, 200, lambda t: 0 if t % 17 == 5 else rng.integers(1, 30),

@@ -1,5 +1,7 @@
 """Parity of the HIP engine (through the C ABI) with the CPU oracle: the four reference media.
 Bit-exact on heard sets / verdicts / draw consumption; rssi is the packet's transmit power."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,7 +174,9 @@ def test_frames_heard_by_everybody(engine, rsa, O, lossy):
         nd.rxprob[:] = np.where(rng.random(n) < 0.6, 1.0, rng.uniform(0, 1, n))
     nd.enabled[rng.choice(n, 30, replace=False)] = 0
     params = {"udgm_transmission_range": 5000.0}
-    engine.set_link_capacity(1 << 20)
+    # (RM_FRAME_TICK=0, the developer knob for the three-launch sweep: its candidate shards follow the receiver tiles, and
+    # a table of 12 tiles with everything heard needs far more room per shard)
+    engine.set_link_capacity(1 << 20 if os.environ.get("RM_FRAME_TICK") != "0" else 1 << 24)
     pk = nd.packets(rng.choice(n, 40, replace=False), 0, 320)
     gpu, cpu = run_both(O, rsa, engine, nd, "udgm", params, pk, seed=3)
     assert cpu.count > 40 * 2900
