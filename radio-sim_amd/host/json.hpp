@@ -75,6 +75,23 @@ inline std::string json_double_text(double d)
     return s;
 }
 
+// writers for messages that are formatted directly (no object tree): the same text as Json::of(v).toString()
+inline void append_int(std::string &out, int64_t v)
+{
+    char buf[24];
+    const auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    out.append(buf, r.ptr);
+}
+inline void append_double(std::string &out, double d)
+{
+    // whole numbers below 1e7 in magnitude -- every idle node's -100 -- are "<integer>.0" in Java, the ".0" cut off
+    if (d == std::floor(d) && std::fabs(d) < 1e7 && !(d == 0.0 && std::signbit(d))) {
+        append_int(out, int64_t(d));
+        return;
+    }
+    out += json_double_text(d);
+}
+
 class Json {
 public:
     enum Type { NUL, BOOL, NUMBER, STRING, ARRAY, OBJECT };
@@ -168,6 +185,10 @@ public:
         write(out);
         return out;
     }
+
+    // the text of a JSON string / of a whole value appended to `out` (for writers that format a message directly)
+    static void quote(const std::string &s, std::string &out) { write_string(s, out); }
+    void append_to(std::string &out) const { write(out); }
 
     static Json parse(const std::string &text)
     {

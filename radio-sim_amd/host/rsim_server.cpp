@@ -94,10 +94,18 @@ struct Connection {
     bool send(const Json &json) // :261-287 (useLength = false)
     {
         if (fd < 0) return false; // output == null after close()
-        out += json.toString();
+        json.append_to(out);
         out += "\r\n";
         ++messagesOut;
         return true;
+    }
+    // the same for a message whose minimal JSON text the caller has written itself (the per-node and per-delivery
+    // messages: no object tree for a hundred thousand node-infos)
+    bool open() const { return fd >= 0; }
+    void sent()
+    {
+        out += "\r\n";
+        ++messagesOut;
     }
 };
 
@@ -404,15 +412,6 @@ private:
         }
         return out;
     }
-    static Json nodeInfoJson(const Node &n, const Info &i)
-    {
-        Json o = Json::object();
-        o.add("node-id", Json::of(n.getId()));
-        o.add("rssi", Json::of(i.rssi));
-        o.add("receiving", Json::of(i.receiving));
-        o.add("wireless-channel", Json::of(i.channel));
-        return o;
-    }
 
     // ---------------------------------------------------------------- Simulator.java's time stepping
     int64_t nextMessageId() // :118-120, :366-372
@@ -436,13 +435,29 @@ private:
         for (Node *n : sim_.getNodes())
             if (connectionOf(n) == &c) mine.push_back(n);
         const std::vector<Info> info = nodeInfo(mine);
-        Json infos = Json::array();
-        for (size_t i = 0; i < mine.size(); ++i) infos.push(nodeInfoJson(*mine[i], info[i]));
-        Json json = Json::object();
-        json.add("command", Json::of("time-step"));
-        json.add("id", Json::of(timeId));
-        json.add("parameters", Json::object().add("time", Json::of(time)).add("node-info", infos));
-        c.send(json);
+        if (!c.open()) return; // send() on a closed connection: nothing goes out
+        // {"command":"time-step","id":..,"parameters":{"time":..,"node-info":[{..},..]}} -- written directly: this is
+        // the one message whose size grows with the node count
+        std::string &o = c.out;
+        o += "{\"command\":\"time-step\",\"id\":";
+        append_int(o, timeId);
+        o += ",\"parameters\":{\"time\":";
+        append_int(o, time);
+        o += ",\"node-info\":[";
+        for (size_t i = 0; i < mine.size(); ++i) {
+            if (i) o += ',';
+            o += "{\"node-id\":";
+            Json::quote(mine[i]->getId(), o);
+            o += ",\"rssi\":";
+            append_double(o, info[i].rssi);
+            o += ",\"receiving\":";
+            append_int(o, info[i].receiving);
+            o += ",\"wireless-channel\":";
+            append_int(o, info[i].channel);
+            o += '}';
+        }
+        o += "]}}";
+        c.sent();
     }
     void stepTime(int64_t time, int64_t id) // :171-194
     {
@@ -457,7 +472,9 @@ private:
         }
         emulatorsLeft_ = int(emulators_.size());
         const std::vector<Connection *> em = emulators_;
+        const auto t0 = std::chrono::steady_clock::now();
         for (Connection *e : em) emulateToTime(*e, time, waitingForTimeId_);
+        usStepMessages_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
     void emulatorTimeStepped(Connection &client, int64_t id) // :134-153
     {
@@ -471,12 +488,16 @@ private:
         waitingForTimeId_ = -1;
         // queued transmissions are evaluated at the old time, the clock moves, the events up to the new time fire:
         // the deliveries come back in the reference queue's pop order
+        const auto t0 = std::chrono::steady_clock::now();
         sim_.calls.clear();
         sim_.emulatorTimeStepDone(stepTime_);
         mediumError("time step");
+        const auto t1 = std::chrono::steady_clock::now();
         for (const emul8::MediumCall &call : sim_.calls)
             if (call.kind == emul8::MediumCall::DELIVER) deliverRadioPacket(*call.packet, *call.destination, call.rssi);
         sim_.calls.clear();
+        usMedium_ += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        usReceiveMessages_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         ++steps_;
         prunePackets();
         if (timeController_) timeController_->send(Json::object().add("reply", Json::of("OK")).add("id", Json::of(timeControllerLastTimeId_)));
@@ -488,15 +509,22 @@ private:
             VLOG("Node %s has no client connection", dst.getId().c_str());
             return;
         }
-        Json json = Json::object();
-        json.add("command", Json::of("receive"));
-        json.add("node-id", Json::of(dst.getId()));
-        json.add("time-start", Json::of(p.getStartTime()));
-        json.add("time-end", Json::of(p.getEndTime()));
-        json.add("rf-power", Json::of(rssi));
-        json.add("wireless-channel", Json::of(p.getWirelessChannel()));
-        json.add("packet-data", Json::of(p.getPacketDataAsHex()));
-        cc->send(json);
+        // RadioPacket.toJsonDestination, written directly (tens of thousands per tick)
+        std::string &o = cc->out;
+        o += "{\"command\":\"receive\",\"node-id\":";
+        Json::quote(dst.getId(), o);
+        o += ",\"time-start\":";
+        append_int(o, p.getStartTime());
+        o += ",\"time-end\":";
+        append_int(o, p.getEndTime());
+        o += ",\"rf-power\":";
+        append_double(o, rssi);
+        o += ",\"wireless-channel\":";
+        append_int(o, p.getWirelessChannel());
+        o += ",\"packet-data\":";
+        Json::quote(p.getPacketDataAsHex(), o);
+        o += '}';
+        cc->sent();
         ++deliveries_;
     }
     void prunePackets() // the medium refers to a packet until its last event has fired
@@ -719,8 +747,12 @@ private:
 public:
     void printStats() const
     {
-        std::fprintf(stderr, "rsim_server: %llu steps, %llu transmissions, %llu deliveries, time %lld\n", (unsigned long long)steps_,
-                     (unsigned long long)transmissions_, (unsigned long long)deliveries_, (long long)sim_.getTime());
+        const double k = steps_ ? 1.0 / double(steps_) : 0.0;
+        std::fprintf(stderr,
+                     "rsim_server: %llu steps, %llu transmissions, %llu deliveries, time %lld; per step: time-step messages %.1f us, "
+                     "medium (tick + drain, deliveries on the host) %.1f us, receive messages %.1f us\n",
+                     (unsigned long long)steps_, (unsigned long long)transmissions_, (unsigned long long)deliveries_,
+                     (long long)sim_.getTime(), usStepMessages_ * k, usMedium_ * k, usReceiveMessages_ * k);
     }
 
 private:
@@ -739,6 +771,7 @@ private:
     int emulatorsLeft_ = 0;
     int64_t stepTime_ = 0, timeControllerLastTimeId_ = -1, waitingForTimeId_ = -1, messageId_ = 1000;
     uint64_t steps_ = 0, transmissions_ = 0, deliveries_ = 0;
+    double usStepMessages_ = 0, usMedium_ = 0, usReceiveMessages_ = 0; // the server's own work per step (printStats)
 };
 
 } // namespace rsim

@@ -26,6 +26,11 @@ int main()
                 } catch (const rsim::JsonError &) {
                     wire = "refused";
                 }
+                if (wire != "refused") { // the direct writer must give the same text
+                    std::string direct;
+                    rsim::append_double(direct, d);
+                    if (direct != wire) wire = "MISMATCH:" + direct;
+                }
                 std::printf("%s %s\n", rsim::java_double_to_string(d).c_str(), wire.c_str());
             } else if (line[0] == 'p') {
                 std::printf("%s\n", rsim::Json::parse(arg).toString().c_str());

@@ -32,6 +32,7 @@ def build_server(rsa, tmp_path):
 class Peer:
     def __init__(self, port):
         self.s = socket.create_connection(("127.0.0.1", port), timeout=10)
+        self.s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)   # many small writes: no 40 ms Nagle / delayed-ACK stalls
         self.buf = b""
 
     def raw(self, data):

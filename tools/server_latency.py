@@ -64,3 +64,4 @@ try:
 finally:
     proc.terminate()
     proc.wait(timeout=10)
+    print(proc.stderr.read().strip().splitlines()[-1])   # the server's own share per step
