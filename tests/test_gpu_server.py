@@ -40,7 +40,9 @@ def info_json(ident, rssi, state, channel):
 
 @pytest.mark.parametrize("model,mode", [("udgm", "tick"), ("udgm", "packet"), ("nullrm", "tick"), ("n2n-link", "tick")])
 def test_server_end_to_end(O, model, mode):
-    n = 90 if model != "n2n-link" else 24
+    n_reg = 90 if model != "n2n-link" else 24      # nodes registered before the first step
+    late = model == "udgm"                         # one more node joins in mid-run (the node table grows under the medium)
+    n = n_reg + (1 if late else 0)
     n_emu = 3
     rng = np.random.default_rng(91)
     nd = O.NodeTable(n)
@@ -53,6 +55,9 @@ def test_server_end_to_end(O, model, mode):
     nd.rxprob[:] = np.where(rng.random(n) < 0.5, 1.0, np.round(rng.uniform(0, 1, n), 3))
     nd.txprob[rng.random(n) < 0.2] = 0.6
     owner = rng.integers(0, n_emu, n)
+    if late:
+        nd.enabled[n - 1] = 0                      # until it joins, the oracle's table holds it as a radio that is off
+        nd.rxprob[n - 1], nd.txprob[n - 1], nd.channel[n - 1] = 1.0, 1.0, 26
     seed = 4242
     if model == "n2n-link":
         matrix = np.round(rng.uniform(0, 1, (n, n)), 3)
@@ -83,7 +88,7 @@ def test_server_end_to_end(O, model, mode):
             assert p.line().startswith(b'{"id":%d,"reply":"OK"' % k[0])
 
         # node registration, in node order (the node table's order is the order of the receivers)
-        for i in range(n):
+        for i in range(n_reg):
             prm = {"node-id": i + 1, "position": [float(nd.x[i]), float(nd.y[i]), float(nd.z[i])], "rf-power": float(nd.txpower[i]),
                    "wireless-channel": int(nd.channel[i]), "rx-loss": float(nd.rxprob[i]), "tx-loss": float(nd.txprob[i])}
             if not nd.enabled[i]:
@@ -104,13 +109,21 @@ def test_server_end_to_end(O, model, mode):
             # every emulator is told, with the state its nodes had after the last drain
             rssi, st = sim.node_info(enabled=nd.enabled)
             for e in range(n_emu):
-                mine = [i for i in range(n) if owner[i] == e]
+                mine = [i for i in range(n_reg) if owner[i] == e]
                 want = '{"command":"time-step","id":%d,"parameters":{"time":%d,"node-info":[%s]}}' % (
                     1001 + t, step, ",".join(info_json(str(i + 1), rssi[i], st[i], nd.channel[i]) for i in mine))
                 assert emus[e].line() == want.encode(), (t, e)
             imm = []
             for e in rng.permutation(n_emu):
-                mine = [i for i in range(n) if owner[i] == e]
+                if late and t == 7 and e == owner[n - 1] and n_reg < n:      # a new node: the whole table is uploaded again
+                    i = n - 1
+                    nd.enabled[i] = 1
+                    emus[e].send({"command": "node-config-set", "id": 7000, "parameters": {
+                        "node-id": i + 1, "position": [float(nd.x[i]), float(nd.y[i]), float(nd.z[i])], "rf-power": float(nd.txpower[i])}})
+                    want = '{"id":7000,"reply":"OK","reply-object":{"node-info":%s}}' % info_json(str(i + 1), -100.0, 0, 26)
+                    assert emus[e].line() == want.encode()
+                    n_reg = n
+                mine = [i for i in range(n_reg) if owner[i] == e]
                 if t in (5, 9) and mine:     # a node moves / changes channel / loses its receiver in mid-run
                     i = mine[int(rng.integers(len(mine)))]
                     nd.x[i], nd.y[i] = float(np.round(rng.uniform(0, side), 3)), float(np.round(rng.uniform(0, side), 3))
