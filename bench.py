@@ -694,9 +694,13 @@ def main():
         a2.steps = 8 if args.steps <= 0 else min(args.steps, 8)
         a2.warmup = 2 if args.warmup < 0 else min(args.warmup, 2)
         a2.no_cpu_baseline = True
-        w = measure(a2)
-        if out is not None and w is not None:
-            out["weak_scaling"] = {k: w[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_tick", "config")}
+        try:
+            w = measure(a2)
+            if out is not None and w is not None:
+                out["weak_scaling"] = {k: w[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_tick", "config")}
+        except Exception as e:   # the headline line is printed whatever happens to the extra pass
+            if out is not None:
+                out["weak_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if out is not None:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         sys.stdout.flush()
