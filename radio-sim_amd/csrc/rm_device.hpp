@@ -445,7 +445,10 @@ struct SinrOut {
 // SINR of one heard link of a new frame (start w_start, length w_air) at the receiver in engine position `pos`: the
 // receiver's list holds every co-channel frame on the air that is significant there; the interferers that overlap the
 // frame in time are summed exactly (Q80: the order of the list does not matter), a SELF entry is half duplex.
-// `self` is the link's own entry.
+// `self` is the link's own entry -- or kAirOwnInSum when the caller does not know it: the link's own entry is then
+// summed like every other and taken out again afterwards, which is exact in Q80 (the entry exists iff the link is an
+// interferer itself, rssi >= ifloor, and it is counted iff the frame overlaps itself and has not left the air).
+constexpr int kAirOwnInSum = -2;
 RM_D SinrOut air_sinr(const ModelDev &m, const TickDev &t, int pos, int self, int64_t w_start, int64_t w_air, double rssi)
 {
     U128 acc = {0, 0};
@@ -466,6 +469,8 @@ RM_D SinrOut air_sinr(const ModelDev &m, const TickDev &t, int pos, int self, in
         }
         idx = k.next;
     }
+    if (self == kAirOwnInSum && rssi >= m.ld_ifloor && w_air > 0 && w_end > t.air.t_begin)
+        acc = u128_sub(acc, q80_from_double(det_pow10(rssi / 10.0))); // eval_link's lin of this very link
     SinrOut r;
     r.sinr = rssi - 10.0 * det_log10(q80_to_double(acc) + m.ld_noise_lin);
     r.collided = half_duplex || !(r.sinr >= m.ld_capture);

@@ -157,6 +157,14 @@ RM_HD U128 u128_add(U128 a, U128 b)
     return r;
 }
 
+RM_HD U128 u128_sub(U128 a, U128 b) // a >= b
+{
+    U128 r;
+    r.lo = a.lo - b.lo;
+    r.hi = a.hi - b.hi - (a.lo < b.lo ? 1u : 0u);
+    return r;
+}
+
 RM_HD U128 q80_from_double(double lin)
 {
     U128 r = {0, 0};

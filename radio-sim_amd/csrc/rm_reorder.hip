@@ -81,7 +81,9 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 in_e = (SINR && valid) ? t.a_e[o] : 0;
             }
             SinrOut so = {0.0, false};
-            if (SINR && t.air.pool != nullptr && valid) { // the lists that live across ticks: the walk happens here, one lane per heard link
+            if (SINR && t.seg_ordered) { // the one-launch tick: k_sinr_frames has written sinr and verdict into the segment
+                if (valid) so.sinr = t.a_sinr[o];
+            } else if (SINR && t.air.pool != nullptr && valid) { // the lists that live across ticks: the walk happens here, one lane per heard link
                 const rm_tx_record &w = t.tx[t.first_new + q];
                 so = air_sinr(m, t, t.st_dst[in_e], t.st_next[in_e], w.start_us, w.air_us, in_rssi);
             }
@@ -112,7 +114,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         }
     }
     if (!STOCH) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-    if (SINR && t.air.pool != nullptr && publisher) air_end(t);
+    if (SINR && t.air.pool != nullptr && !t.seg_ordered && publisher) air_end(t);
 }
 
 template <bool STOCH, bool SINR, int MODE>

@@ -59,7 +59,7 @@ RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
     return dist2_f32(dx, dy, dz) <= f.w;
 }
 
-template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
+template <int MODEL, bool STOCH, bool SHADOW, bool FLAT, bool SINR = false>
 RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev &t, const int seg_len)
 {
     // one LDS block, carved by hand: the lists are dead when a frame that outgrew its segment orders its links,
@@ -136,6 +136,7 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
     if (blockIdx.x == 0) {
         if (tid < 8) t.next_counters[tid] = 0u;
         t.next_shard_count[tid * kShardStride] = 0u; // kBlock == kShards
+        if (SINR && tid == 0 && t.air.bad[0]) t.stage_count[1] = 1u; // the on-air lists are broken until the host rebuilds them
     }
     for (int i = blockIdx.x * blockDim.x + tid; i < t.zero_len; i += gridDim.x * blockDim.x) t.cand_tot_next[i] = 0u;
 
@@ -288,6 +289,9 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
                             bool heard = false;
                             int orig = 0;
                             double rssi = 0.0, prob = 1.0;
+                            bool ins = false; // (SINR) the link is significant at its receiver: an entry of that receiver's on-air list
+                            double ins_lin = 0.0;
+                            int ins_pos = 0;
                             if (c < nc) {
                                 const int pos = s_cand[c];
                                 RxRecord rx_;
@@ -304,7 +308,12 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
                                     rx_.enabled = 1;
                                     rx_.rxprob = (rc32.flags & 1u) ? nd.rxprob[pos] : 1.0;
                                 }
-                                const LinkEval ev = eval_link<MODEL, false>(m, nd, tx, rx_, true);
+                                const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, rx_, true);
+                                if (SINR) {
+                                    ins = pass == 0 && ev.append && (ev.flags & kFlagInterferer) != 0;
+                                    ins_lin = ev.lin;
+                                    ins_pos = pos;
+                                }
                                 if (ev.wanted) {
                                     heard = true;
                                     orig = rx_.orig;
@@ -316,6 +325,11 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
                                         prob = (MODEL == RM_MODEL_UDGM) ? ev.aux : 1.0;
                                     }
                                 }
+                            }
+                            if (SINR) { // every wave of the workgroup is here: one allocation per wave (first pass only)
+                                // (gathering a frame's entries in LDS and inserting them in one go was measured: no faster)
+                                const int aidx = air_alloc(t, ins, air_sub(t));
+                                if (ins) air_link(t, aidx, ins_pos, tx.start_us, tx.air_us, ins_lin, kAirInterferer);
                             }
                             const uint64_t hm = ballot64(heard);
                             if (hm) {
@@ -508,12 +522,48 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
         __syncthreads();
         if (s_nres == 0xFFFFFFFFu) break; // dropped
     }
+    if (SINR && wave == 0) { // half duplex: the frame's SELF entry in its source's list (two atomics in a row: last)
+        const bool want = lane == 0 && tx.src >= nd.rx_first && tx.src < nd.rx_first + nd.n_rx;
+        const int aidx = air_alloc(t, want, air_sub(t));
+        if (want) air_link(t, aidx, nd.pos_of[tx.src - nd.rx_first], tx.start_us, tx.air_us, 0.0, kAirSelf);
+    }
 }
 
 template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
 __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
 {
     tick_frames_body<MODEL, STOCH, SHADOW, FLAT>(nd, m, t, seg_len);
+}
+
+// The SINR medium in the same form (a lone tick that only adds its new frames to the on-air lists, section 4.4 of
+// DESIGN.md): the exact phase also leaves the frame's significant links in their receivers' lists, and a second launch --
+// the lists are complete only when every frame of the tick has been evaluated -- walks them for the heard links.
+template <bool STOCH, bool SHADOW, bool FLAT>
+__global__ void __launch_bounds__(256) k_tick_frames_sinr(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
+{
+    tick_frames_body<RM_MODEL_LOGDIST, STOCH, SHADOW, FLAT, true>(nd, m, t, seg_len);
+}
+
+// one wave per frame, one lane per heard link of its (ordered) segment: sinr and the capture / half-duplex verdict
+__global__ void __launch_bounds__(256) k_sinr_frames(const NodesDev nd, const ModelDev m, const TickDev t)
+{
+    const int lane = threadIdx.x & 63;
+    const int n_new = t.n_active - t.first_new;
+    for (int q = blockIdx.x * 4 + wave_index(); q < n_new; q += gridDim.x * 4) { // wave-uniform
+        const int slot = q + t.shift;
+        const uint32_t src0 = uniform_u(t.seg_off[slot]);
+        const uint32_t len = uniform_u(t.cursor[slot]);
+        const rm_tx_record &w = t.tx[t.first_new + q];
+        for (uint32_t c = lane; c < len; c += 64) {
+            const uint32_t o = src0 + c;
+            const double rssi = t.a_rssi[o];
+            const int pos = nd.pos_of[t.a_dst[o] - nd.rx_first];
+            const SinrOut so = air_sinr(m, t, pos, kAirOwnInSum, w.start_us, w.air_us, rssi);
+            t.a_sinr[o] = so.sinr;
+            if (so.collided) t.a_verdict[o] = uint8_t(RM_INTERFERED);
+        }
+    }
+    if (blockIdx.x == 0) air_end(t); // the next tick's entries begin where the sub-rings' tails are now
 }
 
 // the same for the ticks of a batch (blockIdx.z = tick; descriptors in device memory, as the sweep's batched kernels)
@@ -546,7 +596,6 @@ __global__ void __launch_bounds__(256) k_frames_cand(const NodesDev nd, const Mo
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
     const int e = blockIdx.x; // eval-relative frame
-    const int n_eval = t.n_active - t.first_eval;
     const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
     const int n_boxes = (n_groups + 15) / 16;
     const int abs_i = t.first_eval + e;
@@ -768,7 +817,8 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
                 v.pkt[d] = int(q);
                 v.dst[d] = t.a_dst[src0 + c];
                 v.rssi[d] = t.a_rssi[src0 + c];
-                v.verdict[d] = t.a_verdict[src0 + c]; // (this path has no SINR extension: no sinr column)
+                v.verdict[d] = t.a_verdict[src0 + c];
+                if (v.sinr != nullptr && t.out_sinr != nullptr) v.sinr[d] = t.a_sinr[src0 + c]; // (the SINR extension only)
             }
         }
         if (lane == 0) {
@@ -802,7 +852,10 @@ int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m
 {
     const bool geometric = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_UDGM_CONST || m.kind == RM_MODEL_LOGDIST);
     const bool sinr = m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR);
-    if (!geometric || sinr || !cfg.sorted || !cfg.bbox || cfg.f64_filter || t.use_matrix) return 0;
+    const char *e_sf = getenv("RM_SINR_FRAMES"); // 0: the SINR medium's lone ticks through the sweep kernels (read per tick: tests switch it)
+    const bool no_sinr_frames = e_sf && atoi(e_sf) == 0;
+    if (sinr && (no_sinr_frames || t.air.pool == nullptr || t.first_eval != t.first_new)) return 0; // (a rebuild sweeps old frames too)
+    if (!geometric || !cfg.sorted || !cfg.bbox || cfg.f64_filter || t.use_matrix) return 0;
     if (t.n_cnt <= 0 || t.n_cnt > kFusedScanMax || t.n_rx <= 0 || t.n_active <= t.first_new) return 0;
     // half of the records for the fixed segments, the rest for frames that outgrow theirs
     const uint32_t per = (t.cap / 2u) / uint32_t(t.n_cnt);
@@ -829,6 +882,22 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
         else RM_FR2(MODEL, false, SH);                                                                                 \
     } while (0)
     static const bool no_shadow = getenv("RM_FR_NO_SHADOW") != nullptr;
+    if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
+        const bool sh = cfg.shadow && m.shadow_tbl && !no_shadow;
+        const bool flat = n_groups <= flat_max;
+#define RM_FRS(ST, SH, FL) hipLaunchKernelGGL((k_tick_frames_sinr<ST, SH, FL>), grid, block, 0, s, nd, m, t, seg_len)
+        if (cfg.stochastic) {
+            if (sh) { if (flat) RM_FRS(true, true, true); else RM_FRS(true, true, false); }
+            else { if (flat) RM_FRS(true, false, true); else RM_FRS(true, false, false); }
+        } else {
+            if (sh) { if (flat) RM_FRS(false, true, true); else RM_FRS(false, true, false); }
+            else { if (flat) RM_FRS(false, false, true); else RM_FRS(false, false, false); }
+        }
+#undef RM_FRS
+        const int n_new = t.n_active - t.first_new;
+        hipLaunchKernelGGL(k_sinr_frames, dim3(max(1, min(4096, cdiv(n_new, 4)))), dim3(256), 0, s, nd, m, t);
+        return hipGetLastError();
+    }
     switch (m.kind) {
     case RM_MODEL_UDGM: RM_FR(RM_MODEL_UDGM, false); break;
     case RM_MODEL_UDGM_CONST: RM_FR(RM_MODEL_UDGM_CONST, false); break;

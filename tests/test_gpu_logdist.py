@@ -312,9 +312,11 @@ def test_sinr_lists_after_a_dropped_tick(engine, rsa, O):
 
 
 def test_sinr_lists_with_the_per_frame_candidate_kernel(engine, rsa, O, monkeypatch):
-    """Tables large enough for the tiled filter take their candidates from k_frames_cand (one frame per workgroup);
-    RM_FILTER=wg selects that regime for a table of test size."""
+    """The three-kernel form of a lone SINR tick (rebuild ticks, more than 4096 frames): tables large enough for the tiled
+    filter take their candidates from k_frames_cand (one frame per workgroup); RM_FILTER=wg selects that regime for a
+    table of test size."""
     monkeypatch.setenv("RM_FILTER", "wg")
+    monkeypatch.setenv("RM_SINR_FRAMES", "0")       # (the one-launch form of the SINR tick would take these ticks otherwise)
     n = 6000
     nd = _layout(O, n, seed=53, z=3.0)
     rng = np.random.default_rng(15)

@@ -10,7 +10,7 @@ FIRST=${2:-0}
 LAST=${3:-99}
 K=("RM_FILTER=wg" "RM_FILTER=wg RM_WG_RPT=4" "RM_FILTER=wg RM_WG_RPT=2" "RM_FILTER=grid" "RM_GRAPH=1"
    "RM_NO_SHADOW_TABLE=1" "RM_NO_ONE_LAUNCH=1" "RM_RESORT_AFTER=0" "RM_NO_REC32=1" "RM_EXACT_GRID=1" "RM_EXACT_GRID=7" "RM_EXACT_GRID=256"
-   "RM_FRAME_TICK=0" "RM_AIR_LISTS=0" "RM_FILTER=wg RM_FRAMES_CAND=0" "RM_FR_FLAT_MAX=0" "RM_FR_NO_SHADOW=1")
+   "RM_FRAME_TICK=0" "RM_AIR_LISTS=0" "RM_FILTER=wg RM_FRAMES_CAND=0" "RM_FR_FLAT_MAX=0" "RM_FR_NO_SHADOW=1" "RM_SINR_FRAMES=0" "RM_SINR_FRAMES=0 RM_FILTER=wg")
 for i in "${!K[@]}"; do
     if [ $i -lt $FIRST ] || [ $i -gt $LAST ]; then continue; fi
     knobs="${K[$i]}"
