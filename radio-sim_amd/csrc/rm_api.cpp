@@ -240,6 +240,7 @@ struct rm_context : TickSlot {
         uint64_t rebuilds = 0, incremental = 0;
     } air;
     std::vector<uint32_t> onair_tick; // AirLists::tick per frame of `onair`
+    bool dev_records_from_caller = false; // the tick being prepared takes rm_tx_record arrays the caller built in device memory
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
     rm::TransmitResult *h_transmit = nullptr; // host-mapped result block of rm_transmit
@@ -827,6 +828,9 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.src_air_us = src_air_us;
     t.n_active = n_active;
     t.first_new = first_new;
+    // caller records in device memory are not inspected by the host (rm_tick_run_device, rm_batch_run_device): without
+    // the draw kernels a fractional txProbability in one of them cannot be honoured -- the kernels flag it
+    t.check_txprob = (!stochastic && !src_list && c->dev_records_from_caller && c->params.kind != RM_MODEL_NULL && c->params.kind != RM_MODEL_UDGM_CONST) ? 1 : 0;
     t.first_eval = sinr ? 0 : first_new;
     const bool nothing_to_sweep = (n_new <= 0 || rx_count <= 0); // no launch at all: the lists stay as they are
     if (sinr && air_mode == kAirRebuild && nothing_to_sweep) c->air.valid = false; // rebuilt with the next frames
@@ -1314,6 +1318,14 @@ rm_tx_record make_record(const rm_context *c, int32_t src, int64_t start_us, int
     return r;
 }
 
+// what the kernels' flag word (counters[6], HostHeader::span_flag) says about a tick's records
+static const char *record_flag_message(uint32_t flag)
+{
+    return flag == 2u ? "a record given in device memory has a txprob strictly between 0 and 1, but no node probability asks for "
+                        "java.util.Random draws: records in device memory must carry their source node's txprob"
+                      : "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained";
+}
+
 bool still_on_air(const rm_tx_record &r, int64_t t_begin) { return r.start_us + r.air_us > t_begin; }
 
 } // namespace
@@ -1710,7 +1722,7 @@ static int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uin
     uint32_t oc[5] = {0, 0, 0, 0, 0}; // [4]: a SINR tick of a batch held a frame outside its [t_begin, t_end]
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, s));
     RM_HIP(hipStreamSynchronize(s));
-    if (oc[4]) return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
+    if (oc[4]) return fail(RM_ERR_STATE, record_flag_message(oc[4]));
     if (count) *count = oc[2];
     const uint32_t k = std::min(oc[0], cap);
     if (k) {
@@ -1828,8 +1840,7 @@ int rm_tick_run(rm_context *c)
 
 static int stage_status(rm_context *c, const rm::HostView &v)
 {
-    if (v.hdr->span_flag)
-        return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
+    if (v.hdr->span_flag) return fail(RM_ERR_STATE, record_flag_message(v.hdr->span_flag));
     if (v.hdr->dropped) {
         c->air.valid = false;
         return fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
@@ -2072,7 +2083,10 @@ int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, cons
     RM_HIP(hipSetDevice(c->device));
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
-    return run_tick(c, dev_new, n_new, 0);
+    c->dev_records_from_caller = true;
+    const int rc = run_tick(c, dev_new, n_new, 0);
+    c->dev_records_from_caller = false;
+    return rc;
 }
 
 int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t n,
@@ -2237,7 +2251,7 @@ static int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *
     uint32_t oc[5];
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
-    if (oc[4]) return fail(RM_ERR_STATE, "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
+    if (oc[4]) return fail(RM_ERR_STATE, record_flag_message(oc[4]));
     if (count) *count = oc[2];
     if (dropped) *dropped = oc[1];
     return RM_OK;
@@ -2410,8 +2424,11 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         } else {
             tx = dev_new[b];
         }
-        RM_TRY(prepare_tick(c, ts, plans[b], true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr,
-                            dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0));
+        c->dev_records_from_caller = (dev_src == nullptr);
+        const int rc_prep = prepare_tick(c, ts, plans[b], true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr,
+                                         dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0);
+        c->dev_records_from_caller = false;
+        RM_TRY(rc_prep);
         batched = batched && !plans[b].empty && rm::batch_eligible(plans[b].t, plans[b].cfg, model_dev(c)) &&
                   plans[b].t.rpt == plans[0].t.rpt;
     }
@@ -2534,7 +2551,7 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
         r.sinr = ps.t.out_sinr ? v.sinr + bc.link_base : nullptr;
         int st = RM_OK;
         if (bc.span_flag)
-            st = fail(RM_ERR_STATE, "a frame of a SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained");
+            st = fail(RM_ERR_STATE, record_flag_message(bc.span_flag));
         else if (bc.dropped)
             st = fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
         if (status) status[b] = st;

@@ -183,6 +183,8 @@ struct TickDev {
     int filter_mode;        // kFilterGrid / kFilterWg
     int reset_heads;        // k_tick_prep empties the per-receiver link lists (SINR ticks of a batch)
     int seg_ordered;        // the frames' segments are already in node order (rm_tick.hip): k_reorder only compacts them
+    int check_txprob;       // records given by the caller on the device, tick evaluated without the draw kernels: a record whose
+                            // txprob is strictly between 0 and 1 would need a draw -- flagged (RM_ERR_STATE when the result is read)
     int check_span;         // k_tick_prep verifies that every frame lies inside [span_begin, span_end] (SINR ticks whose
     int64_t span_begin, span_end; // records come from the caller: the batch is only valid if its ticks are self-contained)
     // per (slot, slab) heard counts / offsets (off is relative to the frame's first link), layout [(chunk*n_slabs + slab)*64 + lane]

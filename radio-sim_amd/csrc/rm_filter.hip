@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
                 if (blockIdx.x == 0) t.tx_build[abs_i] = tx;
             } else { // a frame already on the air (or records given by the caller)
                 tx = t.tx[abs_i];
+                if (t.check_txprob && blockIdx.x == 0 && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u;
             }
             tx_prefilter(m, tx, f, thr64);
             ch = tx.channel;
@@ -424,6 +425,7 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     }
     if (t.check_span && tx.src >= 0 && (tx.start_us < t.span_begin || tx.start_us + tx.air_us > t.span_end))
         t.stage_count[6] = 1u; // reported as RM_ERR_STATE when the tick's result is read
+    if (t.check_txprob && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u; // (as well)
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);

@@ -148,6 +148,7 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
         return;
     }
     if (build && tid == 0) t.tx_build[abs_i] = tx;
+    if (!STOCH && t.check_txprob && tid == 0 && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u;
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);
@@ -631,6 +632,7 @@ __global__ void __launch_bounds__(256) k_frames_cand(const NodesDev nd, const Mo
     if (build && tid == 0) t.tx_build[abs_i] = tx;
     if (t.check_span && tid == 0 && tx.src >= 0 && (tx.start_us < t.span_begin || tx.start_us + tx.air_us > t.span_end))
         t.stage_count[6] = 1u;
+    if (t.check_txprob && tid == 0 && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u;
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);

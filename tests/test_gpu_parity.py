@@ -305,3 +305,46 @@ def test_generator_walk_over_thousands_of_packets(engine, rsa, O):
             assert_same(gpu, cpu, "ratio %.2f tick %d" % (ratio, k))
             assert engine.rng_state == state
             assert 0 < int(cpu.pkt_interference.sum()) < t
+
+
+def test_device_records_with_a_fractional_tx_probability_are_refused_without_draws(engine, rsa, O):
+    """Records the caller builds in device memory are not inspected by the host: when no node probability asks for
+    draws, a record whose txprob is strictly between 0 and 1 cannot be honoured (the reference would draw for it,
+    UDGMRadioMedium.java:87-92) -- the kernels flag it and the result reads as RM_ERR_STATE instead of being silently
+    wrong; with a lossy node in the table the draw kernels run and the same records are exact."""
+    from util import DeviceArray
+    n = 3000
+    nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=45)
+    srcs = np.arange(0, n, 60)
+    pk = nd.packets(srcs, 0, 320)
+    pk["txprob"][3] = 0.5
+    recs = to_tx_records(rsa, pk)
+    for kind in ("udgm", "logdist"):
+        configure_engine(engine, nd, kind, {})
+        dev = DeviceArray(recs)
+        engine.tick_run_device(0, 1000, dev.ptr.value, len(recs))
+        with pytest.raises(rsa.RadioMediumError) as e:
+            engine.result_copy(len(recs))
+        assert e.value.code == -5 and "txprob" in str(e.value)
+        # the same tick with its records' probabilities as the table has them: fine
+        pk_ok = nd.packets(srcs, 0, 320)
+        dev2 = DeviceArray(to_tx_records(rsa, pk_ok))
+        engine.tick_run_device(0, 1000, dev2.ptr.value, len(recs))
+        gpu = engine.result_copy(len(recs))
+        cpu = O.tick(oracle_model(O, kind, {}), nd, pk_ok)
+        np.testing.assert_array_equal(gpu.dst, cpu.dst)
+        np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+        dev.free()
+        dev2.free()
+    # a lossy receiver somewhere: the draw kernels run, the record's own probability is honoured
+    nd.rxprob[7] = 0.5
+    configure_engine(engine, nd, "udgm", {})
+    engine.seed(11)
+    dev = DeviceArray(recs)
+    engine.tick_run_device(0, 1000, dev.ptr.value, len(recs))
+    gpu = engine.result_copy(len(recs))
+    cpu = O.tick(oracle_model(O, "udgm", {}), nd, pk, rng_state=O.lib().orc_jrandom_seed(11))
+    np.testing.assert_array_equal(gpu.dst, cpu.dst)
+    np.testing.assert_array_equal(gpu.verdict, cpu.verdict)
+    assert engine.rng_state == cpu.rng_state
+    dev.free()
