@@ -41,7 +41,7 @@ def check_drain(O, eng, sim, t, nodes, what, immediate=(), own=None):
 
 
 def random_session(O, rsa, eng, seed, kind, params, n=1500, ticks=14, per_tick=30, tick_styles=(1000,), aligned=False,
-                   hex_lengths=(0, 2, 20, 64, 254), matrix=None):
+                   hex_lengths=(0, 2, 20, 64, 254), matrix=None, on_air=False):
     rng = np.random.default_rng(seed)
     side = 50.0 * np.sqrt(np.pi * n / 20.0)
     nodes = random_nodes(O, n, side, seed)
@@ -56,6 +56,7 @@ def random_session(O, rsa, eng, seed, kind, params, n=1500, ticks=14, per_tick=3
     state = O.lib().orc_jrandom_seed(seed)
     sim = O.Sim(n)
     now, base, delivered = 0, 0, 0
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)      # (on_air: the SINR extension's frames of earlier ticks, rm_tick_begin's rule)
     for k in range(ticks):
         t_end = now + int(rng.choice(tick_styles))
         t = int(rng.integers(0, per_tick + 1))
@@ -65,7 +66,12 @@ def random_session(O, rsa, eng, seed, kind, params, n=1500, ticks=14, per_tick=3
         pk["air_us"] = 32 * rng.choice(hex_lengths, t)
         assert eng.events_next_packet() == base
         got = eng.tick(to_tx_records(rsa, pk), now, t_end)
-        want = O.tick(mdl, nodes, pk, rng_state=state)
+        if on_air:
+            onair = onair[onair["start_us"] + onair["air_us"] > now]
+            want = O.tick(mdl, nodes, np.concatenate([onair, pk]), first_new=len(onair), rng_state=state)
+            onair = np.concatenate([onair, pk])
+        else:
+            want = O.tick(mdl, nodes, pk, rng_state=state)
         state = want.rng_state
         assert got.count == want.count
         imm = sim.medium_calls(want, pk, pkt_base=base, const_loss=(kind == "udgm_const"))
@@ -92,6 +98,15 @@ def test_aligned_frames_tie_everywhere(O, rsa, engine, seed):
     n = random_session(O, rsa, engine, 200 + seed, "udgm", {}, aligned=True, hex_lengths=(254,), per_tick=60, ticks=20)
     assert n > 0
     n = random_session(O, rsa, engine, 300 + seed, "udgm", {}, aligned=True, hex_lengths=(0, 0, 62), per_tick=60)
+    assert n > 0
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_sinr_sessions_with_frames_on_the_air(O, rsa, engine, seed):
+    """the SINR extension in the closed loop: the tick's one-launch form leaves the on-air entries, the second launch decides
+    capture and half duplex, and the reception stage takes the verdicts from the frames' segments"""
+    n = random_session(O, rsa, engine, 700 + seed, "logdist", dict(ld_flags=1, ld_sigma_db=4.0, ld_seed=5 + seed), n=2500, per_tick=40,
+                       ticks=16, hex_lengths=(10, 64, 254, 254), on_air=True)
     assert n > 0
 
 
