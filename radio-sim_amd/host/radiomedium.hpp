@@ -252,10 +252,14 @@ public:
     }
     void deliverRadioPacket(RadioPacket &p, Node *dst, double rssi) { record(MediumCall::DELIVER, p, dst, rssi, true); }
     std::vector<MediumCall> calls;
+    bool recording = true;   // false: the calls are only counted (timing runs: the list is this stub's, not the engine's, work)
+    uint64_t callCount = 0;
 
 private:
     void record(MediumCall::Kind k, RadioPacket &p, Node *dst, double rssi, bool deliver)
     {
+        ++callCount;
+        if (!recording) return;
         int64_t t0 = p.getStartTime();
         if (t0 < currentTime_) t0 = currentTime_;
         calls.push_back({k, &p, dst, rssi, deliver, t0, t0 + p.getPacketAirTime()});
