@@ -374,12 +374,13 @@ public:
         if ((on ? rm_events_enable(ctx_, 0, 0) : rm_events_disable(ctx_)) != RM_OK) throw std::runtime_error(rm_last_error());
         deviceEvents_ = on;
         inFlight_.clear();
+        inFlightHead_ = 0;
         firstInFlight_ = on ? rm_events_next_packet(ctx_) : 0;
     }
     bool getDeviceEvents() const { return deviceEvents_; }
     // packets the medium still refers to (queued, or with events pending on the device), oldest first: a host that
     // owns the RadioPacket objects may drop all but the last inFlightCount() it handed to transmit()
-    size_t inFlightCount() const { return queue_.size() + inFlight_.size(); }
+    size_t inFlightCount() const { return queue_.size() + inFlight_.size() - inFlightHead_; }
 
     // the transmit() calls queued in tick mode, in ONE evaluation; then the calls the per-packet mode makes
     void flush() override
@@ -427,15 +428,18 @@ public:
         rm_delivery_view v{};
         if (rm_events_process(ctx_, time, &v) != RM_OK) { lastError = rm_last_error(); return; }
         const std::vector<Node *> &nodes = sim->getNodes();
-        for (uint32_t i = 0; i < v.count; ++i) {
-            RadioPacket *p = inFlight_[size_t(v.packet[i] - firstInFlight_)];
-            sim->deliverRadioPacket(*p, nodes[size_t(v.dst[i])], v.rssi[i]);
-        }
+        RadioPacket *const *const flying = inFlight_.data() + inFlightHead_;
+        for (uint32_t i = 0; i < v.count; ++i)
+            sim->deliverRadioPacket(*flying[size_t(v.packet[i] - firstInFlight_)], nodes[size_t(v.dst[i])], v.rssi[i]);
         // packets whose last event has fired are forgotten
         const int64_t oldest = rm_events_next_packet(ctx_) - int64_t(v.pending_packets);
-        while (firstInFlight_ < oldest && !inFlight_.empty()) {
-            inFlight_.pop_front();
+        while (firstInFlight_ < oldest && inFlightHead_ < inFlight_.size()) {
+            ++inFlightHead_;
             ++firstInFlight_;
+        }
+        if (inFlightHead_ > 4096 && inFlightHead_ * 2 > inFlight_.size()) { // the consumed front half goes away
+            inFlight_.erase(inFlight_.begin(), inFlight_.begin() + long(inFlightHead_));
+            inFlightHead_ = 0;
         }
     }
 
@@ -536,7 +540,8 @@ private:
     int kind_;
     bool tickMode_ = false, deviceEvents_ = false;
     std::vector<RadioPacket *> queue_;   // tick mode: transmit() calls since the last flush
-    std::deque<RadioPacket *> inFlight_; // device events: packets with events still queued, by packet number
+    std::vector<RadioPacket *> inFlight_; // device events: packets with events still queued, by packet number (from inFlightHead_)
+    size_t inFlightHead_ = 0;
     int64_t firstInFlight_ = 0;
     uint64_t uploaded_ = ~0ull;
     std::vector<int32_t> dst_;
