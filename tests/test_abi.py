@@ -3,6 +3,7 @@ No compute calls here (no GPU in the CPU test tier)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -92,3 +93,31 @@ def test_header_is_plain_c():
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), c_file, "-L" + lib,
                                "-lradiomedium_hip", "-Wl,-rpath," + lib, "-o", exe])
         assert subprocess.run([exe], timeout=60).returncode == 0   # host-only entry points: no GPU needed
+
+
+def test_jni_glue_type_checks_and_matches_the_java_declarations(tmp_path):
+    """integration/jni/rm_jni.c and the `native` methods of the Java shim cannot be built here (no JDK).  The glue still
+    goes through a C compiler's type checker -- against tests/cpp/jni_check/jni.h, the few JNI declarations it uses with
+    the signatures of the JNI specification -- and every `private static native` method of GpuRadioMedium.java must have a
+    C function of the mangled name with the same parameter list (jint / jlong / jdouble / arrays / ByteBuffer[])."""
+    import re
+    glue = os.path.join(ROOT, "integration", "jni", "rm_jni.c")
+    obj = os.path.join(str(tmp_path), "rm_jni.o")
+    subprocess.check_call(["gcc", "-std=c11", "-c", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "cpp", "jni_check"),
+                           "-I" + os.path.join(ROOT, "include"), glue, "-o", obj])
+    java = open(os.path.join(ROOT, "integration", "java", "se", "sics", "emul8", "radiomedium", "GpuRadioMedium.java")).read()
+    csrc = re.sub(r"/\*.*?\*/", " ", open(glue).read(), flags=re.S)
+    csrc = re.sub(r"//[^\n]*", " ", csrc)
+    jtype = {"int": "jint", "long": "jlong", "double": "jdouble", "boolean": "jboolean", "String": "jstring", "int[]": "jintArray",
+             "double[]": "jdoubleArray", "byte[]": "jbyteArray", "java.nio.ByteBuffer[]": "jobjectArray", "void": "void"}
+    natives = re.findall(r"private static native\s+([\w.\[\]]+)\s+(\w+)\s*\(([^)]*)\)\s*;", re.sub(r"/\*.*?\*/", " ", java, flags=re.S))
+    assert len(natives) >= 19
+    cfuncs = {m.group(2): (m.group(1), m.group(3)) for m in re.finditer(r"JNIEXPORT\s+(\w+)\s+JFN\((\w+)\)\s*\(([^)]*)\)", csrc)}
+    for ret, name, params in natives:
+        assert name in cfuncs, "no C function for native method " + name
+        cret, cparams = cfuncs[name]
+        assert cret == jtype[ret], (name, ret, cret)
+        want = [jtype[" ".join(p.split()[:-1])] for p in params.split(",") if p.strip()]
+        got = [p.split()[0] for p in cparams.split(",")][2:]          # after JNIEnv *env, jclass cls
+        assert got == want, (name, got, want)
+    assert set(cfuncs) == {n for _, n, _ in natives}
