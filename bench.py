@@ -27,7 +27,7 @@ under it) and every rank sweeps the gathered frames against its receivers.  Defa
 STRONG: the BASELINE config itself (100k nodes for configs[2]; `--workload c4` for the 8-GPU config),
 its receivers split over the ranks.  `--scaling weak` grows the node count as 100k x sqrt(N) at constant
 density and Tx fraction instead, so that the link evaluations per GPU and tick stay those of the 1-GPU
-config; `--as-rank R:W` runs one rank's share of a W-GPU weak-scaling run on one GPU, without the
+config; `--as-rank R:W` runs one rank's share of a W-GPU run (strong scaling, or weak with --scaling weak) on one GPU, without the
 collective.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -378,9 +378,11 @@ def main():
         if model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > extra0.get("tick_us", W.TICK_US) and world > 1:
             raise SystemExit("frames that outlive their tick (SINR on-air list) are sharded through the host-record path only")
         as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
-        if as_rank:
+        if as_rank and args.scaling == "weak":
             n = int(round(n * as_rank[1] ** 0.5))
             desc += " -- compute of rank %d of %d (weak scaling: %d nodes), no collective" % (as_rank[0], as_rank[1], n)
+        elif as_rank:
+            desc += " -- compute of rank %d of %d (strong scaling: its share of the %d receivers), no collective" % (as_rank[0], as_rank[1], n)
         elif args.nodes > 0:
             n = args.nodes
             desc += " -- node count overridden: %d" % n

@@ -241,6 +241,9 @@ struct rm_context : TickSlot {
     } air;
     std::vector<uint32_t> onair_tick; // AirLists::tick per frame of `onair`
     bool dev_records_from_caller = false; // the tick being prepared takes rm_tx_record arrays the caller built in device memory
+    mutable rm::ModelDev mdev{};            // model_dev()'s last answer and what it was derived from
+    mutable unsigned char mdev_key[320] = {};
+    mutable bool mdev_valid = false;
 
     DevBuf<uint64_t> d_rng;  // [1] java.util.Random state, shared by all slots
     rm::TransmitResult *h_transmit = nullptr; // host-mapped result block of rm_transmit
@@ -369,6 +372,25 @@ void recompute_frame(rm_context *c)
 
 rm::ModelDev model_dev(const rm_context *c)
 {
+    // planned once per tick of a batch (and more than once): the derived values (a software pow10, the mixed seed) are
+    // kept as long as everything they come from is unchanged
+    struct Key {
+        rm_model_params p;
+        double org[3], coord_bound, f32_slack;
+        const void *n2n, *shadow;
+        int n2n_m;
+    };
+    Key key;
+    std::memset(&key, 0, sizeof(key)); // (padding bytes take part in the comparison)
+    key.p = c->params;
+    key.org[0] = c->org[0]; key.org[1] = c->org[1]; key.org[2] = c->org[2];
+    key.coord_bound = c->coord_bound;
+    key.f32_slack = c->f32_slack;
+    key.n2n = c->d_n2n.p;
+    key.shadow = c->shadow_tbl_valid ? c->d_shadow_tbl.p : nullptr;
+    key.n2n_m = c->n2n_m;
+    static_assert(sizeof(Key) <= sizeof(c->mdev_key), "model key buffer");
+    if (c->mdev_valid && std::memcmp(&key, c->mdev_key, sizeof(key)) == 0) return c->mdev;
     rm::ModelDev m{};
     const rm_model_params &p = c->params;
     m.kind = p.kind;
@@ -405,6 +427,9 @@ rm::ModelDev model_dev(const rm_context *c)
     } else if (p.kind == RM_MODEL_UDGM_CONST) {
         m.geo_cut = (p.const_range > 0.0) ? p.const_range * (1.0 + 1e-9) : -1.0; // strict distance < range
     }
+    std::memcpy(c->mdev_key, &key, sizeof(key));
+    c->mdev = m;
+    c->mdev_valid = true;
     return m;
 }
 
@@ -803,8 +828,9 @@ bool air_lists_current(const rm_context *c, int64_t t_begin, uint32_t oldest)
 
 int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, const rm_tx_record *tx, int n_active,
                  int first_new, const int32_t *src_list = nullptr, int64_t src_start_us = 0, int64_t src_air_us = 0,
-                 int air_mode = kAirNone, uint32_t air_oldest = 0)
+                 int air_mode = kAirNone, uint32_t air_oldest = 0, const rm::PlanKnobs *knobs_in = nullptr)
 {
+    const rm::PlanKnobs knobs = knobs_in ? *knobs_in : rm::read_plan_knobs();
     const int n_new = n_active - first_new;
     ts.have_result = false;
     ts.compact_pending = false;
@@ -886,8 +912,8 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     cfg.f64_filter = c->f32_slack > 0.05 || (m.geo_cut > 0 && c->f32_slack > 0.05 * m.geo_cut);
     cfg.sorted = c->rx_sorted;
     cfg.bbox = c->rx_sorted && !cfg.f64_filter;
-    cfg.shadow = c->shadow_tbl_valid && !cfg.f64_filter && std::getenv("RM_NO_SHADOW_TABLE") == nullptr;
-    const int filter_mode = rm::plan_filter(t, cfg, want_wg); // fixes t.rpt / t.n_slabs
+    cfg.shadow = c->shadow_tbl_valid && !cfg.f64_filter && !knobs.no_shadow_table;
+    const int filter_mode = rm::plan_filter(t, cfg, want_wg, knobs); // fixes t.rpt / t.n_slabs
 
     const size_t cells = size_t(std::max(t.n_cnt, 0) / rm::kTxChunk) * std::max(t.n_slabs, 1) * 64;
     if (!c->rx_sorted) {
@@ -931,6 +957,18 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.next_shard_count = ts.d_shards.p + size_t(ts.parity ^ 1) * rm::kShards * rm::kShardStride;
     t.cap = c->cap;
     t.shard_mask = (want_wg && filter_mode == rm::kFilterWg && t.rpt == 4) ? 63u : uint32_t(rm::kShards - 1);
+    if (want_wg && filter_mode == rm::kFilterWg && partitioned) {
+        // a receiver partition hands the exact stage proportionally fewer candidates per tick: fewer, fuller shards keep
+        // its 256-entry chunks full (64 shards are tuned for ~50 k candidates of 100 k receivers: ~700 per shard)
+        static const int fixed = [] {
+            const char *e = std::getenv("RM_BATCH_SHARDS"); // developer knob: 8 / 16 / 32 / 64
+            return e ? std::atoi(e) : 0;
+        }();
+        uint32_t shards = 64;
+        while (shards > 8 && uint64_t(rx_count) * 64u < uint64_t(100000) * shards) shards >>= 1;
+        if (fixed == 8 || fixed == 16 || fixed == 32 || fixed == 64) shards = uint32_t(fixed);
+        t.shard_mask = shards - 1u;
+    }
     t.seg_cap = uint32_t((size_t((c->cap + rm::kShards - 1) / rm::kShards) * rm::kShards) / (t.shard_mask + 1));
     t.use_matrix = cfg.sorted ? 0 : 1;
     t.cursor = ts.d_cursor.p;
@@ -2406,6 +2444,7 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         return fail(RM_ERR_STATE, "a receiver partition whose links draw needs rm_tick_finish_draws per tick: run it one "
                                   "tick at a time");
     while (c->extra_slots.size() + 1 < size_t(n_ticks)) c->extra_slots.emplace_back(new TickSlot());
+    const rm::PlanKnobs knobs = rm::read_plan_knobs(); // once for the whole batch
     TickSlot *slots[RM_MAX_BATCH];
     TickPlan plans[RM_MAX_BATCH];
     bool batched = true;
@@ -2426,7 +2465,7 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         }
         c->dev_records_from_caller = (dev_src == nullptr);
         const int rc_prep = prepare_tick(c, ts, plans[b], true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr,
-                                         dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0);
+                                         dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0, kAirNone, 0, &knobs);
         c->dev_records_from_caller = false;
         RM_TRY(rc_prep);
         batched = batched && !plans[b].empty && rm::batch_eligible(plans[b].t, plans[b].cfg, model_dev(c)) &&

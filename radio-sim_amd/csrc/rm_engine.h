@@ -408,7 +408,15 @@ hipError_t launch_transmit_one(hipStream_t s, const NodesDev &nd, const ModelDev
 constexpr uint32_t kTransmitFallback = 0xFFFFFFFFu; // TransmitResult::total when k_transmit_one declined
 hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t,
                          const LaunchCfg &cfg);
-int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg);
+// developer knobs read from the environment, once per API call that plans ticks (a batch plans up to 128 of them:
+// three getenv per tick were most of its host time): RM_FILTER=grid|wg, RM_WG_RPT=1|2|4, RM_NO_SHADOW_TABLE
+struct PlanKnobs {
+    int filter;          // 0 = automatic, kFilterGrid + 1 / kFilterWg + 1 = forced
+    int wg_rpt;          // 0 = automatic
+    bool no_shadow_table;
+};
+PlanKnobs read_plan_knobs();
+int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg, const PlanKnobs &knobs);
 bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
 hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDev *dev_ticks);
 hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,

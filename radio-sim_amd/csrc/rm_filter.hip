@@ -759,7 +759,19 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
 // Chooses the filter variant for this tick and fixes the receiver tiling (t.rpt, t.n_slabs):
 //  kFilterGrid: k_filter on a (slab, tile) grid -- the general variant (fp64 frame, unsorted tables);
 //  kFilterWg:   k_tick_prep + k_filter_wg, two-level cull inside one workgroup per 4*rpt groups.
-int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
+PlanKnobs read_plan_knobs()
+{
+    PlanKnobs k{0, 0, false};
+    if (const char *e = getenv("RM_FILTER")) {
+        if (!strcmp(e, "grid")) k.filter = kFilterGrid + 1;
+        else if (!strcmp(e, "wg")) k.filter = kFilterWg + 1;
+    }
+    if (const char *e = getenv("RM_WG_RPT")) k.wg_rpt = (atoi(e) == 4) ? 4 : (atoi(e) == 2 ? 2 : 1);
+    k.no_shadow_table = getenv("RM_NO_SHADOW_TABLE") != nullptr;
+    return k;
+}
+
+int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg, const PlanKnobs &knobs)
 {
     const int n_eval = t.n_active - t.first_eval;
     const int n_chunks = cdiv(max(n_eval, 1), kTxChunk);
@@ -773,16 +785,13 @@ int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg)
         // beyond a few thousand (workgroup, tile) pairs the 2-D grid of k_filter is mostly short-lived
         // workgroups that find nothing (1 M nodes, or thousands of frames on the air)
         if (t.rpt == 4 && pairs > 8192 && t.n_slabs >= 4 * 256) mode = kFilterWg;
-        if (const char *e = getenv("RM_FILTER")) {
-            if (!strcmp(e, "grid")) mode = kFilterGrid;
-            else if (!strcmp(e, "wg")) mode = kFilterWg;
-        }
+        if (knobs.filter) mode = knobs.filter - 1;
         if (want_wg) mode = kFilterWg;
         if (mode == kFilterWg) {
             // batches bring their own parallelism (workgroups x ticks): the coarse tiling halves the frame x
             // workgroup-box tests of phase A twice over; a lone tick needs the workgroups
             int rpt = (t.n_rx > 400000 || (want_wg && t.n_rx >= 16384)) ? 4 : 1;
-            if (const char *e = getenv("RM_WG_RPT")) rpt = (atoi(e) == 4) ? 4 : (atoi(e) == 2 ? 2 : 1);
+            if (knobs.wg_rpt) rpt = knobs.wg_rpt;
             t.rpt = rpt;
             t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
         }
