@@ -592,6 +592,22 @@ public:
     }
 };
 
+// The build's extension medium behind the same contract (NOT a reference class): log-distance path
+// loss, per-link log-normal shadowing, and with setSinr(true) co-channel SINR capture + half duplex over the frames on
+// the air.  With SINR the verdicts of a tick's frames depend on each other: tick mode decides them against everything
+// sent in the tick, the per-packet mode against what was sent before -- the reference media do not have this coupling.
+class LogDistanceRadioMedium : public GpuRadioMedium {
+public:
+    explicit LogDistanceRadioMedium(int device = 0) : GpuRadioMedium(RM_MODEL_LOGDIST, device) {}
+    rm_model_params &params() { return params_; } // change, then apply()
+    using GpuRadioMedium::apply;
+    void setSinr(bool on)
+    {
+        params_.flags = on ? (params_.flags | RM_LD_SINR) : (params_.flags & ~RM_LD_SINR);
+        apply();
+    }
+};
+
 // The same contract over SEVERAL devices (or several partitions of one device): one rm_group behind one medium
 // object, because the reference host is one process (Main.java:65-73).  The receivers are range-partitioned over the
 // members; a packet is handed to every member, the members' heard links come back merged in node order, and the

@@ -699,6 +699,39 @@ private:
                         }
                     } else if (option == "udgm") {
                         if (!opt_.noMedium) setMedium(new emul8::UDGMRadioMedium(opt_.device));
+                    } else if (option == "udgm-constant-loss") { // (not wired to the protocol in the reference: its class exists)
+                        if (!opt_.noMedium) setMedium(new emul8::UDGMConstantLossRadioMedium(opt_.device));
+                    } else if (option == "log-distance") {
+                        // the engine's extension medium: the only additions to the wire are this
+                        // option string and its optional numeric parameters
+                        rm_model_params p;
+                        rm_model_defaults(&p, RM_MODEL_LOGDIST);
+                        auto num = [&](const char *name, double &field) {
+                            const Json *v = params.get(name);
+                            if (isNumber(v)) field = v->asDouble();
+                        };
+                        num("reference-loss-db", p.ld_pl0_db);
+                        num("path-loss-exponent", p.ld_exponent);
+                        num("reference-distance", p.ld_d0);
+                        num("shadowing-sigma-db", p.ld_sigma_db);
+                        num("shadowing-clip", p.ld_clip);
+                        num("sensitivity-dbm", p.ld_sensitivity_dbm);
+                        num("noise-dbm", p.ld_noise_dbm);
+                        num("capture-db", p.ld_capture_db);
+                        num("interference-floor-dbm", p.ld_ifloor_dbm);
+                        if (const Json *v = params.get("shadowing-seed"); isNumber(v)) p.ld_seed = uint64_t(v->asLong());
+                        if (const Json *v = params.get("sinr"); v && v->type() == Json::BOOL && v->toString() == "true") p.flags |= RM_LD_SINR;
+                        if (!opt_.noMedium) {
+                            std::unique_ptr<emul8::LogDistanceRadioMedium> m(new emul8::LogDistanceRadioMedium(opt_.device));
+                            m->params() = p;
+                            try {
+                                m->apply();
+                                setMedium(m.release());
+                            } catch (const std::exception &e) {
+                                reply = replyError(id, "command-error", std::string("log-distance: ") + e.what());
+                                haveReply = true;
+                            }
+                        }
                     } else if (option == "nullrm") {
                         // the null radio medium is the default
                     } else {

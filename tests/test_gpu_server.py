@@ -38,8 +38,14 @@ def info_json(ident, rssi, state, channel):
     return '{"node-id":%s,"rssi":%s,"receiving":%d,"wireless-channel":%d}' % (json.dumps(ident), num(rssi), state, channel)
 
 
-@pytest.mark.parametrize("model,mode", [("udgm", "tick"), ("udgm", "packet"), ("nullrm", "tick"), ("n2n-link", "tick")])
+@pytest.mark.parametrize("model,mode", [("udgm", "tick"), ("udgm", "packet"), ("nullrm", "tick"), ("n2n-link", "tick"),
+                                        ("log-distance", "tick"), ("log-distance", "packet"), ("log-distance-sinr", "tick")])
 def test_server_end_to_end(O, model, mode):
+    """`log-distance`: the engine's extension medium selected over the wire (the option string and its optional numeric
+    parameters are the only additions to the protocol).  With "sinr": true the verdicts of the frames of one evaluation
+    depend on each other, so the oracle evaluates what the server evaluates together: everything sent between two points
+    where the server has to settle (a node-config-set, the end of the step), against the frames still on the air."""
+    sinr = model == "log-distance-sinr"
     n_reg = 90 if model != "n2n-link" else 24      # nodes registered before the first step
     late = model == "udgm"                         # one more node joins in mid-run (the node table grows under the medium)
     n = n_reg + (1 if late else 0)
@@ -63,6 +69,8 @@ def test_server_end_to_end(O, model, mode):
         matrix = np.round(rng.uniform(0, 1, (n, n)), 3)
         matrix[rng.random((n, n)) < 0.4] = 0.0
         mdl = O.model(KINDS["n2n"], n2n_matrix=matrix)
+    elif model.startswith("log-distance"):
+        mdl = O.model(KINDS["logdist"], ld_sigma_db=4.0, ld_seed=77, ld_exponent=3.2, ld_flags=1 if sinr else 0)
     else:
         mdl = O.model(KINDS["udgm" if model == "udgm" else "null"])
 
@@ -77,6 +85,9 @@ def test_server_end_to_end(O, model, mode):
         for p in [ctl] + emus:
             assert p.line() + b"\r\n" == GREETING
         params = {"wireless-standard": "802.15.4", "propagation-option": model}
+        if model.startswith("log-distance"):
+            params = {"propagation-option": "log-distance", "shadowing-sigma-db": 4.0, "shadowing-seed": 77, "path-loss-exponent": 3.2,
+                      "sinr": sinr}
         if model == "n2n-link":
             params.update({"number-of-nodes": n, "matrix-data": [float(v) for v in matrix.reshape(-1)]})
         ctl.send({"command": "configuration-set", "id": 1, "parameters": params})
@@ -102,6 +113,22 @@ def test_server_end_to_end(O, model, mode):
         sim = O.Sim(n)
         pid, now = 0, 0
         n_rx = 0
+        onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+        group = []          # (SINR) the packets of the evaluation the server has not made yet
+
+        def close_group():
+            """what the server evaluates in one go, against the frames on the air (rm_tick_begin's rule at the old time)"""
+            nonlocal state, pid, onair
+            if not group:
+                return
+            new = np.array(group, dtype=O.PACKET_DTYPE)
+            onair = onair[onair["start_us"] + onair["air_us"] > now]
+            r = O.tick(mdl, nd, np.concatenate([onair, new]), first_new=len(onair), rng_state=state)
+            state = r.rng_state
+            sim.medium_calls(r, new, pkt_base=pid)
+            onair = np.concatenate([onair, new])
+            pid += len(group)
+            group.clear()
         hexes = ["", "0102030405", "0102030405" * 2, "0102030405" * 12, "ab" * 125]
         for t in range(16):
             step = now + int(rng.choice([1000, 1000, 1000, 10, 4000]))
@@ -116,6 +143,7 @@ def test_server_end_to_end(O, model, mode):
             imm = []
             for e in rng.permutation(n_emu):
                 if late and t == 7 and e == owner[n - 1] and n_reg < n:      # a new node: the whole table is uploaded again
+                    close_group()
                     i = n - 1
                     nd.enabled[i] = 1
                     emus[e].send({"command": "node-config-set", "id": 7000, "parameters": {
@@ -125,6 +153,7 @@ def test_server_end_to_end(O, model, mode):
                     n_reg = n
                 mine = [i for i in range(n_reg) if owner[i] == e]
                 if t in (5, 9) and mine:     # a node moves / changes channel / loses its receiver in mid-run
+                    close_group()                # (the server settles its queue before a node changes)
                     i = mine[int(rng.integers(len(mine)))]
                     nd.x[i], nd.y[i] = float(np.round(rng.uniform(0, side), 3)), float(np.round(rng.uniform(0, side), 3))
                     nd.channel[i] = 26
@@ -144,12 +173,17 @@ def test_server_end_to_end(O, model, mode):
                         msg["rf-power"], msg["wireless-channel"] = txp, ch
                     emus[e].send(msg)
                     rec = nd.packet(int(s), start, 32 * len(hx), txpower=txp, channel=ch)
+                    if sinr:
+                        packets_hex[pid + len(group)] = (hx, start, ch if ch is not None else int(nd.channel[s]))
+                        group.append(rec)
+                        continue
                     r = O.tick(mdl, nd, rec, rng_state=state)
                     state = r.rng_state
                     sim.medium_calls(r, np.atleast_1d(rec), pkt_base=pid)
                     packets_hex[pid] = (hx, start, ch if ch is not None else int(nd.channel[s]))
                     pid += 1
                 sync(emus[e])
+            close_group()
             for e in range(n_emu):
                 emus[e].send({"reply": "OK", "id": 1001 + t})
             # the drain: receive messages per destination's connection, in pop order, then the controller's reply

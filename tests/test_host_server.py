@@ -145,6 +145,13 @@ def test_configuration_set_n2n_checks(server):
     assert c.line() == b'{"id":2,"reply":"error","reply-object":{"class":"command-error","description":"inconsistent data matrix or nodes"}}'
     c.send({"command": "configuration-set", "id": 3, "parameters": {"propagation-option": "quantum"}})
     assert c.line() == b'{"id":3,"reply":"OK"}'         # unsupported option: logged, the null medium stays
+    # the two option strings this server adds (the engine's extension medium with its optional parameters; the constant-
+    # loss medium, which the reference has as a class but never wired to the protocol)
+    c.send({"command": "configuration-set", "id": 4, "parameters": {"propagation-option": "log-distance", "path-loss-exponent": 3.0,
+                                                                    "shadowing-sigma-db": 4.0, "shadowing-seed": 7, "sinr": True}})
+    assert c.line() == b'{"id":4,"reply":"OK"}'
+    c.send({"command": "configuration-set", "id": 5, "parameters": {"propagation-option": "udgm-constant-loss"}})
+    assert c.line() == b'{"id":5,"reply":"OK"}'
     c.close()
 
 
