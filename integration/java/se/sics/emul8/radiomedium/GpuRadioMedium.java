@@ -90,6 +90,7 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private final java.util.ArrayDeque<RadioPacket> inFlight = new java.util.ArrayDeque<RadioPacket>();
     private long firstInFlight;
     private double[] params; // the double fields of rm_model_params, udgm_success_ratio_tx first (nSetModel)
+    private int flags;       // RM_LD_* (nSetModel)
     private long ctx;
     private Node[] uploaded;          // the Simulator.getNodes() snapshot the device currently mirrors
     private java.util.IdentityHashMap<Node, Integer> index = new java.util.IdentityHashMap<Node, Integer>();
@@ -118,7 +119,21 @@ public class GpuRadioMedium extends AbstractRadioMedium {
                 params = new double[] {1.0, 1.0, 50.0, 100.0, 100.0}; // UDGMRadioMedium.java:18-24, UDGMConstantLossRadioMedium.java:8
             }
             params[index] = v;
-            if (nSetModel(ctx, kind, 0, params) != 0) {
+            if (nSetModel(ctx, kind, flags, params) != 0) {
+                log.error("radio medium: {}", nLastError());
+            }
+        }
+    }
+    /* the extension medium (MODEL_LOGDIST; DESIGN.md section 6): every parameter at once, in the order of
+     * rm_model_params' double fields after the five of the reference media -- pl0, exponent, d0, sigma, clip,
+     * sensitivity, noise, capture, interference floor -- plus the shadowing seed's place in the flags call */
+    public void setLogDistance(double pl0Db, double exponent, double d0, double sigmaDb, double clip, double sensitivityDbm,
+                               double noiseDbm, double captureDb, double interferenceFloorDbm, boolean sinr) {
+        synchronized (lock) {
+            params = new double[] {1.0, 1.0, 50.0, 100.0, 100.0, pl0Db, exponent, d0, sigmaDb, clip, sensitivityDbm, noiseDbm,
+                                   captureDb, interferenceFloorDbm};
+            flags = sinr ? 1 : 0; // RM_LD_SINR
+            if (nSetModel(ctx, kind, flags, params) != 0) {
                 log.error("radio medium: {}", nLastError());
             }
         }
