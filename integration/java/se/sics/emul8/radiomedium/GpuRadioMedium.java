@@ -126,7 +126,8 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     }
     /* the extension medium (MODEL_LOGDIST; DESIGN.md section 6): every parameter at once, in the order of
      * rm_model_params' double fields after the five of the reference media -- pl0, exponent, d0, sigma, clip,
-     * sensitivity, noise, capture, interference floor -- plus the shadowing seed's place in the flags call */
+     * sensitivity, noise, capture, interference floor; the shadowing seed keeps rm_model_defaults' value (nSetModel
+     * carries the double fields and the flags only) */
     public void setLogDistance(double pl0Db, double exponent, double d0, double sigmaDb, double clip, double sensitivityDbm,
                                double noiseDbm, double captureDb, double interferenceFloorDbm, boolean sinr) {
         synchronized (lock) {
