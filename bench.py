@@ -375,8 +375,6 @@ def main():
         result = None
         idx, n, frac, model, desc = WORKLOADS[args.workload]
         extra0 = EXTRA.get(args.workload, {})
-        if model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > extra0.get("tick_us", W.TICK_US) and world > 1:
-            raise SystemExit("frames that outlive their tick (SINR on-air list) are sharded through the host-record path only")
         as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
         if as_rank and args.scaling == "weak":
             n = int(round(n * as_rank[1] ** 0.5))
@@ -443,7 +441,7 @@ def main():
                 slots = D.slots_needed(n, world, sources)
                 pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
                 src_dev = torch.from_numpy(pad).to(dev)
-                sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch)
+                sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch, on_air=stateful)
         stream.synchronize()
 
         links_done = [0]
@@ -488,13 +486,14 @@ def main():
                         if stateful:
                             links_done[0] += engines[0].last_link_evaluations()
                 else:
+                    base = clock[0] - k0      # simulated time never runs backwards (frames on the air)
                     if k1 > k0:
-                        sharded.stage(src_dev[k0 % pool].data_ptr(), k0 * W.TICK_US, W.AIR_US)
+                        sharded.stage(src_dev[k0 % pool].data_ptr(), (base + k0) * tick_us, W.AIR_US)
                     for k in range(k0, k1):
                         cur = sharded.staged
                         if k + 1 < k1:
-                            sharded.stage(src_dev[(k + 1) % pool].data_ptr(), (k + 1) * W.TICK_US, W.AIR_US)
-                        sharded.sweep(cur, k * W.TICK_US + W.TICK_US)
+                            sharded.stage(src_dev[(k + 1) % pool].data_ptr(), (base + k + 1) * tick_us, W.AIR_US)
+                        sharded.sweep(cur, (base + k) * tick_us + tick_us)
             clock[0] += k1 - k0
 
         def fence():
@@ -549,7 +548,7 @@ def main():
         links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * (hi - lo)
         timed_ticks = args.steps * tps
         value = links_per_tick * timed_ticks / elapsed
-        if stateful:
+        if stateful and sharded is None:
             # the links the ticks resolved: the new frames against every receiver; the frames still on the air keep
             # their entries in the per-receiver lists on the device and are not swept again
             value = links_done[0] / elapsed
@@ -558,7 +557,7 @@ def main():
         if stateful:
             inc, reb = engines[0].air_list_stats()
             desc += (" -- %.2e link evaluations per tick (new frames only: the frames still on the air stay in the on-air lists on the "
-                     "device; %d ticks added to the lists, %d rebuilt them)" % (links_done[0] / timed_ticks, inc, reb))
+                     "device; %d ticks added to the lists, %d rebuilt them)" % (value * elapsed / timed_ticks, inc, reb))
         if (inflight > 1 or batch > 1) and sharded is None:
             # the same ticks again, one at a time on one context
             fence()

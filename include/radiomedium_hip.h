@@ -232,6 +232,12 @@ int rm_tick_run_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
  * data) copies txpower / channel from its source, RadioPacket.java:46-52 -- one call per tick */
 int rm_tick_run_sources_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us,
                                const int32_t *dev_src, int32_t n, int64_t start_us, int64_t air_us);
+/* as rm_tick_run_device for the SINR extension, whose frames stay on the air over several ticks (the gathered records
+ * of a receiver-sharded tick): `latest_end_us` is an upper bound of start + air over the records
+ * -- the host never reads them and has to know how long their entries can matter.  The engine keeps a copy of the
+ * records while they are on the air.  Without the SINR extension this is rm_tick_run_device. */
+int rm_tick_run_records_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us, const rm_tx_record *dev_new,
+                               int32_t n_new, int64_t latest_end_us);
 int rm_result_device(rm_context *ctx, rm_device_result *out);
 int rm_result_count(rm_context *ctx, uint32_t *count, uint32_t *dropped); /* synchronises */
 /* copy the last evaluated tick's heard links to host buffers (same layout as rm_tick_flush) */

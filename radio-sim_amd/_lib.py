@@ -135,6 +135,7 @@ SIGNATURES = {
     "rm_pack_tx_batch_device_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                              C.c_void_p]),
     "rm_tick_run_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
+    "rm_tick_run_records_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64]),
     "rm_tick_run_sources_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
                                              C.c_int64]),
     "rm_result_device": (C.c_int, [C.c_void_p, C.POINTER(DeviceResult)]),

@@ -2116,8 +2116,8 @@ int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, cons
 {
     if (!c || n_new < 0 || (n_new > 0 && !dev_new)) return fail(RM_ERR_INVALID, "bad arguments");
     if (is_sinr(c))
-        return fail(RM_ERR_STATE, "device-resident ticks with the SINR on-air list are not available yet; "
-                                  "use rm_tick_begin / rm_enqueue_tx_records / rm_tick_flush");
+        return fail(RM_ERR_STATE, "the SINR medium keeps frames on the air: records in device memory go through "
+                                  "rm_tick_run_records_device, which is told how long they stay (latest_end_us)");
     RM_HIP(hipSetDevice(c->device));
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
@@ -2126,6 +2126,9 @@ int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, cons
     c->dev_records_from_caller = false;
     return rc;
 }
+
+static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n,
+                           int64_t start_us, int64_t air_us, int64_t latest_end_us);
 
 int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t n,
                                int64_t start_us, int64_t air_us)
@@ -2138,7 +2141,16 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
         RM_HIP(c->d_tx.ensure(std::max(n, 1)));
         return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us);
     }
-    // SINR: the frames of earlier calls that are still on the air stay resident on the device.
+    return air_tick_device(c, t_begin_us, dev_src, nullptr, n, start_us, air_us, start_us + air_us);
+}
+
+// The SINR medium's tick with its frames in device memory -- built from source indices (dev_src: all with the same start
+// and air time) or given as records (dev_new; `latest_end_us` bounds their start + air: the host never reads them).
+// The frames of earlier calls that are still on the air stay resident on the device (the window [air_head, air_tail) of
+// d_air): a tick that only adds frames sweeps the new ones, a rebuild of the on-air lists sweeps the whole window.
+static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n,
+                           int64_t start_us, int64_t air_us, int64_t latest_end_us)
+{
     // Expire whole batches (rm_tick_begin's rule: start + air > t_begin stays).
     {
         bool fifo = true; // live batches form a suffix of the window?
@@ -2187,7 +2199,9 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
         c->air_head = 0;
         c->air_tail = live;
     }
-    if (air_us > int64_t(UINT32_MAX)) return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
+    if (dev_src && air_us > int64_t(UINT32_MAX)) return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
+    if (dev_new && n > 0) // the caller's records join the window (they have to be there when the lists are rebuilt)
+        RM_HIP(hipMemcpyAsync(c->d_air.p + c->air_tail, dev_new, size_t(n) * sizeof(rm_tx_record), hipMemcpyDeviceToDevice, c->stream));
     uint32_t oldest = 0;
     bool unknown = false;
     for (const auto &bt : c->air_batches) {
@@ -2206,8 +2220,19 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
     if (air_mode == kAirRebuild)
         for (auto &bt : c->air_batches) bt.tick = c->air.tick;
     c->air_tail += size_t(n);
-    if (n > 0) c->air_batches.push_back({n, start_us + air_us, c->air.tick});
+    if (n > 0) c->air_batches.push_back({n, latest_end_us, c->air.tick});
     return RM_OK;
+}
+
+int rm_tick_run_records_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const rm_tx_record *dev_new, int32_t n_new,
+                               int64_t latest_end_us)
+{
+    if (!c || n_new < 0 || (n_new > 0 && !dev_new)) return fail(RM_ERR_INVALID, "bad arguments");
+    if (!is_sinr(c)) return rm_tick_run_device(c, t_begin_us, t_end_us, dev_new, n_new);
+    RM_HIP(hipSetDevice(c->device));
+    c->t_begin = t_begin_us;
+    c->t_end = t_end_us;
+    return air_tick_device(c, t_begin_us, nullptr, dev_new, n_new, 0, 0, latest_end_us);
 }
 
 static int result_device(rm_context *c, TickSlot &ts, rm_device_result *out)

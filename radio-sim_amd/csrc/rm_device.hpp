@@ -423,6 +423,10 @@ RM_D void air_link(const TickDev &t, int aidx, int pos, int64_t start_us, int64_
     e.start_us = start_us;
     e.lin = lin;
     e.air_us = uint32_t(air_us);
+    if ((unsigned long long)air_us >> 32) { // (records in device memory are not seen by the host: a frame of 2^32 us or more)
+        t.stage_count[1] = 1u;
+        t.air.bad[0] = 1u;
+    }
     e.next = (uint32_t(old >> 32) >= t.air.wtick) ? int(uint32_t(old)) : -1; // an empty head has tick 0
     e.meta = (t.air.tick << 2) | flags;
     e.pad = 0u;

@@ -110,7 +110,7 @@ class ShardedTick:
     carries no state from tick to tick.  Media with draws or an on-air list must use ONE context.
     Works with world == 1 as well (no collective), which is how the choreography is tested on one GPU."""
 
-    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True, batch=1):
+    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True, batch=1, on_air=False):
         import torch
         self.torch = torch
         if not isinstance(engines, (list, tuple)):
@@ -141,6 +141,11 @@ class ShardedTick:
         self.staged = None
         self.cnt_mine = self.cnt_all = None
         self.may_draw = may_draw   # False: the caller knows no java.util.Random draw can happen (saves a call per tick)
+        # the SINR medium with frames that outlive their tick: every rank keeps the on-air lists of ITS receivers on its
+        # device; a tick's gathered records go to rm_tick_run_records_device (ONE context: the ticks are chained)
+        self.on_air = on_air
+        if on_air and len(self.engines) != 1:
+            raise ValueError("frames that stay on the air chain the ticks: one context")
 
     def stage(self, dev_src_ptr, t_begin, air_us):
         """Enqueue packing + all-gather of the next tick on the communication stream."""
@@ -161,16 +166,19 @@ class ShardedTick:
             self.all[b].copy_(self.mine[b], non_blocking=True)
         self.ready[b].record(self.comm)
         prev = self.staged
-        self.staged = (b, t_begin, k)
+        self.staged = (b, t_begin, k, air_us)
         return prev
 
     def sweep(self, staged, t_end):
         """Run the sweep of a staged tick on its context's stream."""
-        b, t_begin, k = staged
+        b, t_begin, k, air_us = staged
         eng = self.engines[k % len(self.engines)]
         stream = self.streams[k % len(self.streams)]
         stream.wait_event(self.ready[b])
-        eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
+        if self.on_air:   # (the packed frames all start at t_begin)
+            eng.tick_run_records_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots, t_begin + air_us)
+        else:
+            eng.tick_run_device(t_begin, t_end, self.all[b].data_ptr(), self.world * self.slots)
         if self.may_draw and eng.draws_pending():
             # probabilistic links: the shared java.util.Random is consumed in node order = rank order;
             # one more tiny all-gather (per-packet draw counts), then every rank places its draws

@@ -271,6 +271,10 @@ class Engine:
     def tick_run_device(self, t_begin, t_end, dev_new_ptr, n_new):
         check(self._L.rm_tick_run_device(self._h, t_begin, t_end, C.c_void_p(dev_new_ptr), n_new))
 
+    def tick_run_records_device(self, t_begin, t_end, dev_new_ptr, n_new, latest_end_us):
+        """records in device memory for the SINR medium, whose frames stay on the air: `latest_end_us` bounds start + air"""
+        check(self._L.rm_tick_run_records_device(self._h, int(t_begin), int(t_end), C.c_void_p(dev_new_ptr), int(n_new), int(latest_end_us)))
+
     def tick_run_sources_device(self, t_begin, t_end, dev_src_ptr, n, start_us, air_us):
         check(self._L.rm_tick_run_sources_device(self._h, t_begin, t_end, C.c_void_p(dev_src_ptr), n, start_us, air_us))
 

@@ -202,3 +202,78 @@ def test_small_partition_with_many_frames_over_several_ticks(rsa, O, kind, param
                 np.testing.assert_array_equal(res.rssi, ref.rssi[keep])
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world):
+    """configs[4]'s sharded form: the SINR medium, frames that stay on the air over several ticks, the tick's records
+    gathered in device memory (padding included) and handed to every rank's context with rm_tick_run_records_device --
+    each context keeps the on-air lists of ITS receivers across the ticks.  Merged, the ranks' links equal the oracle's
+    tick over the full on-air list; a receiver moves in mid-run (every context rebuilds its lists from the records it
+    kept)."""
+    from radio_sim_amd import dist as D
+    from util import DeviceArray
+    n = 4000
+    rng = np.random.default_rng(23)
+    nd = O.NodeTable(n)
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    nd.channel[:] = 11 + rng.integers(0, 2, n)
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 9}
+    mdl = oracle_model(O, "logdist", params)
+    engs = []
+    try:
+        for r in range(world):
+            lo, hi = D.partition(n, r, world)
+            e = rsa.Engine(0)
+            e.upload_table(nd)
+            e.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            if world > 1:
+                e.set_partition(lo, hi - lo)
+            engs.append(e)
+        onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+        airs = [8128, 2048, 8128, 320, 8128, 4064, 8128, 320, 2048, 8128, 8128, 320]
+        interfered = 0
+        for tick, air in enumerate(airs):
+            t0 = tick * 1000
+            if tick == 6:                           # a receiver moves next to a sender: every rank's lists are rebuilt
+                j = int(rng.integers(n))
+                nd.x[j], nd.y[j] = nd.x[(j + 7) % n] + 2.0, nd.y[(j + 7) % n]
+                for e in engs:
+                    e.update_node(j, nd.x[j], nd.y[j], nd.z[j], nd.txpower[j], int(nd.channel[j]), 1, 1.0, 1.0)
+            srcs = np.sort(rng.choice(n, 60, replace=False)).astype(np.int32)
+            slots = D.slots_needed(n, max(world, 1), [srcs])
+            parts = []
+            for r in range(world):
+                lo, hi = D.partition(n, r, world)
+                mine = srcs[(srcs >= lo) & (srcs < hi)]
+                parts.append(D.pad_records(to_tx_records(rsa, nd.packets(mine, t0, air)), slots))
+            gathered = np.concatenate(parts)
+            valid, slot_idx = D.drop_padding(gathered)
+            dev = DeviceArray(gathered)
+            shards = []
+            for e in engs:
+                e.tick_run_records_device(t0, t0 + 1000, dev.ptr.value, len(gathered), t0 + air)
+                res = e.result_copy(len(gathered))
+                shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
+            dev.free()
+            pkt, dst, verdict, rssi, sinr = D.merge_shard_links(shards, len(gathered))
+            onair = onair[onair["start_us"] + onair["air_us"] > t0]
+            new = np.zeros(len(valid), dtype=O.PACKET_DTYPE)
+            for f in ("src", "channel", "x", "y", "z", "txpower", "txprob", "start_us", "air_us"):
+                new[f] = valid[f]
+            ref = O.tick(mdl, nd, np.concatenate([onair, new]), first_new=len(onair))
+            onair = np.concatenate([onair, new])
+            assert len(pkt) == ref.count > 100, (tick, len(pkt), ref.count)
+            np.testing.assert_array_equal(pkt, slot_idx[ref.pkt], err_msg="tick %d" % tick)
+            np.testing.assert_array_equal(dst, ref.dst, err_msg="tick %d" % tick)
+            np.testing.assert_array_equal(verdict, ref.verdict, err_msg="tick %d" % tick)
+            np.testing.assert_array_equal(rssi, ref.rssi, err_msg="tick %d" % tick)
+            np.testing.assert_array_equal(sinr, ref.sinr, err_msg="tick %d" % tick)
+            interfered += int((ref.verdict == O.INTERFERED).sum())
+        assert interfered > 50
+        inc, reb = engs[0].air_list_stats()
+        assert reb == 2 and inc == len(airs) - 2       # the first tick and the one after the move
+    finally:
+        for e in engs:
+            e.close()
