@@ -149,6 +149,25 @@ def test_pipelined_sharded_driver_on_one_gpu():
     assert outs[1]["value"] > 0
 
 
+def test_sharded_driver_with_frames_on_the_air_on_one_gpu():
+    """configs[4] through the multi-GPU driver with world == 1 (rm_tick_run_records_device under ShardedTick.stage / sweep):
+    the same heard links as the plain device path, and only the first tick builds the on-air lists."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ["--force-sharded"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c5", "--nodes", "200000", "--steps", "14",
+                            "--warmup", "10", "--no-cpu-baseline", "--no-host-transfer"] + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        outs.append(json.loads(line))
+    assert outs[0]["config"]["heard_links_last_tick"] == outs[1]["config"]["heard_links_last_tick"] > 0
+    assert "1 rebuilt them" in outs[1]["config"]["workload"]
+
+
 def test_batched_sharded_driver_through_rccl_with_one_rank():
     """The batched multi-GPU tick driver with a real process group: backend "nccl" (= RCCL) with one
     rank, so that packing, the all-gather on the context's own communicator, the transposition and
