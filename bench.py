@@ -574,6 +574,23 @@ def main():
                           "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
                                   "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
 
+        if rank == 0 and sequential is not None and world == 1 and not as_rank:
+            # the one-launch tick against the same roofline: section 8(d)'s bytes of ONE tick over the tick's time (the tick is
+            # a chain of dependent round trips on a mostly idle device: bound by latency, neither by HBM nor by issue slots)
+            b_tick = n * S_NODE + t_per_tick * S_TX + heard * S_REC
+            seq_s = sequential["ms_per_tick"] * 1e-3
+            rl = {"bound": "latency", "algorithmic_bytes_per_tick": int(b_tick), "achieved": b_tick / seq_s / 1e9, "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": b_tick / seq_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "valu_issue_us_per_tick": None}
+            try:
+                ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload + "_tick", {})
+                if args.nodes == 0 and "k_tick_frames" in ent:
+                    rl["traffic"] = ent["k_tick_frames"]["hbm_bytes_per_launch"]
+                    rl["valu_issue_us_per_tick"] = ent["k_tick_frames"].get("valu_issue_us_per_launch")
+                    rl["traffic_source"] = ent["k_tick_frames"]["source"] + " (commit %s)" % ent.get("commit", "unrecorded")
+            except (OSError, ValueError):
+                pass
+            sequential["roofline"] = rl
+
         if rank == 0:
             # Roofline.  Per-stage durations come from HIP events recorded on the engine's
             # stream around every stage of each `profile_every`-th launch of the timed region.  Every stage is priced
