@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--no-scale-probe", action="store_true",
                     help="skip the short 1M-node run that shows the sweep's HBM fraction at scale")
     ap.add_argument("--no-weak-probe", action="store_true", help="several GPUs: skip the extra weak-scaling pass (key weak_scaling)")
+    ap.add_argument("--spatial-ids", action="store_true",
+                    help="experiment: number the synthetic nodes along a space-filling curve, so that a rank's range of node "
+                         "indices is a region of the area (NOT the BASELINE layout's numbering; the link count is the same)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="several GPUs: strong (default) = the BASELINE config itself, receivers split over the ranks; "
                          "weak = node count grown as sqrt(GPUs) so that the link evaluations per GPU stay fixed")
@@ -394,6 +397,22 @@ def main():
         # the SINR extension looks at every frame on the air: ticks are chained unless no frame outlives its tick
         stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > tick_us
         nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
+        if args.spatial_ids:
+            # Morton order of the positions: index ranges become spatial regions (what a host that assigns node ids by
+            # location gives the range partition of the multi-GPU mode)
+            side = float(max(nodes.x.max(), nodes.y.max())) + 1e-9
+            qx = np.minimum((nodes.x / side * 65536).astype(np.uint64), 65535)
+            qy = np.minimum((nodes.y / side * 65536).astype(np.uint64), 65535)
+
+            def spread(v):
+                v = (v | (v << 8)) & np.uint64(0x00FF00FF)
+                v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
+                v = (v | (v << 2)) & np.uint64(0x33333333)
+                return (v | (v << 1)) & np.uint64(0x55555555)
+            order = np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
+            for f in ("x", "y", "z", "txpower", "channel", "enabled", "rxprob", "txprob"):
+                setattr(nodes, f, np.ascontiguousarray(getattr(nodes, f)[order]))
+            desc += " -- node ids along a Morton curve (--spatial-ids)"
         kind_name, kw = W.model_kwargs(model)
         kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
 
