@@ -472,11 +472,12 @@ def main():
 
         def batch_args(k, nb, tk):
             """arguments of one rm_batch_run_sources_device call for the source lists k .. k+nb-1 at simulated ticks tk .."""
-            if (k, nb, tk) not in _bargs:
-                t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
-                _bargs[(k, nb, tk)] = (t0, t0 + tick_us, np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
-                                       np.full(nb, t_per_tick, dtype=np.int32), t0, np.full(nb, W.AIR_US, dtype=np.int64))
-            return _bargs[(k, nb, tk)]
+            if (k, nb) not in _bargs:   # what does not depend on the simulated time: built once per source-list window
+                _bargs[(k, nb)] = (np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
+                                   np.full(nb, t_per_tick, dtype=np.int32), np.full(nb, W.AIR_US, dtype=np.int64))
+            ptrs, cnt, air = _bargs[(k, nb)]
+            t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
+            return (t0, t0 + tick_us, ptrs, cnt, t0, air)
 
         def run_range(k0, k1):
             """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
