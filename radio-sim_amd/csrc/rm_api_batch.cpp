@@ -1,0 +1,308 @@
+// rm_api_batch.cpp -- C ABI: several independent ticks per launch sequence (rm_batch_*), their results in one host-mapped block.
+#include "rm_host.hpp"
+
+using namespace rmh;
+
+namespace rmh {
+
+TickSlot *slot_of(rm_context *c, int32_t slot)
+{
+    if (slot == 0) return c;
+    if (slot < 0 || size_t(slot) > c->extra_slots.size()) return nullptr;
+    return c->extra_slots[size_t(slot) - 1].get();
+}
+
+} // namespace rmh
+
+// the launch sequence of n prepared ticks in four launches (sorted table, fp32 frame, no SINR)
+static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n)
+{
+    rm::TickDev ticks[RM_MAX_BATCH];
+    for (int b = 0; b < n; ++b) ticks[b] = plans[b].t;
+    // the descriptors go to device memory (k_store_ticks, ordered on the stream after the previous
+    // batch's kernels, which read the same array)
+    RM_HIP(c->d_ticks.ensure(RM_MAX_BATCH));
+    rm::TickDev *dev_ticks = c->d_ticks.p;
+    const bool by_copy = n > 2 * 6; // beyond two k_store_ticks launches: one fetch from pinned, host-mapped memory
+    if (by_copy) {
+        const int g = c->h_ticks_gen;
+        c->h_ticks_gen ^= 1;
+        if (!c->h_ticks[g]) {
+            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ticks[g]), sizeof(rm::TickDev) * RM_MAX_BATCH, hipHostMallocMapped));
+            RM_HIP(hipEventCreateWithFlags(&c->h_ticks_ev[g], hipEventDisableTiming));
+        } else {
+            RM_HIP(hipEventSynchronize(c->h_ticks_ev[g]));
+        }
+        std::memcpy(c->h_ticks[g], ticks, sizeof(rm::TickDev) * size_t(n));
+        RM_HIP(rm::launch_fetch_ticks(c->stream, c->h_ticks[g], n, dev_ticks)); // the device reads the mapped block itself
+        RM_HIP(hipEventRecord(c->h_ticks_ev[g], c->stream));
+    }
+    const rm::ModelDev m = model_dev(c);
+    const rm::NodesDev nd = nodes_dev(c);
+    const rm::LaunchCfg &cfg = plans[0].cfg;
+    hipStream_t s = c->stream;
+    const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
+    rm_context::Sample *smp = nullptr;
+    if (sample) {
+        if (c->ev_used == c->ev_pool.size()) {
+            rm_context::Sample ns;
+            for (auto &e : ns.ev) RM_HIP(hipEventCreate(&e));
+            c->ev_pool.push_back(ns);
+        }
+        smp = &c->ev_pool[c->ev_used++];
+        smp->n = 0;
+    }
+    auto stage = [&](int id) -> int {
+        if (smp) {
+            RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+            smp->stage[smp->n++] = id;
+        }
+        return RM_OK;
+    };
+    if (!by_copy) RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
+    if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
+    // RM_BATCH_FRAMES=1: the batch through the one-frame-per-workgroup kernel of the closed-loop tick instead of the
+    // three sweep stages (one launch; the compact arrays on demand, per slot)
+    static const bool batch_frames = std::getenv("RM_BATCH_FRAMES") != nullptr;
+    if (batch_frames && !cfg.stochastic && !plans[0].sinr) {
+        int seg_len = rm::frame_tick_segment(ticks[0], cfg, m);
+        for (int b = 1; b < n && seg_len > 0; ++b) seg_len = std::min(seg_len, rm::frame_tick_segment(ticks[b], cfg, m));
+        if (seg_len > 0) {
+            RM_TRY(stage(RM_STAGE_FILTER));
+            RM_HIP(rm::launch_tick_frames_batch(s, nd, m, ticks, n, dev_ticks, cfg, seg_len));
+            if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+            for (int b = 0; b < n; ++b) {
+                slots[b]->have_result = true;
+                slots[b]->compact_pending = true;
+                slots[b]->last.seg_ordered = 1;
+                slots[b]->last_model = m;
+                slots[b]->last_cfg = cfg;
+            }
+            return RM_OK;
+        }
+    }
+    RM_TRY(stage(RM_STAGE_FILTER));
+    RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, dev_ticks, cfg));
+    RM_TRY(stage(RM_STAGE_EXACT));
+    RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, dev_ticks, cfg));
+    if (plans[0].sinr) {
+        RM_TRY(stage(RM_STAGE_SINR));
+        RM_HIP(rm::launch_batch_stage(s, 3, nd, m, ticks, n, dev_ticks, cfg));
+    }
+    RM_TRY(stage(RM_STAGE_REORDER));
+    RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, dev_ticks, cfg));
+    if (cfg.stochastic) {
+        // the shared generator is walked tick by tick, in slot order, inside one launch
+        RM_TRY(stage(RM_STAGE_DRAWS));
+        RM_HIP(rm::launch_draws_batch(s, m, ticks, n, dev_ticks));
+    }
+    if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+    for (int b = 0; b < n; ++b) {
+        slots[b]->have_result = true;
+        slots[b]->compact_pending = false;
+    }
+    return RM_OK;
+}
+
+static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                     const int32_t *const *dev_src, const rm_tx_record *const *dev_new, const int32_t *n_per,
+                     const int64_t *start_us, const int64_t *air_us)
+{
+    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || !n_per || (!dev_src && !dev_new) ||
+        (dev_src && (!start_us || !air_us)))
+        return fail(RM_ERR_INVALID, "bad arguments");
+    for (int b = 0; b < n_ticks; ++b)
+        if (n_per[b] < 0 || (n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
+            (dev_src && air_us[b] < 0))
+            return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    const bool sinr = is_sinr(c);
+    if (sinr) {
+        // The SINR extension looks at every frame on the air.  A batch is accepted when its ticks are
+        // self-contained: nothing of an earlier call and nothing of an earlier tick of the batch is
+        // still on the air when a tick begins (e.g. air time <= tick length).  Frames given as source
+        // indices carry their time span in the arguments; records given by the caller (the gathered
+        // records of a multi-GPU batch) are verified on the device: every frame of tick b has to lie
+        // inside [t_begin[b], t_end[b]], and the ticks must not overlap.
+        if (!dev_src)
+            for (int b = 0; b < n_ticks; ++b)
+                if (t_end_us[b] < t_begin_us[b] || (b + 1 < n_ticks && t_end_us[b] > t_begin_us[b + 1]))
+                    return fail(RM_ERR_STATE, "SINR batches of records need ticks [t_begin, t_end] that do not overlap");
+        for (const auto &bt : c->air_batches)
+            if (bt.end_us > t_begin_us[0])
+                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
+        for (const auto &r : c->onair)
+            if (still_on_air(r, t_begin_us[0]))
+                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
+        for (int b = 0; dev_src && b + 1 < n_ticks; ++b)
+            if (n_per[b] > 0 && start_us[b] + air_us[b] > t_begin_us[b + 1])
+                return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run "
+                                          "overlapping ticks one at a time");
+        c->onair.clear();
+        c->onair_tick.clear();
+        c->air.valid = false; // the ticks of a batch keep their lists to themselves
+        c->air_batches.clear();
+        c->air_head = c->air_tail = 0;
+    }
+    if (maybe_draws(c) && part_count(c) != c->n)
+        return fail(RM_ERR_STATE, "a receiver partition whose links draw needs rm_tick_finish_draws per tick: run it one "
+                                  "tick at a time");
+    while (c->extra_slots.size() + 1 < size_t(n_ticks)) c->extra_slots.emplace_back(new TickSlot());
+    const rm::PlanKnobs knobs = rm::read_plan_knobs(); // once for the whole batch
+    TickSlot *slots[RM_MAX_BATCH];
+    TickPlan plans[RM_MAX_BATCH];
+    bool batched = true;
+    for (int b = 0; b < n_ticks; ++b) {
+        TickSlot &ts = *slot_of(c, b);
+        slots[b] = &ts;
+        const rm_tx_record *tx = nullptr;
+        if (dev_src && sinr && b == n_ticks - 1) {
+            // the last tick's frames may outlive the batch: they are built where the on-air list of the
+            // one-tick-at-a-time path lives
+            RM_HIP(c->d_air.ensure(std::max<size_t>(size_t(n_per[b]), 1 << 16)));
+            tx = c->d_air.p;
+        } else if (dev_src) {
+            RM_HIP(ts.d_tx.ensure(std::max(n_per[b], 1)));
+            tx = ts.d_tx.p;
+        } else {
+            tx = dev_new[b];
+        }
+        c->dev_records_from_caller = (dev_src == nullptr);
+        const int rc_prep = prepare_tick(c, ts, plans[b], true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr,
+                                         dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0, kAirNone, 0, &knobs);
+        c->dev_records_from_caller = false;
+        RM_TRY(rc_prep);
+        batched = batched && !plans[b].empty && rm::batch_eligible(plans[b].t, plans[b].cfg, model_dev(c)) &&
+                  plans[b].t.rpt == plans[0].t.rpt;
+    }
+    c->t_begin = t_begin_us[0];
+    c->t_end = t_end_us[n_ticks - 1];
+    if (sinr && !dev_src)
+        for (int b = 0; b < n_ticks; ++b) {
+            plans[b].t.check_span = 1;
+            plans[b].t.span_begin = t_begin_us[b];
+            plans[b].t.span_end = t_end_us[b];
+        }
+    if (sinr && dev_src && n_per[n_ticks - 1] > 0) {
+        c->air_tail = size_t(n_per[n_ticks - 1]);
+        c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1], 0u});
+    }
+    if (batched) {
+        if (sinr)
+            for (int b = 0; b < n_ticks; ++b) plans[b].t.reset_heads = 1;
+        return launch_batch(c, slots, plans, n_ticks);
+    }
+    // configurations the batched kernels do not cover (fp64 frame, unsorted table, very many frames,
+    // empty ticks): the same ticks, one launch sequence each
+    for (int b = 0; b < n_ticks; ++b) RM_TRY(launch_tick(c, *slots[b], plans[b]));
+    return RM_OK;
+}
+
+extern "C" {
+
+int rm_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                const int32_t *const *dev_src, const int32_t *n_src, const int64_t *start_us,
+                                const int64_t *air_us)
+{
+    if (!dev_src) return fail(RM_ERR_INVALID, "bad arguments");
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, dev_src, nullptr, n_src, start_us, air_us);
+}
+
+int rm_batch_run_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                        const rm_tx_record *const *dev_new, const int32_t *n_new)
+{
+    if (!dev_new) return fail(RM_ERR_INVALID, "bad arguments");
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, dev_new, n_new, nullptr, nullptr);
+}
+
+int rm_batch_result_device(rm_context *c, int32_t slot, rm_device_result *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts) return fail(RM_ERR_INVALID, "no such result slot");
+    return result_device(c, *ts, out);
+}
+
+int rm_batch_result_count(rm_context *c, int32_t slot, uint32_t *count, uint32_t *dropped)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts) return fail(RM_ERR_INVALID, "no such result slot");
+    return result_count(c, *ts, count, dropped);
+}
+
+int rm_batch_result_copy(rm_context *c, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,
+                         double *sinr, uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    TickSlot *ts = slot_of(c, slot);
+    if (!ts) return fail(RM_ERR_INVALID, "no such result slot");
+    if (!ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    RM_HIP(hipSetDevice(c->device));
+    return copy_out(c, *ts, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+}
+
+int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, int32_t *status)
+{
+    if (!c || !out || n_slots < 1 || n_slots > RM_MAX_BATCH) return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    if (!c->h_pack) RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pack), sizeof(rm::PackSlot) * RM_MAX_BATCH, hipHostMallocDefault));
+    RM_HIP(c->d_pack.ensure(RM_MAX_BATCH));
+    uint32_t packets = 0;
+    for (int b = 0; b < n_slots; ++b) {
+        TickSlot *ts = slot_of(c, b);
+        if (!ts || !ts->have_result) return fail(RM_ERR_STATE, "no evaluated tick in this result slot");
+        if (ts->draws_pending) return fail(RM_ERR_STATE, "a slot's verdicts wait for rm_tick_finish_draws");
+        RM_TRY(materialize(c, *ts));
+        rm::PackSlot &ps = c->h_pack[b];
+        ps.t = ts->last;
+        ps.n_new = std::max(ts->last_n_new, 0);
+        ps.have_offsets = (ps.n_new > 0 && part_count(c) > 0) ? 1 : 0;
+        ps.pkt_base = packets;
+        ps.pad = 0;
+        packets += uint32_t(ps.n_new);
+    }
+    RM_TRY(ensure_stage(c, 0, packets + uint32_t(n_slots)));
+    RM_HIP(hipMemcpyAsync(c->d_pack.p, c->h_pack, sizeof(rm::PackSlot) * size_t(n_slots), hipMemcpyHostToDevice, c->stream));
+    rm::HostView v{};
+    rm::BatchCounts *counts = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
+        counts = stage_counts(c->h_stage);
+        const uint32_t seq = ++c->stage_seq;
+        RM_HIP(rm::launch_pack_batch(c->stream, c->d_pack.p, n_slots, v, counts, c->d_pack_done.p, seq));
+        volatile const uint32_t *flag = &v.hdr->seq;
+        bool seen = false;
+        for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+        if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+        const uint64_t need = uint64_t(counts[n_slots - 1].link_base) + counts[n_slots - 1].stored;
+        if (need <= v.links) break;
+        if (attempt) return fail(RM_ERR_HIP, "result block could not be sized");
+        RM_TRY(ensure_stage(c, uint32_t(std::min<uint64_t>(need + need / 4, 0xFFFFFFFFu)), packets + uint32_t(n_slots)));
+    }
+    int first_error = RM_OK;
+    for (int b = 0; b < n_slots; ++b) {
+        const rm::BatchCounts &bc = counts[b];
+        const rm::PackSlot &ps = c->h_pack[b];
+        rm_host_result &r = out[b];
+        r.count = bc.stored;
+        r.n_packets = uint32_t(ps.n_new);
+        r.pkt_offset = v.pkt_offset + ps.pkt_base + uint32_t(b);
+        r.pkt_interference = v.pkt_interference + ps.pkt_base;
+        r.pkt = v.pkt + bc.link_base;
+        r.dst = v.dst + bc.link_base;
+        r.verdict = v.verdict + bc.link_base;
+        r.rssi = v.rssi + bc.link_base;
+        r.sinr = ps.t.out_sinr ? v.sinr + bc.link_base : nullptr;
+        int st = RM_OK;
+        if (bc.span_flag)
+            st = fail(RM_ERR_STATE, record_flag_message(bc.span_flag));
+        else if (bc.dropped)
+            st = fail(RM_ERR_CAPACITY, "heard links exceed the context's link capacity (rm_set_link_capacity)");
+        if (status) status[b] = st;
+        if (st != RM_OK && first_error == RM_OK) first_error = st;
+    }
+    return first_error;
+}
+
+} // extern "C"

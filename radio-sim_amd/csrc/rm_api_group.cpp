@@ -1,0 +1,195 @@
+// rm_api_group.cpp -- C ABI: several devices (or partitions of one) behind one host thread (rm_group_*).
+#include "rm_host.hpp"
+
+using namespace rmh;
+
+struct rm_group {
+    std::vector<rm_context *> m;
+    int n_nodes = 0;
+    int n_new = 0; // frames of the running tick
+    bool in_tick = false;
+    std::vector<uint32_t> counts; // [world][n_new] per-packet draw counts
+};
+
+extern "C" {
+
+int rm_group_create(int32_t n_members, const int32_t *device_ordinals, rm_group **out)
+{
+    if (!out || n_members < 1 || !device_ordinals) return fail(RM_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    std::unique_ptr<rm_group> g(new rm_group());
+    for (int i = 0; i < n_members; ++i) {
+        rm_context *c = nullptr;
+        const int rc = rm_create(device_ordinals[i], &c);
+        if (rc != RM_OK) {
+            for (rm_context *k : g->m) rm_destroy(k);
+            return rc;
+        }
+        g->m.push_back(c);
+    }
+    *out = g.release();
+    return RM_OK;
+}
+
+void rm_group_destroy(rm_group *g)
+{
+    if (!g) return;
+    for (rm_context *c : g->m) rm_destroy(c);
+    delete g;
+}
+
+int rm_group_size(const rm_group *g) { return g ? int(g->m.size()) : fail(RM_ERR_INVALID, "group is NULL"); }
+
+rm_context *rm_group_context(rm_group *g, int32_t member)
+{
+    if (!g || member < 0 || size_t(member) >= g->m.size()) return nullptr;
+    return g->m[size_t(member)];
+}
+
+#define RM_GROUP_ALL(call)                                                                             \
+    do {                                                                                               \
+        if (!g) return fail(RM_ERR_INVALID, "group is NULL");                                          \
+        for (rm_context *c : g->m) RM_TRY(call);                                                       \
+        return RM_OK;                                                                                  \
+    } while (0)
+
+int rm_group_set_model(rm_group *g, const rm_model_params *p) { RM_GROUP_ALL(rm_set_model(c, p)); }
+int rm_group_set_n2n_matrix(rm_group *g, int32_t m, const double *row_major) { RM_GROUP_ALL(rm_set_n2n_matrix(c, m, row_major)); }
+int rm_group_seed(rm_group *g, int64_t seed) { RM_GROUP_ALL(rm_seed(c, seed)); }
+int rm_group_set_link_capacity(rm_group *g, uint32_t max_links) { RM_GROUP_ALL(rm_set_link_capacity(c, max_links)); }
+int rm_group_set_time(rm_group *g, int64_t t) { RM_GROUP_ALL(rm_set_time(c, t)); }
+int rm_group_node_update(rm_group *g, int32_t node, double x, double y, double z, double txpower, int32_t channel,
+                         uint8_t enabled, double rxprob, double txprob)
+{
+    RM_GROUP_ALL(rm_node_update(c, node, x, y, z, txpower, channel, enabled, rxprob, txprob));
+}
+
+int rm_group_get_rng_state(rm_group *g, uint64_t *state48)
+{
+    if (!g || g->m.empty()) return fail(RM_ERR_INVALID, "group is NULL");
+    return rm_get_rng_state(g->m[0], state48); // every member walks the same generator
+}
+
+int rm_group_nodes_upload(rm_group *g, int32_t n, const double *x, const double *y, const double *z, const double *txpower,
+                          const int32_t *channel, const uint8_t *enabled, const double *rxprob, const double *txprob,
+                          const int32_t *int_id)
+{
+    if (!g) return fail(RM_ERR_INVALID, "group is NULL");
+    const int64_t world = int64_t(g->m.size());
+    for (int64_t r = 0; r < world; ++r) {
+        rm_context *c = g->m[size_t(r)];
+        RM_TRY(rm_nodes_upload(c, n, x, y, z, txpower, channel, enabled, rxprob, txprob, int_id));
+        const int32_t lo = int32_t(int64_t(n) * r / world), hi = int32_t(int64_t(n) * (r + 1) / world);
+        RM_TRY(rm_set_partition(c, lo, hi - lo)); // receivers range-partitioned by node index
+    }
+    g->n_nodes = n;
+    return RM_OK;
+}
+
+int rm_group_tick_begin(rm_group *g, int64_t t_begin_us, int64_t t_end_us)
+{
+    if (!g) return fail(RM_ERR_INVALID, "group is NULL");
+    for (rm_context *c : g->m) RM_TRY(rm_tick_begin(c, t_begin_us, t_end_us));
+    g->n_new = 0;
+    g->in_tick = true;
+    return RM_OK;
+}
+
+int rm_group_enqueue_tx(rm_group *g, int32_t src, int64_t start_us, int64_t air_us, const double *txpower, const int32_t *channel)
+{
+    if (!g || !g->in_tick) return fail(RM_ERR_STATE, "rm_group_enqueue_tx outside a tick");
+    for (rm_context *c : g->m) RM_TRY(rm_enqueue_tx(c, src, start_us, air_us, txpower, channel)); // a "broadcast": the host has the record
+    g->n_new += 1;
+    return RM_OK;
+}
+
+int rm_group_enqueue_tx_records(rm_group *g, const rm_tx_record *recs, int32_t n)
+{
+    if (!g || !g->in_tick) return fail(RM_ERR_STATE, "rm_group_enqueue_tx_records outside a tick");
+    for (rm_context *c : g->m) RM_TRY(rm_enqueue_tx_records(c, recs, n));
+    g->n_new += n;
+    return RM_OK;
+}
+
+int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                        uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!g || !g->in_tick) return fail(RM_ERR_STATE, "rm_group_tick_flush without rm_group_tick_begin");
+    g->in_tick = false;
+    const int world = int(g->m.size());
+    const int n_new = g->n_new;
+    // every member's launches are enqueued before anything is waited for
+    for (rm_context *c : g->m) RM_TRY(tick_run_host(c));
+    // probabilistic links: the members' per-packet draw counts, through the host
+    bool pending = false;
+    for (rm_context *c : g->m) pending = pending || c->draws_pending;
+    if (pending) {
+        g->counts.assign(size_t(world) * size_t(std::max(n_new, 1)), 0u);
+        for (int r = 0; r < world; ++r) {
+            rm_context *c = g->m[size_t(r)];
+            if (!c->draws_pending) return fail(RM_ERR_STATE, "the members disagree on whether their links draw");
+            RM_HIP(hipSetDevice(c->device));
+            if (n_new > 0)
+                RM_HIP(hipMemcpyAsync(g->counts.data() + size_t(r) * n_new, c->d_pkt_draw_cnt.p, size_t(n_new) * 4,
+                                      hipMemcpyDeviceToHost, c->stream));
+        }
+        for (rm_context *c : g->m) {
+            RM_HIP(hipSetDevice(c->device));
+            RM_HIP(hipStreamSynchronize(c->stream));
+        }
+        for (int r = 0; r < world; ++r) RM_TRY(rm_tick_finish_draws(g->m[size_t(r)], g->counts.data(), world, r, 0));
+    }
+    // the members' results in their pinned blocks, then merged packet by packet in member (= node) order
+    std::vector<rm_host_result> res(static_cast<size_t>(world));
+    int first_error = RM_OK;
+    std::string first_msg;
+    for (int r = 0; r < world; ++r) {
+        rm_context *c = g->m[size_t(r)];
+        RM_HIP(hipSetDevice(c->device));
+        rm::HostView v{};
+        RM_TRY(pack_to_stage(c, *c, &v));
+        rm_host_result &o = res[size_t(r)];
+        o.count = v.hdr->stored;
+        o.n_packets = v.hdr->n_packets;
+        o.pkt_offset = v.pkt_offset;
+        o.pkt_interference = v.pkt_interference;
+        o.pkt = v.pkt;
+        o.dst = v.dst;
+        o.verdict = v.verdict;
+        o.rssi = v.rssi;
+        o.sinr = c->last.out_sinr ? v.sinr : nullptr;
+        const int st = stage_status(c, v);
+        if (st != RM_OK && first_error == RM_OK) {
+            first_error = st;
+            first_msg = g_err;
+        }
+    }
+    uint64_t total = 0;
+    for (const auto &o : res) total += o.count;
+    if (count) *count = uint32_t(std::min<uint64_t>(total, 0xFFFFFFFFu));
+    uint32_t w = 0;
+    for (int q = 0; q < n_new; ++q) {
+        if (pkt_offset) pkt_offset[q] = w;
+        for (int r = 0; r < world; ++r) {
+            const rm_host_result &o = res[size_t(r)];
+            if (uint32_t(q) >= o.n_packets) continue;
+            const uint32_t b = o.pkt_offset[q], e = std::min(o.pkt_offset[q + 1], o.count);
+            for (uint32_t i = b; i < e; ++i, ++w) {
+                if (w >= cap) continue;
+                if (pkt) pkt[w] = q;
+                if (dst) dst[w] = o.dst[i];
+                if (verdict) verdict[w] = o.verdict[i];
+                if (rssi) rssi[w] = o.rssi[i];
+                if (sinr) sinr[w] = o.sinr ? o.sinr[i] : 0.0;
+            }
+        }
+        // the packet-level Tx-failure flag is the same on every member (one generator, one draw)
+        if (pkt_interference && world > 0 && uint32_t(q) < res[0].n_packets) pkt_interference[q] = res[0].pkt_interference[q];
+    }
+    if (pkt_offset) pkt_offset[std::max(n_new, 0)] = w;
+    if (first_error != RM_OK) return fail(first_error, first_msg);
+    if (total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
+    return RM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,351 @@
+// rm_api_nodes.cpp -- C ABI: the node table -- Simulator.getNodes() snapshot, receiver table in engine order, changed nodes, partitions.
+#include "rm_host.hpp"
+
+using namespace rmh;
+
+namespace rmh {
+
+// k-d split of items[lo, hi) down to groups of 64: the left part always holds a multiple of 64
+// receivers, so every group of 64 consecutive engine positions is one leaf (a compact box).
+// The items carry their coordinates (no indirection in the comparisons); ties are broken by the node
+// index, so the leaves do not depend on how the work is spread over threads: the first levels hand
+// their right halves to new threads.
+struct KdItem {
+    double v[3];
+    int32_t idx;
+    int32_t pad;
+};
+
+void kd_split(KdItem *items, int lo, int hi, int spawn_levels)
+{
+    const int cnt = hi - lo;
+    if (cnt <= rm::kGroup) return;
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) mn[a] = mx[a] = items[lo].v[a];
+    for (int i = lo + 1; i < hi; ++i)
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], items[i].v[a]);
+            mx[a] = std::max(mx[a], items[i].v[a]);
+        }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    const int groups = (cnt + rm::kGroup - 1) / rm::kGroup;
+    const int mid = lo + ((groups + 1) / 2) * rm::kGroup;
+    std::nth_element(items + lo, items + mid, items + hi, [axis](const KdItem &a, const KdItem &b) {
+        return a.v[axis] < b.v[axis] || (a.v[axis] == b.v[axis] && a.idx < b.idx);
+    });
+    if (spawn_levels > 0 && cnt > 8192) {
+        std::thread right;
+        bool spawned = true;
+        try {
+            right = std::thread(kd_split, items, mid, hi, spawn_levels - 1);
+        } catch (...) { // no thread to be had: this one does both halves
+            spawned = false;
+        }
+        kd_split(items, lo, mid, spawn_levels - 1);
+        if (spawned) right.join();
+        else kd_split(items, mid, hi, 0);
+    } else {
+        kd_split(items, lo, mid, 0);
+        kd_split(items, mid, hi, 0);
+    }
+}
+
+template <typename T> int upload_gather(DevBuf<T> &d, const std::vector<T> &src, const std::vector<int32_t> &perm,
+                                        hipStream_t s, std::vector<T> &tmp)
+{
+    tmp.resize(perm.size());
+    for (size_t i = 0; i < perm.size(); ++i) tmp[i] = src[perm[i]];
+    RM_HIP(d.ensure(std::max<size_t>(tmp.size(), 1)));
+    if (!tmp.empty()) RM_HIP(hipMemcpyAsync(d.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    RM_HIP(hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+// (re)build the receiver table of the partition in engine order
+int rebuild_receivers(rm_context *c)
+{
+    const int first = part_first(c), count = part_count(c);
+    std::vector<int32_t> perm(count);
+    for (int i = 0; i < count; ++i) perm[i] = first + i;
+    c->rx_sorted = false;
+    if (is_geometric(c) && count > rm::kGroup) {
+        std::vector<KdItem> items(static_cast<size_t>(count));
+        for (int i = 0; i < count; ++i) {
+            const int k = first + i;
+            items[size_t(i)] = KdItem{{c->x[k], c->y[k], c->z[k]}, k, 0};
+        }
+        kd_split(items.data(), 0, count, 3); // up to 8 threads
+        for (int i = 0; i < count; ++i) perm[size_t(i)] = items[size_t(i)].idx;
+        c->rx_sorted = true;
+    }
+    std::vector<double> td;
+    std::vector<int32_t> ti;
+    std::vector<uint8_t> tb;
+    RM_TRY(upload_gather(c->d_rx_x, c->x, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_y, c->y, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_z, c->z, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_rxprob, c->rxprob, perm, c->stream, td));
+    RM_TRY(upload_gather(c->d_rx_channel, c->channel, perm, c->stream, ti));
+    RM_TRY(upload_gather(c->d_rx_int_id, c->int_id, perm, c->stream, ti));
+    RM_TRY(upload_gather(c->d_rx_enabled, c->enabled, perm, c->stream, tb));
+    RM_HIP(c->d_rx_orig.ensure(std::max(count, 1)));
+    RM_HIP(c->d_pos_of.ensure(std::max(count, 1)));
+    std::vector<int32_t> pos_of(count);
+    for (int i = 0; i < count; ++i) pos_of[perm[i] - first] = i;
+    if (count) {
+        RM_HIP(hipMemcpyAsync(c->d_rx_orig.p, perm.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipMemcpyAsync(c->d_pos_of.p, pos_of.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+    }
+    {
+        std::vector<rm::RxRecord> recs(count);
+        for (int i = 0; i < count; ++i) {
+            const int k = perm[i];
+            rm::RxRecord &r = recs[i];
+            std::memset(&r, 0, sizeof(r));
+            r.x = c->x[k];
+            r.y = c->y[k];
+            r.z = c->z[k];
+            r.rxprob = c->rxprob[k];
+            r.orig = k;
+            r.int_id = c->int_id[k];
+            r.channel = c->channel[k];
+            r.enabled = c->enabled[k];
+        }
+        std::vector<rm::RxCompact> small(count);
+        for (int i = 0; i < count; ++i) {
+            const int k = perm[i];
+            rm::RxCompact &r = small[i];
+            r.x = c->x[k];
+            r.y = c->y[k];
+            r.z = c->z[k];
+            r.orig = k;
+            r.flags = (c->rxprob[k] != 1.0) ? 1u : 0u;
+        }
+        RM_HIP(c->d_rx_rec32.ensure(std::max(count, 1)));
+        if (count)
+            RM_HIP(hipMemcpyAsync(c->d_rx_rec32.p, small.data(), size_t(count) * sizeof(rm::RxCompact), hipMemcpyHostToDevice, c->stream));
+        RM_HIP(c->d_rx_rec.ensure(std::max(count, 1)));
+        if (count) {
+            RM_HIP(hipMemcpyAsync(c->d_rx_rec.p, recs.data(), size_t(count) * sizeof(rm::RxRecord), hipMemcpyHostToDevice, c->stream));
+            RM_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    c->h_pos_of.swap(pos_of);
+    const int groups = (count + rm::kGroup - 1) / rm::kGroup;
+    c->g_box.assign(size_t(groups), rm_context::GroupBox{});
+    for (int g = 0; g < groups; ++g) {
+        rm_context::GroupBox &b = c->g_box[size_t(g)];
+        for (int i = g * rm::kGroup; i < std::min(count, (g + 1) * rm::kGroup); ++i) {
+            const int k = perm[i];
+            const double v[3] = {c->x[k], c->y[k], c->z[k]};
+            for (int a = 0; a < 3; ++a) {
+                if (i == g * rm::kGroup || v[a] < b.lo[a]) b.lo[a] = v[a];
+                if (i == g * rm::kGroup || v[a] > b.hi[a]) b.hi[a] = v[a];
+            }
+        }
+    }
+    c->g_escaped.assign(size_t(groups), 0);
+    c->table_sorts++;
+    c->escaped_groups = 0;
+    c->drifted_groups = 0;
+    c->n_rx = count;
+    c->rx_dirty = false;
+    c->prefilter_dirty = true;
+    return RM_OK;
+}
+
+// Changed nodes (host mirror already updated) go to the device in place: one launch, no
+// synchronisation for a single node.  The receiver table keeps its engine order -- any permutation
+// is correct, the order only decides how tight the groups' boxes are -- and is sorted again once
+// enough receivers have left the box their group had when it was sorted.
+int patch_nodes(rm_context *c, const int32_t *nodes, int count)
+{
+    if (count <= 0) return RM_OK;
+    const int first = part_first(c), pcount = part_count(c);
+    static const long resort_after = [] {
+        const char *e = std::getenv("RM_RESORT_AFTER"); // escaped groups that trigger a new sort (0: every change)
+        return e ? std::atol(e) : -1L;
+    }();
+    const int groups = int(c->g_box.size());
+    const long limit = resort_after >= 0 ? resort_after : std::max(2, groups / 128);
+    std::vector<rm::NodePatch> list(static_cast<size_t>(count));
+    bool frame_changed = false;
+    for (int k = 0; k < count; ++k) {
+        const int i = nodes[k];
+        rm::NodePatch &p = list[size_t(k)];
+        p.node = i;
+        p.pos = -1;
+        p.x = c->x[i]; p.y = c->y[i]; p.z = c->z[i];
+        p.txpower = c->txpower[i]; p.txprob = c->txprob[i]; p.rxprob = c->rxprob[i];
+        p.channel = c->channel[i];
+        p.enabled = c->enabled[i];
+        const double dv[3] = {p.x - c->org[0], p.y - c->org[1], p.z - c->org[2]};
+        if (std::fabs(dv[0]) > c->coord_bound || std::fabs(dv[1]) > c->coord_bound || std::fabs(dv[2]) > c->coord_bound)
+            frame_changed = true;
+        if (c->rx_dirty || i < first || i >= first + pcount) continue;
+        p.pos = c->h_pos_of[size_t(i - first)];
+        if (!c->rx_sorted) continue;
+        const int g = p.pos / rm::kGroup;
+        const rm_context::GroupBox &b = c->g_box[size_t(g)];
+        const double ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
+        const double v[3] = {p.x, p.y, p.z};
+        bool near = false, far = false;
+        for (int a = 0; a < 3; ++a) {
+            near = near || v[a] < b.lo[a] - 0.125 * ext || v[a] > b.hi[a] + 0.125 * ext;
+            far = far || v[a] < b.lo[a] - 0.5 * ext || v[a] > b.hi[a] + 0.5 * ext;
+        }
+        uint8_t &flag = c->g_escaped[size_t(g)];
+        if (near && !(flag & 1)) {
+            flag |= 1;
+            c->drifted_groups++;
+        }
+        if (far && !(flag & 2)) {
+            flag |= 2;
+            c->escaped_groups++;
+        }
+    }
+    const rm::NodesDev nd = nodes_dev(c);
+    if (count == 1) {
+        RM_HIP(rm::launch_patch_nodes(c->stream, nd, nullptr, 1, list[0]));
+    } else {
+        RM_HIP(c->d_patch.ensure(size_t(count)));
+        RM_HIP(hipMemcpyAsync(c->d_patch.p, list.data(), size_t(count) * sizeof(rm::NodePatch), hipMemcpyHostToDevice, c->stream));
+        RM_HIP(rm::launch_patch_nodes(c->stream, nd, c->d_patch.p, count, list[0]));
+        RM_HIP(hipStreamSynchronize(c->stream)); // the host list goes away
+    }
+    if (frame_changed) recompute_frame(c);
+    c->prefilter_dirty = true;
+    // a far-flung receiver makes its group a candidate for many frames; many slightly grown boxes cost as much
+    if (c->rx_sorted && !c->rx_dirty && (c->escaped_groups > limit || (resort_after < 0 && c->drifted_groups > groups / 4)))
+        c->rx_dirty = true; // sorted again before the next tick
+    return RM_OK;
+}
+
+int prepare_nodes(rm_context *c)
+{
+    if (c->rx_dirty || c->prefilter_dirty) c->air.valid = false; // whatever the SINR lists' entries were computed from has changed
+    if (c->rx_dirty) RM_TRY(rebuild_receivers(c));
+    if (!c->prefilter_dirty) return RM_OK;
+    const int groups = (c->n_rx + rm::kGroup - 1) / rm::kGroup;
+    RM_HIP(c->d_rxf.ensure(std::max(c->n_rx, 1)));
+    RM_HIP(c->d_bbox_xy.ensure(std::max(groups, 1)));
+    RM_HIP(c->d_bbox_z.ensure(std::max(groups, 1)));
+    RM_HIP(c->d_wg_box_xy.ensure(std::max(groups / 16 + 1, 1)));
+    RM_HIP(c->d_wg_box_z.ensure(std::max(groups / 16 + 1, 1)));
+    RM_HIP(rm::launch_prep_rx(c->stream, nodes_dev(c), model_dev(c)));
+    c->prefilter_dirty = false;
+    return RM_OK;
+}
+
+} // namespace rmh
+
+extern "C" {
+
+int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, const double *z,
+                    const double *txpower, const int32_t *channel, const uint8_t *enabled, const double *rxprob,
+                    const double *txprob, const int32_t *int_id)
+{
+    if (!c || n < 0) return fail(RM_ERR_INVALID, "bad arguments");
+    if (n > 0 && (!x || !y)) return fail(RM_ERR_INVALID, "x and y are required");
+    for (int i = 0; i < n; ++i) {
+        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || (z && !std::isfinite(z[i])))
+            return fail(RM_ERR_INVALID, "node positions must be finite");
+    }
+    RM_HIP(hipSetDevice(c->device));
+    c->n = n;
+    c->x.assign(x, x + n);
+    c->y.assign(y, y + n);
+    if (z) c->z.assign(z, z + n); else c->z.assign(n, 0.0);                          // Position.java:44-46
+    if (txpower) c->txpower.assign(txpower, txpower + n); else c->txpower.assign(n, 0.0);   // Transciever.java:11
+    if (channel) c->channel.assign(channel, channel + n); else c->channel.assign(n, 26);    // :12
+    if (enabled) c->enabled.assign(enabled, enabled + n); else c->enabled.assign(n, 1);     // :13
+    if (rxprob) c->rxprob.assign(rxprob, rxprob + n); else c->rxprob.assign(n, 1.0);        // :17
+    if (txprob) c->txprob.assign(txprob, txprob + n); else c->txprob.assign(n, 1.0);        // :18
+    if (int_id) c->int_id.assign(int_id, int_id + n);
+    else {
+        c->int_id.resize(n);
+        for (int i = 0; i < n; ++i) c->int_id[i] = i + 1;
+    }
+    RM_TRY(upload(c->d_x, c->x, c->stream));
+    RM_TRY(upload(c->d_y, c->y, c->stream));
+    RM_TRY(upload(c->d_z, c->z, c->stream));
+    RM_TRY(upload(c->d_txpower, c->txpower, c->stream));
+    RM_TRY(upload(c->d_txprob, c->txprob, c->stream));
+    RM_TRY(upload(c->d_channel, c->channel, c->stream));
+    RM_TRY(upload(c->d_int_id, c->int_id, c->stream));
+    RM_TRY(upload(c->d_enabled, c->enabled, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    if (c->ev.on) RM_TRY(ev_ensure_nodes(c));
+    recompute_frame(c);
+    c->rx_dirty = true;
+    c->frac_probs = -1;
+    c->air_batches.clear();
+    c->air_head = c->air_tail = 0;
+    c->onair.clear();
+    c->onair_tick.clear();
+    c->air.valid = false;
+    c->pending.clear();
+    if (c->rx_count >= 0 && c->rx_first + c->rx_count > n) {
+        c->rx_first = 0;
+        c->rx_count = -1;
+    }
+    c->rx_dirty = true;
+    return RM_OK;
+}
+
+// keep the cached "can a draw happen" answer across a node change where that is possible
+static void note_probabilities(rm_context *c, double old_rx, double old_tx, double new_rx, double new_tx)
+{
+    if (c->frac_probs < 0) return;
+    const bool was = frac(old_rx) || frac(old_tx), is = frac(new_rx) || frac(new_tx);
+    if (is) c->frac_probs = 1;
+    else if (was && c->frac_probs == 1) c->frac_probs = -1; // it may have been the only one: scan again
+}
+
+int rm_node_update(rm_context *c, int32_t i, double x, double y, double z, double txpower, int32_t channel,
+                   uint8_t enabled, double rxprob, double txprob)
+{
+    if (!c || i < 0 || i >= c->n) return fail(RM_ERR_INVALID, "node index out of range");
+    if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return fail(RM_ERR_INVALID, "position must be finite");
+    RM_HIP(hipSetDevice(c->device));
+    note_probabilities(c, c->rxprob[i], c->txprob[i], rxprob, txprob);
+    c->x[i] = x; c->y[i] = y; c->z[i] = z; c->txpower[i] = txpower; c->channel[i] = channel;
+    c->enabled[i] = enabled; c->rxprob[i] = rxprob; c->txprob[i] = txprob;
+    return patch_nodes(c, &i, 1);
+}
+
+int rm_nodes_move(rm_context *c, int32_t count, const int32_t *nodes, const double *x, const double *y, const double *z)
+{
+    if (!c || count < 0 || (count > 0 && (!nodes || !x || !y))) return fail(RM_ERR_INVALID, "bad arguments");
+    for (int k = 0; k < count; ++k) {
+        if (nodes[k] < 0 || nodes[k] >= c->n) return fail(RM_ERR_INVALID, "node index out of range");
+        if (!std::isfinite(x[k]) || !std::isfinite(y[k]) || (z && !std::isfinite(z[k])))
+            return fail(RM_ERR_INVALID, "position must be finite");
+    }
+    RM_HIP(hipSetDevice(c->device));
+    for (int k = 0; k < count; ++k) {
+        const int i = nodes[k];
+        c->x[i] = x[k];
+        c->y[i] = y[k];
+        c->z[i] = z ? z[k] : 0.0; // Position.java:44-46: set(x, y) puts z at 0
+    }
+    return patch_nodes(c, nodes, count);
+}
+
+int64_t rm_receiver_table_builds(const rm_context *c) { return c ? c->table_sorts : 0; }
+
+int rm_node_count(const rm_context *c) { return c ? c->n : fail(RM_ERR_INVALID, "ctx is NULL"); }
+
+int rm_set_partition(rm_context *c, int32_t first, int32_t count)
+{
+    if (!c || first < 0 || count < 0 || first + count > c->n) return fail(RM_ERR_INVALID, "partition out of range");
+    c->rx_first = first;
+    c->rx_count = count;
+    c->rx_dirty = true;
+    return RM_OK;
+}
+
+} // extern "C"
