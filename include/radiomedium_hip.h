@@ -34,7 +34,11 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 1
+/* 2: rm_delivery_view.oldest_packet; rm_host_result.sinr / rm_device_result.sinr are NULL without the SINR extension;
+ *    rm_group_*, rm_events_*, rm_node_info, rm_tick_run_records_device, rm_set_partition_spatial and the draw-node
+ *    exchange were added; rm_tick_run_device refuses the SINR medium (rm_tick_run_records_device takes it).  A host
+ *    built against another version must not load this library: compare rm_abi_version() with RM_ABI_VERSION. */
+#define RM_ABI_VERSION 2
 
 #define RM_OK 0
 #define RM_ERR_INVALID (-1)   /* bad argument */
@@ -368,6 +372,8 @@ int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdic
 typedef struct rm_delivery_view {
     uint32_t count;            /* deliveries of this drain */
     uint32_t pending_packets;  /* packets with events still queued */
+    int64_t oldest_packet;     /* number of the oldest of them (== rm_events_next_packet: none): every packet
+                                * below it has fired its last event and may be forgotten by the host */
     const int64_t *packet;     /* [count] packet number */
     const int32_t *dst;        /* [count] destination node index */
     const double *rssi;        /* [count] */

@@ -49,11 +49,18 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     public static final int MODEL_NULL = 0, MODEL_UDGM = 1, MODEL_UDGM_CONST = 2, MODEL_N2N = 3, MODEL_LOGDIST = 4;
     private static final byte INTERFERED = 1, DELIVERED = 2;
 
+    /** RM_ABI_VERSION of the include/radiomedium_hip.h this shim and its JNI glue were written against */
+    private static final int ABI_VERSION = 2;
+
     static {
         System.loadLibrary("radiomedium_jni"); // integration/jni/rm_jni.c, links libradiomedium_hip.so
+        if (nAbiVersion() != ABI_VERSION) {
+            throw new UnsatisfiedLinkError("libradiomedium_hip.so has ABI version " + nAbiVersion() + ", this shim needs " + ABI_VERSION);
+        }
     }
 
     /* ---- native side: one-to-one with include/radiomedium_hip.h ---- */
+    private static native int nAbiVersion();
     private static native long nCreate(int device);
     private static native void nDestroy(long ctx);
     private static native String nLastError();
@@ -80,7 +87,7 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private static native int nEventsEnable(long ctx, int maxPackets, int maxLinks);
     private static native long nEventsNextPacket(long ctx);
     private static native int nEventsProcess(long ctx, long timeUs, java.nio.ByteBuffer[] views /* packet, dst, rssi */,
-            int[] counts /* deliveries, pending packets */);
+            long[] counts /* deliveries, pending packets, number of the oldest pending packet */);
     private static native int nNodeInfo(long ctx, int[] nodes, double[] rssi, int[] receiving, int[] channel);
 
     private final Object lock = new Object();
@@ -254,9 +261,9 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             int heard = nTransmit(ctx, src, packet.getStartTime(), packet.getPacketDataAsHex() == null ? 0
                     : packet.getPacketDataAsHex().length(), true, packet.getTransmitPower(), true,
                     packet.getWirelessChannel(), dst, verdict, rssi, sinr, interference);
-            if (deviceEvents) { // the engine queued the packet's events itself
+            if (deviceEvents) { // the engine queued the packet's events itself -- if it numbered the packet
                 if (heard < 0) log.error("radio medium: {}", nLastError());
-                inFlight.add(packet);
+                if (nEventsNextPacket(ctx) == firstInFlight + inFlight.size() + 1) inFlight.add(packet);
                 return;
             }
             if (kind != MODEL_UDGM_CONST) {
@@ -290,16 +297,24 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             syncNodes(nodes);
             nSetTime(ctx, sim.getTime());
             int rc = nTickBegin(ctx, sim.getTime(), sim.getTime());
+            // the packets the engine actually took, in the order it numbers them: results are indexed by THIS list
+            // (a packet whose source is not in the node table is not enqueued and must not shift the others)
+            java.util.ArrayList<RadioPacket> enqueued = new java.util.ArrayList<>(queue.size());
             for (RadioPacket p : queue) {
                 Integer src = index.get(p.getSource());
                 if (rc == 0 && src != null) {
                     rc = nEnqueue(ctx, src, p.getStartTime(), p.getPacketAirTime(), p.getTransmitPower(), p.getWirelessChannel());
+                    if (rc == 0) enqueued.add(p);
                 }
             }
             if (deviceEvents) {
+                long before = nEventsNextPacket(ctx);
                 if (rc == 0) rc = nTickRun(ctx);
+                // in flight = numbered by the engine: only after a successful run, and only if the numbers agree
                 if (rc != 0) log.error("radio medium: {}", nLastError());
-                inFlight.addAll(queue);
+                else if (nEventsNextPacket(ctx) - before != enqueued.size() || before != firstInFlight + inFlight.size())
+                    log.error("radio medium: packet numbers out of step with the engine; tick dropped");
+                else inFlight.addAll(enqueued);
                 queue.clear();
                 return;
             }
@@ -310,14 +325,16 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             java.nio.IntBuffer off = rc == 0 ? v[0].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer() : null;
             java.nio.IntBuffer d = rc == 0 ? v[2].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer() : null;
             java.nio.DoubleBuffer r = rc == 0 ? v[4].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer() : null;
-            for (int k = 0; k < queue.size(); k++) { // arrival order, then node order: the per-packet calls
-                RadioPacket p = queue.get(k);
-                if (kind != MODEL_UDGM_CONST) sim.generateTransmissionEvents(p);
-                for (int i = rc == 0 ? off.get(k) : 0; rc == 0 && i < off.get(k + 1); i++) {
+            int k = 0; // index into the engine's packets of this tick
+            for (RadioPacket p : queue) { // arrival order, then node order: the per-packet calls
+                if (kind != MODEL_UDGM_CONST) sim.generateTransmissionEvents(p); // whatever the native call said
+                if (rc != 0 || k >= enqueued.size() || enqueued.get(k) != p) continue; // not evaluated: no receivers
+                for (int i = off.get(k); i < off.get(k + 1); i++) {
                     Node node = nodes[d.get(i)];
                     if (kind == MODEL_UDGM_CONST) sim.deliverRadioPacket(p, node, r.get(i));
                     else sim.generateReceptionEvents(p, node, r.get(i), v[3].get(i) == DELIVERED);
                 }
+                k++;
             }
             queue.clear();
         }
@@ -329,7 +346,7 @@ public class GpuRadioMedium extends AbstractRadioMedium {
         synchronized (lock) {
             if (!deviceEvents || sim == null) return;
             java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[3];
-            int[] counts = new int[2];
+            long[] counts = new long[3]; // deliveries, pending packets, number of the oldest pending packet
             if (nEventsProcess(ctx, time, v, counts) != 0) {
                 log.error("radio medium: {}", nLastError());
                 return;
@@ -340,9 +357,14 @@ public class GpuRadioMedium extends AbstractRadioMedium {
             java.nio.DoubleBuffer r = v[2].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer();
             RadioPacket[] live = inFlight.toArray(new RadioPacket[0]);
             for (int i = 0; i < counts[0]; i++) { // ReceptionEvent.java:41-44, in the queue's pop order
-                sim.deliverRadioPacket(live[(int) (pk.get(i) - firstInFlight)], nodes[d.get(i)], r.get(i));
+                long k = pk.get(i) - firstInFlight;
+                if (k < 0 || k >= live.length || d.get(i) < 0 || d.get(i) >= nodes.length) {
+                    log.error("radio medium: a delivery names a packet or node the host does not hold");
+                    continue;
+                }
+                sim.deliverRadioPacket(live[(int) k], nodes[d.get(i)], r.get(i));
             }
-            long oldest = nEventsNextPacket(ctx) - counts[1]; // packets whose last event has fired are forgotten
+            long oldest = counts[2]; // every packet below the oldest one still queued has fired its last event
             while (firstInFlight < oldest && !inFlight.isEmpty()) {
                 inFlight.poll();
                 firstInFlight++;

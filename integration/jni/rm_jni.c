@@ -178,6 +178,12 @@ JNIEXPORT jint JFN(nTickFlushView)(JNIEnv *env, jclass cls, jlong ctx, jobjectAr
     return RM_OK;
 }
 
+JNIEXPORT jint JFN(nAbiVersion)(JNIEnv *env, jclass cls)
+{
+    (void)env; (void)cls;
+    return rm_abi_version() == RM_ABI_VERSION ? RM_ABI_VERSION : -rm_abi_version(); /* header and library must agree too */
+}
+
 /* ---- reception stage on the device ------------------------------------------------------------------ */
 JNIEXPORT jint JFN(nEventsEnable)(JNIEnv *env, jclass cls, jlong ctx, jint maxPackets, jint maxLinks)
 {
@@ -192,14 +198,14 @@ JNIEXPORT jlong JFN(nEventsNextPacket)(JNIEnv *env, jclass cls, jlong ctx)
     return rm_events_next_packet((rm_context *)(intptr_t)ctx);
 }
 
-JNIEXPORT jint JFN(nEventsProcess)(JNIEnv *env, jclass cls, jlong ctx, jlong timeUs, jobjectArray views, jintArray counts)
+JNIEXPORT jint JFN(nEventsProcess)(JNIEnv *env, jclass cls, jlong ctx, jlong timeUs, jobjectArray views, jlongArray counts)
 {
     (void)cls;
     rm_delivery_view v;
     int rc = rm_events_process((rm_context *)(intptr_t)ctx, timeUs, &v);
     if (rc != RM_OK) return rc;
-    jint c[2] = {(jint)v.count, (jint)v.pending_packets};
-    (*env)->SetIntArrayRegion(env, counts, 0, 2, c);
+    jlong c[3] = {(jlong)v.count, (jlong)v.pending_packets, (jlong)v.oldest_packet};
+    (*env)->SetLongArrayRegion(env, counts, 0, 3, c);
     void *ptr[3] = {(void *)v.packet, (void *)v.dst, (void *)v.rssi};
     jlong len[3] = {(jlong)v.count * 8, (jlong)v.count * 4, (jlong)v.count * 8};
     for (int i = 0; i < 3; i++) (*env)->SetObjectArrayElement(env, views, i, (*env)->NewDirectByteBuffer(env, ptr[i], len[i]));

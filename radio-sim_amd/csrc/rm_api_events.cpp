@@ -199,6 +199,7 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
     if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
     out->count = o.hdr->count;
     out->pending_packets = o.hdr->pending_packets;
+    out->oldest_packet = o.hdr->oldest_packet;
     out->packet = o.pkt;
     out->dst = o.dst;
     out->rssi = o.rssi;

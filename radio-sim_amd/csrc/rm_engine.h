@@ -308,7 +308,7 @@ enum { kEvRxStart = 0, kEvRxEnd = 1, kEvTxStart = 2, kEvTxEnd = 3 };
 struct EvTails {
     int64_t gseq_next;
     uint32_t pk_tail, pool_tail; // monotone counters
-    uint32_t err;                // sticky: 1 packet ring full, 2 link pool full, 8 a tick was dropped for capacity
+    uint32_t err;                // until the next drain has reported it: 1 packet ring full, 2 link pool full, 8 a tick was dropped for capacity
     uint32_t pad;
 };
 struct EvState {
@@ -318,7 +318,7 @@ struct EvState {
     uint32_t pk_head, pool_head; // monotone counters
     uint32_t n_groups;          // fired (packet, phase) groups of the running drain
     uint32_t n_deliv;
-    uint32_t err;               // sticky: 4 group list full
+    uint32_t err;               // until the drain has reported it: 4 group list full
     uint32_t done_a;            // "last workgroup" counter (node-info)
     uint32_t pad1[2];
     EvTails tails[2];
@@ -366,8 +366,11 @@ struct EvHeader {
     int64_t next_packet; // number the next transmitted packet gets
     int64_t time;
     uint32_t seq;        // written last
-    uint32_t pad[7];
+    uint32_t pad0;
+    int64_t oldest_packet; // number of the oldest packet with events still queued (== next_packet: none)
+    uint32_t pad[4];
 };
+static_assert(sizeof(EvHeader) == 64, "one line of host-mapped memory");
 struct EvOut {
     EvHeader *hdr;
     int64_t *pkt;

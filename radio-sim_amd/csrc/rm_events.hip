@@ -429,6 +429,14 @@ __global__ void __launch_bounds__(1024) k_ev_finish(const EvDev e, const EvOut o
     __hip_atomic_store(&out.hdr->err, st.err | tl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out.hdr->pending_packets, tail - new_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out.hdr->next_packet, tl.gseq_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the ring head's own number: a tick that did not fit the rings was numbered but left nothing here, so
+    // "next - pending" would skip packets that are still queued
+    const int64_t oldest = (new_head == tail) ? tl.gseq_next
+                                              : __hip_atomic_load(&e.pk[new_head & e.pk_mask].gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&out.hdr->oldest_packet, oldest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // an overflow is reported by the drain that follows it, once: the rings take the next ticks again
+    st.err = 0u;
+    st.tails[e.par].err = 0u;
     __hip_atomic_store(&out.hdr->time, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&out.hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

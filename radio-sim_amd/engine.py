@@ -370,6 +370,7 @@ class Engine:
         v = DeliveryView()
         check(self._L.rm_events_process(self._h, int(time_us), C.byref(v)))
         k = v.count
+        self.oldest_pending_packet = v.oldest_packet   # every packet below it has fired its last event
 
         def arr(ptr, dtype):
             a = _wrap(ptr, dtype, k)

@@ -343,6 +343,8 @@ class GpuRadioMedium : public AbstractRadioMedium {
 public:
     explicit GpuRadioMedium(int kind, int device = 0) : kind_(kind)
     {
+        if (rm_abi_version() != RM_ABI_VERSION)
+            throw std::runtime_error("libradiomedium_hip.so does not have the ABI version of the header this host was built against");
         if (rm_create(device, &ctx_) != RM_OK) throw std::runtime_error(std::string("no MI355X radio medium: ") + rm_last_error());
         rm_model_defaults(&params_, kind);
         apply();
@@ -373,13 +375,22 @@ public:
         if (on == deviceEvents_) return;
         if ((on ? rm_events_enable(ctx_, 0, 0) : rm_events_disable(ctx_)) != RM_OK) throw std::runtime_error(rm_last_error());
         deviceEvents_ = on;
+        for (size_t i = inFlightHead_; i < inFlight_.size(); ++i) released_.push_back(inFlight_[i]);
         inFlight_.clear();
         inFlightHead_ = 0;
         firstInFlight_ = on ? rm_events_next_packet(ctx_) : 0;
     }
     bool getDeviceEvents() const { return deviceEvents_; }
-    // packets the medium still refers to (queued, or with events pending on the device), oldest first: a host that
-    // owns the RadioPacket objects may drop all but the last inFlightCount() it handed to transmit()
+    // Tick mode / device events: the medium refers to a RadioPacket from transmit() until it says so here -- the
+    // packet's last event has fired on the device, or a failed evaluation dropped it.  A host that owns the
+    // RadioPacket objects frees exactly these (by identity: a failed flush leaves no packet behind that an older,
+    // still pending one could be mistaken for).  Without device events the packets handed to transmit() live in the
+    // host Simulator's own events, as in the reference.
+    void takeReleased(std::vector<RadioPacket *> &out)
+    {
+        out.insert(out.end(), released_.begin(), released_.end());
+        released_.clear();
+    }
     size_t inFlightCount() const { return queue_.size() + inFlight_.size() - inFlightHead_; }
 
     // the transmit() calls queued in tick mode, in ONE evaluation; then the calls the per-packet mode makes
@@ -390,9 +401,14 @@ public:
         Simulator *sim = simulator;
         std::vector<RadioPacket *> q;
         q.swap(queue_);
-        if (!sim) { lastError = "No simulator"; return; }
+        // whatever fails from here on: the tick's packets were never numbered by the engine, nothing refers to them
+        auto dropped = [&](const std::string &why) {
+            lastError = why;
+            if (deviceEvents_) released_.insert(released_.end(), q.begin(), q.end());
+        };
+        if (!sim) return dropped("No simulator");
         const std::vector<Node *> &nodes = sim->getNodes();
-        if (!sync(sim, nodes)) return;
+        if (!sync(sim, nodes)) return dropped(lastError);
         rm_set_time(ctx_, sim->getTime());
         int rc = rm_tick_begin(ctx_, sim->getTime(), sim->getTime());
         for (size_t k = 0; k < q.size() && rc == RM_OK; ++k) {
@@ -400,9 +416,13 @@ public:
             const int32_t ch = q[k]->getWirelessChannel();
             rc = rm_enqueue_tx(ctx_, q[k]->getSource()->index, q[k]->getStartTime(), q[k]->getPacketAirTime(), &txp, &ch);
         }
-        if (rc != RM_OK) { lastError = rm_last_error(); return; }
+        if (rc != RM_OK) return dropped(rm_last_error());
         if (deviceEvents_) { // nothing comes back: packets, links and events stay on the device
-            if (rm_tick_run(ctx_) != RM_OK) { lastError = rm_last_error(); return; }
+            const int64_t before = rm_events_next_packet(ctx_);
+            if (rm_tick_run(ctx_) != RM_OK) return dropped(rm_last_error());
+            // the engine numbers the packets of a tick it has taken, in enqueue order
+            if (rm_events_next_packet(ctx_) - before != int64_t(q.size()) || before != firstInFlight_ + int64_t(inFlight_.size() - inFlightHead_))
+                return dropped("radio medium: packet numbers out of step with the engine");
             for (RadioPacket *p : q) inFlight_.push_back(p);
             return;
         }
@@ -429,11 +449,18 @@ public:
         if (rm_events_process(ctx_, time, &v) != RM_OK) { lastError = rm_last_error(); return; }
         const std::vector<Node *> &nodes = sim->getNodes();
         RadioPacket *const *const flying = inFlight_.data() + inFlightHead_;
-        for (uint32_t i = 0; i < v.count; ++i)
-            sim->deliverRadioPacket(*flying[size_t(v.packet[i] - firstInFlight_)], nodes[size_t(v.dst[i])], v.rssi[i]);
-        // packets whose last event has fired are forgotten
-        const int64_t oldest = rm_events_next_packet(ctx_) - int64_t(v.pending_packets);
-        while (firstInFlight_ < oldest && inFlightHead_ < inFlight_.size()) {
+        const size_t n_flying = inFlight_.size() - inFlightHead_;
+        for (uint32_t i = 0; i < v.count; ++i) {
+            const int64_t k = v.packet[i] - firstInFlight_;
+            if (k < 0 || size_t(k) >= n_flying || v.dst[i] < 0 || size_t(v.dst[i]) >= nodes.size()) {
+                lastError = "radio medium: a delivery names a packet or node the host does not hold";
+                continue;
+            }
+            sim->deliverRadioPacket(*flying[size_t(k)], nodes[size_t(v.dst[i])], v.rssi[i]);
+        }
+        // packets whose last event has fired are forgotten: everything below the oldest number still queued
+        while (firstInFlight_ < v.oldest_packet && inFlightHead_ < inFlight_.size()) {
+            released_.push_back(inFlight_[inFlightHead_]);
             ++inFlightHead_;
             ++firstInFlight_;
         }
@@ -473,15 +500,21 @@ public:
         const int32_t ch = packet.getWirelessChannel();
         uint32_t heard = 0;
         uint8_t interference = 0;
+        const int64_t before = deviceEvents_ ? rm_events_next_packet(ctx_) : 0;
         const int rc = rm_transmit(ctx_, packet.getSource()->index, packet.getStartTime(),
                                    int64_t(packet.getPacketDataAsHex().size()), &txp, &ch, dst_.data(), verdict_.data(),
                                    rssi_.data(), sinr_.data(), uint32_t(dst_.size()), &heard, &interference);
-        if (rc != RM_OK) { lastError = rm_last_error(); return; }
-        lastInterference = interference != 0;
-        if (deviceEvents_) { // the engine queued the packet's events itself
-            inFlight_.push_back(&packet);
+        if (deviceEvents_) { // the engine queued the packet's events itself -- if it numbered the packet
+            if (rm_events_next_packet(ctx_) == before + 1 && before == firstInFlight_ + int64_t(inFlight_.size() - inFlightHead_))
+                inFlight_.push_back(&packet);
+            else
+                released_.push_back(&packet);
+            if (rc != RM_OK) lastError = rm_last_error();
+            else lastInterference = interference != 0;
             return;
         }
+        if (rc != RM_OK) { lastError = rm_last_error(); return; }
+        lastInterference = interference != 0;
         if (kind_ != RM_MODEL_UDGM_CONST) sim->generateTransmissionEvents(packet);
         for (uint32_t i = 0; i < heard; ++i) { // node order, as the reference's for (Node node : nodes)
             Node *node = nodes[dst_[i]];
@@ -511,6 +544,7 @@ private:
                                    nd.getRadio().isEnabled(), nd.getRadio().getRxProbability(),
                                    nd.getRadio().getTxProbability()) != RM_OK) {
                     lastError = rm_last_error();
+                    uploaded_ = ~0ull; // the rest of the dirty list is gone with this call: a fresh snapshot next time
                     return false;
                 }
             }
@@ -541,6 +575,7 @@ private:
     bool tickMode_ = false, deviceEvents_ = false;
     std::vector<RadioPacket *> queue_;   // tick mode: transmit() calls since the last flush
     std::vector<RadioPacket *> inFlight_; // device events: packets with events still queued, by packet number (from inFlightHead_)
+    std::vector<RadioPacket *> released_; // packets the medium has stopped referring to since the last takeReleased()
     size_t inFlightHead_ = 0;
     int64_t firstInFlight_ = 0;
     uint64_t uploaded_ = ~0ull;

@@ -51,6 +51,7 @@
 #include <cmath>
 #include <cstdio>
 #include <deque>
+#include <unordered_map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -247,12 +248,22 @@ private:
                 if (n < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) break;
                 close(c); // "failed to reply to client"
             }
+            // a peer that has stopped reading: the reference blocks that connection's own thread; one thread serves all
+            // of them here, so the connection is given up once its backlog passes the cap
+            if (c.fd >= 0 && c.out.size() > kMaxBacklog) {
+                std::fprintf(stderr, "%s: %zu bytes unsent, peer not reading: closing\n", c.name.c_str(), c.out.size());
+                c.out.clear();
+                close(c);
+            }
         }
     }
+    static constexpr size_t kMaxBacklog = size_t(256) << 20;
     void close(Connection &c) // JSONClientConnection.close: the simulator keeps whatever referred to it
     {
         if (c.fd >= 0) {
-            if (!c.out.empty()) { // what was already "written" in the reference's blocking send
+            if (!c.out.empty()) { // what was already "written" in the reference's blocking send: one bounded attempt
+                const timeval tv{0, 200 * 1000};   // (a peer that does not read must not stall the poll loop)
+                ::setsockopt(c.fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
                 ::fcntl(c.fd, F_SETFL, ::fcntl(c.fd, F_GETFL, 0) & ~O_NONBLOCK);
                 (void)!::send(c.fd, c.out.data(), c.out.size(), MSG_NOSIGNAL);
                 c.out.clear();
@@ -366,6 +377,7 @@ private:
     {
         if (medium_) medium_->flush();
         medium_.reset(m);
+        packets_.clear(); // the old medium's pending events went with it (the reference's queue would still fire them)
         if (m) {
             m->setTickMode(!opt_.perPacket);
             sim_.setRadioMedium(m);
@@ -527,10 +539,18 @@ private:
         cc->sent();
         ++deliveries_;
     }
-    void prunePackets() // the medium refers to a packet until its last event has fired
+    // The medium refers to a packet until its last event has fired, or until a failed evaluation dropped it; it
+    // names the packets it has let go of (by identity -- counting from the front of a queue would free an older,
+    // still pending packet in place of a newer one a failed flush never took).
+    void prunePackets()
     {
-        const size_t live = medium_ ? medium_->inFlightCount() : 0;
-        while (packets_.size() > live) packets_.pop_front();
+        if (!medium_) {
+            packets_.clear();
+            return;
+        }
+        released_.clear();
+        medium_->takeReleased(released_);
+        for (RadioPacket *p : released_) packets_.erase(p);
     }
 
     // ---------------------------------------------------------------- SimulatorJSONHandler.handleMessage
@@ -613,8 +633,9 @@ private:
                 reply = replyError(id, "command-error", "no radio medium available");
                 haveReply = true;
             } else {
-                packets_.emplace_back(new RadioPacket(node, tTime, packetData));
-                RadioPacket &packet = *packets_.back();
+                RadioPacket *owned = new RadioPacket(node, tTime, packetData);
+                packets_.emplace(owned, std::unique_ptr<RadioPacket>(owned));
+                RadioPacket &packet = *owned;
                 const Json *value = json.get("rf-power");
                 if (isNumber(value)) packet.setTransmitPower(value->asDouble());
                 value = json.get("wireless-channel");
@@ -639,8 +660,14 @@ private:
             const Json *value = params.get("position");
             if (value && value->isArray()) {
                 const Json &p = *value;
-                if (p.size() > 2) node->getPosition().set(p[0].asDouble(), p[1].asDouble(), p[2].asDouble());
-                else if (p.size() > 1) node->getPosition().set(p[0].asDouble(), p[1].asDouble());
+                // (deviation: Double.parseDouble("1e999") is Infinity and the reference would keep it, leaving the node
+                // unheard; the device-resident table takes finite coordinates only, so such a position is not applied)
+                const double px = p.size() > 1 ? p[0].asDouble() : 0.0, py = p.size() > 1 ? p[1].asDouble() : 0.0;
+                const double pz = p.size() > 2 ? p[2].asDouble() : 0.0;
+                if (!std::isfinite(px) || !std::isfinite(py) || !std::isfinite(pz))
+                    std::fprintf(stderr, "node %s: non-finite position ignored\n", nodeId.c_str());
+                else if (p.size() > 2) node->getPosition().set(px, py, pz);
+                else if (p.size() > 1) node->getPosition().set(px, py);
             }
             sim_.nodeChanged(node);
             value = params.get("rf-power");
@@ -797,7 +824,8 @@ private:
     int lfd_ = -1;
     std::vector<std::unique_ptr<Connection>> conns_;
     std::vector<Connection *> nodeConn_; // Node.getClientConnection, by node index
-    std::deque<std::unique_ptr<RadioPacket>> packets_;
+    std::unordered_map<RadioPacket *, std::unique_ptr<RadioPacket>> packets_; // owned until the medium releases them
+    std::vector<RadioPacket *> released_;
     // Simulator.java:69-78
     Connection *timeController_ = nullptr;
     std::vector<Connection *> emulators_, eventListeners_;

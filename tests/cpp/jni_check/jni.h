@@ -20,6 +20,7 @@ typedef jobject jarray;
 typedef jarray jobjectArray;
 typedef jarray jbyteArray;
 typedef jarray jintArray;
+typedef jarray jlongArray;
 typedef jarray jdoubleArray;
 
 #define JNIEXPORT __attribute__((visibility("default")))
@@ -39,6 +40,7 @@ struct JNINativeInterface_ {
     void (*ReleaseIntArrayElements)(JNIEnv *env, jintArray array, jint *elems, jint mode);
     void (*ReleaseDoubleArrayElements)(JNIEnv *env, jdoubleArray array, jdouble *elems, jint mode);
     void (*SetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize len, const jint *buf);
+    void (*SetLongArrayRegion)(JNIEnv *env, jlongArray array, jsize start, jsize len, const jlong *buf);
     jobject (*NewDirectByteBuffer)(JNIEnv *env, void *address, jlong capacity);
 };
 #endif

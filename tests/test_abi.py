@@ -27,7 +27,7 @@ def test_header_symbols_exported(rsa):
 def test_binding_covers_header(rsa):
     from radio_sim_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().rm_abi_version() == 1
+    assert _lib.lib().rm_abi_version() == 2
 
 
 def test_struct_layouts(rsa):
@@ -108,7 +108,7 @@ def test_jni_glue_type_checks_and_matches_the_java_declarations(tmp_path):
     java = open(os.path.join(ROOT, "integration", "java", "se", "sics", "emul8", "radiomedium", "GpuRadioMedium.java")).read()
     csrc = re.sub(r"/\*.*?\*/", " ", open(glue).read(), flags=re.S)
     csrc = re.sub(r"//[^\n]*", " ", csrc)
-    jtype = {"int": "jint", "long": "jlong", "double": "jdouble", "boolean": "jboolean", "String": "jstring", "int[]": "jintArray",
+    jtype = {"int": "jint", "long": "jlong", "double": "jdouble", "boolean": "jboolean", "String": "jstring", "int[]": "jintArray", "long[]": "jlongArray",
              "double[]": "jdoubleArray", "byte[]": "jbyteArray", "java.nio.ByteBuffer[]": "jobjectArray", "void": "void"}
     natives = re.findall(r"private static native\s+([\w.\[\]]+)\s+(\w+)\s*\(([^)]*)\)\s*;", re.sub(r"/\*.*?\*/", " ", java, flags=re.S))
     assert len(natives) >= 19

@@ -216,3 +216,62 @@ def test_server_end_to_end(O, model, mode):
 
 
 packets_hex = {}
+
+
+def test_server_keeps_its_packets_straight_when_an_evaluation_fails():
+    """a node-config-set with a position of [1e999, 0] (Double.parseDouble gives Infinity) used to make every
+    later evaluation fail, and the server then freed OLDER packets whose end events were still pending.  Now the position
+    is not applied (stderr says so), nothing fails, and long frames sent before and after it are delivered to the end."""
+    n = 12
+    args = [_build(), "--port", "0", "--bind", "127.0.0.1", "--seed", "7"]
+    proc = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        first = proc.stdout.readline()
+        port = int(first.rstrip(".\n").split()[-1])
+        ctl, emu = Peer(port), Peer(port)
+        for p in (ctl, emu):
+            assert p.line() + b"\r\n" == GREETING
+        ctl.send({"command": "configuration-set", "id": 1, "parameters": {"propagation-option": "udgm"}})
+        assert ctl.line() == b'{"id":1,"reply":"OK"}'
+        for i in range(n):
+            emu.send({"command": "node-config-set", "id": i, "parameters": {"node-id": i + 1, "position": [float(3 * i), 0.0, 0.0]}})
+            assert emu.line().startswith(b'{"id":%d,"reply":"OK"' % i)
+        long_hex = "ab" * 127            # 8128 us on the air: pending over eight 1 ms steps
+        received, now = 0, 0
+        for t in range(14):
+            step = now + 1000
+            ctl.send({"command": "time-set", "id": 1000 + t, "parameters": {"time": step}})
+            assert emu.line().startswith(b'{"command":"time-step"')
+            emu.send({"command": "transmit", "node-id": 1 + (t % n), "time": now, "packet-data": long_hex})
+            if t == 2:
+                emu.raw('{"command":"node-config-set","id":500,"parameters":{"node-id":4,"position":[1e999,0]}}')
+                assert emu.line().startswith(b'{"id":500,"reply":"OK"')
+            emu.send({"command": "transmit", "node-id": 1 + ((t + 5) % n), "time": now, "packet-data": "0102"})
+            emu.send({"reply": "OK", "id": 1001 + t})
+            # receive messages of this drain, then the controller's OK
+            assert ctl.line() == b'{"reply":"OK","id":%d}' % (1000 + t)
+            emu.send({"command": "time-get", "id": 9000 + t})
+            while True:
+                ln = emu.line()
+                if ln.startswith(b'{"id":%d,' % (9000 + t)):
+                    break
+                assert ln.startswith(b'{"command":"receive"'), ln
+                body = json.loads(ln)
+                assert body["packet-data"] in (long_hex, "0102")
+                received += 1
+            now = step
+        # every frame is heard by the 11 other nodes (range 50, nodes 3 m apart); the long frames of the first six steps
+        # have ended by now
+        assert received >= 14 * 11 + 6 * 11, received
+        assert proc.poll() is None
+        for p in (ctl, emu):
+            p.close()
+    finally:
+        proc.terminate()
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        err = proc.stderr.read()
+    assert "non-finite position ignored" in err
+    assert "radio medium error" not in err, err
