@@ -326,8 +326,58 @@ def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=12):
             "value": t * (n - 1) / (el / ticks), "unit": "links/s", "dropped": bool(dropped)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself -- fresh child processes
+    (python -m torch.distributed.run, one rank per GPU over RCCL) -- BEFORE it has imported torch or touched a GPU, relays
+    rank 0's JSON line and exits with the children's code.  Nothing that has initialised the GPU is ever re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out, _ = proc.communicate()
+    line = None
+    for ln in out.decode(errors="replace").splitlines():      # rank 0 prints exactly one JSON line; the launcher may add its own
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    raise SystemExit(proc.returncode if proc.returncode else (0 if line is not None else 1))
+
+
+def dry_run(args, rank, world, result_fd):
+    """RM_BENCH_DRY_RUN=1: the launch plumbing without a GPU (CPU test tier): the ranks rendezvous over gloo, agree on a
+    number, rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        total = 1.0
+    if rank == 0:
+        os.write(result_fd, (json.dumps({"metric": baseline_metric(), "dry_run": True, "n_gpus": world, "steps": args.steps,
+                                         "warmup": args.warmup, "rank_sum": total}) + "\n").encode())
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.as_rank:
+        spawn_ranks(args)
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner
     # on the first communicator), so everything but the result line goes to stderr.
     sys.stdout.flush()
@@ -335,15 +385,15 @@ def main():
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("RM_BENCH_DRY_RUN") == "1":
+        return dry_run(args, rank, world, result_fd)
     if args.inflight <= 0:
         args.inflight = 2 if world == 1 else 3
     if args.batch <= 0:
         args.batch = 64 if world == 1 else 128
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
-        args.gpus = world
+        args.gpus = world      # under a launcher the launcher's world size is the truth
 
     import torch
     import radio_sim_amd as rsa
