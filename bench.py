@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--spatial-ids", action="store_true",
                     help="experiment: number the synthetic nodes along a space-filling curve, so that a rank's range of node "
                          "indices is a region of the area (NOT the BASELINE layout's numbering; the link count is the same)")
+    ap.add_argument("--partition", default="spatial", choices=["spatial", "index"],
+                    help="several GPUs / --as-rank: a rank's receivers are a REGION of the plane (the k-d split of all positions: "
+                         "its filter drops the frames far from the region; default) or a range of node indices")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="several GPUs: strong (default) = the BASELINE config itself, receivers split over the ranks; "
                          "weak = node count grown as sqrt(GPUs) so that the link evaluations per GPU stay fixed")
@@ -479,13 +482,23 @@ def main():
             streams.append(st)
         eng, stream = engines[0], streams[0]
 
-        # receiver range partitioning (strong scaling): rank r owns receivers [lo, hi)
-        lo = (n * rank) // world
-        hi = (n * (rank + 1)) // world
+        # receiver partitioning (strong scaling): rank r owns a region of the plane, or the receivers [lo, hi)
+        spatial = args.partition == "spatial"
+        part_r, part_w = (as_rank if as_rank else (rank, world))
+        lo = (n * part_r) // part_w
+        hi = (n * (part_r + 1)) // part_w
+        own = None                          # owner of every node (who packs a transmitter's record)
+        if part_w > 1:
+            from radio_sim_amd import dist as D0
+            own = D0.owners(n, part_w, eng if spatial else None)
+        n_loc = int((own == part_r).sum()) if own is not None else n
         if as_rank:
-            lo, hi = (n * as_rank[0]) // as_rank[1], (n * (as_rank[0] + 1)) // as_rank[1]
             for e in engines:
-                e.set_partition(lo, hi - lo)
+                if spatial:
+                    e.set_partition_spatial(part_r, part_w)
+                else:
+                    e.set_partition(lo, hi - lo)
+            desc += " (%s partition: %d receivers)" % (args.partition, n_loc)
 
         from radio_sim_amd import dist as D
         use_sharded = world > 1 or args.force_sharded
@@ -507,10 +520,11 @@ def main():
             else:
                 # every rank packs the frames whose source it owns into a fixed number of slots
                 # (padded with src = -1), then the ranks all-gather the slots over RCCL
-                slots = D.slots_needed(n, world, sources)
-                pad = np.stack([D.pad_sources(s[(s >= lo) & (s < hi)], slots) for s in sources])
+                slots = D.slots_needed(n, world, sources, own)
+                pad = np.stack([D.pad_sources(s[own[s] == rank] if own is not None else s, slots) for s in sources])
                 src_dev = torch.from_numpy(pad).to(dev)
-                sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch, on_air=stateful)
+                sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch, on_air=stateful,
+                                        spatial=spatial)
         stream.synchronize()
 
         links_done = [0]
@@ -615,7 +629,7 @@ def main():
         else:
             heard_total = float(heard)
 
-        links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * (hi - lo)
+        links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * n_loc
         timed_ticks = args.steps * tps
         value = links_per_tick * timed_ticks / elapsed
         if stateful and sharded is None:
@@ -671,7 +685,6 @@ def main():
             # The dominant stage's bound is named for what binds it: vector issue slots for these integer / fp32 / fp64
             # sweeps (PMC: profiles/pmc_traffic.json), its HBM fraction is reported next to it; the HBM figure of the
             # whole step is section 8(d)'s bytes (N_loc*37 + T*56 + H*25 per tick) over the DRIVER-timed ms_per_step.
-            n_loc = hi - lo
             h_loc = heard
             ticks_per_launch = batch
             try:
@@ -740,8 +753,8 @@ def main():
                            "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
                            "step": "one launch sequence sweeping ticks_per_step simulated ticks",
                            "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
-                           "sharding": ("receivers range-partitioned over %d ranks, RCCL all-gather of Tx records per batch of ticks"
-                                        % world) if world > 1 else "none"},
+                           "sharding": ("receivers partitioned over %d ranks (%s), RCCL all-gather of Tx records per batch of ticks"
+                                        % (world, "regions of the k-d order" if spatial else "node index ranges")) if world > 1 else "none"},
                 "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": (valu["frac"] if (bound == "valu" and valu) else achieved / HBM_PEAK_GBS),
                              "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

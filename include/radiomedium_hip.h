@@ -150,6 +150,19 @@ int64_t rm_receiver_table_builds(const rm_context *ctx);
 int rm_node_count(const rm_context *ctx);
 /* receiver range owned by this context (multi-GPU range partitioning); default = all */
 int rm_set_partition(rm_context *ctx, int32_t first, int32_t count);
+/* Receivers partitioned by REGION instead of by index range: this context owns part `part` of the `n_parts` regions the
+ * k-d split of ALL node positions yields (groups of 64 nodes in proportion; ties by node index, so every rank computes the
+ * same cut from the same table for itself).  A rank's receivers then lie together, its filter drops the frames far from
+ * its region, and a packet's heard links -- still ascending in node index inside every rank -- are merged by node index
+ * across the ranks.  The members are fixed until the next rm_nodes_upload / partition call: a node that moves stays with
+ * its rank.  n_parts == 1: no partition.  rm_partition_of_nodes labels every node with its part (which rank owns a source,
+ * for the all-gather of Tx records); rm_partition_nodes lists this context's receivers in ascending order. */
+int rm_set_partition_spatial(rm_context *ctx, int32_t part, int32_t n_parts);
+int rm_partition_of_nodes(rm_context *ctx, int32_t n_parts, int32_t *part_of /* [n] */);
+int rm_partition_nodes(rm_context *ctx, int32_t *nodes, int32_t cap, int32_t *count);
+/* the same cut from positions alone (host only, no context, no device): what rm_partition_of_nodes answers for a table
+ * with these positions (z may be NULL: 0) */
+int rm_region_split(int32_t n, const double *x, const double *y, const double *z, int32_t n_parts, int32_t *part_of /* [n] */);
 int rm_set_link_capacity(rm_context *ctx, uint32_t max_links);
 
 /* ---- time ------------------------------------------------------------------------------ */
@@ -214,6 +227,13 @@ int rm_draw_counts_device(rm_context *ctx, const uint32_t **dev_counts, int32_t 
 int rm_draw_counts_to(rm_context *ctx, uint32_t *dev_out); /* async copy into a caller's device buffer */
 int rm_tick_finish_draws(rm_context *ctx, const uint32_t *all_counts /* [world][n_new] */, int32_t world,
                          int32_t rank, int on_device);
+/* Spatial partitions (rm_set_partition_spatial): the ranks' node sets interleave in node order, so the counts are not
+ * enough -- every rank also publishes the node index of each of its links that will draw, packet-major, ascending inside
+ * a packet (rm_draw_nodes_device: sum of its counts entries), the lists are all-gathered into rows of `stride` entries
+ * per rank, and a link's place among its packet's draws is the number of listed nodes below it over all ranks. */
+int rm_draw_nodes_device(rm_context *ctx, const int32_t **dev_nodes);
+int rm_tick_finish_draws_nodes(rm_context *ctx, const uint32_t *all_counts /* [world][n_new] */,
+                               const int32_t *all_nodes /* [world][stride] */, uint32_t stride, int32_t world, int on_device);
 
 /* ---- device-resident path (bench, multi-GPU): no host copies ------------------------------ */
 /* build tx records for sources `dev_src[0..n)` from the resident node state */
@@ -315,18 +335,21 @@ int rm_air_list_stats(const rm_context *ctx, uint64_t *incremental_ticks, uint64
 
 /* ---- several devices behind one caller --------------------------------------------------------------
  * The reference host is ONE process (Main.java:65-73): a group drives n contexts from one host thread, one
- * per device (an ordinal may repeat: several partitions on one GPU).  Receivers are range-partitioned by
- * node index over the members (rm_set_partition); a tick's Tx records are on the host already, so they are
- * simply handed to every member -- no all-gather; every member evaluates them against its receivers, the
- * launches of all members are enqueued before any result is waited for, and the heard links are merged
- * packet-major / node ascending (member order = node order).  Probabilistic links: the per-packet draw
- * counts are exchanged through the host and every member places its draws behind the lower members'
- * (rm_tick_finish_draws), so verdicts, Tx-failure flags and the java.util.Random state are those of one
- * context.  Everything else of a member (reception stage, node-info, device-resident results) is reached
+ * per device (an ordinal may repeat: several partitions on one GPU).  Receivers are partitioned over the
+ * members by region (rm_set_partition_spatial; or by node index range, rm_group_set_partitioning); a tick's
+ * Tx records are on the host already, so they are simply handed to every member -- no all-gather; every
+ * member evaluates them against its receivers, the launches of all members are enqueued before any result
+ * is waited for, and the heard links are merged packet-major / node ascending (a k-way merge by node index).
+ * Probabilistic links: the per-packet draw counts (and, for regions, the drawing links' nodes) are exchanged
+ * through the host and every member places its draws among the other members' (rm_tick_finish_draws*), so
+ * verdicts, Tx-failure flags and the java.util.Random state are those of one context.  Everything else of a member (reception stage, node-info, device-resident results) is reached
  * through rm_group_context. */
 typedef struct rm_group rm_group;
 int rm_group_create(int32_t n_members, const int32_t *device_ordinals, rm_group **out);
 void rm_group_destroy(rm_group *g);
+/* members own regions of the plane (default, rm_set_partition_spatial) or ranges of node indices (spatial = 0);
+ * before rm_group_nodes_upload */
+int rm_group_set_partitioning(rm_group *g, int32_t spatial);
 int rm_group_size(const rm_group *g);
 rm_context *rm_group_context(rm_group *g, int32_t member);
 int rm_group_set_model(rm_group *g, const rm_model_params *p);

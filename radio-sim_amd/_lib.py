@@ -110,6 +110,10 @@ SIGNATURES = {
     "rm_nodes_move": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rm_node_count": (C.c_int, [C.c_void_p]),
     "rm_set_partition": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rm_set_partition_spatial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rm_partition_of_nodes": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "rm_region_split": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rm_partition_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "rm_set_link_capacity": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rm_set_time": (C.c_int, [C.c_void_p, C.c_int64]),
     "rm_air_time_us": (C.c_int64, [C.c_int64]),
@@ -130,6 +134,8 @@ SIGNATURES = {
     "rm_draw_counts_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "rm_draw_counts_to": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rm_tick_finish_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int]),
+    "rm_draw_nodes_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rm_tick_finish_draws_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int]),
     "rm_pack_tx_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "rm_pack_tx_device_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "rm_pack_tx_batch_device_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
@@ -158,6 +164,7 @@ SIGNATURES = {
     "rm_group_create": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rm_group_destroy": (None, [C.c_void_p]),
     "rm_group_size": (C.c_int, [C.c_void_p]),
+    "rm_group_set_partitioning": (C.c_int, [C.c_void_p, C.c_int32]),
     "rm_group_context": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "rm_group_set_model": (C.c_int, [C.c_void_p, C.POINTER(ModelParams)]),
     "rm_group_set_n2n_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

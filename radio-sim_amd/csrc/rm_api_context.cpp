@@ -27,8 +27,10 @@ const char *model_name(int kind)
 
 bool is_sinr(const rm_context *c) { return c->params.kind == RM_MODEL_LOGDIST && (c->params.flags & RM_LD_SINR); }
 
-int part_first(const rm_context *c) { return c->rx_count < 0 ? 0 : c->rx_first; }
-int part_count(const rm_context *c) { return c->rx_count < 0 ? c->n : c->rx_count; }
+bool part_spatial(const rm_context *c) { return c->sp_parts > 1; }
+int part_first(const rm_context *c) { return (part_spatial(c) || c->rx_count < 0) ? 0 : c->rx_first; }
+int part_count(const rm_context *c) { return part_spatial(c) ? int(c->sp_nodes.size()) : (c->rx_count < 0 ? c->n : c->rx_count); }
+int pos_span(const rm_context *c) { return part_spatial(c) ? c->n : part_count(c); }
 
 bool frac(double p) { return p > 0.0 && p < 1.0; }
 
@@ -172,6 +174,7 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.rec32 = no_rec32 ? nullptr : c->d_rx_rec32.p;
     nd.pos_of = c->d_pos_of.p;
     nd.rx_first = part_first(c);
+    nd.pos_span = pos_span(c);
     nd.rxf = c->d_rxf.p;
     nd.bbox_xy = c->d_bbox_xy.p;
     nd.bbox_z = c->d_bbox_z.p;
@@ -292,6 +295,7 @@ void rm_destroy(rm_context *c)
     c->air.pool.release(); c->air.head.release(); c->air.tail.release(); c->air.mark.release(); c->air.bad.release();
     c->d_patch.release();
     c->d_enabled.release();
+    c->d_member.release(); c->d_draw_nodes.release(); c->d_all_off.release(); c->d_all_nodes.release();
     (void)rm_events_disable(c);
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();

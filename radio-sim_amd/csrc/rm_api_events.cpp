@@ -31,6 +31,7 @@ rm::EvDev ev_dev(rm_context *c)
     e.n_nodes = v.state_n;
     e.own_first = part_first(c);
     e.own_count = part_count(c);
+    e.member = part_spatial(c) ? c->d_member.p : nullptr;
     e.par = v.par;
     return e;
 }

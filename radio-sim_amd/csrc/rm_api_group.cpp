@@ -8,7 +8,9 @@ struct rm_group {
     int n_nodes = 0;
     int n_new = 0; // frames of the running tick
     bool in_tick = false;
+    bool spatial = true;          // members own regions of the plane (rm_set_partition_spatial), not ranges of node indices
     std::vector<uint32_t> counts; // [world][n_new] per-packet draw counts
+    std::vector<int32_t> draw_nodes; // [world][stride] spatial partitions: the node of every drawing link, packet-major
 };
 
 extern "C" {
@@ -36,6 +38,14 @@ void rm_group_destroy(rm_group *g)
     if (!g) return;
     for (rm_context *c : g->m) rm_destroy(c);
     delete g;
+}
+
+int rm_group_set_partitioning(rm_group *g, int32_t spatial)
+{
+    if (!g) return fail(RM_ERR_INVALID, "group is NULL");
+    if (g->n_nodes > 0 && (spatial != 0) != g->spatial) return fail(RM_ERR_STATE, "choose the partitioning before rm_group_nodes_upload");
+    g->spatial = spatial != 0;
+    return RM_OK;
 }
 
 int rm_group_size(const rm_group *g) { return g ? int(g->m.size()) : fail(RM_ERR_INVALID, "group is NULL"); }
@@ -80,7 +90,8 @@ int rm_group_nodes_upload(rm_group *g, int32_t n, const double *x, const double 
         rm_context *c = g->m[size_t(r)];
         RM_TRY(rm_nodes_upload(c, n, x, y, z, txpower, channel, enabled, rxprob, txprob, int_id));
         const int32_t lo = int32_t(int64_t(n) * r / world), hi = int32_t(int64_t(n) * (r + 1) / world);
-        RM_TRY(rm_set_partition(c, lo, hi - lo)); // receivers range-partitioned by node index
+        if (g->spatial) RM_TRY(rm_set_partition_spatial(c, int32_t(r), int32_t(world))); // receivers partitioned by region
+        else RM_TRY(rm_set_partition(c, lo, hi - lo));                                   // ... or by node index range
     }
     g->n_nodes = n;
     return RM_OK;
@@ -137,7 +148,31 @@ int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdic
             RM_HIP(hipSetDevice(c->device));
             RM_HIP(hipStreamSynchronize(c->stream));
         }
-        for (int r = 0; r < world; ++r) RM_TRY(rm_tick_finish_draws(g->m[size_t(r)], g->counts.data(), world, r, 0));
+        if (!g->spatial || world == 1) {
+            for (int r = 0; r < world; ++r) RM_TRY(rm_tick_finish_draws(g->m[size_t(r)], g->counts.data(), world, r, 0));
+        } else {
+            // regions interleave in node order: the members' lists of drawing nodes go round as well
+            std::vector<uint64_t> tot(static_cast<size_t>(world), 0);
+            uint64_t stride = 0;
+            for (int r = 0; r < world; ++r) {
+                for (int q = 0; q < n_new; ++q) tot[size_t(r)] += g->counts[size_t(r) * n_new + q];
+                stride = std::max(stride, tot[size_t(r)]);
+            }
+            g->draw_nodes.assign(size_t(world) * size_t(std::max<uint64_t>(stride, 1)), 0);
+            for (int r = 0; r < world; ++r) {
+                rm_context *c = g->m[size_t(r)];
+                RM_HIP(hipSetDevice(c->device));
+                if (tot[size_t(r)])
+                    RM_HIP(hipMemcpyAsync(g->draw_nodes.data() + size_t(r) * stride, c->d_draw_nodes.p, size_t(tot[size_t(r)]) * 4,
+                                          hipMemcpyDeviceToHost, c->stream));
+            }
+            for (rm_context *c : g->m) {
+                RM_HIP(hipSetDevice(c->device));
+                RM_HIP(hipStreamSynchronize(c->stream));
+            }
+            for (int r = 0; r < world; ++r)
+                RM_TRY(rm_tick_finish_draws_nodes(g->m[size_t(r)], g->counts.data(), g->draw_nodes.data(), uint32_t(stride), world, 0));
+        }
     }
     // the members' results in their pinned blocks, then merged packet by packet in member (= node) order
     std::vector<rm_host_result> res(static_cast<size_t>(world));
@@ -168,20 +203,34 @@ int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdic
     for (const auto &o : res) total += o.count;
     if (count) *count = uint32_t(std::min<uint64_t>(total, 0xFFFFFFFFu));
     uint32_t w = 0;
+    std::vector<uint32_t> cur(static_cast<size_t>(world)), end(static_cast<size_t>(world));
     for (int q = 0; q < n_new; ++q) {
         if (pkt_offset) pkt_offset[q] = w;
+        // every member's links of the packet are in node order: a k-way merge by node index restores the reference's
+        // visiting order (with index ranges the members' runs simply follow each other)
         for (int r = 0; r < world; ++r) {
             const rm_host_result &o = res[size_t(r)];
-            if (uint32_t(q) >= o.n_packets) continue;
-            const uint32_t b = o.pkt_offset[q], e = std::min(o.pkt_offset[q + 1], o.count);
-            for (uint32_t i = b; i < e; ++i, ++w) {
-                if (w >= cap) continue;
+            const bool have = uint32_t(q) < o.n_packets;
+            cur[size_t(r)] = have ? o.pkt_offset[q] : 0u;
+            end[size_t(r)] = have ? std::min(o.pkt_offset[q + 1], o.count) : 0u;
+        }
+        for (;;) {
+            int best = -1;
+            for (int r = 0; r < world; ++r)
+                if (cur[size_t(r)] < end[size_t(r)] &&
+                    (best < 0 || res[size_t(r)].dst[cur[size_t(r)]] < res[size_t(best)].dst[cur[size_t(best)]]))
+                    best = r;
+            if (best < 0) break;
+            const rm_host_result &o = res[size_t(best)];
+            const uint32_t i = cur[size_t(best)]++;
+            if (w < cap) {
                 if (pkt) pkt[w] = q;
                 if (dst) dst[w] = o.dst[i];
                 if (verdict) verdict[w] = o.verdict[i];
                 if (rssi) rssi[w] = o.rssi[i];
                 if (sinr) sinr[w] = o.sinr ? o.sinr[i] : 0.0;
             }
+            ++w;
         }
         // the packet-level Tx-failure flag is the same on every member (one generator, one draw)
         if (pkt_interference && world > 0 && uint32_t(q) < res[0].n_packets) pkt_interference[q] = res[0].pkt_interference[q];

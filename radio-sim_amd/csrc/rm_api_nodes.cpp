@@ -63,17 +63,78 @@ template <typename T> int upload_gather(DevBuf<T> &d, const std::vector<T> &src,
     return RM_OK;
 }
 
+// Which region of the plane is part `p` of `parts`?  The top levels of the same k-d split: the node set is cut along its
+// widest axis into two parts holding groups of 64 in proportion to the parts they will be cut into, until one part is
+// left.  Ties go by node index, so every rank -- each computes this for itself from the same table -- gets the same cut.
+// `owner`: instead of following one part, label every node with its part (rm_partition_of_nodes).
+static void region_split(KdItem *items, int lo, int hi, int part0, int parts, int want, std::vector<int32_t> *members, int32_t *owner)
+{
+    if (parts <= 1 || hi - lo <= 0) {
+        if (owner)
+            for (int i = lo; i < hi; ++i) owner[items[i].idx] = part0;
+        if (members && part0 == want)
+            for (int i = lo; i < hi; ++i) members->push_back(items[i].idx);
+        return;
+    }
+    const int cnt = hi - lo;
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) mn[a] = mx[a] = items[lo].v[a];
+    for (int i = lo + 1; i < hi; ++i)
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], items[i].v[a]);
+            mx[a] = std::max(mx[a], items[i].v[a]);
+        }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    const int left_parts = (parts + 1) / 2;
+    const int64_t groups = (cnt + rm::kGroup - 1) / rm::kGroup;
+    const int64_t left_groups = (groups * left_parts + parts - 1) / parts;
+    const int mid = int(std::min<int64_t>(hi, lo + left_groups * rm::kGroup));
+    if (mid < hi)
+        std::nth_element(items + lo, items + mid, items + hi, [axis](const KdItem &a, const KdItem &b) {
+            return a.v[axis] < b.v[axis] || (a.v[axis] == b.v[axis] && a.idx < b.idx);
+        });
+    if (owner || want < part0 + left_parts) region_split(items, lo, mid, part0, left_parts, want, members, owner);
+    if (owner || want >= part0 + left_parts) region_split(items, mid, hi, part0 + left_parts, parts - left_parts, want, members, owner);
+}
+
+static std::vector<KdItem> all_items(const rm_context *c)
+{
+    std::vector<KdItem> items(static_cast<size_t>(c->n));
+    for (int i = 0; i < c->n; ++i) items[size_t(i)] = KdItem{{c->x[i], c->y[i], c->z[i]}, i, 0};
+    return items;
+}
+
+// the member nodes of this context's spatial partition, from the node table as it is now
+int select_region(rm_context *c)
+{
+    c->sp_nodes.clear();
+    if (!part_spatial(c)) return RM_OK;
+    std::vector<KdItem> items = all_items(c);
+    region_split(items.data(), 0, c->n, 0, c->sp_parts, c->sp_part, &c->sp_nodes, nullptr);
+    std::sort(c->sp_nodes.begin(), c->sp_nodes.end());
+    std::vector<uint8_t> member(size_t(std::max(c->n, 1)), 0);
+    for (int32_t i : c->sp_nodes) member[size_t(i)] = 1;
+    RM_HIP(c->d_member.ensure(member.size()));
+    RM_HIP(hipMemcpyAsync(c->d_member.p, member.data(), member.size(), hipMemcpyHostToDevice, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    c->rx_dirty = true;
+    return RM_OK;
+}
+
 // (re)build the receiver table of the partition in engine order
 int rebuild_receivers(rm_context *c)
 {
-    const int first = part_first(c), count = part_count(c);
+    const int first = part_first(c), count = part_count(c), span = pos_span(c);
+    const bool spatial = part_spatial(c);
     std::vector<int32_t> perm(count);
-    for (int i = 0; i < count; ++i) perm[i] = first + i;
+    for (int i = 0; i < count; ++i) perm[i] = spatial ? c->sp_nodes[size_t(i)] : first + i; // ascending node index
     c->rx_sorted = false;
     if (is_geometric(c) && count > rm::kGroup) {
         std::vector<KdItem> items(static_cast<size_t>(count));
         for (int i = 0; i < count; ++i) {
-            const int k = first + i;
+            const int k = perm[size_t(i)];
             items[size_t(i)] = KdItem{{c->x[k], c->y[k], c->z[k]}, k, 0};
         }
         kd_split(items.data(), 0, count, 3); // up to 8 threads
@@ -91,14 +152,12 @@ int rebuild_receivers(rm_context *c)
     RM_TRY(upload_gather(c->d_rx_int_id, c->int_id, perm, c->stream, ti));
     RM_TRY(upload_gather(c->d_rx_enabled, c->enabled, perm, c->stream, tb));
     RM_HIP(c->d_rx_orig.ensure(std::max(count, 1)));
-    RM_HIP(c->d_pos_of.ensure(std::max(count, 1)));
-    std::vector<int32_t> pos_of(count);
-    for (int i = 0; i < count; ++i) pos_of[perm[i] - first] = i;
-    if (count) {
-        RM_HIP(hipMemcpyAsync(c->d_rx_orig.p, perm.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
-        RM_HIP(hipMemcpyAsync(c->d_pos_of.p, pos_of.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
-        RM_HIP(hipStreamSynchronize(c->stream));
-    }
+    RM_HIP(c->d_pos_of.ensure(std::max(span, 1)));
+    std::vector<int32_t> pos_of(size_t(span), -1); // (a spatial partition: every node index, -1 = another rank's receiver)
+    for (int i = 0; i < count; ++i) pos_of[size_t(perm[i] - first)] = i;
+    if (count) RM_HIP(hipMemcpyAsync(c->d_rx_orig.p, perm.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+    if (span) RM_HIP(hipMemcpyAsync(c->d_pos_of.p, pos_of.data(), size_t(span) * 4, hipMemcpyHostToDevice, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
     {
         std::vector<rm::RxRecord> recs(count);
         for (int i = 0; i < count; ++i) {
@@ -164,7 +223,7 @@ int rebuild_receivers(rm_context *c)
 int patch_nodes(rm_context *c, const int32_t *nodes, int count)
 {
     if (count <= 0) return RM_OK;
-    const int first = part_first(c), pcount = part_count(c);
+    const int first = part_first(c), span = pos_span(c);
     static const long resort_after = [] {
         const char *e = std::getenv("RM_RESORT_AFTER"); // escaped groups that trigger a new sort (0: every change)
         return e ? std::atol(e) : -1L;
@@ -185,9 +244,9 @@ int patch_nodes(rm_context *c, const int32_t *nodes, int count)
         const double dv[3] = {p.x - c->org[0], p.y - c->org[1], p.z - c->org[2]};
         if (std::fabs(dv[0]) > c->coord_bound || std::fabs(dv[1]) > c->coord_bound || std::fabs(dv[2]) > c->coord_bound)
             frame_changed = true;
-        if (c->rx_dirty || i < first || i >= first + pcount) continue;
+        if (c->rx_dirty || i < first || i >= first + span) continue;
         p.pos = c->h_pos_of[size_t(i - first)];
-        if (!c->rx_sorted) continue;
+        if (!c->rx_sorted || p.pos < 0) continue;
         const int g = p.pos / rm::kGroup;
         const rm_context::GroupBox &b = c->g_box[size_t(g)];
         const double ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
@@ -293,7 +352,7 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
         c->rx_count = -1;
     }
     c->rx_dirty = true;
-    return RM_OK;
+    return select_region(c); // a spatial partition: the same region of the new table
 }
 
 // keep the cached "can a draw happen" answer across a node change where that is possible
@@ -344,8 +403,48 @@ int rm_set_partition(rm_context *c, int32_t first, int32_t count)
     if (!c || first < 0 || count < 0 || first + count > c->n) return fail(RM_ERR_INVALID, "partition out of range");
     c->rx_first = first;
     c->rx_count = count;
+    c->sp_part = c->sp_parts = 0;
+    c->sp_nodes.clear();
     c->rx_dirty = true;
     return RM_OK;
+}
+
+int rm_set_partition_spatial(rm_context *c, int32_t part, int32_t n_parts)
+{
+    if (!c || n_parts < 1 || part < 0 || part >= n_parts) return fail(RM_ERR_INVALID, "partition out of range");
+    RM_HIP(hipSetDevice(c->device));
+    c->rx_first = 0;
+    c->rx_count = -1;
+    c->sp_part = (n_parts > 1) ? part : 0;
+    c->sp_parts = (n_parts > 1) ? n_parts : 0;
+    c->rx_dirty = true;
+    return select_region(c);
+}
+
+int rm_partition_of_nodes(rm_context *c, int32_t n_parts, int32_t *part_of)
+{
+    if (!c || n_parts < 1 || (c->n > 0 && !part_of)) return fail(RM_ERR_INVALID, "bad arguments");
+    std::vector<KdItem> items = all_items(c);
+    region_split(items.data(), 0, c->n, 0, n_parts, -1, nullptr, part_of);
+    return RM_OK;
+}
+
+int rm_region_split(int32_t n, const double *x, const double *y, const double *z, int32_t n_parts, int32_t *part_of)
+{
+    if (n < 0 || n_parts < 1 || (n > 0 && (!x || !y || !part_of))) return fail(RM_ERR_INVALID, "bad arguments");
+    std::vector<KdItem> items(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) items[size_t(i)] = KdItem{{x[i], y[i], z ? z[i] : 0.0}, i, 0};
+    region_split(items.data(), 0, n, 0, n_parts, -1, nullptr, part_of);
+    return RM_OK;
+}
+
+int rm_partition_nodes(rm_context *c, int32_t *nodes, int32_t cap, int32_t *count)
+{
+    if (!c || !count || (cap > 0 && !nodes)) return fail(RM_ERR_INVALID, "bad arguments");
+    const int k = part_count(c), first = part_first(c);
+    *count = k;
+    for (int i = 0; i < std::min(k, cap); ++i) nodes[i] = part_spatial(c) ? c->sp_nodes[size_t(i)] : first + i;
+    return k > cap ? fail(RM_ERR_CAPACITY, "caller buffer too small for the partition's nodes") : RM_OK;
 }
 
 } // extern "C"

@@ -314,6 +314,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
     const rm::ModelDev m = model_dev(c);
     const rm::NodesDev nd = nodes_dev(c);
     hipStream_t s = c->stream;
+    if (stochastic && partitioned && part_spatial(c)) RM_HIP(c->d_draw_nodes.ensure(size_t(c->cap) + 1));
     // The launch sequence.  On a sampled tick (rm_profile_enable) every stage is bracketed by HIP
     // events on the stream; otherwise the stages are launched back to back (or, with RM_GRAPH=1,
     // replayed from an instantiated hipGraph keyed by the launch arguments).
@@ -360,6 +361,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
                 RM_TRY(stage(RM_STAGE_DRAWS));
                 RM_HIP(rm::launch_draws_scan(s, t));
                 if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
+                else if (part_spatial(c)) RM_HIP(rm::launch_draw_nodes(s, t, c->d_draw_nodes.p));
             }
             if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
             return RM_OK;
@@ -395,6 +397,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
             // a receiver partition sees only its share of every packet's draws: the caller exchanges
             // the per-packet counts (rm_draw_counts_device) and calls rm_tick_finish_draws
             if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
+            else if (part_spatial(c)) RM_HIP(rm::launch_draw_nodes(s, t, c->d_draw_nodes.p)); // ... and the drawing links' nodes
         }
         if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
         return RM_OK;

@@ -626,10 +626,47 @@ int rm_draw_counts_to(rm_context *c, uint32_t *dev_out)
     return RM_OK;
 }
 
+int rm_draw_nodes_device(rm_context *c, const int32_t **dev_nodes)
+{
+    if (!c || !dev_nodes) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!c->have_result || !c->draws_pending || !part_spatial(c))
+        return fail(RM_ERR_STATE, "no tick of a spatial partition is waiting for the draw exchange");
+    *dev_nodes = c->d_draw_nodes.p;
+    return RM_OK;
+}
+
+int rm_tick_finish_draws_nodes(rm_context *c, const uint32_t *all_counts, const int32_t *all_nodes, uint32_t stride, int32_t world,
+                               int on_device)
+{
+    if (!c || !all_counts || world < 1 || (stride > 0 && !all_nodes)) return fail(RM_ERR_INVALID, "bad arguments");
+    if (!c->draws_pending) return fail(RM_ERR_STATE, "no tick is waiting for draw counts");
+    RM_HIP(hipSetDevice(c->device));
+    const int n_new = c->last_n_new;
+    const uint32_t *dev_cnt = all_counts;
+    const int32_t *dev_nodes = all_nodes;
+    if (!on_device) {
+        RM_HIP(c->d_all_cnt.ensure(size_t(world) * std::max(n_new, 1)));
+        RM_HIP(c->d_all_nodes.ensure(std::max<size_t>(size_t(world) * stride, 1)));
+        RM_HIP(hipMemcpyAsync(c->d_all_cnt.p, all_counts, size_t(world) * n_new * 4, hipMemcpyHostToDevice, c->stream));
+        if (stride) RM_HIP(hipMemcpyAsync(c->d_all_nodes.p, all_nodes, size_t(world) * stride * 4, hipMemcpyHostToDevice, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream)); // the caller's buffers may go away
+        dev_cnt = c->d_all_cnt.p;
+        dev_nodes = c->d_all_nodes.p;
+    }
+    RM_HIP(c->d_all_off.ensure(size_t(world) * std::max(n_new, 1)));
+    RM_HIP(rm::launch_draws_apply_nodes(c->stream, c->pending_model, c->last, dev_cnt, c->d_all_off.p, dev_nodes, stride, world));
+    c->draws_pending = false;
+    if (c->ev.on) RM_TRY(ev_append(c, *c)); // the verdicts are final now
+    return RM_OK;
+}
+
 int rm_tick_finish_draws(rm_context *c, const uint32_t *all_counts, int32_t world, int32_t rank, int on_device)
 {
     if (!c || !all_counts || world < 1 || rank < 0 || rank >= world) return fail(RM_ERR_INVALID, "bad arguments");
     if (!c->draws_pending) return fail(RM_ERR_STATE, "no tick is waiting for draw counts");
+    if (part_spatial(c))
+        return fail(RM_ERR_STATE, "a spatial partition's draws interleave with the other ranks': exchange rm_draw_nodes_device as "
+                                  "well and call rm_tick_finish_draws_nodes");
     RM_HIP(hipSetDevice(c->device));
     const uint32_t *dev = all_counts;
     if (!on_device) {

@@ -80,6 +80,13 @@ RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, dou
     }
 }
 
+// engine position of a node in this partition's receiver table, -1 = not a receiver here (another rank's node, padding)
+RM_D int engine_pos(const NodesDev &nd, int node)
+{
+    const uint32_t k = uint32_t(node - nd.rx_first);
+    return (k < uint32_t(nd.pos_span)) ? nd.pos_of[k] : -1;
+}
+
 // RadioPacket(node, time, data): copies the source radio's txpower / channel (RadioPacket.java:46-52)
 RM_D rm_tx_record make_tx_record(const NodesDev &nd, int s, int64_t start_us, int64_t air_us)
 {

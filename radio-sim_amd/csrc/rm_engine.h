@@ -120,8 +120,9 @@ struct NodesDev {
     const uint8_t *enabled;
     const RxRecord *rec;                     // [n_rx] the same data as one record per receiver (k_exact, unsorted tables; k_transmit_one)
     const RxCompact *rec32;                  // [n_rx] 32-byte form for the exact stage of sorted tables
-    const int32_t *pos_of;                   // [rx_count] node index - rx_first -> engine position
-    int rx_first;
+    const int32_t *pos_of;                   // [pos_span] node index - rx_first -> engine position, -1 = not a receiver here
+    int rx_first;                            // index partition: its first node, pos_span = n_rx; spatial partition: 0, pos_span = n
+    int pos_span;
     float4 *rxf;                             // pre-filter record: (fx, fy, fz, channel bits); NaN = never a candidate
     float4 *bbox_xy;                         // per group of 64: (minx, miny, maxx, maxy) in the fp32 frame
     float2 *bbox_z;                          //                 (minz, maxz)
@@ -343,7 +344,8 @@ struct EvDev {
     uint8_t *receiving, *sending;            // [n] Transciever.receivingPacket / sendingPacket != null
     double *latched;                         // [n] Transciever.receivingRSSI
     int n_nodes;
-    int own_first, own_count;                // nodes whose Tx / Rx events this context keeps (receiver partition)
+    int own_first, own_count;                // nodes whose Tx / Rx events this context keeps (receiver partition by index range)
+    const uint8_t *member;                   // spatial partition: [n_nodes] 1 = the node is a receiver of this context (else nullptr)
     int par;                                 // which EvState::tails are current
 };
 
@@ -453,6 +455,9 @@ hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m,
 hipError_t launch_seg_scan(hipStream_t s, const TickDev &t);
 hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_draws_scan(hipStream_t s, const TickDev &t);
+hipError_t launch_draw_nodes(hipStream_t s, const TickDev &t, int32_t *dev_nodes);
+hipError_t launch_draws_apply_nodes(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, uint32_t *all_off,
+                                    const int32_t *all_nodes, uint32_t stride, int world);
 hipError_t launch_draws_batch(hipStream_t s, const ModelDev &m, const TickDev *ticks, int n, const TickDev *dev_ticks);
 hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
                               int rank);

@@ -36,7 +36,11 @@ RM_D unsigned long long ev_key(uint32_t rank, uint32_t kind, uint32_t ref)
     return ((unsigned long long)(rank + 1u) << 32) | ((unsigned long long)kind << 29) | (unsigned long long)(ref & 0x1FFFFFFFu);
 }
 RM_D void amax_key(unsigned long long *p, unsigned long long k) { (void)__hip_atomic_fetch_max(p, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-RM_D bool owned(const EvDev &e, int node) { return node >= e.own_first && node < e.own_first + e.own_count; }
+RM_D bool owned(const EvDev &e, int node)
+{
+    if (e.member) return node >= 0 && node < e.n_nodes && e.member[node] != 0;
+    return node >= e.own_first && node < e.own_first + e.own_count;
+}
 
 // ============================================================================ append
 // One evaluated tick handed to the event stage: per packet an EvPacket (event times, ladders, packet

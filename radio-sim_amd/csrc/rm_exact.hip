@@ -248,10 +248,8 @@ RM_D void self_entries_body(const NodesDev &nd, const TickDev &t)
         rm_tx_record tx{};
         if (e < n_eval) {
             tx = t.tx[t.first_eval + e];
-            if (tx.src >= nd.rx_first && tx.src < nd.rx_first + nd.n_rx) {
-                want = true;
-                pos = nd.pos_of[tx.src - nd.rx_first];
-            }
+            pos = engine_pos(nd, tx.src);
+            want = pos >= 0;
         }
         const int aidx = air_alloc(t, want, air_sub(t));
         if (want) air_link(t, aidx, pos, tx.start_us, tx.air_us, 0.0, kAirSelf);
@@ -259,8 +257,8 @@ RM_D void self_entries_body(const NodesDev &nd, const TickDev &t)
     }
     if (e >= n_eval) return;
     const int src = t.tx[t.first_eval + e].src;
-    if (src < nd.rx_first || src >= nd.rx_first + nd.n_rx) return;
-    const int pos = nd.pos_of[src - nd.rx_first];
+    const int pos = engine_pos(nd, src);
+    if (pos < 0) return;
     const uint32_t shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) & t.shard_mask;
     const uint32_t local = atomicAdd(&t.shard_count[shard * kShardStride], 1u);
     if (local >= t.seg_cap) {

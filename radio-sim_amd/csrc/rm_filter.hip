@@ -406,10 +406,8 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
         if (e < n_eval) {
             const int ai = t.first_eval + e;
             txs = (t.src_list && ai >= t.first_new) ? make_tx_record(nd, t.src_list[ai - t.first_new], t.src_start_us, t.src_air_us) : t.tx[ai];
-            if (txs.src >= nd.rx_first && txs.src < nd.rx_first + nd.n_rx) {
-                want = true;
-                pos = nd.pos_of[txs.src - nd.rx_first];
-            }
+            pos = engine_pos(nd, txs.src);
+            want = pos >= 0;
         }
         const int aidx = air_alloc(t, want, air_sub(t));
         if (want) air_link(t, aidx, pos, txs.start_us, txs.air_us, 0.0, kAirSelf);

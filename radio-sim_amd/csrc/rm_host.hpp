@@ -153,7 +153,7 @@ struct rm_context : TickSlot {
     struct GroupBox {
         double lo[3], hi[3];
     };
-    std::vector<int32_t> h_pos_of;  // node index - rx_first -> engine position (host copy of d_pos_of)
+    std::vector<int32_t> h_pos_of;  // node index - pos_first -> engine position, -1 = no receiver here (host copy of d_pos_of)
     std::vector<GroupBox> g_box;    // per group of 64: its box when the table was sorted
     std::vector<uint8_t> g_escaped; // bit 0 / 1: a receiver of this group has left the box by more than 1/8 / 1/2 of its extent
     int drifted_groups = 0, escaped_groups = 0;
@@ -193,7 +193,16 @@ struct rm_context : TickSlot {
     double org[3] = {0, 0, 0};
     double coord_bound = 0, f32_slack = 0;
 
-    int rx_first = 0, rx_count = -1; // -1 = all nodes
+    int rx_first = 0, rx_count = -1; // receiver partition by index range (rm_set_partition); -1 = all nodes
+    // receiver partition by region (rm_set_partition_spatial): region sp_part of sp_parts of the k-d split over ALL nodes;
+    // sp_parts == 0: none.  The member nodes are fixed when the partition is set / the table is uploaded: a node that moves
+    // stays with its rank (no other rank could learn that it left).
+    int sp_part = 0, sp_parts = 0;
+    std::vector<int32_t> sp_nodes;   // the region's nodes, ascending
+    DevBuf<uint8_t> d_member;        // [n] 1 = a receiver of this context (spatial partitions; the reception stage's "owned")
+    DevBuf<int32_t> d_draw_nodes;    // spatial partitions whose links draw: node index of every drawing link, packet-major
+    DevBuf<uint32_t> d_all_off;      // [world][n_new] scratch of rm_tick_finish_draws_nodes
+    DevBuf<int32_t> d_all_nodes;     // its host lists, uploaded
     uint32_t cap = 1u << 22;
 
     int64_t current_time = 0;
@@ -286,8 +295,10 @@ namespace rmh {
 // ---- rm_api_context.cpp: model, derived constants
 const char *model_name(int kind);
 bool is_sinr(const rm_context *c);
-int part_first(const rm_context *c);
-int part_count(const rm_context *c);
+int part_first(const rm_context *c); // first node index the position map covers
+int part_count(const rm_context *c); // receivers of this context
+int pos_span(const rm_context *c);   // node indices the position map covers (index partition: its nodes; spatial: all)
+bool part_spatial(const rm_context *c);
 bool frac(double p);
 bool maybe_draws(rm_context *c);
 int validate_model(const rm_model_params *p);
@@ -299,6 +310,7 @@ int build_shadow_table(rm_context *c);
 
 // ---- rm_api_nodes.cpp: the receiver table
 int rebuild_receivers(rm_context *c);
+int select_region(rm_context *c);    // the member nodes of a spatial partition from the current node table
 int patch_nodes(rm_context *c, const int32_t *nodes, int count);
 int prepare_nodes(rm_context *c);
 

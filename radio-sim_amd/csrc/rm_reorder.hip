@@ -452,7 +452,92 @@ RM_D void apply_draws_body(const TickDev &t)
 __global__ void __launch_bounds__(256) k_apply_draws(TickDev t) { apply_draws_body(t); }
 __global__ void __launch_bounds__(256) k_apply_draws_batch(const TickDev *__restrict__ ticks) { apply_draws_body(ticks[blockIdx.z]); }
 
+// ---- draws under a SPATIAL receiver partition ------------------------------------------------------------------
+// The reference visits a packet's receivers in node order (UDGMRadioMedium.java:99) and draws where :106 says so.  With
+// receivers partitioned by region the ranks' node sets interleave, so a rank cannot place its draws from the other
+// ranks' COUNTS alone: every rank also publishes, packet-major, the node index of each of its links that will draw
+// (k_draw_nodes), the lists are exchanged, and a link's place among its packet's draws is the number of listed nodes
+// below it over all ranks (a binary search per rank: every list is ascending inside a packet).
+__global__ void __launch_bounds__(256) k_draw_nodes(TickDev t, int32_t *__restrict__ dn)
+{
+    const uint32_t n = t.out_count[0];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += stride)
+        if (draw_flag(t, pos)) dn[t.draw_scan[pos]] = t.out_dst[pos];
+}
+
+// all_off[r][q] = first entry of packet q in rank r's node list = exclusive scan of all_cnt[r][.] (one workgroup per rank)
+__global__ void __launch_bounds__(1024) k_draw_offsets(const uint32_t *__restrict__ all_cnt, int n_new, uint32_t *__restrict__ all_off)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t *cnt = all_cnt + size_t(blockIdx.x) * n_new;
+    uint32_t *off = all_off + size_t(blockIdx.x) * n_new;
+    uint32_t carry = 0;
+    for (int base = 0; base < n_new; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < n_new) ? cnt[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
+        if (i < n_new) off[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_apply_draws_nodes(TickDev t, const uint32_t *__restrict__ all_cnt, const uint32_t *__restrict__ all_off,
+                    const int32_t *__restrict__ all_nodes, uint32_t stride, int world)
+{
+    const uint32_t n = t.out_count[0];
+    const int n_new = t.n_active - t.first_new;
+    const uint32_t step = gridDim.x * blockDim.x;
+    for (uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += step) {
+        const int q = t.out_pkt[pos];
+        uint8_t v = t.out_verdict[pos];
+        if (t.pkt_interference[q]) {
+            v = RM_INTERFERED; // UDGMRadioMedium.java:106: no draw once the Tx failed
+        } else if (v == 0) {
+            const double p = t.out_prob[pos];
+            if (p < 1.0) {
+                const int node = t.out_dst[pos];
+                uint32_t k = 0; // drawing links of this packet with a smaller node index, over all ranks
+                for (int r = 0; r < world; ++r) {
+                    const int32_t *lst = all_nodes + size_t(r) * stride + all_off[size_t(r) * n_new + q];
+                    uint32_t lo = 0, hi = all_cnt[size_t(r) * n_new + q];
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (lst[mid] < node) lo = mid + 1; else hi = mid;
+                    }
+                    k += lo;
+                }
+                uint64_t A, C;
+                lcg_jump_map(2ull * k, A, C);
+                uint64_t s = (A * t.pkt_rng[q] + C) & kLcgMask; // pkt_rng: where the packet's receiver draws begin (chain with rank 0)
+                v = (lcg_next_double(s) > p) ? RM_INTERFERED : RM_DELIVERED;
+            } else {
+                v = RM_DELIVERED;
+            }
+        }
+        t.out_verdict[pos] = v;
+    }
+}
+
 // ============================================================================ launchers
+
+hipError_t launch_draw_nodes(hipStream_t s, const TickDev &t, int32_t *dev_nodes)
+{
+    hipLaunchKernelGGL(k_draw_nodes, dim3(256), dim3(256), 0, s, t, dev_nodes);
+    return hipGetLastError();
+}
+
+hipError_t launch_draws_apply_nodes(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, uint32_t *all_off,
+                                    const int32_t *all_nodes, uint32_t stride, int world)
+{
+    const int n_new = t.n_active - t.first_new;
+    if (n_new > 0) hipLaunchKernelGGL(k_draw_offsets, dim3(world), dim3(1024), 0, s, all_cnt, n_new, all_off);
+    hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, 0);
+    hipLaunchKernelGGL(k_apply_draws_nodes, dim3(256), dim3(256), 0, s, t, all_cnt, all_off, all_nodes, stride, world);
+    return hipGetLastError();
+}
 
 // sorted tables only
 hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg)

@@ -368,7 +368,7 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
             const uint32_t base = s_base;
             // Node indices are unique inside a frame: a bitmap over the partition's nodes in LDS ranks all of them in
             // O(links + nodes / 32): rank(j) = bits set below j = prefix of its 256-bit block + the words before it.
-            const uint32_t n_bits = uint32_t(nd.n_rx), nw = (n_bits + 31u) >> 5, nblk = (nw + 7u) >> 3;
+            const uint32_t n_bits = uint32_t(nd.pos_span), nw = (n_bits + 31u) >> 5, nblk = (nw + 7u) >> 3;
             const bool bitmap = nw + nblk + 8u <= uint32_t(kWords);
             if (bitmap) {
                 uint32_t *const bits = s_mem, *const bpre = s_mem + ((nw + 7u) & ~7u);
@@ -524,9 +524,10 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
         if (s_nres == 0xFFFFFFFFu) break; // dropped
     }
     if (SINR && wave == 0) { // half duplex: the frame's SELF entry in its source's list (two atomics in a row: last)
-        const bool want = lane == 0 && tx.src >= nd.rx_first && tx.src < nd.rx_first + nd.n_rx;
+        const int self_pos = (lane == 0) ? engine_pos(nd, tx.src) : -1;
+        const bool want = self_pos >= 0;
         const int aidx = air_alloc(t, want, air_sub(t));
-        if (want) air_link(t, aidx, nd.pos_of[tx.src - nd.rx_first], tx.start_us, tx.air_us, 0.0, kAirSelf);
+        if (want) air_link(t, aidx, self_pos, tx.start_us, tx.air_us, 0.0, kAirSelf);
     }
 }
 
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(256) k_sinr_frames(const NodesDev nd, const Mo
         for (uint32_t c = lane; c < len; c += 64) {
             const uint32_t o = src0 + c;
             const double rssi = t.a_rssi[o];
-            const int pos = nd.pos_of[t.a_dst[o] - nd.rx_first];
+            const int pos = engine_pos(nd, t.a_dst[o]); // (a heard link's receiver is one of this partition's)
             const SinrOut so = air_sinr(m, t, pos, kAirOwnInSum, w.start_us, w.air_us, rssi);
             t.a_sinr[o] = so.sinr;
             if (so.collided) t.a_verdict[o] = uint8_t(RM_INTERFERED);
@@ -779,9 +780,10 @@ __global__ void __launch_bounds__(256) k_frames_cand(const NodesDev nd, const Mo
     flush();
     if (counted && tid == 0 && total) t.cand_tot[e - t.cnt_base] = total; // (zeroed by the tick before; one workgroup per frame)
     if (t.air.pool != nullptr && wave == 0) { // half duplex: the frame's SELF entry in its source's list (two atomics in a row: last)
-        const bool want = lane == 0 && tx.src >= nd.rx_first && tx.src < nd.rx_first + nd.n_rx;
+        const int self_pos = (lane == 0) ? engine_pos(nd, tx.src) : -1;
+        const bool want = self_pos >= 0;
         const int aidx = air_alloc(t, want, air_sub(t));
-        if (want) air_link(t, aidx, nd.pos_of[tx.src - nd.rx_first], tx.start_us, tx.air_us, 0.0, kAirSelf);
+        if (want) air_link(t, aidx, self_pos, tx.start_us, tx.air_us, 0.0, kAirSelf);
     }
 }
 

@@ -1,13 +1,20 @@
-"""Receiver-sharded multi-GPU tick: one process per GPU, receivers range-partitioned by node
-index, one RCCL all-gather of the tick's Tx records over xGMI.
+"""Receiver-sharded multi-GPU tick: one process per GPU, receivers partitioned over the ranks, one
+RCCL all-gather of the tick's Tx records over xGMI.
 
-Every rank owns the nodes [lo, hi): their receiver state lives in its HBM (sorted, boxed), and it
-is the rank that learns about their transmissions (the emulators of those nodes are attached to
-its host process).  Per tick each rank packs the frames of ITS transmitters into a fixed number of
-64-byte slots (padding slots carry src = -1), the ranks all-gather the slots, and every rank then
-sweeps the full on-air list against its own receivers.  Because the partition is by index range
-and each rank's frames are in node order, the gathered list is in canonical (node index) order;
-the heard links of rank r for packet p are exactly the [lo_r, hi_r) slice of the global list.
+Every rank owns a set of nodes: their receiver state lives in its HBM (sorted, boxed), and it is
+the rank that learns about their transmissions (the emulators of those nodes are attached to its
+host process).  Two ways to cut the node set:
+  * by node index range [lo, hi) (SURVEY.md 8e as written; `partition`): a rank's receivers lie all
+    over the area, every rank's tiles look at every frame;
+  * by REGION (`Engine.set_partition_spatial`, `owners(..., engine)`): rank r owns the r-th region of
+    the k-d split of all positions, so its filter drops the frames far from its region and the
+    per-rank work really is 1/world of the tick's -- at the price of a merge by node index, because
+    the ranks' node sets interleave.
+Per tick each rank packs the frames of ITS transmitters into a fixed number of 64-byte slots
+(padding slots carry src = -1), the ranks all-gather the slots, and every rank then sweeps the full
+on-air list against its own receivers.  The gathered order [rank][slot] is the tick's packet order;
+every rank's heard links of a packet are ascending in node index, and the global list is their
+merge by node index (with index ranges: the ranks' runs one after the other).
 
 Only plumbing here (torch.distributed tensors, numpy); the compute is Engine.tick_run_device.
 """
@@ -29,12 +36,27 @@ def owner_of(n, world, node):
     return np.searchsorted(edges, np.asarray(node, dtype=np.int64), side="right") - 1
 
 
-def slots_needed(n, world, source_lists):
-    """Smallest slot count that fits every rank's share of every tick."""
+def owners(n, world, engine=None, positions=None):
+    """int32[n]: the rank owning every node -- by index range, or by region, as Engine.set_partition_spatial(rank, world)
+    cuts the table on every rank: `engine` = any context holding the node table, or `positions` = (x, y, z) (host only)."""
+    if engine is not None:
+        return engine.partition_of_nodes(world)
+    if positions is not None:
+        from . import _lib
+        x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in positions)
+        out = np.empty(max(n, 1), dtype=np.int32)
+        _lib.check(_lib.lib().rm_region_split(n, x.ctypes.data, y.ctypes.data, z.ctypes.data, world, out.ctypes.data))
+        return out[:n]
+    return owner_of(n, world, np.arange(n)).astype(np.int32)
+
+
+def slots_needed(n, world, source_lists, owner=None):
+    """Smallest slot count that fits every rank's share of every tick (owner: owners(); default index ranges)."""
     need = 1
     for s in source_lists:
         if len(s):
-            need = max(need, int(np.bincount(owner_of(n, world, s), minlength=world).max()))
+            own = owner_of(n, world, s) if owner is None else owner[np.asarray(s)]
+            need = max(need, int(np.bincount(own, minlength=world).max()))
     return need
 
 
@@ -89,15 +111,28 @@ def drop_padding(records):
 def merge_shard_links(shards, n_slots):
     """Global packet-major heard-link list from the per-rank lists.
 
-    shards: per rank (pkt, dst, verdict, rssi, sinr) with pkt = gathered slot index; ranks in order.
-    Rank r's links of a packet all have dst in [lo_r, hi_r), so concatenating the ranks' segments
-    per packet in rank order yields ascending receiver order."""
+    shards: per rank (pkt, dst, verdict, rssi, sinr) with pkt = gathered slot index.  Every rank's links of a packet are
+    ascending in node index and no node belongs to two ranks, so the global list -- the reference's visiting order -- is
+    the merge of the ranks' lists by (packet, node index): index ranges give runs that follow each other, regions
+    interleave."""
     pkt = np.concatenate([s[0] for s in shards])
-    rank_of = np.concatenate([np.full(len(s[0]), r, dtype=np.int64) for r, s in enumerate(shards)])
-    order = np.lexsort((np.concatenate([s[1] for s in shards]), rank_of, pkt))
+    dst = np.concatenate([s[1] for s in shards])
+    order = np.lexsort((dst, pkt))
     cols = [np.concatenate([s[i] for s in shards])[order] for i in range(len(shards[0]))]
     assert cols[0].max(initial=-1) < n_slots
+    assert len(dst) == 0 or np.all((np.diff(cols[0]) > 0) | (np.diff(cols[1]) > 0)), "a receiver reported by two ranks"
     return cols
+
+
+def exchange_draw_nodes(counts, node_lists):
+    """What the second all-gather of a spatial partition's draw exchange delivers: counts [world, n_new] (uint32) and the
+    ranks' lists of drawing nodes (packet-major) -> (all_nodes [world, stride] int32, stride)."""
+    world = len(node_lists)
+    stride = max(1, max(int(c.sum()) for c in counts))
+    out = np.zeros((world, stride), dtype=np.int32)
+    for r, lst in enumerate(node_lists):
+        out[r, : len(lst)] = lst
+    return out, stride
 
 
 class ShardedTick:
@@ -110,7 +145,8 @@ class ShardedTick:
     carries no state from tick to tick.  Media with draws or an on-air list must use ONE context.
     Works with world == 1 as well (no collective), which is how the choreography is tested on one GPU."""
 
-    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True, batch=1, on_air=False):
+    def __init__(self, engines, dist, n, rank, world, slots, device, compute_streams, may_draw=True, batch=1, on_air=False,
+                 spatial=False):
         import torch
         self.torch = torch
         if not isinstance(engines, (list, tuple)):
@@ -119,9 +155,13 @@ class ShardedTick:
         self.eng = self.engines[0]
         self.dist, self.n, self.rank, self.world, self.slots = dist, n, rank, world, slots
         self.lo, self.hi = partition(n, rank, world)
+        self.spatial = spatial and world > 1
         if world > 1:
             for e in self.engines:
-                e.set_partition(self.lo, self.hi - self.lo)
+                if spatial:
+                    e.set_partition_spatial(rank, world)     # a region of the plane (the k-d split of all positions)
+                else:
+                    e.set_partition(self.lo, self.hi - self.lo)
         self.comm = torch.cuda.Stream(device=device)
         ring = len(self.engines) + 1
         # batch > 1: a stage covers `batch` ticks -- one packing launch, ONE all-gather of
@@ -193,7 +233,20 @@ class ShardedTick:
                     self.dist.all_gather_into_tensor(self.cnt_all, self.cnt_mine)
                 else:
                     self.cnt_all.copy_(self.cnt_mine, non_blocking=True)
-                eng.finish_draws(self.cnt_all.data_ptr(), self.world, self.rank)
+                if not self.spatial:
+                    eng.finish_draws(self.cnt_all.data_ptr(), self.world, self.rank)
+                else:
+                    # regions interleave in node order: the drawing links' nodes go round as well, in rows as long as the
+                    # longest rank's list (the one host read-back of this path)
+                    totals = self.cnt_all.view(self.world, n_new).sum(dim=1)
+                    stride = max(1, int(totals.max().item()))
+                    mine = torch.zeros(stride, dtype=torch.int32, device=self.all[b].device)
+                    k = int(totals[self.rank].item())
+                    if k:
+                        mine[:k].copy_(self._device_int32(eng.draw_nodes_device(), k))
+                    gathered = torch.empty(self.world * stride, dtype=torch.int32, device=mine.device)
+                    self.dist.all_gather_into_tensor(gathered, mine)
+                    eng.finish_draws_nodes(self.cnt_all.data_ptr(), gathered.data_ptr(), stride, self.world)
         self.done[b].record(stream)
         self.used[b] = True
 
@@ -227,6 +280,12 @@ class ShardedTick:
             per_tick = self.world * self.slots
             ptrs = src.data_ptr() + np.arange(nb, dtype=np.uint64) * np.uint64(per_tick * RECORD_BYTES)
             eng.batch_run_device(t_begins, t_begins + tick_us, ptrs, np.full(nb, per_tick, dtype=np.int32))
+
+    def _device_int32(self, ptr, count):
+        """`count` int32 of engine-owned device memory as a tensor (no copy)"""
+        class _Mem:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        return self.torch.as_tensor(_Mem(), device=self.comm.device)
 
     def run(self, dev_src_ptr, t_begin, t_end, air_us):
         """Unpipelined convenience: stage and sweep one tick."""

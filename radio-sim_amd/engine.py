@@ -139,6 +139,23 @@ class Engine:
     def set_partition(self, first, count):
         check(self._L.rm_set_partition(self._h, first, count))
 
+    def set_partition_spatial(self, part, n_parts):
+        """this context's receivers = region `part` of `n_parts` of the k-d split over all node positions"""
+        check(self._L.rm_set_partition_spatial(self._h, part, n_parts))
+
+    def partition_of_nodes(self, n_parts):
+        """part owning every node under set_partition_spatial(., n_parts) (int32[n])"""
+        out = np.empty(max(self.n, 1), dtype=np.int32)
+        check(self._L.rm_partition_of_nodes(self._h, n_parts, out.ctypes.data))
+        return out[: self.n]
+
+    def partition_nodes(self):
+        """node indices of this context's receivers, ascending"""
+        out = np.empty(max(self.n, 1), dtype=np.int32)
+        k = C.c_int32()
+        check(self._L.rm_partition_nodes(self._h, out.ctypes.data, len(out), C.byref(k)))
+        return out[: k.value].copy()
+
     def set_link_capacity(self, cap):
         check(self._L.rm_set_link_capacity(self._h, cap))
 
@@ -247,6 +264,22 @@ class Engine:
         else:
             a = np.ascontiguousarray(all_counts, dtype=np.uint32)
             check(self._L.rm_tick_finish_draws(self._h, a.ctypes.data, world, rank, 0))
+
+    def draw_nodes_device(self):
+        """device pointer of the node index of every link of the last tick that will draw (spatial partitions)"""
+        p = C.c_void_p()
+        check(self._L.rm_draw_nodes_device(self._h, C.byref(p)))
+        return p.value
+
+    def finish_draws_nodes(self, all_counts, all_nodes, stride, world):
+        """spatial partitions: all_counts [world, n_new] uint32 and all_nodes [world, stride] int32, host arrays or device
+        pointers (both ints)"""
+        if isinstance(all_counts, int):
+            check(self._L.rm_tick_finish_draws_nodes(self._h, C.c_void_p(all_counts), C.c_void_p(all_nodes), stride, world, 1))
+        else:
+            a = np.ascontiguousarray(all_counts, dtype=np.uint32)
+            b = np.ascontiguousarray(all_nodes, dtype=np.int32)
+            check(self._L.rm_tick_finish_draws_nodes(self._h, a.ctypes.data, b.ctypes.data, stride, world, 0))
 
     def tick(self, recs, t_begin=0, t_end=0, cap=None):
         self.tick_begin(t_begin, t_end)
@@ -427,13 +460,14 @@ class Group:
     """n engine contexts behind one caller (rm_group_*): receivers range-partitioned over the members, a tick's Tx
     records handed to every member from the host, results merged in node order."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, spatial=True):
         self._L = _lib.lib()
         devs = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
         check(self._L.rm_group_create(len(devices), devs, C.byref(h)))
         self._h = h
         self._n_new = 0
+        check(self._L.rm_group_set_partitioning(self._h, 1 if spatial else 0))   # regions of the plane / index ranges
 
     def close(self):
         if self._h:

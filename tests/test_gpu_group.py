@@ -1,6 +1,7 @@
 """Several contexts behind one caller (rm_group_*, SURVEY.md section 8e for a single-process host): receivers
-range-partitioned over the members, a tick's Tx records handed to every member from the host (no all-gather), the
-per-packet java.util.Random draw counts exchanged through the host.  On a one-GPU box every member sits on device 0;
+partitioned over the members -- by region of the plane (the default) or by node index range --, a tick's Tx records handed
+to every member from the host (no all-gather), the per-packet java.util.Random draw counts (regions: also the drawing
+links' nodes) exchanged through the host, the members' links merged by node index.  On a one-GPU box every member sits on device 0;
 the result must be what one context -- and the oracle -- gives: links, order, verdicts, Tx-failure flags and the
 generator state after every tick."""
 import numpy as np
@@ -11,17 +12,17 @@ from util import KINDS, _PARAM_MAP, assert_same, oracle_model, random_nodes, to_
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("members", [2, 3])
+@pytest.mark.parametrize("members,spatial", [(2, False), (3, False), (2, True), (3, True), (8, True)])
 @pytest.mark.parametrize("kind,params", [("udgm", {}), ("udgm", {"udgm_success_ratio_rx": 0.8}),
                                          ("logdist", {"ld_sigma_db": 4.0, "ld_seed": 5}), ("null", {}), ("udgm_const", {})])
-def test_group_equals_one_context_and_the_oracle(rsa, O, members, kind, params):
+def test_group_equals_one_context_and_the_oracle(rsa, O, members, spatial, kind, params):
     n = 3000 if kind != "null" else 400
     rng = np.random.default_rng(17)
     nd = random_nodes(O, n, 50.0 * np.sqrt(np.pi * n / 20.0), seed=17)
     if params.get("udgm_success_ratio_rx", 1.0) != 1.0:
         nd.rxprob[rng.choice(n, n // 4, replace=False)] = 0.5
         nd.txprob[rng.choice(n, n // 10, replace=False)] = 0.7
-    g = rsa.Group([0] * members)
+    g = rsa.Group([0] * members, spatial=spatial)
     one = rsa.Engine(0)
     try:
         kw = {_PARAM_MAP[k]: v for k, v in params.items()}

@@ -1,6 +1,7 @@
-"""Receiver-sharded evaluation on the GPU: two contexts with the two halves of the receivers see
-the same gathered Tx slots (padding included); their merged heard links equal the global oracle
-run.  (The all-gather itself is covered on CPU by tests/test_dist_gloo.py.)"""
+"""Receiver-sharded evaluation on the GPU: several contexts, each with its share of the receivers -- a range of node
+indices, or a REGION of the plane (rm_set_partition_spatial) -- see the same gathered Tx slots (padding included); their
+heard links, merged by node index, equal the global oracle run.  (The all-gather itself is covered on CPU by
+tests/test_dist_gloo.py.)"""
 import numpy as np
 import pytest
 
@@ -9,10 +10,30 @@ from util import to_tx_records, KINDS, _PARAM_MAP, oracle_model
 pytestmark = pytest.mark.gpu
 
 
+def owners_and_setter(rsa, D, nd, n, world, mode):
+    """(owner of every node, function that puts a context on rank r's share)"""
+    if mode == "index":
+        own = D.owners(n, world)
+        return own, lambda eng, r: eng.set_partition(*(lambda lo, hi: (lo, hi - lo))(*D.partition(n, r, world)))
+    probe = rsa.Engine(0)
+    try:
+        probe.upload_table(nd)
+        own = D.owners(n, world, probe)
+    finally:
+        probe.close()
+    return own, lambda eng, r: eng.set_partition_spatial(r, world)
+
+
+def check_members(eng, own, r, res):
+    mine = np.nonzero(own == r)[0]
+    np.testing.assert_array_equal(eng.partition_nodes(), mine)       # every rank computes the same cut for itself
+    assert res is None or res.count == 0 or np.all(own[res.dst] == r)
+
+
 @pytest.mark.parametrize("kind,params", [("udgm", {}), ("logdist", {"ld_sigma_db": 4.0, "ld_seed": 5}),
                                          ("logdist", {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 6})])
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_global(rsa, O, kind, params, world):
+@pytest.mark.parametrize("world,mode", [(2, "index"), (3, "index"), (2, "spatial"), (3, "spatial"), (8, "spatial")])
+def test_sharded_equals_global(rsa, O, kind, params, world, mode):
     from radio_sim_amd import dist as D
     n = 3001
     rng = np.random.default_rng(17)
@@ -21,12 +42,13 @@ def test_sharded_equals_global(rsa, O, kind, params, world):
     nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
     nd.channel[:] = 11 + rng.integers(0, 3, n)
     srcs = np.sort(rng.choice(n, 90, replace=False)).astype(np.int32)
-    slots = D.slots_needed(n, world, [srcs])
+    own, put = owners_and_setter(rsa, D, nd, n, world, mode)
+    assert np.bincount(own, minlength=world).min() > 0 and (mode == "index" or len(np.unique(np.diff(own))) > 2)
+    slots = D.slots_needed(n, world, [srcs], own)
     # what the all-gather would deliver: per rank `slots` records, padded with src = -1
     parts = []
     for r in range(world):
-        lo, hi = D.partition(n, r, world)
-        mine = srcs[(srcs >= lo) & (srcs < hi)]
+        mine = srcs[own[srcs] == r]
         pk = nd.packets(mine, 0, 8128)
         pk["start_us"] = rng.integers(0, 1000, len(pk))
         parts.append(D.pad_records(to_tx_records(rsa, pk), slots))
@@ -35,14 +57,13 @@ def test_sharded_equals_global(rsa, O, kind, params, world):
 
     shards = []
     for r in range(world):
-        lo, hi = D.partition(n, r, world)
         eng = rsa.Engine(0)
         try:
             eng.upload_table(nd)
             eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
-            eng.set_partition(lo, hi - lo)
+            put(eng, r)
             res = eng.tick(gathered)
-            assert res.count == 0 or (res.dst.min() >= lo and res.dst.max() < hi)
+            check_members(eng, own, r, res)
             shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
         finally:
             eng.close()
@@ -62,12 +83,13 @@ def test_sharded_equals_global(rsa, O, kind, params, world):
 
 @pytest.mark.parametrize("kind,params", [("udgm", {"udgm_success_ratio_rx": 0.7}), ("logdist", {"ld_sigma_db": 3.0, "ld_seed": 2}),
                                          ("n2n", {})])
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_probabilistic_links_follow_the_global_draw_order(rsa, O, kind, params, world):
+@pytest.mark.parametrize("world,mode", [(2, "index"), (3, "index"), (2, "spatial"), (3, "spatial"), (8, "spatial")])
+def test_sharded_probabilistic_links_follow_the_global_draw_order(rsa, O, kind, params, world, mode):
     """Receiver partitions with java.util.Random draws: every rank runs the sweep, the per-packet
     draw counts are exchanged (the all-gather), rm_tick_finish_draws places each rank's draws after
-    the lower ranks' -- verdicts, Tx-failure flags and the generator state equal the one-process
-    oracle, on every rank."""
+    the lower ranks' -- or, for regions, whose node sets interleave, among the other ranks' by the exchanged
+    lists of drawing nodes (rm_tick_finish_draws_nodes) -- verdicts, Tx-failure flags and the generator
+    state equal the one-process oracle, on every rank."""
     from radio_sim_amd import dist as D
     from util import DeviceArray
     n = 1500
@@ -80,15 +102,15 @@ def test_sharded_probabilistic_links_follow_the_global_draw_order(rsa, O, kind, 
     matrix = np.where(rng.random((n, n)) < 0.02, rng.uniform(0, 1.2, (n, n)), 0.0) if kind == "n2n" else None
     ticks = [np.sort(rng.choice(n, 70, replace=False)).astype(np.int32) for _ in range(3)]
     engines = []
+    own, put = owners_and_setter(rsa, D, nd, n, world, mode)
     try:
         for r in range(world):
-            lo, hi = D.partition(n, r, world)
             eng = rsa.Engine(0)
             eng.upload_table(nd)
             eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
             if matrix is not None:
                 eng.set_n2n_matrix(matrix)
-            eng.set_partition(lo, hi - lo)
+            put(eng, r)
             eng.seed(77)
             engines.append(eng)
         state = O.lib().orc_jrandom_seed(77)
@@ -96,7 +118,7 @@ def test_sharded_probabilistic_links_follow_the_global_draw_order(rsa, O, kind, 
         for k, srcs in enumerate(ticks):
             pk = nd.packets(srcs, 1000 * k, 8128)
             recs = to_tx_records(rsa, pk)
-            counts = []
+            counts, lists = [], []
             for eng in engines:
                 eng.tick_begin(1000 * k, 1000 * k + 1000)
                 eng.enqueue_records(recs)
@@ -106,10 +128,20 @@ def test_sharded_probabilistic_links_follow_the_global_draw_order(rsa, O, kind, 
                     eng.result_copy(len(srcs))
                 ptr, n_new = eng.draw_counts_device()
                 counts.append(DeviceArray.read(ptr, np.uint32, n_new))
+                if mode == "spatial":
+                    with pytest.raises(rsa.RadioMediumError):  # counts alone cannot place a region's draws
+                        eng.finish_draws(np.stack(counts), 1, 0)
+                    k_draw = int(counts[-1].sum())
+                    lists.append(DeviceArray.read(eng.draw_nodes_device(), np.int32, k_draw) if k_draw else np.zeros(0, np.int32))
             allc = np.stack(counts)                              # what the all-gather delivers
+            if mode == "spatial":
+                all_nodes, stride = D.exchange_draw_nodes(counts, lists)
             shards = []
             for r, eng in enumerate(engines):
-                eng.finish_draws(allc, world, r)
+                if mode == "spatial":
+                    eng.finish_draws_nodes(allc, all_nodes, stride, world)
+                else:
+                    eng.finish_draws(allc, world, r)
                 res = eng.result_copy(len(srcs))
                 shards.append((res.pkt, res.dst, res.verdict, res.rssi, res.sinr))
                 last = res
@@ -223,8 +255,8 @@ def test_small_partition_with_many_frames_over_several_ticks(rsa, O, kind, param
             eng.close()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world):
+@pytest.mark.parametrize("world,mode", [(1, "index"), (2, "index"), (3, "index"), (2, "spatial"), (3, "spatial"), (8, "spatial")])
+def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world, mode):
     """configs[4]'s sharded form: the SINR medium, frames that stay on the air over several ticks, the tick's records
     gathered in device memory (padding included) and handed to every rank's context with rm_tick_run_records_device --
     each context keeps the on-air lists of ITS receivers across the ticks.  Merged, the ranks' links equal the oracle's
@@ -241,14 +273,14 @@ def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world):
     params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 9}
     mdl = oracle_model(O, "logdist", params)
     engs = []
+    own, put = owners_and_setter(rsa, D, nd, n, world, mode)
     try:
         for r in range(world):
-            lo, hi = D.partition(n, r, world)
             e = rsa.Engine(0)
             e.upload_table(nd)
             e.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
             if world > 1:
-                e.set_partition(lo, hi - lo)
+                put(e, r)
             engs.append(e)
         onair = np.zeros(0, dtype=O.PACKET_DTYPE)
         airs = [8128, 2048, 8128, 320, 8128, 4064, 8128, 320, 2048, 8128, 8128, 320]
@@ -261,11 +293,10 @@ def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world):
                 for e in engs:
                     e.update_node(j, nd.x[j], nd.y[j], nd.z[j], nd.txpower[j], int(nd.channel[j]), 1, 1.0, 1.0)
             srcs = np.sort(rng.choice(n, 60, replace=False)).astype(np.int32)
-            slots = D.slots_needed(n, max(world, 1), [srcs])
+            slots = D.slots_needed(n, max(world, 1), [srcs], own)
             parts = []
             for r in range(world):
-                lo, hi = D.partition(n, r, world)
-                mine = srcs[(srcs >= lo) & (srcs < hi)]
+                mine = srcs[own[srcs] == r]
                 parts.append(D.pad_records(to_tx_records(rsa, nd.packets(mine, t0, air)), slots))
             gathered = np.concatenate(parts)
             valid, slot_idx = D.drop_padding(gathered)
