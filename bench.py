@@ -32,6 +32,7 @@ collective.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import copy
+import ctypes
 import json
 import os
 import sys
@@ -100,6 +101,10 @@ def parse():
     ap.add_argument("--partition", default="spatial", choices=["spatial", "index"],
                     help="several GPUs / --as-rank: a rank's receivers are a REGION of the plane (the k-d split of all positions: "
                          "its filter drops the frames far from the region; default) or a range of node indices")
+    ap.add_argument("--collective", default="auto", choices=["auto", "lib", "torch"],
+                    help="several GPUs: who runs the all-gather of Tx records -- lib: libradiomedium_hip.so itself (RCCL bound inside "
+                         "the library: pack + ncclAllGather + sweep are ONE call per batch), torch: torch.distributed around the "
+                         "engine calls (the gloo rehearsal on one GPU needs it); auto: lib with the nccl backend")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="several GPUs: strong (default) = the BASELINE config itself, receivers split over the ranks; "
                          "weak = node count grown as sqrt(GPUs) so that the link evaluations per GPU stay fixed")
@@ -393,7 +398,9 @@ def main():
     if args.inflight <= 0:
         args.inflight = 2 if world == 1 else 3
     if args.batch <= 0:
-        args.batch = 64 if world == 1 else 128
+        # several GPUs: a rank's share of a tick shrinks with the ranks, a batch's fixed costs (five launches, the collective)
+        # do not: more ticks per launch sequence
+        args.batch = 64 if world == 1 else min(512, 64 * world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world      # under a launcher the launcher's world size is the truth
@@ -477,7 +484,9 @@ def main():
             e.set_stream(st.cuda_stream)
             e.upload_table(nodes)
             e.set_model(kind, **kw)
-            e.set_link_capacity(extra.get("link_capacity", 1 << 21))
+            # (a rank's share of the links: its result slots -- up to 512 per context -- are sized for it, with a margin)
+            share = as_rank[1] if as_rank else world
+            e.set_link_capacity(max(1 << 17, extra.get("link_capacity", 1 << 21) * 2 // share) if share > 1 else extra.get("link_capacity", 1 << 21))
             engines.append(e)
             streams.append(st)
         eng, stream = engines[0], streams[0]
@@ -513,8 +522,23 @@ def main():
         # synthetic input: a pool of distinct ticks (a multiple of the batch), reused in turn by longer runs
         pool = min(ticks, -(-2112 // tps) * tps)
         sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(pool)]
+        # who runs the collective of a sharded batch: the library (one C call per batch: pack, ncclAllGather, sweep) or
+        # torch.distributed around the engine calls
+        lib_dist = batch > 1 and not stateful and ((world > 1 and args.collective != "torch" and backend == "nccl")
+                                                  or (world == 1 and args.collective == "lib" and not as_rank))
+        if lib_dist:
+            use_sharded = False
+        pad_dev, slots = None, 0
         with torch.cuda.stream(stream):
-            if not use_sharded:
+            if lib_dist or (as_rank and batch > 1 and not stateful):
+                # every rank's transmitters of every tick in a fixed number of slots (src = -1: padding)
+                slots = D.slots_needed(n, part_w, sources, own)
+                ranks = range(part_w) if as_rank else [rank]
+                pad_dev = {r: torch.from_numpy(np.stack([D.pad_sources(s[own[s] == r] if own is not None else s, slots)
+                                                         for s in sources])).to(dev) for r in ranks}
+                src_dev = torch.from_numpy(np.stack(sources)).to(dev)
+                sharded = None
+            elif not use_sharded:
                 src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
                 sharded = None
             else:
@@ -526,6 +550,18 @@ def main():
                 sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch, on_air=stateful,
                                         spatial=spatial)
         stream.synchronize()
+        if lib_dist:
+            # one communicator per context (their collectives are independent): rank 0 makes the ids, torch.distributed -- here
+            # only the out-of-band channel -- hands them round, every rank joins with ncclCommInitRank inside the library
+            for e in engines:
+                if world > 1:
+                    e.set_partition_spatial(rank, world) if spatial else e.set_partition(lo, hi - lo)
+                uid = torch.from_numpy(rsa.Engine.comm_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8))
+                if world > 1:
+                    uid = uid.to(dev)
+                    dist.broadcast(uid, src=0)
+                    uid = uid.cpu()
+                e.comm_init_rank(uid.numpy(), world, rank)
 
         links_done = [0]
         last_run = [eng, 0]     # (context, result slot) of the last tick issued
@@ -543,16 +579,55 @@ def main():
             t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
             return (t0, t0 + tick_us, ptrs, cnt, t0, air)
 
-        def run_range(k0, k1):
-            """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept"""
+        prepared = {}   # (context, source window, ticks, simulated tick) -> the step's call, its arguments converted once
+        keep_alive = []
+
+        def step_call(g, k, nb, tk):
+            """One step = one launch sequence of nb ticks on context g, as a closure that costs ONE ctypes call: what the
+            interpreter adds per step would otherwise bound a rank whose share of a batch needs less device time than the
+            argument conversion takes.  Built before the timed region (`plan_only`)."""
+            key = (g, k, nb, tk)
+            if key in prepared:
+                return prepared[key]
+            t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
+            e = engines[g]
+            if lib_dist:
+                call = e.prepared("rm_dist_batch_run_sources_device", nb, t0, t0 + tick_us, ctypes.c_void_p(pad_dev[rank][k % pool].data_ptr()),
+                                  slots, t0, W.AIR_US)
+            elif pad_dev is not None:
+                # --as-rank: what the all-gather would deliver, [rank][tick][slot], packed here once per step
+                gathered = torch.empty(part_w * nb * slots * 64, dtype=torch.uint8, device=dev)
+                for r in range(part_w):
+                    e.pack_tx_batch_device_on(streams[g].cuda_stream, pad_dev[r][k % pool].data_ptr(), nb, slots, t0, W.AIR_US,
+                                              gathered.data_ptr() + r * nb * slots * 64)
+                keep_alive.append(gathered)
+                call = e.prepared("rm_batch_run_gathered_device", nb, t0, t0 + tick_us, ctypes.c_void_p(gathered.data_ptr()), part_w, slots)
+            else:
+                ptrs = np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64)
+                call = e.prepared("rm_batch_run_sources_device", nb, t0, t0 + tick_us, ptrs, np.full(nb, t_per_tick, dtype=np.int32), t0,
+                                  np.full(nb, W.AIR_US, dtype=np.int64))
+            prepared[key] = call
+            return call
+
+        def run_range(k0, k1, plan_only=False):
+            """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept.  plan_only: build the steps'
+            calls without issuing them (and leave the clock where it is)"""
             with torch.cuda.stream(stream if sharded is None else sharded.comm):
                 if sharded is None and batch > 1:
+                    rr = ctx_rr[0]
                     for k in range(k0, k1, batch):
-                        a = batch_args(k, min(batch, k1 - k), clock[0] + k - k0)
-                        g = ctx_rr[0] % inflight       # contexts take the batches in turn
-                        ctx_rr[0] += 1
-                        engines[g].batch_run_sources_device(*a)
-                        last_run[:] = [engines[g], min(batch, k1 - k) - 1]
+                        nb = min(batch, k1 - k)
+                        g = rr % inflight       # contexts take the batches in turn
+                        rr += 1
+                        call = step_call(g, k, nb, clock[0] + k - k0)
+                        if not plan_only:
+                            call()
+                            last_run[:] = [engines[g], nb - 1]
+                    if plan_only:
+                        return
+                    ctx_rr[0] = rr
+                elif plan_only:
+                    return
                 elif batch > 1:
                     # sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream
                     for k in range(k0, k1, batch):
@@ -594,6 +669,7 @@ def main():
             run_range(0, min(ticks, batch))
         fence()
         run_range(0, warm_ticks)
+        run_range(warm_ticks, ticks, plan_only=True)     # the timed steps' calls, arguments converted
         fence()
         # HIP-event brackets on every n-th launch sequence of every context; few launches: all of them
         launches = args.steps
@@ -642,7 +718,7 @@ def main():
             inc, reb = engines[0].air_list_stats()
             desc += (" -- %.2e link evaluations per tick (new frames only: the frames still on the air stay in the on-air lists on the "
                      "device; %d ticks added to the lists, %d rebuilt them)" % (value * elapsed / timed_ticks, inc, reb))
-        if (inflight > 1 or batch > 1) and sharded is None:
+        if (inflight > 1 or batch > 1) and sharded is None and world == 1:
             # the same ticks again, one at a time on one context
             fence()
             t_seq = time.perf_counter()

@@ -287,13 +287,18 @@ int rm_sync(rm_context *ctx);
  * lie inside its tick -- verified on the device, a violation is reported as RM_ERR_STATE when
  * the tick's result is read.  Anything else of it, and partitioned contexts whose links draw,
  * are refused with RM_ERR_STATE -- run those one tick at a time. */
-#define RM_MAX_BATCH 128
+#define RM_MAX_BATCH 512
 int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,
                                 const int64_t *t_end_us, const int32_t *const *dev_src /* device int32[n_src[b]] each */,
                                 const int32_t *n_src, const int64_t *start_us, const int64_t *air_us);
 /* the same with the ticks' Tx records given (device memory, canonical order), as rm_tick_run_device */
 int rm_batch_run_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                         const rm_tx_record *const *dev_new, const int32_t *n_new);
+/* the same with the ticks' records where an all-gather of per-rank blocks left them: dev_gathered[rank][tick][slot]
+ * (`world` ranks, each packed `slots` records per tick for all n_ticks ticks, src = -1 = padding); tick b's packets are
+ * the world * slots records dev_gathered[(r * n_ticks + b) * slots + s], rank-major -- no transposition in between */
+int rm_batch_run_gathered_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                 const rm_tx_record *dev_gathered, int32_t world, int32_t slots);
 int rm_batch_result_device(rm_context *ctx, int32_t slot, rm_device_result *out);
 int rm_batch_result_count(rm_context *ctx, int32_t slot, uint32_t *count, uint32_t *dropped); /* synchronises */
 int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,
@@ -370,6 +375,44 @@ int rm_group_enqueue_tx_records(rm_group *g, const rm_tx_record *recs, int32_t n
 /* as rm_tick_flush, over all members */
 int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
                         uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset);
+
+/* the device-resident tick of a group: dev_src[r] = `slots` source node indices in member r's device memory (the
+ * transmitters member r owns, -1 = padding).  Every member packs the Tx records of its transmitters from its resident node
+ * state, the members all-gather the packed blocks -- RCCL (ncclAllGather over a communicator from ncclCommInitAll, xGMI
+ * between the devices; rm_group_uses_rccl tells) when every member has its own device, copies on the device when several
+ * members share one -- and every member sweeps the gathered frames (packet order: member after member, slot after slot)
+ * against its receivers.  Nothing crosses PCIe; rm_group_result_copy merges the members' heard links like
+ * rm_group_tick_flush, rm_group_context(g, r) + rm_result_device leave them on the devices. */
+int rm_group_tick_run_sources_device(rm_group *g, int64_t t_begin_us, int64_t t_end_us, const int32_t *const *dev_src,
+                                     int32_t slots, int64_t start_us, int64_t air_us);
+int rm_group_result_copy(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                         uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset);
+int rm_group_uses_rccl(rm_group *g); /* 1: the members exchange over RCCL, 0: copies on one device, < 0: error */
+
+/* ---- RCCL inside the library: one process per GPU without a framework in between -------------------------------
+ * The receiver-sharded tick of SURVEY.md section 8e as ONE call per rank: pack the Tx records of the transmitters this
+ * rank owns (from its resident node state), ncclAllGather of the packed blocks over xGMI, sweep of the gathered frames
+ * against this rank's receivers (rm_set_partition_spatial / rm_set_partition), all on the context's stream.  RCCL is
+ * bound at run time (dlopen: a process that already holds an RCCL shares it; RM_RCCL_LIB names another file);
+ * rm_comm_available() tells whether it could be.  Rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks by
+ * whatever means the host has (a file, a socket, MPI, torch.distributed's store); every rank then calls rm_comm_init_rank
+ * on its context.  A context without a communicator is a world of one (no collective).
+ *   dev_src: n_ticks rows of `slots` source node indices (this rank's transmitters of every tick, -1 = padding).
+ *   Packet order of a tick: rank after rank, slot after slot (world * slots packets, padding included).
+ * rm_dist_tick_run_sources_device also exchanges the java.util.Random draw counts (regions: the drawing links' nodes)
+ * over the same communicator and finishes the draws; it is the form for media with draws and for the SINR medium with
+ * frames that stay on the air.  Results: rm_result_* / rm_batch_result_*, as after rm_tick_run_device / rm_batch_run_device. */
+#define RM_COMM_ID_BYTES 128
+int rm_comm_available(void);
+int rm_comm_get_unique_id(uint8_t *id /* [RM_COMM_ID_BYTES] */);
+int rm_comm_init_rank(rm_context *ctx, const uint8_t *id, int32_t world, int32_t rank);
+int rm_comm_destroy(rm_context *ctx);
+int rm_comm_world(const rm_context *ctx);
+int rm_comm_rank(const rm_context *ctx);
+int rm_dist_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                     const int32_t *dev_src, int32_t slots, const int64_t *start_us, int64_t air_us);
+int rm_dist_tick_run_sources_device(rm_context *ctx, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t slots,
+                                    int64_t start_us, int64_t air_us);
 
 /* ---- reception stage: what the reference does with the verdicts, on the device -------------------------
  * SURVEY.md section 8f-1 / 8f-3.  After rm_events_enable every evaluated tick (rm_transmit, rm_tick_flush*,

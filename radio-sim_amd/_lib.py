@@ -16,7 +16,7 @@ _SO = os.environ.get("RM_LIBRARY") or os.path.join(_CSRC, "libradiomedium_hip.so
 MODEL_NULL, MODEL_UDGM, MODEL_UDGM_CONST, MODEL_N2N, MODEL_LOGDIST = range(5)
 UNHEARD, INTERFERED, DELIVERED = 0, 1, 2
 LD_SINR = 1
-MAX_BATCH = 128
+MAX_BATCH = 512
 RM_OK, RM_ERR_INVALID, RM_ERR_NO_DEVICE, RM_ERR_HIP, RM_ERR_CAPACITY, RM_ERR_STATE = 0, -1, -2, -3, -4, -5
 
 
@@ -152,6 +152,20 @@ SIGNATURES = {
     "rm_batch_run_sources_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
     "rm_batch_run_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rm_batch_run_gathered_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "rm_comm_available": (C.c_int, []),
+    "rm_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "rm_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "rm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rm_comm_world": (C.c_int, [C.c_void_p]),
+    "rm_comm_rank": (C.c_int, [C.c_void_p]),
+    "rm_dist_batch_run_sources_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                   C.c_int64]),
+    "rm_dist_tick_run_sources_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),
+    "rm_group_tick_run_sources_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),
+    "rm_group_result_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
+    "rm_group_uses_rccl": (C.c_int, [C.c_void_p]),
     "rm_batch_result_device": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(DeviceResult)]),
     "rm_batch_result_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rm_batch_result_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1,7 +1,28 @@
 // rm_api_batch.cpp -- C ABI: several independent ticks per launch sequence (rm_batch_*), their results in one host-mapped block.
 #include "rm_host.hpp"
 
+#include <chrono>
+
 using namespace rmh;
+
+// RM_HOST_TIMING=1: what a batch call costs the host, phase by phase (stderr, every 16th call): the issue cost bounds a
+// rank whose share of a tick needs less device time than the call takes (multi-GPU)
+namespace {
+struct HostClock {
+    bool on = std::getenv("RM_HOST_TIMING") != nullptr;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    long calls = 0;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void report()
+    {
+        if (!on || ++calls % 16) return;
+        std::fprintf(stderr, "rm host timing per batch call [us]: checks %.1f  plan %.1f  descriptors %.1f  launches %.1f  total %.1f\n",
+                     acc[0] / 16, acc[1] / 16, acc[2] / 16, acc[3] / 16, (acc[0] + acc[1] + acc[2] + acc[3]) / 16);
+        for (double &a : acc) a = 0;
+    }
+};
+HostClock g_clock;
+} // namespace
 
 namespace rmh {
 
@@ -17,7 +38,10 @@ TickSlot *slot_of(rm_context *c, int32_t slot)
 // the launch sequence of n prepared ticks in four launches (sorted table, fp32 frame, no SINR)
 static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n)
 {
-    rm::TickDev ticks[RM_MAX_BATCH];
+    const double tc0 = g_clock.on ? HostClock::now() : 0;
+    static thread_local std::vector<rm::TickDev> ticks_v; // (RM_MAX_BATCH descriptors: not on the stack)
+    ticks_v.resize(size_t(n));
+    rm::TickDev *const ticks = ticks_v.data();
     for (int b = 0; b < n; ++b) ticks[b] = plans[b].t;
     // the descriptors go to device memory (k_store_ticks, ordered on the stream after the previous
     // batch's kernels, which read the same array)
@@ -41,6 +65,12 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     const rm::NodesDev nd = nodes_dev(c);
     const rm::LaunchCfg &cfg = plans[0].cfg;
     hipStream_t s = c->stream;
+    const double tc1 = g_clock.on ? HostClock::now() : 0;
+    if (g_clock.on) g_clock.acc[2] += tc1 - tc0;
+    struct Done { // (every return below has issued what it will issue)
+        double t0;
+        ~Done() { if (g_clock.on) g_clock.acc[3] += HostClock::now() - t0; }
+    } done{tc1};
     const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
     rm_context::Sample *smp = nullptr;
     if (sample) {
@@ -104,17 +134,25 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
     return RM_OK;
 }
 
-static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
-                     const int32_t *const *dev_src, const rm_tx_record *const *dev_new, const int32_t *n_per,
-                     const int64_t *start_us, const int64_t *air_us)
+// gathered: the ticks' records as an all-gather of per-rank blocks [rank][tick][slot] left them (gather_world ranks,
+// gather_slots records per rank and tick); every tick then has gather_world * gather_slots frames
+int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                   const int32_t *const *dev_src, const rm_tx_record *const *dev_new, const int32_t *n_per,
+                   const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world, int gather_slots)
 {
-    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || !n_per || (!dev_src && !dev_new) ||
-        (dev_src && (!start_us || !air_us)))
+    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || (!n_per && !gathered) ||
+        (!dev_src && !dev_new && !gathered) || (dev_src && (!start_us || !air_us)) || (gathered && (gather_world < 1 || gather_slots < 1)))
         return fail(RM_ERR_INVALID, "bad arguments");
+    static thread_local std::vector<int32_t> n_gath;
+    if (gathered) {
+        n_gath.assign(size_t(n_ticks), gather_world * gather_slots);
+        n_per = n_gath.data();
+    }
     for (int b = 0; b < n_ticks; ++b)
-        if (n_per[b] < 0 || (n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
+        if (n_per[b] < 0 || (!gathered && n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
             (dev_src && air_us[b] < 0))
             return fail(RM_ERR_INVALID, "bad arguments");
+    const double th0 = g_clock.on ? HostClock::now() : 0;
     RM_HIP(hipSetDevice(c->device));
     const bool sinr = is_sinr(c);
     if (sinr) {
@@ -149,8 +187,13 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
                                   "tick at a time");
     while (c->extra_slots.size() + 1 < size_t(n_ticks)) c->extra_slots.emplace_back(new TickSlot());
     const rm::PlanKnobs knobs = rm::read_plan_knobs(); // once for the whole batch
-    TickSlot *slots[RM_MAX_BATCH];
-    TickPlan plans[RM_MAX_BATCH];
+    const double th1 = g_clock.on ? HostClock::now() : 0;
+    static thread_local std::vector<TickSlot *> slots_v;
+    static thread_local std::vector<TickPlan> plans_v;
+    slots_v.resize(size_t(n_ticks));
+    plans_v.resize(size_t(n_ticks));
+    TickSlot **const slots = slots_v.data();
+    TickPlan *const plans = plans_v.data();
     bool batched = true;
     for (int b = 0; b < n_ticks; ++b) {
         TickSlot &ts = *slot_of(c, b);
@@ -161,7 +204,7 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
             // one-tick-at-a-time path lives
             RM_HIP(c->d_air.ensure(std::max<size_t>(size_t(n_per[b]), 1 << 16)));
             tx = c->d_air.p;
-        } else if (dev_src) {
+        } else if (dev_src || gathered) {
             RM_HIP(ts.d_tx.ensure(std::max(n_per[b], 1)));
             tx = ts.d_tx.p;
         } else {
@@ -172,6 +215,14 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
                                          dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0, kAirNone, 0, &knobs);
         c->dev_records_from_caller = false;
         RM_TRY(rc_prep);
+        if (gathered) {
+            rm::TickDev &t = plans[b].t;
+            t.gather_src = gathered + size_t(b) * size_t(gather_slots);
+            t.gather_slots = gather_slots;
+            t.gather_stride = n_ticks * gather_slots;
+            t.tx_build = ts.d_tx.p;
+            ts.last = t;
+        }
         batched = batched && !plans[b].empty && rm::batch_eligible(plans[b].t, plans[b].cfg, model_dev(c)) &&
                   plans[b].t.rpt == plans[0].t.rpt;
     }
@@ -187,10 +238,19 @@ static int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, 
         c->air_tail = size_t(n_per[n_ticks - 1]);
         c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1], 0u});
     }
+    if (gathered && !batched)
+        return fail(RM_ERR_STATE, "gathered records go through the batched kernels only (sorted receiver table, fp32 frame, "
+                                  "at most 8192 frames per tick, no empty tick)");
     if (batched) {
         if (sinr)
             for (int b = 0; b < n_ticks; ++b) plans[b].t.reset_heads = 1;
-        return launch_batch(c, slots, plans, n_ticks);
+        if (g_clock.on) {
+            g_clock.acc[0] += th1 - th0;
+            g_clock.acc[1] += HostClock::now() - th1;
+        }
+        const int rc = launch_batch(c, slots, plans, n_ticks);
+        g_clock.report();
+        return rc;
     }
     // configurations the batched kernels do not cover (fp64 frame, unsorted table, very many frames,
     // empty ticks): the same ticks, one launch sequence each
@@ -213,6 +273,13 @@ int rm_batch_run_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_u
 {
     if (!dev_new) return fail(RM_ERR_INVALID, "bad arguments");
     return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, dev_new, n_new, nullptr, nullptr);
+}
+
+int rm_batch_run_gathered_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                 const rm_tx_record *dev_gathered, int32_t world, int32_t slots)
+{
+    if (!dev_gathered) return fail(RM_ERR_INVALID, "bad arguments");
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, nullptr, nullptr, dev_gathered, world, slots);
 }
 
 int rm_batch_result_device(rm_context *c, int32_t slot, rm_device_result *out)

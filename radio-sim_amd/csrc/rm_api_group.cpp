@@ -11,6 +11,10 @@ struct rm_group {
     bool spatial = true;          // members own regions of the plane (rm_set_partition_spatial), not ranges of node indices
     std::vector<uint32_t> counts; // [world][n_new] per-packet draw counts
     std::vector<int32_t> draw_nodes; // [world][stride] spatial partitions: the node of every drawing link, packet-major
+    // the device-resident tick (rm_group_tick_run_sources_device): one RCCL communicator over the members' devices
+    // (ncclCommInitAll), or -- several members on ONE device, where RCCL has no second rank to offer -- copies on that device
+    int comm_state = 0;           // 0 not tried, 1 RCCL, 2 device copies
+    std::vector<hipEvent_t> packed; // per member: its frames are packed (device-copy mode)
 };
 
 extern "C" {
@@ -36,6 +40,7 @@ int rm_group_create(int32_t n_members, const int32_t *device_ordinals, rm_group 
 void rm_group_destroy(rm_group *g)
 {
     if (!g) return;
+    for (hipEvent_t e : g->packed) (void)hipEventDestroy(e);
     for (rm_context *c : g->m) rm_destroy(c);
     delete g;
 }
@@ -122,16 +127,10 @@ int rm_group_enqueue_tx_records(rm_group *g, const rm_tx_record *recs, int32_t n
     return RM_OK;
 }
 
-int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
-                        uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+// probabilistic links: the members' per-packet draw counts (regions: and the drawing links' nodes), through the host
+static int group_finish_draws(rm_group *g, int n_new)
 {
-    if (!g || !g->in_tick) return fail(RM_ERR_STATE, "rm_group_tick_flush without rm_group_tick_begin");
-    g->in_tick = false;
     const int world = int(g->m.size());
-    const int n_new = g->n_new;
-    // every member's launches are enqueued before anything is waited for
-    for (rm_context *c : g->m) RM_TRY(tick_run_host(c));
-    // probabilistic links: the members' per-packet draw counts, through the host
     bool pending = false;
     for (rm_context *c : g->m) pending = pending || c->draws_pending;
     if (pending) {
@@ -174,7 +173,14 @@ int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdic
                 RM_TRY(rm_tick_finish_draws_nodes(g->m[size_t(r)], g->counts.data(), g->draw_nodes.data(), uint32_t(stride), world, 0));
         }
     }
-    // the members' results in their pinned blocks, then merged packet by packet in member (= node) order
+    return RM_OK;
+}
+
+// the members' results in their pinned blocks, merged packet by packet by node index
+static int group_merge(rm_group *g, int n_new, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                       uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    const int world = int(g->m.size());
     std::vector<rm_host_result> res(static_cast<size_t>(world));
     int first_error = RM_OK;
     std::string first_msg;
@@ -239,6 +245,102 @@ int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdic
     if (first_error != RM_OK) return fail(first_error, first_msg);
     if (total > cap) return fail(RM_ERR_CAPACITY, "caller buffers too small for the heard links");
     return RM_OK;
+}
+
+// How the members exchange their packed frames: RCCL when every member has its own device (or there is one member),
+// copies on the device when several members share one (a test configuration: RCCL admits one rank per device).
+static int group_comm(rm_group *g)
+{
+    if (g->comm_state) return RM_OK;
+    const int world = int(g->m.size());
+    bool distinct = true;
+    for (int i = 0; i < world; ++i)
+        for (int k = i + 1; k < world; ++k) distinct = distinct && g->m[size_t(i)]->device != g->m[size_t(k)]->device;
+    static const bool no_rccl = std::getenv("RM_GROUP_NO_RCCL") != nullptr;
+    if (distinct && !no_rccl) {
+        RM_TRY(group_comm_init(g->m.data(), world, nullptr));
+        g->comm_state = 1;
+        return RM_OK;
+    }
+    for (int i = 0; i < world; ++i) {
+        hipEvent_t e = nullptr;
+        RM_HIP(hipSetDevice(g->m[size_t(i)]->device));
+        RM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g->packed.push_back(e);
+        g->m[size_t(i)]->comm_world = world; // (no communicator: the group moves the blocks itself)
+        g->m[size_t(i)]->comm_rank = i;
+    }
+    g->comm_state = 2;
+    return RM_OK;
+}
+
+int rm_group_uses_rccl(rm_group *g)
+{
+    if (!g) return fail(RM_ERR_INVALID, "group is NULL");
+    RM_TRY(group_comm(g));
+    return g->comm_state == 1 ? 1 : 0;
+}
+
+int rm_group_tick_run_sources_device(rm_group *g, int64_t t_begin_us, int64_t t_end_us, const int32_t *const *dev_src, int32_t slots,
+                                     int64_t start_us, int64_t air_us)
+{
+    if (!g || !dev_src || slots < 1 || air_us < 0) return fail(RM_ERR_INVALID, "bad arguments");
+    RM_TRY(group_comm(g));
+    const int world = int(g->m.size());
+    const size_t block = size_t(slots) * sizeof(rm_tx_record);
+    std::vector<const void *> mine(static_cast<size_t>(world));
+    std::vector<void *> all(static_cast<size_t>(world));
+    // every member packs the frames of ITS transmitters (dev_src[r]: `slots` node indices on member r's device, -1 = padding)
+    for (int r = 0; r < world; ++r) {
+        rm_context *c = g->m[size_t(r)];
+        if (!dev_src[r]) return fail(RM_ERR_INVALID, "bad arguments");
+        RM_HIP(hipSetDevice(c->device));
+        RM_HIP(c->d_dist_mine.ensure(size_t(slots)));
+        RM_HIP(c->d_dist_all.ensure(size_t(slots) * size_t(world)));
+        RM_HIP(rm::launch_pack_tx(c->stream, nodes_dev(c), dev_src[r], slots, start_us, air_us, c->d_dist_mine.p));
+        mine[size_t(r)] = c->d_dist_mine.p;
+        all[size_t(r)] = c->d_dist_all.p;
+        if (g->comm_state == 2) RM_HIP(hipEventRecord(g->packed[size_t(r)], c->stream));
+    }
+    if (g->comm_state == 1) {
+        RM_TRY(group_all_gather(g->m.data(), world, mine.data(), all.data(), block)); // RCCL over xGMI, all ranks in one group call
+    } else {
+        for (int q = 0; q < world; ++q) {
+            rm_context *c = g->m[size_t(q)];
+            RM_HIP(hipSetDevice(c->device));
+            for (int r = 0; r < world; ++r) {
+                if (r != q) RM_HIP(hipStreamWaitEvent(c->stream, g->packed[size_t(r)], 0));
+                RM_HIP(hipMemcpyAsync(static_cast<char *>(all[size_t(q)]) + size_t(r) * block, mine[size_t(r)], block,
+                                      hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+    }
+    // every member sweeps the gathered frames against its receivers; all launches are enqueued before anything is waited for
+    for (rm_context *c : g->m)
+        RM_TRY(rm_tick_run_records_device(c, t_begin_us, t_end_us, c->d_dist_all.p, slots * world, start_us + air_us));
+    g->n_new = slots * world;
+    return group_finish_draws(g, g->n_new);
+}
+
+int rm_group_result_copy(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                         uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!g) return fail(RM_ERR_INVALID, "group is NULL");
+    for (rm_context *c : g->m)
+        if (!c->have_result) return fail(RM_ERR_STATE, "no evaluated tick");
+    return group_merge(g, g->n_new, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
+}
+
+int rm_group_tick_flush(rm_group *g, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr, uint32_t cap,
+                        uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
+{
+    if (!g || !g->in_tick) return fail(RM_ERR_STATE, "rm_group_tick_flush without rm_group_tick_begin");
+    g->in_tick = false;
+    const int n_new = g->n_new;
+    // every member's launches are enqueued before anything is waited for
+    for (rm_context *c : g->m) RM_TRY(tick_run_host(c));
+    RM_TRY(group_finish_draws(g, n_new));
+    return group_merge(g, n_new, pkt, dst, verdict, rssi, sinr, cap, count, pkt_interference, pkt_offset);
 }
 
 } // extern "C"

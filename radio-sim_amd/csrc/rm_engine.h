@@ -172,6 +172,11 @@ struct TickDev {
     const int32_t *src_list;
     rm_tx_record *tx_build;
     int64_t src_start_us, src_air_us;
+    // gather mode (a tick of a receiver-sharded batch): the frames are read from the buffer an all-gather of per-rank blocks
+    // [rank][tick][slot] left them in -- frame i of this tick is gather_src[(i / gather_slots) * gather_stride + i % gather_slots]
+    // -- and copied to tx_build (== tx) by k_tick_prep, where every later stage finds them in the tick's packet order
+    const rm_tx_record *gather_src;
+    int gather_slots, gather_stride;
     int n_active;
     int first_new;          // frames [first_new, n_active) get verdicts
     int first_eval;         // frames [first_eval, n_active) are swept by the filter kernel

@@ -115,16 +115,17 @@ k_pack_tx(NodesDev nd, const int32_t *src, int n, int64_t start_us, int64_t air_
     out[i] = r;
 }
 
+constexpr int kPackChunk = 128; // ticks per k_pack_tx_batch launch: their start times travel in the kernel arguments (1 KB)
 struct PackStarts {
-    int64_t start_us[kMaxBatch];
+    int64_t start_us[kPackChunk];
 };
 
 __global__ void __launch_bounds__(256)
-k_pack_tx_batch(NodesDev nd, const int32_t *src, int n, PackStarts st, int64_t air_us, rm_tx_record *out)
+k_pack_tx_batch(NodesDev nd, const int32_t *src, int n, PackStarts st, int64_t air_us, rm_tx_record *out, int tick0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const size_t o = size_t(blockIdx.y) * n + i;
+    const size_t o = size_t(tick0 + blockIdx.y) * n + i;
     const rm_tx_record r = make_tx_record(nd, src[o], st.start_us[blockIdx.y], air_us);
     out[o] = r;
 }
@@ -417,6 +418,9 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     rm_tx_record tx;
     if (t.src_list && abs_i >= t.first_new) {
         tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
+        t.tx_build[abs_i] = tx;
+    } else if (t.gather_src) { // (batches only: first_eval == first_new == 0)
+        tx = t.gather_src[size_t(abs_i / t.gather_slots) * size_t(t.gather_stride) + size_t(abs_i % t.gather_slots)];
         t.tx_build[abs_i] = tx;
     } else {
         tx = t.tx[abs_i];
@@ -748,9 +752,12 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
 {
     if (n <= 0 || n_ticks <= 0) return hipSuccess;
     if (n_ticks > kMaxBatch) return hipErrorInvalidValue;
-    PackStarts st{};
-    for (int b = 0; b < n_ticks; ++b) st.start_us[b] = start_us[b];
-    hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), n_ticks), dim3(256), 0, s, nd, dev_src, n, st, air_us, out);
+    for (int b0 = 0; b0 < n_ticks; b0 += kPackChunk) {
+        const int nb = min(kPackChunk, n_ticks - b0);
+        PackStarts st{};
+        for (int b = 0; b < nb; ++b) st.start_us[b] = start_us[b0 + b];
+        hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), nb), dim3(256), 0, s, nd, dev_src, n, st, air_us, out, b0);
+    }
     return hipGetLastError();
 }
 

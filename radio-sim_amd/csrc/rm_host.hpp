@@ -203,6 +203,11 @@ struct rm_context : TickSlot {
     DevBuf<int32_t> d_draw_nodes;    // spatial partitions whose links draw: node index of every drawing link, packet-major
     DevBuf<uint32_t> d_all_off;      // [world][n_new] scratch of rm_tick_finish_draws_nodes
     DevBuf<int32_t> d_all_nodes;     // its host lists, uploaded
+    // RCCL inside the library (rm_comm_*, rm_dist_*; rm_api_comm.cpp): this context's rank of a communicator
+    void *comm = nullptr;            // ncclComm_t
+    bool comm_owned = false;
+    int comm_world = 1, comm_rank = 0;
+    DevBuf<rm_tx_record> d_dist_mine, d_dist_all; // this rank's packed frames / the gathered blocks [rank][tick][slot]
     uint32_t cap = 1u << 22;
 
     int64_t current_time = 0;
@@ -373,7 +378,16 @@ int tick_run_host(rm_context *c);
 int result_device(rm_context *c, TickSlot &ts, rm_device_result *out);
 int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *dropped);
 
+// ---- rm_api_comm.cpp
+int comm_all_gather(rm_context *c, const void *mine, void *all, size_t bytes);
+int comm_finish_draws(rm_context *c);
+int group_comm_init(rm_context *const *members, int n, void **comms_out);
+int group_all_gather(rm_context *const *members, int n, const void *const *mine, void *const *all, size_t bytes);
+
 // ---- rm_api_batch.cpp
 TickSlot *slot_of(rm_context *c, int32_t slot);
+int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
+              const rm_tx_record *const *dev_new, const int32_t *n_per, const int64_t *start_us, const int64_t *air_us,
+              const rm_tx_record *gathered = nullptr, int gather_world = 0, int gather_slots = 0);
 
 } // namespace rmh

@@ -332,6 +332,60 @@ class Engine:
         assert len(tb) == len(te) == len(cnt) == n
         check(self._L.rm_batch_run_device(self._h, n, tb.ctypes.data, te.ctypes.data, ptrs.ctypes.data, cnt.ctypes.data))
 
+    def batch_run_gathered_device(self, t_begin, t_end, dev_gathered_ptr, world, slots):
+        """the ticks' records where an all-gather of per-rank blocks left them: [rank][tick][slot]"""
+        tb = np.ascontiguousarray(t_begin, dtype=np.int64)
+        te = np.ascontiguousarray(t_end, dtype=np.int64)
+        check(self._L.rm_batch_run_gathered_device(self._h, len(tb), tb.ctypes.data, te.ctypes.data, C.c_void_p(dev_gathered_ptr),
+                                                   world, slots))
+
+    def prepared(self, name, *args):
+        """A call with its arguments converted once: `name` is an entry point that takes the context first; numpy arrays are
+        passed by address (and kept alive by the closure).  The returned function costs one ctypes call -- what a host
+        loop that issues the same shape of call thousands of times wants (bench.py's timed region)."""
+        fn = getattr(self._L, name)
+        keep = [np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a for a in args]
+        conv = [C.c_void_p(a.ctypes.data) if isinstance(a, np.ndarray) else a for a in keep]
+        h = self._h
+
+        def call(_fn=fn, _h=h, _conv=tuple(conv), _keep=keep):
+            rc = _fn(_h, *_conv)
+            if rc != 0:
+                check(rc)
+        return call
+
+    # -- RCCL inside the library (rm_comm_*, rm_dist_*)
+    @staticmethod
+    def comm_available():
+        return bool(_lib.lib().rm_comm_available())
+
+    @staticmethod
+    def comm_unique_id():
+        buf = np.zeros(128, dtype=np.uint8)
+        check(_lib.lib().rm_comm_get_unique_id(buf.ctypes.data))
+        return buf
+
+    def comm_init_rank(self, unique_id, world, rank):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        check(self._L.rm_comm_init_rank(self._h, uid.ctypes.data, world, rank))
+
+    def comm_destroy(self):
+        check(self._L.rm_comm_destroy(self._h))
+
+    def dist_batch_run_sources_device(self, t_begin, t_end, dev_src_ptr, slots, start_us, air_us):
+        """one batch of a receiver-sharded run: pack this rank's transmitters (rows of `slots` node indices), RCCL
+        all-gather, sweep -- one call"""
+        tb = np.ascontiguousarray(t_begin, dtype=np.int64)
+        te = np.ascontiguousarray(t_end, dtype=np.int64)
+        st = np.ascontiguousarray(start_us, dtype=np.int64)
+        check(self._L.rm_dist_batch_run_sources_device(self._h, len(tb), tb.ctypes.data, te.ctypes.data, C.c_void_p(dev_src_ptr),
+                                                       slots, st.ctypes.data, int(air_us)))
+
+    def dist_tick_run_sources_device(self, t_begin, t_end, dev_src_ptr, slots, start_us, air_us):
+        check(self._L.rm_dist_tick_run_sources_device(self._h, int(t_begin), int(t_end), C.c_void_p(dev_src_ptr), slots,
+                                                      int(start_us), int(air_us)))
+
     def batch_result_device(self, slot):
         r = DeviceResult()
         check(self._L.rm_batch_result_device(self._h, slot, C.byref(r)))
@@ -511,6 +565,35 @@ class Group:
                       arr(nd.txprob, np.float64), arr(nd.int_id, np.int32)]
         check(self._L.rm_group_nodes_upload(self._h, nd.n, *[a.ctypes.data for a in self._keep]))
         self._n = nd.n
+
+    def uses_rccl(self):
+        rc = self._L.rm_group_uses_rccl(self._h)
+        if rc < 0:
+            check(rc)
+        return bool(rc)
+
+    def tick_run_sources_device(self, t_begin, t_end, dev_src_ptrs, slots, start_us, air_us):
+        """the device-resident tick: dev_src_ptrs[r] = `slots` source indices in member r's device memory"""
+        ptrs = (C.c_void_p * len(dev_src_ptrs))(*[int(p) for p in dev_src_ptrs])
+        check(self._L.rm_group_tick_run_sources_device(self._h, int(t_begin), int(t_end), ptrs, slots, int(start_us), int(air_us)))
+        self._n_new = slots * len(dev_src_ptrs)
+
+    def result_copy(self, cap=None):
+        n_new = self._n_new
+        if cap is None:
+            cap = max(1, n_new) * max(1, self._n)
+        pkt = np.empty(cap, dtype=np.int32)
+        dst = np.empty(cap, dtype=np.int32)
+        verdict = np.empty(cap, dtype=np.uint8)
+        rssi = np.empty(cap, dtype=np.float64)
+        sinr = np.empty(cap, dtype=np.float64)
+        pint = np.zeros(max(1, n_new), dtype=np.uint8)
+        poff = np.zeros(n_new + 1, dtype=np.uint32)
+        cnt = C.c_uint32(0)
+        check(self._L.rm_group_result_copy(self._h, pkt.ctypes.data, dst.ctypes.data, verdict.ctypes.data, rssi.ctypes.data,
+                                           sinr.ctypes.data, cap, C.byref(cnt), pint.ctypes.data, poff.ctypes.data))
+        k = cnt.value
+        return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
 
     def tick(self, recs, t_begin=0, t_end=0, cap=None):
         recs = np.ascontiguousarray(recs, dtype=TX_RECORD_DTYPE)
