@@ -105,6 +105,9 @@ def parse():
                     help="several GPUs: who runs the all-gather of Tx records -- lib: libradiomedium_hip.so itself (RCCL bound inside "
                          "the library: pack + ncclAllGather + sweep are ONE call per batch), torch: torch.distributed around the "
                          "engine calls (the gloo rehearsal on one GPU needs it); auto: lib with the nccl backend")
+    ap.add_argument("--host-cull", type=float, default=0.0, metavar="METRES",
+                    help="experiment (--as-rank): hand the rank only the frames within METRES of its region's bounding box, as if "
+                         "the frame list had been compacted already -- what rank-level frame culling can buy at most")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="several GPUs: strong (default) = the BASELINE config itself, receivers split over the ranks; "
                          "weak = node count grown as sqrt(GPUs) so that the link evaluations per GPU stay fixed")
@@ -396,11 +399,11 @@ def main():
     if os.environ.get("RM_BENCH_DRY_RUN") == "1":
         return dry_run(args, rank, world, result_fd)
     if args.inflight <= 0:
-        args.inflight = 2 if world == 1 else 3
+        args.inflight = 3
     if args.batch <= 0:
         # several GPUs: a rank's share of a tick shrinks with the ranks, a batch's fixed costs (five launches, the collective)
         # do not: more ticks per launch sequence
-        args.batch = 64 if world == 1 else min(512, 64 * world)
+        args.batch = 128 if world == 1 else min(512, 64 * world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world      # under a launcher the launcher's world size is the truth
@@ -532,11 +535,18 @@ def main():
         with torch.cuda.stream(stream):
             if lib_dist or (as_rank and batch > 1 and not stateful):
                 # every rank's transmitters of every tick in a fixed number of slots (src = -1: padding)
+                src_dev = torch.from_numpy(np.stack(sources)).to(dev)
+                if as_rank and args.host_cull > 0:
+                    mine = eng.partition_nodes()
+                    bx0, bx1, by0, by1 = nodes.x[mine].min(), nodes.x[mine].max(), nodes.y[mine].min(), nodes.y[mine].max()
+                    m = args.host_cull
+                    sources = [s[(nodes.x[s] >= bx0 - m) & (nodes.x[s] <= bx1 + m) & (nodes.y[s] >= by0 - m) & (nodes.y[s] <= by1 + m)]
+                               for s in sources]
+                    desc += " -- HOST-CULLED frames (experiment): %.0f of %d per tick" % (np.mean([len(s) for s in sources]), t_per_tick)
                 slots = D.slots_needed(n, part_w, sources, own)
                 ranks = range(part_w) if as_rank else [rank]
                 pad_dev = {r: torch.from_numpy(np.stack([D.pad_sources(s[own[s] == r] if own is not None else s, slots)
                                                          for s in sources])).to(dev) for r in ranks}
-                src_dev = torch.from_numpy(np.stack(sources)).to(dev)
                 sharded = None
             elif not use_sharded:
                 src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32

@@ -186,7 +186,8 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         return fail(RM_ERR_STATE, "a receiver partition whose links draw needs rm_tick_finish_draws per tick: run it one "
                                   "tick at a time");
     while (c->extra_slots.size() + 1 < size_t(n_ticks)) c->extra_slots.emplace_back(new TickSlot());
-    const rm::PlanKnobs knobs = rm::read_plan_knobs(); // once for the whole batch
+    rm::PlanKnobs knobs = rm::read_plan_knobs(); // once for the whole batch
+    knobs.batch_ticks = n_ticks;
     const double th1 = g_clock.on ? HostClock::now() : 0;
     static thread_local std::vector<TickSlot *> slots_v;
     static thread_local std::vector<TickPlan> plans_v;

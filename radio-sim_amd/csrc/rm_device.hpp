@@ -280,6 +280,7 @@ RM_D uint32_t block_scan_counts(const uint32_t *cnt, int n, uint32_t *s_off, uin
         run += cnt[i];
     }
     if (pub && threadIdx.x == 0) pub[n] = total;
+    if (threadIdx.x == 0) s_off[n] = total; // (a consumer takes a frame's count as the difference of two offsets)
     if (vmax_out) {
         for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), d)));
         *vmax_out = vmax;
@@ -334,6 +335,7 @@ RM_D uint32_t small_scan(const SmallCounts<PER> &c, int n, uint32_t *s_off, uint
         run += c.v[k];
     }
     if (pub && threadIdx.x == 0) pub[n] = total;
+    if (threadIdx.x == 0) s_off[n] = total;
     if (vmax_out) {
         uint32_t vmax = 0;
 #pragma unroll

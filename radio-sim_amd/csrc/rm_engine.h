@@ -424,6 +424,7 @@ struct PlanKnobs {
     int filter;          // 0 = automatic, kFilterGrid + 1 / kFilterWg + 1 = forced
     int wg_rpt;          // 0 = automatic
     bool no_shadow_table;
+    int batch_ticks;     // ticks of the batch being planned (0: a lone tick): a batch brings its own parallelism
 };
 PlanKnobs read_plan_knobs();
 int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg, const PlanKnobs &knobs);

@@ -766,7 +766,7 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
 //  kFilterWg:   k_tick_prep + k_filter_wg, two-level cull inside one workgroup per 4*rpt groups.
 PlanKnobs read_plan_knobs()
 {
-    PlanKnobs k{0, 0, false};
+    PlanKnobs k{0, 0, false, 0};
     if (const char *e = getenv("RM_FILTER")) {
         if (!strcmp(e, "grid")) k.filter = kFilterGrid + 1;
         else if (!strcmp(e, "wg")) k.filter = kFilterWg + 1;
@@ -795,7 +795,8 @@ int plan_filter(TickDev &t, const LaunchCfg &cfg, bool want_wg, const PlanKnobs 
         if (mode == kFilterWg) {
             // batches bring their own parallelism (workgroups x ticks): the coarse tiling halves the frame x
             // workgroup-box tests of phase A twice over; a lone tick needs the workgroups
-            int rpt = (t.n_rx > 400000 || (want_wg && t.n_rx >= 16384)) ? 4 : 1;
+            // (a receiver partition's few tiles per tick are enough when the batch has hundreds of ticks: 13 workgroups x 256)
+            int rpt = (t.n_rx > 400000 || (want_wg && (t.n_rx >= 16384 || long(t.n_rx) * knobs.batch_ticks >= (1L << 20)))) ? 4 : 1;
             if (knobs.wg_rpt) rpt = knobs.wg_rpt;
             t.rpt = rpt;
             t.n_slabs = cdiv(t.n_rx, 64 * t.rpt);
