@@ -9,9 +9,15 @@ RM_COMMIT=<id> stamps the commit the counters were collected for into the JSON (
 issue time.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md), so
 issue time on the whole chip = 4 * count / 1024 SIMDs / 2.4 GHz (tools/clockprobe.hip: 2.4 GHz held).
 
-bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes
-(MI355X_MICROARCH.md section HBM), both counters are in KiB.  Kernels are grouped into the stages
-bench.py brackets with HIP events; the JSON is what bench.py reads for roofline.traffic.
+bytes = (factor * FETCH_SIZE + WRITE_SIZE) * 1024, both counters in KiB.  On gfx950 FETCH_SIZE counts the 128-byte
+requests of a wide coalesced stream at 64 bytes (MI355X_MICROARCH.md section HBM: double it) -- and "other access widths
+are uncalibrated", so the factor of every stage comes from profiles/fetch_calibration.json (tools/fetch_calib.hip under
+the same counter): 2.0 for the streaming stages (k_filter: 16-byte pre-filter records; k_reorder: runs of a frame's
+records; k_self_entries), 1.0 for the gather stages (k_exact, k_sinr: aligned 32- and 64-byte records at scattered
+places move one 64-byte request each, which is what the counter reports).  The one-launch tick (k_tick_frames) streams
+the near groups' records and gathers the candidates' in one kernel: both readings are written (min = factor 1, the
+headline figure = factor 2, an upper bound).  Kernels are grouped into the stages bench.py brackets with HIP events; the
+JSON is what bench.py reads for roofline.traffic.
 """
 import collections
 import csv
@@ -23,6 +29,20 @@ import sys
 STAGE = (("k_tick_frames", "k_tick_frames"), ("k_frames_cand", "k_filter"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
          ("k_reorder", "k_reorder"), ("k_self_entries", "k_self_entries"), ("k_sinr", "k_sinr"),
          ("k_cell_off", "k_cell_off+k_slot_scan"), ("k_slot_scan", "k_cell_off+k_slot_scan"), ("k_finalize", "k_finalize"))
+
+
+# access pattern of a stage's reads -> calibration entry (profiles/fetch_calibration.json)
+PATTERN = {"k_filter": "stream16", "k_reorder": "runs8", "k_self_entries": "stream4", "k_exact": "gather32", "k_sinr": "gather32",
+           "k_finalize": "gather32", "k_cell_off+k_slot_scan": "stream4", "k_tick_frames": "stream16"}
+
+
+def fetch_factor(stage):
+    try:
+        cal = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "fetch_calibration.json")))
+        pat = PATTERN.get(stage, "stream16")
+        return max(1.0, float(cal["patterns"][pat]["factor"])), pat, cal.get("commit", "unrecorded")
+    except (OSError, ValueError, KeyError):
+        return 2.0, "uncalibrated (the guide's factor for wide streams)", "none"
 
 
 def short(name):
@@ -60,7 +80,12 @@ def main():
         f = sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [0])))
         w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
         n = max(len(fetch.get(k, [])), len(write.get(k, [])))
-        rows.append((k, n, f, w, int((2 * f + w) * 1024)))
+        fac = 2.0
+        for prefix, stage in STAGE:
+            if k.startswith(prefix):
+                fac = fetch_factor(stage)[0]
+                break
+        rows.append((k, n, f, w, fac, int((fac * f + w) * 1024)))
         if n > 8:   # per-tick kernels only (set-up kernels run once)
             for prefix, stage in STAGE:
                 if k.startswith(prefix):
@@ -68,22 +93,26 @@ def main():
                     stages[stage][1] += w
                     break
     with open(out_csv, "w") as fh:
-        fh.write("kernel,dispatches,FETCH_SIZE_KB_avg_raw,WRITE_SIZE_KB_avg,hbm_bytes_per_launch_corrected\n")
+        fh.write("kernel,dispatches,FETCH_SIZE_KB_avg_raw,WRITE_SIZE_KB_avg,fetch_factor,hbm_bytes_per_launch_corrected\n")
         for r in rows:
-            fh.write("%s,%d,%.1f,%.1f,%d\n" % r)
+            fh.write("%s,%d,%.1f,%.1f,%.2f,%d\n" % r)
     try:
         out = json.load(open(out_json))
     except (OSError, ValueError):
         out = {}
     src = ("%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --inflight 1, %s ticks per "
-           "launch), (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads half of a wide "
-           "coalesced stream)" % (os.path.relpath(out_csv), tpl))
+           "launch), (factor*FETCH_SIZE + WRITE_SIZE)*1024, factor per access pattern from profiles/fetch_calibration.json"
+           % (os.path.relpath(out_csv), tpl))
     out[workload] = {"ticks_per_launch": int(tpl), "commit": os.environ.get("RM_COMMIT", "unrecorded")}
     for stage, (f, w) in stages.items():
         if (stage == "k_tick_frames") != (int(tpl) == 1):
             continue   # the one-launch tick belongs to the ticks_per_launch = 1 passes (the batch runs contain bench.py's sequential leg)
-        out[workload][stage] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_size_kb_raw": round(f, 1),
-                                "write_size_kb": round(w, 1), "source": src}
+        fac, pat, cal_commit = fetch_factor(stage)
+        out[workload][stage] = {"hbm_bytes_per_launch": int((fac * f + w) * 1024), "fetch_size_kb_raw": round(f, 1),
+                                "write_size_kb": round(w, 1), "fetch_factor": fac, "fetch_pattern": pat,
+                                "calibration_commit": cal_commit, "source": src}
+        if stage == "k_tick_frames":   # streams and gathers in one kernel: the other reading as well
+            out[workload][stage]["hbm_bytes_per_launch_min"] = int((f + w) * 1024)
     for stage, (quad, n_inst) in valu_stage.items():
         if stage in out[workload]:
             out[workload][stage]["valu_issue_us_per_launch"] = round(4.0 * quad / 1024.0 / 2400.0, 2)
