@@ -755,6 +755,8 @@ def main():
                 ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload + "_tick", {})
                 if args.nodes == 0 and "k_tick_frames" in ent:
                     rl["traffic"] = ent["k_tick_frames"]["hbm_bytes_per_launch"]
+                    rl["traffic_min"] = ent["k_tick_frames"].get("hbm_bytes_per_launch_min")   # (the kernel both streams and gathers: fetch factor 2 / 1)
+                    rl["from_profile_file"] = True
                     rl["valu_issue_us_per_tick"] = ent["k_tick_frames"].get("valu_issue_us_per_launch")
                     rl["traffic_source"] = ent["k_tick_frames"]["source"] + " (commit %s)" % ent.get("commit", "unrecorded")
             except (OSError, ValueError):
@@ -794,33 +796,40 @@ def main():
                 stages[k] = {"us": us, "algorithmic_bytes": b,
                              "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
                              "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
+            # roofline.achieved as the contract defines it: SURVEY.md 8(d)'s bytes of everything one launch processes
+            # (N_loc*37 + T*56 + H*25 per tick, times the ticks of the launch) over the dominant kernel's average duration,
+            # measured here with HIP events on the stream the kernel is launched on
             dom_bytes = stage_bytes.get(dominant, b_step)
-            achieved = dom_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
+            achieved = b_step / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
+            step_s = elapsed / args.steps
+            # What the PMC passes say (profiles/pmc_traffic.json: collected by tools/collect_profiles.sh at the commit named
+            # in the file, NOT in this run -- every such number is marked from_profile_file): HBM bytes per launch of the
+            # dominant stage, and the vector-issue time of all stages' instructions, whose share of the driver-timed step
+            # is the chip's VALU-issue utilisation -- the resource that binds these integer / fp32 / fp64 sweeps.
             traffic = None
             valu = None
-            bound = "hbm"
-            pmc_note = "no PMC pass on file for this workload"
+            pmc_note = "no PMC pass on file for this workload and launch shape"
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 wl = pmc.get(args.workload, {})
                 if batch == 1 and wl.get("ticks_per_launch", 1) != 1:
                     wl = pmc.get(args.workload + "_tick", {})   # the one-launch tick has its own counter passes
                 ent = wl.get(dominant) or (wl.get("k_tick_frames") if dominant == "k_filter" else None)
-                if ent and world == 1 and wl.get("ticks_per_launch", 1) == batch and args.nodes == 0:
-                    traffic = ent["hbm_bytes_per_launch"]
-                    pmc_note = ent["source"] + " (commit %s)" % wl.get("commit", "unrecorded")
-                    if "valu_issue_us_per_launch" in ent and kern_avg_s > 0:
-                        # vector-issue time of the stage's instructions on the whole chip (PMC, one context) over the
-                        # stage's duration here: the binding resource of the sweep
-                        share = ent["valu_issue_us_per_launch"] / (kern_avg_s * 1e6)
-                        valu = {"issue_us_per_launch": ent["valu_issue_us_per_launch"], "frac": share,
-                                "instructions_per_launch": ent.get("valu_instructions_per_launch"),
-                                "source": "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU pass of tools/collect_profiles.sh (profiles/pmc_traffic.json)"}
-                        if share > achieved / HBM_PEAK_GBS:
-                            bound = "valu"
-            except (OSError, ValueError):
+                tpl = wl.get("ticks_per_launch", 1)
+                if ent and world == 1 and not as_rank and args.nodes == 0:
+                    scale = batch / float(tpl)          # the counters are per launch of `tpl` ticks; per tick they do not depend on it
+                    traffic = int(ent["hbm_bytes_per_launch"] * scale)
+                    pmc_note = ent["source"] + " (commit %s; per launch of %d ticks, scaled to %d)" % (wl.get("commit", "unrecorded"), tpl, batch)
+                    issue = {k: v["valu_issue_us_per_launch"] * scale for k, v in wl.items()
+                             if isinstance(v, dict) and "valu_issue_us_per_launch" in v}
+                    if issue:
+                        valu = {"from_profile_file": True, "commit": wl.get("commit", "unrecorded"),
+                                "stage_issue_us_per_launch": issue, "sum_us_per_launch": sum(issue.values()),
+                                "chip_utilisation": sum(issue.values()) / (step_s * 1e6),
+                                "what": "SQ_ACTIVE_INST_VALU (quad-cycles over 1024 SIMDs at 2.4 GHz) of every stage of one launch sequence, "
+                                        "summed, over THIS run's driver-timed step: the share of the chip's vector issue slots the step uses"}
+            except (OSError, ValueError, KeyError, TypeError):
                 pass
-            step_s = elapsed / args.steps
             out = {
                 "metric": baseline_metric(),
                 "value": value,
@@ -841,19 +850,21 @@ def main():
                            "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
                            "sharding": ("receivers partitioned over %d ranks (%s), RCCL all-gather of Tx records per batch of ticks"
                                         % (world, "regions of the k-d order" if spatial else "node index ranges")) if world > 1 else "none"},
-                "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": (valu["frac"] if (bound == "valu" and valu) else achieved / HBM_PEAK_GBS),
-                             "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_profile_file": traffic is not None,
+                             "traffic_source": pmc_note,
                              "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
-                             "algorithmic_bytes_per_launch": dom_bytes, "traffic_source": pmc_note,
-                             "stages": stages, "event_bracket_us": bracket_us, "valu": valu,
+                             "algorithmic_bytes_per_launch": b_step,
+                             "algorithmic_bytes_per_tick": "N_loc*37 + T*56 + H*25 = %d" % (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC),
+                             "stages": stages, "event_bracket_us": bracket_us, "valu_issue": valu,
                              "whole_step": {"algorithmic_bytes": b_step, "ms_per_step": step_s * 1e3,
                                             "achieved": b_step / step_s / 1e9, "frac": b_step / step_s / 1e9 / HBM_PEAK_GBS,
                                             "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step"},
-                             "note": "`frac` is the fraction of the BINDING resource: with bound = valu the share of the dominant "
-                                     "kernel's time its vector instructions need to issue (hbm_frac: the same kernel's own "
-                                     "algorithmic bytes against 8 TB/s); one launch sweeps `ticks_per_launch` ticks; durations are "
-                                     "HIP-event brackets on the context's stream while the other contexts' launches share the device"},
+                             "note": "achieved = SURVEY.md 8(d) bytes of one launch (ticks_per_launch ticks) / the dominant kernel's average "
+                                     "duration (HIP events on the context's stream over the timed region, the other contexts' launches sharing "
+                                     "the device; the empty-bracket cost subtracted); frac = achieved / 8 TB/s.  The sweep is bound by vector "
+                                     "issue slots, not by HBM (SURVEY.md 8d: a small HBM fraction by construction): valu_issue.chip_utilisation; "
+                                     "stages[*] price every stage with its own bytes"},
             }
             if sequential is not None:
                 out["sequential_ticks"] = sequential
