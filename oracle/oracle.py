@@ -89,6 +89,9 @@ def lib():
                                C.c_void_p, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p]
+        L.orc_tick_mt.restype = C.c_int64
+        L.orc_tick_mt.argtypes = [C.POINTER(Model), C.POINTER(Nodes), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_count_links.restype = C.c_int64
         L.orc_count_links.argtypes = [C.POINTER(Model), C.POINTER(Nodes), C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.POINTER(C.c_int64)]
@@ -345,6 +348,33 @@ def tick(mdl, nodes, active, first_new=0, rng_state=0, cap=None):
     k = min(cnt, cap)
     return TickResult(cnt, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], pdraw[:n_new],
                       st.value)
+
+
+def tick_mt(mdl, nodes, active, first_new=0, threads=0, cap=None):
+    """The pass over `threads` threads (0: all the box offers) -- only for ticks in which no java.util.Random draw happens
+    (raises otherwise): the packets are then independent.  Same result object as tick(); rng_state / pkt_draws are 0."""
+    L = lib()
+    active = np.ascontiguousarray(np.atleast_1d(active), dtype=PACKET_DTYPE)
+    n_active = len(active)
+    n_new = n_active - first_new
+    ns = nodes.as_struct()
+    if cap is None:
+        cap = max(1, n_new) * max(1, nodes.n)
+    pkt = np.empty(cap, dtype=np.int32)
+    dst = np.empty(cap, dtype=np.int32)
+    verdict = np.empty(cap, dtype=np.uint8)
+    rssi = np.empty(cap, dtype=np.float64)
+    sinr = np.empty(cap, dtype=np.float64)
+    pint = np.zeros(max(1, n_new), dtype=np.uint8)
+    cnt = L.orc_tick_mt(C.byref(mdl), C.byref(ns), active.ctypes.data, n_active, first_new, threads or L.orc_max_threads(),
+                        pkt.ctypes.data, dst.ctypes.data, verdict.ctypes.data, rssi.ctypes.data, sinr.ctypes.data, cap,
+                        pint.ctypes.data)
+    if cnt == -2:
+        raise ValueError("this tick consumes java.util.Random draws: only the serial pass (tick) is the reference's")
+    if cnt < 0:
+        raise MemoryError("orc_tick_mt")
+    k = min(cnt, cap)
+    return TickResult(cnt, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], np.zeros(max(1, n_new), dtype=np.int32)[:n_new], 0)
 
 
 def count_links(mdl, nodes, active, first_new=0, threads=1):

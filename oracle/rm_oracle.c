@@ -371,17 +371,15 @@ static int logdist_collided(const orc_model_t *m, const orc_nodes_t *nd, const o
     return half_duplex || !(sinr >= m->ld_capture_db);
 }
 
-int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_state,
-                 const orc_packet_t *active, int32_t n_active, int32_t first_new,
-                 int32_t *out_pkt, int32_t *out_dst, uint8_t *out_verdict,
-                 double *out_rssi, double *out_sinr, int64_t cap,
-                 uint8_t *pkt_interference, int32_t *pkt_draws)
+/* One packet of the pass: the body of the reference's transmit() (UDGMRadioMedium.java:83-117 and siblings) for the
+ * active frame `pi`.  rs == NULL: the caller evaluates packets out of order (orc_tick_mt), which is only the reference's
+ * result when no java.util.Random draw happens -- a draw that would be needed sets *need_draw instead. */
+static void packet_pass(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rs, int *need_draw,
+                        const orc_packet_t *active, int32_t n_active, int32_t first_new, int32_t pi, sink_t *sp,
+                        uint8_t *pkt_interference, int32_t *pkt_draws)
 {
-    sink_t s = { out_pkt, out_dst, out_verdict, out_rssi, out_sinr, cap, 0 };
-    uint64_t local_state = 0;
-    uint64_t *rs = rng_state ? rng_state : &local_state;
-
-    for (int32_t pi = first_new; pi < n_active; pi++) {
+    sink_t s = *sp;
+    {
         const orc_packet_t *p = &active[pi];
         int32_t rel = pi - first_new;
         int draws = 0;
@@ -394,7 +392,8 @@ int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_stat
                 interference = 1;
             } else if (txSuccess < 1.0) {
                 draws++;
-                if (orc_jrandom_next_double(rs) > txSuccess) interference = 1;
+                if (!rs) *need_draw = 1;
+                else if (orc_jrandom_next_double(rs) > txSuccess) interference = 1;
             }
         }
         double pkt_rssi = p->txpower; /* UDGMRadioMedium.java:95 etc.: rssi = packet txpower */
@@ -422,7 +421,8 @@ int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_stat
                     int failed = interference;
                     if (!failed && rxSuccess < 1.0) {
                         draws++;
-                        failed = orc_jrandom_next_double(rs) > rxSuccess;
+                        if (!rs) *need_draw = 1;
+                        else failed = orc_jrandom_next_double(rs) > rxSuccess;
                     }
                     emit(&s, rel, j, failed ? ORC_INTERFERED : ORC_DELIVERED, pkt_rssi, 0.0);
                 }
@@ -441,7 +441,8 @@ int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_stat
                 int failed = interference || collided;
                 if (!failed && rx < 1.0) {
                     draws++;
-                    failed = orc_jrandom_next_double(rs) > rx;
+                    if (!rs) *need_draw = 1;
+                    else failed = orc_jrandom_next_double(rs) > rx;
                 }
                 emit(&s, rel, j, failed ? ORC_INTERFERED : ORC_DELIVERED, rssi, sinr);
                 break;
@@ -453,7 +454,84 @@ int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_stat
         if (pkt_interference) pkt_interference[rel] = (uint8_t)interference;
         if (pkt_draws) pkt_draws[rel] = draws;
     }
+    *sp = s;
+}
+
+int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_state,
+                 const orc_packet_t *active, int32_t n_active, int32_t first_new,
+                 int32_t *out_pkt, int32_t *out_dst, uint8_t *out_verdict,
+                 double *out_rssi, double *out_sinr, int64_t cap,
+                 uint8_t *pkt_interference, int32_t *pkt_draws)
+{
+    sink_t s = { out_pkt, out_dst, out_verdict, out_rssi, out_sinr, cap, 0 };
+    uint64_t local_state = 0;
+    uint64_t *rs = rng_state ? rng_state : &local_state;
+    int unused = 0;
+    /* packets in arrival order, one after the other: the shared generator chains them */
+    for (int32_t pi = first_new; pi < n_active; pi++)
+        packet_pass(m, nd, rs, &unused, active, n_active, first_new, pi, &s, pkt_interference, pkt_draws);
     return s.n;
+}
+
+/* The same pass with the packets spread over `threads` threads, for ticks in which NO java.util.Random draw happens (every
+ * probability that is looked at is 0 or 1): the packets are then independent of each other -- the only thing that chains them
+ * in the reference is the shared generator -- and their links are written packet by packet in arrival order all the same.
+ * Returns the number of heard links, or -2 if a draw would have been needed (the result is then not the reference's: use
+ * orc_tick).  Full-size parity checks (tests/test_gpu_fullsize.py) need it: a whole configs[3] tick is 25 s on one thread. */
+int64_t orc_tick_mt(const orc_model_t *m, const orc_nodes_t *nd, const orc_packet_t *active, int32_t n_active, int32_t first_new,
+                    int32_t threads, int32_t *out_pkt, int32_t *out_dst, uint8_t *out_verdict, double *out_rssi, double *out_sinr,
+                    int64_t cap, uint8_t *pkt_interference)
+{
+    const int32_t n_new = n_active - first_new;
+    if (n_new <= 0) return 0;
+    if (threads < 1) threads = 1;
+    /* every packet into its own small buffer (a frame is heard by tens to hundreds of receivers; grown when needed) */
+    typedef struct { int32_t *dst; uint8_t *verdict; double *rssi, *sinr; int64_t n, cap; } part_t;
+    part_t *parts = (part_t *)calloc((size_t)n_new, sizeof(part_t));
+    int need_draw = 0, oom = 0;
+    if (!parts) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+    for (int32_t rel = 0; rel < n_new; rel++) {
+        part_t *pt = &parts[rel];
+        int my_draw = 0;
+        for (int64_t want = 256;; want = pt->n + 64) {
+            free(pt->dst); free(pt->verdict); free(pt->rssi); free(pt->sinr);
+            pt->cap = want;
+            pt->dst = (int32_t *)malloc((size_t)want * 4);
+            pt->verdict = (uint8_t *)malloc((size_t)want);
+            pt->rssi = (double *)malloc((size_t)want * 8);
+            pt->sinr = (double *)malloc((size_t)want * 8);
+            if (!pt->dst || !pt->verdict || !pt->rssi || !pt->sinr) { oom = 1; break; }
+            sink_t s = { NULL, pt->dst, pt->verdict, pt->rssi, pt->sinr, want, 0 };
+            packet_pass(m, nd, NULL, &my_draw, active, n_active, first_new, first_new + rel, &s, pkt_interference, NULL);
+            pt->n = s.n;
+            if (s.n <= want) break; /* everything fitted; otherwise once more with room for all of it */
+        }
+        if (my_draw) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            need_draw = 1;
+        }
+    }
+    int64_t total = 0;
+    for (int32_t rel = 0; rel < n_new; rel++) {
+        const part_t *pt = &parts[rel];
+        for (int64_t i = 0; i < pt->n && !oom; i++, total++) {
+            if (total >= cap) continue;
+            if (out_pkt) out_pkt[total] = rel;
+            if (out_dst) out_dst[total] = pt->dst[i];
+            if (out_verdict) out_verdict[total] = pt->verdict[i];
+            if (out_rssi) out_rssi[total] = pt->rssi[i];
+            if (out_sinr) out_sinr[total] = pt->sinr[i];
+        }
+        free(pt->dst); free(pt->verdict); free(pt->rssi); free(pt->sinr);
+    }
+    free(parts);
+    if (oom) return -1;
+    return need_draw ? -2 : total;
 }
 
 int32_t orc_max_threads(void)

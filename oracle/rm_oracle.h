@@ -123,6 +123,10 @@ int64_t orc_tick(const orc_model_t *m, const orc_nodes_t *nd, uint64_t *rng_stat
                  int32_t *out_pkt, int32_t *out_dst, uint8_t *out_verdict,
                  double *out_rssi, double *out_sinr, int64_t cap,
                  uint8_t *pkt_interference, int32_t *pkt_draws);
+/* the same pass over `threads` threads, for ticks without java.util.Random draws (returns -2 if one would be needed) */
+int64_t orc_tick_mt(const orc_model_t *m, const orc_nodes_t *nd, const orc_packet_t *active, int32_t n_active, int32_t first_new,
+                    int32_t threads, int32_t *out_pkt, int32_t *out_dst, uint8_t *out_verdict, double *out_rssi, double *out_sinr,
+                    int64_t cap, uint8_t *pkt_interference);
 
 /*
  * CPU-baseline leg: verdict pass without record storage, `threads` OpenMP threads over

@@ -136,10 +136,24 @@ def _sampled_sinr_check(O, mdl, nd, onair_all, new_all, gpu, sample):
     return cpu
 
 
+def _whole_tick_check(O, mdl, nd, onair, new, gpu, what):
+    """EVERY new frame of the tick against the oracle (threaded: the tick draws nothing), with every frame on the air as
+    a potential interferer."""
+    cpu = O.tick_mt(mdl, nd, np.concatenate([onair, new]), first_new=len(onair), cap=1 << 22)
+    assert cpu.count == gpu.count > 1000, (what, cpu.count, gpu.count)
+    np.testing.assert_array_equal(gpu.pkt, cpu.pkt, err_msg=what)
+    np.testing.assert_array_equal(gpu.dst, cpu.dst, err_msg=what)
+    np.testing.assert_array_equal(gpu.verdict, cpu.verdict, err_msg=what)
+    np.testing.assert_array_equal(gpu.rssi, cpu.rssi, err_msg=what)
+    np.testing.assert_array_equal(gpu.sinr, cpu.sinr, err_msg=what)
+    np.testing.assert_array_equal(gpu.pkt_interference, cpu.pkt_interference, err_msg=what)
+    return cpu
+
+
 def test_c4_16_channels_sinr_capture_full_size(rsa, O):
     """BASELINE configs[3]: 100k nodes, 5% concurrent Tx (5000 frames), 16 channels, co-channel SINR
-    capture -- one full tick on the GPU; 24 sampled frames checked against the oracle with all 5000
-    frames as potential interferers."""
+    capture -- one full tick on the GPU, ALL 5000 frames checked against the oracle (every link's rssi, sinr and verdict
+    bit for bit) with all 5000 frames as potential interferers."""
     from radio_sim_amd import workload as W
     n, t = 100_000, 5000
     src_nd = W.make_nodes(n, 4, channels16=True)
@@ -159,8 +173,8 @@ def test_c4_16_channels_sinr_capture_full_size(rsa, O):
         assert gpu.count > 10_000          # 5000 frames x ~44 neighbours / 16 channels
         frac_interfered = (gpu.verdict == rsa.INTERFERED).mean()
         assert 0.005 < frac_interfered < 0.6
-        sample = np.arange(0, t, 50)
-        _sampled_sinr_check(O, oracle_model(O, "logdist", params), nd, pk[:0], pk, gpu, sample)
+        cpu = _whole_tick_check(O, oracle_model(O, "logdist", params), nd, pk[:0], pk, gpu, "configs[3], whole tick")
+        assert (cpu.verdict == O.INTERFERED).sum() > 100
     finally:
         eng.close()
 
@@ -202,8 +216,10 @@ def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
 
 def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
     """BASELINE configs[4] at its steady state: 8128 us frames over 1000 us ticks keep ~9 ticks of frames (8000-9000)
-    on the air.  Eleven ticks; the last two are checked -- 17 sampled new frames each against the oracle with
-    the FULL on-air list (8000+ frames) as interferers."""
+    on the air; the per-receiver interferer lists live on the device from tick to tick.  WHOLE ticks -- all 1000 new
+    frames, every link -- are checked against the oracle with the FULL on-air list (8000+ frames) as interferers: a tick
+    of the steady state, the tick in which a node has moved (every list is rebuilt from the frames on the air) and the
+    one after it, and a tick after the lists' entry ring has wrapped round (link capacity 2^23: ~0.45 M entries per tick)."""
     from radio_sim_amd import workload as W
     n, t = 1_000_000, 1000
     src_nd = W.make_nodes(n, 5)
@@ -214,12 +230,19 @@ def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
     try:
         eng.upload_table(nd)
         eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
-        eng.set_link_capacity(1 << 25)      # ~3.6 M candidate links per tick with 9000 frames on the air
+        eng.set_link_capacity(1 << 23)      # the lists' ring: 2^23 entries, ~18 ticks' worth -- it wraps during this run
         rng = np.random.default_rng(6)
         onair = np.zeros(0, dtype=O.PACKET_DTYPE)
         mdl = oracle_model(O, "logdist", params)
-        for tick in range(11):
+        checked = {10: "steady state", 13: "the tick a node moved in (lists rebuilt)", 14: "the tick after the rebuild",
+                   29: "after the entry ring wrapped"}
+        links = 0
+        for tick in range(30):
             t0 = tick * 1000
+            if tick == 13:                      # a receiver moves next to a sender: everything its entries were computed from changed
+                j = int(rng.integers(n))
+                nd.x[j], nd.y[j] = nd.x[(j + 7) % n] + 2.0, nd.y[(j + 7) % n]
+                eng.update_node(j, nd.x[j], nd.y[j], nd.z[j], nd.txpower[j], int(nd.channel[j]), 1, 1.0, 1.0)
             onair = onair[onair["start_us"] + onair["air_us"] > t0]
             srcs = W.choose_sources(n, t, 0xC0FFEE05, tick)
             new = nd.packets(srcs, 0, W.AIR_US)
@@ -228,11 +251,16 @@ def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
             eng.enqueue_records(to_tx_records(rsa, new))
             gpu = eng.tick_flush(cap=1 << 20)
             assert gpu.count > 30_000
-            if tick >= 9:
+            links += gpu.count
+            if tick in checked:
                 assert len(onair) >= 8000, len(onair)
-                cpu = _sampled_sinr_check(O, mdl, nd, onair, new, gpu, np.arange(tick, t, 59))
+                cpu = _whole_tick_check(O, mdl, nd, onair, new, gpu, "configs[4], tick %d: %s" % (tick, checked[tick]))
                 assert (cpu.verdict == O.INTERFERED).sum() > 0      # the overlap does interfere
             onair = np.concatenate([onair, new])
+        inc, reb = eng.air_list_stats()
+        assert reb == 2 and inc == 28, (inc, reb)     # the first tick and the one with the move
+        # significant links (entries) are several times the heard ones: the ring of 2^23 entries went round at least once
+        assert links * 4 > (1 << 23), links
     finally:
         eng.close()
 

@@ -4,6 +4,7 @@ Reference paths: /root/reference/radio-medium/java/se/sics/emul8/radiomedium/.""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 
 def test_k1_java_lcg(O):
@@ -130,3 +131,35 @@ def test_null_medium_everyone_same_channel(O):
     nd = _three(O, [(0, 0, 0), (1e6, 0, 0), (2, 0, 0)])
     res = O.tick(O.model(O.MODEL_NULL), nd, nd.packet(1, txpower=-3.5))
     assert list(res.dst) == [0, 2] and list(res.rssi) == [-3.5, -3.5]      # rssi = packet txpower (:57)
+
+
+def test_threaded_pass_equals_the_serial_pass_without_draws(O):
+    """orc_tick_mt spreads the packets of a tick over threads; that is the reference's result exactly when no
+    java.util.Random draw happens (the shared generator is all that chains the packets): equal to orc_tick bit for bit
+    with the SINR extension and frames on the air, refused when a link would draw."""
+    n = 6000
+    rng = np.random.default_rng(1)
+    nd = O.NodeTable(n)
+    side = 50 * np.sqrt(np.pi * n / 20)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    nd.channel[:] = 11 + rng.integers(0, 3, n)
+    nd.enabled[rng.random(n) < 0.05] = 0
+    nd.rxprob[rng.random(n) < 0.05] = 0.0        # 0 and 1 draw nothing
+    nd.txprob[rng.random(n) < 0.05] = 0.0
+    old = nd.packets(np.sort(rng.choice(n, 150, replace=False)), -4000, 8128)
+    new = nd.packets(np.sort(rng.choice(n, 200, replace=False)), 0, 8128)
+    new["start_us"] = rng.integers(0, 1000, len(new))
+    active = np.concatenate([old, new])
+    for kind, kw in ((O.MODEL_LOGDIST, dict(ld_sigma_db=4.0, ld_seed=3, ld_flags=1)), (O.MODEL_LOGDIST, dict(ld_sigma_db=0.0)),
+                     (O.MODEL_UDGM, {}), (O.MODEL_UDGM_CONST, {}), (O.MODEL_NULL, {})):
+        mdl = O.model(kind, **kw)
+        a = O.tick(mdl, nd, active, first_new=len(old))
+        for threads in (1, 3, 0):
+            b = O.tick_mt(mdl, nd, active, first_new=len(old), threads=threads)
+            assert a.count == b.count and a.count > 0
+            for f in ("pkt", "dst", "verdict", "rssi", "sinr", "pkt_interference"):
+                np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
+        assert a.pkt_draws.sum() == 0
+    nd.rxprob[:] = np.where(rng.random(n) < 0.5, 0.5, 1.0)
+    with pytest.raises(ValueError):
+        O.tick_mt(O.model(O.MODEL_UDGM), nd, new)
