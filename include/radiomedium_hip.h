@@ -337,6 +337,9 @@ int rm_slot_stats(rm_context *ctx, int32_t slot, uint64_t *candidates, uint64_t 
  * frames to the per-receiver interferer lists kept on the device, and how many rebuilt the lists from every frame on the
  * air (first tick, after a node / model / partition / capacity change, after a dropped tick, when t_begin went back) */
 int rm_air_list_stats(const rm_context *ctx, uint64_t *incremental_ticks, uint64_t *rebuilt_ticks);
+/* the entry ring behind those lists (synchronises): entries allocated since the lists were last rebuilt in the busiest of the
+ * 256 sub-rings, and the entries a sub-ring holds -- more allocated than held: the ring has gone round (old entries were reclaimed) */
+int rm_air_ring_stats(rm_context *ctx, uint64_t *max_allocated, uint64_t *sub_ring_entries);
 
 /* ---- several devices behind one caller --------------------------------------------------------------
  * The reference host is ONE process (Main.java:65-73): a group drives n contexts from one host thread, one

@@ -447,6 +447,22 @@ int rm_air_list_stats(const rm_context *c, uint64_t *incremental_ticks, uint64_t
     return RM_OK;
 }
 
+int rm_air_ring_stats(rm_context *c, uint64_t *max_allocated, uint64_t *sub_ring_entries)
+{
+    if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
+    uint64_t mx = 0;
+    if (c->air.tail.p && c->air.valid) {
+        RM_HIP(hipSetDevice(c->device));
+        std::vector<uint32_t> tails(size_t(rm::kShards) * rm::kShardStride);
+        RM_HIP(hipMemcpyAsync(tails.data(), c->air.tail.p, tails.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < rm::kShards; ++k) mx = std::max<uint64_t>(mx, tails[size_t(k) * rm::kShardStride]);
+    }
+    if (max_allocated) *max_allocated = mx;
+    if (sub_ring_entries) *sub_ring_entries = c->air.sub_cap;
+    return RM_OK;
+}
+
 int rm_set_time(rm_context *c, int64_t t)
 {
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");

@@ -506,6 +506,12 @@ class Engine:
         check(self._L.rm_air_list_stats(self._h, C.byref(inc), C.byref(reb)))
         return inc.value, reb.value
 
+    def air_ring_stats(self):
+        """(entries allocated in the busiest sub-ring since the lists were last rebuilt, entries a sub-ring holds)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.rm_air_ring_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def last_link_evaluations(self):
         return self._L.rm_last_link_evaluations(self._h)
 
