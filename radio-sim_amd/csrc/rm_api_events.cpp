@@ -176,6 +176,7 @@ int rm_events_enable(rm_context *c, uint32_t max_pending_packets, uint32_t max_p
     v.seq = 0;
     v.on = true;
     v.next_packet = 0;
+    v.oldest_packet = 0;
     v.par = 0;
     RM_TRY(ev_ensure_nodes(c));
     return RM_OK;
@@ -192,7 +193,9 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
     RM_TRY(ev_ensure_nodes(c));
     const rm::EvOut o = ev_out(c);
     const uint32_t seq = ++c->ev.seq;
-    RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq));
+    // (the ring window the drain looks at: at most the packets numbered since the oldest pending one of the last drain)
+    const int64_t window = c->ev.next_packet - c->ev.oldest_packet;
+    RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq, uint32_t(std::min<int64_t>(std::max<int64_t>(window, 1), 0x7FFFFFFF))));
     c->current_time = time_us; // Simulator.java:156
     volatile const uint32_t *flag = &o.hdr->seq;
     bool seen = false;
@@ -201,6 +204,7 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
     out->count = o.hdr->count;
     out->pending_packets = o.hdr->pending_packets;
     out->oldest_packet = o.hdr->oldest_packet;
+    c->ev.oldest_packet = o.hdr->oldest_packet;
     out->packet = o.pkt;
     out->dst = o.dst;
     out->rssi = o.rssi;

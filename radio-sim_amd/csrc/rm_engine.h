@@ -326,7 +326,8 @@ struct EvState {
     uint32_t n_deliv;
     uint32_t err;               // until the drain has reported it: 4 group list full
     uint32_t done_a;            // "last workgroup" counter (node-info)
-    uint32_t pad1[2];
+    uint32_t done_apply;        // ... of k_ev_apply (the last one finishes the drain)
+    uint32_t pad1;
     EvTails tails[2];
     // (its own 128-byte line: k_ev_select's workgroups add to n_groups and take minima here at the same time)
     alignas(128) uint32_t first_live; // window index of the oldest packet with events still queued (0xFFFFFFFF: none)
@@ -471,7 +472,8 @@ hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t
 // reception stage (rm_events.hip)
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,
                             int immediate, const uint32_t *dropped_flag);
-hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq);
+// window: the host's bound on the pending packets (0: unknown)
+hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window);
 hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, const int32_t *dev_nodes, int n, double base_rssi,
                             const NodeInfoOut &out, uint32_t seq);
 

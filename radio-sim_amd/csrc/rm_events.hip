@@ -26,6 +26,8 @@
 #include "rm_device.hpp"
 #include "rm_evorder.hpp"
 
+#include <stdlib.h>
+
 namespace rm {
 
 constexpr int64_t kI64Min = int64_t(0x8000000000000000ull);
@@ -149,9 +151,8 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
     EvState &st = *e.st;
     const uint32_t head = st.pk_head, w = st.tails[e.par].pk_tail - head;
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x * blockDim.x >= ((w + 63u) & ~63u)) return;
+    if (blockIdx.x * blockDim.x >= ((w + 63u) & ~63u)) return; // (the grid is sized for the host's bound on the window)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (2u * i + 1u < e.g_cap) e.g_rank[2u * i] = e.g_rank[2u * i + 1u] = 0u; // at most 2 w groups fire: k_ev_rank adds into these
     const uint32_t idx = (head + i) & e.pk_mask;
     EvPacket p{};
     bool valid = false;
@@ -176,6 +177,11 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
     const bool imm = (p.flags & kEvImmediate) != 0u;
     const bool fire_start = valid && !imm && !(p.flags & kEvStartDone) && p.t0 < T;
     const bool fire_end = valid && (imm || p.t1 < T);
+    { // the drain's deliveries, one atomic per wave
+        uint32_t nd = fire_end ? p.n_deliver : 0u;
+        for (int d = 32; d >= 1; d >>= 1) nd += uint32_t(__shfl_xor(int(nd), d));
+        if (lane == 0 && nd) atomicAdd(&st.n_deliv, nd);
+    }
     for (int ph = 0; ph < 2; ++ph) { // 0 end, 1 start
         const bool fire = ph ? fire_start : fire_end;
         const uint64_t hm = ballot64(fire);
@@ -197,6 +203,7 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
                 e.g_meta[k] = ev_meta(uint32_t((ph ? p.lad0 : p.lad1) - lb), 0xFFFFFFFFu - rel, uint32_t(ph));
             }
             e.g_ref[k] = (idx << 1) | uint32_t(ph);
+            e.cnt_by_rank[k] = ph ? 0u : p.n_deliver; // (by group here: an end group delivers its packet's delivery-mode links)
             // a node that starts to send in this drain: reception starts on it must take part in the "sending"
             // field's last-writer contest (k_ev_emit skips that for every other idle node)
             if (ph && !(p.flags & kEvNoTx)) e.send_key[p.src] = 1ull;
@@ -204,77 +211,52 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
     }
 }
 
-// k_ev_rank: a group's rank = the number of groups with a smaller key (keys are unique).  The G x G comparisons
-// are cut into tiles of 64 groups x 512 keys; the workgroups take the tiles in turn (the host does not know G).
-// Inside a tile every lane owns a group, the four waves each scan a quarter of the keys from LDS (eight reads
-// in flight) and add their partial counts to the group's rank.
-constexpr int kEvTile = 512;
-__global__ void __launch_bounds__(256) k_ev_rank(const EvDev e)
-{
-    __shared__ int64_t s_time[kEvTile];
-    __shared__ uint64_t s_meta[kEvTile];
-    const uint32_t G = min(e.st->n_groups, e.g_cap);
-    const uint32_t ni = (G + 63u) / 64u, nj = (G + uint32_t(kEvTile) - 1u) / uint32_t(kEvTile);
-    const int lane = threadIdx.x & 63, part = wave_index();
-    for (uint32_t tile = blockIdx.x; tile < ni * nj; tile += gridDim.x) { // block-uniform
-        const uint32_t i = (tile % ni) * 64u + uint32_t(lane), k0 = (tile / ni) * uint32_t(kEvTile);
-        const bool mine = i < G;
-        const int64_t ti = mine ? e.g_time[i] : 0;
-        const uint64_t mi = mine ? e.g_meta[i] : 0;
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < uint32_t(kEvTile); k += blockDim.x) {
-            const bool ok = k0 + k < G;
-            s_time[k] = ok ? e.g_time[k0 + k] : int64_t(0x7FFFFFFFFFFFFFFFll); // padding keys are larger than every key
-            s_meta[k] = ok ? e.g_meta[k0 + k] : ~0ull;
-        }
-        __syncthreads();
-        uint32_t rank = 0;
-        for (uint32_t k = uint32_t(part) * uint32_t(kEvTile / 4); k < uint32_t(part + 1) * uint32_t(kEvTile / 4); k += 8u) {
-            int64_t tk[8];
-            uint64_t mk[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                tk[u] = s_time[k + u];
-                mk[u] = s_meta[k + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rank += (tk[u] < ti || (tk[u] == ti && mk[u] < mi)) ? 1u : 0u;
-        }
-        if (mine && rank) atomicAdd(&e.g_rank[i], rank);
-    }
-}
-
-// k_ev_scan: first delivery of every group, in rank order
-__global__ void __launch_bounds__(1024) k_ev_scan(const EvDev e)
-{
-    __shared__ uint32_t s_wave[16];
-    const uint32_t G = min(e.st->n_groups, e.g_cap);
-    for (uint32_t g = threadIdx.x; g < G; g += 1024) { // an end group delivers its packet's delivery-mode links
-        const uint32_t ref = e.g_ref[g];
-        e.cnt_by_rank[e.g_rank[g]] = ((ref & 1u) == 0u) ? e.pk[ref >> 1].n_deliver : 0u;
-    }
-    __syncthreads();
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < G; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < G) ? e.cnt_by_rank[i] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan_1024(v, s_wave, total);
-        if (i < G) e.off_by_rank[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) e.st->n_deliv = carry;
-}
-
-// k_ev_emit: one wave per fired group: the deliveries of an end group to their places of the delivery
-// list, and every event's (rank, event) key to the fields of the node it touches.
-__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out)
+// k_ev_emit: one wave per fired group: its place in the pop order, and every event's (rank, event) key to the fields of
+// the node it touches (the last-writer contest).  The deliveries themselves are written by k_ev_apply: they depend on
+// nothing the contest decides, and their stores into host-mapped memory (PCIe-bound) then run under the state update.
+__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
 {
     const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
     for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
         const uint32_t ref = uniform_u(e.g_ref[g]);
-        const uint32_t r = uniform_u(e.g_rank[g]);
+        // The group's place in the queue's pop order = the number of fired groups with a smaller key (keys are unique), and
+        // the place of its deliveries in the list = the deliveries of those groups: one pass of the wave over all groups'
+        // keys (a few thousand, L2-resident) -- no sort, no scan, no launch in between.
+        uint32_t r = 0, first = 0;
+        {
+            const int64_t tg = e.g_time[g];
+            const uint64_t mg = e.g_meta[g];
+            for (uint32_t k0 = 0; k0 < G; k0 += 64 * 8) { // eight groups per lane in flight: the pass is a chain of L2 round trips
+                int64_t tk[8];
+                uint64_t mk[8];
+                uint32_t ck[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t k = k0 + uint32_t(u) * 64u + uint32_t(lane);
+                    const bool in = k < G;
+                    tk[u] = in ? e.g_time[k] : int64_t(0x7FFFFFFFFFFFFFFFll);
+                    mk[u] = in ? e.g_meta[k] : ~0ull;
+                    ck[u] = in ? e.cnt_by_rank[k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool less = tk[u] < tg || (tk[u] == tg && mk[u] < mg);
+                    r += less ? 1u : 0u;
+                    first += less ? ck[u] : 0u;
+                }
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                r += uint32_t(__shfl_xor(int(r), d));
+                first += uint32_t(__shfl_xor(int(first), d));
+            }
+            r = uniform_u(r);
+            first = uniform_u(first);
+            if (lane == 0) {
+                e.g_rank[g] = r;        // k_ev_apply recomputes the events' keys from it ...
+                e.off_by_rank[g] = first; // ... and writes the group's deliveries from here on
+            }
+        }
         const EvPacket &p = e.pk[ref >> 1];
         const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
         const int src = uniform_i(p.src);
@@ -298,40 +280,22 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out)
                 amax_key(&e.recv_key[src], k);
             }
         } else {
-            const uint32_t n_del = uniform_u(e.cnt_by_rank[r]), first = uniform_u(e.off_by_rank[r]);
-            const int64_t gseq = p.gseq;
-            uint32_t seen = 0;
-            for (uint32_t j0 = 0; j0 < cnt; j0 += 64) { // wave-uniform
-                const uint32_t j = j0 + lane;
-                bool deliver = false;
-                uint32_t o = 0;
-                if (j < cnt) {
-                    o = (off0 + j) & e.pool_mask;
-                    deliver = e.l_verdict[o] == RM_DELIVERED;
-                    if (!imm) amax_key(&e.recv_key[e.l_dst[o]], ev_key(r, kEvRxEnd, o)); // end flank: clearReceiving, whichever packet
+            if (!imm)
+                for (uint32_t j = lane; j < cnt; j += 64) { // end flank: clearReceiving, whichever packet
+                    const uint32_t o = (off0 + j) & e.pool_mask;
+                    amax_key(&e.recv_key[e.l_dst[o]], ev_key(r, kEvRxEnd, o));
                 }
-                const uint64_t dm = ballot64(deliver);
-                if (deliver) {
-                    const uint32_t nth = seen + lane_prefix(dm); // n-th delivered link of the packet in node order
-                    // queued end events pop in reverse insertion order = reverse node order; the constant-loss
-                    // medium delivers synchronously in node order
-                    const uint32_t pos = first + (imm ? nth : (n_del - 1u - nth));
-                    if (pos < out.cap) {
-                        out.pkt[pos] = gseq;
-                        out.dst[pos] = e.l_dst[o];
-                        out.rssi[pos] = e.l_rssi[o];
-                    }
-                }
-                seen += uint32_t(__popcll(dm));
-            }
             if (lane == 0 && !(fl & kEvNoTx)) amax_key(&e.send_key[src], ev_key(r, kEvTxEnd, 0u)); // clearSending
         }
     }
 }
 
-// k_ev_apply: the last writer of a field writes it (and clears its key).
-__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e)
+RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t seq);
+
+// k_ev_apply: the last writer of a field writes it (and clears its key); the workgroup that is done last finishes the drain.
+__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out, int64_t T, uint32_t seq)
 {
+    __shared__ uint32_t s_lastwg;
     const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
     for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
@@ -342,6 +306,37 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e)
         const int src = uniform_i(p.src);
         const bool start = (ref & 1u) != 0u;
         const bool imm = (fl & kEvImmediate) != 0u;
+        if (!start) { // the group's deliveries, into the host-mapped list at the place its rank gives them
+            const uint32_t n_del = uniform_u(e.cnt_by_rank[g]), first = uniform_u(e.off_by_rank[g]);
+            const int64_t gseq = p.gseq;
+            uint32_t seen = 0;
+            for (uint32_t j0 = 0; n_del != 0u && j0 < cnt; j0 += 64) { // wave-uniform
+                const uint32_t j = j0 + lane;
+                bool deliver = false;
+                uint32_t o = 0;
+                if (j < cnt) {
+                    o = (off0 + j) & e.pool_mask;
+                    deliver = e.l_verdict[o] == RM_DELIVERED;
+                }
+                const uint64_t dm = ballot64(deliver);
+                if (deliver) {
+                    const uint32_t nth = seen + lane_prefix(dm); // n-th delivered link of the packet in node order
+                    // queued end events pop in reverse insertion order = reverse node order; the constant-loss
+                    // medium delivers synchronously in node order
+                    const uint32_t pos = first + (imm ? nth : (n_del - 1u - nth));
+                    if (pos < out.cap) { // host-mapped memory: write-through stores at system scope (drained below, before the
+                        // workgroup is counted: no release fence, which would also write back this XCD's whole L2)
+                        __hip_atomic_store(&out.pkt[pos], gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&out.dst[pos], e.l_dst[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&out.rssi[pos], e.l_rssi[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+                seen += uint32_t(__popcll(dm));
+            }
+        }
+        // the fired flank is done (k_ev_select of the next drain reads this; the other flank's wave reads only the bits
+        // that never change)
+        if (lane == 0) atomicOr(&p.flags, start ? kEvStartDone : (kEvDone | kEvStartDone));
         if (start) {
             for (uint32_t j = lane; j < cnt; j += 64) {
                 const uint32_t o = (off0 + j) & e.pool_mask;
@@ -389,20 +384,26 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e)
             }
         }
     }
+    {
+        // (the radio state and the deliveries this workgroup wrote are read by later launches / by the host after the
+        // header's sequence number: every storing wave drains its stores before the workgroup reports in)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_lastwg = (atomicAdd(&e.st->done_apply, 1u) == gridDim.x - 1u) ? 1u : 0u;
+        __syncthreads();
+        if (!s_lastwg) return;
+        if (threadIdx.x == 0) e.st->done_apply = 0u;
+        ev_finish_body(e, out, T, seq);
+    }
 }
 
 // k_ev_finish (one workgroup, after k_ev_apply): the fired groups' packets are marked, the ring heads move, the
 // queue's ladder rule for this drain (rm_evorder.hpp) is applied and the delivery list's header is published.
-__global__ void __launch_bounds__(1024) k_ev_finish(const EvDev e, const EvOut out, int64_t T, uint32_t seq)
+RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t seq)
 {
     EvState &st = *e.st;
-    const uint32_t G = min(st.n_groups, e.g_cap);
     const EvTails tl = st.tails[e.par];
     const uint32_t head = st.pk_head, tail = tl.pk_tail;
-    for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) {
-        const uint32_t ref = e.g_ref[g];
-        atomicOr(&e.pk[ref >> 1].flags, (ref & 1u) ? kEvStartDone : (kEvDone | kEvStartDone));
-    }
     if (threadIdx.x != 0) return;
     // ring heads: up to the oldest packet that still had events queued when this drain began (k_ev_select)
     const uint32_t live = st.first_live;
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__(1024) k_ev_finish(const EvDev e, const EvOut o
     const uint32_t total = st.n_deliv;
     if (st.n_groups > e.g_cap) st.err |= 4u;
     st.n_groups = 0u;
+    st.n_deliv = 0u;
     // The header lives in host-mapped memory: write-through stores, drained, then the sequence number the host
     // polls.  (A system-scope release fence here would also write back every dirty line the drain's kernels left in
     // this XCD's L2 -- microseconds, and nothing the host reads: the delivery records were stored by an earlier
@@ -499,15 +501,16 @@ hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, 
     return hipGetLastError();
 }
 
-hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq)
+hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window)
 {
+    // Three launches.  Selection (what fires before time_us; `window`: the host's bound on the pending packets); every
+    // fired group's wave finds its place in the pop order by counting, writes its deliveries and enters the last-writer
+    // contest of the radio fields; the winners write the state and the workgroup that is done last finishes the drain.
     const uint32_t pk_cap = e.pk_mask + 1u;
-    hipLaunchKernelGGL(k_ev_select, dim3(cdiv(int(pk_cap), 256)), dim3(256), 0, s, e, time_us);
-    hipLaunchKernelGGL(k_ev_rank, dim3(256), dim3(256), 0, s, e);
-    hipLaunchKernelGGL(k_ev_scan, dim3(1), dim3(1024), 0, s, e);
-    hipLaunchKernelGGL(k_ev_emit, dim3(512), dim3(256), 0, s, e, out);
-    hipLaunchKernelGGL(k_ev_apply, dim3(256), dim3(256), 0, s, e);
-    hipLaunchKernelGGL(k_ev_finish, dim3(1), dim3(1024), 0, s, e, out, time_us, seq);
+    const uint32_t w = (window == 0u || window > pk_cap) ? pk_cap : window;
+    hipLaunchKernelGGL(k_ev_select, dim3(cdiv(int(w), 256)), dim3(256), 0, s, e, time_us);
+    hipLaunchKernelGGL(k_ev_emit, dim3(512), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(k_ev_apply, dim3(512), dim3(256), 0, s, e, out, time_us, seq);
     return hipGetLastError();
 }
 

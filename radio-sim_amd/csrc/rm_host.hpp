@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <string>
 #include <thread>
@@ -182,6 +183,7 @@ struct rm_context : TickSlot {
         uint32_t seq = 0, info_seq = 0;
         DevBuf<int32_t> d_info_nodes;
         int64_t next_packet = 0;  // host mirror of EvTails::gseq_next
+        int64_t oldest_packet = 0; // number of the oldest pending packet as the last drain published it (a bound on the ring window)
         int par = 0;              // which EvState::tails are current (flips with every appended tick)
     } ev;
     DevBuf<uint8_t> d_enabled;   // Transciever.isEnabled by node index
