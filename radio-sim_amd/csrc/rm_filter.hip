@@ -447,8 +447,71 @@ __global__ void __launch_bounds__(256) k_tick_prep(const NodesDev nd, const Mode
     tick_prep_body(nd, m, t);
 }
 
+// A filter workgroup's receivers: one per lane in each of the wave's RPT groups, with the groups' boxes and the union box
+// of the workgroup's 4 * RPT groups.  They stay in registers for all the ticks the workgroup sweeps (filter_wg_body).
+template <int RPT> struct WgRx {
+    float fx[RPT], fy[RPT], fz[RPT];
+    int fch[RPT], forig[RPT];
+    float4 bxy[RPT];
+    float2 bz[RPT];
+    float4 wxy;
+    float2 wz;
+};
+
 template <int RPT, bool SHADOW>
-RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
+RM_D void wg_rx_load(const NodesDev &nd, const TickDev &t, WgRx<RPT> &rx)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    const int wg = blockIdx.x;
+    const int slab = wg * kWavesPerBlock + wave;
+    const int jbase = slab * (kGroup * RPT);
+    const bool live = slab < t.n_slabs;
+    const int n_groups = (t.n_rx + kGroup - 1) / kGroup;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int j = jbase + r * kGroup + lane;
+        rx.fx[r] = rx.fy[r] = rx.fz[r] = __builtin_nanf("");
+        rx.fch[r] = 0;
+        rx.forig[r] = 0;
+        if (live && j < t.n_rx) {
+            const float4 v = nd.rxf[j];
+            rx.fx[r] = v.x;
+            rx.fy[r] = v.y;
+            rx.fz[r] = v.z;
+            rx.fch[r] = __float_as_int(v.w);
+            if (SHADOW) rx.forig[r] = nd.orig[j];
+        }
+        const int g = slab * RPT + r;
+        const bool ok = live && g * kGroup < t.n_rx;
+        rx.bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        rx.bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
+    }
+    // union box of the workgroup's 4*RPT groups
+    if (RPT == 4) {
+        rx.wxy = nd.wg_box_xy[wg];
+        rx.wz = nd.wg_box_z[wg];
+    } else {
+        const float inf_ = __builtin_inff();
+        rx.wxy = make_float4(inf_, inf_, -inf_, -inf_);
+        rx.wz = make_float2(inf_, -inf_);
+        for (int g = wg * kWavesPerBlock * RPT; g < min(n_groups, (wg + 1) * kWavesPerBlock * RPT); ++g) { // uniform
+            const float4 q = nd.bbox_xy[g];
+            const float2 qz = nd.bbox_z[g];
+            rx.wxy.x = fminf(rx.wxy.x, q.x);
+            rx.wxy.y = fminf(rx.wxy.y, q.y);
+            rx.wxy.z = fmaxf(rx.wxy.z, q.z);
+            rx.wxy.w = fmaxf(rx.wxy.w, q.w);
+            rx.wz.x = fminf(rx.wz.x, qz.x);
+            rx.wz.y = fmaxf(rx.wz.y, qz.y);
+        }
+    }
+}
+
+// one tick of the two-level filter for the receivers in `rx`; tick_salt spreads the ticks of a launch over the shards
+template <int RPT, bool SHADOW>
+RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t, const WgRx<RPT> &rx, const bool first_of_wg,
+                         const uint32_t tick_salt)
 {
     __shared__ float4 s_txf[kNearLds];
     __shared__ int s_ch[kNearLds];
@@ -466,9 +529,8 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     const int jbase = slab * (kGroup * RPT);
     const bool live = slab < t.n_slabs;
     const int n_eval = t.n_active - t.first_eval;
-    const int n_groups = (t.n_rx + kGroup - 1) / kGroup;
 
-    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
+    if (first_of_wg && SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
     if (threadIdx.x == 0) s_n = 0u;
 
     // phase A works on kUnrollA x 256 frames at a time: their records are requested together (one
@@ -496,53 +558,12 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
         }
     };
     request(0);
-
-    // this wave's receivers, resident in registers for the whole tick
-    float fx[RPT], fy[RPT], fz[RPT];
-    int fch[RPT], forig[RPT];
-    float4 bxy[RPT];
-    float2 bz[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int j = jbase + r * kGroup + lane;
-        fx[r] = fy[r] = fz[r] = __builtin_nanf("");
-        fch[r] = 0;
-        forig[r] = 0;
-        if (live && j < t.n_rx) {
-            const float4 v = nd.rxf[j];
-            fx[r] = v.x;
-            fy[r] = v.y;
-            fz[r] = v.z;
-            fch[r] = __float_as_int(v.w);
-            if (SHADOW) forig[r] = nd.orig[j];
-        }
-        const int g = slab * RPT + r;
-        const bool ok = live && g * kGroup < t.n_rx;
-        bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-        bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
-    }
-
-    // union box of the workgroup's 4*RPT groups
-    float4 wxy;
-    float2 wz;
-    if (RPT == 4) {
-        wxy = nd.wg_box_xy[wg];
-        wz = nd.wg_box_z[wg];
-    } else {
-        const float inf_ = __builtin_inff();
-        wxy = make_float4(inf_, inf_, -inf_, -inf_);
-        wz = make_float2(inf_, -inf_);
-        for (int g = wg * kWavesPerBlock * RPT; g < min(n_groups, (wg + 1) * kWavesPerBlock * RPT); ++g) { // uniform
-            const float4 q = nd.bbox_xy[g];
-            const float2 qz = nd.bbox_z[g];
-            wxy.x = fminf(wxy.x, q.x);
-            wxy.y = fminf(wxy.y, q.y);
-            wxy.z = fmaxf(wxy.z, q.z);
-            wxy.w = fmaxf(wxy.w, q.w);
-            wz.x = fminf(wz.x, qz.x);
-            wz.y = fmaxf(wz.y, qz.y);
-        }
-    }
+    const float (&fx)[RPT] = rx.fx, (&fy)[RPT] = rx.fy, (&fz)[RPT] = rx.fz;
+    const int (&fch)[RPT] = rx.fch, (&forig)[RPT] = rx.forig;
+    const float4 (&bxy)[RPT] = rx.bxy;
+    const float2 (&bz)[RPT] = rx.bz;
+    const float4 wxy = rx.wxy;
+    const float2 wz = rx.wz;
     __syncthreads();
 
     uint32_t round = 0;
@@ -662,7 +683,7 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
                     if (lane >= d) inc += o;
                 }
                 const uint32_t wave_total = __shfl(inc, 63);
-                const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + blockIdx.z * 101u) & t.shard_mask;
+                const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + tick_salt * 101u) & t.shard_mask;
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&t.shard_count[shard * kShardStride], wave_total);
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -701,12 +722,24 @@ RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
         }
     }
     }
+    __syncthreads(); // (the next tick of this workgroup reuses the LDS lists)
+}
+
+// `ticks[first .. first + count)`: the ticks this workgroup sweeps one after the other against ITS receivers, which stay
+// in registers (and their boxes) for all of them -- at a million receivers the 16 MB of pre-filter records then leave HBM
+// once per `count` ticks instead of once per tick.
+template <int RPT, bool SHADOW>
+RM_D void filter_wg_body(const NodesDev &nd, const ModelDev &m, const TickDev *__restrict__ ticks, const int first, const int count)
+{
+    WgRx<RPT> rx;
+    wg_rx_load<RPT, SHADOW>(nd, ticks[first], rx); // (the receiver tiling is the same for every tick of a launch)
+    for (int b = 0; b < count; ++b) filter_wg_tick<RPT, SHADOW>(nd, m, ticks[first + b], rx, b == 0, uint32_t(first + b));
 }
 
 template <int RPT, bool SHADOW>
 __global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6)) k_filter_wg(const NodesDev nd, const ModelDev m, const TickDev t)
 {
-    filter_wg_body<RPT, SHADOW>(nd, m, t);
+    filter_wg_body<RPT, SHADOW>(nd, m, &t, 0, 1);
 }
 
 __global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
@@ -715,10 +748,11 @@ __global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, cons
 }
 
 template <int RPT, bool SHADOW>
-__global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6))
-k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
+__global__ void __launch_bounds__(kBlock, 6)
+k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks, const int n_ticks, const int per_wg)
 {
-    filter_wg_body<RPT, SHADOW>(nd, m, ticks[blockIdx.z]);
+    const int first = int(blockIdx.z) * per_wg;
+    filter_wg_body<RPT, SHADOW>(nd, m, ticks, first, min(per_wg, n_ticks - first));
 }
 
 // ============================================================================ launchers
@@ -859,16 +893,21 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
     const TickDev &t0 = ticks[0];
     hipLaunchKernelGGL(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
-    const dim3 grid(cdiv(t0.n_slabs, kWavesPerBlock), 1, n), block(kBlock);
+    // A workgroup keeps its receivers for `per_wg` ticks: as many as leave a few thousand workgroups for the chip (a table
+    // of a million receivers has a thousand tiles: 16 ticks = 4 per workgroup; 100 k receivers: one tick per workgroup).
+    const int tiles = cdiv(t0.n_slabs, kWavesPerBlock);
+    int per_wg = max(1, min(n, (tiles * n) / 3072));
+    if (const char *e = getenv("RM_FILTER_TICKS_PER_WG")) per_wg = max(1, min(n, atoi(e)));
+    const dim3 grid(tiles, 1, cdiv(n, per_wg)), block(kBlock);
     if (t0.rpt == 4) {
-        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b);
-        else hipLaunchKernelGGL((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b);
+        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else hipLaunchKernelGGL((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     } else if (t0.rpt == 2) {
-        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<2, true>), grid, block, 0, s, nd, m, b);
-        else hipLaunchKernelGGL((k_filter_wg_batch<2, false>), grid, block, 0, s, nd, m, b);
+        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<2, true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else hipLaunchKernelGGL((k_filter_wg_batch<2, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     } else {
-        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b);
-        else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b);
+        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     }
     return hipGetLastError();
 }

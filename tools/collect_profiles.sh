@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round evidence, run on the GPU box from the repository root:  RM_COMMIT=<commit> ROUND=r02 bash tools/collect_profiles.sh
+# Round evidence, run on the GPU box from the repository root:  RM_COMMIT=<commit> ROUND=r03 bash tools/collect_profiles.sh
 # Writes under gpurun_out/$ROUND/; the summaries to be judged are then copied into profiles/.
 set -e -o pipefail
 R=$PWD
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -13,9 +13,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/be
 echo "stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --batch 1 --steps 400 --warmup 40 > $O/stats_seq.log 2>&1
 echo "sequential stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 10 --warmup 2 > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 10 --warmup 2 > $O/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --inflight 1 --steps 10 --warmup 2 > $O/pmc_sq.log 2>&1
+# the access-pattern calibration of FETCH_SIZE first (tools/pmc_traffic.py takes its factors from profiles/fetch_calibration.json)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib -- $R/tools/fetch_calib > $O/calib.log 2>&1
+(cd $R && python tools/fetch_calib.py $O/calib profiles/fetch_calibration.json > $O/fetch_calibration.log)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --inflight 1 --steps 6 --warmup 2 > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --inflight 1 --steps 6 --warmup 2 > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --inflight 1 --steps 6 --warmup 2 > $O/pmc_sq.log 2>&1
+# ... and the same vector-issue counters with the bench's own number of contexts sharing the device (the counts must agree:
+# instructions do not depend on who else runs)
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq3 -- python $R/bench.py --no-cpu-baseline --no-scale-probe --no-host-transfer --steps 9 --warmup 3 > $O/pmc_sq3.log 2>&1
 echo "pmc c3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/m1_stats -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --batch 16 --steps 24 --warmup 6 > $O/m1_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/m1_fetch -- python $R/bench.py --no-cpu-baseline --no-scale-probe --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3 > $O/m1_fetch.log 2>&1
@@ -32,7 +38,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -- python $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ev_stats -- python $R/tools/events_latency.py c3 100 > $O/ev_stats.log 2>&1
 echo "c5 / events done"
 cd $R
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 64 $O/${ROUND}_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3 128 $O/${ROUND}_c3_pmc.csv $O/pmc_traffic.json $O/pmc_sq
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write c3_three_contexts 128 $O/${ROUND}_c3_pmc_three_contexts.csv $O/pmc_traffic.json $O/pmc_sq3
 python tools/pmc_traffic.py $O/m1_fetch $O/m1_write m1 16 $O/${ROUND}_m1_pmc.csv $O/pmc_traffic.json
 python tools/pmc_traffic.py $O/tick_fetch $O/tick_write c3_tick 1 $O/${ROUND}_c3_tick_pmc.csv $O/pmc_traffic.json $O/tick_sq
 cp $(find $O/c5_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c5_kernel_stats.csv
@@ -43,5 +50,9 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_kernel_st
 cp $(find $O/stats_seq -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_sequential_kernel_stats.csv
 cp $(find $O/m1_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_m1_kernel_stats.csv
 for f in $O/${ROUND}_c3_kernel_stats.csv $O/${ROUND}_c3_sequential_kernel_stats.csv $O/${ROUND}_m1_kernel_stats.csv $O/${ROUND}_c5_kernel_stats.csv $O/${ROUND}_c3_events_kernel_stats.csv; do echo "# commit ${RM_COMMIT:-unrecorded}" >> $f; done
-rm -rf $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/m1_stats $O/m1_fetch $O/m1_write $O/tick_fetch $O/tick_write $O/tick_sq $O/c5_stats $O/ev_stats
+# one rank's share of an 8-GPU run, rank by rank (compute side of strong scaling), and the closed loop through the C ABI
+tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c3.jsonl 8 c3 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c3.jsonl > $O/${ROUND}_asrank8_c3.txt
+tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c4.jsonl 8 c4 256 32 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c4.jsonl > $O/${ROUND}_asrank8_c4.txt
+tools/loop_latency > $O/${ROUND}_closed_loop_c_abi.jsonl 2> /dev/null || true
+rm -rf $O/calib $O/pmc_sq3 $O/stats $O/stats_seq $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/m1_stats $O/m1_fetch $O/m1_write $O/tick_fetch $O/tick_write $O/tick_sq $O/c5_stats $O/ev_stats
 echo "all done"
