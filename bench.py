@@ -240,12 +240,21 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
         recs.append(r)
     links_per_tick = t_per_tick * (n - 1)
 
+    # the C ABI called directly (what a compiled host does: tools/loop_latency.cpp is the same loop in C++); the binding's
+    # conveniences -- array wrappers, argument conversion -- are not part of the engine
+    from radio_sim_amd._lib import HostResult, DeliveryView, check
+    L, h = eng._L, eng._h
+    rec_ptr = [C.c_void_p(r.ctypes.data) for r in recs]
+    n_rec = len(recs[0])
+    hres = HostResult()
+
     def flush_loop(k0, k1):
         got = 0
         for k in range(k0, k1):
-            eng.tick_begin(k * tick_us, (k + 1) * tick_us)
-            eng.enqueue_records(recs[k % len(recs)])
-            got += eng.tick_flush_view().count
+            check(L.rm_tick_begin(h, k * tick_us, (k + 1) * tick_us))
+            check(L.rm_enqueue_tx_records(h, rec_ptr[k % len(recs)], n_rec))
+            check(L.rm_tick_flush_view(h, C.byref(hres)))
+            got += hres.count
         return got
     with torch.cuda.stream(stream):
         flush_loop(0, 16)
@@ -262,13 +271,17 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
 
         split = [0.0, 0.0]   # host time inside the two calls (the drain call includes waiting for the device)
 
+        src_ptr = [C.c_void_p(src_dev[k].data_ptr()) for k in range(pool)]
+        dview = DeliveryView()
+
         def ev_loop(k0, k1):
             got = 0
             for k in range(k0, k1):
                 ta = time.perf_counter()
-                eng.tick_run_sources_device(k * tick_us, (k + 1) * tick_us, src_dev[k % pool].data_ptr(), t_per_tick, k * tick_us, W.AIR_US)
+                check(L.rm_tick_run_sources_device(h, k * tick_us, (k + 1) * tick_us, src_ptr[k % pool], t_per_tick, k * tick_us, W.AIR_US))
                 tb = time.perf_counter()
-                got += len(eng.events_process((k + 1) * tick_us, copy=False)[0])   # read in place, as rm_tick_flush_view's records
+                check(L.rm_events_process(h, (k + 1) * tick_us, C.byref(dview)))   # the deliveries are read in place
+                got += dview.count
                 split[0] += tb - ta
                 split[1] += time.perf_counter() - tb
             return got

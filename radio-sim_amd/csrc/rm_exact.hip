@@ -587,7 +587,12 @@ hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &
     int max_eval = 0;
     for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
     hipLaunchKernelGGL(k_self_entries_batch, dim3(cdiv(max(max_eval, 1), 256), 1, n), dim3(256), 0, s, nd, b);
-    hipLaunchKernelGGL(k_sinr_batch, dim3(4, kShards, n), dim3(256), 0, s, m, b);
+    // one row of workgroups per shard IN USE (a batch appends to 64 of the 256 shards, a receiver partition to 8): the rows of
+    // the others would be a thousand workgroups per tick that find nothing
+    const int shards = int(ticks[0].shard_mask) + 1;
+    int gx = 2; // (measured 1 / 2 / 4 / 8: 5.10 / 5.03 / 5.09 / 5.26 us per tick on a rank's share of configs[3])
+    if (const char *e = getenv("RM_SINR_GX")) gx = max(1, atoi(e));
+    hipLaunchKernelGGL(k_sinr_batch, dim3(gx, shards, n), dim3(256), 0, s, m, b);
     return hipGetLastError();
 }
 

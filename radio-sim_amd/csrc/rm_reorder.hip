@@ -603,8 +603,12 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     // workgroups); a receiver partition hears 1/share of a frame's links, so its waves take more
     // ... and every workgroup redoes the scan over all frames of its tick: with thousands of frames per tick
     // fewer workgroups do it (configs[3], 5000 frames: 36.6 -> 33.8 us per tick)
-    // (measured on one rank's share of an 8-GPU run, 256 ticks per launch: 8 -> 16 frames per wave 0.69 -> 0.61 us per tick)
-    int fpw = max(max(2, min(32, nd.n_rx > 0 ? 4 * (nd.n / nd.n_rx) : 1)), min(32, max_new / 256));
+    // A receiver partition hears 1/share of the links and nothing at all of most frames: far more frames per wave (a rank's
+    // share of an 8-GPU tick: configs[2] 16 / 32 / 64 frames per wave 0.536 / 0.513 / 0.505 us per tick, configs[3] with its
+    // 5000 frames 32 / 64 / 128 / 256: 4.98 / 4.58 / 4.37 / 4.27 us).
+    const int share = (nd.n_rx > 0 && nd.n_rx < nd.n) ? max(1, nd.n / nd.n_rx) : 1;
+    int fpw = max(2, min(32, max_new / 256));
+    if (share > 1) fpw = min(256, fpw * 4 * share);
     if (const char *e = getenv("RM_FPW")) fpw = max(1, atoi(e));
     const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {

@@ -37,6 +37,29 @@ class TickResult:
         self.pkt_interference, self.pkt_offset = pkt_interference, pkt_offset
 
 
+class HostTickView:
+    """The same fields as TickResult over the engine's pinned host block, each wrapped in place the first time it is read
+    (a host loop that only looks at a count or two columns does not pay for seven array wrappers per tick)."""
+    _FIELDS = {"pkt": ("pkt", np.int32, 0), "dst": ("dst", np.int32, 0), "verdict": ("verdict", np.uint8, 0),
+               "rssi": ("rssi", np.float64, 0), "sinr": ("sinr", np.float64, 0),
+               "pkt_interference": ("pkt_interference", np.uint8, 1), "pkt_offset": ("pkt_offset", np.uint32, 2)}
+
+    def __init__(self, r):
+        self.count = r.count
+        self._n_packets = r.n_packets
+        self._ptr = {k: getattr(r, v[0]) for k, v in self._FIELDS.items()}
+
+    def __getattr__(self, name):
+        spec = HostTickView._FIELDS.get(name)
+        if spec is None:
+            raise AttributeError(name)
+        n = (self.count, self._n_packets, self._n_packets + 1)[spec[2]]
+        p = self._ptr[name]
+        a = np.zeros(n) if (name == "sinr" and not p) else _wrap(p, spec[1], n)
+        setattr(self, name, a)
+        return a
+
+
 class Engine:
     """One GPU context == one Simulator's radio medium (RadioMedium.java:35-45)."""
 
@@ -217,11 +240,7 @@ class Engine:
 
     @staticmethod
     def _wrap_host_result(r):
-        arr = _wrap
-        k, p = r.count, r.n_packets
-        return TickResult(k, arr(r.pkt, np.int32, k), arr(r.dst, np.int32, k), arr(r.verdict, np.uint8, k),
-                          arr(r.rssi, np.float64, k), arr(r.sinr, np.float64, k) if r.sinr else np.zeros(k), arr(r.pkt_interference, np.uint8, p),
-                          arr(r.pkt_offset, np.uint32, p + 1))
+        return HostTickView(r)
 
     def batch_result_view(self, n_slots, raise_on_error=True):
         """Results of slots 0..n_slots-1 of the last batch, wrapped in place in the engine's pinned host
