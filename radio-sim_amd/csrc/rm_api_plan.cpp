@@ -108,6 +108,12 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.first_new = first_new;
     // caller records in device memory are not inspected by the host (rm_tick_run_device, rm_batch_run_device): without
     // the draw kernels a fractional txProbability in one of them cannot be honoured -- the kernels flag it
+    if (c->host_src && !src_list) { // rm_tick_flush*: the records are read where the host put them (no copy engine in the chain)
+        t.gather_src = c->host_src;
+        t.gather_slots = std::max(n_active, 1);
+        t.gather_stride = 0;
+        t.tx_build = const_cast<rm_tx_record *>(tx);
+    }
     t.check_txprob = (!stochastic && !src_list && c->dev_records_from_caller && c->params.kind != RM_MODEL_NULL && c->params.kind != RM_MODEL_UDGM_CONST) ? 1 : 0;
     t.first_eval = sinr ? 0 : first_new;
     const bool nothing_to_sweep = (n_new <= 0 || rx_count <= 0); // no launch at all: the lists stay as they are
@@ -342,6 +348,11 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         return e ? std::atoi(e) : 4096;
     }();
     const int seg_len = (t.n_active - t.first_new <= frame_tick_max) ? rm::frame_tick_segment(t, cfg, m) : 0;
+    if (t.gather_src && seg_len == 0 && t.filter_mode != rm::kFilterWg) {
+        // only the one-launch tick and the two-level filter's pre-pass read records from the host's block: the other
+        // kernels want them in device memory first
+        RM_HIP(hipMemcpyAsync(t.tx_build, t.gather_src, size_t(t.n_active) * sizeof(rm_tx_record), hipMemcpyHostToDevice, s));
+    }
     auto sequence = [&]() -> int {
         const bool air = sinr && t.air.pool != nullptr;
         const bool air_in_prep = air && t.filter_mode == rm::kFilterWg; // k_tick_prep leaves the SELF entries and looks at the sticky flag

@@ -184,6 +184,8 @@ int tick_run_host(rm_context *c)
     const size_t n_old = (air_mode == kAirIncremental) ? 0 : c->onair.size();
     const int first_new = int(n_old);
     const size_t total = n_old + c->pending.size();
+    bool zero_copy = false;
+    int staged = -1;
     RM_HIP(c->d_tx.ensure(std::max<size_t>(total, 1)));
     if (total) {
         // through pinned staging: the copy is asynchronous, the buffer is reused only after its copy has completed
@@ -196,15 +198,24 @@ int tick_run_host(rm_context *c)
             c->h_tx[g] = nullptr;
             c->h_tx_n[g] = 0;
             const size_t want = std::max<size_t>(total + total / 2, 1024);
-            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_tx[g]), want * sizeof(rm_tx_record), hipHostMallocDefault));
+            RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_tx[g]), want * sizeof(rm_tx_record), hipHostMallocMapped));
             c->h_tx_n[g] = want;
         }
         if (n_old) std::memcpy(c->h_tx[g], c->onair.data(), n_old * sizeof(rm_tx_record));
         if (!c->pending.empty()) std::memcpy(c->h_tx[g] + n_old, c->pending.data(), c->pending.size() * sizeof(rm_tx_record));
-        RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
-        RM_HIP(hipEventRecord(c->h_tx_ev[g], c->stream));
+        // A tick of a few thousand frames: the kernels read the records straight from this pinned, host-mapped block (every
+        // frame's workgroup fetches its own 64 bytes and leaves them in device memory for whoever comes later) -- a copy
+        // engine's ~10 us hand-over per tick is most of what the transfer costs.  Larger ticks and the SINR medium (whose
+        // rebuilds sweep old frames too) take the copy.
+        static const bool no_zero_copy = std::getenv("RM_NO_ZERO_COPY") != nullptr;
+        zero_copy = !sinr && !no_zero_copy && total <= 8192;
+        if (!zero_copy) RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
+        c->host_src = zero_copy ? c->h_tx[g] : nullptr;
+        staged = g;
     }
     const int rc = run_tick(c, c->d_tx.p, int(total), first_new, nullptr, 0, 0, air_mode, oldest);
+    c->host_src = nullptr;
+    if (staged >= 0) RM_HIP(hipEventRecord(c->h_tx_ev[staged], c->stream)); // (the block is rewritten only after whatever read it)
     c->tick_frac_records = false;
     if (rc != RM_OK) {
         c->air.valid = false;

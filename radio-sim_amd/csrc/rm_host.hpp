@@ -261,6 +261,7 @@ struct rm_context : TickSlot {
     size_t h_tx_n[2] = {0, 0};
     hipEvent_t h_tx_ev[2] = {nullptr, nullptr};
     int h_tx_gen = 0;
+    const rm_tx_record *host_src = nullptr; // the tick being prepared reads its records from this host-mapped block (prepare_tick)
     uint32_t transmit_seq = 0;
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
     // larger batches: k_fetch_ticks reads them from pinned, host-mapped memory (two staging buffers, each

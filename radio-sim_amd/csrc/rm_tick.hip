@@ -96,7 +96,9 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
     const bool build = t.src_list != nullptr;
     rm_tx_record tx;
     int s_idx = -1;
+    const bool from_host = !build && t.gather_src != nullptr; // the records still lie in the host's pinned block (rm_tick_flush*)
     if (build) s_idx = t.src_list[real ? q : 0];
+    else if (from_host) tx = t.gather_src[size_t(abs_i / t.gather_slots) * size_t(t.gather_stride) + size_t(abs_i % t.gather_slots)];
     else tx = t.tx[abs_i];
 
     // the first round's boxes do not depend on the frame (branch-free: the index is clamped, validity is tested at use)
@@ -147,7 +149,7 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
         }
         return;
     }
-    if (build && tid == 0) t.tx_build[abs_i] = tx;
+    if ((build || from_host) && tid == 0) t.tx_build[abs_i] = tx; // where every later consumer of the tick finds the record
     if (!STOCH && t.check_txprob && tid == 0 && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u;
     float4 f;
     double thr64;
