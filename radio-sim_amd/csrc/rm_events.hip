@@ -31,7 +31,6 @@
 namespace rm {
 
 constexpr int64_t kI64Min = int64_t(0x8000000000000000ull);
-constexpr int kEvKeyTile = 512; // fired groups' keys staged in LDS at a time (k_ev_emit)
 
 RM_D void amax_i64(int64_t *p, int64_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RM_D unsigned long long ev_key(uint32_t rank, uint32_t kind, uint32_t ref)
@@ -217,39 +216,34 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
 // nothing the contest decides, and their stores into host-mapped memory (PCIe-bound) then run under the state update.
 __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
 {
-    __shared__ int64_t s_kt[kEvKeyTile];
-    __shared__ uint64_t s_km[kEvKeyTile];
-    __shared__ uint32_t s_kc[kEvKeyTile];
     const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
-    for (uint32_t g0 = blockIdx.x * 4; g0 < G; g0 += gridDim.x * 4) { // block-uniform: the four waves share the key tiles
-        const uint32_t g = g0 + uint32_t(wave_index());
-        const bool have = g < G; // wave-uniform
+    for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
+        const uint32_t ref = uniform_u(e.g_ref[g]);
         // The group's place in the queue's pop order = the number of fired groups with a smaller key (keys are unique), and
-        // the place of its deliveries in the list = the deliveries of those groups: one pass over all groups' keys -- no
-        // sort, no scan, no launch in between.  The workgroup stages the keys through LDS, 512 at a time: every key
-        // leaves L2 once per workgroup, not once per wave.
+        // the place of its deliveries in the list = the deliveries of those groups: one pass of the wave over all groups'
+        // keys (a few thousand, L2-resident) -- no sort, no scan, no launch in between.
         uint32_t r = 0, first = 0;
         {
-            const int64_t tg = have ? e.g_time[g] : 0;
-            const uint64_t mg = have ? e.g_meta[g] : 0ull;
-            for (uint32_t k0 = 0; k0 < G; k0 += uint32_t(kEvKeyTile)) { // block-uniform
-                __syncthreads();
-                for (uint32_t k = threadIdx.x; k < uint32_t(kEvKeyTile); k += blockDim.x) {
-                    const bool in = k0 + k < G;
-                    s_kt[k] = in ? e.g_time[k0 + k] : int64_t(0x7FFFFFFFFFFFFFFFll); // padding: larger than every key
-                    s_km[k] = in ? e.g_meta[k0 + k] : ~0ull;
-                    s_kc[k] = in ? e.cnt_by_rank[k0 + k] : 0u;
-                }
-                __syncthreads();
+            const int64_t tg = e.g_time[g];
+            const uint64_t mg = e.g_meta[g];
+            for (uint32_t k0 = 0; k0 < G; k0 += 64 * 8) { // eight groups per lane in flight: the pass is a chain of L2 round trips
+                int64_t tk[8];
+                uint64_t mk[8];
+                uint32_t ck[8];
 #pragma unroll
-                for (int u = 0; u < kEvKeyTile / 64; ++u) {
-                    const int k = u * 64 + lane;
-                    const int64_t tk = s_kt[k];
-                    const uint64_t mk = s_km[k];
-                    const bool less = tk < tg || (tk == tg && mk < mg);
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t k = k0 + uint32_t(u) * 64u + uint32_t(lane);
+                    const bool in = k < G;
+                    tk[u] = in ? e.g_time[k] : int64_t(0x7FFFFFFFFFFFFFFFll);
+                    mk[u] = in ? e.g_meta[k] : ~0ull;
+                    ck[u] = in ? e.cnt_by_rank[k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool less = tk[u] < tg || (tk[u] == tg && mk[u] < mg);
                     r += less ? 1u : 0u;
-                    first += less ? s_kc[k] : 0u;
+                    first += less ? ck[u] : 0u;
                 }
             }
             for (int d = 32; d >= 1; d >>= 1) {
@@ -258,13 +252,11 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
             }
             r = uniform_u(r);
             first = uniform_u(first);
-            if (have && lane == 0) {
+            if (lane == 0) {
                 e.g_rank[g] = r;        // k_ev_apply recomputes the events' keys from it ...
                 e.off_by_rank[g] = first; // ... and writes the group's deliveries from here on
             }
         }
-        if (!have) continue; // (after the tiles: the barriers above are the whole workgroup's)
-        const uint32_t ref = uniform_u(e.g_ref[g]);
         const EvPacket &p = e.pk[ref >> 1];
         const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
         const int src = uniform_i(p.src);
