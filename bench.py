@@ -543,6 +543,32 @@ def main():
         lib_dist = batch > 1 and not stateful and ((world > 1 and args.collective != "torch" and backend == "nccl")
                                                   or (world == 1 and args.collective == "lib" and not as_rank))
         if lib_dist:
+            # one communicator per context (their collectives are independent): rank 0 makes the ids, torch.distributed -- here
+            # only the out-of-band channel -- hands them round, every rank joins with ncclCommInitRank inside the library.
+            # If the library cannot have RCCL on some rank (rm_comm_available), every rank falls back to torch's collective.
+            ok = 1 if rsa.Engine.comm_available() else 0
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok and args.collective != "lib" and os.environ.get("RM_BENCH_NO_LIB_COLLECTIVE") == "1":
+                ok = 0
+            if ok:
+                for e in engines:
+                    if world > 1:
+                        e.set_partition_spatial(rank, world) if spatial else e.set_partition(lo, hi - lo)
+                    uid = torch.from_numpy(rsa.Engine.comm_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8))
+                    if world > 1:
+                        uid = uid.to(dev)
+                        dist.broadcast(uid, src=0)
+                        uid = uid.cpu()
+                    e.comm_init_rank(uid.numpy(), world, rank)
+            elif args.collective == "lib":
+                raise SystemExit("--collective lib: RCCL could not be bound inside libradiomedium_hip.so on every rank")
+            else:
+                print("bench: the library could not bind RCCL on every rank: torch.distributed runs the collective", file=sys.stderr)
+                lib_dist = False
+        if lib_dist:
             use_sharded = False
         pad_dev, slots = None, 0
         with torch.cuda.stream(stream):
@@ -573,19 +599,6 @@ def main():
                 sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch, on_air=stateful,
                                         spatial=spatial)
         stream.synchronize()
-        if lib_dist:
-            # one communicator per context (their collectives are independent): rank 0 makes the ids, torch.distributed -- here
-            # only the out-of-band channel -- hands them round, every rank joins with ncclCommInitRank inside the library
-            for e in engines:
-                if world > 1:
-                    e.set_partition_spatial(rank, world) if spatial else e.set_partition(lo, hi - lo)
-                uid = torch.from_numpy(rsa.Engine.comm_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8))
-                if world > 1:
-                    uid = uid.to(dev)
-                    dist.broadcast(uid, src=0)
-                    uid = uid.cpu()
-                e.comm_init_rank(uid.numpy(), world, rank)
-
         links_done = [0]
         last_run = [eng, 0]     # (context, result slot) of the last tick issued
         ctx_rr = [0]
@@ -861,8 +874,10 @@ def main():
                            "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
                            "step": "one launch sequence sweeping ticks_per_step simulated ticks",
                            "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
-                           "sharding": ("receivers partitioned over %d ranks (%s), RCCL all-gather of Tx records per batch of ticks"
-                                        % (world, "regions of the k-d order" if spatial else "node index ranges")) if world > 1 else "none"},
+                           "sharding": ("receivers partitioned over %d ranks (%s), RCCL all-gather of Tx records per batch of ticks (%s)"
+                                        % (world, "regions of the k-d order" if spatial else "node index ranges",
+                                           "ncclAllGather inside libradiomedium_hip.so: pack + collective + sweep in one call" if lib_dist
+                                           else "torch.distributed around the engine calls")) if world > 1 else "none"},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_profile_file": traffic is not None,
                              "traffic_source": pmc_note,
