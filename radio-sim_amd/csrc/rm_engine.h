@@ -1,4 +1,4 @@
-// rm_engine.h -- internal interface between the C-ABI host code (rm_api.cpp) and the
+// rm_engine.h -- internal interface between the C-ABI host code (rm_api_*.cpp behind rm_host.hpp) and the
 // gfx950 kernels (rm_*.hip).  Not part of the public boundary (include/radiomedium_hip.h).
 //
 // The gfx950 (CDNA4, wave64) kernels of the radio-medium engine, in short:
@@ -21,7 +21,7 @@
 // Files: rm_math.hpp (exact arithmetic: E-math, link hash, Q80, java.util.Random), rm_device.hpp
 // (shared device code: wave helpers, pre-filter records, eval_link, fused scans), rm_filter.hip,
 // rm_exact.hip, rm_reorder.hip, rm_transmit.hip, rm_tick.hip, rm_events.hip (kernels + their launchers),
-// rm_evorder.hpp (the reference event queue's pop order as a sort key), rm_api.cpp (C ABI).
+// rm_evorder.hpp (the reference event queue's pop order as a sort key), rm_api_*.cpp (C ABI, by concern).
 #pragma once
 
 #include <hip/hip_runtime.h>
