@@ -337,6 +337,9 @@ int rm_slot_stats(rm_context *ctx, int32_t slot, uint64_t *candidates, uint64_t 
  * frames to the per-receiver interferer lists kept on the device, and how many rebuilt the lists from every frame on the
  * air (first tick, after a node / model / partition / capacity change, after a dropped tick, when t_begin went back) */
 int rm_air_list_stats(const rm_context *ctx, uint64_t *incremental_ticks, uint64_t *rebuilt_ticks);
+/* ... and how many ticks needed no lists at all: a tick of at most 4096 new frames over a spatially sorted table finds the
+ * interferers of its heard links among the frames on the air themselves (rm_airscan.hip; RM_SINR_SCAN=0 keeps the lists) */
+int rm_air_scan_ticks(const rm_context *ctx, uint64_t *scan_ticks);
 /* the entry ring behind those lists (synchronises): entries allocated since the lists were last rebuilt in the busiest of the
  * 256 sub-rings, and the entries a sub-ring holds -- more allocated than held: the ring has gone round (old entries were reclaimed) */
 int rm_air_ring_stats(rm_context *ctx, uint64_t *max_allocated, uint64_t *sub_ring_entries);

@@ -176,6 +176,7 @@ SIGNATURES = {
     "rm_slot_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_air_ring_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_air_list_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rm_air_scan_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rm_group_create": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rm_group_destroy": (None, [C.c_void_p]),
     "rm_group_size": (C.c_int, [C.c_void_p]),

@@ -228,7 +228,8 @@ void TickSlot::release_all()
     d_st_lin.release(); d_st_sinr.release(); d_st_prob.release(); d_st_orig.release(); d_st_flags.release(); d_st_coll.release();
     d_out_pkt.release(); d_out_dst.release(); d_a_pkt.release(); d_a_dst.release(); d_out_verdict.release(); d_pkt_interf.release();
     d_a_verdict.release(); d_out_rssi.release(); d_out_sinr.release(); d_out_prob.release(); d_a_rssi.release(); d_a_sinr.release();
-    d_a_prob.release(); d_draw_scan.release(); d_scan_block.release(); d_pkt_rng.release(); d_pkt_draw_cnt.release(); d_all_cnt.release();
+    d_a_prob.release(); d_draw_scan.release(); d_scan_block.release(); d_scan_xyzr.release(); d_scan_ch.release(); d_sg_cnt.release(); d_sg_bxyzr.release(); d_sg_bci.release(); d_sg_every.release();
+    d_self_next.release(); d_self_slot.release(); sg_clean[0] = sg_clean[1] = false; d_pkt_rng.release(); d_pkt_draw_cnt.release(); d_all_cnt.release();
     alloc_cap = 0;
     alloc_feat = 0;
     have_result = false;
@@ -444,6 +445,13 @@ int rm_air_list_stats(const rm_context *c, uint64_t *incremental_ticks, uint64_t
     if (!c) return fail(RM_ERR_INVALID, "ctx is NULL");
     if (incremental_ticks) *incremental_ticks = c->air.incremental;
     if (rebuilt_ticks) *rebuilt_ticks = c->air.rebuilds;
+    return RM_OK;
+}
+
+int rm_air_scan_ticks(const rm_context *c, uint64_t *scan_ticks)
+{
+    if (!c || !scan_ticks) return fail(RM_ERR_INVALID, "NULL argument");
+    *scan_ticks = c->air.scans;
     return RM_OK;
 }
 

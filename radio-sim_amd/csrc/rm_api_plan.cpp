@@ -78,6 +78,30 @@ bool air_lists_current(const rm_context *c, int64_t t_begin, uint32_t oldest)
     return a.pool.p != nullptr && a.sub_cap == air_sub_cap(c) && a.head.n >= size_t(std::max(c->n_rx, 1));
 }
 
+// frames per tick up to which a lone tick takes the one-frame-per-workgroup path (RM_FRAME_TICK=0: never)
+static int frame_tick_max()
+{
+    static const int v = [] {
+        const char *e = std::getenv("RM_FRAME_TICK");
+        return e ? std::atoi(e) : 4096;
+    }();
+    return v;
+}
+
+// Can this tick of the SINR medium be evaluated by scan (rm_airscan.hip)?  Exactly when the one-launch tick applies to its
+// new frames (rm::frame_tick_segment: sorted table with boxes, fp32 pre-filter, room for the frames' segments): then no
+// per-receiver lists are needed at all.  RM_SINR_SCAN=0 / RM_SINR_FRAMES=0 (read per tick: tests switch them) keep the lists.
+bool air_scan_applies(rm_context *c, int n_new)
+{
+    const char *e_scan = std::getenv("RM_SINR_SCAN"), *e_fr = std::getenv("RM_SINR_FRAMES");
+    if ((e_scan && std::atoi(e_scan) == 0) || (e_fr && std::atoi(e_fr) == 0)) return false;
+    if (!is_sinr(c) || n_new <= 0 || n_new > frame_tick_max() || c->n_rx <= 0) return false;
+    if (!c->rx_sorted || c->f32_slack > 0.05) return false; // (LaunchCfg::sorted / bbox / f64_filter of prepare_tick)
+    const int n_cnt = ((n_new + rm::kTxChunk - 1) / rm::kTxChunk) * rm::kTxChunk;
+    if (n_cnt > rm::kFusedScanMax) return false;
+    return (c->cap / 2u) / uint32_t(n_cnt) >= 64u;
+}
+
 int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, const rm_tx_record *tx, int n_active,
                  int first_new, const int32_t *src_list, int64_t src_start_us, int64_t src_air_us, int air_mode,
                  uint32_t air_oldest, const rm::PlanKnobs *knobs_in)
@@ -115,11 +139,59 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
         t.tx_build = const_cast<rm_tx_record *>(tx);
     }
     t.check_txprob = (!stochastic && !src_list && c->dev_records_from_caller && c->params.kind != RM_MODEL_NULL && c->params.kind != RM_MODEL_UDGM_CONST) ? 1 : 0;
-    t.first_eval = sinr ? 0 : first_new;
+    t.first_eval = (sinr && air_mode != kAirScan) ? 0 : first_new;
     const bool nothing_to_sweep = (n_new <= 0 || rx_count <= 0); // no launch at all: the lists stay as they are
     if (sinr && air_mode == kAirRebuild && nothing_to_sweep) c->air.valid = false; // rebuilt with the next frames
     if (sinr && air_mode == kAirIncremental && nothing_to_sweep) c->air.last_t_begin = c->t_begin;
-    if (sinr && air_mode != kAirNone && !nothing_to_sweep) {
+    if (sinr && air_mode == kAirScan) {
+        // by scan: every frame on the air is in `tx`, nothing is kept per receiver -- and whatever the lists hold is stale now
+        c->air.valid = false;
+        if (!nothing_to_sweep) {
+            c->air.scans++;
+            rm::ScanDev &sd = plan.scan;
+            sd = rm::ScanDev{};
+            t.air_scan = 1;
+            t.air.t_begin = c->t_begin;
+            sd.level = model_dev(c).ld_level;
+            const size_t frames = size_t(std::max(n_active, 1));
+            const size_t cnt_len = size_t(rm::kSgCells) + 1 + rm::kSgMax;
+            RM_HIP(ts.d_scan_xyzr.ensure(frames));
+            RM_HIP(ts.d_scan_ch.ensure(frames));
+            RM_HIP(ts.d_sg_every.ensure(frames));
+            RM_HIP(ts.d_self_next.ensure(frames));
+            if (!ts.d_sg_cnt.p) {
+                RM_HIP(ts.d_sg_cnt.ensure(2 * cnt_len));
+                RM_HIP(ts.d_sg_bxyzr.ensure(size_t(rm::kSgCells) * rm::kSgK));
+                RM_HIP(ts.d_sg_bci.ensure(size_t(rm::kSgCells) * rm::kSgK));
+                ts.sg_clean[0] = ts.sg_clean[1] = false;
+            }
+            if (ts.d_self_slot.n < size_t(std::max(c->n, 1))) {
+                RM_HIP(ts.d_self_slot.ensure(size_t(std::max(c->n, 1))));
+                RM_HIP(hipMemsetAsync(ts.d_self_slot.p, 0, ts.d_self_slot.n * sizeof(unsigned long long), c->stream));
+            }
+            if (uint32_t(c->air.scans) == 0u) { // (the stamps have gone round: forget the old ones)
+                c->air.scans++;
+                RM_HIP(hipMemsetAsync(ts.d_self_slot.p, 0, ts.d_self_slot.n * sizeof(unsigned long long), c->stream));
+            }
+            const int par = ts.sg_parity;
+            // this tick's counters were zeroed by the tick by scan before it (k_sinr_scan); anything else in between: by a fill
+            if (!ts.sg_clean[par]) RM_HIP(hipMemsetAsync(ts.d_sg_cnt.p + size_t(par) * cnt_len, 0, cnt_len * sizeof(uint32_t), c->stream));
+            ts.sg_clean[0] = ts.sg_clean[1] = false; // (this one is used now; the other is zeroed by this tick's second launch: launch_tick)
+            ts.sg_parity = par ^ 1;
+            sd.xyzr = ts.d_scan_xyzr.p;
+            sd.ch = ts.d_scan_ch.p;
+            sd.cnt = ts.d_sg_cnt.p + size_t(par) * cnt_len;
+            sd.cnt_next = ts.d_sg_cnt.p + size_t(par ^ 1) * cnt_len;
+            sd.bucket_xyzr = ts.d_sg_bxyzr.p;
+            sd.bucket_ci = ts.d_sg_bci.p;
+            sd.every = ts.d_sg_every.p;
+            sd.self_slot = ts.d_self_slot.p;
+            sd.self_next = ts.d_self_next.p;
+            sd.stamp = uint32_t(c->air.scans);
+            sd.half = std::max(float(c->coord_bound), 1e-20f);
+            sd.inv = float(rm::kSgG) / (2.0f * sd.half);
+        }
+    } else if (sinr && air_mode != kAirNone && !nothing_to_sweep) {
         // the lists that live across ticks: kAirIncremental -- `tx` holds the new frames only (first_new == 0);
         // kAirRebuild -- `tx` holds every frame on the air and all of them leave their entries again
         rm_context::AirLists &a = c->air;
@@ -342,12 +414,8 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         }
         return RM_OK;
     };
-    // frames per tick up to which a lone tick takes the one-frame-per-workgroup path (RM_FRAME_TICK=0: never)
-    static const int frame_tick_max = [] {
-        const char *e = std::getenv("RM_FRAME_TICK");
-        return e ? std::atoi(e) : 4096;
-    }();
-    const int seg_len = (t.n_active - t.first_new <= frame_tick_max) ? rm::frame_tick_segment(t, cfg, m) : 0;
+    const int seg_len = (t.n_active - t.first_new <= frame_tick_max()) ? rm::frame_tick_segment(t, cfg, m) : 0;
+    if (t.air_scan && seg_len == 0) return fail(RM_ERR_STATE, "internal: a tick planned by scan cannot take the one-launch form");
     if (t.gather_src && seg_len == 0 && t.filter_mode != rm::kFilterWg) {
         // only the one-launch tick and the two-level filter's pre-pass read records from the host's block: the other
         // kernels want them in device memory first
@@ -357,13 +425,13 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         const bool air = sinr && t.air.pool != nullptr;
         const bool air_in_prep = air && t.filter_mode == rm::kFilterWg; // k_tick_prep leaves the SELF entries and looks at the sticky flag
         if (air && !air_in_prep) RM_HIP(rm::launch_air_begin(s, t));
-        else if (sinr && !air) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
+        else if (sinr && !air && !t.air_scan) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
         if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         if (seg_len > 0) {
             // the closed-loop tick: filter, exact evaluation and node order of a frame inside one workgroup
             // (rm_tick.hip) -- ONE launch; the compact arrays only for the draw kernels, or on demand
             RM_TRY(stage(RM_STAGE_FILTER));
-            RM_HIP(rm::launch_tick_frames(s, nd, m, t, cfg, seg_len));
+            RM_HIP(rm::launch_tick_frames(s, nd, m, t, cfg, seg_len, t.air_scan ? &plan.scan : nullptr));
             if (stochastic) {
                 RM_TRY(stage(RM_STAGE_REORDER));
                 rm::TickDev tr = t;
@@ -461,6 +529,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         ts.draws_pending = true;
         ts.pending_model = m;
     }
+    if (t.air_scan) ts.sg_clean[ts.sg_parity] = true; // (k_sinr_scan has zeroed the next tick's index counters)
     ts.compact_pending = seg_len > 0 && !stochastic;
     ts.last.seg_ordered = (seg_len > 0) ? 1 : 0;
     ts.last_model = m;

@@ -179,7 +179,9 @@ int tick_run_host(rm_context *c)
         c->onair_tick.resize(c->onair.size(), 0u);
         for (uint32_t k : c->onair_tick) oldest = (oldest == 0 || k < oldest) ? k : oldest;
         const bool unknown = std::find(c->onair_tick.begin(), c->onair_tick.end(), 0u) != c->onair_tick.end();
-        air_mode = (!unknown && air_lists_current(c, c->t_begin, oldest)) ? kAirIncremental : kAirRebuild;
+        RM_TRY(prepare_nodes(c)); // (a changed table makes the lists stale, and decides whether the tick can go by scan)
+        if (air_scan_applies(c, int(c->pending.size()))) air_mode = kAirScan; // every frame on the air goes to the device, no lists
+        else air_mode = (!unknown && air_lists_current(c, c->t_begin, oldest)) ? kAirIncremental : kAirRebuild;
     }
     const size_t n_old = (air_mode == kAirIncremental) ? 0 : c->onair.size();
     const int first_new = int(n_old);
@@ -224,7 +226,7 @@ int tick_run_host(rm_context *c)
     if (sinr) {
         if (air_mode == kAirRebuild) std::fill(c->onair_tick.begin(), c->onair_tick.end(), c->air.tick);
         c->onair.insert(c->onair.end(), c->pending.begin(), c->pending.end());
-        c->onair_tick.resize(c->onair.size(), c->air.tick);
+        c->onair_tick.resize(c->onair.size(), air_mode == kAirScan ? 0u : c->air.tick); // (0: not in the lists)
     }
     c->pending.clear();
     return RM_OK;
@@ -583,7 +585,9 @@ static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev
         unknown = unknown || bt.tick == 0;
         oldest = (oldest == 0 || bt.tick < oldest) ? bt.tick : oldest;
     }
-    const int air_mode = (!unknown && air_lists_current(c, t_begin_us, oldest)) ? kAirIncremental : kAirRebuild;
+    RM_TRY(prepare_nodes(c)); // (a changed table makes the lists stale, and decides whether the tick can go by scan)
+    const int air_mode = air_scan_applies(c, n) ? kAirScan
+                                                : ((!unknown && air_lists_current(c, t_begin_us, oldest)) ? kAirIncremental : kAirRebuild);
     // the records of the new frames are built at the window's tail either way; an incremental tick sweeps only those
     const int first_new = (air_mode == kAirIncremental) ? 0 : int(live);
     const rm_tx_record *base = c->d_air.p + c->air_head + (air_mode == kAirIncremental ? live : 0);
@@ -595,7 +599,7 @@ static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev
     if (air_mode == kAirRebuild)
         for (auto &bt : c->air_batches) bt.tick = c->air.tick;
     c->air_tail += size_t(n);
-    if (n > 0) c->air_batches.push_back({n, latest_end_us, c->air.tick});
+    if (n > 0) c->air_batches.push_back({n, latest_end_us, air_mode == kAirScan ? 0u : c->air.tick}); // (0: not in the lists)
     return RM_OK;
 }
 

@@ -80,6 +80,44 @@ RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, dou
     }
 }
 
+// One frame on the air, indexed for the second launch of a tick by scan (rm_airscan.hip; ScanDev):
+// where it is in the fp32 frame and how far it can matter at the level of `m` -- the pre-filter's own cut-off, as a radius --,
+// its cell of the frame grid, and its place in its source node's chain of frames (half duplex does not ask for reach).
+RM_D float sqrt_up(float v) { return nextafterf(__builtin_sqrtf(v), __builtin_inff()); }
+RM_D int sg_cell1(float x, float half, float inv) // (monotone in x: a range of positions maps to a range of cells)
+{
+    const int c = int((x + half) * inv);
+    return min(max(c, 0), kSgG - 1);
+}
+RM_D void scan_index(const ModelDev &m, const TickDev &t, const ScanDev &sd, int n_nodes, int i, const rm_tx_record &r)
+{
+    float4 f;
+    double thr64;
+    tx_prefilter(m, r, f, thr64);
+    const bool on_air = r.src >= 0 && r.src < n_nodes && r.start_us + r.air_us > t.air.t_begin;
+    float rad = -1.f;
+    if (on_air && f.w >= 0.f) rad = (f.w < __builtin_inff()) ? sqrt_up(f.w) : __builtin_inff();
+    sd.xyzr[i] = make_float4(f.x, f.y, f.z, rad);
+    sd.ch[i] = r.channel;
+    if (!on_air) return;
+    const unsigned long long stamp = (unsigned long long)sd.stamp << 32;
+    const unsigned long long old = atomicExch(&sd.self_slot[r.src], stamp | (unsigned long long)uint32_t(i));
+    sd.self_next[i] = ((old >> 32) == sd.stamp) ? int(uint32_t(old)) : -1;
+    if (rad < 0.f) return;
+    bool placed = false;
+    if (rad < __builtin_inff()) {
+        const int cell = sg_cell1(f.y, sd.half, sd.inv) * kSgG + sg_cell1(f.x, sd.half, sd.inv);
+        const uint32_t k = atomicAdd(&sd.cnt[cell], 1u);
+        if (k < uint32_t(kSgK)) {
+            sd.bucket_xyzr[cell * kSgK + int(k)] = make_float4(f.x, f.y, f.z, rad);
+            sd.bucket_ci[cell * kSgK + int(k)] = make_int2(r.channel, i);
+            placed = true;
+        }
+        atomicMax(&sd.cnt[kSgCells + 1 + (i & (kSgMax - 1))], __float_as_uint(rad)); // (radii are >= 0: their bits order like they do)
+    }
+    if (!placed) sd.every[atomicAdd(&sd.cnt[kSgCells], 1u)] = uint32_t(i); // no bound, or the cell is full: everybody looks at it
+}
+
 // engine position of a node in this partition's receiver table, -1 = not a receiver here (another rank's node, padding)
 RM_D int engine_pos(const NodesDev &nd, int node)
 {
@@ -250,7 +288,6 @@ RM_D LinkEval eval_link(const ModelDev &m, const NodesDev &nd, const rm_tx_recor
 // Exclusive scan of n per-frame counts inside one 256-thread workgroup, result in LDS (and in
 // `pub` if not null).  Every workgroup of a consumer kernel redoes it (T counts, a few KB from L2)
 // instead of paying a separate kernel for it.  Returns the total; *vmax gets the largest count.
-constexpr int kFusedScanMax = 8192;
 RM_D uint32_t block_scan_counts(const uint32_t *cnt, int n, uint32_t *s_off, uint32_t *s_wave /*[4]*/, uint32_t *pub,
                                 uint32_t *vmax_out)
 {

@@ -40,6 +40,8 @@ constexpr int kShadowBins = 256;    // bins over rho = d^2 / cut^2 of the shadow
 constexpr double kShadowPad = 0.02; // relative pad on rho folded into the table
 enum { kFilterGrid = 0, kFilterWg = 2 }; // TickDev::filter_mode (plan_filter)
 constexpr int kShardStride = 32;
+constexpr int kSgG = 64, kSgCells = kSgG * kSgG, kSgK = 16, kSgMax = 64; // the frame grid of a tick by scan (TickDev::sg_*)
+constexpr int kFusedScanMax = 8192; // per-frame counts a consumer kernel scans by itself in LDS (block_scan_counts, rm_device.hpp)
 constexpr int kFrameSegMax = 512;   // heard links of one frame kept in LDS by k_tick_frames (rm_tick.hip) = its fixed segment of the A records
 constexpr int kMaxBatch = RM_MAX_BATCH; // ticks per batched launch (descriptors in device memory)    // u32 words between shard counters: one 128-byte line each
 
@@ -164,6 +166,26 @@ struct AirDev {
     int64_t t_begin;           // entries with start + air <= t_begin have left the air
 };
 
+// The SINR medium's lone tick "by scan" (rm_airscan.hip): every heard link of a new frame finds its interferers among the
+// frames on the air themselves -- no per-receiver lists.  The first launch (k_tick_frames) leaves one scan record per
+// frame on the air and indexes them, from scratch every tick (nothing to keep current): a kSgG x kSgG grid over the fp32
+// frame with up to kSgK frames per cell, the rest -- and frames without a place or a bound -- in a list every new frame
+// looks at; the largest radius; and per NODE the chain of its own frames on the air (half duplex).
+struct ScanDev {
+    double level;           // the level a link has to reach to interfere (ModelDev::ld_level of the SINR medium)
+    float4 *xyzr;           // [n_active] position in the fp32 frame + cut-off radius at that level (-1: nobody; +inf: no bound)
+    int32_t *ch;            // [n_active] channel
+    uint32_t *cnt;          // [kSgCells] frames per cell, [kSgCells] entries of `every`, [kSgCells + 1 ..][kSgMax] largest radius (float bits)
+    uint32_t *cnt_next;     // the other parity, zeroed by k_sinr_scan for the next tick by scan
+    float4 *bucket_xyzr;    // [kSgCells][kSgK] the cell's frames: their scan records (a new frame tests them without a second round trip) ...
+    int2 *bucket_ci;        // ... channel, frame index
+    uint32_t *every;        // [n_active]
+    unsigned long long *self_slot; // [n] stamp << 32 | newest frame of the node on the air
+    int32_t *self_next;     // [n_active] the node's frame before that one, -1: none
+    uint32_t stamp;         // this tick's stamp (never 0)
+    float half, inv;        // cell = int((x + half) * inv)
+};
+
 struct TickDev {
     AirDev air;
     const rm_tx_record *tx; // on-air list, canonical order [n_active]
@@ -191,6 +213,8 @@ struct TickDev {
     int seg_ordered;        // the frames' segments are already in node order (rm_tick.hip): k_reorder only compacts them
     int check_txprob;       // records given by the caller on the device, tick evaluated without the draw kernels: a record whose
                             // txprob is strictly between 0 and 1 would need a draw -- flagged (RM_ERR_STATE when the result is read)
+    int air_scan;           // the SINR medium's lone tick "by scan" (rm_airscan.hip; ScanDev below): `tx` holds EVERY frame on the
+                            // air, only the new ones are swept (first_eval == first_new), nothing is kept per receiver
     int check_span;         // k_tick_prep verifies that every frame lies inside [span_begin, span_end] (SINR ticks whose
     int64_t span_begin, span_end; // records come from the caller: the batch is only valid if its ticks are self-contained)
     // per (slot, slab) heard counts / offsets (off is relative to the frame's first link), layout [(chunk*n_slabs + slab)*64 + lane]
@@ -448,7 +472,9 @@ int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m
 bool frames_cand_applies(const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_frames_cand(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg);
 hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg,
-                              int seg_len);
+                              int seg_len, const ScanDev *scan = nullptr);
+// (rm_airscan.hip) second launch of the SINR medium's lone tick by scan: interference sums, sinr and verdicts of the new frames' heard links
+hipError_t launch_sinr_scan(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const ScanDev &sd, const LaunchCfg &cfg);
 hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                                     const TickDev *dev_ticks, const LaunchCfg &cfg, int seg_len);
 hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t, int n_new, const HostView &v, uint32_t *done_counter,

@@ -98,6 +98,15 @@ struct TickSlot {
     DevBuf<uint8_t> d_out_verdict, d_pkt_interf, d_a_verdict;
     DevBuf<double> d_out_rssi, d_out_sinr, d_out_prob, d_a_rssi, d_a_sinr, d_a_prob;
     DevBuf<uint32_t> d_draw_scan, d_scan_block;
+    DevBuf<float4> d_scan_xyzr;  // the SINR medium's tick by scan: one record per frame on the air (TickDev::scan_xyzr / scan_ch) ...
+    DevBuf<int32_t> d_scan_ch;
+    DevBuf<uint32_t> d_sg_cnt, d_sg_every; // ... and the tick's index of them (ScanDev): counters in two parities, the cells' entries
+    DevBuf<float4> d_sg_bxyzr;
+    DevBuf<int2> d_sg_bci;
+    DevBuf<int32_t> d_self_next;
+    DevBuf<unsigned long long> d_self_slot; // per node; entries carry the tick's stamp (never cleared)
+    int sg_parity = 0;
+    bool sg_clean[2] = {false, false};      // the parity's counters are zero (the tick by scan before left them so)
     DevBuf<uint64_t> d_pkt_rng;
     DevBuf<uint32_t> d_pkt_draw_cnt, d_all_cnt;
     bool draws_pending = false; // partitioned + probabilistic: waiting for rm_tick_finish_draws
@@ -240,6 +249,7 @@ struct rm_context : TickSlot {
         uint32_t sub_cap = 0;     // entries per sub-ring (a power of two)
         int64_t last_t_begin = 0;
         uint64_t rebuilds = 0, incremental = 0;
+        uint64_t scans = 0;       // ticks evaluated by scan (rm_airscan.hip): they leave nothing in the lists
     } air;
     std::vector<uint32_t> onair_tick; // AirLists::tick per frame of `onair`
     bool dev_records_from_caller = false; // the tick being prepared takes rm_tx_record arrays the caller built in device memory
@@ -340,6 +350,7 @@ int ensure_link_buffers(rm_context *c, TickSlot &ts, int feat);
 // What one tick's launch sequence needs besides the slot: filled by prepare_tick.
 struct TickPlan {
     rm::TickDev t{};
+    rm::ScanDev scan{};  // (t.air_scan only)
     rm::LaunchCfg cfg{};
     bool sinr = false, stochastic = false, partitioned = false;
     bool empty = false; // nothing to sweep: the result is an empty one
@@ -347,7 +358,10 @@ struct TickPlan {
 
 // Buffers and descriptor of one tick in result slot `ts`; `tx` is the on-air list in device memory
 // (build mode: where the records of the source indices `src_list` are written).
-enum { kAirNone = 0, kAirIncremental = 1, kAirRebuild = 2 };
+// kAirScan: `tx` holds every frame on the air (as for a rebuild), only the new ones are evaluated, their interferers are found
+// among the frames themselves (rm_airscan.hip); the lists are not touched and count as stale afterwards
+enum { kAirNone = 0, kAirIncremental = 1, kAirRebuild = 2, kAirScan = 3 };
+bool air_scan_applies(rm_context *c, int n_new); // (after prepare_nodes)
 uint32_t air_sub_cap(const rm_context *c);
 bool air_lists_current(const rm_context *c, int64_t t_begin, uint32_t oldest);
 int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, const rm_tx_record *tx, int n_active,

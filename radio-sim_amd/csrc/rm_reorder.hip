@@ -40,7 +40,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
             in_rssi = t.a_rssi[o];
             v = t.a_verdict[o];
             if (STOCH) in_prob = t.a_prob[o];
-            if (SINR) in_e = t.a_e[o];
+            if (SINR && !t.seg_ordered) in_e = t.a_e[o]; // (ordered segments carry sinr and verdict themselves)
         }
     }
 
@@ -105,10 +105,10 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 in_rssi = valid ? t.a_rssi[o] : 0.0;
                 v = valid ? t.a_verdict[o] : uint8_t(0);
                 in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
-                in_e = (SINR && valid) ? t.a_e[o] : 0;
+                in_e = (SINR && valid && !t.seg_ordered) ? t.a_e[o] : 0;
             }
             SinrOut so = {0.0, false};
-            if (SINR && t.seg_ordered) { // the one-launch tick: k_sinr_frames has written sinr and verdict into the segment
+            if (SINR && t.seg_ordered) { // the one-launch tick: k_sinr_frames / k_sinr_scan have written sinr and verdict into the segment
                 if (valid) so.sinr = t.a_sinr[o];
             } else if (SINR && t.air.pool != nullptr && valid) { // the lists that live across ticks: the walk happens here, one lane per heard link
                 const rm_tx_record &w = t.tx[t.first_new + q];
@@ -128,7 +128,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 t.out_dst[d] = mine;
                 t.out_rssi[d] = in_rssi;
                 uint8_t vv = v;
-                if (SINR && t.air.pool != nullptr) {
+                if (SINR && (t.seg_ordered || t.air.pool != nullptr)) {
                     t.out_sinr[d] = so.sinr;
                     if (so.collided) vv = RM_INTERFERED;
                 } else if (SINR) {

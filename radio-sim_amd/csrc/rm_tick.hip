@@ -60,7 +60,7 @@ RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
 }
 
 template <int MODEL, bool STOCH, bool SHADOW, bool FLAT, bool SINR = false>
-RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev &t, const int seg_len)
+RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev &t, const int seg_len, const ScanDev *sdp = nullptr)
 {
     // one LDS block, carved by hand: the lists are dead when a frame that outgrew its segment orders its links,
     // and that ordering wants all of it for a bitmap over the node indices (below)
@@ -141,6 +141,22 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
         if (SINR && tid == 0 && t.air.bad[0]) t.stage_count[1] = 1u; // the on-air lists are broken until the host rebuilds them
     }
     for (int i = blockIdx.x * blockDim.x + tid; i < t.zero_len; i += gridDim.x * blockDim.x) t.cand_tot_next[i] = 0u;
+
+    // the SINR medium's tick by scan (rm_airscan.hip): every frame on the air indexed for the second launch
+    if (MODEL == RM_MODEL_LOGDIST && !SINR && sdp != nullptr) {
+        const ScanDev &sd = *sdp;
+        ModelDev ml = m;
+        ml.ld_level = sd.level;
+        if (slot >= t.n_cnt) { // (the launch has extra workgroups for this behind the frames' own: one frame on the air per thread)
+            const int i = (slot - t.n_cnt) * int(blockDim.x) + tid;
+            if (i < t.n_active) {
+                // (a new frame given as a source index: the same record its own workgroup builds)
+                const rm_tx_record r = (build && i >= t.first_new) ? make_tx_record(nd, t.src_list[i - t.first_new], t.src_start_us, t.src_air_us)
+                                                                   : t.tx[i];
+                scan_index(ml, t, sd, nd.n, i, r);
+            }
+        }
+    }
 
     if (!real) { // padding slot of the per-frame counters (a batch launches the largest tick's grid for every tick)
         if (tid == 0 && slot < t.n_cnt) {
@@ -539,6 +555,15 @@ __global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const Mo
     tick_frames_body<MODEL, STOCH, SHADOW, FLAT>(nd, m, t, seg_len);
 }
 
+// ... and as the first launch of the SINR medium's tick by scan (rm_airscan.hip): the heard links as the medium without SINR
+// finds them, and every frame on the air indexed for the second launch
+template <bool STOCH, bool SHADOW, bool FLAT>
+__global__ void __launch_bounds__(256)
+k_tick_frames_scan(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len, const ScanDev sd)
+{
+    tick_frames_body<RM_MODEL_LOGDIST, STOCH, SHADOW, FLAT>(nd, m, t, seg_len, &sd);
+}
+
 // The SINR medium in the same form (a lone tick that only adds its new frames to the on-air lists, section 4.4 of
 // DESIGN.md): the exact phase also leaves the frame's significant links in their receivers' lists, and a second launch --
 // the lists are complete only when every frame of the tick has been evaluated -- walks them for the heard links.
@@ -860,7 +885,7 @@ int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m
     const bool sinr = m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR);
     const char *e_sf = getenv("RM_SINR_FRAMES"); // 0: the SINR medium's lone ticks through the sweep kernels (read per tick: tests switch it)
     const bool no_sinr_frames = e_sf && atoi(e_sf) == 0;
-    if (sinr && (no_sinr_frames || t.air.pool == nullptr || t.first_eval != t.first_new)) return 0; // (a rebuild sweeps old frames too)
+    if (sinr && !t.air_scan && (no_sinr_frames || t.air.pool == nullptr || t.first_eval != t.first_new)) return 0; // (a rebuild sweeps old frames too)
     if (!geometric || !cfg.sorted || !cfg.bbox || cfg.f64_filter || t.use_matrix) return 0;
     if (t.n_cnt <= 0 || t.n_cnt > kFusedScanMax || t.n_rx <= 0 || t.n_active <= t.first_new) return 0;
     // half of the records for the fixed segments, the rest for frames that outgrow theirs
@@ -869,25 +894,50 @@ int frame_tick_segment(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m
     return int(per < uint32_t(kFrameSegMax) ? (per / 64u) * 64u : uint32_t(kFrameSegMax));
 }
 
-hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg, int seg_len)
+hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const LaunchCfg &cfg, int seg_len,
+                              const ScanDev *scan)
 {
-    const dim3 grid(t.n_cnt), block(256);
+    dim3 grid(t.n_cnt);
+    const dim3 block(256);
     const int n_groups = cdiv(nd.n_rx, kGroup);
     static const int flat_max = [] {
         const char *e = getenv("RM_FR_FLAT_MAX");
         return e ? max(0, min(kFrGroups * 2, atoi(e))) : kFrFlatGroups;
     }();
-#define RM_FR2(MODEL, ST, SH)                                                                                          \
+#define RM_FR2(M_, MODEL, ST, SH)                                                                                      \
     do {                                                                                                               \
-        if (n_groups <= flat_max) hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, m, t, seg_len); \
-        else hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, m, t, seg_len);          \
+        if (n_groups <= flat_max) hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, M_, t, seg_len); \
+        else hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, M_, t, seg_len);         \
     } while (0)
-#define RM_FR(MODEL, SH)                                                                                               \
+#define RM_FR3(M_, MODEL, SH)                                                                                          \
     do {                                                                                                               \
-        if (cfg.stochastic) RM_FR2(MODEL, true, SH);                                                                   \
-        else RM_FR2(MODEL, false, SH);                                                                                 \
+        if (cfg.stochastic) RM_FR2(M_, MODEL, true, SH);                                                               \
+        else RM_FR2(M_, MODEL, false, SH);                                                                             \
     } while (0)
+#define RM_FR(MODEL, SH) RM_FR3(m, MODEL, SH)
     static const bool no_shadow = getenv("RM_FR_NO_SHADOW") != nullptr;
+    if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR) && t.air_scan) {
+        // the tick by scan: the heard links as the medium without SINR finds them (cut-off at the sensitivity, nothing
+        // left per receiver), then the interference sums from the frames on the air themselves (rm_airscan.hip)
+        if (scan == nullptr) return hipErrorInvalidValue;
+        ModelDev ms = m;
+        ms.ld_level = m.ld_sens;
+        grid.x += unsigned(cdiv(t.n_active, 256)); // (workgroups that index the frames on the air)
+        const bool sh = cfg.shadow && m.shadow_tbl && !no_shadow;
+        const bool flat = n_groups <= flat_max;
+#define RM_FSC(ST, SH, FL) hipLaunchKernelGGL((k_tick_frames_scan<ST, SH, FL>), grid, block, 0, s, nd, ms, t, seg_len, *scan)
+        if (cfg.stochastic) {
+            if (sh) { if (flat) RM_FSC(true, true, true); else RM_FSC(true, true, false); }
+            else { if (flat) RM_FSC(true, false, true); else RM_FSC(true, false, false); }
+        } else {
+            if (sh) { if (flat) RM_FSC(false, true, true); else RM_FSC(false, true, false); }
+            else { if (flat) RM_FSC(false, false, true); else RM_FSC(false, false, false); }
+        }
+#undef RM_FSC
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_sinr_scan(s, nd, m, t, *scan, cfg);
+    }
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
         const bool sh = cfg.shadow && m.shadow_tbl && !no_shadow;
         const bool flat = n_groups <= flat_max;
@@ -914,6 +964,7 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     default: return hipErrorInvalidValue;
     }
 #undef RM_FR
+#undef RM_FR3
 #undef RM_FR2
     return hipGetLastError();
 }

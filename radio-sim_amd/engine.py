@@ -525,6 +525,12 @@ class Engine:
         check(self._L.rm_air_list_stats(self._h, C.byref(inc), C.byref(reb)))
         return inc.value, reb.value
 
+    def air_scan_ticks(self):
+        """ticks of the SINR extension evaluated by scan: interferers found among the frames on the air, no lists"""
+        v = C.c_uint64(0)
+        check(self._L.rm_air_scan_ticks(self._h, C.byref(v)))
+        return v.value
+
     def air_ring_stats(self):
         """(entries allocated in the busiest sub-ring since the lists were last rebuilt, entries a sub-ring holds)"""
         a, b = C.c_uint64(0), C.c_uint64(0)

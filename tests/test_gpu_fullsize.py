@@ -210,7 +210,8 @@ def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
         eng.close()
 
 
-def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
+@pytest.mark.parametrize("form", ["scan", "lists"])
+def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O, form, monkeypatch):
     """BASELINE configs[4] at its steady state: 8128 us frames over 1000 us ticks keep ~9 ticks of frames (8000-9000)
     on the air; the per-receiver interferer lists live on the device from tick to tick.  WHOLE ticks -- all 1000 new
     frames, every link -- are checked against the oracle with the FULL on-air list (8000+ frames) as interferers: a tick
@@ -222,6 +223,11 @@ def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
     nd = O.NodeTable(n)
     nd.x, nd.y = src_nd.x, src_nd.y
     params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 11}
+    # the default form of these ticks is the scan (rm_airscan.hip: the interferers found among the 9000 frames themselves,
+    # nothing kept per receiver); RM_SINR_SCAN=0 runs the same ticks through the lists, whose ring has to wrap as well
+    if form == "lists":
+        monkeypatch.setenv("RM_SINR_SCAN", "0")
+    n_ticks = 60 if form == "lists" else 16
     eng = rsa.Engine(0)
     try:
         eng.upload_table(nd)
@@ -233,7 +239,7 @@ def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
         checked = {10: "steady state", 13: "the tick a node moved in (lists rebuilt)", 14: "the tick after the rebuild",
                    59: "after the entry ring wrapped"}
         links = 0
-        for tick in range(60):
+        for tick in range(n_ticks):
             t0 = tick * 1000
             if tick == 13:                      # a receiver moves next to a sender: everything its entries were computed from changed
                 j = int(rng.integers(n))
@@ -254,9 +260,12 @@ def test_c5_steady_state_nine_thousand_frames_on_the_air(rsa, O):
                 assert (cpu.verdict == O.INTERFERED).sum() > 0      # the overlap does interfere
             onair = np.concatenate([onair, new])
         inc, reb = eng.air_list_stats()
-        assert reb == 2 and inc == 58, (inc, reb)     # the first tick and the one with the move
-        allocated, held = eng.air_ring_stats()
-        assert allocated > held > 0, (allocated, held)   # the entry ring has gone round since the rebuild: old entries were reclaimed
+        if form == "scan":
+            assert (inc, reb, eng.air_scan_ticks()) == (0, 0, n_ticks)
+        else:
+            assert reb == 2 and inc == 58, (inc, reb)     # the first tick and the one with the move
+            allocated, held = eng.air_ring_stats()
+            assert allocated > held > 0, (allocated, held)   # the entry ring has gone round since the rebuild: old entries were reclaimed
     finally:
         eng.close()
 

@@ -12,6 +12,16 @@ from util import (run_both, assert_same, random_nodes, to_tx_records, configure_
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["scan", "lists"])
+def sinr_form(request, monkeypatch):
+    """Both forms of the SINR medium's lone tick: by scan (the interferers of a heard link found among the frames on the air,
+    rm_airscan.hip -- the default wherever the one-launch tick applies) and with the per-receiver lists kept on the device
+    (RM_SINR_SCAN=0: what larger ticks and unsorted tables take)."""
+    if request.param == "lists":
+        monkeypatch.setenv("RM_SINR_SCAN", "0")
+    return request.param
+
+
 def _layout(O, n, seed, z=0.0, k=20.0):
     side = 50.0 * np.sqrt(np.pi * n / k)
     return random_nodes(O, n, side, seed=seed, z_span=z)
@@ -76,7 +86,7 @@ def _sinr_params(**kw):
     return p
 
 
-def test_sinr_single_tick_16_channels(engine, rsa, O):
+def test_sinr_single_tick_16_channels(engine, rsa, O, sinr_form):
     n, t = 3000, 400          # dense traffic: many co-channel collisions
     nd = _layout(O, n, seed=21)
     rng = np.random.default_rng(4)
@@ -90,7 +100,7 @@ def test_sinr_single_tick_16_channels(engine, rsa, O):
     assert_same(gpu, cpu, "sinr 16ch")
 
 
-def test_sinr_single_channel_heavy_interference(engine, rsa, O):
+def test_sinr_single_channel_heavy_interference(engine, rsa, O, sinr_form):
     n, t = 2000, 300
     nd = _layout(O, n, seed=22)
     rng = np.random.default_rng(5)
@@ -103,7 +113,7 @@ def test_sinr_single_channel_heavy_interference(engine, rsa, O):
     assert_same(gpu, cpu, "sinr 1ch")
 
 
-def test_sinr_multi_tick_overlap_and_half_duplex(engine, rsa, O):
+def test_sinr_multi_tick_overlap_and_half_duplex(engine, rsa, O, sinr_form):
     """Frames stay on the air over several ticks (8128 us frames, 1000 us ticks)."""
     n = 2500
     nd = _layout(O, n, seed=23)
@@ -134,7 +144,7 @@ def test_sinr_multi_tick_overlap_and_half_duplex(engine, rsa, O):
     assert total_interfered > 50
 
 
-def test_sinr_receiver_is_transmitting(engine, rsa, O):
+def test_sinr_receiver_is_transmitting(engine, rsa, O, sinr_form):
     """Half duplex: a node that is itself on the air cannot receive an overlapping frame."""
     nd = O.NodeTable(3)
     nd.x[:] = [0.0, 20.0, 40.0]
@@ -163,7 +173,7 @@ def test_logdist_far_origin(engine, rsa, O):
     assert_same(gpu, cpu, "logdist far origin")
 
 
-def test_sinr_device_resident_on_air_list(engine, rsa, O):
+def test_sinr_device_resident_on_air_list(engine, rsa, O, sinr_form):
     """rm_tick_run_sources_device with the SINR medium: the frames of earlier ticks stay on the
     device as interferers (batches expire by start + air > t_begin, also out of order)."""
     from util import DeviceArray
@@ -224,7 +234,7 @@ def _overlap_run(engine, rsa, O, nd, mdl, rng, ticks, per_tick, airs, hook=None,
     return interfered
 
 
-def test_sinr_lists_live_across_ticks(engine, rsa, O):
+def test_sinr_lists_live_across_ticks(engine, rsa, O, sinr_form):
     """The per-receiver interferer lists stay on the device: a tick adds its new frames only.  A small link capacity
     makes the entry rings wrap many times; frames of very different lengths leave the air out of order; empty ticks."""
     n = 10000                                       # enough receiver groups to spread the candidates over the shards
@@ -237,15 +247,18 @@ def test_sinr_lists_live_across_ticks(engine, rsa, O):
     engine.set_link_capacity(1 << 19 if not os.environ.get("RM_NO_SHADOW_TABLE") else 1 << 23)
     mdl = oracle_model(O, "logdist", params)
     inc0, reb0 = engine.air_list_stats()
+    sc0 = engine.air_scan_ticks()
     got = _overlap_run(engine, rsa, O, nd, mdl, rng, 200, lambda t: 0 if t % 17 == 5 else rng.integers(1, 30),
                        [320, 2048, 8128, 8128, 20000], what="rings")
     inc, reb = engine.air_list_stats()
     assert got > 100
-    if os.environ.get("RM_AIR_LISTS") != "0":        # (the developer knob that rebuilds the lists every tick)
+    if sinr_form == "scan":                         # no lists at all (12 ticks had no frames)
+        assert (inc - inc0, reb - reb0, engine.air_scan_ticks() - sc0) == (0, 0, 188)
+    elif os.environ.get("RM_AIR_LISTS") != "0":      # (the developer knob that rebuilds the lists every tick)
         assert (inc - inc0, reb - reb0) == (187, 1) # one build, then only new frames (12 ticks had none)
 
 
-def test_sinr_lists_rebuilt_when_something_changes(engine, rsa, O):
+def test_sinr_lists_rebuilt_when_something_changes(engine, rsa, O, sinr_form):
     """Whatever an old entry was computed from may change while its frame is on the air: a receiver moves or changes
     its channel, the model changes, the clock goes back.  The next tick rebuilds the lists from every frame on the
     air (the oracle evaluates the full on-air list against the node table as it is now)."""
@@ -275,11 +288,13 @@ def test_sinr_lists_rebuilt_when_something_changes(engine, rsa, O):
     got = _overlap_run(engine, rsa, O, nd, mdl, rng, 20, 35, [320, 2048, 8128], hook=hook, t_of=t_of, what="changes")
     inc, reb = engine.air_list_stats()
     assert got > 30
-    if os.environ.get("RM_AIR_LISTS") != "0":
+    if sinr_form == "scan":                         # nothing to rebuild: every tick looks at the table as it is
+        assert (inc - inc0, reb - reb0) == (0, 0)
+    elif os.environ.get("RM_AIR_LISTS") != "0":
         assert reb - reb0 == 5 and inc - inc0 == 15 # first tick, three node changes, the clock going back
 
 
-def test_sinr_lists_after_a_dropped_tick(engine, rsa, O):
+def test_sinr_lists_after_a_dropped_tick(engine, rsa, O, sinr_form):
     """A tick whose links do not fit the capacity is reported and leaves the lists unusable; with more room the
     next tick rebuilds them and is exact again."""
     n = 10000
@@ -309,6 +324,63 @@ def test_sinr_lists_after_a_dropped_tick(engine, rsa, O):
             engine.set_link_capacity(1 << 22)
         onair = active
     assert failed == 1
+
+
+def test_sinr_scan_through_the_frame_grid(engine, rsa, O):
+    """The tick by scan looks its frames up in a 64 x 64 grid when their reach is small against the world (rm_airscan.hip):
+    weak transmitters on a large field, thousands of frames on the air; a tight cluster of transmitters overfills its cell
+    (more than 16 frames: the rest go to the list every new frame looks at); one frame has no bound at all (its transmitter
+    shouts), one transmitter moves while its frame is on the air (half duplex goes by node, not by place)."""
+    n = 20000
+    nd = _layout(O, n, seed=61)
+    rng = np.random.default_rng(16)
+    nd.txpower[:] = -20.0
+    cluster = np.arange(100, 160)
+    nd.x[cluster] = nd.x[100] + rng.uniform(0, 8, len(cluster))
+    nd.y[cluster] = nd.y[100] + rng.uniform(0, 8, len(cluster))
+    nd.txpower[7] = 40.0
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    interfered = deaf = 0
+    sc0 = engine.air_scan_ticks()
+    for tick in range(9):
+        t0 = tick * 1000
+        if tick == 6:                               # a node with a frame on the air is somewhere else now
+            j = int(onair["src"][-1])
+            nd.x[j], nd.y[j] = nd.x[(j + 11) % n] + 1.0, nd.y[(j + 11) % n]
+            engine.update_node(j, nd.x[j], nd.y[j], nd.z[j], nd.txpower[j], int(nd.channel[j]), 1, 1.0, 1.0)
+        onair = onair[onair["start_us"] + onair["air_us"] > t0]
+        src = rng.choice(np.setdiff1d(np.arange(n), cluster), 340, replace=False)
+        src = np.sort(np.concatenate([src, cluster[rng.random(len(cluster)) < 0.5], [7] if tick == 3 else []]).astype(np.int64))
+        src = np.unique(src)
+        new = nd.packets(src, 0, 0)
+        new["start_us"] = t0 + rng.integers(0, 1000, len(new))
+        new["air_us"] = rng.choice([2048, 8128, 8128], len(new))
+        active = np.concatenate([onair, new])
+        cpu = O.tick(mdl, nd, active, first_new=len(onair))
+        engine.tick_begin(t0, t0 + 1000)
+        engine.enqueue_records(to_tx_records(rsa, new))
+        gpu = engine.tick_flush()
+        assert_same(gpu, cpu, "frame grid, tick %d (%d frames on the air)" % (tick, len(active)))
+        interfered += int((cpu.verdict == O.INTERFERED).sum())
+        onair = active
+    assert interfered > 200 and engine.air_scan_ticks() - sc0 == 9
+
+
+def test_sinr_scan_with_more_near_frames_than_its_list_holds(engine, rsa, O):
+    """1500 co-channel frames within reach of each other: a wave's quarter of the near list (256) overflows and the new
+    frame's workgroup goes over the frames once more, pair phase by pair phase."""
+    n, t = 3000, 1500
+    nd = _layout(O, n, seed=67)
+    rng = np.random.default_rng(17)
+    src = np.sort(rng.choice(n, t, replace=False))
+    pk = nd.packets(src, 0, 8128)
+    pk["start_us"] = rng.integers(0, 1000, t)
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", _sinr_params(), pk)
+    assert cpu.count > 5000 and (cpu.verdict == O.INTERFERED).sum() > 1000
+    assert_same(gpu, cpu, "near list overflow")
 
 
 def test_sinr_lists_with_the_per_frame_candidate_kernel(engine, rsa, O, monkeypatch):
