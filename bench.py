@@ -745,15 +745,18 @@ def main():
         timed_ticks = args.steps * tps
         value = links_per_tick * timed_ticks / elapsed
         if stateful and sharded is None:
-            # the links the ticks resolved: the new frames against every receiver; the frames still on the air keep
-            # their entries in the per-receiver lists on the device and are not swept again
+            # the links the ticks resolved: the new frames against every receiver; the frames still on the air stay on the
+            # device (as records the new frames' links are tested against, or as entries of per-receiver lists) and are not
+            # swept again
             value = links_done[0] / elapsed
 
         sequential = None
         if stateful:
             inc, reb = engines[0].air_list_stats()
-            desc += (" -- %.2e link evaluations per tick (new frames only: the frames still on the air stay in the on-air lists on the "
-                     "device; %d ticks added to the lists, %d rebuilt them)" % (value * elapsed / timed_ticks, inc, reb))
+            scans = engines[0].air_scan_ticks()
+            desc += (" -- %.2e link evaluations per tick (new frames only; the frames still on the air stay on the device: %d ticks "
+                     "found their interferers among them by scan, %d added their frames to per-receiver lists, %d rebuilt those)"
+                     % (value * elapsed / timed_ticks, scans, inc, reb))
         if (inflight > 1 or batch > 1) and sharded is None and world == 1:
             # the same ticks again, one at a time on one context
             fence()

@@ -40,6 +40,7 @@ constexpr int kScU = 6;         // grid slots per thread requested together
 constexpr int kScBatch = 4;     // scan records per thread requested together when every frame is looked at
 constexpr int kScSub = 128;     // near frames whose records sit in LDS during a pair phase
 constexpr int kScPairsW = 512;  // pairs that passed the conservative tests, per wave, between two exact phases
+constexpr int kScPU = 3;        // pairs per lane tested together
 constexpr int kScSteps = 2;     // (slow path) scan steps between two looks at the near list's fill
 static_assert(kScLinks <= 256 && kScSub <= 256, "a pair is kept as link << 8 | near frame in 16 bits");
 static_assert(kSgK == 16, "a grid slot is cell << 4 | entry");
@@ -75,9 +76,11 @@ __global__ void __launch_bounds__(256, 4) k_sinr_scan(const NodesDev nd, const M
     __shared__ unsigned long long s_acc[kScLinks * 2]; // Q80 interference sum per link
     __shared__ uint32_t s_hd[kScLinks];              // half duplex
     __shared__ int s_near[kScNear];
-    __shared__ rm_tx_record s_fr[kScSub];
+    __shared__ double s_fx[kScSub], s_fy[kScSub], s_fz[kScSub], s_fp[kScSub]; // the near frames: position, power ...
+    __shared__ int s_fch[kScSub];                    // ... channel (field by field: records of 64 bytes would put every lane on two banks)
     __shared__ float4 s_ff[kScSub];                  // pre-filter record of a near frame at the interference floor (w < 0: not a partner)
     __shared__ float s_inv[kScSub];
+    __shared__ int s_fsrc[kScSub];                   // ... its source
     __shared__ uint16_t s_pairs[4 * kScPairsW];
     __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
     __shared__ uint32_t s_nn, s_over, s_wn[4];
@@ -236,10 +239,11 @@ __global__ void __launch_bounds__(256, 4) k_sinr_scan(const NodesDev nd, const M
     auto pairs_phase = [&](const int n_near, const int nl) {
         for (int c0 = 0; c0 < n_near; c0 += kScSub) {
             const int ns = min(kScSub, n_near - c0);
-            __syncthreads(); // (s_fr / s_ff of the phase before are done with; the links are in LDS)
+            __syncthreads(); // (the near frames of the phase before are done with; the links are in LDS)
             if (tid < kScSub) {
                 float4 f = make_float4(0.f, 0.f, 0.f, -1.f);
                 float inv = 0.f;
+                int fs = -1;
                 if (tid < ns) {
                     const rm_tx_record w = t.tx[near_at(c0 + tid)];
                     const int64_t w_end = w.start_us + w.air_us;
@@ -252,10 +256,16 @@ __global__ void __launch_bounds__(256, 4) k_sinr_scan(const NodesDev nd, const M
                             if (1.01f * (2.0f * float(m.f32_slack)) / (0.15f * cut) + 1e-5f <= float(kShadowPad)) inv = float(kShadowBins) / f.w;
                         }
                     }
-                    s_fr[tid] = w;
+                    s_fx[tid] = w.x;
+                    s_fy[tid] = w.y;
+                    s_fz[tid] = w.z;
+                    s_fp[tid] = w.txpower;
+                    s_fch[tid] = w.channel;
+                    fs = w.src;
                 }
                 s_ff[tid] = f;
                 s_inv[tid] = inv;
+                s_fsrc[tid] = fs;
             }
             __syncthreads();
             RM_STAMP(3); // the near frames' records are in LDS
@@ -271,10 +281,19 @@ __global__ void __launch_bounds__(256, 4) k_sinr_scan(const NodesDev nd, const M
                     rx_.z = s_rx[l * 3 + 2];
                     rx_.orig = s_dst[l];
                     rx_.int_id = 0;
-                    rx_.channel = s_fr[c].channel; // (the link was heard on the new frame's channel, and the near frames are on it)
+                    rx_.channel = s_fch[c]; // (the link was heard on the new frame's channel, and the near frames are on it)
                     rx_.enabled = 1;
                     rx_.rxprob = 1.0;
-                    const LinkEval ev = eval_link<RM_MODEL_LOGDIST, true>(m, nd, s_fr[c], rx_, false);
+                    rm_tx_record w; // (what eval_link reads of it)
+                    w.x = s_fx[c];
+                    w.y = s_fy[c];
+                    w.z = s_fz[c];
+                    w.txpower = s_fp[c];
+                    w.txprob = 1.0;
+                    w.start_us = w.air_us = 0;
+                    w.src = s_fsrc[c];
+                    w.channel = s_fch[c];
+                    const LinkEval ev = eval_link<RM_MODEL_LOGDIST, true>(m, nd, w, rx_, false);
                     if (ev.flags & kFlagInterferer) lds_add_u128(&s_acc[l * 2], q80_from_double(ev.lin));
                 }
                 my_np = 0;
@@ -282,33 +301,44 @@ __global__ void __launch_bounds__(256, 4) k_sinr_scan(const NodesDev nd, const M
             // pair p = (link p / ns, near frame p % ns), the waves interleaved: full lanes whatever ns is
             const int n_pairs = nl * ns;
             const uint32_t inv_ns = (ns > 1) ? uint32_t((0x100000000ull + uint32_t(ns) - 1u) / uint32_t(ns)) : 0u;
-            for (int p0 = wave * 64; p0 < n_pairs; p0 += 256) { // wave-uniform
-                const int p = p0 + lane;
-                bool hit = false;
-                int l = 0, c = 0;
-                if (p < n_pairs) {
-                    l = (ns > 1) ? int(__umulhi(uint32_t(p), inv_ns)) : p; // p / ns (exact: p < 2^15)
-                    c = p - l * ns;
-                    const float4 f = s_ff[c];
-                    if (f.w >= 0.f) {
-                        const float4 v = s_rxf[l];
-                        const int d = s_dst[l];
-                        const float s2 = dist2_f32(v.x - f.x, v.y - f.y, v.z - f.z);
-                        hit = s2 <= f.w && s_fr[c].src != d;
-                        if (SHADOW && hit) {
-                            const int bin = min(kShadowBins - 1, int(s2 * s_inv[c]));
-                            const uint32_t a = uint32_t(s_fr[c].src), b = uint32_t(d);
-                            const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
-                            hit = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+            for (int p0 = wave * 64; p0 < n_pairs; p0 += 256 * kScPU) { // wave-uniform
+                bool hit[kScPU];
+                int pl[kScPU], pc[kScPU];
+#pragma unroll
+                for (int u = 0; u < kScPU; ++u) { // independent pairs: their LDS reads overlap
+                    const int p = p0 + u * 256 + lane;
+                    hit[u] = false;
+                    pl[u] = pc[u] = 0;
+                    if (p < n_pairs) {
+                        const int l = (ns > 1) ? int(__umulhi(uint32_t(p), inv_ns)) : p; // p / ns (exact: p < 2^15)
+                        const int c = p - l * ns;
+                        pl[u] = l;
+                        pc[u] = c;
+                        const float4 f = s_ff[c];
+                        if (f.w >= 0.f) {
+                            const float4 v = s_rxf[l];
+                            const int d = s_dst[l];
+                            const float s2 = dist2_f32(v.x - f.x, v.y - f.y, v.z - f.z);
+                            const int fsrc = s_fsrc[c];
+                            hit[u] = s2 <= f.w && fsrc != d;
+                            if (SHADOW && hit[u]) {
+                                const int bin = min(kShadowBins - 1, int(s2 * s_inv[c]));
+                                const uint32_t a = uint32_t(fsrc), b = uint32_t(d);
+                                const uint64_t key = (uint64_t(a < b ? a : b) << 32) | uint64_t(a < b ? b : a);
+                                hit[u] = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                            }
                         }
                     }
                 }
-                const uint64_t hm = ballot64(hit);
-                const int cnt = int(__popcll(hm));
-                if (cnt) {
-                    if (my_np + cnt > kScPairsW) exact_mine(); // wave-uniform: room first
-                    if (hit) s_pairs[wave * kScPairsW + my_np + int(lane_prefix(hm))] = uint16_t((l << 8) | c);
-                    my_np += cnt;
+#pragma unroll
+                for (int u = 0; u < kScPU; ++u) {
+                    const uint64_t hm = ballot64(hit[u]);
+                    const int cnt = int(__popcll(hm));
+                    if (cnt) {
+                        if (my_np + cnt > kScPairsW) exact_mine(); // wave-uniform: room first
+                        if (hit[u]) s_pairs[wave * kScPairsW + my_np + int(lane_prefix(hm))] = uint16_t((pl[u] << 8) | pc[u]);
+                        my_np += cnt;
+                    }
                 }
             }
             RM_STAMP(4); // pairs tested
