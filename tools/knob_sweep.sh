@@ -7,14 +7,15 @@
 # reception-stage / group suites in every run.
 # Round 3 added: several ticks per filter workgroup on tables that would take one (RM_FILTER_TICKS_PER_WG=3), the copied
 # instead of the zero-copy records of a flushed tick (RM_NO_ZERO_COPY=1), few / very many frames per reorder wave (RM_FPW),
-# another SINR grid (RM_SINR_GX=5), groups without RCCL (RM_GROUP_NO_RCCL=1), and the comm suite in every run.
+# another SINR grid (RM_SINR_GX=5), groups without RCCL (RM_GROUP_NO_RCCL=1), the SINR medium's lone ticks with the per-receiver
+# lists instead of by scan (RM_SINR_SCAN=0; RM_AIR_LISTS=0 only means something with it), and the comm suite in every run.
 B=${1:-24}
 FIRST=${2:-0}
 LAST=${3:-99}
 K=("RM_FILTER=wg" "RM_FILTER=wg RM_WG_RPT=4" "RM_FILTER=wg RM_WG_RPT=2" "RM_FILTER=grid" "RM_GRAPH=1"
    "RM_NO_SHADOW_TABLE=1" "RM_NO_ONE_LAUNCH=1" "RM_RESORT_AFTER=0" "RM_NO_REC32=1" "RM_EXACT_GRID=1" "RM_EXACT_GRID=7" "RM_EXACT_GRID=256"
-   "RM_FRAME_TICK=0" "RM_AIR_LISTS=0" "RM_FILTER=wg RM_FRAMES_CAND=0" "RM_FR_FLAT_MAX=0" "RM_FR_NO_SHADOW=1" "RM_SINR_FRAMES=0" "RM_SINR_FRAMES=0 RM_FILTER=wg"
-   "RM_FILTER_TICKS_PER_WG=3" "RM_NO_ZERO_COPY=1" "RM_FPW=3" "RM_FPW=200" "RM_SINR_GX=5" "RM_GROUP_NO_RCCL=1")
+   "RM_FRAME_TICK=0" "RM_SINR_SCAN=0 RM_AIR_LISTS=0" "RM_FILTER=wg RM_FRAMES_CAND=0" "RM_FR_FLAT_MAX=0" "RM_FR_NO_SHADOW=1" "RM_SINR_FRAMES=0" "RM_SINR_FRAMES=0 RM_FILTER=wg"
+   "RM_FILTER_TICKS_PER_WG=3" "RM_NO_ZERO_COPY=1" "RM_FPW=3" "RM_FPW=200" "RM_SINR_GX=5" "RM_GROUP_NO_RCCL=1" "RM_SINR_SCAN=0")
 for i in "${!K[@]}"; do
     if [ $i -lt $FIRST ] || [ $i -gt $LAST ]; then continue; fi
     knobs="${K[$i]}"
