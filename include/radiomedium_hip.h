@@ -34,11 +34,12 @@
 extern "C" {
 #endif
 
-/* 2: rm_delivery_view.oldest_packet; rm_host_result.sinr / rm_device_result.sinr are NULL without the SINR extension;
+/* 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe); rm_air_scan_ticks.
+ * 2: rm_delivery_view.oldest_packet; rm_host_result.sinr / rm_device_result.sinr are NULL without the SINR extension;
  *    rm_group_*, rm_events_*, rm_node_info, rm_tick_run_records_device, rm_set_partition_spatial and the draw-node
  *    exchange were added; rm_tick_run_device refuses the SINR medium (rm_tick_run_records_device takes it).  A host
  *    built against another version must not load this library: compare rm_abi_version() with RM_ABI_VERSION. */
-#define RM_ABI_VERSION 2
+#define RM_ABI_VERSION 3
 
 #define RM_OK 0
 #define RM_ERR_INVALID (-1)   /* bad argument */
@@ -205,7 +206,9 @@ typedef struct rm_host_result {
     uint32_t n_packets;              /* frames of this tick */
     const uint32_t *pkt_offset;      /* [n_packets + 1] first link of every packet */
     const uint8_t *pkt_interference; /* [n_packets] Tx-failure flag (UDGMRadioMedium.java:88-92) */
-    const int32_t *pkt, *dst;        /* [count] packet, receiver node index (ascending per packet) */
+    const int32_t *pkt;              /* NULL since ABI version 3: link i belongs to the packet q with pkt_offset[q] <= i < pkt_offset[q + 1]
+                                      * (4 of a record's 17 bytes that need not cross PCIe; rm_tick_flush still fills its caller's array) */
+    const int32_t *dst;              /* [count] receiver node index (ascending per packet) */
     const uint8_t *verdict;          /* [count] RM_INTERFERED / RM_DELIVERED */
     const double *rssi;              /* [count] */
     const double *sinr;              /* [count] with the SINR extension, else NULL (as rm_device_result.sinr) */

@@ -357,7 +357,7 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
         r.n_packets = uint32_t(ps.n_new);
         r.pkt_offset = v.pkt_offset + ps.pkt_base + uint32_t(b);
         r.pkt_interference = v.pkt_interference + ps.pkt_base;
-        r.pkt = v.pkt + bc.link_base;
+        r.pkt = nullptr; // (ABI version 3: pkt_offset says it all)
         r.dst = v.dst + bc.link_base;
         r.verdict = v.verdict + bc.link_base;
         r.rssi = v.rssi + bc.link_base;

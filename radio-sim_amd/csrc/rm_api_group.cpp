@@ -194,7 +194,7 @@ static int group_merge(rm_group *g, int n_new, int32_t *pkt, int32_t *dst, uint8
         o.n_packets = v.hdr->n_packets;
         o.pkt_offset = v.pkt_offset;
         o.pkt_interference = v.pkt_interference;
-        o.pkt = v.pkt;
+        o.pkt = nullptr;
         o.dst = v.dst;
         o.verdict = v.verdict;
         o.rssi = v.rssi;

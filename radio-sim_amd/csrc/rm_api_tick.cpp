@@ -84,7 +84,6 @@ rm::HostView stage_view(char *base, uint32_t links, uint32_t packets, size_t *by
     o += pad64(sizeof(rm::BatchCounts) * RM_MAX_BATCH); // per-slot counts of rm_batch_result_view (stage_counts)
     v.pkt_offset = reinterpret_cast<uint32_t *>(base + o); o += pad64((size_t(packets) + 1) * 4);
     v.pkt_interference = reinterpret_cast<uint8_t *>(base + o); o += pad64(size_t(packets) + 1);
-    v.pkt = reinterpret_cast<int32_t *>(base + o); o += pad64(size_t(links) * 4);
     v.dst = reinterpret_cast<int32_t *>(base + o); o += pad64(size_t(links) * 4);
     v.rssi = reinterpret_cast<double *>(base + o); o += pad64(size_t(links) * 8);
     v.sinr = reinterpret_cast<double *>(base + o); o += pad64(size_t(links) * 8);
@@ -332,7 +331,7 @@ int rm_tick_flush_view(rm_context *c, rm_host_result *out)
     out->n_packets = v.hdr->n_packets;
     out->pkt_offset = v.pkt_offset;
     out->pkt_interference = v.pkt_interference;
-    out->pkt = v.pkt;
+    out->pkt = nullptr; // (ABI version 3: pkt_offset says it all)
     out->dst = v.dst;
     out->verdict = v.verdict;
     out->rssi = v.rssi;
@@ -351,7 +350,11 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
     if (count) *count = v.hdr->total;
     const uint32_t k = std::min(v.hdr->stored, cap);
     if (k) {
-        if (pkt) std::memcpy(pkt, v.pkt, k * sizeof(int32_t));
+        if (pkt) { // the packet column is not in the block any more: written here from the offsets
+            const uint32_t np_ = v.hdr->n_packets;
+            for (uint32_t q = 0; q < np_; ++q)
+                for (uint32_t i = v.pkt_offset[q], e = std::min(v.pkt_offset[q + 1], k); i < e; ++i) pkt[i] = int32_t(q);
+        }
         if (dst) std::memcpy(dst, v.dst, k * sizeof(int32_t));
         if (verdict) std::memcpy(verdict, v.verdict, k);
         if (rssi) std::memcpy(rssi, v.rssi, k * sizeof(double));

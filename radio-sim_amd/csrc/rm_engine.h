@@ -298,7 +298,7 @@ struct HostView {
     HostHeader *hdr;
     uint32_t *pkt_offset;       // [packets + 1]
     uint8_t *pkt_interference;  // [packets]
-    int32_t *pkt, *dst;
+    int32_t *dst;               // (no packet column: a link's packet follows from pkt_offset)
     double *rssi, *sinr;
     uint8_t *verdict;
     uint32_t links, packets;    // room

@@ -845,7 +845,6 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
         for (uint32_t c = lane; c < len; c += 64) {
             const uint32_t d = dst0 + c;
             if (d < room) {
-                v.pkt[d] = int(q);
                 v.dst[d] = t.a_dst[src0 + c];
                 v.rssi[d] = t.a_rssi[src0 + c];
                 v.verdict[d] = t.a_verdict[src0 + c];

@@ -100,7 +100,6 @@ k_pack_tick(TickDev t, int n_new, int have_offsets, HostView v, uint32_t *done_c
     const uint32_t n = min(min(t.out_count[0], total), v.links);
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
     for (uint32_t i = tid; i < n; i += step) {
-        v.pkt[i] = t.out_pkt[i];
         v.dst[i] = t.out_dst[i];
         v.verdict[i] = t.out_verdict[i];
         v.rssi[i] = t.out_rssi[i];
@@ -155,7 +154,6 @@ k_pack_batch(const PackSlot *__restrict__ slots, int n_slots, HostView v, BatchC
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
     for (uint32_t i = tid; i < n; i += step) {
         const uint32_t o = link_base + i;
-        v.pkt[o] = t.out_pkt[i];
         v.dst[o] = t.out_dst[i];
         v.verdict[o] = t.out_verdict[i];
         v.rssi[o] = t.out_rssi[i];

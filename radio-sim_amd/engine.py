@@ -55,7 +55,11 @@ class HostTickView:
             raise AttributeError(name)
         n = (self.count, self._n_packets, self._n_packets + 1)[spec[2]]
         p = self._ptr[name]
-        a = np.zeros(n) if (name == "sinr" and not p) else _wrap(p, spec[1], n)
+        if name == "pkt" and not p:   # (the block carries no packet column since ABI version 3: it follows from the offsets)
+            off = self.pkt_offset.astype(np.int64)
+            a = np.repeat(np.arange(self._n_packets, dtype=np.int32), np.diff(off))[:n]
+        else:
+            a = np.zeros(n) if (name == "sinr" and not p) else _wrap(p, spec[1], n)
         setattr(self, name, a)
         return a
 
