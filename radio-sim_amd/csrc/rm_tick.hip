@@ -858,6 +858,10 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
         }
     }
     if (np == 0 && blockIdx.x == 0 && threadIdx.x == 0) v.pkt_offset[0] = 0u;
+    // Ordinary stores + one release fence per workgroup: the stores gather in this XCD's L2 and the fence writes them out in
+    // bursts (33 GB/s on the measured box).  Write-through stores at system scope -- what k_ev_apply uses for its scattered
+    // deliveries, with far more waves in flight -- were measured here too: each is acknowledged from the far end of the link,
+    // 71 us per tick instead of 45; drained ordinary stores without the fence arrive after the sequence number (tests fail).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its stores, ...
     __syncthreads();                                  // ... the workgroup meets, one lane releases them to the host
     if (threadIdx.x == 0) {
