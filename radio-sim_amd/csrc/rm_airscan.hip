@@ -460,6 +460,22 @@ __global__ void __launch_bounds__(256, 4) k_sinr_scan(const NodesDev nd, const M
     }
 }
 
+// Frames of the on-air window that had left the air when an earlier tick began are retired for good (padding records):
+// rm_tick_begin's rule is applied tick by tick, and the kernels only compare with the current tick's t_begin.  Launched by
+// air_tick_device when the clock goes back.
+__global__ void __launch_bounds__(256) k_air_expire(rm_tx_record *recs, int n, int64_t t_seen)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && recs[i].src >= 0 && recs[i].start_us + recs[i].air_us <= t_seen) recs[i].src = -1;
+}
+
+hipError_t launch_air_expire(hipStream_t s, rm_tx_record *recs, int n, int64_t t_seen)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_air_expire, dim3(cdiv(n, 256)), dim3(256), 0, s, recs, n, t_seen);
+    return hipGetLastError();
+}
+
 hipError_t launch_sinr_scan(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const ScanDev &sd, const LaunchCfg &cfg)
 {
     if (t.n_cnt <= 0) return hipSuccess;

@@ -169,15 +169,10 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         for (const auto &bt : c->air_batches)
             if (bt.end_us > t_begin_us[0])
                 return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
-        for (const auto &r : c->onair)
-            if (still_on_air(r, t_begin_us[0]))
-                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
         for (int b = 0; dev_src && b + 1 < n_ticks; ++b)
             if (n_per[b] > 0 && start_us[b] + air_us[b] > t_begin_us[b + 1])
                 return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run "
                                           "overlapping ticks one at a time");
-        c->onair.clear();
-        c->onair_tick.clear();
         c->air.valid = false; // the ticks of a batch keep their lists to themselves
         c->air_batches.clear();
         c->air_head = c->air_tail = 0;

@@ -365,8 +365,6 @@ int rm_set_model(rm_context *c, const rm_model_params *p)
     RM_TRY(build_shadow_table(c));
     c->air_batches.clear();
     c->air_head = c->air_tail = 0;
-    c->onair.clear();
-    c->onair_tick.clear();
     c->air.valid = false;
     c->pending.clear();
     return RM_OK;

@@ -343,8 +343,6 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     c->frac_probs = -1;
     c->air_batches.clear();
     c->air_head = c->air_tail = 0;
-    c->onair.clear();
-    c->onair_tick.clear();
     c->air.valid = false;
     c->pending.clear();
     if (c->rx_count >= 0 && c->rx_first + c->rx_count > n) {

@@ -29,7 +29,6 @@ const char *record_flag_message(uint32_t flag)
                       : "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained";
 }
 
-bool still_on_air(const rm_tx_record &r, int64_t t_begin) { return r.start_us + r.air_us > t_begin; }
 
 int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
                     uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset)
@@ -166,28 +165,17 @@ int tick_run_host(rm_context *c)
     if (!c->in_tick) return fail(RM_ERR_STATE, "rm_tick_flush without rm_tick_begin");
     RM_HIP(hipSetDevice(c->device));
     c->in_tick = false;
-    // SINR: the frames of earlier ticks have their entries in the lists on the device -- only the new frames go there
-    // (and are evaluated), unless the lists have to be rebuilt from everything on the air
+    // SINR: the frames of earlier ticks stay on the device (the window air_tick_device keeps, shared with the ticks whose
+    // frames are in device memory already); only the new records cross the link
     const bool sinr = is_sinr(c);
-    int air_mode = kAirNone;
-    uint32_t oldest = 0;
-    if (sinr) {
+    if (sinr)
         for (const rm_tx_record &r : c->pending)
             if (r.air_us < 0 || r.air_us > int64_t(UINT32_MAX))
                 return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
-        c->onair_tick.resize(c->onair.size(), 0u);
-        for (uint32_t k : c->onair_tick) oldest = (oldest == 0 || k < oldest) ? k : oldest;
-        const bool unknown = std::find(c->onair_tick.begin(), c->onair_tick.end(), 0u) != c->onair_tick.end();
-        RM_TRY(prepare_nodes(c)); // (a changed table makes the lists stale, and decides whether the tick can go by scan)
-        if (air_scan_applies(c, int(c->pending.size()))) air_mode = kAirScan; // every frame on the air goes to the device, no lists
-        else air_mode = (!unknown && air_lists_current(c, c->t_begin, oldest)) ? kAirIncremental : kAirRebuild;
-    }
-    const size_t n_old = (air_mode == kAirIncremental) ? 0 : c->onair.size();
-    const int first_new = int(n_old);
-    const size_t total = n_old + c->pending.size();
+    const size_t total = c->pending.size();
     bool zero_copy = false;
     int staged = -1;
-    RM_HIP(c->d_tx.ensure(std::max<size_t>(total, 1)));
+    if (!sinr) RM_HIP(c->d_tx.ensure(std::max<size_t>(total, 1)));
     if (total) {
         // through pinned staging: the copy is asynchronous, the buffer is reused only after its copy has completed
         const int g = c->h_tx_gen;
@@ -202,30 +190,31 @@ int tick_run_host(rm_context *c)
             RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_tx[g]), want * sizeof(rm_tx_record), hipHostMallocMapped));
             c->h_tx_n[g] = want;
         }
-        if (n_old) std::memcpy(c->h_tx[g], c->onair.data(), n_old * sizeof(rm_tx_record));
-        if (!c->pending.empty()) std::memcpy(c->h_tx[g] + n_old, c->pending.data(), c->pending.size() * sizeof(rm_tx_record));
+        std::memcpy(c->h_tx[g], c->pending.data(), total * sizeof(rm_tx_record));
         // A tick of a few thousand frames: the kernels read the records straight from this pinned, host-mapped block (every
         // frame's workgroup fetches its own 64 bytes and leaves them in device memory for whoever comes later) -- a copy
-        // engine's ~10 us hand-over per tick is most of what the transfer costs.  Larger ticks and the SINR medium (whose
-        // rebuilds sweep old frames too) take the copy.
+        // engine's ~10 us hand-over per tick is most of what the transfer costs.  Larger ticks take the copy; the SINR
+        // medium's records are copied to the tail of its on-air window.
         static const bool no_zero_copy = std::getenv("RM_NO_ZERO_COPY") != nullptr;
         zero_copy = !sinr && !no_zero_copy && total <= 8192;
-        if (!zero_copy) RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
+        if (!zero_copy && !sinr) RM_HIP(hipMemcpyAsync(c->d_tx.p, c->h_tx[g], total * sizeof(rm_tx_record), hipMemcpyHostToDevice, c->stream));
         c->host_src = zero_copy ? c->h_tx[g] : nullptr;
         staged = g;
     }
-    const int rc = run_tick(c, c->d_tx.p, int(total), first_new, nullptr, 0, 0, air_mode, oldest);
+    int rc;
+    if (sinr) {
+        int64_t latest_end = INT64_MIN;
+        for (const rm_tx_record &r : c->pending) latest_end = std::max(latest_end, r.start_us + r.air_us);
+        rc = air_tick_device(c, c->t_begin, nullptr, staged >= 0 ? c->h_tx[staged] : nullptr, int32_t(total), 0, 0, latest_end, true);
+    } else {
+        rc = run_tick(c, c->d_tx.p, int(total), 0, nullptr, 0, 0, kAirNone, 0);
+    }
     c->host_src = nullptr;
     if (staged >= 0) RM_HIP(hipEventRecord(c->h_tx_ev[staged], c->stream)); // (the block is rewritten only after whatever read it)
     c->tick_frac_records = false;
     if (rc != RM_OK) {
         c->air.valid = false;
         return rc;
-    }
-    if (sinr) {
-        if (air_mode == kAirRebuild) std::fill(c->onair_tick.begin(), c->onair_tick.end(), c->air.tick);
-        c->onair.insert(c->onair.end(), c->pending.begin(), c->pending.end());
-        c->onair_tick.resize(c->onair.size(), air_mode == kAirScan ? 0u : c->air.tick); // (0: not in the lists)
     }
     c->pending.clear();
     return RM_OK;
@@ -272,21 +261,7 @@ int rm_tick_begin(rm_context *c, int64_t t_begin_us, int64_t t_end_us)
     c->t_end = t_end_us;
     c->pending.clear();
     c->tick_frac_records = false;
-    if (is_sinr(c)) {
-        size_t k = 0;
-        c->onair_tick.resize(c->onair.size(), 0u);
-        for (size_t i = 0; i < c->onair.size(); ++i)
-            if (still_on_air(c->onair[i], t_begin_us)) {
-                c->onair_tick[k] = c->onair_tick[i];
-                c->onair[k++] = c->onair[i];
-            }
-        c->onair.resize(k);
-        c->onair_tick.resize(k);
-    } else {
-        c->onair.clear();
-        c->onair_tick.clear();
-        c->air.valid = false;
-    }
+    if (!is_sinr(c)) c->air.valid = false; // (the SINR medium's frames of earlier ticks stay on the device: air_tick_device)
     c->in_tick = true;
     return RM_OK;
 }
@@ -389,8 +364,6 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
     c->t_begin = c->t_end = start_us;
     c->in_tick = false;
     c->pending.clear();
-    c->onair.clear();
-    c->onair_tick.clear();
     c->air.valid = false;
     if (!c->h_transmit) {
         RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_transmit), sizeof(rm::TransmitResult), hipHostMallocMapped));
@@ -507,9 +480,6 @@ int rm_tick_run_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, cons
     return rc;
 }
 
-static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n,
-                           int64_t start_us, int64_t air_us, int64_t latest_end_us);
-
 int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t n,
                                int64_t start_us, int64_t air_us)
 {
@@ -521,16 +491,22 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
         RM_HIP(c->d_tx.ensure(std::max(n, 1)));
         return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us);
     }
-    return air_tick_device(c, t_begin_us, dev_src, nullptr, n, start_us, air_us, start_us + air_us);
+    return air_tick_device(c, t_begin_us, dev_src, nullptr, n, start_us, air_us, start_us + air_us, false);
 }
 
-// The SINR medium's tick with its frames in device memory -- built from source indices (dev_src: all with the same start
-// and air time) or given as records (dev_new; `latest_end_us` bounds their start + air: the host never reads them).
+} // extern "C"
+
+namespace rmh {
+
+// The SINR medium's tick (rm_host.hpp) -- its new frames built from source indices (dev_src: all with the same start and air
+// time) or given as records (dev_new, in device memory or in the host's pinned staging block; `latest_end_us` bounds their
+// start + air: records in device memory are never read by the host).
 // The frames of earlier calls that are still on the air stay resident on the device (the window [air_head, air_tail) of
 // d_air): a tick that only adds frames sweeps the new ones, a rebuild of the on-air lists sweeps the whole window.
-static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n,
-                           int64_t start_us, int64_t air_us, int64_t latest_end_us)
+int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n, int64_t start_us,
+                    int64_t air_us, int64_t latest_end_us, bool new_on_host)
 {
+    if (c->air_batches.empty()) c->air_max_t_begin = INT64_MIN;
     // Expire whole batches (rm_tick_begin's rule: start + air > t_begin stays).
     {
         bool fifo = true; // live batches form a suffix of the window?
@@ -580,8 +556,15 @@ static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev
         c->air_tail = live;
     }
     if (dev_src && air_us > int64_t(UINT32_MAX)) return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
-    if (dev_new && n > 0) // the caller's records join the window (they have to be there when the lists are rebuilt)
-        RM_HIP(hipMemcpyAsync(c->d_air.p + c->air_tail, dev_new, size_t(n) * sizeof(rm_tx_record), hipMemcpyDeviceToDevice, c->stream));
+    if (dev_new && n > 0) // the caller's records join the window (every later tick looks at them while they are on the air)
+        RM_HIP(hipMemcpyAsync(c->d_air.p + c->air_tail, dev_new, size_t(n) * sizeof(rm_tx_record),
+                              new_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    // rm_tick_begin's rule is applied tick by tick: a frame that had left the air when an earlier tick began does not
+    // come back when the clock does.  The kernels compare with THIS tick's t_begin, so (rarely) such frames are retired
+    // for good in the window first.
+    if (live > 0 && t_begin_us < c->air_max_t_begin)
+        RM_HIP(rm::launch_air_expire(c->stream, c->d_air.p + c->air_head, int(live), c->air_max_t_begin));
+    c->air_max_t_begin = std::max(c->air_max_t_begin, t_begin_us);
     uint32_t oldest = 0;
     bool unknown = false;
     for (const auto &bt : c->air_batches) {
@@ -606,6 +589,10 @@ static int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev
     return RM_OK;
 }
 
+} // namespace rmh
+
+extern "C" {
+
 int rm_tick_run_records_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const rm_tx_record *dev_new, int32_t n_new,
                                int64_t latest_end_us)
 {
@@ -614,7 +601,7 @@ int rm_tick_run_records_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
     RM_HIP(hipSetDevice(c->device));
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
-    return air_tick_device(c, t_begin_us, nullptr, dev_new, n_new, 0, 0, latest_end_us);
+    return air_tick_device(c, t_begin_us, nullptr, dev_new, n_new, 0, 0, latest_end_us, false);
 }
 
 int rm_result_device(rm_context *c, rm_device_result *out)

@@ -475,6 +475,7 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
                               int seg_len, const ScanDev *scan = nullptr);
 // (rm_airscan.hip) second launch of the SINR medium's lone tick by scan: interference sums, sinr and verdicts of the new frames' heard links
 hipError_t launch_sinr_scan(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, const ScanDev &sd, const LaunchCfg &cfg);
+hipError_t launch_air_expire(hipStream_t s, rm_tx_record *recs, int n, int64_t t_seen); // (the on-air window when the clock goes back)
 hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                                     const TickDev *dev_ticks, const LaunchCfg &cfg, int seg_len);
 hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t, int n_new, const HostView &v, uint32_t *done_counter,

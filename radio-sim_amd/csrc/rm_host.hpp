@@ -226,7 +226,6 @@ struct rm_context : TickSlot {
     bool in_tick = false;
 
     // on-air list (host-record mode)
-    std::vector<rm_tx_record> onair;   // frames of earlier ticks still on the air (SINR mode)
     std::vector<rm_tx_record> pending; // frames enqueued in the current tick
     // on-air list (device-source mode, SINR): the live batches are a window [air_head, air_tail) of
     // d_air; a batch = the frames of one rm_tick_run_sources_device call (same start and air time)
@@ -251,7 +250,7 @@ struct rm_context : TickSlot {
         uint64_t rebuilds = 0, incremental = 0;
         uint64_t scans = 0;       // ticks evaluated by scan (rm_airscan.hip): they leave nothing in the lists
     } air;
-    std::vector<uint32_t> onair_tick; // AirLists::tick per frame of `onair`
+    int64_t air_max_t_begin = INT64_MIN; // the latest t_begin a tick over the on-air window has had (air_tick_device)
     bool dev_records_from_caller = false; // the tick being prepared takes rm_tx_record arrays the caller built in device memory
     mutable rm::ModelDev mdev{};            // model_dev()'s last answer and what it was derived from
     mutable unsigned char mdev_key[320] = {};
@@ -382,7 +381,6 @@ int ev_append(rm_context *c, TickSlot &ts);
 rm_tx_record make_record(const rm_context *c, int32_t src, int64_t start_us, int64_t air_us, const double *txpower,
                          const int32_t *channel);
 const char *record_flag_message(uint32_t flag);
-bool still_on_air(const rm_tx_record &r, int64_t t_begin);
 int copy_out(rm_context *c, TickSlot &ts, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi, double *sinr,
              uint32_t cap, uint32_t *count, uint8_t *pkt_interference, uint32_t *pkt_offset);
 size_t pad64(size_t v);
@@ -392,6 +390,11 @@ int ensure_stage(rm_context *c, uint32_t links, uint32_t packets);
 int pack_to_stage(rm_context *c, TickSlot &ts, rm::HostView *view);
 int stage_status(rm_context *c, const rm::HostView &v);
 int tick_run_host(rm_context *c);
+// The SINR medium's tick: the frames of earlier ticks that are still on the air stay resident on the device (the window
+// [air_head, air_tail) of d_air); the new ones are built from source indices (dev_src), or given as records in device memory
+// or -- new_on_host -- in the host's pinned staging block, and join the window's tail.
+int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n, int64_t start_us,
+                    int64_t air_us, int64_t latest_end_us, bool new_on_host);
 int result_device(rm_context *c, TickSlot &ts, rm_device_result *out);
 int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *dropped);
 

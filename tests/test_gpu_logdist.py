@@ -207,6 +207,40 @@ def test_sinr_device_resident_on_air_list(engine, rsa, O, sinr_form):
     assert interfered > 100
 
 
+def test_sinr_host_and_device_ticks_share_the_frames_on_the_air(engine, rsa, O, sinr_form):
+    """One window of frames on the air per context, whoever brought them: ticks whose records come from the host
+    (rm_tick_flush) and ticks built on the device from source indices (rm_tick_run_sources_device) interfere with each other."""
+    from util import DeviceArray
+    n = 4000
+    nd = _layout(O, n, seed=31)
+    rng = np.random.default_rng(9)
+    params = _sinr_params()
+    configure_engine(engine, nd, "logdist", params)
+    mdl = oracle_model(O, "logdist", params)
+    onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+    interfered = 0
+    for tick in range(14):
+        t0 = tick * 1000
+        onair = onair[onair["start_us"] + onair["air_us"] > t0]
+        srcs = np.sort(rng.choice(n, 60, replace=False)).astype(np.int32)
+        air = int(rng.choice([2048, 8128]))
+        new = nd.packets(srcs, t0, air)
+        cpu = O.tick(mdl, nd, np.concatenate([onair, new]), first_new=len(onair))
+        if tick % 3 == 1:
+            dev = DeviceArray(srcs)
+            engine.tick_run_sources_device(t0, t0 + 1000, dev.ptr.value, len(srcs), t0, air)
+            gpu = engine.result_copy(len(srcs))
+            dev.free()
+        else:
+            engine.tick_begin(t0, t0 + 1000)
+            engine.enqueue_records(to_tx_records(rsa, new))
+            gpu = engine.tick_flush()
+        assert_same(gpu, cpu, "shared window, tick %d" % tick)
+        interfered += int((cpu.verdict == O.INTERFERED).sum())
+        onair = np.concatenate([onair, new])
+    assert interfered > 100
+
+
 def _overlap_run(engine, rsa, O, nd, mdl, rng, ticks, per_tick, airs, hook=None, t_of=None, what=""):
     """ticks of new frames through the tick API against the oracle's tick over the full on-air list"""
     n = nd.n
