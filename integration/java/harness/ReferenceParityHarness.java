@@ -1,0 +1,340 @@
+/*
+ * ReferenceParityHarness -- turns "parity unpinned" into "pinned" on a box that has a JDK (this build's has none:
+ * this file has never been compiled or run; DESIGN.md section 2).
+ *
+ * The golden vectors under tests/golden/*.npz are outputs of the CPU oracle (oracle/rm_oracle.c), which restates the
+ * reference's loops statement by statement but is checked only against hand-derived known answers.  This harness
+ * drives the REFERENCE'S OWN classes -- UDGMRadioMedium, UDGMConstantLossRadioMedium, N2NRadioMedium, NullRadioMedium,
+ * Node, Transciever, RadioPacket, with a Simulator whose event generation is replaced by a recorder -- over the very
+ * scenarios of tests/golden/make_golden.py (node tables, model parameters, java.util.Random seed, packets tick by tick,
+ * all read from the .npz) and compares every RadioMedium -> Simulator call with the vectors: packet, receiver, rssi and the
+ * delivered / interfered flag, in call order, and the generator's state after the last tick.  If it prints PINNED for
+ * the four reference media, the oracle -- and through the GPU tests the engine -- reproduces the reference bit for bit
+ * on these scenarios, including the one JDK assumption nothing here could check, Math.pow(x, 2.0) == x * x.
+ *
+ * Nothing of the reference is copied: it is used through its public API only.
+ *
+ *   cd <radio-sim>/radio-medium && ant                     # or: javac -cp 'lib/*' -d build $(find java -name '*.java')
+ *   javac -cp 'build:lib/*' -d /tmp/h <repo>/integration/java/harness/ReferenceParityHarness.java
+ *   java -cp '/tmp/h:build:lib/*' ReferenceParityHarness <repo>/tests/golden
+ *
+ * The scenarios of the build's own extension medium (logdist_*.npz) have no reference class and are skipped.
+ */
+import java.io.ByteArrayOutputStream;
+import java.io.File;
+import java.io.IOException;
+import java.io.InputStream;
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.nio.charset.StandardCharsets;
+import java.util.ArrayList;
+import java.util.Enumeration;
+import java.util.HashMap;
+import java.util.IdentityHashMap;
+import java.util.List;
+import java.util.Map;
+import java.util.Random;
+import java.util.regex.Matcher;
+import java.util.regex.Pattern;
+import java.util.zip.ZipEntry;
+import java.util.zip.ZipFile;
+
+import se.sics.emul8.radiomedium.N2NRadioMedium;
+import se.sics.emul8.radiomedium.Node;
+import se.sics.emul8.radiomedium.NullRadioMedium;
+import se.sics.emul8.radiomedium.RadioMedium;
+import se.sics.emul8.radiomedium.RadioPacket;
+import se.sics.emul8.radiomedium.Simulator;
+import se.sics.emul8.radiomedium.Transciever;
+import se.sics.emul8.radiomedium.UDGMConstantLossRadioMedium;
+import se.sics.emul8.radiomedium.UDGMRadioMedium;
+
+public final class ReferenceParityHarness {
+
+    /** One array of an .npz file: raw little-endian bytes + what the .npy header says about them. */
+    static final class Npy {
+        ByteBuffer data;
+        int[] shape;
+        String descr;                                    // "<f8", "<i4", "|u1", "<U21", ... ; null for a structured array
+        List<String> fieldNames = new ArrayList<>();     // structured arrays (the packets): fields in storage order
+        List<String> fieldTypes = new ArrayList<>();
+        int itemSize;
+
+        int count() {
+            int n = 1;
+            for (int s : shape) n *= s;
+            return n;
+        }
+
+        static int sizeOf(String t) {
+            return Integer.parseInt(t.substring(2)) * (t.charAt(1) == 'U' ? 4 : 1);
+        }
+
+        double f64(int i) { return data.getDouble(i * 8); }
+        long i64(int i) { return data.getLong(i * 8); }
+        int i32(int i) { return data.getInt(i * 4); }
+        int u8(int i) { return data.get(i) & 0xFF; }
+
+        /** numeric field `name` of record i of a structured array */
+        double field(int i, String name) {
+            int off = 0;
+            for (int k = 0; k < fieldNames.size(); ++k) {
+                final String t = fieldTypes.get(k);
+                if (fieldNames.get(k).equals(name)) {
+                    final int at = i * itemSize + off;
+                    switch (t) {
+                    case "<f8": return data.getDouble(at);
+                    case "<i8": return (double) data.getLong(at);
+                    case "<i4": return data.getInt(at);
+                    default: throw new IllegalStateException("field type " + t);
+                    }
+                }
+                off += sizeOf(t);
+            }
+            throw new IllegalStateException("no field " + name);
+        }
+
+        long fieldLong(int i, String name) {
+            int off = 0;
+            for (int k = 0; k < fieldNames.size(); ++k) {
+                final String t = fieldTypes.get(k);
+                if (fieldNames.get(k).equals(name)) {
+                    final int at = i * itemSize + off;
+                    return t.equals("<i8") ? data.getLong(at) : data.getInt(at);
+                }
+                off += sizeOf(t);
+            }
+            throw new IllegalStateException("no field " + name);
+        }
+
+        /** element i of a unicode string array ("<U<n>": n UTF-32 code units, zero padded) */
+        String str(int i) {
+            final int units = Integer.parseInt(descr.substring(2));
+            final StringBuilder sb = new StringBuilder();
+            for (int k = 0; k < units; ++k) {
+                final int cp = data.getInt((i * units + k) * 4);
+                if (cp == 0) break;
+                sb.appendCodePoint(cp);
+            }
+            return sb.toString();
+        }
+    }
+
+    static Npy parseNpy(byte[] raw) {
+        if (raw.length < 10 || (raw[0] & 0xFF) != 0x93 || raw[1] != 'N') throw new IllegalStateException("not an .npy array");
+        final int major = raw[6];
+        final int hlen = major == 1 ? ((raw[8] & 0xFF) | ((raw[9] & 0xFF) << 8))
+                                    : ((raw[8] & 0xFF) | ((raw[9] & 0xFF) << 8) | ((raw[10] & 0xFF) << 16) | ((raw[11] & 0xFF) << 24));
+        final int hoff = major == 1 ? 10 : 12;
+        final String header = new String(raw, hoff, hlen, StandardCharsets.ISO_8859_1);
+        final Npy a = new Npy();
+        final Matcher simple = Pattern.compile("'descr':\\s*'([^']+)'").matcher(header);
+        if (simple.find()) {
+            a.descr = simple.group(1);
+            a.itemSize = Npy.sizeOf(a.descr);
+        } else { // [('src', '<i4'), ('channel', '<i4'), ...]
+            final Matcher f = Pattern.compile("\\('([^']+)',\\s*'([^']+)'\\)").matcher(header);
+            while (f.find()) {
+                a.fieldNames.add(f.group(1));
+                a.fieldTypes.add(f.group(2));
+                a.itemSize += Npy.sizeOf(f.group(2));
+            }
+        }
+        if (header.contains("'fortran_order': True")) throw new IllegalStateException("fortran order");
+        final Matcher sh = Pattern.compile("'shape':\\s*\\(([^)]*)\\)").matcher(header);
+        if (!sh.find()) throw new IllegalStateException("no shape");
+        final List<Integer> dims = new ArrayList<>();
+        for (String p : sh.group(1).split(",")) if (!p.trim().isEmpty()) dims.add(Integer.parseInt(p.trim()));
+        a.shape = new int[dims.size()];
+        for (int i = 0; i < dims.size(); ++i) a.shape[i] = dims.get(i);
+        a.data = ByteBuffer.wrap(raw, hoff + hlen, raw.length - hoff - hlen).slice().order(ByteOrder.LITTLE_ENDIAN);
+        return a;
+    }
+
+    static Map<String, Npy> loadNpz(File f) throws IOException {
+        final Map<String, Npy> out = new HashMap<>();
+        try (ZipFile z = new ZipFile(f)) {
+            for (Enumeration<? extends ZipEntry> e = z.entries(); e.hasMoreElements();) {
+                final ZipEntry ze = e.nextElement();
+                try (InputStream in = z.getInputStream(ze)) {
+                    final ByteArrayOutputStream b = new ByteArrayOutputStream();
+                    final byte[] buf = new byte[1 << 16];
+                    for (int n; (n = in.read(buf)) > 0;) b.write(buf, 0, n);
+                    out.put(ze.getName().replaceAll("\\.npy$", ""), parseNpy(b.toByteArray()));
+                }
+            }
+        }
+        return out;
+    }
+
+    /** what a medium told the simulator about one heard link */
+    static final class Call {
+        final int packet, node;
+        final double rssi;
+        final boolean deliver;
+
+        Call(int packet, int node, double rssi, boolean deliver) {
+            this.packet = packet;
+            this.node = node;
+            this.rssi = rssi;
+            this.deliver = deliver;
+        }
+    }
+
+    /** The reference's Simulator with the event queue taken out: the media's calls are recorded instead of scheduled. */
+    static final class RecordingSimulator extends Simulator {
+        final List<Call> calls = new ArrayList<>();
+        final IdentityHashMap<Node, Integer> index = new IdentityHashMap<>();
+        int currentPacket;
+
+        RecordingSimulator(Random r) {
+            super(r);
+        }
+
+        @Override
+        public void generateReceptionEvents(RadioPacket packet, Node destination, double rssi, boolean doDeliver) {
+            calls.add(new Call(currentPacket, index.get(destination), rssi, doDeliver));
+        }
+
+        @Override
+        public void generateTransmissionEvents(RadioPacket packet) {
+            /* (TransmissionEvents carry no verdict) */
+        }
+
+        @Override
+        public void deliverRadioPacket(RadioPacket packet, Node destination, double rssi) {
+            calls.add(new Call(currentPacket, index.get(destination), rssi, true)); // the constant-loss medium delivers at once
+        }
+    }
+
+    static String hexOfAirTime(long airUs) { // RadioPacket.getPacketAirTime: 32 us per hex character
+        if (airUs % 32 != 0) throw new IllegalStateException("air time " + airUs + " is not a whole number of hex characters");
+        final StringBuilder sb = new StringBuilder();
+        for (long k = 0; k < airUs / 32; ++k) sb.append('0');
+        return sb.toString();
+    }
+
+    static boolean runScenario(File f) throws IOException {
+        final Map<String, Npy> g = loadNpz(f);
+        final String kind = g.get("kind").str(0);
+        if (kind.equals("logdist")) {
+            System.out.println(f.getName() + ": the build's extension medium (no reference class) -- skipped");
+            return true;
+        }
+        final long seed = g.get("seed").i64(0);
+        final Random random = seed >= 0 ? new Random(seed) : new Random(0);
+        final RecordingSimulator sim = new RecordingSimulator(random);
+
+        // the node table, in registration order (Simulator.getNodes() order = the vectors' node index)
+        final Npy x = g.get("node_x"), y = g.get("node_y"), z = g.get("node_z"), txp = g.get("node_txpower"), ch = g.get("node_channel");
+        final Npy en = g.get("node_enabled"), rxp = g.get("node_rxprob"), txq = g.get("node_txprob"), ids = g.get("node_int_id");
+        final int n = x.count();
+        final Node[] nodes = new Node[n];
+        for (int i = 0; i < n; ++i) {
+            final int id = ids.i32(i);
+            final Node node = sim.addNode(id > 0 ? Integer.toString(id) : "n" + i, null); // a non-numeric id has no matrix row (Node.java:52-57)
+            node.getPosition().set(x.f64(i), y.f64(i), z.f64(i));
+            final Transciever radio = node.getRadio();
+            radio.setTransmitPower(txp.f64(i));
+            radio.setWirelessChannel(ch.i32(i));
+            radio.setEnabled(en.u8(i) != 0);
+            radio.setRxProbability(rxp.f64(i));
+            radio.setTxProbability(txq.f64(i));
+            nodes[i] = node;
+            sim.index.put(node, i);
+        }
+
+        // the medium and its parameters
+        final Map<String, Double> params = new HashMap<>();
+        final Npy pn = g.get("param_names"), pv = g.get("param_values");
+        for (int i = 0; pn != null && i < pn.count(); ++i) params.put(pn.str(i), pv.f64(i));
+        final RadioMedium medium;
+        switch (kind) {
+        case "udgm": {
+            final UDGMRadioMedium m = new UDGMRadioMedium();
+            if (params.containsKey("udgm_success_ratio_rx")) m.setSuccessRatioRx(params.get("udgm_success_ratio_rx"));
+            if (params.containsKey("udgm_success_ratio_tx")) m.setSuccessRatioTx(params.get("udgm_success_ratio_tx"));
+            if (params.containsKey("udgm_transmission_range")) m.setTransmissionRange(params.get("udgm_transmission_range"));
+            if (params.containsKey("udgm_interference_range")) m.setInterferenceRange(params.get("udgm_interference_range"));
+            medium = m;
+            break;
+        }
+        case "udgm_const":
+            medium = new UDGMConstantLossRadioMedium();
+            break;
+        case "n2n": {
+            final Npy mat = g.get("matrix");
+            final int rows = mat.shape[0], cols = mat.shape[1];
+            final double[][] m = new double[rows][cols];
+            for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) m[r][c] = mat.f64(r * cols + c);
+            medium = new N2NRadioMedium(m);
+            break;
+        }
+        case "null":
+            medium = new NullRadioMedium();
+            break;
+        default:
+            throw new IllegalStateException("kind " + kind);
+        }
+        medium.setSimulator(sim);
+        sim.setRadioMedium(medium);
+
+        // tick by tick: every packet through RadioMedium.transmit, in the vectors' order
+        final int ticks = (int) g.get("n_ticks").i64(0);
+        long links = 0;
+        for (int t = 0; t < ticks; ++t) {
+            final Npy pk = g.get("t" + t + "_packets");
+            sim.calls.clear();
+            for (int q = 0; q < pk.count(); ++q) {
+                final Node src = nodes[(int) pk.fieldLong(q, "src")];
+                final RadioPacket packet = new RadioPacket(src, pk.fieldLong(q, "start_us"), hexOfAirTime(pk.fieldLong(q, "air_us")));
+                // (RadioPacket copies power and channel from its source, RadioPacket.java:46-52; the vectors' packets carry the same)
+                if (packet.getTransmitPower() != pk.field(q, "txpower") || packet.getWirelessChannel() != (int) pk.fieldLong(q, "channel")) {
+                    packet.setTransmitPower(pk.field(q, "txpower"));
+                    packet.setWirelessChannel((int) pk.fieldLong(q, "channel"));
+                }
+                sim.currentPacket = q;
+                medium.transmit(packet);
+            }
+            final Npy ePkt = g.get("t" + t + "_pkt"), eDst = g.get("t" + t + "_dst"), eVer = g.get("t" + t + "_verdict"), eRssi = g.get("t" + t + "_rssi");
+            if (sim.calls.size() != ePkt.count()) {
+                System.out.println(f.getName() + " tick " + t + ": " + sim.calls.size() + " heard links from the reference, " + ePkt.count() + " in the vectors");
+                return false;
+            }
+            for (int i = 0; i < sim.calls.size(); ++i) {
+                final Call c = sim.calls.get(i);
+                final boolean deliver = eVer.u8(i) == 2; // RM_INTERFERED = 1, RM_DELIVERED = 2 (include/radiomedium_hip.h)
+                if (c.packet != ePkt.i32(i) || c.node != eDst.i32(i) || c.deliver != deliver
+                        || Double.doubleToRawLongBits(c.rssi) != Double.doubleToRawLongBits(eRssi.f64(i))) {
+                    System.out.println(f.getName() + " tick " + t + " link " + i + ": reference (packet " + c.packet + ", node " + c.node + ", rssi " + c.rssi
+                            + ", deliver " + c.deliver + ") vectors (packet " + ePkt.i32(i) + ", node " + eDst.i32(i) + ", rssi " + eRssi.f64(i) + ", deliver " + deliver + ")");
+                    return false;
+                }
+            }
+            links += sim.calls.size();
+        }
+        // the generator: the vectors hold the 48-bit state after the last tick; the reference's next draw must be the one that follows it
+        if (seed >= 0) {
+            final long state = g.get("final_rng_state").i64(0);
+            final long next = (state * 0x5DEECE66DL + 0xBL) & ((1L << 48) - 1);
+            final int expected = (int) (next >>> 16);
+            final int got = random.nextInt();
+            if (got != expected) {
+                System.out.println(f.getName() + ": java.util.Random is at another state after the run (next int " + got + ", vectors say " + expected + ")");
+                return false;
+            }
+        }
+        System.out.println(f.getName() + ": " + medium.getName() + ", " + n + " nodes, " + ticks + " tick(s), " + links + " heard links -- identical");
+        return true;
+    }
+
+    public static void main(String[] args) throws IOException {
+        final File dir = new File(args.length > 0 ? args[0] : "tests/golden");
+        final String[] names = {"udgm_default.npz", "udgm_stochastic.npz", "const_lattice.npz", "n2n.npz", "null.npz",
+                                "logdist_shadow.npz", "logdist_sinr_overlap.npz"};
+        boolean ok = true;
+        for (String name : names) ok &= runScenario(new File(dir, name));
+        System.out.println(ok ? "PINNED: the reference's own media reproduce tests/golden bit for bit" : "MISMATCH (see above)");
+        System.exit(ok ? 0 : 1);
+    }
+}

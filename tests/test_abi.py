@@ -121,3 +121,24 @@ def test_jni_glue_type_checks_and_matches_the_java_declarations(tmp_path):
         got = [p.split()[0] for p in cparams.split(",")][2:]          # after JNIEnv *env, jclass cls
         assert got == want, (name, got, want)
     assert set(cfuncs) == {n for _, n, _ in natives}
+
+
+def test_parity_harness_reads_the_goldens_as_they_are():
+    """integration/java/harness/ReferenceParityHarness.java cannot be compiled here (no JDK); what can be held: the scenario
+    files it names exist, the verdict code it compares with is the header's, and the .npy headers have the shape its reader
+    expects (version 1, a quoted descr or a list of (name, type) pairs, C order)."""
+    import zipfile
+    src = open(os.path.join(ROOT, "integration", "java", "harness", "ReferenceParityHarness.java")).read()
+    hdr = open(os.path.join(ROOT, "include", "radiomedium_hip.h")).read()
+    delivered = int(re.search(r"RM_DELIVERED\s*=\s*(\d+)", hdr).group(1))
+    assert "eVer.u8(i) == %d" % delivered in src
+    names = re.findall(r'"(\w+\.npz)"', src)
+    assert len(names) >= 5
+    for name in names:
+        z = zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", name))
+        for entry in z.namelist():
+            raw = z.read(entry)
+            assert raw[:6] == b"\x93NUMPY" and raw[6] == 1, entry
+            header = raw[10:10 + (raw[8] | (raw[9] << 8))].decode("latin1")
+            assert "'fortran_order': False" in header
+            assert re.search(r"'descr':\s*'[<|][fiuU]\d+'", header) or re.findall(r"\('\w+',\s*'<[fi][48]'\)", header), (name, entry, header)
