@@ -481,7 +481,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
         return RM_OK;
     };
-    if (c->use_graphs && !sample) {
+    if (c->use_graphs && !sample && !t.air_scan) { // (a tick by scan carries a new stamp every time: nothing to replay)
         uint64_t key = 1469598103934665603ull;
         auto mix = [&](const void *p, size_t n) {
             const unsigned char *b = static_cast<const unsigned char *>(p);
