@@ -559,11 +559,7 @@ int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, c
     if (dev_new && n > 0) // the caller's records join the window (every later tick looks at them while they are on the air)
         RM_HIP(hipMemcpyAsync(c->d_air.p + c->air_tail, dev_new, size_t(n) * sizeof(rm_tx_record),
                               new_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
-    // rm_tick_begin's rule is applied tick by tick: a frame that had left the air when an earlier tick began does not
-    // come back when the clock does.  The kernels compare with THIS tick's t_begin, so (rarely) such frames are retired
-    // for good in the window first.
-    if (live > 0 && t_begin_us < c->air_max_t_begin)
-        RM_HIP(rm::launch_air_expire(c->stream, c->d_air.p + c->air_head, int(live), c->air_max_t_begin));
+    const bool clock_back = t_begin_us < c->air_max_t_begin;
     c->air_max_t_begin = std::max(c->air_max_t_begin, t_begin_us);
     uint32_t oldest = 0;
     bool unknown = false;
@@ -574,6 +570,12 @@ int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, c
     RM_TRY(prepare_nodes(c)); // (a changed table makes the lists stale, and decides whether the tick can go by scan)
     const int air_mode = air_scan_applies(c, n) ? kAirScan
                                                 : ((!unknown && air_lists_current(c, t_begin_us, oldest)) ? kAirIncremental : kAirRebuild);
+    // rm_tick_begin's rule is applied tick by tick: a frame that had left the air when a tick began does not come back when
+    // the clock does.  The kernels compare with THIS tick's t_begin, so when the clock goes back such frames are first
+    // retired in the window for good; a rebuild of the lists retires them too, so that it does not sweep frames (inside
+    // batches that are still alive) that have nothing to say any more.
+    if (live > 0 && (clock_back || air_mode == kAirRebuild))
+        RM_HIP(rm::launch_air_expire(c->stream, c->d_air.p + c->air_head, int(live), c->air_max_t_begin));
     // the records of the new frames are built at the window's tail either way; an incremental tick sweeps only those
     const int first_new = (air_mode == kAirIncremental) ? 0 : int(live);
     const rm_tx_record *base = c->d_air.p + c->air_head + (air_mode == kAirIncremental ? live : 0);

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import (run_both, assert_same, random_nodes, to_tx_records, configure_engine, oracle_model)
+from util import (run_both, assert_same, random_nodes, to_tx_records, configure_engine, oracle_model, sinr_lists_forced)
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ def sinr_form(request, monkeypatch):
     """Both forms of the SINR medium's lone tick: by scan (the interferers of a heard link found among the frames on the air,
     rm_airscan.hip -- the default wherever the one-launch tick applies) and with the per-receiver lists kept on the device
     (RM_SINR_SCAN=0: what larger ticks and unsorted tables take)."""
-    forced = os.environ.get("RM_SINR_SCAN") == "0" or os.environ.get("RM_SINR_FRAMES") == "0"    # (tools/knob_sweep.sh)
+    forced = sinr_lists_forced()                 # (tools/knob_sweep.sh)
     if request.param == "lists":
         monkeypatch.setenv("RM_SINR_SCAN", "0")
     elif forced:
@@ -368,7 +368,7 @@ def test_sinr_scan_through_the_frame_grid(engine, rsa, O):
     weak transmitters on a large field, thousands of frames on the air; a tight cluster of transmitters overfills its cell
     (more than 16 frames: the rest go to the list every new frame looks at); one frame has no bound at all (its transmitter
     shouts), one transmitter moves while its frame is on the air (half duplex goes by node, not by place)."""
-    if os.environ.get("RM_SINR_SCAN") == "0" or os.environ.get("RM_SINR_FRAMES") == "0":
+    if sinr_lists_forced():
         pytest.skip("the run's knobs keep the lists")
     n = 20000
     nd = _layout(O, n, seed=61)

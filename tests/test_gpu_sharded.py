@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import to_tx_records, KINDS, _PARAM_MAP, oracle_model
+from util import to_tx_records, KINDS, _PARAM_MAP, oracle_model, sinr_lists_forced
 
 pytestmark = pytest.mark.gpu
 
@@ -199,7 +199,7 @@ def test_sharded_driver_with_frames_on_the_air_on_one_gpu():
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
         outs.append(json.loads(line))
     assert outs[0]["config"]["heard_links_last_tick"] == outs[1]["config"]["heard_links_last_tick"] > 0
-    if os.environ.get("RM_SINR_SCAN") == "0" or os.environ.get("RM_SINR_FRAMES") == "0":   # (the list form: tools/knob_sweep.sh)
+    if sinr_lists_forced():                            # (the list form: tools/knob_sweep.sh)
         assert ("1 rebuilt those" if os.environ.get("RM_AIR_LISTS") != "0" else "0 added their frames to per-receiver lists") in outs[1]["config"]["workload"]
     else:
         assert "by scan, 0 added their frames to per-receiver lists, 0 rebuilt those" in outs[1]["config"]["workload"]
@@ -328,7 +328,7 @@ def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world, 
             interfered += int((ref.verdict == O.INTERFERED).sum())
         assert interfered > 50
         inc, reb = engs[0].air_list_stats()
-        if os.environ.get("RM_SINR_SCAN") == "0" or os.environ.get("RM_SINR_FRAMES") == "0":   # (the list form, tools/knob_sweep.sh)
+        if sinr_lists_forced():                        # (the list form, tools/knob_sweep.sh)
             if os.environ.get("RM_AIR_LISTS") != "0":
                 assert reb == 2 and inc == len(airs) - 2   # the first tick and the one after the move
         else:                                          # by scan: nothing is kept per receiver, nothing to rebuild

@@ -1,6 +1,15 @@
 """Shared helpers of the parity tests: run the same inputs through the CPU oracle and the HIP
 engine (through its C ABI) and compare the heard-link lists."""
+import os
+
 import numpy as np
+
+
+def sinr_lists_forced():
+    """Do the run's developer knobs (tools/knob_sweep.sh) keep the SINR medium's lone ticks on the per-receiver lists instead of
+    the scan (rm_airscan.hip)?"""
+    return os.environ.get("RM_SINR_SCAN") == "0" or os.environ.get("RM_SINR_FRAMES") == "0" or os.environ.get("RM_FRAME_TICK") == "0"
+
 
 KINDS = {"null": 0, "udgm": 1, "udgm_const": 2, "n2n": 3, "logdist": 4}
 
