@@ -263,7 +263,7 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
         got = flush_loop(16, 16 + reps)
         el = time.perf_counter() - t0
     out["tick_flush_view"] = {"us_per_tick": el / reps * 1e6, "value": links_per_tick * reps / el, "unit": "links/s",
-                              "bytes_out_per_tick": got / reps * 17, "bytes_in_per_tick": t_per_tick * 64}
+                              "bytes_out_per_tick": got / reps * 13 + t_per_tick * 5, "bytes_in_per_tick": t_per_tick * 64}
     # the reception stage on: frames of 8128 us over 1000 us ticks, ~9 ticks of packets pending at any time
     with torch.cuda.stream(stream):
         eng.events_enable(1 << 16, 1 << 21)
@@ -314,7 +314,7 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
             el = time.perf_counter() - t0
         links = sum(v.count for v in views)
         out["batch_result_view"] = {"us_per_tick": el / (reps_b * nb) * 1e6, "value": links_per_tick * reps_b * nb / el,
-                                    "unit": "links/s", "ticks_per_launch": nb, "bytes_out_per_tick": links / nb * 17}
+                                    "unit": "links/s", "ticks_per_launch": nb, "bytes_out_per_tick": links / nb * 13}
     return out
 
 
