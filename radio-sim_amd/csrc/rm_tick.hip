@@ -837,7 +837,15 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
     const uint32_t room = dropped ? 0u : v.links;
     const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
     const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
-    for (uint32_t q = blockIdx.x * 4 + wave_index(); q < np; q += gridDim.x * 4) { // wave-uniform
+    // Workgroups go round the XCDs (blockIdx % 8), and the stores below gather in an XCD's own L2 until its workgroups'
+    // fences write them out: every XCD packs ONE contiguous eighth of the frames, so that a line of the host's block is
+    // filled by one L2 and crosses the link as one full write (frames dealt out wave by wave shared a third of their lines
+    // between two XCDs).
+    const uint32_t per_x = (np + 7u) / 8u, xcd = blockIdx.x & 7u;
+    const uint32_t waves_x = max(1u, (gridDim.x / 8u) * 4u), wave_x = (blockIdx.x / 8u) * 4u + uint32_t(wave_index());
+    for (uint32_t k = wave_x; k < per_x && (gridDim.x & 7u) == 0u; k += waves_x) { // wave-uniform
+        const uint32_t q = xcd * per_x + k;
+        if (q >= np) break;
         const int slot = int(q) + t.shift;
         const uint32_t src0 = uniform_u(t.seg_off[slot]);
         const uint32_t len = uniform_u(t.cursor[slot]);
@@ -1021,7 +1029,11 @@ hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const Mod
 hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t, int n_new, const HostView &v, uint32_t *done_counter,
                               uint32_t seq)
 {
-    const dim3 grid(64), block(256);
+    static const int wgs = [] { // (developer knob: workgroups of the pack, a multiple of the eight XCDs)
+        const char *e = getenv("RM_PACK_WGS");
+        return e ? max(8, min(1024, atoi(e) & ~7)) : 64;
+    }();
+    const dim3 grid(wgs), block(256);
     const int scan = scan_variant(t.n_cnt);
     if (scan == 3) hipLaunchKernelGGL(k_pack_frames<3>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
     else if (scan == 4) hipLaunchKernelGGL(k_pack_frames<4>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
