@@ -302,6 +302,13 @@ int rm_batch_run_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin
  * the world * slots records dev_gathered[(r * n_ticks + b) * slots + s], rank-major -- no transposition in between */
 int rm_batch_run_gathered_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                                  const rm_tx_record *dev_gathered, int32_t world, int32_t slots);
+/* the same from the ticks' SOURCE INDICES where an all-gather of per-rank blocks left them: dev_src_all[rank][tick][slot]
+ * (-1: padding; all frames of tick b start at start_us[b] and last air_us).  Every rank holds the whole node table, so
+ * it builds the records of all ranks' frames itself: what has to cross the links between the GPUs is 4 bytes per frame
+ * instead of a 64-byte record (rm_dist_batch_run_sources_device does exactly this around its ncclAllGather) */
+int rm_batch_run_gathered_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                         const int32_t *dev_src_all, int32_t world, int32_t slots, const int64_t *start_us,
+                                         int64_t air_us);
 int rm_batch_result_device(rm_context *ctx, int32_t slot, rm_device_result *out);
 int rm_batch_result_count(rm_context *ctx, int32_t slot, uint32_t *count, uint32_t *dropped); /* synchronises */
 int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,

@@ -186,22 +186,37 @@ int rm_comm_init_rank(rm_context *c, const uint8_t *id, int32_t world, int32_t r
 int rm_comm_world(const rm_context *c) { return c ? c->comm_world : fail(RM_ERR_INVALID, "ctx is NULL"); }
 int rm_comm_rank(const rm_context *c) { return c ? c->comm_rank : fail(RM_ERR_INVALID, "ctx is NULL"); }
 
+// The ticks' transmitters as every rank's own source indices, already gathered: dev_src_all[rank][tick][slot].  Every rank
+// builds ALL the records itself from its copy of the node table (the same bytes a rank's own pack would have sent), in
+// the layout rm_batch_run_gathered_device reads: what crosses the links between the GPUs is 4 bytes per frame, not 64.
+int rm_batch_run_gathered_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                         const int32_t *dev_src_all, int32_t world, int32_t slots, const int64_t *start_us, int64_t air_us)
+{
+    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || slots < 1 || world < 1 || !dev_src_all || !start_us || !t_begin_us || !t_end_us || air_us < 0)
+        return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    const size_t all = size_t(world) * size_t(n_ticks) * size_t(slots);
+    RM_HIP(c->d_dist_all.ensure(all));
+    RM_HIP(rm::launch_pack_tx_batch(c->stream, nodes_dev(c), dev_src_all, n_ticks, slots, start_us, air_us, c->d_dist_all.p, world));
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, nullptr, nullptr, c->d_dist_all.p, world, slots);
+}
+
 int rm_dist_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                                      const int32_t *dev_src, int32_t slots, const int64_t *start_us, int64_t air_us)
 {
     if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || slots < 1 || !dev_src || !start_us || !t_begin_us || !t_end_us || air_us < 0)
         return fail(RM_ERR_INVALID, "bad arguments");
     RM_HIP(hipSetDevice(c->device));
+    // the all-gather carries the source INDICES (4 bytes per frame): every rank has the whole node table and builds the
+    // records of all ranks' frames itself
     const size_t mine = size_t(n_ticks) * size_t(slots);
-    RM_HIP(c->d_dist_mine.ensure(mine));
-    RM_HIP(c->d_dist_all.ensure(mine * size_t(c->comm_world)));
-    RM_HIP(rm::launch_pack_tx_batch(c->stream, nodes_dev(c), dev_src, n_ticks, slots, start_us, air_us, c->d_dist_mine.p));
-    const rm_tx_record *gathered = c->d_dist_mine.p;
+    const int32_t *all = dev_src;
     if (c->comm) {
-        RM_TRY(comm_all_gather(c, c->d_dist_mine.p, c->d_dist_all.p, mine * sizeof(rm_tx_record)));
-        gathered = c->d_dist_all.p;
+        RM_HIP(c->d_dist_idx.ensure(mine * size_t(c->comm_world)));
+        RM_TRY(comm_all_gather(c, dev_src, c->d_dist_idx.p, mine * sizeof(int32_t)));
+        all = c->d_dist_idx.p;
     }
-    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, nullptr, nullptr, gathered, c->comm_world, slots);
+    return rm_batch_run_gathered_sources_device(c, n_ticks, t_begin_us, t_end_us, all, c->comm ? c->comm_world : 1, slots, start_us, air_us);
 }
 
 int rm_dist_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t slots,
@@ -209,16 +224,17 @@ int rm_dist_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t
 {
     if (!c || slots < 1 || !dev_src || air_us < 0) return fail(RM_ERR_INVALID, "bad arguments");
     RM_HIP(hipSetDevice(c->device));
-    RM_HIP(c->d_dist_mine.ensure(size_t(slots)));
-    RM_HIP(c->d_dist_all.ensure(size_t(slots) * size_t(c->comm_world)));
-    RM_HIP(rm::launch_pack_tx(c->stream, nodes_dev(c), dev_src, slots, start_us, air_us, c->d_dist_mine.p));
-    const rm_tx_record *gathered = c->d_dist_mine.p;
-    if (c->comm) {
-        RM_TRY(comm_all_gather(c, c->d_dist_mine.p, c->d_dist_all.p, size_t(slots) * sizeof(rm_tx_record)));
-        gathered = c->d_dist_all.p;
+    const int world = c->comm ? c->comm_world : 1;
+    const int32_t *all = dev_src;
+    if (c->comm) { // (indices, as above)
+        RM_HIP(c->d_dist_idx.ensure(size_t(slots) * size_t(world)));
+        RM_TRY(comm_all_gather(c, dev_src, c->d_dist_idx.p, size_t(slots) * sizeof(int32_t)));
+        all = c->d_dist_idx.p;
     }
+    RM_HIP(c->d_dist_all.ensure(size_t(slots) * size_t(world)));
+    RM_HIP(rm::launch_pack_tx(c->stream, nodes_dev(c), all, slots * world, start_us, air_us, c->d_dist_all.p));
     // (the SINR medium keeps the frames on the air: the packed frames all end at start + air)
-    RM_TRY(rm_tick_run_records_device(c, t_begin_us, t_end_us, gathered, slots * c->comm_world, start_us + air_us));
+    RM_TRY(rm_tick_run_records_device(c, t_begin_us, t_end_us, c->d_dist_all.p, slots * world, start_us + air_us));
     return comm_finish_draws(c);
 }
 

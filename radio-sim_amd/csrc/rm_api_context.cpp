@@ -298,7 +298,7 @@ void rm_destroy(rm_context *c)
     c->d_enabled.release();
     c->d_member.release(); c->d_draw_nodes.release(); c->d_all_off.release(); c->d_all_nodes.release();
     (void)rm_comm_destroy(c);
-    c->d_dist_mine.release(); c->d_dist_all.release();
+    c->d_dist_mine.release(); c->d_dist_all.release(); c->d_dist_idx.release();
     (void)rm_events_disable(c);
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();

@@ -430,7 +430,7 @@ hipError_t launch_patch_nodes(hipStream_t s, const NodesDev &nd, const NodePatch
 hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n, int64_t start_us,
                           int64_t air_us, rm_tx_record *out);
 hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
-                                const int64_t *start_us, int64_t air_us, rm_tx_record *out);
+                                const int64_t *start_us, int64_t air_us, rm_tx_record *out, int world = 1); // dev_src / out: [world][n_ticks][n]
 hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst);
 hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int pkt_shift_valid, const HostView &v, uint32_t *done_counter,
                             uint32_t seq);

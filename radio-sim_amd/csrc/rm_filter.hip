@@ -120,12 +120,15 @@ struct PackStarts {
     int64_t start_us[kPackChunk];
 };
 
+// (blockIdx.z: the rank whose [n_ticks][n] block of source indices this is -- one block when a rank packs its own
+// transmitters, `world` of them when the INDICES were all-gathered and every rank builds all records itself: 4 bytes per
+// frame over the links between the GPUs instead of 64)
 __global__ void __launch_bounds__(256)
-k_pack_tx_batch(NodesDev nd, const int32_t *src, int n, PackStarts st, int64_t air_us, rm_tx_record *out, int tick0)
+k_pack_tx_batch(NodesDev nd, const int32_t *src, int n, PackStarts st, int64_t air_us, rm_tx_record *out, int tick0, int n_ticks)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const size_t o = size_t(tick0 + blockIdx.y) * n + i;
+    const size_t o = (size_t(blockIdx.z) * n_ticks + size_t(tick0 + blockIdx.y)) * n + i;
     const rm_tx_record r = make_tx_record(nd, src[o], st.start_us[blockIdx.y], air_us);
     out[o] = r;
 }
@@ -782,7 +785,7 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
 }
 
 hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t *dev_src, int n_ticks, int n,
-                                const int64_t *start_us, int64_t air_us, rm_tx_record *out)
+                                const int64_t *start_us, int64_t air_us, rm_tx_record *out, int world)
 {
     if (n <= 0 || n_ticks <= 0) return hipSuccess;
     if (n_ticks > kMaxBatch) return hipErrorInvalidValue;
@@ -790,7 +793,7 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
         const int nb = min(kPackChunk, n_ticks - b0);
         PackStarts st{};
         for (int b = 0; b < nb; ++b) st.start_us[b] = start_us[b0 + b];
-        hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), nb), dim3(256), 0, s, nd, dev_src, n, st, air_us, out, b0);
+        hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), nb, max(world, 1)), dim3(256), 0, s, nd, dev_src, n, st, air_us, out, b0, n_ticks);
     }
     return hipGetLastError();
 }

@@ -218,7 +218,8 @@ struct rm_context : TickSlot {
     void *comm = nullptr;            // ncclComm_t
     bool comm_owned = false;
     int comm_world = 1, comm_rank = 0;
-    DevBuf<rm_tx_record> d_dist_mine, d_dist_all; // this rank's packed frames / the gathered blocks [rank][tick][slot]
+    DevBuf<rm_tx_record> d_dist_mine, d_dist_all; // this rank's packed frames / the frames of all ranks [rank][tick][slot]
+    DevBuf<int32_t> d_dist_idx;                   // the gathered source indices [rank][tick][slot] (what crosses the links)
     uint32_t cap = 1u << 22;
 
     int64_t current_time = 0;

@@ -164,14 +164,11 @@ class ShardedTick:
                     e.set_partition(self.lo, self.hi - self.lo)
         self.comm = torch.cuda.Stream(device=device)
         ring = len(self.engines) + 1
-        # batch > 1: a stage covers `batch` ticks -- one packing launch, ONE all-gather of
-        # world x batch x slots records (xGMI likes few, larger collectives), one transposition to
-        # tick-major order, and the sweep of all of them through rm_batch_run_device
+        # batch > 1: a stage covers `batch` ticks -- ONE all-gather of world x batch x slots source indices (xGMI likes few,
+        # larger collectives) and the sweep of all of them (run_batch)
         self.batch = batch
         self.mine = [torch.empty(batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
         self.all = [torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
-        # (also for batch == 1: run_batch may be called with a single tick)
-        self.tick_major = [torch.empty(world * batch * slots * RECORD_BYTES, dtype=torch.uint8, device=device) for _ in range(ring)]
         # one process group (RCCL communicator) per context: their collectives are independent
         self.groups = [dist.new_group() for _ in self.engines] if dist is not None else None
         self.ready = [torch.cuda.Event() for _ in range(ring)]  # gathered records of the buffer are complete
@@ -252,9 +249,8 @@ class ShardedTick:
 
     def run_batch(self, ctx, dev_src_ptr, t_begins, air_us, tick_us):
         """len(t_begins) <= batch ticks on context `ctx`, everything on that context's own stream:
-        one packing launch (sources: rows of `slots` int32 at dev_src_ptr), ONE all-gather of
-        world x ticks x slots records on the context's own process group, one transposition to
-        tick-major order, the sweep through rm_batch_run_device.  No cross-stream events: on this
+        ONE all-gather of world x ticks x slots source indices (rows of `slots` int32 at dev_src_ptr) on the
+        context's own process group, then the sweep.  No cross-stream events: on this
         runtime an event wait between two streams costs far more than the collective it would hide,
         and with two contexts the other context's sweep runs under this one's all-gather anyway."""
         torch = self.torch
@@ -264,28 +260,26 @@ class ShardedTick:
             raise ValueError("run_batch cannot place java.util.Random draws across ranks: use stage() / sweep() per tick "
                              "(or construct ShardedTick with may_draw=False for media without draws)")
         eng, stream = self.engines[ctx], self.streams[ctx]
-        nb, row = len(t_begins), self.slots * RECORD_BYTES
+        nb = len(t_begins)
         if nb > self.batch:
             raise ValueError("run_batch: %d ticks, the buffers hold %d" % (nb, self.batch))
         with torch.cuda.stream(stream):
-            eng.pack_tx_batch_device_on(stream.cuda_stream, dev_src_ptr, nb, self.slots, t_begins, air_us,
-                                        self.mine[ctx].data_ptr())
-            src = self.mine[ctx]
+            # the all-gather carries the ticks' SOURCE INDICES (4 bytes per frame: every rank has the whole node table and
+            # builds all ranks' records itself, rm_batch_run_gathered_sources_device) -- a 64-byte record per frame over the
+            # links between the GPUs would cost more than the sweep of a rank's share of the receivers
+            all_ptr, ranks = dev_src_ptr, 1
             if self.dist is not None:
-                mine, gathered = self.mine[ctx][: nb * row], self.all[ctx][: self.world * nb * row]
+                mine = self._device_int32(dev_src_ptr, nb * self.slots, stream.device).view(torch.uint8)
+                gathered = self.all[ctx][: self.world * nb * self.slots * 4]
                 all_gather_records(self.dist, mine, self.world, gathered, group=self.groups[ctx])
-                # [rank][tick][slot] -> [tick][rank][slot]: a tick's frames in canonical (rank = source range) order
-                src = self.tick_major[ctx]
-                src[: self.world * nb * row].view(nb, self.world, row).copy_(gathered.view(self.world, nb, row).permute(1, 0, 2))
-            per_tick = self.world * self.slots
-            ptrs = src.data_ptr() + np.arange(nb, dtype=np.uint64) * np.uint64(per_tick * RECORD_BYTES)
-            eng.batch_run_device(t_begins, t_begins + tick_us, ptrs, np.full(nb, per_tick, dtype=np.int32))
+                all_ptr, ranks = gathered.data_ptr(), self.world
+            eng.batch_run_gathered_sources_device(t_begins, t_begins + tick_us, all_ptr, ranks, self.slots, t_begins, air_us)
 
-    def _device_int32(self, ptr, count):
-        """`count` int32 of engine-owned device memory as a tensor (no copy)"""
+    def _device_int32(self, ptr, count, device=None):
+        """`count` int32 of device memory somebody else owns as a tensor (no copy)"""
         class _Mem:
             __cuda_array_interface__ = {"shape": (count,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-        return self.torch.as_tensor(_Mem(), device=self.comm.device)
+        return self.torch.as_tensor(_Mem(), device=device if device is not None else self.comm.device)
 
     def run(self, dev_src_ptr, t_begin, t_end, air_us):
         """Unpipelined convenience: stage and sweep one tick."""

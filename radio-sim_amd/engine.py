@@ -362,6 +362,14 @@ class Engine:
         check(self._L.rm_batch_run_gathered_device(self._h, len(tb), tb.ctypes.data, te.ctypes.data, C.c_void_p(dev_gathered_ptr),
                                                    world, slots))
 
+    def batch_run_gathered_sources_device(self, t_begin, t_end, dev_src_all_ptr, world, slots, start_us, air_us):
+        """the ticks' source indices where an all-gather of per-rank blocks left them: [rank][tick][slot] (-1: padding)"""
+        tb = np.ascontiguousarray(t_begin, dtype=np.int64)
+        te = np.ascontiguousarray(t_end, dtype=np.int64)
+        st = np.ascontiguousarray(start_us, dtype=np.int64)
+        check(self._L.rm_batch_run_gathered_sources_device(self._h, len(tb), tb.ctypes.data, te.ctypes.data, C.c_void_p(dev_src_all_ptr),
+                                                           world, slots, st.ctypes.data, int(air_us)))
+
     def prepared(self, name, *args):
         """A call with its arguments converted once: `name` is an entry point that takes the context first; numpy arrays are
         passed by address (and kept alive by the closure).  The returned function costs one ctypes call -- what a host

@@ -61,6 +61,51 @@ def test_gathered_layout_equals_tick_major_records(rsa, O):
         eng.close()
 
 
+def test_gathered_sources_build_the_records_every_rank_would_have_sent(rsa, O):
+    """rm_batch_run_gathered_sources_device: the all-gather of a sharded batch carries source indices (4 bytes per frame), and
+    every rank builds all ranks' records from its own copy of the node table -- the same ticks as from gathered records, and
+    as the oracle has them."""
+    n, world, slots, n_ticks = 6000, 3, 9, 7
+    nd = _nodes(O, n, 5)
+    rng = np.random.default_rng(5)
+    nd.txpower[:] = rng.uniform(-10, 0, n)
+    nd.channel[rng.random(n) < 0.3] = 11
+    eng = rsa.Engine(0)
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"], ld_sigma_db=4.0, ld_seed=3)
+        idx = np.full((world, n_ticks, slots), -1, dtype=np.int32)
+        records = np.zeros((world, n_ticks, slots), dtype=rsa.TX_RECORD_DTYPE)
+        records["src"] = -1
+        t0 = np.arange(n_ticks, dtype=np.int64) * 1000
+        for r in range(world):
+            for b in range(n_ticks):
+                k = int(rng.integers(0, slots + 1))
+                idx[r, b, :k] = np.sort(rng.choice(n, k, replace=False))
+                records[r, b, :k] = to_tx_records(rsa, nd.packets(idx[r, b, :k], int(t0[b]), 8128))
+        dev_idx, dev_rec = DeviceArray(idx), DeviceArray(records)
+        eng.batch_run_gathered_sources_device(t0, t0 + 1000, dev_idx.ptr.value, world, slots, t0, 8128)
+        got = [eng.batch_result_copy(b, world * slots) for b in range(n_ticks)]
+        eng.batch_run_gathered_device(t0, t0 + 1000, dev_rec.ptr.value, world, slots)
+        mdl = oracle_model(O, "logdist", {"ld_sigma_db": 4.0, "ld_seed": 3})
+        links = 0
+        for b in range(n_ticks):
+            assert_same(got[b], eng.batch_result_copy(b, world * slots), "tick %d: from indices vs from records" % b)
+            order = idx[:, b, :].reshape(-1)
+            valid = np.nonzero(order >= 0)[0]
+            cpu = O.tick(mdl, nd, nd.packets(order[valid], int(t0[b]), 8128))
+            assert got[b].count == cpu.count
+            np.testing.assert_array_equal(got[b].pkt, valid[cpu.pkt])
+            np.testing.assert_array_equal(got[b].dst, cpu.dst)
+            np.testing.assert_array_equal(got[b].rssi, cpu.rssi)
+            links += cpu.count
+        assert links > 500
+        dev_idx.free()
+        dev_rec.free()
+    finally:
+        eng.close()
+
+
 def test_dist_calls_through_rccl_with_one_rank(rsa, O):
     """rm_comm_init_rank with a world of one: ncclGetUniqueId, ncclCommInitRank and ncclAllGather really run (RCCL is bound
     by dlopen inside the library); the batch and the single tick -- with java.util.Random draws -- equal the plain calls."""
