@@ -292,7 +292,7 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
         el = time.perf_counter() - t0
         eng.events_disable()
     out["tick_events"] = {"us_per_tick": el / reps * 1e6, "value": links_per_tick * reps / el, "unit": "links/s",
-                          "deliveries_per_tick": got / reps, "bytes_out_per_tick": got / reps * 20,
+                          "deliveries_per_tick": got / reps, "bytes_out_per_tick": got / reps * 12 + t_per_tick * 16,
                           "tick_call_us": split[0] / reps * 1e6, "drain_call_us": split[1] / reps * 1e6,
                           "what": "rm_tick_run_sources_device + rm_events_process per tick: Simulator.generate*Events, "
                                   "processAllEvents and the Transciever state on the device, the deliveries on the host"}

@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-/* 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe); rm_air_scan_ticks.
+/* 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe) and so is
+ *    rm_delivery_view.packet (the packet numbers come once per run of deliveries: n_runs, run_*); rm_air_scan_ticks,
+ *    rm_batch_run_gathered_sources_device.
  * 2: rm_delivery_view.oldest_packet; rm_host_result.sinr / rm_device_result.sinr are NULL without the SINR extension;
  *    rm_group_*, rm_events_*, rm_node_info, rm_tick_run_records_device, rm_set_partition_spatial and the draw-node
  *    exchange were added; rm_tick_run_device refuses the SINR medium (rm_tick_run_records_device takes it).  A host
@@ -456,9 +458,16 @@ typedef struct rm_delivery_view {
     uint32_t pending_packets;  /* packets with events still queued */
     int64_t oldest_packet;     /* number of the oldest of them (== rm_events_next_packet: none): every packet
                                 * below it has fired its last event and may be forgotten by the host */
-    const int64_t *packet;     /* [count] packet number */
+    const int64_t *packet;     /* NULL since ABI version 3: the packet numbers come once per run (below) */
     const int32_t *dst;        /* [count] destination node index */
     const double *rssi;        /* [count] */
+    /* The list in runs: all deliveries of one packet in this drain are adjacent (one fired end group of the queue), so the
+     * packet number crosses the link once per run instead of once per delivery (8 of 20 bytes).  Run r covers the
+     * deliveries [run_first[r], run_first[r] + run_count[r]); the runs are in list order and cover it completely. */
+    uint32_t n_runs;
+    const int64_t *run_packet; /* [n_runs] */
+    const uint32_t *run_first; /* [n_runs] */
+    const uint32_t *run_count; /* [n_runs] */
 } rm_delivery_view;
 int rm_events_enable(rm_context *ctx, uint32_t max_pending_packets, uint32_t max_pending_links); /* 0, 0: defaults */
 int rm_events_disable(rm_context *ctx);

@@ -86,8 +86,8 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     /* reception stage on the device */
     private static native int nEventsEnable(long ctx, int maxPackets, int maxLinks);
     private static native long nEventsNextPacket(long ctx);
-    private static native int nEventsProcess(long ctx, long timeUs, java.nio.ByteBuffer[] views /* packet, dst, rssi */,
-            long[] counts /* deliveries, pending packets, number of the oldest pending packet */);
+    private static native int nEventsProcess(long ctx, long timeUs, java.nio.ByteBuffer[] views /* run packet, run first, run count, dst, rssi */,
+            long[] counts /* deliveries, pending packets, number of the oldest pending packet, runs */);
     private static native int nNodeInfo(long ctx, int[] nodes, double[] rssi, int[] receiving, int[] channel);
 
     private final Object lock = new Object();
@@ -345,24 +345,34 @@ public class GpuRadioMedium extends AbstractRadioMedium {
         Simulator sim = this.simulator;
         synchronized (lock) {
             if (!deviceEvents || sim == null) return;
-            java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[3];
-            long[] counts = new long[3]; // deliveries, pending packets, number of the oldest pending packet
+            java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[5];
+            long[] counts = new long[4]; // deliveries, pending packets, number of the oldest pending packet, runs
             if (nEventsProcess(ctx, time, v, counts) != 0) {
                 log.error("radio medium: {}", nLastError());
                 return;
             }
             Node[] nodes = sim.getNodes();
-            java.nio.LongBuffer pk = v[0].order(java.nio.ByteOrder.nativeOrder()).asLongBuffer();
-            java.nio.IntBuffer d = v[1].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer();
-            java.nio.DoubleBuffer r = v[2].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer();
+            // the deliveries of one packet are adjacent in the queue's pop order: its number comes once per run
+            java.nio.LongBuffer runPacket = v[0].order(java.nio.ByteOrder.nativeOrder()).asLongBuffer();
+            java.nio.IntBuffer runFirst = v[1].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer();
+            java.nio.IntBuffer runCount = v[2].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer();
+            java.nio.IntBuffer d = v[3].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer();
+            java.nio.DoubleBuffer r = v[4].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer();
             RadioPacket[] live = inFlight.toArray(new RadioPacket[0]);
-            for (int i = 0; i < counts[0]; i++) { // ReceptionEvent.java:41-44, in the queue's pop order
-                long k = pk.get(i) - firstInFlight;
-                if (k < 0 || k >= live.length || d.get(i) < 0 || d.get(i) >= nodes.length) {
-                    log.error("radio medium: a delivery names a packet or node the host does not hold");
+            for (int run = 0; run < counts[3]; run++) {
+                long k = runPacket.get(run) - firstInFlight;
+                int first = runFirst.get(run), end = first + runCount.get(run);
+                if (k < 0 || k >= live.length || first < 0 || end > counts[0]) {
+                    log.error("radio medium: a delivery names a packet the host does not hold");
                     continue;
                 }
-                sim.deliverRadioPacket(live[(int) k], nodes[d.get(i)], r.get(i));
+                for (int i = first; i < end; i++) { // ReceptionEvent.java:41-44, in the queue's pop order
+                    if (d.get(i) < 0 || d.get(i) >= nodes.length) {
+                        log.error("radio medium: a delivery names a node the host does not hold");
+                        continue;
+                    }
+                    sim.deliverRadioPacket(live[(int) k], nodes[d.get(i)], r.get(i));
+                }
             }
             long oldest = counts[2]; // every packet below the oldest one still queued has fired its last event
             while (firstInFlight < oldest && !inFlight.isEmpty()) {

@@ -204,11 +204,12 @@ JNIEXPORT jint JFN(nEventsProcess)(JNIEnv *env, jclass cls, jlong ctx, jlong tim
     rm_delivery_view v;
     int rc = rm_events_process((rm_context *)(intptr_t)ctx, timeUs, &v);
     if (rc != RM_OK) return rc;
-    jlong c[3] = {(jlong)v.count, (jlong)v.pending_packets, (jlong)v.oldest_packet};
-    (*env)->SetLongArrayRegion(env, counts, 0, 3, c);
-    void *ptr[3] = {(void *)v.packet, (void *)v.dst, (void *)v.rssi};
-    jlong len[3] = {(jlong)v.count * 8, (jlong)v.count * 4, (jlong)v.count * 8};
-    for (int i = 0; i < 3; i++) (*env)->SetObjectArrayElement(env, views, i, (*env)->NewDirectByteBuffer(env, ptr[i], len[i]));
+    jlong c[4] = {(jlong)v.count, (jlong)v.pending_packets, (jlong)v.oldest_packet, (jlong)v.n_runs};
+    (*env)->SetLongArrayRegion(env, counts, 0, 4, c);
+    /* the packet numbers once per run of deliveries (a packet's deliveries are adjacent), then the deliveries */
+    void *ptr[5] = {(void *)v.run_packet, (void *)v.run_first, (void *)v.run_count, (void *)v.dst, (void *)v.rssi};
+    jlong len[5] = {(jlong)v.n_runs * 8, (jlong)v.n_runs * 4, (jlong)v.n_runs * 4, (jlong)v.count * 4, (jlong)v.count * 8};
+    for (int i = 0; i < 5; i++) (*env)->SetObjectArrayElement(env, views, i, (*env)->NewDirectByteBuffer(env, ptr[i], len[i]));
     return RM_OK;
 }
 

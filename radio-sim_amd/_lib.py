@@ -62,7 +62,7 @@ class HostResult(C.Structure):
 
 class DeliveryView(C.Structure):
     _fields_ = [("count", C.c_uint32), ("pending_packets", C.c_uint32), ("oldest_packet", C.c_int64), ("packet", C.c_void_p), ("dst", C.c_void_p),
-                ("rssi", C.c_void_p)]
+                ("rssi", C.c_void_p), ("n_runs", C.c_uint32), ("run_packet", C.c_void_p), ("run_first", C.c_void_p), ("run_count", C.c_void_p)]
 
 
 class EvqOrder(C.Structure):

@@ -22,6 +22,8 @@ rm::EvDev ev_dev(rm_context *c)
     e.g_rank = v.d_grank.p;
     e.cnt_by_rank = v.d_cnt.p;
     e.off_by_rank = v.d_off.p;
+    e.g_run = v.d_grun.p;
+    e.run_rec = v.d_run_rec.p;
     e.g_cap = v.g_cap;
     e.recv_key = v.d_recv_key.p;
     e.send_key = v.d_send_key.p;
@@ -94,9 +96,9 @@ int ev_append(rm_context *c, TickSlot &ts)
 
 } // namespace rmh
 
-static size_t ev_out_bytes(uint32_t cap)
+static size_t ev_out_bytes(uint32_t cap, uint32_t run_cap)
 {
-    return pad64(sizeof(rm::EvHeader)) + pad64(size_t(cap) * 8) + pad64(size_t(cap) * 4) + pad64(size_t(cap) * 8);
+    return pad64(sizeof(rm::EvHeader)) + pad64(size_t(run_cap) * 8) + 2 * pad64(size_t(run_cap) * 4) + pad64(size_t(cap) * 4) + pad64(size_t(cap) * 8);
 }
 
 static rm::EvOut ev_out(rm_context *c)
@@ -105,11 +107,15 @@ static rm::EvOut ev_out(rm_context *c)
     char *b = c->ev.h_out;
     const uint32_t cap = c->ev.pool_cap;
     size_t off = 0;
+    const uint32_t run_cap = c->ev.g_cap; // (a run is a fired end group)
     o.hdr = reinterpret_cast<rm::EvHeader *>(b + off); off += pad64(sizeof(rm::EvHeader));
-    o.pkt = reinterpret_cast<int64_t *>(b + off); off += pad64(size_t(cap) * 8);
+    o.run_packet = reinterpret_cast<int64_t *>(b + off); off += pad64(size_t(run_cap) * 8);
+    o.run_first = reinterpret_cast<uint32_t *>(b + off); off += pad64(size_t(run_cap) * 4);
+    o.run_count = reinterpret_cast<uint32_t *>(b + off); off += pad64(size_t(run_cap) * 4);
     o.dst = reinterpret_cast<int32_t *>(b + off); off += pad64(size_t(cap) * 4);
     o.rssi = reinterpret_cast<double *>(b + off);
     o.cap = cap;
+    o.run_cap = run_cap;
     return o;
 }
 
@@ -131,7 +137,7 @@ int rm_events_disable(rm_context *c)
         (void)hipStreamSynchronize(c->stream);
     }
     v.d_st.release(); v.d_pk.release(); v.d_ldst.release(); v.d_lrssi.release(); v.d_lverdict.release();
-    v.d_gtime.release(); v.d_gmeta.release(); v.d_gref.release(); v.d_grank.release(); v.d_cnt.release(); v.d_off.release();
+    v.d_gtime.release(); v.d_gmeta.release(); v.d_gref.release(); v.d_grank.release(); v.d_cnt.release(); v.d_off.release(); v.d_grun.release(); v.d_run_rec.release();
     v.d_recv_key.release(); v.d_send_key.release(); v.d_receiving.release(); v.d_sending.release(); v.d_latched.release();
     v.d_info_nodes.release();
     if (v.h_out) (void)hipHostFree(v.h_out);
@@ -165,12 +171,14 @@ int rm_events_enable(rm_context *c, uint32_t max_pending_packets, uint32_t max_p
     RM_HIP(v.d_grank.ensure(v.g_cap));
     RM_HIP(v.d_cnt.ensure(v.g_cap));
     RM_HIP(v.d_off.ensure(v.g_cap));
+    RM_HIP(v.d_grun.ensure(v.g_cap));
+    RM_HIP(v.d_run_rec.ensure(2 * size_t(v.g_cap)));
     rm::EvState st{};
     st.top_max = int64_t(0x8000000000000000ull); // the top list is empty
     st.first_live = 0xFFFFFFFFu;
     RM_HIP(hipMemcpyAsync(v.d_st.p, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
-    RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&v.h_out), ev_out_bytes(v.pool_cap), hipHostMallocMapped));
+    RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&v.h_out), ev_out_bytes(v.pool_cap, v.g_cap), hipHostMallocMapped));
 
     std::memset(v.h_out, 0, pad64(sizeof(rm::EvHeader)));
     v.seq = 0;
@@ -205,9 +213,13 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
     out->pending_packets = o.hdr->pending_packets;
     out->oldest_packet = o.hdr->oldest_packet;
     c->ev.oldest_packet = o.hdr->oldest_packet;
-    out->packet = o.pkt;
+    out->packet = nullptr; // (ABI version 3: the packet number comes once per run)
     out->dst = o.dst;
     out->rssi = o.rssi;
+    out->n_runs = o.hdr->runs;
+    out->run_packet = o.run_packet;
+    out->run_first = o.run_first;
+    out->run_count = o.run_count;
     if (o.hdr->err & 8u) c->air.valid = false;
     if (o.hdr->err & 8u) return fail(RM_ERR_CAPACITY, "a tick's heard links exceeded the link capacity (rm_set_link_capacity): its events are missing");
     if (o.hdr->err) return fail(RM_ERR_CAPACITY, "the reception stage ran out of room for pending packets / links (rm_events_enable)");

@@ -351,7 +351,7 @@ struct EvState {
     uint32_t err;               // until the drain has reported it: 4 group list full
     uint32_t done_a;            // "last workgroup" counter (node-info)
     uint32_t done_apply;        // ... of k_ev_apply (the last one finishes the drain)
-    uint32_t pad1;
+    uint32_t n_dgroups;         // fired end groups that deliver something: the runs of the drain's delivery list
     EvTails tails[2];
     // (its own 128-byte line: k_ev_select's workgroups add to n_groups and take minima here at the same time)
     alignas(128) uint32_t first_live; // window index of the oldest packet with events still queued (0xFFFFFFFF: none)
@@ -369,6 +369,8 @@ struct EvDev {
     uint64_t *g_meta;
     uint32_t *g_ref;      // ... packet ring index << 1 | phase (0 end, 1 start)
     uint32_t *g_rank, *cnt_by_rank, *off_by_rank;
+    uint32_t *g_run;      // which run of the delivery list the (delivering end) group is
+    unsigned long long *run_rec; // [2 * g_cap] per run: packet number, first delivery | count << 32 (copied to the host in one go at the end)
     uint32_t g_cap;
     unsigned long long *recv_key, *send_key; // [n] last writer of the node's receivingPacket / sendingPacket in the running drain
     uint8_t *receiving, *sending;            // [n] Transciever.receivingPacket / sendingPacket != null
@@ -398,17 +400,21 @@ struct EvHeader {
     int64_t next_packet; // number the next transmitted packet gets
     int64_t time;
     uint32_t seq;        // written last
-    uint32_t pad0;
+    uint32_t runs;       // runs of the delivery list (one per packet that delivers in this drain)
     int64_t oldest_packet; // number of the oldest packet with events still queued (== next_packet: none)
     uint32_t pad[4];
 };
 static_assert(sizeof(EvHeader) == 64, "one line of host-mapped memory");
+// (the deliveries of one fired end group -- one packet -- are adjacent in the list: the packet number is sent once per run,
+// not with each of its deliveries: 8 of 20 bytes that need not cross PCIe)
 struct EvOut {
     EvHeader *hdr;
-    int64_t *pkt;
-    int32_t *dst;
-    double *rssi;
-    uint32_t cap;
+    int64_t *run_packet;  // [run_cap]
+    uint32_t *run_first;  // [run_cap] first delivery of the run
+    uint32_t *run_count;  // [run_cap]
+    int32_t *dst;         // [cap]
+    double *rssi;         // [cap]
+    uint32_t cap, run_cap;
 };
 struct NodeInfoOut {
     uint32_t *seq;

@@ -177,10 +177,14 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
     const bool imm = (p.flags & kEvImmediate) != 0u;
     const bool fire_start = valid && !imm && !(p.flags & kEvStartDone) && p.t0 < T;
     const bool fire_end = valid && (imm || p.t1 < T);
-    { // the drain's deliveries, one atomic per wave
+    { // the drain's deliveries and the runs they come in (a packet's), one atomic per wave each
         uint32_t nd = fire_end ? p.n_deliver : 0u;
+        const uint32_t runs = uint32_t(__popcll(ballot64(nd != 0u)));
         for (int d = 32; d >= 1; d >>= 1) nd += uint32_t(__shfl_xor(int(nd), d));
-        if (lane == 0 && nd) atomicAdd(&st.n_deliv, nd);
+        if (lane == 0 && nd) {
+            atomicAdd(&st.n_deliv, nd);
+            atomicAdd(&st.n_dgroups, runs);
+        }
     }
     for (int ph = 0; ph < 2; ++ph) { // 0 end, 1 start
         const bool fire = ph ? fire_start : fire_end;
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
         // The group's place in the queue's pop order = the number of fired groups with a smaller key (keys are unique), and
         // the place of its deliveries in the list = the deliveries of those groups: one pass of the wave over all groups'
         // keys (a few thousand, L2-resident) -- no sort, no scan, no launch in between.
-        uint32_t r = 0, first = 0;
+        uint32_t r = 0, first = 0, run = 0;
         {
             const int64_t tg = e.g_time[g];
             const uint64_t mg = e.g_meta[g];
@@ -244,17 +248,20 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
                     const bool less = tk[u] < tg || (tk[u] == tg && mk[u] < mg);
                     r += less ? 1u : 0u;
                     first += less ? ck[u] : 0u;
+                    run += (less && ck[u] != 0u) ? 1u : 0u;
                 }
             }
             for (int d = 32; d >= 1; d >>= 1) {
                 r += uint32_t(__shfl_xor(int(r), d));
                 first += uint32_t(__shfl_xor(int(first), d));
+                run += uint32_t(__shfl_xor(int(run), d));
             }
             r = uniform_u(r);
             first = uniform_u(first);
             if (lane == 0) {
                 e.g_rank[g] = r;        // k_ev_apply recomputes the events' keys from it ...
-                e.off_by_rank[g] = first; // ... and writes the group's deliveries from here on
+                e.off_by_rank[g] = first; // ... and writes the group's deliveries from here on ...
+                e.g_run[g] = run;       // ... as this run of the list
             }
         }
         const EvPacket &p = e.pk[ref >> 1];
@@ -308,7 +315,16 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out
         const bool imm = (fl & kEvImmediate) != 0u;
         if (!start) { // the group's deliveries, into the host-mapped list at the place its rank gives them
             const uint32_t n_del = uniform_u(e.cnt_by_rank[g]), first = uniform_u(e.off_by_rank[g]);
-            const int64_t gseq = p.gseq;
+            if (n_del != 0u && lane == 0) { // the run: the packet's number once, not with each delivery -- left in device memory
+                // (write-through: the workgroup that finishes the drain, on whatever XCD, copies all runs to the host in one go;
+                // a thousand scattered 16-byte writes over PCIe cost more than the deliveries' packet numbers had)
+                const uint32_t run = e.g_run[g];
+                if (run < out.run_cap) {
+                    __hip_atomic_store(&e.run_rec[2u * run], (unsigned long long)p.gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&e.run_rec[2u * run + 1u], (unsigned long long)first | ((unsigned long long)n_del << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             uint32_t seen = 0;
             for (uint32_t j0 = 0; n_del != 0u && j0 < cnt; j0 += 64) { // wave-uniform
                 const uint32_t j = j0 + lane;
@@ -326,7 +342,6 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out
                     const uint32_t pos = first + (imm ? nth : (n_del - 1u - nth));
                     if (pos < out.cap) { // host-mapped memory: write-through stores at system scope (drained below, before the
                         // workgroup is counted: no release fence, which would also write back this XCD's whole L2)
-                        __hip_atomic_store(&out.pkt[pos], gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(&out.dst[pos], e.l_dst[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(&out.rssi[pos], e.l_rssi[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
@@ -404,6 +419,18 @@ RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t s
     EvState &st = *e.st;
     const EvTails tl = st.tails[e.par];
     const uint32_t head = st.pk_head, tail = tl.pk_tail;
+    { // the runs of the delivery list, from where the groups' waves left them: one coalesced copy to the host
+        const uint32_t runs_all = min(__hip_atomic_load(&st.n_dgroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), out.run_cap);
+        for (uint32_t r = threadIdx.x; r < runs_all; r += blockDim.x) {
+            const unsigned long long pk = __hip_atomic_load(&e.run_rec[2u * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long fc = __hip_atomic_load(&e.run_rec[2u * r + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&out.run_packet[r], (int64_t)pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out.run_first[r], uint32_t(fc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out.run_count[r], uint32_t(fc >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
     // ring heads: up to the oldest packet that still had events queued when this drain began (k_ev_select)
     const uint32_t live = st.first_live;
@@ -422,16 +449,18 @@ RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t s
     st.ladders = o.ladders;
     if (!o.top_nonempty) st.top_max = kI64Min;
     st.t_prev = T;
-    const uint32_t total = st.n_deliv;
+    const uint32_t total = st.n_deliv, runs = st.n_dgroups;
     if (st.n_groups > e.g_cap) st.err |= 4u;
     st.n_groups = 0u;
     st.n_deliv = 0u;
+    st.n_dgroups = 0u;
     // The header lives in host-mapped memory: write-through stores, drained, then the sequence number the host
     // polls.  (A system-scope release fence here would also write back every dirty line the drain's kernels left in
     // this XCD's L2 -- microseconds, and nothing the host reads: the delivery records were stored by an earlier
     // launch.)
     __hip_atomic_store(&out.hdr->count, min(total, out.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out.hdr->total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out.hdr->runs, min(runs, out.run_cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out.hdr->err, st.err | tl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out.hdr->pending_packets, tail - new_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out.hdr->next_packet, tl.gseq_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

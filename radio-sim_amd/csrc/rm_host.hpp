@@ -181,7 +181,8 @@ struct rm_context : TickSlot {
         DevBuf<uint8_t> d_lverdict;
         DevBuf<int64_t> d_gtime;
         DevBuf<uint64_t> d_gmeta;
-        DevBuf<uint32_t> d_gref, d_grank, d_cnt, d_off;
+        DevBuf<uint32_t> d_gref, d_grank, d_cnt, d_off, d_grun;
+        DevBuf<unsigned long long> d_run_rec;
         DevBuf<unsigned long long> d_recv_key, d_send_key;
         DevBuf<uint8_t> d_receiving, d_sending;
         DevBuf<double> d_latched;

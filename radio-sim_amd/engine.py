@@ -490,10 +490,15 @@ class Engine:
         k = v.count
         self.oldest_pending_packet = v.oldest_packet   # every packet below it has fired its last event
 
-        def arr(ptr, dtype):
-            a = _wrap(ptr, dtype, k)
+        def arr(ptr, dtype, count=k):
+            a = _wrap(ptr, dtype, count)
             return a.copy() if copy else a
-        return arr(v.packet, np.int64), arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets
+        # the packet numbers come once per run of deliveries (a packet's deliveries are adjacent): spread out here
+        runs = v.n_runs
+        first, cnt = _wrap(v.run_first, np.uint32, runs), _wrap(v.run_count, np.uint32, runs)
+        assert runs == 0 or (first[0] == 0 and int(first[-1]) + int(cnt[-1]) == k and np.all(first[1:] == (first[:-1] + cnt[:-1])))
+        packet = np.repeat(_wrap(v.run_packet, np.int64, runs), cnt)
+        return packet, arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets
 
     def node_info(self, nodes=None, n=None):
         """(rssi, receiving state, channel) per node: the node-info of a time-step message."""

@@ -450,13 +450,20 @@ public:
         const std::vector<Node *> &nodes = sim->getNodes();
         RadioPacket *const *const flying = inFlight_.data() + inFlightHead_;
         const size_t n_flying = inFlight_.size() - inFlightHead_;
-        for (uint32_t i = 0; i < v.count; ++i) {
-            const int64_t k = v.packet[i] - firstInFlight_;
-            if (k < 0 || size_t(k) >= n_flying || v.dst[i] < 0 || size_t(v.dst[i]) >= nodes.size()) {
-                lastError = "radio medium: a delivery names a packet or node the host does not hold";
+        for (uint32_t r = 0; r < v.n_runs; ++r) { // a run = the deliveries of one packet (adjacent in the queue's pop order)
+            const int64_t k = v.run_packet[r] - firstInFlight_;
+            const uint32_t first = v.run_first[r], end = first + v.run_count[r];
+            if (k < 0 || size_t(k) >= n_flying || end > v.count || end < first) {
+                lastError = "radio medium: a delivery names a packet the host does not hold";
                 continue;
             }
-            sim->deliverRadioPacket(*flying[size_t(k)], nodes[size_t(v.dst[i])], v.rssi[i]);
+            for (uint32_t i = first; i < end; ++i) {
+                if (v.dst[i] < 0 || size_t(v.dst[i]) >= nodes.size()) {
+                    lastError = "radio medium: a delivery names a node the host does not hold";
+                    continue;
+                }
+                sim->deliverRadioPacket(*flying[size_t(k)], nodes[size_t(v.dst[i])], v.rssi[i]);
+            }
         }
         // packets whose last event has fired are forgotten: everything below the oldest number still queued
         while (firstInFlight_ < v.oldest_packet && inFlightHead_ < inFlight_.size()) {
