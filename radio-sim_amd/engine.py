@@ -480,10 +480,11 @@ class Engine:
     def events_next_packet(self):
         return self._L.rm_events_next_packet(self._h)
 
-    def events_process(self, time_us, copy=True):
+    def events_process(self, time_us, copy=True, runs=False):
         """Simulator.emulatorTimeStepDone: currentTime = time; processAllEvents(time).  Returns the deliveries of
-        the drain in call order: (packet numbers, destination node indices, rssi), copied out of the pinned block
-        (copy=False: wrapped in place, valid until the next call)."""
+        the drain in call order: (packet numbers, destination node indices, rssi, pending packets), copied out of the pinned
+        block (copy=False: wrapped in place, valid until the next call).  runs=True: as the engine hands them over -- the
+        packet numbers once per run of deliveries: (run packet, run first, run count, destinations, rssi, pending packets)."""
         from ._lib import DeliveryView
         v = DeliveryView()
         check(self._L.rm_events_process(self._h, int(time_us), C.byref(v)))
@@ -494,10 +495,13 @@ class Engine:
             a = _wrap(ptr, dtype, count)
             return a.copy() if copy else a
         # the packet numbers come once per run of deliveries (a packet's deliveries are adjacent): spread out here
-        runs = v.n_runs
-        first, cnt = _wrap(v.run_first, np.uint32, runs), _wrap(v.run_count, np.uint32, runs)
-        assert runs == 0 or (first[0] == 0 and int(first[-1]) + int(cnt[-1]) == k and np.all(first[1:] == (first[:-1] + cnt[:-1])))
-        packet = np.repeat(_wrap(v.run_packet, np.int64, runs), cnt)
+        n_runs = v.n_runs
+        if runs:
+            return (arr(v.run_packet, np.int64, n_runs), arr(v.run_first, np.uint32, n_runs), arr(v.run_count, np.uint32, n_runs),
+                    arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets)
+        first, cnt = _wrap(v.run_first, np.uint32, n_runs), _wrap(v.run_count, np.uint32, n_runs)
+        assert n_runs == 0 or (first[0] == 0 and int(first[-1]) + int(cnt[-1]) == k and np.all(first[1:] == (first[:-1] + cnt[:-1])))
+        packet = np.repeat(_wrap(v.run_packet, np.int64, n_runs), cnt)
         return packet, arr(v.dst, np.int32), arr(v.rssi, np.float64), v.pending_packets
 
     def node_info(self, nodes=None, n=None):

@@ -38,7 +38,7 @@ def loop(k0, k1):
     got = 0
     for k in range(k0, k1):
         eng.tick_run_sources_device(k * 1000, k * 1000 + 1000, devs[k % 32].ptr.value, t, k * 1000, W.AIR_US)
-        got += len(eng.events_process(k * 1000 + 1000, copy=False)[0])
+        got += len(eng.events_process(k * 1000 + 1000, copy=False, runs=True)[3])
     return got
 
 
