@@ -62,7 +62,8 @@ WORKLOADS = {
     "c5": (5, 1_000_000, 0.001, "logdist_sinr_overlap", "1M nodes, 0.1% new Tx per tick, multi-tick packet overlap (SINR)"),
 }
 # per-workload overrides: 16 channels; tick length (c4: one frame time, so the 5% are the concurrent set)
-EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23), "c5": dict(link_capacity=1 << 25)}
+# (c5: a result slot per tick of a batch holds ~45 k heard links; the per-receiver lists of RM_SINR_SCAN=0 want 2^25 entries: --link-capacity)
+EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23), "c5": dict(link_capacity=1 << 18)}
 
 
 def baseline_metric():
@@ -90,6 +91,7 @@ def parse():
     ap.add_argument("--as-rank", default="", metavar="R:W",
                     help="one process, no collective: sweep the weak-scaling workload of W ranks against the receiver "
                          "range of rank R only (what one GPU of a W-GPU run computes per tick)")
+    ap.add_argument("--link-capacity", type=int, default=0, help="override the workload's link capacity per result slot")
     ap.add_argument("--nodes", type=int, default=0, help="override the workload's node count (same density and Tx fraction)")
     ap.add_argument("--no-host-transfer", action="store_true", help="skip the PCIe-inclusive legs (with_host_transfer)")
     ap.add_argument("--no-scale-probe", action="store_true",
@@ -116,6 +118,146 @@ def parse():
     ap.add_argument("--profile-every", type=int, default=16,
                     help="HIP-event sample of the dominant kernel every n-th tick of the timed region")
     return ap.parse_args()
+
+
+# a kernel (base name as rocprofv3 prints it) -> the stage whose algorithmic bytes price it, and its key in
+# profiles/pmc_traffic.json (tools/pmc_traffic.py groups the counters the same way)
+KERNEL_STAGE = (("k_tick_frames_scan", "tick"), ("k_tick_frames", "tick"), ("k_sinr_scan", "sinr_scan"), ("k_ov_pairs", "ov_pairs"),
+                ("k_ov_exact", "ov_exact"), ("k_ov_verdict", "ov_verdict"), ("k_filter", "filter"),
+                ("k_frames_cand", "filter"), ("k_exact", "exact"), ("k_reorder", "reorder"), ("k_sinr", "sinr"),
+                ("k_self_entries", "sinr"))
+# (the interference stages of a batch of overlapping SINR ticks, rm_airbatch.hip: ov_pairs reads per heard link its receiver's
+# records and per new frame ~its near frames' index entries, and writes the surviving pairs; ov_exact gathers a 32-byte receiver
+# record and a 64-byte frame record per pair and adds to the link's 16-byte sum; ov_verdict reads sum, rssi, flag and writes sinr, verdict)
+PMC_KEY = {"filter": "k_filter", "exact": "k_exact", "reorder": "k_reorder", "sinr": "k_sinr", "tick": "k_tick_frames",
+           "sinr_scan": "k_sinr_scan"}
+
+
+def kernel_stage(name):
+    for prefix, stage in KERNEL_STAGE:
+        if name.startswith(prefix):
+            return stage
+    return None
+
+
+def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_per_launch, step_s, contexts, workload, pmc_ok=True,
+                    tick_key=False, pairs_per_launch=0, under_profiler=None):
+    """The result line's `roofline`.
+
+    achieved = section 8(d)'s bytes of everything ONE launch sequence processes, (N_loc*37 + T*56 + H*25) x ticks per launch,
+    over the device time of the sequence's kernels; frac = achieved / 8 TB/s.  A kernel's duration is its OWN dispatch interval:
+    every sampled launch of the timed region carries a pair of HIP events bound to that dispatch (rm_profile_enable ->
+    hipExtLaunchKernelGGL), the interval `rocprofv3 --kernel-trace --stats` reports for the same kernel (the summaries under
+    profiles/ are of this command; `kernel` / `kernel_avg_us` name the dominant one).  With several contexts in flight a
+    kernel's interval overlaps the other contexts' kernels, so one interval may be longer than the step; what cannot be is the
+    per-context share: the intervals of one launch sequence, summed, over the contexts in flight (`overlap_check`), which is
+    what `achieved` divides by.  `kernels` prices every kernel with ITS OWN bytes:
+      filter     ticks x (N_loc*16 pre-filter records + T*28 frame records + cand*12 candidate entries written)
+      exact      ticks x (cand*(12 + 32) entries and receiver records + H*13 staged link records written)
+      reorder    ticks x (H*13 read + H*17 written)
+      tick       the one-launch tick: the whole of section 8(d)'s bytes of its tick
+    `traffic` = HBM bytes of ALL kernels of a launch sequence from the PMC passes on file (profiles/pmc_traffic.json: collected
+    by tools/collect_profiles.sh at the commit named there, not in this run: marked from_profile_file), so that
+    traffic / algorithmic_bytes_per_launch compares like with like; `valu_issue` = the kernels' vector-issue time from the same
+    file over THIS run's driver-timed step: the share of the chip's issue slots the step uses -- the resource that binds
+    these integer / fp32 / fp64 sweeps (the HBM fraction is small by construction)."""
+    b_tick = n_loc * S_NODE + t_per_tick * S_TX + heard * S_REC
+    b_launch = b_tick * ticks_per_launch
+    own = {"filter": (n_loc * 16 + t_per_tick * 28 + cand * 12) * ticks_per_launch,
+           "exact": (cand * 44 + heard * 13) * ticks_per_launch,
+           "reorder": heard * 30 * ticks_per_launch,
+           "tick": b_launch,
+           "ov_pairs": (heard * 49 + t_per_tick * 64 * 48) * ticks_per_launch + pairs_per_launch * 16,
+           "ov_exact": pairs_per_launch * (16 + 32 + 64 + 16),
+           "ov_verdict": heard * 34 * ticks_per_launch}
+    per_kernel = {}
+    for name, k in kernels.items():
+        if k["launches"] == 0:
+            continue
+        us = k["ms"] / k["launches"] * 1e3
+        st = kernel_stage(name)
+        b = own.get(st)
+        # launches of this kernel per sampled sequence (a stage may launch a kernel more than once)
+        per_seq = k["launches"] / max(1, n_samples)
+        per_kernel[name] = {"avg_us": us, "launches_sampled": k["launches"], "launches_per_sequence": per_seq, "stage": st,
+                            "algorithmic_bytes": b, "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
+                            "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
+    priced = {n: v for n, v in per_kernel.items() if v["stage"] is not None}
+    if priced:
+        dominant = max(priced, key=lambda n: priced[n]["avg_us"] * priced[n]["launches_per_sequence"])
+        kern_us = priced[dominant]["avg_us"]
+    else:
+        dominant, kern_us = None, 0.0
+    seq_us = sum(v["avg_us"] * v["launches_per_sequence"] for v in per_kernel.values())
+    share_us = seq_us / max(1, contexts)
+    # achieved: the bytes of one launch sequence over the device time its kernels take -- every kernel's own interval, summed;
+    # with several contexts in flight the sequences overlap and each kernel's interval is stretched by the others', so the sum
+    # is divided by the contexts in flight.  (The whole launch's bytes over the DOMINANT kernel's interval alone -- the other
+    # kernels' time left out -- is printed as dominant_kernel.launch_bytes_over_this_kernel_frac: it overstates a sequence of
+    # several comparable kernels, 0.93 for configs[4]'s twelve.)
+    achieved = b_launch / (share_us * 1e-6) / 1e9 if share_us > 0 else 0.0
+    dom = dict(priced[dominant]) if dominant else None
+    if dom:
+        dom["name"] = dominant
+        dom["launch_bytes_over_this_kernel_frac"] = b_launch / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS if kern_us > 0 else None
+    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+          "traffic": None, "kernel": dominant, "kernel_avg_us": kern_us, "launches_sampled": n_samples,
+          "kernel_time_source": "HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL start/stop) on the sampled launch "
+                                "sequences of the timed region: the interval rocprofv3 --kernel-trace reports (+ ~1.4 us per launch: "
+                                "tools/probe_check.hip)",
+          "sequence_kernel_us": seq_us, "contexts_in_flight": contexts,
+          "algorithmic_bytes_per_launch": b_launch,
+          "algorithmic_bytes_per_tick": "N_loc*37 + T*56 + H*25 = %d" % b_tick,
+          "dominant_kernel": dom,
+          "kernels": per_kernel,
+          "overlap_check": {"kernel_us_per_sequence": seq_us, "contexts_in_flight": contexts, "per_context_share_us": share_us,
+                            "step_us": step_s * 1e6, "ok": bool(share_us <= step_s * 1e6 * 1.02),
+                            "what": "the kernel intervals of one launch sequence, summed, over the contexts in flight: cannot exceed the "
+                                    "driver-timed step"},
+          "whole_step": {"algorithmic_bytes": b_launch, "ms_per_step": step_s * 1e3, "achieved": b_launch / step_s / 1e9,
+                         "frac": b_launch / step_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step (kernels + launch gaps + host): no overlap can "
+                                 "inflate or deflate it"},
+          "valu_issue": None, "traffic_source": "no PMC pass on file for this workload and launch shape"}
+    if under_profiler is None:   # (a profiler stretches every launch: the bench's own cross-check is for runs without one)
+        under_profiler = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH"))
+    rl["overlap_check"]["under_profiler"] = bool(under_profiler)
+    if not rl["overlap_check"]["ok"] and not under_profiler:
+        raise SystemExit("roofline cross-check failed: the kernels of one launch sequence take %.1f us per context in flight, the "
+                         "driver-timed step only %.1f us" % (share_us, step_s * 1e6))
+    if not pmc_ok:
+        return rl
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        wl = pmc.get(workload + "_tick" if tick_key else workload, {})
+        if ticks_per_launch == 1 and wl.get("ticks_per_launch", 1) != 1:
+            wl = pmc.get(workload + "_tick", {})   # the one-launch tick has its own counter passes
+        tpl = wl.get("ticks_per_launch", 1)
+        scale = ticks_per_launch / float(tpl)      # the counters are per launch of `tpl` ticks; per tick they do not depend on it
+        ents = {k: v for k, v in wl.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+        if ents:
+            by_stage = {k: int(v["hbm_bytes_per_launch"] * scale) for k, v in ents.items()}
+            rl["traffic"] = int(sum(by_stage.values()))
+            rl["traffic_by_kernel"] = by_stage
+            rl["traffic_over_algorithmic"] = rl["traffic"] / b_launch if b_launch else None
+            rl["traffic_from_profile_file"] = True
+            rl["traffic_source"] = ("%s (commit %s; all kernels of a launch sequence, per launch of %d ticks, scaled to %d): rocprofv3 "
+                                    "--pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, (factor*FETCH_SIZE + WRITE_SIZE)*1024, factor "
+                                    "per access pattern from profiles/fetch_calibration.json"
+                                    % (wl.get("csv", "profiles/pmc_traffic.json"), wl.get("commit", "unrecorded"), tpl, ticks_per_launch))
+            issue = {k: v["valu_issue_us_per_launch"] * scale for k, v in ents.items() if "valu_issue_us_per_launch" in v}
+            if issue:
+                rl["valu_issue"] = {"from_profile_file": True, "commit": wl.get("commit", "unrecorded"),
+                                    "kernel_issue_us_per_launch": issue, "sum_us_per_launch": sum(issue.values()),
+                                    "chip_utilisation": sum(issue.values()) / (step_s * 1e6),
+                                    "lane_utilisation": {k: v.get("valu_lane_utilisation") for k, v in ents.items()
+                                                         if v.get("valu_lane_utilisation") is not None} or None,
+                                    "what": "SQ_ACTIVE_INST_VALU (quad-cycles over 1024 SIMDs at 2.4 GHz) of every kernel of one launch "
+                                            "sequence, summed, over THIS run's driver-timed step: the share of the chip's vector issue "
+                                            "slots the step uses"}
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return rl
 
 
 def cpu_baseline(wl, nodes, sources, cpu_ticks):
@@ -202,23 +344,23 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=384, 
     run(warm, warm + ticks)
     fence()
     el = time.perf_counter() - t0
-    n_samples, stage_ms = engines[0].profile_read()
+    n_samples, _ = engines[0].profile_read()
+    kernels = {name: {"launches": l, "ms": ms, "stage": st} for name, (l, ms, st) in engines[0].profile_kernels().items()}
     engines[0].profile_enable(0)
     heard, dropped = engines[0].result_count()
-    raw = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
-    bracket = raw.pop("empty bracket", 0.0)
-    stages = {k: max(v - bracket, 0.0) for k, v in raw.items()}
-    dominant = max(stages, key=stages.get)
-    b_tick = n * S_NODE + t_per_tick * S_TX + heard * S_REC
+    try:
+        cand, _ = engines[0].slot_stats(0)
+    except Exception:
+        cand = 0
     per_tick = el / ticks
+    rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t_per_tick, heard=heard, cand=cand,
+                         ticks_per_launch=batch, step_s=per_tick * batch, contexts=inflight, workload="m1")
     for e in engines:
         e.close()
     return {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "ticks_in_flight": inflight * batch,
             "ticks_per_launch": batch, "contexts": inflight,
             "value": t_per_tick * (n - 1) / per_tick, "unit": "links/s", "ms_per_tick": per_tick * 1e3,
-            "ms_per_step": per_tick * batch * 1e3,
-            "algorithmic_bytes_per_tick": b_tick, "dominant_kernel": dominant, "stages_avg_us_per_launch": stages,
-            "hbm_frac_whole_tick": b_tick / per_tick / 1e9 / HBM_PEAK_GBS, "dropped": bool(dropped)}
+            "ms_per_step": per_tick * batch * 1e3, "roofline": rl, "dropped": bool(dropped)}
 
 
 def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick, tick_us, src_dev, pool, batch):
@@ -413,6 +555,7 @@ def main():
         return dry_run(args, rank, world, result_fd)
     if args.inflight <= 0:
         args.inflight = 3
+    args.batch_default = args.batch <= 0
     if args.batch <= 0:
         # several GPUs: a rank's share of a tick shrinks with the ranks, a batch's fixed costs (five launches, the collective)
         # do not: more ticks per launch sequence
@@ -468,9 +611,12 @@ def main():
             n = int(round(n * world ** 0.5))
             desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
         t_per_tick = int(round(frac * n))
-        extra = EXTRA.get(args.workload, {})
+        extra = dict(EXTRA.get(args.workload, {}))
+        if args.link_capacity > 0:
+            extra["link_capacity"] = args.link_capacity
         tick_us = extra.get("tick_us", W.TICK_US)
-        # the SINR extension looks at every frame on the air: ticks are chained unless no frame outlives its tick
+        # the SINR extension looks at every frame on the air: ticks are chained through the frames on the air unless no frame
+        # outlives its tick -- ONE context, one timeline; a batch of such ticks is still one launch sequence (rm_airbatch.hip)
         stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > tick_us
         nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
         if args.spatial_ids:
@@ -527,7 +673,7 @@ def main():
 
         from radio_sim_amd import dist as D
         use_sharded = world > 1 or args.force_sharded
-        batch = 1 if stateful else max(1, min(args.batch, rsa.MAX_BATCH))
+        batch = max(1, min(args.batch if not (stateful and args.batch_default) else 64, rsa.MAX_BATCH))
         tps = batch                          # ticks per step: a step is one launch sequence
         if args.steps <= 0:
             args.steps = -(-1920 // tps)
@@ -540,7 +686,7 @@ def main():
         sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(pool)]
         # who runs the collective of a sharded batch: the library (one C call per batch: pack, ncclAllGather, sweep) or
         # torch.distributed around the engine calls
-        lib_dist = batch > 1 and not stateful and ((world > 1 and args.collective != "torch" and backend == "nccl")
+        lib_dist = batch > 1 and ((world > 1 and args.collective != "torch" and backend == "nccl")
                                                   or (world == 1 and args.collective == "lib" and not as_rank))
         if lib_dist:
             # one communicator per context (their collectives are independent): rank 0 makes the ids, torch.distributed -- here
@@ -572,7 +718,7 @@ def main():
             use_sharded = False
         pad_dev, slots = None, 0
         with torch.cuda.stream(stream):
-            if lib_dist or (as_rank and batch > 1 and not stateful):
+            if lib_dist or (as_rank and batch > 1):
                 # every rank's transmitters of every tick in a fixed number of slots (src = -1: padding)
                 src_dev = torch.from_numpy(np.stack(sources)).to(dev)
                 if as_rank and args.host_cull > 0:
@@ -631,13 +777,13 @@ def main():
                 call = e.prepared("rm_dist_batch_run_sources_device", nb, t0, t0 + tick_us, ctypes.c_void_p(pad_dev[rank][k % pool].data_ptr()),
                                   slots, t0, W.AIR_US)
             elif pad_dev is not None:
-                # --as-rank: what the all-gather would deliver, [rank][tick][slot], packed here once per step
-                gathered = torch.empty(part_w * nb * slots * 64, dtype=torch.uint8, device=dev)
-                for r in range(part_w):
-                    e.pack_tx_batch_device_on(streams[g].cuda_stream, pad_dev[r][k % pool].data_ptr(), nb, slots, t0, W.AIR_US,
-                                              gathered.data_ptr() + r * nb * slots * 64)
+                # --as-rank: what the all-gather of the source indices would deliver, [rank][tick][slot]; the call builds every
+                # rank's records from the node table, as a rank of a real run does behind its collective
+                k_in = k % pool                      # (the pool is a multiple of the batch: the window does not wrap)
+                gathered = torch.stack([pad_dev[r][k_in:k_in + nb] for r in range(part_w)]).contiguous()
                 keep_alive.append(gathered)
-                call = e.prepared("rm_batch_run_gathered_device", nb, t0, t0 + tick_us, ctypes.c_void_p(gathered.data_ptr()), part_w, slots)
+                call = e.prepared("rm_batch_run_gathered_sources_device", nb, t0, t0 + tick_us, ctypes.c_void_p(gathered.data_ptr()), part_w,
+                                  slots, t0, W.AIR_US)
             else:
                 ptrs = np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64)
                 call = e.prepared("rm_batch_run_sources_device", nb, t0, t0 + tick_us, ptrs, np.full(nb, t_per_tick, dtype=np.int32), t0,
@@ -707,9 +853,10 @@ def main():
         run_range(0, warm_ticks)
         run_range(warm_ticks, ticks, plan_only=True)     # the timed steps' calls, arguments converted
         fence()
-        # HIP-event brackets on every n-th launch sequence of every context; few launches: all of them
+        # kernel probes (a pair of HIP events bound to the kernel's own dispatch: no stream time) on every n-th launch sequence
+        # of every context; few launches: all of them
         launches = args.steps
-        every = args.profile_every if batch == 1 else max(1, args.profile_every // 4)
+        every = args.profile_every if batch == 1 else 1
         if launches <= 4 * inflight:
             every = 1
         for e in engines:
@@ -719,13 +866,15 @@ def main():
         run_range(warm_ticks, ticks)
         fence()
         elapsed = time.perf_counter() - t_start
-        n_samples, stage_ms = 0, {}
+        n_samples, kernels = 0, {}
         for e in engines:
-            ns, ms = e.profile_read()
+            ns, _ = e.profile_read()
+            for name, (launches, ms, stage) in e.profile_kernels().items():
+                k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "stage": stage})
+                k["launches"] += launches
+                k["ms"] += ms
             e.profile_enable(0)
             n_samples += ns
-            for k, v in ms.items():
-                stage_ms[k] = stage_ms.get(k, 0.0) + v
         heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
         if dropped:
             raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
@@ -744,7 +893,7 @@ def main():
         links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * n_loc
         timed_ticks = args.steps * tps
         value = links_per_tick * timed_ticks / elapsed
-        if stateful and sharded is None:
+        if stateful and sharded is None and batch == 1:
             # the links the ticks resolved: the new frames against every receiver; the frames still on the air stay on the
             # device (as records the new frames' links are tested against, or as entries of per-receiver lists) and are not
             # swept again
@@ -754,12 +903,15 @@ def main():
         if stateful:
             inc, reb = engines[0].air_list_stats()
             scans = engines[0].air_scan_ticks()
-            desc += (" -- %.2e link evaluations per tick (new frames only; the frames still on the air stay on the device: %d ticks "
-                     "found their interferers among them by scan, %d added their frames to per-receiver lists, %d rebuilt those)"
-                     % (value * elapsed / timed_ticks, scans, inc, reb))
+            ob, ot = engines[0].air_batch_stats()
+            desc += (" -- %.2e link evaluations per tick (new frames only; the frames still on the air stay on the device: %d ticks in %d "
+                     "batches found their interferers through the batch's index of the frames on the air, %d lone ticks among the frames by "
+                     "scan, %d added their frames to per-receiver lists, %d rebuilt those)"
+                     % (value * elapsed / timed_ticks, ot, ob, scans, inc, reb))
         if (inflight > 1 or batch > 1) and sharded is None and world == 1:
             # the same ticks again, one at a time on one context
             fence()
+            eng.profile_enable(args.profile_every)
             t_seq = time.perf_counter()
             with torch.cuda.stream(stream):
                 seq_ticks = min(timed_ticks, 1920)
@@ -768,97 +920,43 @@ def main():
                     eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick, t0, W.AIR_US)
             fence()
             el = time.perf_counter() - t_seq
+            seq_samples, _ = eng.profile_read()
+            seq_kernels = {name: {"launches": l, "ms": ms, "stage": st} for name, (l, ms, st) in eng.profile_kernels().items()}
+            eng.profile_enable(0)
             sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
                           "ms_per_tick": el / seq_ticks * 1e3,
                           "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
                                   "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
 
         if rank == 0 and sequential is not None and world == 1 and not as_rank:
-            # the one-launch tick against the same roofline: section 8(d)'s bytes of ONE tick over the tick's time (the tick is
-            # a chain of dependent round trips on a mostly idle device: bound by latency, neither by HBM nor by issue slots)
-            b_tick = n * S_NODE + t_per_tick * S_TX + heard * S_REC
-            seq_s = sequential["ms_per_tick"] * 1e-3
-            rl = {"bound": "latency", "algorithmic_bytes_per_tick": int(b_tick), "achieved": b_tick / seq_s / 1e9, "peak": HBM_PEAK_GBS,
-                  "unit": "GB/s", "frac": b_tick / seq_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "valu_issue_us_per_tick": None}
+            # the one-launch tick against the same roofline: section 8(d)'s bytes of ONE tick over the kernel's own interval (the
+            # tick is a chain of dependent round trips on a mostly idle device: bound by latency, neither by HBM nor by issue slots)
             try:
-                ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload + "_tick", {})
-                if args.nodes == 0 and "k_tick_frames" in ent:
-                    rl["traffic"] = ent["k_tick_frames"]["hbm_bytes_per_launch"]
-                    rl["traffic_min"] = ent["k_tick_frames"].get("hbm_bytes_per_launch_min")   # (the kernel both streams and gathers: fetch factor 2 / 1)
-                    rl["from_profile_file"] = True
-                    rl["valu_issue_us_per_tick"] = ent["k_tick_frames"].get("valu_issue_us_per_launch")
-                    rl["traffic_source"] = ent["k_tick_frames"]["source"] + " (commit %s)" % ent.get("commit", "unrecorded")
-            except (OSError, ValueError):
-                pass
+                cand1, _ = eng.slot_stats(0)
+            except Exception:
+                cand1 = 0
+            rl = roofline_object(kernels=seq_kernels, n_samples=seq_samples, n_loc=n_loc, t_per_tick=t_per_tick, heard=heard, cand=cand1,
+                                 ticks_per_launch=1, step_s=sequential["ms_per_tick"] * 1e-3, contexts=1, workload=args.workload,
+                                 pmc_ok=(args.nodes == 0), tick_key=True)
+            rl["bound_note"] = ("latency: a lone tick of this size is a chain of dependent launches and memory round trips on a mostly idle "
+                                "device; neither HBM bytes nor issue slots bind it (DESIGN.md section 4.8)")
             sequential["roofline"] = rl
 
         if rank == 0:
-            # Roofline.  Per-stage durations come from HIP events recorded on the engine's
-            # stream around every stage of each `profile_every`-th launch of the timed region.  Every stage is priced
-            # with ITS OWN algorithmic bytes:
-            #   filter   N_loc*16 (pre-filter records) + T*28 (frame pre-filter records) + cand*12 (candidate entries written)
-            #   exact    cand*(12 + 32) (entries + 32-byte receiver records) + H*13 (staged link records written)
-            #   reorder  H*13 read + H*17 written (pkt 4, dst 4, rssi 8, verdict 1)
-            # The dominant stage's bound is named for what binds it: vector issue slots for these integer / fp32 / fp64
-            # sweeps (PMC: profiles/pmc_traffic.json), its HBM fraction is reported next to it; the HBM figure of the
-            # whole step is section 8(d)'s bytes (N_loc*37 + T*56 + H*25 per tick) over the DRIVER-timed ms_per_step.
-            h_loc = heard
-            ticks_per_launch = batch
             try:
                 cand, _ = (last_run[0].slot_stats(last_run[1]) if batch > 1 else eng.slot_stats(0))
             except Exception:
                 cand = 0
-            b_step = (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC) * ticks_per_launch
-            stage_bytes = {"k_filter": (n_loc * 16 + t_per_tick * 28 + cand * 12) * ticks_per_launch,
-                           "k_exact": (cand * 44 + h_loc * 13) * ticks_per_launch,
-                           "k_reorder": (h_loc * 30) * ticks_per_launch}
-            raw_us = {k: v / max(1, n_samples) * 1e3 for k, v in stage_ms.items() if v > 0}
-            # an event pair with nothing between it measures the bracketing itself (a few us on this
-            # runtime): subtracted from every stage so that the durations are the kernels'
-            bracket_us = raw_us.pop("empty bracket", 0.0)
-            per_stage_us = {k: max(v - bracket_us, 0.0) for k, v in raw_us.items()}
-            dominant = max(per_stage_us, key=per_stage_us.get) if per_stage_us else "k_filter"
-            kern_avg_s = per_stage_us.get(dominant, 0.0) * 1e-6
-            stages = {}
-            for k, us in per_stage_us.items():
-                b = stage_bytes.get(k)
-                stages[k] = {"us": us, "algorithmic_bytes": b,
-                             "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
-                             "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
-            # roofline.achieved as the contract defines it: SURVEY.md 8(d)'s bytes of everything one launch processes
-            # (N_loc*37 + T*56 + H*25 per tick, times the ticks of the launch) over the dominant kernel's average duration,
-            # measured here with HIP events on the stream the kernel is launched on
-            dom_bytes = stage_bytes.get(dominant, b_step)
-            achieved = b_step / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
             step_s = elapsed / args.steps
-            # What the PMC passes say (profiles/pmc_traffic.json: collected by tools/collect_profiles.sh at the commit named
-            # in the file, NOT in this run -- every such number is marked from_profile_file): HBM bytes per launch of the
-            # dominant stage, and the vector-issue time of all stages' instructions, whose share of the driver-timed step
-            # is the chip's VALU-issue utilisation -- the resource that binds these integer / fp32 / fp64 sweeps.
-            traffic = None
-            valu = None
-            pmc_note = "no PMC pass on file for this workload and launch shape"
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                wl = pmc.get(args.workload, {})
-                if batch == 1 and wl.get("ticks_per_launch", 1) != 1:
-                    wl = pmc.get(args.workload + "_tick", {})   # the one-launch tick has its own counter passes
-                ent = wl.get(dominant) or (wl.get("k_tick_frames") if dominant == "k_filter" else None)
-                tpl = wl.get("ticks_per_launch", 1)
-                if ent and world == 1 and not as_rank and args.nodes == 0:
-                    scale = batch / float(tpl)          # the counters are per launch of `tpl` ticks; per tick they do not depend on it
-                    traffic = int(ent["hbm_bytes_per_launch"] * scale)
-                    pmc_note = ent["source"] + " (commit %s; per launch of %d ticks, scaled to %d)" % (wl.get("commit", "unrecorded"), tpl, batch)
-                    issue = {k: v["valu_issue_us_per_launch"] * scale for k, v in wl.items()
-                             if isinstance(v, dict) and "valu_issue_us_per_launch" in v}
-                    if issue:
-                        valu = {"from_profile_file": True, "commit": wl.get("commit", "unrecorded"),
-                                "stage_issue_us_per_launch": issue, "sum_us_per_launch": sum(issue.values()),
-                                "chip_utilisation": sum(issue.values()) / (step_s * 1e6),
-                                "what": "SQ_ACTIVE_INST_VALU (quad-cycles over 1024 SIMDs at 2.4 GHz) of every stage of one launch sequence, "
-                                        "summed, over THIS run's driver-timed step: the share of the chip's vector issue slots the step uses"}
-            except (OSError, ValueError, KeyError, TypeError):
-                pass
+            pairs = 0
+            if stateful and batch > 1:
+                pairs, _, interferers = eng.air_batch_pairs()
+            roofline = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n_loc, t_per_tick=t_per_tick, heard=heard, cand=cand,
+                                       ticks_per_launch=batch, step_s=step_s, contexts=inflight, workload=args.workload,
+                                       pmc_ok=(world == 1 and not as_rank and args.nodes == 0), pairs_per_launch=pairs)
+            if pairs:
+                roofline["surviving_pairs_per_launch"] = pairs
+                roofline["interfering_pairs_per_launch"] = interferers
             out = {
                 "metric": baseline_metric(),
                 "value": value,
@@ -881,21 +979,7 @@ def main():
                                         % (world, "regions of the k-d order" if spatial else "node index ranges",
                                            "ncclAllGather inside libradiomedium_hip.so: pack + collective + sweep in one call" if lib_dist
                                            else "torch.distributed around the engine calls")) if world > 1 else "none"},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from_profile_file": traffic is not None,
-                             "traffic_source": pmc_note,
-                             "kernel": dominant, "kernel_avg_us": kern_avg_s * 1e6, "launches_sampled": n_samples,
-                             "algorithmic_bytes_per_launch": b_step,
-                             "algorithmic_bytes_per_tick": "N_loc*37 + T*56 + H*25 = %d" % (n_loc * S_NODE + t_per_tick * S_TX + h_loc * S_REC),
-                             "stages": stages, "event_bracket_us": bracket_us, "valu_issue": valu,
-                             "whole_step": {"algorithmic_bytes": b_step, "ms_per_step": step_s * 1e3,
-                                            "achieved": b_step / step_s / 1e9, "frac": b_step / step_s / 1e9 / HBM_PEAK_GBS,
-                                            "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step"},
-                             "note": "achieved = SURVEY.md 8(d) bytes of one launch (ticks_per_launch ticks) / the dominant kernel's average "
-                                     "duration (HIP events on the context's stream over the timed region, the other contexts' launches sharing "
-                                     "the device; the empty-bracket cost subtracted); frac = achieved / 8 TB/s.  The sweep is bound by vector "
-                                     "issue slots, not by HBM (SURVEY.md 8d: a small HBM fraction by construction): valu_issue.chip_utilisation; "
-                                     "stages[*] price every stage with its own bytes"},
+                "roofline": roofline,
             }
             if sequential is not None:
                 out["sequential_ticks"] = sequential

@@ -34,14 +34,17 @@
 extern "C" {
 #endif
 
-/* 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe) and so is
+/* 4: rm_profile_enable times every kernel by its own dispatch (rm_profile_kernels; RM_STAGE_EMPTY is always 0);
+ *    rm_batch_run_sources_device / rm_batch_run_gathered_sources_device / rm_dist_batch_run_sources_device take ticks of
+ *    the SINR medium whose frames outlive their tick (rm_air_batch_stats).
+ * 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe) and so is
  *    rm_delivery_view.packet (the packet numbers come once per run of deliveries: n_runs, run_*); rm_air_scan_ticks,
  *    rm_batch_run_gathered_sources_device.
  * 2: rm_delivery_view.oldest_packet; rm_host_result.sinr / rm_device_result.sinr are NULL without the SINR extension;
  *    rm_group_*, rm_events_*, rm_node_info, rm_tick_run_records_device, rm_set_partition_spatial and the draw-node
  *    exchange were added; rm_tick_run_device refuses the SINR medium (rm_tick_run_records_device takes it).  A host
  *    built against another version must not load this library: compare rm_abi_version() with RM_ABI_VERSION. */
-#define RM_ABI_VERSION 3
+#define RM_ABI_VERSION 4
 
 #define RM_OK 0
 #define RM_ERR_INVALID (-1)   /* bad argument */
@@ -283,14 +286,20 @@ int rm_sync(rm_context *ctx);
  * launches of a few microseconds each).  Tick b's results live in result slot b of the context
  * (slot 0 is also what rm_result_* read) until the next rm_batch_* / rm_tick_* call.  The
  * java.util.Random draws are consumed tick by tick in slot order, i.e. exactly as n_ticks
- * single rm_tick_run_sources_device calls would.  The RM_LD_SINR extension looks at every frame
- * on the air, so it is batched only when the ticks are self-contained: no frame of an earlier
- * call or of an earlier tick of the batch still on the air when a tick begins (air time <= tick
- * length).  With source indices the time spans are in the arguments, and the last tick's frames
- * stay on the air for the calls that follow; with records (rm_batch_run_device, e.g. the gathered
- * records of a multi-GPU batch) the ticks [t_begin, t_end] must not overlap and every frame has to
- * lie inside its tick -- verified on the device, a violation is reported as RM_ERR_STATE when
- * the tick's result is read.  Anything else of it, and partitioned contexts whose links draw,
+ * single rm_tick_run_sources_device calls would.
+ * The RM_LD_SINR extension looks at every frame on the air.  With source indices (rm_batch_run_sources_device and the
+ * gathered-sources forms) the frames' time spans are in the arguments, and both kinds of batch are taken:
+ *  - self-contained ticks (no frame of an earlier call or of an earlier tick of the batch still on the air when a tick
+ *    begins: air time <= tick length) keep per-tick interferer lists inside the sweep;
+ *  - ticks whose frames OUTLIVE them (BASELINE configs[4]: 8128 us frames over 1000 us ticks), or that begin while frames
+ *    of earlier calls are on the air: the heard links of all ticks come from the sweep of the medium without SINR, then
+ *    every frame the batch can see -- the context's on-air window, then the batch's ticks -- is indexed once and the
+ *    interference sums of all ticks are formed in bulk (rm_airbatch.hip).  A frame's verdicts are decided against the
+ *    frames of its own and earlier ticks, exactly as n_ticks single calls would decide them; the batch's frames join the
+ *    on-air window for the calls that follow.  The ticks have to be in time order and their links must not draw.
+ * With records (rm_batch_run_device, rm_batch_run_gathered_device) the host cannot see the time spans: the ticks
+ * [t_begin, t_end] must not overlap and every frame has to lie inside its tick -- verified on the device, a violation is
+ * reported as RM_ERR_STATE when the tick's result is read.  Anything else of it, and partitioned contexts whose links draw,
  * are refused with RM_ERR_STATE -- run those one tick at a time. */
 #define RM_MAX_BATCH 512
 int rm_batch_run_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us /* [n_ticks] */,
@@ -322,10 +331,11 @@ int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *d
  * value is the first of them that is not RM_OK. */
 int rm_batch_result_view(rm_context *ctx, int32_t n_slots, rm_host_result *out, int32_t *status);
 
-/* Per-stage timing on the context's stream: on every `every_n`-th tick each stage of the launch
- * sequence is bracketed by HIP events (0 = off; an event costs microseconds of stream time on
- * this runtime, so dense sampling perturbs the throughput it measures).  rm_profile_read returns
- * the number of sampled ticks and the summed milliseconds per stage. */
+/* Kernel timing on the context's stream: on every `every_n`-th launch sequence (0 = off) every kernel launch carries its
+ * own pair of HIP events (hipExtLaunchKernelGGL), which take the start and the end of THAT dispatch -- the interval a
+ * rocprofv3 kernel trace reports for it, without the launch gap before it and without whatever other contexts have in
+ * flight.  rm_profile_read returns the number of sampled sequences and the summed kernel milliseconds per stage,
+ * rm_profile_kernels the same per kernel, under the name rocprofv3 prints (template arguments as the launch site spells them). */
 enum rm_profile_stage {
     RM_STAGE_FILTER = 0,  /* k_filter (or k_tick_prep + k_filter_wg): all (frame, receiver) pairs, conservative */
     RM_STAGE_EXACT = 1,   /* k_exact: the reference's fp64 arithmetic on the candidates */
@@ -335,11 +345,19 @@ enum rm_profile_stage {
     RM_STAGE_SCATTER = 5, /* k_finalize */
     RM_STAGE_REORDER = 6, /* k_reorder */
     RM_STAGE_DRAWS = 7,   /* java.util.Random kernels */
-    RM_STAGE_EMPTY = 8,   /* two events with nothing between them: the cost of the bracketing itself */
+    RM_STAGE_EMPTY = 8,   /* unused since ABI version 4 (was: the cost of an event bracket); always 0 */
     RM_PROFILE_STAGES = 9
 };
 int rm_profile_enable(rm_context *ctx, int every_n);
 int rm_profile_read(rm_context *ctx, uint32_t *samples, double *stage_ms /* [RM_PROFILE_STAGES] */);
+typedef struct rm_kernel_time {
+    char name[96];      /* e.g. "k_filter_wg_batch<4, true>" */
+    int32_t stage;      /* rm_profile_stage the launch belongs to */
+    uint32_t launches;  /* sampled launches */
+    double total_ms;    /* their summed duration */
+} rm_kernel_time;
+/* count gets the number of distinct kernels sampled since rm_profile_enable; at most cap entries are written */
+int rm_profile_kernels(rm_context *ctx, rm_kernel_time *out, int32_t cap, int32_t *count);
 /* number of Tx->Rx link evaluations resolved by the last tick ( T * (N_loc) minus self links ) */
 int64_t rm_last_link_evaluations(const rm_context *ctx);
 /* observability (synchronises): the candidate links the sweep's conservative filter handed to the exact stage for the
@@ -352,6 +370,12 @@ int rm_air_list_stats(const rm_context *ctx, uint64_t *incremental_ticks, uint64
 /* ... and how many ticks needed no lists at all: a tick of at most 4096 new frames over a spatially sorted table finds the
  * interferers of its heard links among the frames on the air themselves (rm_airscan.hip; RM_SINR_SCAN=0 keeps the lists) */
 int rm_air_scan_ticks(const rm_context *ctx, uint64_t *scan_ticks);
+/* ... and the batches of ticks whose frames outlive their tick (rm_batch_run_sources_device and the gathered-sources forms take
+ * them since ABI version 4: heard links by the batch sweep, interference over the whole batch, rm_airbatch.hip), and their ticks */
+int rm_air_batch_stats(const rm_context *ctx, uint64_t *batches, uint64_t *ticks);
+/* observability (synchronises): the (heard link, frame on the air) pairs the last such batch evaluated exactly, the frames
+ * its index held (on-air window + the batch's own), and how many of the pairs turned out to interfere */
+int rm_air_batch_pairs(rm_context *ctx, uint64_t *pairs, uint64_t *frames, uint64_t *interferers);
 /* the entry ring behind those lists (synchronises): entries allocated since the lists were last rebuilt in the busiest of the
  * 256 sub-rings, and the entries a sub-ring holds -- more allocated than held: the ring has gone round (old entries were reclaimed) */
 int rm_air_ring_stats(rm_context *ctx, uint64_t *max_allocated, uint64_t *sub_ring_entries);

@@ -54,6 +54,11 @@ class DeviceResult(C.Structure):
                 ("verdict", C.c_void_p), ("rssi", C.c_void_p), ("sinr", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class KernelTime(C.Structure):
+    """rm_kernel_time"""
+    _fields_ = [("name", C.c_char * 96), ("stage", C.c_int32), ("launches", C.c_uint32), ("total_ms", C.c_double)]
+
+
 class HostResult(C.Structure):
     _fields_ = [("count", C.c_uint32), ("n_packets", C.c_uint32), ("pkt_offset", C.c_void_p),
                 ("pkt_interference", C.c_void_p), ("pkt", C.c_void_p), ("dst", C.c_void_p), ("verdict", C.c_void_p),
@@ -173,11 +178,14 @@ SIGNATURES = {
                                        C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "rm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rm_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
+    "rm_profile_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "rm_last_link_evaluations": (C.c_int64, [C.c_void_p]),
     "rm_slot_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_air_ring_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_air_list_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_air_scan_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rm_air_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rm_air_batch_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rm_group_create": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rm_group_destroy": (None, [C.c_void_p]),
     "rm_group_size": (C.c_int, [C.c_void_p]),

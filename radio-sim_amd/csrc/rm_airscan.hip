@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256) k_air_expire(rm_tx_record *recs, int n, i
 hipError_t launch_air_expire(hipStream_t s, rm_tx_record *recs, int n, int64_t t_seen)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_air_expire, dim3(cdiv(n, 256)), dim3(256), 0, s, recs, n, t_seen);
+    RM_KLAUNCH(k_air_expire, dim3(cdiv(n, 256)), dim3(256), 0, s, recs, n, t_seen);
     return hipGetLastError();
 }
 
@@ -480,8 +480,8 @@ hipError_t launch_sinr_scan(hipStream_t s, const NodesDev &nd, const ModelDev &m
 {
     if (t.n_cnt <= 0) return hipSuccess;
     const dim3 grid(t.n_cnt), block(256);
-    if (cfg.shadow && m.shadow_tbl) hipLaunchKernelGGL((k_sinr_scan<true>), grid, block, 0, s, nd, m, t, sd);
-    else hipLaunchKernelGGL((k_sinr_scan<false>), grid, block, 0, s, nd, m, t, sd);
+    if (cfg.shadow && m.shadow_tbl) RM_KLAUNCH((k_sinr_scan<true>), grid, block, 0, s, nd, m, t, sd);
+    else RM_KLAUNCH((k_sinr_scan<false>), grid, block, 0, s, nd, m, t, sd);
     return hipGetLastError();
 }
 

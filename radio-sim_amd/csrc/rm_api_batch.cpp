@@ -35,8 +35,9 @@ TickSlot *slot_of(rm_context *c, int32_t slot)
 
 } // namespace rmh
 
-// the launch sequence of n prepared ticks in four launches (sorted table, fp32 frame, no SINR)
-static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n)
+// the launch sequence of n prepared ticks in four launches (sorted table, fp32 frame)
+int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n, const rm::ModelDev *m_override,
+                      int (*after_sweep)(rm_context *, void *), void *after_arg)
 {
     const double tc0 = g_clock.on ? HostClock::now() : 0;
     static thread_local std::vector<rm::TickDev> ticks_v; // (RM_MAX_BATCH descriptors: not on the stack)
@@ -61,7 +62,7 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
         RM_HIP(rm::launch_fetch_ticks(c->stream, c->h_ticks[g], n, dev_ticks)); // the device reads the mapped block itself
         RM_HIP(hipEventRecord(c->h_ticks_ev[g], c->stream));
     }
-    const rm::ModelDev m = model_dev(c);
+    const rm::ModelDev m = m_override ? *m_override : model_dev(c);
     const rm::NodesDev nd = nodes_dev(c);
     const rm::LaunchCfg &cfg = plans[0].cfg;
     hipStream_t s = c->stream;
@@ -71,36 +72,22 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
         double t0;
         ~Done() { if (g_clock.on) g_clock.acc[3] += HostClock::now() - t0; }
     } done{tc1};
-    const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
-    rm_context::Sample *smp = nullptr;
-    if (sample) {
-        if (c->ev_used == c->ev_pool.size()) {
-            rm_context::Sample ns;
-            for (auto &e : ns.ev) RM_HIP(hipEventCreate(&e));
-            c->ev_pool.push_back(ns);
-        }
-        smp = &c->ev_pool[c->ev_used++];
-        smp->n = 0;
-    }
+    ProbeScope probe(c);
+    rm_context::Sample *const smp = probe.smp;
     auto stage = [&](int id) -> int {
-        if (smp) {
-            RM_HIP(hipEventRecord(smp->ev[smp->n], s));
-            smp->stage[smp->n++] = id;
-        }
+        sample_stage(smp, id);
         return RM_OK;
     };
     if (!by_copy) RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
-    if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
     // RM_BATCH_FRAMES=1: the batch through the one-frame-per-workgroup kernel of the closed-loop tick instead of the
     // three sweep stages (one launch; the compact arrays on demand, per slot)
     static const bool batch_frames = std::getenv("RM_BATCH_FRAMES") != nullptr;
-    if (batch_frames && !cfg.stochastic && !plans[0].sinr) {
+    if (batch_frames && !cfg.stochastic && !plans[0].sinr && !after_sweep) {
         int seg_len = rm::frame_tick_segment(ticks[0], cfg, m);
         for (int b = 1; b < n && seg_len > 0; ++b) seg_len = std::min(seg_len, rm::frame_tick_segment(ticks[b], cfg, m));
         if (seg_len > 0) {
             RM_TRY(stage(RM_STAGE_FILTER));
             RM_HIP(rm::launch_tick_frames_batch(s, nd, m, ticks, n, dev_ticks, cfg, seg_len));
-            if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
             for (int b = 0; b < n; ++b) {
                 slots[b]->have_result = true;
                 slots[b]->compact_pending = true;
@@ -126,7 +113,10 @@ static int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *p
         RM_TRY(stage(RM_STAGE_DRAWS));
         RM_HIP(rm::launch_draws_batch(s, m, ticks, n, dev_ticks));
     }
-    if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
+    if (after_sweep) {
+        RM_TRY(stage(RM_STAGE_SINR));
+        RM_TRY(after_sweep(c, after_arg));
+    }
     for (int b = 0; b < n; ++b) {
         slots[b]->have_result = true;
         slots[b]->compact_pending = false;
@@ -156,23 +146,22 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
     RM_HIP(hipSetDevice(c->device));
     const bool sinr = is_sinr(c);
     if (sinr) {
-        // The SINR extension looks at every frame on the air.  A batch is accepted when its ticks are
-        // self-contained: nothing of an earlier call and nothing of an earlier tick of the batch is
-        // still on the air when a tick begins (e.g. air time <= tick length).  Frames given as source
-        // indices carry their time span in the arguments; records given by the caller (the gathered
-        // records of a multi-GPU batch) are verified on the device: every frame of tick b has to lie
-        // inside [t_begin[b], t_end[b]], and the ticks must not overlap.
+        // The SINR extension looks at every frame on the air.  Ticks whose frames are named by source indices carry their
+        // time spans in the arguments: when a frame of an earlier call or of an earlier tick of the batch can still be on the
+        // air the batch takes the overlap form (rm_api_airbatch.cpp: heard links by the sweep, interference over the whole
+        // batch).  Self-contained ticks -- nothing of an earlier call and nothing of an earlier tick is still on the air when
+        // a tick begins (e.g. air time <= tick length) -- keep their per-tick lists.  Records given by the caller are
+        // verified on the device: every frame of tick b has to lie inside [t_begin[b], t_end[b]], and the ticks must not overlap.
+        if (start_us && air_us && (dev_src || gathered) && overlap_wanted(c, n_ticks, t_begin_us, n_per, start_us, air_us))
+            return batch_run_overlap(c, n_ticks, t_begin_us, t_end_us, dev_src, n_per, start_us, air_us, gathered, gather_world, gather_slots);
         if (!dev_src)
             for (int b = 0; b < n_ticks; ++b)
                 if (t_end_us[b] < t_begin_us[b] || (b + 1 < n_ticks && t_end_us[b] > t_begin_us[b + 1]))
                     return fail(RM_ERR_STATE, "SINR batches of records need ticks [t_begin, t_end] that do not overlap");
         for (const auto &bt : c->air_batches)
             if (bt.end_us > t_begin_us[0])
-                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own");
-        for (int b = 0; dev_src && b + 1 < n_ticks; ++b)
-            if (n_per[b] > 0 && start_us[b] + air_us[b] > t_begin_us[b + 1])
-                return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run "
-                                          "overlapping ticks one at a time");
+                return fail(RM_ERR_STATE, "frames of earlier calls are still on the air: run this tick on its own (or name the "
+                                          "frames by source indices: rm_batch_run_sources_device takes overlapping ticks)");
         c->air.valid = false; // the ticks of a batch keep their lists to themselves
         c->air_batches.clear();
         c->air_head = c->air_tail = 0;

@@ -198,7 +198,10 @@ int rm_batch_run_gathered_sources_device(rm_context *c, int32_t n_ticks, const i
     const size_t all = size_t(world) * size_t(n_ticks) * size_t(slots);
     RM_HIP(c->d_dist_all.ensure(all));
     RM_HIP(rm::launch_pack_tx_batch(c->stream, nodes_dev(c), dev_src_all, n_ticks, slots, start_us, air_us, c->d_dist_all.p, world));
-    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, nullptr, nullptr, c->d_dist_all.p, world, slots);
+    // (the frames' time spans travel with the call: the SINR medium's ticks may outlive each other)
+    static thread_local std::vector<int64_t> air_v;
+    air_v.assign(size_t(n_ticks), air_us);
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, start_us, air_v.data(), c->d_dist_all.p, world, slots);
 }
 
 int rm_dist_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,

@@ -6,6 +6,11 @@ using namespace rmh;
 namespace rmh {
 
 thread_local std::string g_err;
+} // namespace rmh
+namespace rm {
+thread_local KernelProbe g_probe = {nullptr, nullptr};
+} // namespace rm
+namespace rmh {
 
 int fail(int code, const std::string &msg)
 {
@@ -286,7 +291,10 @@ void rm_destroy(rm_context *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &sm : c->ev_pool)
-        for (auto &e : sm.ev) (void)hipEventDestroy(e);
+        for (auto &k : sm.k) {
+            (void)hipEventDestroy(k.a);
+            (void)hipEventDestroy(k.b);
+        }
     c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release();
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
@@ -294,6 +302,17 @@ void rm_destroy(rm_context *c)
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
     c->air.pool.release(); c->air.head.release(); c->air.tail.release(); c->air.mark.release(); c->air.bad.release();
+    {
+        rm_context::Overlap &o = c->ov;
+        o.fr_f.release(); o.e_f.release(); o.fr_m.release(); o.e_m.release(); o.fr_t.release(); o.e_t.release();
+        o.fr_bin.release(); o.bin_cnt.release(); o.bin_off.release(); o.block_sum.release(); o.every.release(); o.misc.release();
+        o.pair_tail.release(); o.self_next.release(); o.defer.release(); o.slot_first.release(); o.ticks.release(); o.pairs.release();
+        for (int g = 0; g < 2; ++g) {
+            if (o.h_ev[g]) (void)hipEventDestroy(o.h_ev[g]);
+            if (o.h_desc[g]) (void)hipHostFree(o.h_desc[g]);
+        }
+        if (o.h_flag) (void)hipHostFree(o.h_flag);
+    }
     c->d_patch.release();
     c->d_enabled.release();
     c->d_member.release(); c->d_draw_nodes.release(); c->d_all_off.release(); c->d_all_nodes.release();
@@ -450,6 +469,36 @@ int rm_air_scan_ticks(const rm_context *c, uint64_t *scan_ticks)
 {
     if (!c || !scan_ticks) return fail(RM_ERR_INVALID, "NULL argument");
     *scan_ticks = c->air.scans;
+    return RM_OK;
+}
+
+int rm_air_batch_stats(const rm_context *c, uint64_t *batches, uint64_t *ticks)
+{
+    if (!c) return fail(RM_ERR_INVALID, "NULL argument");
+    if (batches) *batches = c->ov.batches;
+    if (ticks) *ticks = c->ov.ticks_done;
+    return RM_OK;
+}
+
+int rm_air_batch_pairs(rm_context *c, uint64_t *pairs, uint64_t *frames, uint64_t *interferers)
+{
+    if (!c || !pairs) return fail(RM_ERR_INVALID, "NULL argument");
+    *pairs = 0;
+    if (frames) *frames = 0;
+    if (interferers) *interferers = 0;
+    if (!c->ov.pair_tail.p || c->ov.batches == 0) return RM_OK;
+    RM_HIP(hipSetDevice(c->device));
+    std::vector<uint32_t> tails(size_t(rm::kShards) * rm::kShardStride);
+    RM_HIP(hipMemcpyAsync(tails.data(), c->ov.pair_tail.p, tails.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < rm::kShards; ++k) *pairs += std::min<uint64_t>(tails[size_t(k) * rm::kShardStride], c->ov.pair_cap / rm::kShards);
+    if (frames) *frames = c->ov.last_frames;
+    if (interferers) {
+        uint32_t v = 0;
+        RM_HIP(hipMemcpyAsync(&v, c->ov.misc.p + 2, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream));
+        *interferers = v;
+    }
     return RM_OK;
 }
 

@@ -113,9 +113,11 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     ts.last_n_new = n_new;
     RM_TRY(prepare_nodes(c));
 
-    const bool sinr = is_sinr(c);
+    // (kAirBatch: the tick is swept as the medium without SINR; the SINR medium's buffers are there for the stages that follow)
+    const bool sinr_medium = is_sinr(c);
+    const bool sinr = sinr_medium && air_mode != kAirBatch;
     const bool stochastic = maybe_draws(c);
-    RM_TRY(ensure_link_buffers(c, ts, ((!c->rx_sorted || sinr) ? kFeatPayload : 0) | (sinr ? kFeatSinr : 0) |
+    RM_TRY(ensure_link_buffers(c, ts, ((!c->rx_sorted || sinr_medium) ? kFeatPayload : 0) | (sinr_medium ? kFeatSinr : 0) |
                                           (stochastic ? kFeatDraws : 0)));
     const int rx_count = c->n_rx;
     const bool partitioned = rx_count != c->n;
@@ -169,8 +171,8 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
                 RM_HIP(ts.d_self_slot.ensure(size_t(std::max(c->n, 1))));
                 RM_HIP(hipMemsetAsync(ts.d_self_slot.p, 0, ts.d_self_slot.n * sizeof(unsigned long long), c->stream));
             }
-            if (uint32_t(c->air.scans) == 0u) { // (the stamps have gone round: forget the old ones)
-                c->air.scans++;
+            if (++c->air.stamp == 0u) { // (the stamps have gone round: forget the old ones)
+                c->air.stamp = 1u;
                 RM_HIP(hipMemsetAsync(ts.d_self_slot.p, 0, ts.d_self_slot.n * sizeof(unsigned long long), c->stream));
             }
             const int par = ts.sg_parity;
@@ -187,7 +189,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
             sd.every = ts.d_sg_every.p;
             sd.self_slot = ts.d_self_slot.p;
             sd.self_next = ts.d_self_next.p;
-            sd.stamp = uint32_t(c->air.scans);
+            sd.stamp = c->air.stamp;
             sd.half = std::max(float(c->coord_bound), 1e-20f);
             sd.inv = float(rm::kSgG) / (2.0f * sd.half);
         }
@@ -338,7 +340,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     t.out_dst = ts.d_out_dst.p;
     t.out_verdict = ts.d_out_verdict.p;
     t.out_rssi = ts.d_out_rssi.p;
-    t.out_sinr = sinr ? ts.d_out_sinr.p : nullptr; // only the SINR extension writes it: 8 of a record's 25 bytes
+    t.out_sinr = sinr_medium ? ts.d_out_sinr.p : nullptr; // only the SINR extension writes it: 8 of a record's 25 bytes
     t.out_prob = ts.d_out_prob.p;
     if (cfg.sorted) {
         t.a_pkt = ts.d_a_pkt.p;
@@ -393,25 +395,13 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
     const rm::NodesDev nd = nodes_dev(c);
     hipStream_t s = c->stream;
     if (stochastic && partitioned && part_spatial(c)) RM_HIP(c->d_draw_nodes.ensure(size_t(c->cap) + 1));
-    // The launch sequence.  On a sampled tick (rm_profile_enable) every stage is bracketed by HIP
-    // events on the stream; otherwise the stages are launched back to back (or, with RM_GRAPH=1,
-    // replayed from an instantiated hipGraph keyed by the launch arguments).
-    const bool sample = c->profile && (c->tick_index++ % uint64_t(c->profile_every) == 0);
-    rm_context::Sample *smp = nullptr;
-    if (sample) {
-        if (c->ev_used == c->ev_pool.size()) {
-            rm_context::Sample ns;
-            for (auto &e : ns.ev) RM_HIP(hipEventCreate(&e));
-            c->ev_pool.push_back(ns);
-        }
-        smp = &c->ev_pool[c->ev_used++];
-        smp->n = 0;
-    }
+    // The launch sequence.  On a sampled tick (rm_profile_enable) every kernel launch carries its own pair of events
+    // (rm::KernelProbe); otherwise the stages are launched as ever (or, with RM_GRAPH=1, replayed from an instantiated
+    // hipGraph keyed by the launch arguments).
+    ProbeScope probe(c);
+    rm_context::Sample *const smp = probe.smp;
     auto stage = [&](int id) -> int {
-        if (smp) {
-            RM_HIP(hipEventRecord(smp->ev[smp->n], s));
-            smp->stage[smp->n++] = id;
-        }
+        sample_stage(smp, id);
         return RM_OK;
     };
     const int seg_len = (t.n_active - t.first_new <= frame_tick_max()) ? rm::frame_tick_segment(t, cfg, m) : 0;
@@ -426,7 +416,6 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         const bool air_in_prep = air && t.filter_mode == rm::kFilterWg; // k_tick_prep leaves the SELF entries and looks at the sticky flag
         if (air && !air_in_prep) RM_HIP(rm::launch_air_begin(s, t));
         else if (sinr && !air && !t.air_scan) RM_HIP(hipMemsetAsync(ts.d_head.p, 0xFF, size_t(rx_count) * sizeof(int32_t), s));
-        if (smp) RM_TRY(stage(RM_STAGE_EMPTY)); // calibration: an empty bracket
         if (seg_len > 0) {
             // the closed-loop tick: filter, exact evaluation and node order of a frame inside one workgroup
             // (rm_tick.hip) -- ONE launch; the compact arrays only for the draw kernels, or on demand
@@ -442,7 +431,6 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
                 if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
                 else if (part_spatial(c)) RM_HIP(rm::launch_draw_nodes(s, t, c->d_draw_nodes.p));
             }
-            if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
             return RM_OK;
         }
         RM_TRY(stage(RM_STAGE_FILTER));
@@ -478,10 +466,9 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
             if (!partitioned) RM_HIP(rm::launch_draws_apply(s, m, t, nullptr, 1, 0));
             else if (part_spatial(c)) RM_HIP(rm::launch_draw_nodes(s, t, c->d_draw_nodes.p)); // ... and the drawing links' nodes
         }
-        if (smp) RM_HIP(hipEventRecord(smp->ev[smp->n], s));
         return RM_OK;
     };
-    if (c->use_graphs && !sample && !t.air_scan) { // (a tick by scan carries a new stamp every time: nothing to replay)
+    if (c->use_graphs && !smp && !t.air_scan) { // (a tick by scan carries a new stamp every time: nothing to replay)
         uint64_t key = 1469598103934665603ull;
         auto mix = [&](const void *p, size_t n) {
             const unsigned char *b = static_cast<const unsigned char *>(p);
@@ -563,15 +550,73 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
     return RM_OK;
 }
 
+static bool probe_take(void *user, const char *kernel, hipEvent_t *start, hipEvent_t *stop)
+{
+    rm_context::Sample *sm = static_cast<rm_context::Sample *>(user);
+    if (size_t(sm->n) == sm->k.size()) {
+        rm_context::Sample::K nk;
+        if (hipEventCreate(&nk.a) != hipSuccess) return false;
+        if (hipEventCreate(&nk.b) != hipSuccess) {
+            (void)hipEventDestroy(nk.a);
+            return false;
+        }
+        sm->k.push_back(nk);
+    }
+    rm_context::Sample::K &k = sm->k[size_t(sm->n++)];
+    k.stage = sm->cur_stage;
+    k.name = kernel;
+    *start = k.a;
+    *stop = k.b;
+    return true;
+}
+
+rm_context::Sample *begin_sample(rm_context *c)
+{
+    if (!c->profile || (c->tick_index++ % uint64_t(c->profile_every)) != 0) return nullptr;
+    if (c->ev_used == c->ev_pool.size()) c->ev_pool.emplace_back();
+    rm_context::Sample *sm = &c->ev_pool[c->ev_used++];
+    sm->n = 0;
+    sm->cur_stage = RM_STAGE_FILTER;
+    rm::g_probe.take = probe_take;
+    rm::g_probe.user = sm;
+    return sm;
+}
+
+void end_sample()
+{
+    rm::g_probe.take = nullptr;
+    rm::g_probe.user = nullptr;
+}
+
+// "(k_filter_wg_batch<4, true>)" as the launch site spells it -> "k_filter_wg_batch<4, true>" as rocprofv3 prints it
+static std::string kernel_label(const char *site)
+{
+    std::string n(site ? site : "?");
+    while (!n.empty() && (n.front() == '(' || n.front() == ' ')) n.erase(n.begin());
+    while (!n.empty() && (n.back() == ')' || n.back() == ' ')) n.pop_back();
+    return n;
+}
+
 int drain_profile(rm_context *c)
 {
     for (size_t i = 0; i < c->ev_used; ++i) {
         rm_context::Sample &sm = c->ev_pool[i];
-        RM_HIP(hipEventSynchronize(sm.ev[sm.n]));
         for (int k = 0; k < sm.n; ++k) {
+            const rm_context::Sample::K &pk = sm.k[size_t(k)];
             float ms = 0;
-            RM_HIP(hipEventElapsedTime(&ms, sm.ev[k], sm.ev[k + 1]));
-            c->prof_ms[sm.stage[k]] += ms;
+            RM_HIP(hipEventSynchronize(pk.b));
+            RM_HIP(hipEventElapsedTime(&ms, pk.a, pk.b));
+            if (pk.stage >= 0 && pk.stage < RM_PROFILE_STAGES) c->prof_ms[pk.stage] += ms;
+            const std::string label = kernel_label(pk.name);
+            rm_context::KernelTime *kt = nullptr;
+            for (auto &e : c->prof_kernels)
+                if (e.name == label) kt = &e;
+            if (!kt) {
+                c->prof_kernels.push_back({label, pk.stage, 0u, 0.0});
+                kt = &c->prof_kernels.back();
+            }
+            kt->launches++;
+            kt->ms += ms;
         }
         c->prof_samples++;
     }
@@ -593,6 +638,7 @@ int rm_profile_enable(rm_context *c, int enable)
     c->tick_index = 0;
     c->prof_samples = 0;
     for (double &v : c->prof_ms) v = 0;
+    c->prof_kernels.clear();
     return RM_OK;
 }
 
@@ -604,6 +650,23 @@ int rm_profile_read(rm_context *c, uint32_t *samples, double *stage_ms)
     if (samples) *samples = c->prof_samples;
     if (stage_ms)
         for (int k = 0; k < RM_PROFILE_STAGES; ++k) stage_ms[k] = c->prof_ms[k];
+    return RM_OK;
+}
+
+int rm_profile_kernels(rm_context *c, rm_kernel_time *out, int32_t cap, int32_t *count)
+{
+    if (!c || !count || cap < 0 || (cap > 0 && !out)) return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(drain_profile(c));
+    *count = int32_t(c->prof_kernels.size());
+    for (int32_t i = 0; i < cap && size_t(i) < c->prof_kernels.size(); ++i) {
+        const rm_context::KernelTime &kt = c->prof_kernels[size_t(i)];
+        std::memset(&out[i], 0, sizeof(out[i]));
+        std::strncpy(out[i].name, kt.name.c_str(), sizeof(out[i].name) - 1);
+        out[i].stage = kt.stage;
+        out[i].launches = kt.launches;
+        out[i].total_ms = kt.ms;
+    }
     return RM_OK;
 }
 

@@ -498,16 +498,11 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
 
 namespace rmh {
 
-// The SINR medium's tick (rm_host.hpp) -- its new frames built from source indices (dev_src: all with the same start and air
-// time) or given as records (dev_new, in device memory or in the host's pinned staging block; `latest_end_us` bounds their
-// start + air: records in device memory are never read by the host).
-// The frames of earlier calls that are still on the air stay resident on the device (the window [air_head, air_tail) of
-// d_air): a tick that only adds frames sweeps the new ones, a rebuild of the on-air lists sweeps the whole window.
-int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n, int64_t start_us,
-                    int64_t air_us, int64_t latest_end_us, bool new_on_host)
+// The on-air window [air_head, air_tail) of d_air.  Whole batches leave it when their last frame has left the air
+// (rm_tick_begin's rule: start + air > t_begin stays).
+int air_window_expire(rm_context *c, int64_t t_begin_us)
 {
     if (c->air_batches.empty()) c->air_max_t_begin = INT64_MIN;
-    // Expire whole batches (rm_tick_begin's rule: start + air > t_begin stays).
     {
         bool fifo = true; // live batches form a suffix of the window?
         size_t first_live = c->air_batches.size();
@@ -541,7 +536,13 @@ int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, c
             c->air_tail = dst;
         }
     }
-    // room for the new batch at the tail; slide the window to the front when the buffer is used up
+    return RM_OK;
+}
+
+// room for n more frames at the window's tail; the window slides to the front when the buffer is used up
+int air_window_reserve(rm_context *c, size_t n_more)
+{
+    const size_t n = n_more;
     const size_t live = c->air_tail - c->air_head;
     if (c->air_tail + size_t(n) > c->d_air.n) {
         const size_t want = std::max<size_t>(4 * (live + size_t(n)), 1 << 16);
@@ -555,6 +556,20 @@ int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, c
         c->air_head = 0;
         c->air_tail = live;
     }
+    return RM_OK;
+}
+
+// The SINR medium's tick (rm_host.hpp) -- its new frames built from source indices (dev_src: all with the same start and air
+// time) or given as records (dev_new, in device memory or in the host's pinned staging block; `latest_end_us` bounds their
+// start + air: records in device memory are never read by the host).
+// The frames of earlier calls that are still on the air stay resident on the device (the window [air_head, air_tail) of
+// d_air): a tick that only adds frames sweeps the new ones, a rebuild of the on-air lists sweeps the whole window.
+int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n, int64_t start_us,
+                    int64_t air_us, int64_t latest_end_us, bool new_on_host)
+{
+    RM_TRY(air_window_expire(c, t_begin_us));
+    RM_TRY(air_window_reserve(c, size_t(n)));
+    const size_t live = c->air_tail - c->air_head;
     if (dev_src && air_us > int64_t(UINT32_MAX)) return fail(RM_ERR_INVALID, "a frame of the SINR medium has to be shorter than 2^32 us");
     if (dev_new && n > 0) // the caller's records join the window (every later tick looks at them while they are on the air)
         RM_HIP(hipMemcpyAsync(c->d_air.p + c->air_tail, dev_new, size_t(n) * sizeof(rm_tx_record),

@@ -32,7 +32,10 @@ RM_D float round_up_to_float(double v)
 // distance (and the fp64 threshold for the fp64 variant).  thr < 0: nobody can be a candidate;
 // thr = +inf: every enabled same-channel receiver is one (non-geometric media, or a frame whose
 // position lies outside the frame the fp32 slack was computed for).
-RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, double &thr64)
+RM_D void tx_prefilter_at(const ModelDev &m, const double level, const rm_tx_record &tx, float4 &f, double &thr64);
+RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, double &thr64) { tx_prefilter_at(m, m.ld_level, tx, f, thr64); }
+// (the same with the level given: the log-distance medium's cut-off at another level than the model's candidate level)
+RM_D void tx_prefilter_at(const ModelDev &m, const double level, const rm_tx_record &tx, float4 &f, double &thr64)
 {
     const double inf = u2f(0x7FF0000000000000ull);
     double cut; // cut-off distance (metres): no link beyond it can matter
@@ -41,7 +44,7 @@ RM_D void tx_prefilter(const ModelDev &m, const rm_tx_record &tx, float4 &f, dou
     } else if (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_UDGM_CONST) {
         cut = m.geo_cut;
     } else if (m.kind == RM_MODEL_LOGDIST) {
-        const double margin = tx.txpower - m.ld_pl0 + m.ld_sigma * m.ld_clip - (m.ld_level - 1e-6);
+        const double margin = tx.txpower - m.ld_pl0 + m.ld_sigma * m.ld_clip - (level - 1e-6);
         if (!(margin >= 0.0)) {
             cut = -1.0;
         } else if (!(m.ld_exp > 0.0)) {

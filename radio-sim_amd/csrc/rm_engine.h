@@ -25,11 +25,30 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/radiomedium_hip.h"
 
 namespace rm {
+
+// Kernel probes (rm_profile_enable).  On a sampled launch sequence every kernel launch binds a pair of events to its
+// OWN dispatch (hipExtLaunchKernelGGL: the events take the start and the end of that kernel -- the interval rocprofv3's
+// kernel trace reports -- not the stream time around it, which also holds the launch gap and whatever other contexts
+// have in flight).  Unsampled sequences launch as ever.
+struct KernelProbe {
+    bool (*take)(void *user, const char *kernel, hipEvent_t *start, hipEvent_t *stop);
+    void *user;
+};
+extern thread_local KernelProbe g_probe;
+#define RM_KLAUNCH(kern, grid, block, shm, s, ...)                                                      \
+    do {                                                                                                \
+        hipEvent_t pa_ = nullptr, pb_ = nullptr;                                                        \
+        if (rm::g_probe.take && rm::g_probe.take(rm::g_probe.user, #kern, &pa_, &pb_))                  \
+            hipExtLaunchKernelGGL(kern, grid, block, shm, s, pa_, pb_, 0, __VA_ARGS__);                 \
+        else                                                                                            \
+            hipLaunchKernelGGL(kern, grid, block, shm, s, __VA_ARGS__);                                 \
+    } while (0)
 
 constexpr int kTxChunk = 64;        // transmitters per LDS tile == wave width (one lane per frame)
 constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
@@ -185,6 +204,59 @@ struct ScanDev {
     uint32_t stamp;         // this tick's stamp (never 0)
     float half, inv;        // cell = int((x + half) * inv)
 };
+
+// A BATCH of SINR ticks whose frames outlive their tick (rm_airbatch.hip; BASELINE configs[4]).  The frames the batch can
+// see -- the window of frames still on the air from earlier calls, then the batch's ticks one after the other -- are ONE
+// array, cut into time slots (a window batch or a tick each).  The heard links of all ticks come from the sweep of the medium
+// without SINR; then every frame is indexed once per batch by (cell of the fp32 frame's grid, slot), slot fastest, so that
+// "the frames near this place that can still be on the air in tick b" -- slots slot_lo(b) .. slot(b) -- is ONE contiguous
+// run per cell; a new frame looks only at frames of its own and earlier slots (verdicts are causal: DESIGN.md section 6, E4).
+struct OvTick {                 // one tick of the batch as the interference stages see it
+    int frame_first, n_new;     // its new frames in OvDev::tx
+    int slot, slot_lo;          // its time slot; the oldest slot that may hold a frame still on the air when it begins
+    int64_t t_begin;
+    int shift, pad;             // TickDev::shift of its result slot
+    const uint32_t *slot_off;   // its heard links, packet-major (the compact arrays of the tick's result slot) ...
+    const int32_t *out_dst;
+    const double *out_rssi;
+    double *out_sinr;           // ... and what the stages write
+    uint8_t *out_verdict;
+    unsigned long long *acc_lo, *acc_hi; // [links] Q80 interference sum per heard link
+    uint8_t *hd;                // [links] half duplex: the receiver is itself on the air
+    uint32_t *flags;            // the tick's TickDev::stage_count ([1]: dropped for capacity)
+};
+struct OvPair {                 // a (heard link, frame on the air) pair that passed the conservative tests
+    uint32_t link, tick;
+    int32_t pos, frame;         // the link's receiver (engine position), the frame (index in OvDev::tx)
+};
+struct OvDev {
+    const rm_tx_record *tx;     // [n_frames]
+    int n_frames, n_slots, n_ticks, n_bins; // n_bins = kSgCells * n_slots
+    int max_new;                // most new frames of a tick of the batch
+    const int32_t *slot_first;  // [n_slots + 1] first frame of a slot
+    const OvTick *ticks;        // [n_ticks]
+    // per frame: pre-filter record at the interference level (position in the fp32 frame, threshold; w < 0: reaches nobody),
+    // (shadow-bin scale, source node, channel, frame index), (start, end), bin
+    float4 *fr_f;
+    int4 *fr_m;
+    longlong2 *fr_t;
+    uint32_t *fr_bin;           // 0xFFFFFFFF: not in the grid
+    uint32_t *bin_cnt, *bin_off, *block_sum; // [n_bins], [n_bins + 1], [ceil(n_bins / kOvScanBlock)]
+    float4 *e_f;                // the same records sorted by bin
+    int4 *e_m;
+    longlong2 *e_t;
+    uint8_t *defer;             // [n_frames] 1: the frame's pairs did not all fit the pair list -- its sums are formed by the second go
+    uint32_t *every;            // [n_frames] frames without a cell (no bound, outside the frame)
+    uint32_t *misc;             // [0] entries of `every`, [1] a frame was deferred (the pair list was full), [2] pairs that interfered (statistics), [8 .. 8 + kSgMax) largest radius (float bits)
+    unsigned long long *self_slot; // [n] stamp << 32 | newest frame of the node
+    int32_t *self_next;         // [n_frames]
+    uint32_t stamp;
+    float half, inv;
+    OvPair *pairs;              // kShards regions of pair_seg entries
+    uint32_t *pair_tail;        // [kShards * kShardStride]
+    uint32_t pair_seg;
+};
+constexpr int kOvScanBlock = 4096;
 
 struct TickDev {
     AirDev air;
@@ -501,6 +573,10 @@ hipError_t launch_draws_apply_nodes(hipStream_t s, const ModelDev &m, const Tick
 hipError_t launch_draws_batch(hipStream_t s, const ModelDev &m, const TickDev *ticks, int n, const TickDev *dev_ticks);
 hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
                               int rank);
+
+// (rm_airbatch.hip) a batch of SINR ticks with frames that outlive their tick: index of the frames, then pairs / exact / verdicts
+hipError_t launch_ov_index(hipStream_t s, const NodesDev &nd, const ModelDev &m, const OvDev &ov, int max_slot_frames);
+hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, const OvDev &ov, int max_new, int max_links, const LaunchCfg &cfg);
 
 // reception stage (rm_events.hip)
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,

@@ -523,9 +523,9 @@ hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, 
     const dim3 grid(max(1, min(256, cdiv(n_new, 4)))), block(256);
     if (ls.n_scan > 0) {
         if (ls.n_scan > kFusedScanMax) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_ev_append<true>, grid, block, 0, s, e, ls, tx, n_new, now, immediate, dropped_flag);
+        RM_KLAUNCH(k_ev_append<true>, grid, block, 0, s, e, ls, tx, n_new, now, immediate, dropped_flag);
     } else {
-        hipLaunchKernelGGL(k_ev_append<false>, grid, block, 0, s, e, ls, tx, n_new, now, immediate, dropped_flag);
+        RM_KLAUNCH(k_ev_append<false>, grid, block, 0, s, e, ls, tx, n_new, now, immediate, dropped_flag);
     }
     return hipGetLastError();
 }
@@ -537,9 +537,9 @@ hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int6
     // contest of the radio fields; the winners write the state and the workgroup that is done last finishes the drain.
     const uint32_t pk_cap = e.pk_mask + 1u;
     const uint32_t w = (window == 0u || window > pk_cap) ? pk_cap : window;
-    hipLaunchKernelGGL(k_ev_select, dim3(cdiv(int(w), 256)), dim3(256), 0, s, e, time_us);
-    hipLaunchKernelGGL(k_ev_emit, dim3(512), dim3(256), 0, s, e);
-    hipLaunchKernelGGL(k_ev_apply, dim3(512), dim3(256), 0, s, e, out, time_us, seq);
+    RM_KLAUNCH(k_ev_select, dim3(cdiv(int(w), 256)), dim3(256), 0, s, e, time_us);
+    RM_KLAUNCH(k_ev_emit, dim3(512), dim3(256), 0, s, e);
+    RM_KLAUNCH(k_ev_apply, dim3(512), dim3(256), 0, s, e, out, time_us, seq);
     return hipGetLastError();
 }
 
@@ -550,7 +550,7 @@ hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, c
 {
     (void)g_dummy;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_node_info, dim3(max(1, min(256, cdiv(n, 256)))), dim3(256), 0, s, e, nd, dev_nodes, n, base_rssi, out, seq,
+    RM_KLAUNCH(k_node_info, dim3(max(1, min(256, cdiv(n, 256)))), dim3(256), 0, s, e, nd, dev_nodes, n, base_rssi, out, seq,
                        &e.st->done_a);
     return hipGetLastError();
 }

@@ -453,7 +453,7 @@ static void launch_exact_m(hipStream_t s, const NodesDev &nd, const ModelDev &m,
 {
     const dim3 grid(4, kShards), block(256);
     const int seg = t.use_matrix ? 0 : scan_variant(t.n_cnt);
-#define RM_EX(ST, SG) hipLaunchKernelGGL((k_exact<MODEL, SINR, ST, SG>), grid, block, 0, s, nd, m, t)
+#define RM_EX(ST, SG) RM_KLAUNCH((k_exact<MODEL, SINR, ST, SG>), grid, block, 0, s, nd, m, t)
     if (cfg.stochastic) {
         if (seg == 0) RM_EX(true, 0); else if (seg == 1) RM_EX(true, 1); else if (seg == 3) RM_EX(true, 3); else if (seg == 4) RM_EX(true, 4); else RM_EX(true, 2);
     } else {
@@ -482,13 +482,13 @@ hipError_t launch_exact(hipStream_t s, const NodesDev &nd, const ModelDev &m, co
 hipError_t launch_seg_scan(hipStream_t s, const TickDev &t)
 {
     if (!t.use_matrix && t.n_cnt > kFusedScanMax)
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cand_tot, t.seg_off, t.n_cnt);
+        RM_KLAUNCH(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cand_tot, t.seg_off, t.n_cnt);
     return hipGetLastError();
 }
 
 hipError_t launch_air_begin(hipStream_t s, const TickDev &t)
 {
-    hipLaunchKernelGGL(k_air_begin, dim3(1), dim3(64), 0, s, t);
+    RM_KLAUNCH(k_air_begin, dim3(1), dim3(64), 0, s, t);
     return hipGetLastError();
 }
 
@@ -496,7 +496,7 @@ hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev 
 {
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_self_entries, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, t);
+    RM_KLAUNCH(k_self_entries, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, t);
     return hipGetLastError();
 }
 
@@ -504,17 +504,17 @@ hipError_t launch_self_entries(hipStream_t s, const NodesDev &nd, const TickDev 
 hipError_t launch_offsets(hipStream_t s, const TickDev &t)
 {
     if (t.use_matrix) {
-        if (t.n_cnt > 0 && t.n_slabs > 0) hipLaunchKernelGGL(k_cell_off, dim3(t.n_cnt / 64), dim3(1024), 0, s, t);
-        hipLaunchKernelGGL(k_slot_scan, dim3(1), dim3(1024), 0, s, t);
+        if (t.n_cnt > 0 && t.n_slabs > 0) RM_KLAUNCH(k_cell_off, dim3(t.n_cnt / 64), dim3(1024), 0, s, t);
+        RM_KLAUNCH(k_slot_scan, dim3(1), dim3(1024), 0, s, t);
     } else if (t.n_cnt > kFusedScanMax) {
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cursor, t.slot_off, t.n_cnt);
+        RM_KLAUNCH(k_scan_counts, dim3(1), dim3(1024), 0, s, t.cursor, t.slot_off, t.n_cnt);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_sinr(hipStream_t s, const ModelDev &m, const TickDev &t)
 {
-    hipLaunchKernelGGL(k_sinr, dim3(4, kShards), dim3(256), 0, s, m, t);
+    RM_KLAUNCH(k_sinr, dim3(4, kShards), dim3(256), 0, s, m, t);
     return hipGetLastError();
 }
 
@@ -530,10 +530,10 @@ hipError_t launch_finalize(hipStream_t s, const NodesDev &nd, const ModelDev &m,
     (void)nd;
     const dim3 grid(4, kShards), block(256);
     if (cfg.stochastic) {
-        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, s, m, t);
+        RM_KLAUNCH(k_finalize<true>, grid, block, 0, s, m, t);
     } else {
-        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, s, m, t);
-        hipLaunchKernelGGL(k_pkt_interference, dim3(8), dim3(256), 0, s, m, t);
+        RM_KLAUNCH(k_finalize<false>, grid, block, 0, s, m, t);
+        RM_KLAUNCH(k_pkt_interference, dim3(8), dim3(256), 0, s, m, t);
     }
     return hipGetLastError();
 }
@@ -554,19 +554,19 @@ hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev 
 #define RM_EXB(MODEL)                                                                                                \
 do {                                                                                                             \
     if (cfg.stochastic) {                                                                                        \
-        if (scan == 3) hipLaunchKernelGGL((k_exact_batch<MODEL, true, 3>), grid, block, 0, s, nd, m, b);         \
-        else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<MODEL, true, 4>), grid, block, 0, s, nd, m, b);    \
-        else hipLaunchKernelGGL((k_exact_batch<MODEL, true, 1>), grid, block, 0, s, nd, m, b);                   \
+        if (scan == 3) RM_KLAUNCH((k_exact_batch<MODEL, true, 3>), grid, block, 0, s, nd, m, b);         \
+        else if (scan == 4) RM_KLAUNCH((k_exact_batch<MODEL, true, 4>), grid, block, 0, s, nd, m, b);    \
+        else RM_KLAUNCH((k_exact_batch<MODEL, true, 1>), grid, block, 0, s, nd, m, b);                   \
     } else {                                                                                                     \
-        if (scan == 3) hipLaunchKernelGGL((k_exact_batch<MODEL, false, 3>), grid, block, 0, s, nd, m, b);        \
-        else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<MODEL, false, 4>), grid, block, 0, s, nd, m, b);   \
-        else hipLaunchKernelGGL((k_exact_batch<MODEL, false, 1>), grid, block, 0, s, nd, m, b);                  \
+        if (scan == 3) RM_KLAUNCH((k_exact_batch<MODEL, false, 3>), grid, block, 0, s, nd, m, b);        \
+        else if (scan == 4) RM_KLAUNCH((k_exact_batch<MODEL, false, 4>), grid, block, 0, s, nd, m, b);   \
+        else RM_KLAUNCH((k_exact_batch<MODEL, false, 1>), grid, block, 0, s, nd, m, b);                  \
     }                                                                                                            \
 } while (0)
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) { // self-contained ticks of the SINR extension (no draws)
-        if (scan == 3) hipLaunchKernelGGL((k_exact_batch<RM_MODEL_LOGDIST, false, 3, true>), grid, block, 0, s, nd, m, b);
-        else if (scan == 4) hipLaunchKernelGGL((k_exact_batch<RM_MODEL_LOGDIST, false, 4, true>), grid, block, 0, s, nd, m, b);
-        else hipLaunchKernelGGL((k_exact_batch<RM_MODEL_LOGDIST, false, 1, true>), grid, block, 0, s, nd, m, b);
+        if (scan == 3) RM_KLAUNCH((k_exact_batch<RM_MODEL_LOGDIST, false, 3, true>), grid, block, 0, s, nd, m, b);
+        else if (scan == 4) RM_KLAUNCH((k_exact_batch<RM_MODEL_LOGDIST, false, 4, true>), grid, block, 0, s, nd, m, b);
+        else RM_KLAUNCH((k_exact_batch<RM_MODEL_LOGDIST, false, 1, true>), grid, block, 0, s, nd, m, b);
         return hipGetLastError();
     }
     switch (m.kind) {
@@ -586,13 +586,13 @@ hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &
 {
     int max_eval = 0;
     for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
-    hipLaunchKernelGGL(k_self_entries_batch, dim3(cdiv(max(max_eval, 1), 256), 1, n), dim3(256), 0, s, nd, b);
+    RM_KLAUNCH(k_self_entries_batch, dim3(cdiv(max(max_eval, 1), 256), 1, n), dim3(256), 0, s, nd, b);
     // one row of workgroups per shard IN USE (a batch appends to 64 of the 256 shards, a receiver partition to 8): the rows of
     // the others would be a thousand workgroups per tick that find nothing
     const int shards = int(ticks[0].shard_mask) + 1;
     int gx = 2; // (measured 1 / 2 / 4 / 8: 5.10 / 5.03 / 5.09 / 5.26 us per tick on a rank's share of configs[3])
     if (const char *e = getenv("RM_SINR_GX")) gx = max(1, atoi(e));
-    hipLaunchKernelGGL(k_sinr_batch, dim3(gx, shards, n), dim3(256), 0, s, m, b);
+    RM_KLAUNCH(k_sinr_batch, dim3(gx, shards, n), dim3(256), 0, s, m, b);
     return hipGetLastError();
 }
 

@@ -763,16 +763,16 @@ k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict
 hipError_t launch_patch_nodes(hipStream_t s, const NodesDev &nd, const NodePatch *dev_list, int n, const NodePatch &one)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_patch_nodes, dim3(cdiv(n, 256)), dim3(256), 0, s, nd, dev_list, n, one);
+    RM_KLAUNCH(k_patch_nodes, dim3(cdiv(n, 256)), dim3(256), 0, s, nd, dev_list, n, one);
     return hipGetLastError();
 }
 
 hipError_t launch_prep_rx(hipStream_t s, const NodesDev &nd, const ModelDev &m)
 {
     if (nd.n_rx <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_rx, dim3(cdiv(nd.n_rx, kGroup)), dim3(64), 0, s, nd, m);
+    RM_KLAUNCH(k_prep_rx, dim3(cdiv(nd.n_rx, kGroup)), dim3(64), 0, s, nd, m);
     const int n_wg = cdiv(nd.n_rx, kGroup * 16);
-    hipLaunchKernelGGL(k_wg_boxes, dim3(cdiv(n_wg, 256)), dim3(256), 0, s, nd, n_wg);
+    RM_KLAUNCH(k_wg_boxes, dim3(cdiv(n_wg, 256)), dim3(256), 0, s, nd, n_wg);
     return hipGetLastError();
 }
 
@@ -780,7 +780,7 @@ hipError_t launch_pack_tx(hipStream_t s, const NodesDev &nd, const int32_t *dev_
                           int64_t air_us, rm_tx_record *out)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_tx, dim3(cdiv(n, 256)), dim3(256), 0, s, nd, dev_src, n, start_us, air_us, out);
+    RM_KLAUNCH(k_pack_tx, dim3(cdiv(n, 256)), dim3(256), 0, s, nd, dev_src, n, start_us, air_us, out);
     return hipGetLastError();
 }
 
@@ -793,7 +793,7 @@ hipError_t launch_pack_tx_batch(hipStream_t s, const NodesDev &nd, const int32_t
         const int nb = min(kPackChunk, n_ticks - b0);
         PackStarts st{};
         for (int b = 0; b < nb; ++b) st.start_us[b] = start_us[b0 + b];
-        hipLaunchKernelGGL(k_pack_tx_batch, dim3(cdiv(n, 256), nb, max(world, 1)), dim3(256), 0, s, nd, dev_src, n, st, air_us, out, b0, n_ticks);
+        RM_KLAUNCH(k_pack_tx_batch, dim3(cdiv(n, 256), nb, max(world, 1)), dim3(256), 0, s, nd, dev_src, n, st, air_us, out, b0, n_ticks);
     }
     return hipGetLastError();
 }
@@ -849,17 +849,17 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0 || t.n_slabs <= 0) return hipSuccess;
     if (t.filter_mode == kFilterWg) {
-        hipLaunchKernelGGL(k_tick_prep, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, m, t);
+        RM_KLAUNCH(k_tick_prep, dim3(cdiv(n_eval, 256)), dim3(256), 0, s, nd, m, t);
         const dim3 grid(cdiv(t.n_slabs, kWavesPerBlock)), block(kBlock);
         if (t.rpt == 4) {
-            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<4, true>), grid, block, 0, s, nd, m, t);
-            else hipLaunchKernelGGL((k_filter_wg<4, false>), grid, block, 0, s, nd, m, t);
+            if (cfg.shadow) RM_KLAUNCH((k_filter_wg<4, true>), grid, block, 0, s, nd, m, t);
+            else RM_KLAUNCH((k_filter_wg<4, false>), grid, block, 0, s, nd, m, t);
         } else if (t.rpt == 2) {
-            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<2, true>), grid, block, 0, s, nd, m, t);
-            else hipLaunchKernelGGL((k_filter_wg<2, false>), grid, block, 0, s, nd, m, t);
+            if (cfg.shadow) RM_KLAUNCH((k_filter_wg<2, true>), grid, block, 0, s, nd, m, t);
+            else RM_KLAUNCH((k_filter_wg<2, false>), grid, block, 0, s, nd, m, t);
         } else {
-            if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg<1, true>), grid, block, 0, s, nd, m, t);
-            else hipLaunchKernelGGL((k_filter_wg<1, false>), grid, block, 0, s, nd, m, t);
+            if (cfg.shadow) RM_KLAUNCH((k_filter_wg<1, true>), grid, block, 0, s, nd, m, t);
+            else RM_KLAUNCH((k_filter_wg<1, false>), grid, block, 0, s, nd, m, t);
         }
         return hipGetLastError();
     }
@@ -869,7 +869,7 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
     // per XCD (placement is a speed matter only; the padding workgroups exit at once)
     const dim3 grid((cdiv(t.n_slabs, kWavesPerBlock) + 7) / 8 * 8, cdiv(n_eval, kTxChunk));
     const dim3 block(kBlock);
-#define RM_LAUNCH(RPT, F64, BBOX, SH) hipLaunchKernelGGL((k_filter<RPT, F64, BBOX, SH>), grid, block, 0, s, nd, m, t)
+#define RM_LAUNCH(RPT, F64, BBOX, SH) RM_KLAUNCH((k_filter<RPT, F64, BBOX, SH>), grid, block, 0, s, nd, m, t)
     if (t.rpt == 4) {
         if (cfg.f64_filter) RM_LAUNCH(4, true, false, false);
         else if (cfg.bbox && cfg.shadow) RM_LAUNCH(4, false, true, true);
@@ -895,7 +895,7 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     int max_eval = 0;
     for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
     const TickDev &t0 = ticks[0];
-    hipLaunchKernelGGL(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
+    RM_KLAUNCH(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
     // A workgroup keeps its receivers for `per_wg` ticks: as many as leave a few thousand workgroups for the chip (a table
     // of a million receivers has a thousand tiles: 16 ticks = 4 per workgroup; 100 k receivers: one tick per workgroup).
     const int tiles = cdiv(t0.n_slabs, kWavesPerBlock);
@@ -903,14 +903,14 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     if (const char *e = getenv("RM_FILTER_TICKS_PER_WG")) per_wg = max(1, min(n, atoi(e)));
     const dim3 grid(tiles, 1, cdiv(n, per_wg)), block(kBlock);
     if (t0.rpt == 4) {
-        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b, n, per_wg);
-        else hipLaunchKernelGGL((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b, n, per_wg);
+        if (cfg.shadow) RM_KLAUNCH((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else RM_KLAUNCH((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     } else if (t0.rpt == 2) {
-        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<2, true>), grid, block, 0, s, nd, m, b, n, per_wg);
-        else hipLaunchKernelGGL((k_filter_wg_batch<2, false>), grid, block, 0, s, nd, m, b, n, per_wg);
+        if (cfg.shadow) RM_KLAUNCH((k_filter_wg_batch<2, true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else RM_KLAUNCH((k_filter_wg_batch<2, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     } else {
-        if (cfg.shadow) hipLaunchKernelGGL((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b, n, per_wg);
-        else hipLaunchKernelGGL((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b, n, per_wg);
+        if (cfg.shadow) RM_KLAUNCH((k_filter_wg_batch<1, true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else RM_KLAUNCH((k_filter_wg_batch<1, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     }
     return hipGetLastError();
 }

@@ -251,8 +251,29 @@ struct rm_context : TickSlot {
         int64_t last_t_begin = 0;
         uint64_t rebuilds = 0, incremental = 0;
         uint64_t scans = 0;       // ticks evaluated by scan (rm_airscan.hip): they leave nothing in the lists
+        uint32_t stamp = 0;       // of the nodes' chains of own frames (TickSlot::d_self_slot of the context): one per tick by scan / per batch of overlapping ticks
     } air;
     int64_t air_max_t_begin = INT64_MIN; // the latest t_begin a tick over the on-air window has had (air_tick_device)
+    // a batch of SINR ticks whose frames outlive their tick (rm_airbatch.hip, rm_api_airbatch.cpp): the batch's index of
+    // the frames it can see, the surviving (link, frame) pairs, the descriptors' pinned staging
+    struct Overlap {
+        DevBuf<float4> fr_f, e_f;
+        DevBuf<int4> fr_m, e_m;
+        DevBuf<longlong2> fr_t, e_t;
+        DevBuf<uint32_t> fr_bin, bin_cnt, bin_off, block_sum, every, misc, pair_tail;
+        DevBuf<int32_t> self_next, slot_first;
+        DevBuf<uint8_t> defer;
+        DevBuf<rm::OvTick> ticks;
+        DevBuf<rm::OvPair> pairs;
+        size_t pair_cap = 0;        // entries over all shards
+        size_t pair_cap_forced = 0; // RM_OV_PAIR_CAP (tests)
+        char *h_desc[2] = {nullptr, nullptr}; // pinned: OvTick[RM_MAX_BATCH] then slot_first
+        size_t h_desc_bytes[2] = {0, 0};
+        hipEvent_t h_ev[2] = {nullptr, nullptr};
+        int gen = 0;
+        uint32_t *h_flag = nullptr; // pinned: OvDev::misc[1] of the batch before (frames were deferred, the pair list was full: grown for the next one)
+        uint64_t batches = 0, ticks_done = 0, last_frames = 0;
+    } ov;
     bool dev_records_from_caller = false; // the tick being prepared takes rm_tx_record arrays the caller built in device memory
     mutable rm::ModelDev mdev{};            // model_dev()'s last answer and what it was derived from
     mutable unsigned char mdev_key[320] = {};
@@ -293,20 +314,32 @@ struct rm_context : TickSlot {
     bool use_graphs = false; // RM_GRAPH=1: replay the tick from a cached hipGraph (measured slower than eager
                              // launches on ROCm 7.2 for this 5-kernel sequence: 50 vs 46 us per tick)
 
-    // profiling of the dominant kernel
+    // profiling (rm_profile_enable): on every n-th launch sequence each kernel launch carries its own pair of events
+    // (rm::KernelProbe); the intervals are summed per stage and per kernel
     bool profile = false;   // sampling on
-    int profile_every = 1;  // take an event-timed sample every n-th tick
+    int profile_every = 1;  // sample every n-th launch sequence
     uint64_t tick_index = 0;
-    // a sampled tick records one event before every stage and one after the last
     struct Sample {
-        hipEvent_t ev[RM_PROFILE_STAGES + 1];
-        int stage[RM_PROFILE_STAGES];
-        int n = 0;
+        struct K {
+            hipEvent_t a = nullptr, b = nullptr;
+            int stage = 0;
+            const char *name = nullptr;
+        };
+        std::vector<K> k;   // (events are created once and reused)
+        int n = 0;          // launches probed in this sample
+        int cur_stage = 0;  // stage the launches being issued belong to
     };
-    std::vector<Sample> ev_pool;
+    std::deque<Sample> ev_pool;
     size_t ev_used = 0;
     uint32_t prof_samples = 0;
     double prof_ms[RM_PROFILE_STAGES] = {0};
+    struct KernelTime {
+        std::string name;
+        int stage;
+        uint32_t launches;
+        double ms;
+    };
+    std::vector<KernelTime> prof_kernels;
 };
 
 namespace rmh {
@@ -361,7 +394,9 @@ struct TickPlan {
 // (build mode: where the records of the source indices `src_list` are written).
 // kAirScan: `tx` holds every frame on the air (as for a rebuild), only the new ones are evaluated, their interferers are found
 // among the frames themselves (rm_airscan.hip); the lists are not touched and count as stale afterwards
-enum { kAirNone = 0, kAirIncremental = 1, kAirRebuild = 2, kAirScan = 3 };
+// kAirBatch: a tick of a batch of overlapping SINR ticks (rm_api_airbatch.cpp): swept as the medium without SINR (heard links
+// only, cut-off at the sensitivity); the interference stages of the whole batch follow the sweep
+enum { kAirNone = 0, kAirIncremental = 1, kAirRebuild = 2, kAirScan = 3, kAirBatch = 4 };
 bool air_scan_applies(rm_context *c, int n_new); // (after prepare_nodes)
 uint32_t air_sub_cap(const rm_context *c);
 bool air_lists_current(const rm_context *c, int64_t t_begin, uint32_t oldest);
@@ -373,6 +408,19 @@ int materialize(rm_context *c, TickSlot &ts);
 int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
              int64_t src_start_us = 0, int64_t src_air_us = 0, int air_mode = kAirNone, uint32_t air_oldest = 0);
 int drain_profile(rm_context *c);
+// a sampled launch sequence: begin_sample() returns the sample (or nullptr: not sampled) and routes the kernel probes of
+// this thread to it; sample_stage() names the stage of the launches that follow; end_sample() unroutes.  (ProbeScope
+// does the last two on every way out of a launch function.)
+rm_context::Sample *begin_sample(rm_context *c);
+inline void sample_stage(rm_context::Sample *smp, int stage) { if (smp) smp->cur_stage = stage; }
+void end_sample();
+struct ProbeScope {
+    rm_context::Sample *smp;
+    explicit ProbeScope(rm_context *c) : smp(begin_sample(c)) {}
+    ~ProbeScope() { if (smp) end_sample(); }
+    ProbeScope(const ProbeScope &) = delete;
+    ProbeScope &operator=(const ProbeScope &) = delete;
+};
 
 // ---- rm_api_events.cpp: the reception stage
 rm::EvDev ev_dev(rm_context *c);
@@ -397,6 +445,8 @@ int tick_run_host(rm_context *c);
 // or -- new_on_host -- in the host's pinned staging block, and join the window's tail.
 int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, const rm_tx_record *dev_new, int32_t n, int64_t start_us,
                     int64_t air_us, int64_t latest_end_us, bool new_on_host);
+int air_window_expire(rm_context *c, int64_t t_begin_us);
+int air_window_reserve(rm_context *c, size_t n_more);
 int result_device(rm_context *c, TickSlot &ts, rm_device_result *out);
 int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *dropped);
 
@@ -408,6 +458,16 @@ int group_all_gather(rm_context *const *members, int n, const void *const *mine,
 
 // ---- rm_api_batch.cpp
 TickSlot *slot_of(rm_context *c, int32_t slot);
+// the launch sequence of n prepared ticks; m_override: the model the sweep runs with (a batch of overlapping SINR ticks
+// sweeps with the medium without SINR), after_sweep: issued behind the last sweep stage, inside the sampled sequence
+int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n, const rm::ModelDev *m_override = nullptr,
+                 int (*after_sweep)(rm_context *, void *) = nullptr, void *after_arg = nullptr);
+// ---- rm_api_airbatch.cpp
+bool overlap_wanted(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int32_t *n_per, const int64_t *start_us,
+                    const int64_t *air_us);
+int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
+                      const int32_t *n_per, const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world,
+                      int gather_slots);
 int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
               const rm_tx_record *const *dev_new, const int32_t *n_per, const int64_t *start_us, const int64_t *air_us,
               const rm_tx_record *gathered = nullptr, int gather_world = 0, int gather_slots = 0);

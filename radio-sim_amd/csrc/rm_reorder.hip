@@ -553,7 +553,7 @@ k_apply_draws_nodes(TickDev t, const uint32_t *__restrict__ all_cnt, const uint3
 
 hipError_t launch_draw_nodes(hipStream_t s, const TickDev &t, int32_t *dev_nodes)
 {
-    hipLaunchKernelGGL(k_draw_nodes, dim3(256), dim3(256), 0, s, t, dev_nodes);
+    RM_KLAUNCH(k_draw_nodes, dim3(256), dim3(256), 0, s, t, dev_nodes);
     return hipGetLastError();
 }
 
@@ -561,9 +561,9 @@ hipError_t launch_draws_apply_nodes(hipStream_t s, const ModelDev &m, const Tick
                                     const int32_t *all_nodes, uint32_t stride, int world)
 {
     const int n_new = t.n_active - t.first_new;
-    if (n_new > 0) hipLaunchKernelGGL(k_draw_offsets, dim3(world), dim3(1024), 0, s, all_cnt, n_new, all_off);
-    hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, 0);
-    hipLaunchKernelGGL(k_apply_draws_nodes, dim3(256), dim3(256), 0, s, t, all_cnt, all_off, all_nodes, stride, world);
+    if (n_new > 0) RM_KLAUNCH(k_draw_offsets, dim3(world), dim3(1024), 0, s, all_cnt, n_new, all_off);
+    RM_KLAUNCH(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, 0);
+    RM_KLAUNCH(k_apply_draws_nodes, dim3(256), dim3(256), 0, s, t, all_cnt, all_off, all_nodes, stride, world);
     return hipGetLastError();
 }
 
@@ -574,7 +574,7 @@ hipError_t launch_reorder(hipStream_t s, const ModelDev &m, const TickDev &t, co
     const dim3 grid(max(1, min(2048, (n_new + 3) / 4))), block(256);
     const bool sinr = (m.kind == RM_MODEL_LOGDIST) && (m.flags & RM_LD_SINR);
     const int mode = scan_variant(t.n_cnt);
-#define RM_RE(ST, SI, MO) hipLaunchKernelGGL((k_reorder<ST, SI, MO>), grid, block, 0, s, m, t)
+#define RM_RE(ST, SI, MO) RM_KLAUNCH((k_reorder<ST, SI, MO>), grid, block, 0, s, m, t)
     if (mode == 3) {
         if (cfg.stochastic) { if (sinr) RM_RE(true, true, 3); else RM_RE(true, false, 3); }
         else { if (sinr) RM_RE(false, true, 3); else RM_RE(false, false, 3); }
@@ -612,17 +612,17 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     if (const char *e = getenv("RM_FPW")) fpw = max(1, atoi(e));
     const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
-        if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<false, 3, true>), grid, block, 0, s, m, b);
-        else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<false, 4, true>), grid, block, 0, s, m, b);
-        else hipLaunchKernelGGL((k_reorder_batch<false, 1, true>), grid, block, 0, s, m, b);
+        if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3, true>), grid, block, 0, s, m, b);
+        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4, true>), grid, block, 0, s, m, b);
+        else RM_KLAUNCH((k_reorder_batch<false, 1, true>), grid, block, 0, s, m, b);
     } else if (cfg.stochastic) {
-        if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
-        else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
-        else hipLaunchKernelGGL((k_reorder_batch<true, 1>), grid, block, 0, s, m, b);
+        if (scan == 3) RM_KLAUNCH((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
+        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
+        else RM_KLAUNCH((k_reorder_batch<true, 1>), grid, block, 0, s, m, b);
     } else {
-        if (scan == 3) hipLaunchKernelGGL((k_reorder_batch<false, 3>), grid, block, 0, s, m, b);
-        else if (scan == 4) hipLaunchKernelGGL((k_reorder_batch<false, 4>), grid, block, 0, s, m, b);
-        else hipLaunchKernelGGL((k_reorder_batch<false, 1>), grid, block, 0, s, m, b);
+        if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3>), grid, block, 0, s, m, b);
+        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4>), grid, block, 0, s, m, b);
+        else RM_KLAUNCH((k_reorder_batch<false, 1>), grid, block, 0, s, m, b);
     }
     return hipGetLastError();
 }
@@ -632,10 +632,10 @@ hipError_t launch_draws_scan(hipStream_t s, const TickDev &t)
 {
     const int tiles = min(256, cdiv(int(t.cap), kScanTile)); // grid-stride over the tiles that hold records
     const int n_new = t.n_active - t.first_new;
-    hipLaunchKernelGGL(k_draw_tile_sums, dim3(tiles), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(k_draw_tile_scan, dim3(1), dim3(1024), 0, s, t);
-    hipLaunchKernelGGL(k_draw_scan, dim3(tiles), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(k_pkt_draw_counts, dim3(max(1, cdiv(n_new, 256))), dim3(256), 0, s, t);
+    RM_KLAUNCH(k_draw_tile_sums, dim3(tiles), dim3(256), 0, s, t);
+    RM_KLAUNCH(k_draw_tile_scan, dim3(1), dim3(1024), 0, s, t);
+    RM_KLAUNCH(k_draw_scan, dim3(tiles), dim3(256), 0, s, t);
+    RM_KLAUNCH(k_pkt_draw_counts, dim3(max(1, cdiv(n_new, 256))), dim3(256), 0, s, t);
     return hipGetLastError();
 }
 
@@ -643,8 +643,8 @@ hipError_t launch_draws_scan(hipStream_t s, const TickDev &t)
 hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *all_cnt, int world,
                               int rank)
 {
-    hipLaunchKernelGGL(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, rank);
-    hipLaunchKernelGGL(k_apply_draws, dim3(256), dim3(256), 0, s, t);
+    RM_KLAUNCH(k_rng_chain, dim3(1), dim3(1024), 0, s, m, t, all_cnt, world, rank);
+    RM_KLAUNCH(k_apply_draws, dim3(256), dim3(256), 0, s, t);
     return hipGetLastError();
 }
 
@@ -655,12 +655,12 @@ hipError_t launch_draws_batch(hipStream_t s, const ModelDev &m, const TickDev *t
     int max_new = 0;
     for (int i = 0; i < n; ++i) max_new = max(max_new, ticks[i].n_active - ticks[i].first_new);
     const int tiles = min(64, cdiv(int(ticks[0].cap), kScanTile));
-    hipLaunchKernelGGL(k_draw_tile_sums_batch, dim3(tiles, 1, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_draw_tile_scan_batch, dim3(1, 1, n), dim3(1024), 0, s, b);
-    hipLaunchKernelGGL(k_draw_scan_batch, dim3(tiles, 1, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_pkt_draw_counts_batch, dim3(max(1, cdiv(max_new, 256)), 1, n), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_rng_chain_batch, dim3(1), dim3(1024), 0, s, m, b, n);
-    hipLaunchKernelGGL(k_apply_draws_batch, dim3(32, 1, n), dim3(256), 0, s, b);
+    RM_KLAUNCH(k_draw_tile_sums_batch, dim3(tiles, 1, n), dim3(256), 0, s, b);
+    RM_KLAUNCH(k_draw_tile_scan_batch, dim3(1, 1, n), dim3(1024), 0, s, b);
+    RM_KLAUNCH(k_draw_scan_batch, dim3(tiles, 1, n), dim3(256), 0, s, b);
+    RM_KLAUNCH(k_pkt_draw_counts_batch, dim3(max(1, cdiv(max_new, 256)), 1, n), dim3(256), 0, s, b);
+    RM_KLAUNCH(k_rng_chain_batch, dim3(1), dim3(1024), 0, s, m, b, n);
+    RM_KLAUNCH(k_apply_draws_batch, dim3(32, 1, n), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

@@ -917,8 +917,8 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     }();
 #define RM_FR2(M_, MODEL, ST, SH)                                                                                      \
     do {                                                                                                               \
-        if (n_groups <= flat_max) hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, M_, t, seg_len); \
-        else hipLaunchKernelGGL((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, M_, t, seg_len);         \
+        if (n_groups <= flat_max) RM_KLAUNCH((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, M_, t, seg_len); \
+        else RM_KLAUNCH((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, M_, t, seg_len);         \
     } while (0)
 #define RM_FR3(M_, MODEL, SH)                                                                                          \
     do {                                                                                                               \
@@ -936,7 +936,7 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
         grid.x += unsigned(cdiv(t.n_active, 256)); // (workgroups that index the frames on the air)
         const bool sh = cfg.shadow && m.shadow_tbl && !no_shadow;
         const bool flat = n_groups <= flat_max;
-#define RM_FSC(ST, SH, FL) hipLaunchKernelGGL((k_tick_frames_scan<ST, SH, FL>), grid, block, 0, s, nd, ms, t, seg_len, *scan)
+#define RM_FSC(ST, SH, FL) RM_KLAUNCH((k_tick_frames_scan<ST, SH, FL>), grid, block, 0, s, nd, ms, t, seg_len, *scan)
         if (cfg.stochastic) {
             if (sh) { if (flat) RM_FSC(true, true, true); else RM_FSC(true, true, false); }
             else { if (flat) RM_FSC(true, false, true); else RM_FSC(true, false, false); }
@@ -952,7 +952,7 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
         const bool sh = cfg.shadow && m.shadow_tbl && !no_shadow;
         const bool flat = n_groups <= flat_max;
-#define RM_FRS(ST, SH, FL) hipLaunchKernelGGL((k_tick_frames_sinr<ST, SH, FL>), grid, block, 0, s, nd, m, t, seg_len)
+#define RM_FRS(ST, SH, FL) RM_KLAUNCH((k_tick_frames_sinr<ST, SH, FL>), grid, block, 0, s, nd, m, t, seg_len)
         if (cfg.stochastic) {
             if (sh) { if (flat) RM_FRS(true, true, true); else RM_FRS(true, true, false); }
             else { if (flat) RM_FRS(true, false, true); else RM_FRS(true, false, false); }
@@ -962,7 +962,7 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
         }
 #undef RM_FRS
         const int n_new = t.n_active - t.first_new;
-        hipLaunchKernelGGL(k_sinr_frames, dim3(max(1, min(4096, cdiv(n_new, 4)))), dim3(256), 0, s, nd, m, t);
+        RM_KLAUNCH(k_sinr_frames, dim3(max(1, min(4096, cdiv(n_new, 4)))), dim3(256), 0, s, nd, m, t);
         return hipGetLastError();
     }
     switch (m.kind) {
@@ -995,8 +995,8 @@ hipError_t launch_frames_cand(hipStream_t s, const NodesDev &nd, const ModelDev 
 {
     const int n_eval = t.n_active - t.first_eval;
     if (n_eval <= 0 || t.n_rx <= 0) return hipSuccess;
-    if (cfg.shadow && m.shadow_tbl) hipLaunchKernelGGL((k_frames_cand<true>), dim3(n_eval), dim3(256), 0, s, nd, m, t);
-    else hipLaunchKernelGGL((k_frames_cand<false>), dim3(n_eval), dim3(256), 0, s, nd, m, t);
+    if (cfg.shadow && m.shadow_tbl) RM_KLAUNCH((k_frames_cand<true>), dim3(n_eval), dim3(256), 0, s, nd, m, t);
+    else RM_KLAUNCH((k_frames_cand<false>), dim3(n_eval), dim3(256), 0, s, nd, m, t);
     return hipGetLastError();
 }
 
@@ -1010,8 +1010,8 @@ hipError_t launch_tick_frames_batch(hipStream_t s, const NodesDev &nd, const Mod
     const bool flat = n_groups <= kFrFlatGroups;
 #define RM_FRB(MODEL, SH)                                                                                              \
     do {                                                                                                               \
-        if (flat) hipLaunchKernelGGL((k_tick_frames_batch<MODEL, false, SH, true>), grid, block, 0, s, nd, m, dev_ticks, seg_len); \
-        else hipLaunchKernelGGL((k_tick_frames_batch<MODEL, false, SH, false>), grid, block, 0, s, nd, m, dev_ticks, seg_len);     \
+        if (flat) RM_KLAUNCH((k_tick_frames_batch<MODEL, false, SH, true>), grid, block, 0, s, nd, m, dev_ticks, seg_len); \
+        else RM_KLAUNCH((k_tick_frames_batch<MODEL, false, SH, false>), grid, block, 0, s, nd, m, dev_ticks, seg_len);     \
     } while (0)
     switch (m.kind) {
     case RM_MODEL_UDGM: RM_FRB(RM_MODEL_UDGM, false); break;
@@ -1035,9 +1035,9 @@ hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t
     }();
     const dim3 grid(wgs), block(256);
     const int scan = scan_variant(t.n_cnt);
-    if (scan == 3) hipLaunchKernelGGL(k_pack_frames<3>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
-    else if (scan == 4) hipLaunchKernelGGL(k_pack_frames<4>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
-    else hipLaunchKernelGGL(k_pack_frames<1>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
+    if (scan == 3) RM_KLAUNCH(k_pack_frames<3>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
+    else if (scan == 4) RM_KLAUNCH(k_pack_frames<4>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
+    else RM_KLAUNCH(k_pack_frames<1>, grid, block, 0, s, m, t, n_new, v, done_counter, seq);
     return hipGetLastError();
 }
 

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64) k_fetch_ticks(const TickDev *__restrict__ 
 
 hipError_t launch_fetch_ticks(hipStream_t s, const TickDev *host_mapped, int n, TickDev *dev_ticks)
 {
-    hipLaunchKernelGGL(k_fetch_ticks, dim3(n), dim3(64), 0, s, host_mapped, dev_ticks, n);
+    RM_KLAUNCH(k_fetch_ticks, dim3(n), dim3(64), 0, s, host_mapped, dev_ticks, n);
     return hipGetLastError();
 }
 
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(1024) k_transmit_one(const NodesDev nd, const 
 
 hipError_t launch_store_record(hipStream_t s, const rm_tx_record &r, rm_tx_record *dst)
 {
-    hipLaunchKernelGGL(k_store_record, dim3(1), dim3(64), 0, s, r, dst);
+    RM_KLAUNCH(k_store_record, dim3(1), dim3(64), 0, s, r, dst);
     return hipGetLastError();
 }
 
@@ -370,11 +370,11 @@ hipError_t launch_transmit_one(hipStream_t s, const NodesDev &nd, const ModelDev
 {
     const dim3 grid(1), block(1024);
     switch (m.kind) {
-    case RM_MODEL_UDGM: hipLaunchKernelGGL(k_transmit_one<RM_MODEL_UDGM>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq); break;
+    case RM_MODEL_UDGM: RM_KLAUNCH(k_transmit_one<RM_MODEL_UDGM>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq); break;
     case RM_MODEL_UDGM_CONST:
-        hipLaunchKernelGGL(k_transmit_one<RM_MODEL_UDGM_CONST>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq);
+        RM_KLAUNCH(k_transmit_one<RM_MODEL_UDGM_CONST>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq);
         break;
-    case RM_MODEL_LOGDIST: hipLaunchKernelGGL(k_transmit_one<RM_MODEL_LOGDIST>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq); break;
+    case RM_MODEL_LOGDIST: RM_KLAUNCH(k_transmit_one<RM_MODEL_LOGDIST>, grid, block, 0, s, nd, m, tx, rng_state, host_mapped, seq); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -384,7 +384,7 @@ hipError_t launch_pack_tick(hipStream_t s, const TickDev &t, int n_new, int have
                             uint32_t seq)
 {
     // enough workgroups to keep the PCIe writes streaming, few enough for a short tail
-    hipLaunchKernelGGL(k_pack_tick, dim3(64), dim3(256), 0, s, t, n_new, have_offsets, v, done_counter, seq);
+    RM_KLAUNCH(k_pack_tick, dim3(64), dim3(256), 0, s, t, n_new, have_offsets, v, done_counter, seq);
     return hipGetLastError();
 }
 
@@ -392,13 +392,13 @@ hipError_t launch_pack_batch(hipStream_t s, const PackSlot *dev_slots, int n_slo
                              uint32_t *done_counter, uint32_t seq)
 {
     if (n_slots < 1 || n_slots > kMaxBatch) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_pack_batch, dim3(16, n_slots), dim3(256), 0, s, dev_slots, n_slots, v, host_counts, done_counter, seq);
+    RM_KLAUNCH(k_pack_batch, dim3(16, n_slots), dim3(256), 0, s, dev_slots, n_slots, v, host_counts, done_counter, seq);
     return hipGetLastError();
 }
 
 hipError_t launch_pack_result(hipStream_t s, const TickDev &t, TransmitResult *host_mapped)
 {
-    hipLaunchKernelGGL(k_pack_result, dim3(4), dim3(256), 0, s, t, host_mapped);
+    RM_KLAUNCH(k_pack_result, dim3(4), dim3(256), 0, s, t, host_mapped);
     return hipGetLastError();
 }
 
@@ -418,7 +418,7 @@ hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDe
         TickGroup g{};
         const int k = min(kStoreTicks, n - b0);
         for (int i = 0; i < k; ++i) g.t[i] = ticks[b0 + i];
-        hipLaunchKernelGGL(k_store_ticks, dim3(k), dim3(64), 0, s, g, dev_ticks + b0, k);
+        RM_KLAUNCH(k_store_ticks, dim3(k), dim3(64), 0, s, g, dev_ticks + b0, k);
     }
     return hipGetLastError();
 }

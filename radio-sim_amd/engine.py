@@ -534,6 +534,14 @@ class Engine:
         check(self._L.rm_profile_read(self._h, C.byref(n), ms))
         return n.value, {name: ms[i] for i, name in enumerate(self.STAGES)}
 
+    def profile_kernels(self):
+        """-> {kernel name as rocprofv3 prints it: (sampled launches, summed milliseconds of the kernel's own dispatch intervals, stage)}"""
+        from ._lib import KernelTime
+        n = C.c_int32(0)
+        buf = (KernelTime * 64)()
+        check(self._L.rm_profile_kernels(self._h, buf, 64, C.byref(n)))
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms, self.STAGES[buf[i].stage]) for i in range(min(n.value, 64))}
+
     def slot_stats(self, slot=0):
         """(candidate links of the sweep's filter, heard links) of result slot `slot`; synchronises"""
         cand, heard = C.c_uint64(0), C.c_uint64(0)
@@ -551,6 +559,18 @@ class Engine:
         v = C.c_uint64(0)
         check(self._L.rm_air_scan_ticks(self._h, C.byref(v)))
         return v.value
+
+    def air_batch_stats(self):
+        """(batches, ticks) of the SINR extension whose frames outlived their tick and that were swept as batches (rm_airbatch.hip)"""
+        b, t = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.rm_air_batch_stats(self._h, C.byref(b), C.byref(t)))
+        return b.value, t.value
+
+    def air_batch_pairs(self):
+        """(pairs evaluated exactly, frames indexed, pairs that interfered) of the last batch of overlapping SINR ticks; synchronises"""
+        p, f, i = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(self._L.rm_air_batch_pairs(self._h, C.byref(p), C.byref(f), C.byref(i)))
+        return p.value, f.value, i.value
 
     def air_ring_stats(self):
         """(entries allocated in the busiest sub-ring since the lists were last rebuilt, entries a sub-ring holds)"""

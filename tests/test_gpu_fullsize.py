@@ -439,3 +439,55 @@ def test_c3_full_size_batch_of_64_ticks(rsa, O):
             d.free()
     finally:
         eng.close()
+
+
+def test_c5_batches_of_overlapping_ticks_at_one_million_nodes(rsa, O):
+    """BASELINE configs[4] as the bench runs it: 1M nodes, 1000 new frames per tick that stay on the air for 8 more ticks, swept
+    as BATCHES of 32 ticks (rm_airbatch.hip).  WHOLE ticks against the oracle with the full on-air list: in the steady state
+    (9000 frames on the air: 8 ticks of this batch), the first tick of the next batch (its interferers are all frames of the
+    batch before), and -- after a receiver and a transmitter on the air have moved between the batches -- a tick in the middle."""
+    from radio_sim_amd import workload as W
+    from util import DeviceArray
+    n, t, nb = 1_000_000, 1000, 32
+    src_nd = W.make_nodes(n, 5)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = src_nd.x, src_nd.y
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 11}
+    eng = rsa.Engine(0)
+    dev = []
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+        eng.set_link_capacity(1 << 18)          # per result slot: a tick has ~45 k heard links
+        mdl = oracle_model(O, "logdist", params)
+        onair = np.zeros(0, dtype=O.PACKET_DTYPE)
+        checked = {20: "steady state inside a batch", 32: "first tick of the second batch", 45: "after nodes moved between the batches"}
+        for rnd in range(2):
+            if rnd == 1:
+                j = int(onair["src"][-17])       # a transmitter whose frame is on the air, and some receiver
+                r = (j + 12345) % n
+                for node in (j, r):
+                    nd.x[node], nd.y[node] = nd.x[(node + 7) % n] + 2.0, nd.y[(node + 7) % n]
+                    eng.update_node(node, nd.x[node], nd.y[node], nd.z[node], nd.txpower[node], int(nd.channel[node]), 1, 1.0, 1.0)
+            ticks = [W.choose_sources(n, t, 0xC0FFEE05, rnd * nb + b) for b in range(nb)]
+            arrs = [DeviceArray(s) for s in ticks]
+            dev.extend(arrs)
+            starts = [(rnd * nb + b) * 1000 for b in range(nb)]
+            eng.batch_run_sources_device(starts, [s + 1000 for s in starts], [a.ptr.value for a in arrs], [t] * nb, starts, [W.AIR_US] * nb)
+            for b in range(nb):
+                k = rnd * nb + b
+                onair = onair[onair["start_us"] + onair["air_us"] > starts[b]]
+                new = nd.packets(ticks[b], starts[b], W.AIR_US)
+                if k in checked:
+                    assert len(onair) >= 8000, len(onair)
+                    gpu = eng.batch_result_copy(b, t, cap=1 << 20)
+                    cpu = _whole_tick_check(O, mdl, nd, onair, new, gpu, "configs[4] in batches, tick %d: %s" % (k, checked[k]))
+                    assert (cpu.verdict == O.INTERFERED).sum() > 0
+                onair = np.concatenate([onair, new])
+        assert eng.air_batch_stats() == (2, 2 * nb)
+        pairs, frames, interferers = eng.air_batch_pairs()
+        assert frames == 8000 + nb * t and pairs >= interferers > 100 * nb * t
+    finally:
+        for d in dev:
+            d.free()
+        eng.close()

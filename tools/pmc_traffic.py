@@ -1,7 +1,9 @@
 """HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one counter group per
 pass -- TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ticks_per_launch> <out_csv> <out_json> [<sq_dir>]
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ticks_per_launch> <out_csv> <out_json> [<sq_dir> [<tracked_csv>]]
+
+<tracked_csv>: where the CSV will live in the repository (profiles/...): the path the JSON entries cite.
 
 RM_COMMIT=<id> stamps the commit the counters were collected for into the JSON (the GPU box has no .git).
 
@@ -26,13 +28,15 @@ import json
 import os
 import sys
 
-STAGE = (("k_tick_frames", "k_tick_frames"), ("k_frames_cand", "k_filter"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
+STAGE = (("k_ov_pairs", "k_ov_pairs"), ("k_ov_exact", "k_ov_exact"), ("k_ov_verdict", "k_ov_verdict"), ("k_ov_", "k_ov_index"),
+         ("k_sinr_scan", "k_sinr_scan"), ("k_tick_frames", "k_tick_frames"), ("k_frames_cand", "k_filter"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
          ("k_reorder", "k_reorder"), ("k_self_entries", "k_self_entries"), ("k_sinr", "k_sinr"),
          ("k_cell_off", "k_cell_off+k_slot_scan"), ("k_slot_scan", "k_cell_off+k_slot_scan"), ("k_finalize", "k_finalize"))
 
 
 # access pattern of a stage's reads -> calibration entry (profiles/fetch_calibration.json)
-PATTERN = {"k_filter": "stream16", "k_reorder": "runs8", "k_self_entries": "stream4", "k_exact": "gather32", "k_sinr": "gather32",
+PATTERN = {"k_ov_pairs": "gather32", "k_ov_exact": "gather32", "k_ov_verdict": "stream16", "k_ov_index": "stream16", "k_sinr_scan": "gather32",
+           "k_filter": "stream16", "k_reorder": "runs8", "k_self_entries": "stream4", "k_exact": "gather32", "k_sinr": "gather32",
            "k_finalize": "gather32", "k_cell_off+k_slot_scan": "stream4", "k_tick_frames": "stream16"}
 
 
@@ -62,16 +66,21 @@ def read(path, counter):
 def main():
     fetch_dir, write_dir, workload, tpl, out_csv, out_json = sys.argv[1:7]
     sq_dir = sys.argv[7] if len(sys.argv) > 7 else None
+    tracked_csv = sys.argv[8] if len(sys.argv) > 8 else os.path.relpath(out_csv)
     fetch, write = read(fetch_dir, "FETCH_SIZE"), read(write_dir, "WRITE_SIZE")
     valu = read(sq_dir, "SQ_ACTIVE_INST_VALU") if sq_dir else {}
     insts = read(sq_dir, "SQ_INSTS_VALU") if sq_dir else {}
-    valu_stage = collections.defaultdict(lambda: [0.0, 0.0])
+    thr_cyc = read(sq_dir, "SQ_THREAD_CYCLES_VALU") if sq_dir else {}
+    inst_cyc = read(sq_dir, "SQ_INST_CYCLES_VALU") if sq_dir else {}
+    valu_stage = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0.0])
     for k in valu:
         if len(valu[k]) > 8:
             for prefix, stage in STAGE:
                 if k.startswith(prefix):
                     valu_stage[stage][0] += sum(valu[k]) / len(valu[k])
                     valu_stage[stage][1] += sum(insts.get(k, [0])) / max(1, len(insts.get(k, [0])))
+                    valu_stage[stage][2] += sum(thr_cyc.get(k, [0])) / max(1, len(thr_cyc.get(k, [0])))
+                    valu_stage[stage][3] += sum(inst_cyc.get(k, [0])) / max(1, len(inst_cyc.get(k, [0])))
                     break
     rows, stages = [], collections.defaultdict(lambda: [0.0, 0.0])
     for k in sorted(set(fetch) | set(write)):
@@ -102,21 +111,25 @@ def main():
         out = {}
     src = ("%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --inflight 1, %s ticks per "
            "launch), (factor*FETCH_SIZE + WRITE_SIZE)*1024, factor per access pattern from profiles/fetch_calibration.json"
-           % (os.path.relpath(out_csv), tpl))
-    out[workload] = {"ticks_per_launch": int(tpl), "commit": os.environ.get("RM_COMMIT", "unrecorded")}
+           % (tracked_csv, tpl))
+    out[workload] = {"ticks_per_launch": int(tpl), "commit": os.environ.get("RM_COMMIT", "unrecorded"), "csv": tracked_csv}
     for stage, (f, w) in stages.items():
-        if (stage == "k_tick_frames") != (int(tpl) == 1):
-            continue   # the one-launch tick belongs to the ticks_per_launch = 1 passes (the batch runs contain bench.py's sequential leg)
+        if stage in ("k_tick_frames", "k_sinr_scan") and int(tpl) != 1:
+            continue   # the lone tick's kernels belong to the ticks_per_launch = 1 passes (the batch runs contain bench.py's sequential leg)
+        if stage not in ("k_tick_frames", "k_sinr_scan") and int(tpl) == 1 and ("k_tick_frames" in stages) and workload.endswith("_tick"):
+            continue   # ... and the sweep's kernels (set-up launches of a tick run) do not belong to them
         fac, pat, cal_commit = fetch_factor(stage)
         out[workload][stage] = {"hbm_bytes_per_launch": int((fac * f + w) * 1024), "fetch_size_kb_raw": round(f, 1),
                                 "write_size_kb": round(w, 1), "fetch_factor": fac, "fetch_pattern": pat,
                                 "calibration_commit": cal_commit, "source": src}
         if stage == "k_tick_frames":   # streams and gathers in one kernel: the other reading as well
             out[workload][stage]["hbm_bytes_per_launch_min"] = int((f + w) * 1024)
-    for stage, (quad, n_inst) in valu_stage.items():
+    for stage, (quad, n_inst, thr, icyc) in valu_stage.items():
         if stage in out[workload]:
             out[workload][stage]["valu_issue_us_per_launch"] = round(4.0 * quad / 1024.0 / 2400.0, 2)
             out[workload][stage]["valu_instructions_per_launch"] = int(n_inst)
+            if thr > 0 and icyc > 0:   # active lanes per issued vector instruction cycle, of 64
+                out[workload][stage]["valu_lane_utilisation"] = round(thr / (64.0 * icyc), 3)
     json.dump(out, open(out_json, "w"), indent=1)
     print(json.dumps(out[workload], indent=1))
 
