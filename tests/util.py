@@ -90,11 +90,13 @@ class DeviceArray:
     """A device buffer through the HIP runtime the engine itself uses (ctypes; no torch in the process:
     torch wheels carry their own HIP/HSA runtime, and two runtimes in one process do not mix)."""
 
-    def __init__(self, host_array=None, nbytes=None):
+    def __init__(self, host_array=None, nbytes=None, device=None):
         import ctypes as C
         self._C = C
         self._hip = C.CDLL("libamdhip64.so.7")
         self.ptr = C.c_void_p()
+        if device is not None:   # (multi-GPU tests: the buffer belongs to that device)
+            assert self._hip.hipSetDevice(C.c_int(device)) == 0
         n = host_array.nbytes if host_array is not None else nbytes
         assert self._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(n, 1))) == 0
         if host_array is not None:
