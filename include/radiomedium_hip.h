@@ -36,7 +36,7 @@ extern "C" {
 
 /* 4: rm_profile_enable times every kernel by its own dispatch (rm_profile_kernels; RM_STAGE_EMPTY is always 0);
  *    rm_batch_run_sources_device / rm_batch_run_gathered_sources_device / rm_dist_batch_run_sources_device take ticks of
- *    the SINR medium whose frames outlive their tick (rm_air_batch_stats).
+ *    the SINR medium whose frames outlive their tick (rm_air_batch_stats); rm_node_info_changed.
  * 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe) and so is
  *    rm_delivery_view.packet (the packet numbers come once per run of deliveries: n_runs, run_*); rm_air_scan_ticks,
  *    rm_batch_run_gathered_sources_device.
@@ -498,6 +498,12 @@ int rm_events_disable(rm_context *ctx);
 int64_t rm_events_next_packet(rm_context *ctx);
 int rm_events_process(rm_context *ctx, int64_t time_us, rm_delivery_view *out);
 int rm_node_info(rm_context *ctx, const int32_t *nodes, int32_t n, double *rssi, int32_t *receiving, int32_t *channel);
+/* The same, incrementally (ABI version 4): only the nodes whose (rssi, receiving state, channel) differ from what THIS call
+ * reported for them last -- the first call after rm_events_enable or a new node table reports every node.  A time-step
+ * message repeats every node's fields each step (net/JSONClientConnection.java:326-353); a host that keeps the text it sent
+ * last re-serialises only these.  nodes / rssi / receiving / channel take up to cap entries (cap >= the node count), in no
+ * particular order; count gets how many there are. */
+int rm_node_info_changed(rm_context *ctx, int32_t *nodes, double *rssi, int32_t *receiving, int32_t *channel, int32_t cap, int32_t *count);
 
 /* ---- host-side helpers exported for tests ------------------------------------------------- */
 /* java.util.Random LCG: state after `steps` next() calls */

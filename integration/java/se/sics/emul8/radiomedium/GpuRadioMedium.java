@@ -89,6 +89,8 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private static native int nEventsProcess(long ctx, long timeUs, java.nio.ByteBuffer[] views /* run packet, run first, run count, dst, rssi */,
             long[] counts /* deliveries, pending packets, number of the oldest pending packet, runs */);
     private static native int nNodeInfo(long ctx, int[] nodes, double[] rssi, int[] receiving, int[] channel);
+    /* returns the number of nodes whose node-info changed since it was last reported (< 0: error); the arrays take that many */
+    private static native int nNodeInfoChanged(long ctx, int[] nodes, double[] rssi, int[] receiving, int[] channel);
 
     private final Object lock = new Object();
     private final int kind;
@@ -386,6 +388,19 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     public boolean nodeInfo(int[] nodes, double[] rssi, int[] receiving, int[] channel) {
         synchronized (lock) {
             return nNodeInfo(ctx, nodes, rssi, receiving, channel) == 0;
+        }
+    }
+
+    /**
+     * The nodes whose (rssi, receiving state, channel) differ from what this call reported for them last -- every node the
+     * first time.  JSONClientConnection.emulateToTime writes every node's fields into every time-step message; a connection
+     * that keeps the text it sent last rewrites only these.  The arrays must hold one entry per node; returns how many were
+     * filled, or -1.
+     */
+    public int nodeInfoChanged(int[] nodes, double[] rssi, int[] receiving, int[] channel) {
+        synchronized (lock) {
+            if (simulator != null) syncNodes(simulator.getNodes());
+            return nNodeInfoChanged(ctx, nodes, rssi, receiving, channel);
         }
     }
 

@@ -228,6 +228,23 @@ JNIEXPORT jint JFN(nNodeInfo)(JNIEnv *env, jclass cls, jlong ctx, jintArray node
     (*env)->ReleaseIntArrayElements(env, channel, pc, 0);
     return rc;
 }
+
+JNIEXPORT jint JFN(nNodeInfoChanged)(JNIEnv *env, jclass cls, jlong ctx, jintArray nodes, jdoubleArray rssi, jintArray receiving,
+                                     jintArray channel)
+{
+    (void)cls;
+    jsize cap = (*env)->GetArrayLength(env, nodes);
+    jint *pn = (*env)->GetIntArrayElements(env, nodes, NULL);
+    jdouble *pr = (*env)->GetDoubleArrayElements(env, rssi, NULL);
+    jint *px = (*env)->GetIntArrayElements(env, receiving, NULL), *pc = (*env)->GetIntArrayElements(env, channel, NULL);
+    int32_t count = 0;
+    int rc = rm_node_info_changed((rm_context *)(intptr_t)ctx, (int32_t *)pn, pr, (int32_t *)px, (int32_t *)pc, cap, &count);
+    (*env)->ReleaseIntArrayElements(env, nodes, pn, 0);
+    (*env)->ReleaseDoubleArrayElements(env, rssi, pr, 0);
+    (*env)->ReleaseIntArrayElements(env, receiving, px, 0);
+    (*env)->ReleaseIntArrayElements(env, channel, pc, 0);
+    return rc == RM_OK ? count : -1;
+}
 #else
 /* no JDK on this machine: nothing to build (the C ABI is exercised through ctypes and C++ instead) */
 typedef int rm_jni_unavailable;

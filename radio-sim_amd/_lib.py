@@ -211,6 +211,7 @@ SIGNATURES = {
     "rm_events_next_packet": (C.c_int64, [C.c_void_p]),
     "rm_events_process": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rm_node_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rm_node_info_changed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "rm_det_math": (C.c_double, [C.c_int32, C.c_double]),
     "rm_link_hash": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "rm_evq_init": (None, [C.c_void_p]),

@@ -140,6 +140,11 @@ int rm_events_disable(rm_context *c)
     v.d_gtime.release(); v.d_gmeta.release(); v.d_gref.release(); v.d_grank.release(); v.d_cnt.release(); v.d_off.release(); v.d_grun.release(); v.d_run_rec.release();
     v.d_recv_key.release(); v.d_send_key.release(); v.d_receiving.release(); v.d_sending.release(); v.d_latched.release();
     v.d_info_nodes.release();
+    v.d_rep_rssi.release(); v.d_rep_sc.release(); v.d_rep_cnt.release();
+    v.rep_n = 0;
+    if (v.h_changed) (void)hipHostFree(v.h_changed);
+    v.h_changed = nullptr;
+    v.changed_n = 0;
     if (v.h_out) (void)hipHostFree(v.h_out);
     if (v.h_info) (void)hipHostFree(v.h_info);
     v.h_out = v.h_info = nullptr;
@@ -265,6 +270,57 @@ int rm_node_info(rm_context *c, const int32_t *nodes, int32_t n, double *rssi, i
     if (rssi) std::memcpy(rssi, o.rssi, size_t(n) * 8);
     if (receiving) std::memcpy(receiving, o.receiving, size_t(n) * 4);
     if (channel) std::memcpy(channel, o.channel, size_t(n) * 4);
+    return RM_OK;
+}
+
+int rm_node_info_changed(rm_context *c, int32_t *nodes, double *rssi, int32_t *receiving, int32_t *channel, int32_t cap, int32_t *count)
+{
+    if (!c || !count || cap < 0 || (cap > 0 && (!nodes || !rssi || !receiving || !channel))) return fail(RM_ERR_INVALID, "bad arguments");
+    if (!c->ev.on) return fail(RM_ERR_STATE, "rm_events_enable first");
+    *count = 0;
+    const int n = c->n;
+    if (n == 0) return RM_OK;
+    if (cap < n) return fail(RM_ERR_CAPACITY, "room for every node, please: a first call reports them all");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_ensure_nodes(c));
+    rm_context::Events &v = c->ev;
+    if (v.rep_n != n) { // a new table: nothing of it has been reported
+        RM_HIP(v.d_rep_rssi.ensure(size_t(n)));
+        RM_HIP(v.d_rep_sc.ensure(size_t(n)));
+        RM_HIP(v.d_rep_cnt.ensure(2));
+        RM_HIP(hipMemsetAsync(v.d_rep_sc.p, 0xFF, size_t(n) * sizeof(int2), c->stream)); // state -1
+        RM_HIP(hipMemsetAsync(v.d_rep_cnt.p, 0, 2 * sizeof(uint32_t), c->stream));
+        v.rep_n = n;
+    }
+    if (v.changed_n < n) {
+        RM_HIP(hipStreamSynchronize(c->stream));
+        if (v.h_changed) RM_HIP(hipHostFree(v.h_changed));
+        v.h_changed = nullptr;
+        const int want = std::max(n + n / 2, 1024);
+        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&v.h_changed), 64 + pad64(size_t(want) * 8) + 3 * pad64(size_t(want) * 4), hipHostMallocMapped));
+        std::memset(v.h_changed, 0, 64);
+        v.changed_n = want;
+    }
+    rm::NodeChangeOut o{};
+    o.seq = reinterpret_cast<uint32_t *>(v.h_changed);
+    o.count = o.seq + 1;
+    o.rssi = reinterpret_cast<double *>(v.h_changed + 64);
+    o.node = reinterpret_cast<int32_t *>(v.h_changed + 64 + pad64(size_t(v.changed_n) * 8));
+    o.receiving = reinterpret_cast<int32_t *>(v.h_changed + 64 + pad64(size_t(v.changed_n) * 8) + pad64(size_t(v.changed_n) * 4));
+    o.channel = reinterpret_cast<int32_t *>(v.h_changed + 64 + pad64(size_t(v.changed_n) * 8) + 2 * pad64(size_t(v.changed_n) * 4));
+    const uint32_t seq = ++v.changed_seq;
+    RM_HIP(rm::launch_node_info_changed(c->stream, ev_dev(c), nodes_dev(c), n, c->base_rssi, v.d_rep_rssi.p, v.d_rep_sc.p, o, uint32_t(v.changed_n),
+                                        seq, v.d_rep_cnt.p));
+    volatile const uint32_t *flag = o.seq;
+    bool seen = false;
+    for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
+    if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t k = std::min<uint32_t>(*o.count, uint32_t(n));
+    std::memcpy(nodes, o.node, size_t(k) * 4);
+    std::memcpy(rssi, o.rssi, size_t(k) * 8);
+    std::memcpy(receiving, o.receiving, size_t(k) * 4);
+    std::memcpy(channel, o.channel, size_t(k) * 4);
+    *count = int32_t(k);
     return RM_OK;
 }
 

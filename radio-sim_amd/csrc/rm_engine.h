@@ -493,6 +493,12 @@ struct NodeInfoOut {
     double *rssi;
     int32_t *receiving, *channel;
 };
+struct NodeChangeOut { // the nodes whose node-info changed since it was last reported (host-mapped)
+    uint32_t *seq, *count;
+    int32_t *node;
+    double *rssi;
+    int32_t *receiving, *channel;
+};
 
 struct LaunchCfg {
     bool f64_filter;  // fp32 frame too coarse: filter in fp64, no bounding boxes
@@ -585,6 +591,8 @@ hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, 
 hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window);
 hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, const int32_t *dev_nodes, int n, double base_rssi,
                             const NodeInfoOut &out, uint32_t seq);
+hipError_t launch_node_info_changed(hipStream_t s, const EvDev &e, const NodesDev &nd, int n, double base_rssi, double *rep_rssi,
+                                    int2 *rep_sc, const NodeChangeOut &out, uint32_t cap, uint32_t seq, uint32_t *counters);
 
 // host-side mirrors of device math used for constants (rm_math.hpp, exported by rm_transmit.hip)
 double host_det_pow10(double y);

@@ -514,6 +514,63 @@ k_node_info(const EvDev e, const NodesDev nd, const int32_t *__restrict__ nodes,
     }
 }
 
+// The same, incrementally: only the nodes whose fields differ from what was REPORTED for them last (rep_*: a device-resident
+// copy of the last report; state -1 = never reported).  The changed nodes go to the host-mapped block in whatever order the
+// waves find them (one atomic per wave); the workgroup that is done last publishes the count and the sequence number.
+// A time-step message repeats every node's fields whether they changed or not (net/JSONClientConnection.java:326-353): a
+// host that keeps the text it sent last only needs these.
+__global__ void __launch_bounds__(256)
+k_node_info_changed(const EvDev e, const NodesDev nd, int n, double base_rssi, double *rep_rssi, int2 *rep_sc, NodeChangeOut out,
+                    uint32_t cap, uint32_t seq, uint32_t *counters /* [0] done, [1] changed */)
+{
+    __shared__ uint32_t s_last;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) { // (whole waves: they count together)
+        const int i = i0 + int(threadIdx.x);
+        double rssi = base_rssi;
+        int state = 0, ch = 0;
+        bool changed = false;
+        if (i < n) {
+            if (i < e.n_nodes) {
+                const bool rx = e.receiving[i] != 0;
+                if (rx) rssi = e.latched[i];
+                state = !nd.senabled[i] ? 3 : (rx ? 2 : (e.sending[i] ? 1 : 0));
+                ch = nd.schannel[i];
+            }
+            const int2 was = rep_sc[i];
+            changed = was.x != state || was.y != ch || __double_as_longlong(rep_rssi[i]) != __double_as_longlong(rssi);
+        }
+        const uint64_t cm = ballot64(changed);
+        if (cm == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)cm) - 1) base = atomicAdd(&counters[1], uint32_t(__popcll(cm)));
+        base = uint32_t(__shfl(int(base), __ffsll((long long)cm) - 1));
+        if (changed) {
+            const uint32_t k = base + lane_prefix(cm);
+            if (k < cap) { // (always: the host's block holds every node)
+                __hip_atomic_store(&out.node[k], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&out.rssi[k], rssi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&out.receiving[k], state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&out.channel[k], ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                rep_rssi[i] = rssi;
+                rep_sc[i] = make_int2(state, ch);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[0], 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        const uint32_t total = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        counters[0] = 0u;
+        counters[1] = 0u;
+        __hip_atomic_store(out.count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(out.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ============================================================================ launchers
 
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,
@@ -552,6 +609,15 @@ hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, c
     if (n <= 0) return hipSuccess;
     RM_KLAUNCH(k_node_info, dim3(max(1, min(256, cdiv(n, 256)))), dim3(256), 0, s, e, nd, dev_nodes, n, base_rssi, out, seq,
                        &e.st->done_a);
+    return hipGetLastError();
+}
+
+hipError_t launch_node_info_changed(hipStream_t s, const EvDev &e, const NodesDev &nd, int n, double base_rssi, double *rep_rssi,
+                                    int2 *rep_sc, const NodeChangeOut &out, uint32_t cap, uint32_t seq, uint32_t *counters)
+{
+    if (n <= 0) return hipSuccess;
+    RM_KLAUNCH(k_node_info_changed, dim3(max(1, min(256, cdiv(n, 256)))), dim3(256), 0, s, e, nd, n, base_rssi, rep_rssi, rep_sc, out, cap,
+               seq, counters);
     return hipGetLastError();
 }
 

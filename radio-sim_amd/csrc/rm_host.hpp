@@ -192,6 +192,14 @@ struct rm_context : TickSlot {
         int info_n = 0;
         uint32_t seq = 0, info_seq = 0;
         DevBuf<int32_t> d_info_nodes;
+        // rm_node_info_changed: what was reported last per node, the kernel's counters, the host-mapped block of the changes
+        DevBuf<double> d_rep_rssi;
+        DevBuf<int2> d_rep_sc;
+        DevBuf<uint32_t> d_rep_cnt;
+        int rep_n = 0;            // nodes the report arrays hold (all "never reported" when (re)allocated)
+        char *h_changed = nullptr;
+        int changed_n = 0;
+        uint32_t changed_seq = 0;
         int64_t next_packet = 0;  // host mirror of EvTails::gseq_next
         int64_t oldest_packet = 0; // number of the oldest pending packet as the last drain published it (a bound on the ring window)
         int par = 0;              // which EvState::tails are current (flips with every appended tick)

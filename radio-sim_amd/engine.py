@@ -518,6 +518,17 @@ class Engine:
                                    rx.ctypes.data, ch.ctypes.data))
         return rssi, rx, ch
 
+    def node_info_changed(self):
+        """(nodes, rssi, receiving, channel) of the nodes whose node-info differs from what this call reported for them last"""
+        n = max(self.n, 1)
+        nodes = np.empty(n, dtype=np.int32)
+        rssi = np.empty(n, dtype=np.float64)
+        rx = np.empty(n, dtype=np.int32)
+        ch = np.empty(n, dtype=np.int32)
+        k = C.c_int32(0)
+        check(self._L.rm_node_info_changed(self._h, nodes.ctypes.data, rssi.ctypes.data, rx.ctypes.data, ch.ctypes.data, n, C.byref(k)))
+        return nodes[:k.value], rssi[:k.value], rx[:k.value], ch[:k.value]
+
     def sync(self):
         check(self._L.rm_sync(self._h))
 

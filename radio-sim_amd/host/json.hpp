@@ -28,51 +28,81 @@ struct JsonError : std::runtime_error {
 };
 
 // java.lang.Double.toString: shortest digits that identify the double; decimal notation for 1e-3 <= |d| < 1e7,
-// else "d.dddE[-]n"; always at least one digit after the point
+// else "d.dddE[-]n"; always at least one digit after the point.  Written into `dst` (at least 32 bytes), no allocation:
+// the server formats a double per delivery and per changed node -- tens of thousands per step.  Finite d only.
+inline size_t java_double_chars(double d, char *dst)
+{
+    char *o = dst;
+    if (d == 0.0) {
+        if (std::signbit(d)) *o++ = '-';
+        *o++ = '0', *o++ = '.', *o++ = '0';
+        return size_t(o - dst);
+    }
+    const double a = std::fabs(d);
+    char sci[40]; // d[.ddd]e[+-]XX, shortest round-trip digits
+    const auto r = std::to_chars(sci, sci + sizeof(sci), a, std::chars_format::scientific);
+    char digits[24];
+    int nd = 0;
+    const char *p = sci;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    int exp10 = 0;
+    std::from_chars(p + (p + 1 < r.ptr && p[1] == '+' ? 2 : 1), r.ptr, exp10);
+    if (nd == 1) { // Java always writes two digits, the pair closest to the exact value (4.9E-324, not 5.0E-324)
+        char two[40]; // d.de[+-]XX
+        const auto r2 = std::to_chars(two, two + sizeof(two), a, std::chars_format::scientific, 1);
+        digits[0] = two[0];
+        nd = 1;
+        if (two[2] != '0') digits[nd++] = two[2];
+        exp10 = 0;
+        std::from_chars(two + (two[4] == '+' ? 5 : 4), r2.ptr, exp10);
+    }
+    if (std::signbit(d)) *o++ = '-';
+    if (a >= 1e-3 && a < 1e7) {
+        if (exp10 >= 0) {
+            for (int i = 0; i <= exp10; ++i) *o++ = i < nd ? digits[i] : '0';
+            *o++ = '.';
+            if (nd > exp10 + 1)
+                for (int i = exp10 + 1; i < nd; ++i) *o++ = digits[i];
+            else
+                *o++ = '0';
+        } else {
+            *o++ = '0', *o++ = '.';
+            for (int i = 0; i < -exp10 - 1; ++i) *o++ = '0';
+            for (int i = 0; i < nd; ++i) *o++ = digits[i];
+        }
+    } else {
+        *o++ = digits[0];
+        *o++ = '.';
+        if (nd > 1)
+            for (int i = 1; i < nd; ++i) *o++ = digits[i];
+        else
+            *o++ = '0';
+        *o++ = 'E';
+        o = std::to_chars(o, o + 8, exp10).ptr;
+    }
+    return size_t(o - dst);
+}
 inline std::string java_double_to_string(double d)
 {
     if (std::isnan(d)) return "NaN";
     if (std::isinf(d)) return d > 0 ? "Infinity" : "-Infinity";
-    if (d == 0.0) return std::signbit(d) ? "-0.0" : "0.0";
-    char buf[64];
-    const auto r = std::to_chars(buf, buf + sizeof(buf), std::fabs(d), std::chars_format::scientific);
-    std::string sci(buf, r.ptr); // d[.ddd]e[+-]XX, shortest round-trip digits
-    const size_t epos = sci.find('e');
-    std::string digits;
-    for (size_t i = 0; i < epos; ++i)
-        if (sci[i] != '.') digits += sci[i];
-    int exp10 = std::atoi(sci.c_str() + epos + 1);
-    if (digits.size() == 1) { // Java always writes two digits, the pair closest to the exact value (4.9E-324, not 5.0E-324)
-        const auto r2 = std::to_chars(buf, buf + sizeof(buf), std::fabs(d), std::chars_format::scientific, 1);
-        const std::string two(buf, r2.ptr); // d.de[+-]XX
-        digits = std::string(1, two[0]);
-        if (two[2] != '0') digits += two[2];
-        exp10 = std::atoi(two.c_str() + 4);
-    }
-    std::string out = std::signbit(d) ? "-" : "";
-    const double a = std::fabs(d);
-    if (a >= 1e-3 && a < 1e7) {
-        if (exp10 >= 0) {
-            std::string ip = digits.substr(0, std::min(digits.size(), size_t(exp10) + 1));
-            while (ip.size() < size_t(exp10) + 1) ip += '0';
-            std::string fp = digits.size() > size_t(exp10) + 1 ? digits.substr(size_t(exp10) + 1) : "0";
-            out += ip + "." + fp;
-        } else {
-            out += "0." + std::string(size_t(-exp10 - 1), '0') + digits;
-        }
-    } else {
-        out += digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(exp10);
-    }
-    return out;
+    char buf[48];
+    return std::string(buf, java_double_chars(d, buf));
 }
 
 // JsonValue.valueOf(double): cutOffPointZero(Double.toString(value))
+inline size_t json_double_chars(double d, char *dst) // (finite d; dst: at least 32 bytes)
+{
+    size_t n = java_double_chars(d, dst);
+    if (n > 2 && dst[n - 2] == '.' && dst[n - 1] == '0') n -= 2;
+    return n;
+}
 inline std::string json_double_text(double d)
 {
     if (std::isnan(d) || std::isinf(d)) throw JsonError("Infinite and NaN values not permitted in JSON");
-    std::string s = java_double_to_string(d);
-    if (s.size() > 2 && s.compare(s.size() - 2, 2, ".0") == 0) s.erase(s.size() - 2);
-    return s;
+    char buf[48];
+    return std::string(buf, json_double_chars(d, buf));
 }
 
 // writers for messages that are formatted directly (no object tree): the same text as Json::of(v).toString()
@@ -89,7 +119,9 @@ inline void append_double(std::string &out, double d)
         append_int(out, int64_t(d));
         return;
     }
-    out += json_double_text(d);
+    if (std::isnan(d) || std::isinf(d)) throw JsonError("Infinite and NaN values not permitted in JSON");
+    char buf[48];
+    out.append(buf, json_double_chars(d, buf));
 }
 
 class Json {

@@ -490,6 +490,25 @@ public:
         return true;
     }
 
+    // ... and only of the nodes whose fields differ from what this call reported for them last (every node the first time,
+    // and after the node table has changed size): a host that keeps the text of its last time-step message re-serialises these
+    bool nodeInfoChanged(std::vector<int32_t> &nodes, std::vector<double> &rssi, std::vector<int32_t> &receiving, std::vector<int32_t> &channel)
+    {
+        nodes.clear(); rssi.clear(); receiving.clear(); channel.clear();
+        if (!simulator) return true;
+        const size_t n = simulator->getNodes().size();
+        if (!sync(simulator, simulator->getNodes())) return false; // the device mirrors the node table first
+        if (n == 0) return true;
+        nodes.resize(n); rssi.resize(n); receiving.resize(n); channel.resize(n);
+        int32_t count = 0;
+        if (rm_node_info_changed(ctx_, nodes.data(), rssi.data(), receiving.data(), channel.data(), int32_t(n), &count) != RM_OK) {
+            lastError = rm_last_error();
+            return false;
+        }
+        nodes.resize(size_t(count)); rssi.resize(size_t(count)); receiving.resize(size_t(count)); channel.resize(size_t(count));
+        return true;
+    }
+
     // transmit(): never throws (the reference's returns void); failures are reported through lastError
     void transmit(RadioPacket &packet) override
     {

@@ -74,15 +74,21 @@ struct Connection {
     std::string name;
     bool connected = false;
     int64_t emulationTime = 0; // how far this emulator has reached (setTime)
-    // processInput's state
-    bool parsingJson = false, stuffed = false, quoted = false;
-    int brackets = 0;
-    std::string sb;
-    int64_t rawLeft = 0; // bytes of a length-prefixed payload still to read
-    std::string raw;
+    // the framer (Framer below): which of the protocol's three kinds of input the next byte belongs to, and how far into it
+    enum class Input { HeaderLine, JsonText, SizedPayload } input = Input::HeaderLine;
+    bool escaped = false, inString = false; // JsonText: after a backslash / inside a string literal
+    int depth = 0;                          // JsonText: open braces
+    std::string text;                       // bytes of the unit being read
+    int64_t payloadLeft = 0;                // SizedPayload: bytes still to come
     // pending output
     std::string out;
     uint64_t messagesIn = 0, messagesOut = 0;
+    // the node-info array of this emulator's time-step messages as it was sent last: the nodes' objects joined by commas.
+    // A step rewrites only the objects of nodes whose fields changed (in place when the new text is as long as the old).
+    std::vector<int32_t> infoNodes;   // this connection's nodes (node index), in registration order
+    std::string infoBody;
+    std::vector<uint32_t> infoAt;     // infoBody offset of node k's object
+    bool infoStale = true;            // the body has to be put together again from the nodes' texts
 
     bool setTime(int64_t time) // JSONClientConnection.java:361-367
     {
@@ -297,59 +303,75 @@ private:
             s += char(0x80 | (c & 0x3F));
         }
     }
+    // What the wire may carry (net/JSONClientConnection.java:134-255 is the behaviour to match, byte for byte): a JSON object
+    // wherever a '{' turns up -- read to its matching '}', braces inside string literals and escaped characters not counted,
+    // CRs outside literals dropped, bytes taken as Latin-1 --, or a header line "<size>;attributes" followed by exactly
+    // <size> bytes of UTF-8 JSON; a header without a size means "JSON follows"; blank lines and CRs between units are noise.
+    // One unit complete -> one message dispatched.
     void feedByte(Connection &c, unsigned ch)
     {
-        if (c.rawLeft > 0) { // a length-prefixed payload: bytes as they are, UTF-8
-            c.raw += char(ch);
-            if (--c.rawLeft == 0) {
-                std::string text;
-                text.swap(c.raw);
-                dispatch(c, Json::parse_object(text));
+        using Input = Connection::Input;
+        switch (c.input) {
+        case Input::SizedPayload:
+            c.text += char(ch);
+            if (--c.payloadLeft == 0) completeUnit(c);
+            return;
+        case Input::HeaderLine:
+            if (ch == '{') { // an object begins, whatever the line held so far (it stays in front of the text, as in the reference)
+                c.input = Input::JsonText;
+                c.escaped = c.inString = false;
+                break;       // ... and this brace is its first byte
             }
-            return;
-        }
-        if (ch == '{') c.parsingJson = true;
-        if (c.parsingJson) {
-            if (ch == '\r' && !c.stuffed && !c.quoted) return;
-            appendLatin1(c.sb, ch);
-            if (c.stuffed) c.stuffed = false;
-            else if (ch == '\\') c.stuffed = true;
-            else if (c.quoted) {
-                if (ch == '"') c.quoted = false;
-            } else if (ch == '"') c.quoted = true;
-            else if (ch == '{') c.brackets++;
-            else if (ch == '}') {
-                c.brackets--;
-                if (c.brackets == 0) {
-                    std::string text;
-                    text.swap(c.sb);
-                    c.parsingJson = false;
-                    dispatch(c, Json::parse_object(text));
-                }
+            if (ch == '\r') return;
+            if (ch != '\n') {
+                appendLatin1(c.text, ch);
+                return;
             }
+            headerLine(c);
             return;
+        case Input::JsonText:
+            break;
         }
-        if (ch == '\r') return;
-        if (ch != '\n') {
-            appendLatin1(c.sb, ch);
-            return;
+        // JsonText
+        if (ch == '\r' && !c.escaped && !c.inString) return;
+        appendLatin1(c.text, ch);
+        if (c.escaped) {
+            c.escaped = false;
+        } else if (ch == '\\') {
+            c.escaped = true;
+        } else if (c.inString) {
+            c.inString = ch != '"';
+        } else if (ch == '"') {
+            c.inString = true;
+        } else if (ch == '{') {
+            ++c.depth;
+        } else if (ch == '}' && --c.depth == 0) {
+            completeUnit(c);
         }
-        std::string parameters;
-        parameters.swap(c.sb);
-        if (parameters.find_first_not_of(" \t\n\v\f\r") == std::string::npos) return; // trim().length() == 0
-        const std::string first = parameters.substr(0, parameters.find(';'));
-        const int64_t dataSize = parseJavaInt(first);
-        if (dataSize > 20 * 1024 * 1024) throw std::runtime_error("too large payload: " + std::to_string(dataSize));
-        if (dataSize == 0) return;
-        if (dataSize < 0) { // no size: assume JSON and read until its end
-            c.parsingJson = true;
-            c.stuffed = c.quoted = false;
-            c.brackets = 0;
-            return;
+    }
+    void completeUnit(Connection &c)
+    {
+        std::string unit;
+        unit.swap(c.text);
+        c.input = Connection::Input::HeaderLine;
+        dispatch(c, Json::parse_object(unit));
+    }
+    void headerLine(Connection &c)
+    {
+        std::string line;
+        line.swap(c.text);
+        if (line.find_first_not_of(" \t\n\v\f\r") == std::string::npos) return; // nothing but white space
+        const int64_t size = parseJavaInt(line.substr(0, line.find(';')));
+        if (size > 20 * 1024 * 1024) throw std::runtime_error("too large payload: " + std::to_string(size));
+        if (size < 0) { // no size given: JSON text follows, to be read to its closing brace
+            c.input = Connection::Input::JsonText;
+            c.escaped = c.inString = false;
+            c.depth = 0;
+        } else if (size > 0) {
+            c.input = Connection::Input::SizedPayload;
+            c.payloadLeft = size;
+            c.text.reserve(size_t(size));
         }
-        c.rawLeft = dataSize;
-        c.raw.clear();
-        c.raw.reserve(size_t(dataSize));
     }
     static int64_t parseJavaInt(const std::string &s) // Integer.parseInt: sign, digits, nothing else
     {
@@ -439,14 +461,88 @@ private:
         Node *n = sim_.addNode(id);
         nodeConn_.resize(size_t(n->index) + 1, nullptr);
         nodeConn_[size_t(n->index)] = client;
+        noteNode(n, client);
         return n;
+    }
+    // ---- the node-info of a time-step message (net/JSONClientConnection.java:326-353: every node of the connection, every
+    // step).  Writing a hundred thousand objects per step -- a shortest-digits double each -- was 4.3 ms of a step whose
+    // evaluation takes 0.8; but between two steps most nodes' fields are what they were (idle, or still locked on the same
+    // frame).  So every node keeps the text of its object, every connection the joined text it sent last, and a step asks
+    // the device which nodes differ from what was reported last (rm_node_info_changed) and rewrites only those.
+    struct NodeText {
+        std::string quotedId; // the node id as a JSON string
+        std::string head;   // {"node-id":<id>,"rssi":   -- written once
+        std::string text;   // the whole object as it was sent last
+        Connection *conn = nullptr;
+        uint32_t slot = 0;  // place among its connection's nodes
+    };
+    std::vector<NodeText> nodeText_;   // by node index
+    static void writeNodeObject(NodeText &t, const Info &v)
+    {
+        t.text.assign(t.head);
+        append_double(t.text, v.rssi);
+        t.text += ",\"receiving\":";
+        append_int(t.text, v.receiving);
+        t.text += ",\"wireless-channel\":";
+        append_int(t.text, v.channel);
+        t.text += '}';
+    }
+    void noteNode(Node *n, Connection *c) // a node seen for the first time
+    {
+        if (nodeText_.size() <= size_t(n->index)) nodeText_.resize(size_t(n->index) + 1);
+        NodeText &t = nodeText_[size_t(n->index)];
+        t.quotedId.clear();
+        Json::quote(n->getId(), t.quotedId);
+        t.head = "{\"node-id\":";
+        t.head += t.quotedId;
+        t.head += ",\"rssi\":";
+        t.conn = c;
+        t.slot = uint32_t(c->infoNodes.size());
+        c->infoNodes.push_back(n->index);
+        c->infoStale = true;
+        writeNodeObject(t, {n->getRadio().getRSSI(), n->getRadio().getReceivingState(), n->getRadio().getWirelessChannel()});
+    }
+    void applyNodeInfo(int32_t index, const Info &v)
+    {
+        NodeText &t = nodeText_[size_t(index)];
+        const size_t before = t.text.size();
+        writeNodeObject(t, v);
+        Connection &c = *t.conn;
+        if (c.infoStale) return;
+        if (t.text.size() == before) std::memcpy(&c.infoBody[c.infoAt[t.slot]], t.text.data(), before); // same length: in place
+        else c.infoStale = true;
+    }
+    // once per step, before the time-step messages: bring the nodes' texts up to the device's radio state
+    void refreshNodeInfo()
+    {
+        if (medium_) {
+            std::vector<int32_t> idx, recv, chan;
+            std::vector<double> rssi;
+            if (!medium_->nodeInfoChanged(idx, rssi, recv, chan)) {
+                mediumError("node-info");
+                throw std::runtime_error("node-info failed");
+            }
+            for (size_t k = 0; k < idx.size(); ++k)
+                if (size_t(idx[k]) < nodeText_.size() && nodeText_[size_t(idx[k])].conn) applyNodeInfo(idx[k], {rssi[k], recv[k], chan[k]});
+            nodeInfoChanges_ += idx.size();
+        } else { // no medium: nothing ever starts a reception, the host's radios are the state
+            for (Node *n : sim_.getNodes())
+                if (size_t(n->index) < nodeText_.size() && nodeText_[size_t(n->index)].conn)
+                    applyNodeInfo(n->index, {n->getRadio().getRSSI(), n->getRadio().getReceivingState(), n->getRadio().getWirelessChannel()});
+        }
     }
     void emulateToTime(Connection &c, int64_t time, int64_t timeId) // JSONClientConnection.java:326-353
     {
-        std::vector<Node *> mine;
-        for (Node *n : sim_.getNodes())
-            if (connectionOf(n) == &c) mine.push_back(n);
-        const std::vector<Info> info = nodeInfo(mine);
+        if (c.infoStale) { // (a node joined, or an object changed its length: the joined text once more)
+            c.infoBody.clear();
+            c.infoAt.resize(c.infoNodes.size());
+            for (size_t k = 0; k < c.infoNodes.size(); ++k) {
+                if (k) c.infoBody += ',';
+                c.infoAt[k] = uint32_t(c.infoBody.size());
+                c.infoBody += nodeText_[size_t(c.infoNodes[k])].text;
+            }
+            c.infoStale = false;
+        }
         if (!c.open()) return; // send() on a closed connection: nothing goes out
         // {"command":"time-step","id":..,"parameters":{"time":..,"node-info":[{..},..]}} -- written directly: this is
         // the one message whose size grows with the node count
@@ -456,18 +552,7 @@ private:
         o += ",\"parameters\":{\"time\":";
         append_int(o, time);
         o += ",\"node-info\":[";
-        for (size_t i = 0; i < mine.size(); ++i) {
-            if (i) o += ',';
-            o += "{\"node-id\":";
-            Json::quote(mine[i]->getId(), o);
-            o += ",\"rssi\":";
-            append_double(o, info[i].rssi);
-            o += ",\"receiving\":";
-            append_int(o, info[i].receiving);
-            o += ",\"wireless-channel\":";
-            append_int(o, info[i].channel);
-            o += '}';
-        }
+        o += c.infoBody;
         o += "]}}";
         c.sent();
     }
@@ -485,6 +570,7 @@ private:
         emulatorsLeft_ = int(emulators_.size());
         const std::vector<Connection *> em = emulators_;
         const auto t0 = std::chrono::steady_clock::now();
+        refreshNodeInfo();
         for (Connection *e : em) emulateToTime(*e, time, waitingForTimeId_);
         usStepMessages_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -505,6 +591,7 @@ private:
         sim_.emulatorTimeStepDone(stepTime_);
         mediumError("time step");
         const auto t1 = std::chrono::steady_clock::now();
+        framedPacket_ = nullptr;
         for (const emul8::MediumCall &call : sim_.calls)
             if (call.kind == emul8::MediumCall::DELIVER) deliverRadioPacket(*call.packet, *call.destination, call.rssi);
         sim_.calls.clear();
@@ -521,21 +608,28 @@ private:
             VLOG("Node %s has no client connection", dst.getId().c_str());
             return;
         }
-        // RadioPacket.toJsonDestination, written directly (tens of thousands per tick)
+        // RadioPacket.toJsonDestination, written directly (tens of thousands per tick).  The deliveries of one packet come one
+        // after the other, and all but the receiver and its rssi is the packet's: that text is put together once per packet.
+        if (&p != framedPacket_) {
+            framedPacket_ = &p;
+            framedHead_.assign(",\"time-start\":");
+            append_int(framedHead_, p.getStartTime());
+            framedHead_ += ",\"time-end\":";
+            append_int(framedHead_, p.getEndTime());
+            framedHead_ += ",\"rf-power\":";
+            framedTail_.assign(",\"wireless-channel\":");
+            append_int(framedTail_, p.getWirelessChannel());
+            framedTail_ += ",\"packet-data\":";
+            Json::quote(p.getPacketDataAsHex(), framedTail_);
+            framedTail_ += '}';
+        }
         std::string &o = cc->out;
         o += "{\"command\":\"receive\",\"node-id\":";
-        Json::quote(dst.getId(), o);
-        o += ",\"time-start\":";
-        append_int(o, p.getStartTime());
-        o += ",\"time-end\":";
-        append_int(o, p.getEndTime());
-        o += ",\"rf-power\":";
+        if (size_t(dst.index) < nodeText_.size() && !nodeText_[size_t(dst.index)].quotedId.empty()) o += nodeText_[size_t(dst.index)].quotedId;
+        else Json::quote(dst.getId(), o);
+        o += framedHead_;
         append_double(o, rssi);
-        o += ",\"wireless-channel\":";
-        append_int(o, p.getWirelessChannel());
-        o += ",\"packet-data\":";
-        Json::quote(p.getPacketDataAsHex(), o);
-        o += '}';
+        o += framedTail_;
         cc->sent();
         ++deliveries_;
     }
@@ -571,215 +665,234 @@ private:
     }
     static bool isNumber(const Json *v) { return v && v->isNumber(); }
 
+    // ---- one message in, at most one reply out.
+    // A message is either an emulator's answer to a time step ("reply") or a request ("command").  Requests go through a
+    // table: name -> handler, and what the sender is owed afterwards.  A handler answers by itself (Answer::sent), asks for
+    // the protocol's plain acknowledgement ({"id":..,"reply":"OK"}, only if the request carried an id >= 0), or -- time-set --
+    // leaves the answer to the moment the step completes.  The wire behaviour (strings, member order, which malformed input
+    // ends the connection and which gets an error reply) is what net/SimulatorJSONHandler.java:28-274 does; it is pinned by
+    // tests/test_host_server.py and tests/test_gpu_server.py, not by the shape of this code.
+    enum class Answer { ack, sent, later };
+    struct Request {
+        Connection &from;
+        const Json &body;
+        int64_t id; // -1: no reply wanted
+    };
+    using Handler = Answer (RadioLinkServer::*)(const Request &);
+    struct Command {
+        const char *name;
+        Handler run;
+    };
+    static const Command *findCommand(const std::string &name)
+    {
+        static const Command table[] = {
+            {"time-get", &RadioLinkServer::onTimeGet},
+            {"time-set", &RadioLinkServer::onTimeSet},
+            {"transmit", &RadioLinkServer::onTransmit},
+            {"log", &RadioLinkServer::onLog},
+            {"node-config-set", &RadioLinkServer::onNodeConfig},
+            {"link-quality", &RadioLinkServer::onLinkQuality},
+            {"configuration-set", &RadioLinkServer::onConfiguration},
+            {"subscribe-event", &RadioLinkServer::onSubscribe},
+            {"unsubscribe-event", &RadioLinkServer::onUnsubscribe},
+        };
+        for (const Command &c : table)
+            if (name == c.name) return &c;
+        return nullptr;
+    }
+    void refuse(const Request &rq, const std::string &why) { rq.from.send(replyError(rq.id, "command-error", why)); }
+
     void handleMessage(Connection &client, const Json &json)
     {
-        int64_t time = sim_.getTime();
-        if (json.get("reply")) { // getString("reply", null): a non-string member throws
+        if (json.get("reply")) { // an emulator answering a time-step (a non-string "reply" throws: the connection ends)
             const std::string status = json.at("reply").asString();
-            const int64_t id = json.getLong("id", -1);
-            if (status == "OK") {
-                if (id >= 0 && id == waitingForTimeId_) emulatorTimeStepped(client, id);
-            } else {
-                VLOG("%s error reply: %s", client.name.c_str(), json.toString().c_str());
-            }
+            const int64_t step = json.getLong("id", -1);
+            if (status != "OK") VLOG("%s error reply: %s", client.name.c_str(), json.toString().c_str());
+            else if (step >= 0 && step == waitingForTimeId_) emulatorTimeStepped(client, step);
             return;
         }
-        const int64_t id = json.getLong("id", -1);
-        Json reply;
-        bool haveReply = false, noreply = false;
-        const Json *cmd = json.get("command");
-        const std::string command = cmd ? cmd->asString() : std::string();
-        if (!cmd) {
-            reply = replyError(id, "command-error", "no command specified");
-            haveReply = true;
-        } else if (command == "time-get") {
-            if (id >= 0) {
-                reply = replyObject(id).set("reply-object", Json::object().add("time", Json::of(time)));
-                haveReply = true;
-            }
-        } else if (command == "time-set") {
-            if (id < 0) {
-                reply = replyError(id, "command-error", "time-set must include reply id");
-                haveReply = true;
-            } else {
-                if (!timeController_) timeController_ = &client;
-                if (timeController_ == &client) {
-                    try {
-                        time = member(member(json, "parameters").asObject(), "time").asLong();
-                        stepTime(time, id);
-                        noreply = true;
-                    } catch (const MissingMember &) { // a NullPointerException there: getMessage() is null
-                        reply = replyError(id, "command-error", "failed to set time:null");
-                        haveReply = true;
-                    } catch (const std::exception &e) {
-                        reply = replyError(id, "command-error", std::string("failed to set time:") + e.what());
-                        haveReply = true;
-                    }
-                } else {
-                    reply = replyError(id, "command-error", "only one time controller allowed");
-                    haveReply = true;
-                }
-            }
-        } else if (command == "transmit") {
-            const std::string nodeId = member(json, "node-id").toString();
-            const int64_t tTime = member(json, "time").asLong();
-            const std::string packetData = json.getString("packet-data", "");
-            Node *node = sim_.getNode(nodeId);
-            if (!node) {
-                VLOG("non-existing node sending radio packet: %s", nodeId.c_str());
-                reply = replyError(id, "command-error", "could not find source node");
-                haveReply = true;
-            } else if (!medium_) {
-                reply = replyError(id, "command-error", "no radio medium available");
-                haveReply = true;
-            } else {
-                RadioPacket *owned = new RadioPacket(node, tTime, packetData);
-                packets_.emplace(owned, std::unique_ptr<RadioPacket>(owned));
-                RadioPacket &packet = *owned;
-                const Json *value = json.get("rf-power");
-                if (isNumber(value)) packet.setTransmitPower(value->asDouble());
-                value = json.get("wireless-channel");
-                if (isNumber(value)) packet.setWirelessChannel(value->asInt());
-                sim_.notifyRadioListeners(packet);
-                medium_->transmit(packet);
-                mediumError("transmit");
-                ++transmissions_;
-            }
-        } else if (command == "log") {
-            const Json &params = member(json, "parameters").asObject();
-            const std::string nodeId = member(params, "node-id").toString();
-            const std::string logMsg = member(params, "message").asString();
-            Node *node = sim_.getNode(nodeId);
-            if (!node) throw std::runtime_error("log from a node that does not exist: " + nodeId); // node.log on null
-            deliverLogEvent(*node, logMsg);
-        } else if (command == "node-config-set") {
-            const Json &params = member(json, "parameters").asObject();
-            const std::string nodeId = member(params, "node-id").toString();
-            settle(); // what was sent before this message saw the nodes as they were
-            Node *node = addNode(nodeId, &client);
-            const Json *value = params.get("position");
-            if (value && value->isArray()) {
-                const Json &p = *value;
-                // (deviation: Double.parseDouble("1e999") is Infinity and the reference would keep it, leaving the node
-                // unheard; the device-resident table takes finite coordinates only, so such a position is not applied)
-                const double px = p.size() > 1 ? p[0].asDouble() : 0.0, py = p.size() > 1 ? p[1].asDouble() : 0.0;
-                const double pz = p.size() > 2 ? p[2].asDouble() : 0.0;
-                if (!std::isfinite(px) || !std::isfinite(py) || !std::isfinite(pz))
-                    std::fprintf(stderr, "node %s: non-finite position ignored\n", nodeId.c_str());
-                else if (p.size() > 2) node->getPosition().set(px, py, pz);
-                else if (p.size() > 1) node->getPosition().set(px, py);
-            }
-            sim_.nodeChanged(node);
-            value = params.get("rf-power");
-            if (isNumber(value)) node->getRadio().setTransmitPower(value->asDouble());
-            value = params.get("wireless-channel");
-            if (isNumber(value)) node->getRadio().setWirelessChannel(value->asInt());
-            value = params.get("rx-loss");
-            if (isNumber(value)) node->getRadio().setRxProbability(value->asDouble());
-            value = params.get("tx-loss");
-            if (isNumber(value)) node->getRadio().setTxProbability(value->asDouble());
-            value = params.get("radio-state");
-            if (value && value->isString()) node->getRadio().setEnabled(value->asString() != "disabled");
-            if (id >= 0) {
-                const std::vector<Info> info = nodeInfo({node});
-                Json nodeInfo = Json::object();
-                nodeInfo.add("node-id", Json::of(nodeId));
-                nodeInfo.add("rssi", Json::of(info[0].rssi));
-                nodeInfo.add("receiving", Json::of(info[0].receiving));
-                nodeInfo.add("wireless-channel", Json::of(info[0].channel));
-                reply = replyObject(id).set("reply-object", Json::object().add("node-info", nodeInfo));
-                haveReply = true;
-            }
-        } else if (command == "link-quality") {
-            const Json &link = member(json, "link").asObject();
-            (void)member(link, "src").toString();
-            (void)member(link, "dst").toString();
-            const Json *value = json.get("wireless-channel");
-            if (isNumber(value)) (void)value->asInt();
-            value = link.get("quality");
-            if (isNumber(value)) (void)value->asInt(); // "TODO update radio medium" in the reference: parsed, not used
-        } else if (command == "configuration-set") {
-            if (timeController_) {
-                reply = replyError(id, "command-error", "already initialized");
-                haveReply = true;
-            } else {
-                const Json &params = member(json, "parameters").asObject();
-                const Json *value = params.get("propagation-option");
-                if (value) {
-                    const std::string option = value->asString();
-                    if (option == "n2n-link") {
-                        const Json *matrix = params.get("matrix-data");
-                        const Json *numberOfNodes = params.get("number-of-nodes");
-                        if (!matrix || !matrix->isArray() || matrix->size() == 0) {
-                            reply = replyError(id, "command-error", "no matrix specified");
-                            haveReply = true;
-                        } else if (member(params, "number-of-nodes").asInt() != int(std::sqrt(double(matrix->size())))) {
-                            reply = replyError(id, "command-error", "inconsistent data matrix or nodes");
-                            haveReply = true;
-                        } else {
-                            const int n = numberOfNodes->asInt();
-                            std::vector<std::vector<double>> m;
-                            m.assign(size_t(n), std::vector<double>(size_t(n), 0.0));
-                            for (int i = 0; i < n; ++i)
-                                for (int j = 0; j < n; ++j) m[size_t(i)][size_t(j)] = (*matrix)[size_t(j + i * n)].asDouble();
-                            if (!opt_.noMedium) setMedium(new emul8::N2NRadioMedium(m, opt_.device));
-                        }
-                    } else if (option == "udgm") {
-                        if (!opt_.noMedium) setMedium(new emul8::UDGMRadioMedium(opt_.device));
-                    } else if (option == "udgm-constant-loss") { // (not wired to the protocol in the reference: its class exists)
-                        if (!opt_.noMedium) setMedium(new emul8::UDGMConstantLossRadioMedium(opt_.device));
-                    } else if (option == "log-distance") {
-                        // the engine's extension medium: the only additions to the wire are this
-                        // option string and its optional numeric parameters
-                        rm_model_params p;
-                        rm_model_defaults(&p, RM_MODEL_LOGDIST);
-                        auto num = [&](const char *name, double &field) {
-                            const Json *v = params.get(name);
-                            if (isNumber(v)) field = v->asDouble();
-                        };
-                        num("reference-loss-db", p.ld_pl0_db);
-                        num("path-loss-exponent", p.ld_exponent);
-                        num("reference-distance", p.ld_d0);
-                        num("shadowing-sigma-db", p.ld_sigma_db);
-                        num("shadowing-clip", p.ld_clip);
-                        num("sensitivity-dbm", p.ld_sensitivity_dbm);
-                        num("noise-dbm", p.ld_noise_dbm);
-                        num("capture-db", p.ld_capture_db);
-                        num("interference-floor-dbm", p.ld_ifloor_dbm);
-                        if (const Json *v = params.get("shadowing-seed"); isNumber(v)) p.ld_seed = uint64_t(v->asLong());
-                        if (const Json *v = params.get("sinr"); v && v->type() == Json::BOOL && v->toString() == "true") p.flags |= RM_LD_SINR;
-                        if (!opt_.noMedium) {
-                            std::unique_ptr<emul8::LogDistanceRadioMedium> m(new emul8::LogDistanceRadioMedium(opt_.device));
-                            m->params() = p;
-                            try {
-                                m->apply();
-                                setMedium(m.release());
-                            } catch (const std::exception &e) {
-                                reply = replyError(id, "command-error", std::string("log-distance: ") + e.what());
-                                haveReply = true;
-                            }
-                        }
-                    } else if (option == "nullrm") {
-                        // the null radio medium is the default
-                    } else {
-                        std::fprintf(stderr, "Unsupported propagation-option: %s - reverting to null radio medium\n", option.c_str());
-                    }
-                }
-            }
-        } else if (command == "subscribe-event") {
-            eventListeners_.push_back(&client); // ArrayUtils.add: appended, duplicates allowed
-        } else if (command == "unsubscribe-event") {
-            auto it = std::find(eventListeners_.begin(), eventListeners_.end(), &client); // ArrayUtils.remove: the first one
-            if (it != eventListeners_.end()) eventListeners_.erase(it);
+        const Request rq{client, json, json.getLong("id", -1)};
+        const Json *name = json.get("command");
+        if (!name) return refuse(rq, "no command specified");
+        const std::string word = name->asString();
+        const Command *cmd = findCommand(word);
+        if (!cmd) return refuse(rq, "unsupported command: " + word);
+        if ((this->*cmd->run)(rq) == Answer::ack && rq.id >= 0) client.send(replyObject(rq.id));
+    }
+
+    Answer onTimeGet(const Request &rq)
+    {
+        if (rq.id < 0) return Answer::sent; // nobody asked
+        rq.from.send(replyObject(rq.id).set("reply-object", Json::object().add("time", Json::of(sim_.getTime()))));
+        return Answer::sent;
+    }
+    // the first connection to set the time is the time controller from then on; its reply comes when every emulator has stepped
+    Answer onTimeSet(const Request &rq)
+    {
+        if (rq.id < 0) return refuse(rq, "time-set must include reply id"), Answer::sent;
+        if (!timeController_) timeController_ = &rq.from;
+        if (timeController_ != &rq.from) return refuse(rq, "only one time controller allowed"), Answer::sent;
+        try {
+            stepTime(member(member(rq.body, "parameters").asObject(), "time").asLong(), rq.id);
+            return Answer::later;
+        } catch (const MissingMember &) { // (the reference reports a NullPointerException's null message here)
+            refuse(rq, "failed to set time:null");
+        } catch (const std::exception &e) {
+            refuse(rq, std::string("failed to set time:") + e.what());
+        }
+        return Answer::sent;
+    }
+    Answer onTransmit(const Request &rq)
+    {
+        const std::string who = member(rq.body, "node-id").toString();
+        const int64_t when = member(rq.body, "time").asLong();
+        const std::string payloadHex = rq.body.getString("packet-data", "");
+        Node *sender = sim_.getNode(who);
+        if (!sender) {
+            VLOG("non-existing node sending radio packet: %s", who.c_str());
+            return refuse(rq, "could not find source node"), Answer::sent;
+        }
+        if (!medium_) return refuse(rq, "no radio medium available"), Answer::sent;
+        RadioPacket *frame = new RadioPacket(sender, when, payloadHex);
+        packets_.emplace(frame, std::unique_ptr<RadioPacket>(frame));
+        if (const Json *v = rq.body.get("rf-power"); isNumber(v)) frame->setTransmitPower(v->asDouble());
+        if (const Json *v = rq.body.get("wireless-channel"); isNumber(v)) frame->setWirelessChannel(v->asInt());
+        sim_.notifyRadioListeners(*frame);
+        medium_->transmit(*frame);
+        mediumError("transmit");
+        ++transmissions_;
+        return Answer::ack;
+    }
+    Answer onLog(const Request &rq)
+    {
+        const Json &args = member(rq.body, "parameters").asObject();
+        const std::string who = member(args, "node-id").toString();
+        const std::string text = member(args, "message").asString();
+        Node *source = sim_.getNode(who);
+        if (!source) throw std::runtime_error("log from a node that does not exist: " + who); // (ends the connection, as the reference's null dereference does)
+        deliverLogEvent(*source, text);
+        return Answer::ack;
+    }
+    // creates the node on first sight; every attribute is optional and applied only if it has the right JSON type
+    Answer onNodeConfig(const Request &rq)
+    {
+        const Json &args = member(rq.body, "parameters").asObject();
+        const std::string who = member(args, "node-id").toString();
+        settle(); // what was sent before this message saw the nodes as they were
+        Node *node = addNode(who, &rq.from);
+        if (const Json *at = args.get("position"); at && at->isArray() && at->size() > 1) {
+            // (deviation: Double.parseDouble("1e999") is Infinity and the reference would keep it, leaving the node unheard;
+            // the device-resident table takes finite coordinates only, so such a position is not applied)
+            const double px = (*at)[0].asDouble(), py = (*at)[1].asDouble(), pz = at->size() > 2 ? (*at)[2].asDouble() : 0.0;
+            if (!std::isfinite(px) || !std::isfinite(py) || !std::isfinite(pz)) std::fprintf(stderr, "node %s: non-finite position ignored\n", who.c_str());
+            else if (at->size() > 2) node->getPosition().set(px, py, pz);
+            else node->getPosition().set(px, py);
+        }
+        sim_.nodeChanged(node);
+        emul8::Transciever &radio = node->getRadio();
+        struct {
+            const char *key;
+            void (*apply)(emul8::Transciever &, const Json &);
+        } static const numeric[] = {
+            {"rf-power", [](emul8::Transciever &r, const Json &v) { r.setTransmitPower(v.asDouble()); }},
+            {"wireless-channel", [](emul8::Transciever &r, const Json &v) { r.setWirelessChannel(v.asInt()); }},
+            {"rx-loss", [](emul8::Transciever &r, const Json &v) { r.setRxProbability(v.asDouble()); }},
+            {"tx-loss", [](emul8::Transciever &r, const Json &v) { r.setTxProbability(v.asDouble()); }},
+        };
+        for (const auto &attr : numeric)
+            if (const Json *v = args.get(attr.key); isNumber(v)) attr.apply(radio, *v);
+        if (const Json *v = args.get("radio-state"); v && v->isString()) radio.setEnabled(v->asString() != "disabled");
+        if (rq.id < 0) return Answer::sent;
+        const Info now = nodeInfo({node})[0];
+        Json described = Json::object();
+        described.add("node-id", Json::of(who)).add("rssi", Json::of(now.rssi)).add("receiving", Json::of(now.receiving));
+        described.add("wireless-channel", Json::of(now.channel));
+        rq.from.send(replyObject(rq.id).set("reply-object", Json::object().add("node-info", described)));
+        return Answer::sent;
+    }
+    // parsed for its types (a malformed one ends the connection), then dropped: the reference never applies link qualities
+    Answer onLinkQuality(const Request &rq)
+    {
+        const Json &link = member(rq.body, "link").asObject();
+        (void)member(link, "src").toString();
+        (void)member(link, "dst").toString();
+        if (const Json *v = rq.body.get("wireless-channel"); isNumber(v)) (void)v->asInt();
+        if (const Json *v = link.get("quality"); isNumber(v)) (void)v->asInt();
+        return Answer::ack;
+    }
+    // the medium is chosen by "propagation-option", before the first time-set only
+    Answer onConfiguration(const Request &rq)
+    {
+        if (timeController_) return refuse(rq, "already initialized"), Answer::sent;
+        const Json &args = member(rq.body, "parameters").asObject();
+        const Json *chosen = args.get("propagation-option");
+        if (!chosen) return Answer::ack;
+        const std::string option = chosen->asString();
+        if (option == "nullrm") return Answer::ack; // the default medium
+        if (option == "n2n-link") return configureMatrix(rq, args);
+        if (option == "log-distance") return configureLogDistance(rq, args);
+        if (option == "udgm") {
+            if (!opt_.noMedium) setMedium(new emul8::UDGMRadioMedium(opt_.device));
+        } else if (option == "udgm-constant-loss") { // (the reference has the class but no option for it)
+            if (!opt_.noMedium) setMedium(new emul8::UDGMConstantLossRadioMedium(opt_.device));
         } else {
-            reply = replyError(id, "command-error", "unsupported command: " + command);
-            haveReply = true;
+            std::fprintf(stderr, "Unsupported propagation-option: %s - reverting to null radio medium\n", option.c_str());
         }
-        if (!haveReply && id >= 0 && !noreply) {
-            reply = replyObject(id);
-            haveReply = true;
+        return Answer::ack;
+    }
+    Answer configureMatrix(const Request &rq, const Json &args)
+    {
+        const Json *cells = args.get("matrix-data");
+        if (!cells || !cells->isArray() || cells->size() == 0) return refuse(rq, "no matrix specified"), Answer::sent;
+        const int n = member(args, "number-of-nodes").asInt();
+        if (n != int(std::sqrt(double(cells->size())))) return refuse(rq, "inconsistent data matrix or nodes"), Answer::sent;
+        std::vector<std::vector<double>> rows(size_t(n), std::vector<double>(size_t(n), 0.0));
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) rows[size_t(i)][size_t(j)] = (*cells)[size_t(i * n + j)].asDouble();
+        if (!opt_.noMedium) setMedium(new emul8::N2NRadioMedium(rows, opt_.device));
+        return Answer::ack;
+    }
+    // the engine's extension medium: the only additions to the wire are this option string and its
+    // optional numeric parameters
+    Answer configureLogDistance(const Request &rq, const Json &args)
+    {
+        rm_model_params p;
+        rm_model_defaults(&p, RM_MODEL_LOGDIST);
+        struct {
+            const char *key;
+            double rm_model_params::*field;
+        } static const knobs[] = {
+            {"reference-loss-db", &rm_model_params::ld_pl0_db},     {"path-loss-exponent", &rm_model_params::ld_exponent},
+            {"reference-distance", &rm_model_params::ld_d0},         {"shadowing-sigma-db", &rm_model_params::ld_sigma_db},
+            {"shadowing-clip", &rm_model_params::ld_clip},           {"sensitivity-dbm", &rm_model_params::ld_sensitivity_dbm},
+            {"noise-dbm", &rm_model_params::ld_noise_dbm},           {"capture-db", &rm_model_params::ld_capture_db},
+            {"interference-floor-dbm", &rm_model_params::ld_ifloor_dbm},
+        };
+        for (const auto &k : knobs)
+            if (const Json *v = args.get(k.key); isNumber(v)) p.*(k.field) = v->asDouble();
+        if (const Json *v = args.get("shadowing-seed"); isNumber(v)) p.ld_seed = uint64_t(v->asLong());
+        if (const Json *v = args.get("sinr"); v && v->type() == Json::BOOL && v->toString() == "true") p.flags |= RM_LD_SINR;
+        if (opt_.noMedium) return Answer::ack;
+        std::unique_ptr<emul8::LogDistanceRadioMedium> m(new emul8::LogDistanceRadioMedium(opt_.device));
+        m->params() = p;
+        try {
+            m->apply();
+        } catch (const std::exception &e) {
+            return refuse(rq, std::string("log-distance: ") + e.what()), Answer::sent;
         }
-        if (haveReply) client.send(reply);
+        setMedium(m.release());
+        return Answer::ack;
+    }
+    Answer onSubscribe(const Request &rq)
+    {
+        eventListeners_.push_back(&rq.from); // (a second subscription means a second copy of every event, as in the reference)
+        return Answer::ack;
+    }
+    Answer onUnsubscribe(const Request &rq)
+    {
+        auto it = std::find(eventListeners_.begin(), eventListeners_.end(), &rq.from); // one subscription per request
+        if (it != eventListeners_.end()) eventListeners_.erase(it);
+        return Answer::ack;
     }
     struct MissingMember : JsonError {
         explicit MissingMember(const std::string &n) : JsonError("missing member \"" + n + "\"") {}
@@ -809,10 +922,10 @@ public:
     {
         const double k = steps_ ? 1.0 / double(steps_) : 0.0;
         std::fprintf(stderr,
-                     "rsim_server: %llu steps, %llu transmissions, %llu deliveries, time %lld; per step: time-step messages %.1f us, "
-                     "medium (tick + drain, deliveries on the host) %.1f us, receive messages %.1f us\n",
+                     "rsim_server: %llu steps, %llu transmissions, %llu deliveries, time %lld; per step: time-step messages %.1f us "
+                     "(%.1f node objects rewritten), medium (tick + drain, deliveries on the host) %.1f us, receive messages %.1f us\n",
                      (unsigned long long)steps_, (unsigned long long)transmissions_, (unsigned long long)deliveries_,
-                     (long long)sim_.getTime(), usStepMessages_ * k, usMedium_ * k, usReceiveMessages_ * k);
+                     (long long)sim_.getTime(), usStepMessages_ * k, double(nodeInfoChanges_) * k, usMedium_ * k, usReceiveMessages_ * k);
     }
 
 private:
@@ -833,6 +946,9 @@ private:
     int64_t stepTime_ = 0, timeControllerLastTimeId_ = -1, waitingForTimeId_ = -1, messageId_ = 1000;
     uint64_t steps_ = 0, transmissions_ = 0, deliveries_ = 0;
     double usStepMessages_ = 0, usMedium_ = 0, usReceiveMessages_ = 0; // the server's own work per step (printStats)
+    const RadioPacket *framedPacket_ = nullptr; // deliverRadioPacket: the packet whose constant text is in framedHead_ / framedTail_
+    std::string framedHead_, framedTail_;
+    uint64_t nodeInfoChanges_ = 0;     // node objects rewritten for time-step messages (the rest went out as they were)
 };
 
 } // namespace rsim

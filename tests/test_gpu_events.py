@@ -11,6 +11,17 @@ from util import DeviceArray, KINDS, configure_engine, oracle_model, random_node
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fresh_reports(rsa, monkeypatch):
+    """rm_events_enable begins a new session: the engine has reported nothing of it yet (check_drain's shadow of the reports)"""
+    orig = rsa.Engine.events_enable
+
+    def enable(self, *a, **kw):
+        self._reported = None
+        return orig(self, *a, **kw)
+    monkeypatch.setattr(rsa.Engine, "events_enable", enable)
+
+
 def oracle_deliveries(O, ev):
     d = ev[ev["kind"] == O.EV_RX_END_DELIVERY]
     return d["pkt"].astype(np.int64), d["node"].astype(np.int32), d["rssi"].astype(np.float64)
@@ -37,6 +48,22 @@ def check_drain(O, eng, sim, t, nodes, what, immediate=(), own=None):
     np.testing.assert_array_equal(got_state[sel], want_state[sel], err_msg=what + " receiving state")
     np.testing.assert_array_equal(got_rssi[sel], want_rssi[sel], err_msg=what + " rssi of node-info")
     np.testing.assert_array_equal(got_ch, nodes.channel, err_msg=what + " channel")
+    # ... and incrementally (rm_node_info_changed): the nodes reported since the last call, applied to what was reported before,
+    # give the same table; the first call reports every node, later ones only nodes whose fields really differ
+    cn, cr, cs, cc = eng.node_info_changed()
+    shadow = getattr(eng, "_reported", None)
+    if shadow is None or len(shadow[0]) != len(got_rssi):
+        assert sorted(cn.tolist()) == list(range(len(got_rssi))), what + ": a first report names every node once"
+        shadow = [np.zeros(len(got_rssi)), np.zeros(len(got_rssi), dtype=np.int32), np.zeros(len(got_rssi), dtype=np.int32)]
+    else:
+        assert len(set(cn.tolist())) == len(cn), what + ": a node reported twice"
+        same = (shadow[0][cn].view(np.int64) == cr.view(np.int64)) & (shadow[1][cn] == cs) & (shadow[2][cn] == cc)
+        assert not same.any(), what + ": reported without a change"
+    shadow[0][cn], shadow[1][cn], shadow[2][cn] = cr, cs, cc
+    eng._reported = shadow
+    np.testing.assert_array_equal(shadow[0].view(np.int64), got_rssi.view(np.int64), err_msg=what + " incremental rssi")
+    np.testing.assert_array_equal(shadow[1], got_state, err_msg=what + " incremental state")
+    np.testing.assert_array_equal(shadow[2], got_ch, err_msg=what + " incremental channel")
     return len(pkt)
 
 
