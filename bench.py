@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=-1, help="untimed steps before them; default: 192 ticks' worth")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-only", action="store_true", help="only the dense layouts (nothing to cull: unit disc over the whole field, "
+                                                              "the reference's default Null medium), as the result line")
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
     ap.add_argument("--inflight", type=int, default=0,
                     help="engine contexts per GPU, each with its own stream, taking the batches in turn (ticks are "
@@ -122,7 +124,7 @@ def parse():
 
 # a kernel (base name as rocprofv3 prints it) -> the stage whose algorithmic bytes price it, and its key in
 # profiles/pmc_traffic.json (tools/pmc_traffic.py groups the counters the same way)
-KERNEL_STAGE = (("k_tick_frames_scan", "tick"), ("k_tick_frames", "tick"), ("k_sinr_scan", "sinr_scan"), ("k_ov_pairs", "ov_pairs"),
+KERNEL_STAGE = (("k_dense_write", "dense"), ("k_dense_count", "dense_count"), ("k_tick_frames_scan", "tick"), ("k_tick_frames", "tick"), ("k_sinr_scan", "sinr_scan"), ("k_ov_pairs", "ov_pairs"),
                 ("k_ov_exact", "ov_exact"), ("k_ov_verdict", "ov_verdict"), ("k_filter", "filter"),
                 ("k_frames_cand", "filter"), ("k_exact", "exact"), ("k_reorder", "reorder"), ("k_sinr", "sinr"),
                 ("k_self_entries", "sinr"))
@@ -169,7 +171,10 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
            "tick": b_launch,
            "ov_pairs": (heard * 49 + t_per_tick * 64 * 48) * ticks_per_launch + pairs_per_launch * 16,
            "ov_exact": pairs_per_launch * (16 + 32 + 64 + 16),
-           "ov_verdict": heard * 34 * ticks_per_launch}
+           "ov_verdict": heard * 34 * ticks_per_launch,
+           # the dense tick (rm_dense.hip): both passes read the node-ordered columns (N*37 at most, L2-resident after the first
+           # frame), the second writes the records: it is priced with the whole of 8(d)'s bytes of its tick
+           "dense": b_launch, "dense_count": n_loc * S_NODE + t_per_tick * S_TX}
     per_kernel = {}
     for name, k in kernels.items():
         if k["launches"] == 0:
@@ -460,36 +465,52 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
     return out
 
 
-def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=12):
-    """A layout the spatial cull cannot help: 20k nodes inside one transmission range (the reference UDGM medium with
-    range >= the square's diagonal), every frame heard by every node -- the rate when ALL T x (N-1) links are
-    evaluated exactly and 4 M records per tick are ordered and written.  One tick at a time."""
+def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
+    """Layouts the spatial cull cannot help: 20k nodes, 200 frames per tick, every frame heard by every node -- the reference
+    UDGM medium with a range beyond the square's diagonal, and the reference's DEFAULT medium (NullRadioMedium.java:47-77:
+    every same-channel node hears everything).  4 M heard links per tick are evaluated in node order, compacted and written
+    (rm_dense.hip); one tick at a time.  The roofline is the record-writing one: SURVEY.md 8(d)'s bytes of the tick
+    (N*37 + T*56 + H*25) over the kernels' own time."""
+    out = {}
     nodes = W.make_nodes(n, 3)
     side = W.side_length(n)
-    e = rsa.Engine(device_ordinal)
-    st = torch.cuda.Stream(device=dev)
-    e.set_stream(st.cuda_stream)
-    e.upload_table(nodes)
-    e.set_model(rsa.MODEL_UDGM, udgm_transmission_range=float(side * 1.5))
-    e.set_link_capacity(1 << 24)
-    srcs = [W.choose_sources(n, t, 0xC0FFEE0D, k) for k in range(4)]
-    with torch.cuda.stream(st):
-        src_dev = torch.from_numpy(np.stack(srcs)).to(dev)
-        st.synchronize()
-        for k in range(2):
-            e.tick_run_sources_device(k * 1000, k * 1000 + 1000, src_dev[k % 4].data_ptr(), t, k * 1000, W.AIR_US)
-        heard, dropped = e.result_count()
-        st.synchronize()
-        t0 = time.perf_counter()
-        for k in range(ticks):
-            e.tick_run_sources_device(k * 1000, k * 1000 + 1000, src_dev[k % 4].data_ptr(), t, k * 1000, W.AIR_US)
-        heard, dropped = e.result_count()       # includes ordering the last tick's records into the compact arrays
-        st.synchronize()
-        el = time.perf_counter() - t0
-    e.close()
-    return {"workload": "20k nodes, 200 frames per tick, reference UDGM with everyone in range (nothing to cull)", "nodes": n,
-            "tx_per_tick": t, "heard_links_per_tick": int(heard), "ms_per_tick": el / ticks * 1e3,
-            "value": t * (n - 1) / (el / ticks), "unit": "links/s", "dropped": bool(dropped)}
+    for name, kind, kw in (("udgm_everyone_in_range", rsa.MODEL_UDGM, dict(udgm_transmission_range=float(side * 1.5))),
+                           ("null_medium", rsa.MODEL_NULL, {})):
+        e = rsa.Engine(device_ordinal)
+        st = torch.cuda.Stream(device=dev)
+        e.set_stream(st.cuda_stream)
+        e.upload_table(nodes)
+        e.set_model(kind, **kw)
+        e.set_link_capacity(1 << 24)
+        srcs = [W.choose_sources(n, t, 0xC0FFEE0D, k) for k in range(4)]
+        with torch.cuda.stream(st):
+            src_dev = torch.from_numpy(np.stack(srcs)).to(dev)
+            st.synchronize()
+            calls = [e.prepared("rm_tick_run_sources_device", k * 1000, k * 1000 + 1000, ctypes.c_void_p(src_dev[k % 4].data_ptr()), t, k * 1000,
+                                W.AIR_US) for k in range(ticks)]   # (the arguments converted once: the loop times the engine, not the binding)
+            for k in range(3):
+                calls[k]()
+            heard, dropped = e.result_count()
+            st.synchronize()
+            e.profile_enable(4)
+            t0 = time.perf_counter()
+            for call in calls:
+                call()
+            st.synchronize()
+            el = time.perf_counter() - t0
+            heard, dropped = e.result_count()
+        n_samples, _ = e.profile_read()
+        kernels = {nm: {"launches": l, "ms": ms, "stage": sg} for nm, (l, ms, sg) in e.profile_kernels().items()}
+        e.profile_enable(0)
+        e.close()
+        per_tick = el / ticks
+        rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t, heard=heard, cand=0, ticks_per_launch=1,
+                             step_s=per_tick, contexts=1, workload="dense_" + name)
+        out[name] = {"workload": "20k nodes, 200 frames per tick, every frame heard by every node (nothing to cull): " + name, "nodes": n,
+                     "tx_per_tick": t, "heard_links_per_tick": int(heard), "ms_per_tick": per_tick * 1e3,
+                     "value": t * (n - 1) / per_tick, "unit": "links/s", "record_bytes_per_s": heard * S_REC / per_tick,
+                     "roofline": rl, "dropped": bool(dropped)}
+    return out
 
 
 def spawn_ranks(args):
@@ -590,6 +611,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.dense_only:
+        d = dense_probe(rsa, W, torch, dev, device_ordinal)
+        lead = d["null_medium"]
+        out = {"metric": baseline_metric(), "value": lead["value"], "unit": "links/s", "n_gpus": 1, "steps": 24, "warmup": 3,
+               "ms_per_step": lead["ms_per_tick"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": {"workload": lead["workload"], "nodes": lead["nodes"], "tx_per_tick": lead["tx_per_tick"]},
+               "roofline": lead["roofline"], "dense_layout": d}
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        return
 
     def measure(args):
         """one configuration through the whole bench; rank 0 gets the result line's dictionary"""

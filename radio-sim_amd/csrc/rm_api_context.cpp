@@ -162,6 +162,7 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.sz = c->d_z.p;
     nd.stxpower = c->d_txpower.p;
     nd.stxprob = c->d_txprob.p;
+    nd.srxprob = c->d_rxprob_node.p;
     nd.schannel = c->d_channel.p;
     nd.sint_id = c->d_int_id.p;
     nd.senabled = c->d_enabled.p;
@@ -295,7 +296,7 @@ void rm_destroy(rm_context *c)
             (void)hipEventDestroy(k.a);
             (void)hipEventDestroy(k.b);
         }
-    c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release();
+    c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release(); c->d_rxprob_node.release();
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rx_rec32.release(); c->d_rxf.release(); c->d_bbox_xy.release();

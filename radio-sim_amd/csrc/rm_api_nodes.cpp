@@ -333,6 +333,7 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     RM_TRY(upload(c->d_z, c->z, c->stream));
     RM_TRY(upload(c->d_txpower, c->txpower, c->stream));
     RM_TRY(upload(c->d_txprob, c->txprob, c->stream));
+    RM_TRY(upload(c->d_rxprob_node, c->rxprob, c->stream));
     RM_TRY(upload(c->d_channel, c->channel, c->stream));
     RM_TRY(upload(c->d_int_id, c->int_id, c->stream));
     RM_TRY(upload(c->d_enabled, c->enabled, c->stream));

@@ -404,6 +404,22 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         sample_stage(smp, id);
         return RM_OK;
     };
+    if (!sinr && rm::dense_tick_applies(t, cfg, m, nd, !part_spatial(c))) {
+        // a medium in which a frame is heard by a large share of the nodes (the reference's default Null medium, a lossless
+        // matrix, a range over most of the field): node-order evaluation and ordered compaction, rm_dense.hip
+        const size_t cells = size_t(rm::dense_tick_cells(nd, t));
+        RM_HIP(ts.d_cnt.ensure(std::max<size_t>(cells, 1)));
+        RM_HIP(ts.d_off.ensure(std::max<size_t>(cells, 1)));
+        if (t.gather_src) RM_HIP(hipMemcpyAsync(t.tx_build, t.gather_src, size_t(t.n_active) * sizeof(rm_tx_record), hipMemcpyHostToDevice, s));
+        RM_TRY(stage(RM_STAGE_FILTER));
+        RM_HIP(rm::launch_dense_tick(s, nd, m, t, ts.d_cnt.p, ts.d_off.p));
+        ts.compact_pending = false;
+        ts.last.seg_ordered = 0;
+        ts.last_model = m;
+        ts.last_cfg = cfg;
+        ts.have_result = true;
+        return RM_OK;
+    }
     const int seg_len = (t.n_active - t.first_new <= frame_tick_max()) ? rm::frame_tick_segment(t, cfg, m) : 0;
     if (t.air_scan && seg_len == 0) return fail(RM_ERR_STATE, "internal: a tick planned by scan cannot take the one-launch form");
     if (t.gather_src && seg_len == 0 && t.filter_mode != rm::kFilterWg) {

@@ -133,6 +133,7 @@ struct alignas(32) RxCompact {
 struct NodesDev {
     int n;                                   // nodes in the simulator
     const double *sx, *sy, *sz, *stxpower, *stxprob;
+    const double *srxprob;                   // Transciever.rxProbability by node index (the dense tick visits receivers in node order)
     const int32_t *schannel, *sint_id;
     const uint8_t *senabled;                 // Transciever.isEnabled by node index (node-info)
     int n_rx;                                // receivers of this partition
@@ -583,6 +584,11 @@ hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t
 // (rm_airbatch.hip) a batch of SINR ticks with frames that outlive their tick: index of the frames, then pairs / exact / verdicts
 hipError_t launch_ov_index(hipStream_t s, const NodesDev &nd, const ModelDev &m, const OvDev &ov, int max_slot_frames);
 hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, const OvDev &ov, int max_new, int max_links, const LaunchCfg &cfg);
+
+// (rm_dense.hip) the tick of a medium in which a frame is heard by a large share of all nodes: node-order evaluation, ordered compaction
+bool dense_tick_applies(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m, const NodesDev &nd, bool whole_or_range);
+int dense_tick_cells(const NodesDev &nd, const TickDev &t);
+hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off);
 
 // reception stage (rm_events.hip)
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256) k_patch_nodes(NodesDev nd, const NodePatc
     const_cast<double *>(nd.sz)[p.node] = p.z;
     const_cast<double *>(nd.stxpower)[p.node] = p.txpower;
     const_cast<double *>(nd.stxprob)[p.node] = p.txprob;
+    const_cast<double *>(nd.srxprob)[p.node] = p.rxprob;
     const_cast<int32_t *>(nd.schannel)[p.node] = p.channel;
     const_cast<uint8_t *>(nd.senabled)[p.node] = uint8_t(p.enabled);
     if (p.pos < 0) return;

@@ -83,6 +83,7 @@ struct TickSlot {
     DevBuf<float> d_p_inv;
 
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
+
     DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
     DevBuf<uint32_t> d_shards;   // two parities x kShards x kShardStride append counters
     DevBuf<uint32_t> d_cursor, d_cand_tot, d_seg_off;
@@ -142,7 +143,7 @@ struct rm_context : TickSlot {
     std::vector<int32_t> channel, int_id;
     std::vector<uint8_t> enabled;
     // device-resident source table (SoA, node-index order): what a packet copies from its source
-    DevBuf<double> d_x, d_y, d_z, d_txpower, d_txprob;
+    DevBuf<double> d_x, d_y, d_z, d_txpower, d_txprob, d_rxprob_node;
     DevBuf<int32_t> d_channel, d_int_id;
     // device-resident receiver table of this partition (SoA, engine order = spatially sorted)
     DevBuf<double> d_rx_x, d_rx_y, d_rx_z, d_rx_rxprob;

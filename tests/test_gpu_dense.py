@@ -1,0 +1,109 @@
+"""Media in which a frame is heard by a large share of the nodes -- the reference's default NullRadioMedium
+(NullRadioMedium.java:47-77: every same-channel node with its radio on hears every frame), a unit disc that covers the
+field, a lossless N2N matrix: the tick takes the dense form (rm_dense.hip: node-order evaluation, ordered compaction).
+Whole ticks against the oracle, and against the culled paths (RM_DENSE_TICK=0) the same ticks took before."""
+import numpy as np
+import pytest
+
+from util import KINDS, DeviceArray, assert_same, configure_engine, oracle_model, to_tx_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _nodes(O, n, side, seed, channels=(26,)):
+    rng = np.random.default_rng(seed)
+    nd = O.NodeTable(n)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    nd.channel[:] = rng.choice(channels, n)
+    nd.enabled[rng.choice(n, n // 40, replace=False)] = 0
+    nd.txpower[:] = rng.uniform(-10.0, 0.0, n)
+    return nd, rng
+
+
+@pytest.mark.parametrize("kind,params", [("null", {}), ("udgm", {"udgm_transmission_range": 400.0}), ("udgm_const", {"const_range": 500.0})])
+def test_dense_tick_equals_the_oracle(rsa, O, kind, params):
+    """20 k nodes, 200 frames, everyone (on the channel, radio on) in range: 4 M links of one tick, every record"""
+    n, t = 20_000, 200
+    nd, rng = _nodes(O, n, 250.0, 3, channels=(26, 26, 26, 11))
+    eng = rsa.Engine(0)
+    try:
+        configure_engine(eng, nd, kind, params)
+        eng.set_link_capacity(1 << 23)
+        srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+        pk = nd.packets(srcs, 0, 8128)
+        cpu = O.tick_mt(oracle_model(O, kind, params), nd, pk, cap=1 << 23)
+        assert cpu.count > 2_000_000
+        gpu = eng.tick(to_tx_records(rsa, pk), cap=1 << 23)
+        assert_same(gpu, cpu, kind + " host records")
+        np.testing.assert_array_equal(gpu.pkt_offset, np.concatenate([[0], np.cumsum(np.bincount(cpu.pkt, minlength=t))]))
+        d = DeviceArray(srcs)
+        eng.tick_run_sources_device(0, 1000, d.ptr.value, t, 0, 8128)
+        assert_same(eng.result_copy(t, cap=1 << 23), cpu, kind + " source indices on the device")
+        d.free()
+    finally:
+        eng.close()
+
+
+def test_dense_and_culled_forms_agree_and_alternate(rsa, O, monkeypatch):
+    """the same ticks through the dense form and through the forms they took before; ticks of the two kinds one after the
+    other on one context (the dense tick leaves the other parity's counters as the sweep's first kernel would)"""
+    n = 6000
+    nd, rng = _nodes(O, n, 300.0, 5)
+    nd.enabled[:] = 1
+    eng = rsa.Engine(0)
+    try:
+        for kind, params in (("udgm", {"udgm_transmission_range": 300.0}), ("null", {})):
+            configure_engine(eng, nd, kind, params)
+            eng.set_link_capacity(1 << 22)
+            mdl = oracle_model(O, kind, params)
+            for k in range(6):
+                srcs = np.sort(rng.choice(n, 40 + 7 * k, replace=False)).astype(np.int32)
+                pk = nd.packets(srcs, k * 1000, 8128)
+                cpu = O.tick_mt(mdl, nd, pk, cap=1 << 22)
+                monkeypatch.setenv("RM_DENSE_TICK", "1" if k % 2 == 0 else "0")
+                assert_same(eng.tick(to_tx_records(rsa, pk), k * 1000, k * 1000 + 1000, cap=1 << 22), cpu, "%s tick %d" % (kind, k))
+    finally:
+        eng.close()
+
+
+def test_dense_tick_on_index_partitions_padding_and_capacity(rsa, O):
+    """receivers = an index range (two ranks together = the whole tick), padding records among the frames, and a link capacity
+    that is too small is reported, never silently truncated"""
+    n, t = 9000, 60
+    nd, rng = _nodes(O, n, 200.0, 8)
+    params = {"udgm_transmission_range": 400.0}
+    mdl = oracle_model(O, "udgm", params)
+    srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+    pk = nd.packets(srcs, 0, 8128)
+    recs = to_tx_records(rsa, pk)
+    recs["src"][5::11] = -1                       # padding slots of a gathered tick
+    real = recs["src"] >= 0
+    renum = np.cumsum(real) - 1
+    cpu = O.tick_mt(mdl, nd, pk[real], cap=1 << 22)
+    parts = []
+    for first, count in ((0, 4000), (4000, 5000)):
+        eng = rsa.Engine(0)
+        try:
+            configure_engine(eng, nd, "udgm", params)
+            eng.set_partition(first, count)
+            d = DeviceArray(recs)
+            eng.tick_run_device(0, 1000, d.ptr.value, t)
+            parts.append(eng.result_copy(t, cap=1 << 22))
+            d.free()
+        finally:
+            eng.close()
+    pk_all = np.concatenate([renum[p.pkt] for p in parts])
+    dst_all = np.concatenate([p.dst for p in parts])
+    key = np.lexsort((dst_all, pk_all))
+    np.testing.assert_array_equal(pk_all[key], cpu.pkt)
+    np.testing.assert_array_equal(dst_all[key], cpu.dst)
+    np.testing.assert_array_equal(np.concatenate([p.verdict for p in parts])[key], cpu.verdict)
+    eng = rsa.Engine(0)
+    try:
+        configure_engine(eng, nd, "udgm", params)
+        eng.set_link_capacity(100_000)
+        with pytest.raises(rsa.RadioMediumError) as e:
+            eng.tick(recs, cap=1 << 22)
+        assert e.value.code == -4
+    finally:
+        eng.close()
