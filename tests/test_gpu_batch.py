@@ -162,8 +162,15 @@ def test_batch_refusals(engine, rsa, O):
     assert e.value.code == _lib.RM_ERR_STATE
     engine.batch_run_device([0], [320], [recs.ptr.value], [10])
     assert engine.batch_result_count(0)[1] == 0
-    with pytest.raises(rsa.RadioMediumError) as e:                 # SINR: tick 0's frames (8128 us) outlive their tick
-        engine.batch_run_sources_device([0, 1000], [1000, 2000], [src.ptr.value] * 2, [10, 10], [0, 1000], [AIR, AIR])
+    # SINR: tick 0's frames (8128 us) outlive their tick -- taken since ABI version 4 (rm_airbatch.hip; tests/test_gpu_overlap.py) ...
+    engine.batch_run_sources_device([0, 1000], [1000, 2000], [src.ptr.value] * 2, [10, 10], [0, 1000], [AIR, AIR])
+    mdl = oracle_model(O, "logdist", dict(ld_flags=1))
+    first = nd.packets(np.arange(10), 0, AIR)
+    assert_same(engine.batch_result_copy(0, 10), O.tick(mdl, nd, first), "overlapping SINR batch, tick 0")
+    assert_same(engine.batch_result_copy(1, 10), O.tick(mdl, nd, np.concatenate([first, nd.packets(np.arange(10), 1000, AIR)]), first_new=10),
+                "overlapping SINR batch, tick 1")
+    with pytest.raises(rsa.RadioMediumError) as e:                 # ... but not out of time order
+        engine.batch_run_sources_device([5000, 4000], [6000, 5000], [src.ptr.value] * 2, [10, 10], [5000, 4000], [AIR, AIR])
     assert e.value.code == _lib.RM_ERR_STATE
     configure_engine(engine, nd, "udgm", dict(udgm_success_ratio_rx=0.5))
     engine.set_partition(0, n // 2)
@@ -186,8 +193,7 @@ def test_batch_refusals(engine, rsa, O):
 def test_sinr_batch_of_self_contained_ticks(engine, rsa, O):
     """The SINR extension in a batch: allowed when no frame outlives its tick (air time <= tick length),
     every tick then equals the oracle's answer for its own frames; the last tick's frames stay on the
-    air for the one-tick-at-a-time calls that follow; an earlier call's frames still on the air make
-    the next batch be refused."""
+    air for the one-tick-at-a-time calls that follow, and for a batch that begins while they are (the overlap form)."""
     from radio_sim_amd import _lib
     n = 6000
     nd = _layout(O, n, seed=41)
@@ -215,9 +221,11 @@ def test_sinr_batch_of_self_contained_ticks(engine, rsa, O):
     engine.tick_run_sources_device(7000, 8000, d_more.ptr.value, len(more), 7000, 2048)
     cpu = O.tick(mdl, nd, np.concatenate([onair, nd.packets(more, 7000, 2048)]), first_new=len(onair))
     assert_same(engine.result_copy(len(more)), cpu, "one tick after the batch, with the batch's last frames on the air")
-    with pytest.raises(rsa.RadioMediumError) as e:                 # ... and a batch starting at 8000 would miss them
-        engine.batch_run_sources_device([8000], [9000], [d_more.ptr.value], [len(more)], [8000], [320])
-    assert e.value.code == _lib.RM_ERR_STATE
+    # ... and a batch that begins at 8000 sees them too (the overlap form, rm_airbatch.hip: refused before ABI version 4)
+    engine.batch_run_sources_device([8000], [9000], [d_more.ptr.value], [len(more)], [8000], [320])
+    still = np.concatenate([onair, nd.packets(more, 7000, 2048)])
+    cpu = O.tick(mdl, nd, np.concatenate([still, nd.packets(more, 8000, 320)]), first_new=len(still))
+    assert_same(engine.batch_result_copy(0, len(more)), cpu, "a batch that begins with frames of earlier calls on the air")
     engine.batch_run_sources_device([20000], [21000], [d_more.ptr.value], [len(more)], [20000], [320])   # all expired
     assert_same(engine.batch_result_copy(0, len(more)), O.tick(mdl, nd, nd.packets(more, 20000, 320)), "batch after expiry")
     for d in dev + [d_more]:
