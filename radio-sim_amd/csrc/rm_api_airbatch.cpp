@@ -43,7 +43,7 @@ bool overlap_wanted(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, c
 
 int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
                       const int32_t *n_per, const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world,
-                      int gather_slots)
+                      int gather_slots, const int32_t *gathered_idx)
 {
     // what the batched kernels carry: no java.util.Random draws (the draw stage walks compact records tick by tick and knows
     // nothing of verdicts that come later), time that does not run backwards inside the batch
@@ -100,9 +100,15 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
         c->t_begin = t_begin_us[b];
         RM_TRY(prepare_tick(c, ts, pl, true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr, dev_src ? start_us[b] : 0,
                             dev_src ? air_us[b] : 0, kAirBatch, 0, &knobs));
-        if (gathered) {
+        if (gathered || gathered_idx) {
             rm::TickDev &t = pl.t;
-            t.gather_src = gathered + size_t(b) * size_t(gather_slots);
+            if (gathered_idx) {
+                t.gather_idx = gathered_idx + size_t(b) * size_t(gather_slots);
+                t.src_start_us = start_us[b];
+                t.src_air_us = air_us[b];
+            } else {
+                t.gather_src = gathered + size_t(b) * size_t(gather_slots);
+            }
             t.gather_slots = gather_slots;
             t.gather_stride = n_ticks * gather_slots;
             t.tx_build = const_cast<rm_tx_record *>(tx);

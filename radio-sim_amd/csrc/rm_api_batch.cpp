@@ -128,18 +128,21 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
 // gather_slots records per rank and tick); every tick then has gather_world * gather_slots frames
 int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                    const int32_t *const *dev_src, const rm_tx_record *const *dev_new, const int32_t *n_per,
-                   const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world, int gather_slots)
+                   const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world, int gather_slots,
+                   const int32_t *gathered_idx)
 {
-    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || (!n_per && !gathered) ||
-        (!dev_src && !dev_new && !gathered) || (dev_src && (!start_us || !air_us)) || (gathered && (gather_world < 1 || gather_slots < 1)))
+    const bool any_gathered = gathered || gathered_idx;
+    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || (!n_per && !any_gathered) ||
+        (!dev_src && !dev_new && !any_gathered) || ((dev_src || gathered_idx) && (!start_us || !air_us)) ||
+        (any_gathered && (gather_world < 1 || gather_slots < 1)))
         return fail(RM_ERR_INVALID, "bad arguments");
     static thread_local std::vector<int32_t> n_gath;
-    if (gathered) {
+    if (any_gathered) {
         n_gath.assign(size_t(n_ticks), gather_world * gather_slots);
         n_per = n_gath.data();
     }
     for (int b = 0; b < n_ticks; ++b)
-        if (n_per[b] < 0 || (!gathered && n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
+        if (n_per[b] < 0 || (!any_gathered && n_per[b] > 0 && !(dev_src ? (const void *)dev_src[b] : (const void *)dev_new[b])) ||
             (dev_src && air_us[b] < 0))
             return fail(RM_ERR_INVALID, "bad arguments");
     const double th0 = g_clock.on ? HostClock::now() : 0;
@@ -152,9 +155,10 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         // batch).  Self-contained ticks -- nothing of an earlier call and nothing of an earlier tick is still on the air when
         // a tick begins (e.g. air time <= tick length) -- keep their per-tick lists.  Records given by the caller are
         // verified on the device: every frame of tick b has to lie inside [t_begin[b], t_end[b]], and the ticks must not overlap.
-        if (start_us && air_us && (dev_src || gathered) && overlap_wanted(c, n_ticks, t_begin_us, n_per, start_us, air_us))
-            return batch_run_overlap(c, n_ticks, t_begin_us, t_end_us, dev_src, n_per, start_us, air_us, gathered, gather_world, gather_slots);
-        if (!dev_src)
+        if (start_us && air_us && (dev_src || any_gathered) && overlap_wanted(c, n_ticks, t_begin_us, n_per, start_us, air_us))
+            return batch_run_overlap(c, n_ticks, t_begin_us, t_end_us, dev_src, n_per, start_us, air_us, gathered, gather_world, gather_slots,
+                                     gathered_idx);
+        if (!dev_src && !gathered_idx)
             for (int b = 0; b < n_ticks; ++b)
                 if (t_end_us[b] < t_begin_us[b] || (b + 1 < n_ticks && t_end_us[b] > t_begin_us[b + 1]))
                     return fail(RM_ERR_STATE, "SINR batches of records need ticks [t_begin, t_end] that do not overlap");
@@ -189,20 +193,26 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
             // one-tick-at-a-time path lives
             RM_HIP(c->d_air.ensure(std::max<size_t>(size_t(n_per[b]), 1 << 16)));
             tx = c->d_air.p;
-        } else if (dev_src || gathered) {
+        } else if (dev_src || any_gathered) {
             RM_HIP(ts.d_tx.ensure(std::max(n_per[b], 1)));
             tx = ts.d_tx.p;
         } else {
             tx = dev_new[b];
         }
-        c->dev_records_from_caller = (dev_src == nullptr);
+        c->dev_records_from_caller = (dev_src == nullptr && gathered_idx == nullptr);
         const int rc_prep = prepare_tick(c, ts, plans[b], true, tx, n_per[b], 0, dev_src ? dev_src[b] : nullptr,
                                          dev_src ? start_us[b] : 0, dev_src ? air_us[b] : 0, kAirNone, 0, &knobs);
         c->dev_records_from_caller = false;
         RM_TRY(rc_prep);
-        if (gathered) {
+        if (any_gathered) {
             rm::TickDev &t = plans[b].t;
-            t.gather_src = gathered + size_t(b) * size_t(gather_slots);
+            if (gathered_idx) {
+                t.gather_idx = gathered_idx + size_t(b) * size_t(gather_slots);
+                t.src_start_us = start_us[b];
+                t.src_air_us = air_us[b];
+            } else {
+                t.gather_src = gathered + size_t(b) * size_t(gather_slots);
+            }
             t.gather_slots = gather_slots;
             t.gather_stride = n_ticks * gather_slots;
             t.tx_build = ts.d_tx.p;
@@ -213,7 +223,7 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
     }
     c->t_begin = t_begin_us[0];
     c->t_end = t_end_us[n_ticks - 1];
-    if (sinr && !dev_src)
+    if (sinr && !dev_src && !gathered_idx)
         for (int b = 0; b < n_ticks; ++b) {
             plans[b].t.check_span = 1;
             plans[b].t.span_begin = t_begin_us[b];
@@ -223,7 +233,7 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         c->air_tail = size_t(n_per[n_ticks - 1]);
         c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1], 0u});
     }
-    if (gathered && !batched)
+    if (any_gathered && !batched)
         return fail(RM_ERR_STATE, "gathered records go through the batched kernels only (sorted receiver table, fp32 frame, "
                                   "at most 8192 frames per tick, no empty tick)");
     if (batched) {

@@ -195,13 +195,11 @@ int rm_batch_run_gathered_sources_device(rm_context *c, int32_t n_ticks, const i
     if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || slots < 1 || world < 1 || !dev_src_all || !start_us || !t_begin_us || !t_end_us || air_us < 0)
         return fail(RM_ERR_INVALID, "bad arguments");
     RM_HIP(hipSetDevice(c->device));
-    const size_t all = size_t(world) * size_t(n_ticks) * size_t(slots);
-    RM_HIP(c->d_dist_all.ensure(all));
-    RM_HIP(rm::launch_pack_tx_batch(c->stream, nodes_dev(c), dev_src_all, n_ticks, slots, start_us, air_us, c->d_dist_all.p, world));
-    // (the frames' time spans travel with the call: the SINR medium's ticks may outlive each other)
+    // (the sweep's pre-pass builds every frame's record from its source index where it needs it: no packed copy in between;
+    // the frames' time spans travel with the call -- the SINR medium's ticks may outlive each other)
     static thread_local std::vector<int64_t> air_v;
     air_v.assign(size_t(n_ticks), air_us);
-    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, start_us, air_v.data(), c->d_dist_all.p, world, slots);
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, start_us, air_v.data(), nullptr, world, slots, dev_src_all);
 }
 
 int rm_dist_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,

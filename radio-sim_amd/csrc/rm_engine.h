@@ -271,6 +271,8 @@ struct TickDev {
     // [rank][tick][slot] left them in -- frame i of this tick is gather_src[(i / gather_slots) * gather_stride + i % gather_slots]
     // -- and copied to tx_build (== tx) by k_tick_prep, where every later stage finds them in the tick's packet order
     const rm_tx_record *gather_src;
+    const int32_t *gather_idx; // ... or, instead of records, the frames' SOURCE INDICES in the same layout (what the all-gather of a
+                               // sharded batch carries): k_tick_prep builds the record from the node table (src_start_us / src_air_us)
     int gather_slots, gather_stride;
     int n_active;
     int first_new;          // frames [first_new, n_active) get verdicts

@@ -423,7 +423,11 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     if (t.src_list && abs_i >= t.first_new) {
         tx = make_tx_record(nd, t.src_list[abs_i - t.first_new], t.src_start_us, t.src_air_us);
         t.tx_build[abs_i] = tx;
-    } else if (t.gather_src) { // (batches only: first_eval == first_new == 0)
+    } else if (t.gather_idx) { // (batches only: first_eval == first_new == 0) the gathered source indices: the record is built here
+        tx = make_tx_record(nd, t.gather_idx[size_t(abs_i / t.gather_slots) * size_t(t.gather_stride) + size_t(abs_i % t.gather_slots)],
+                            t.src_start_us, t.src_air_us);
+        t.tx_build[abs_i] = tx;
+    } else if (t.gather_src) { // (batches only) gathered records
         tx = t.gather_src[size_t(abs_i / t.gather_slots) * size_t(t.gather_stride) + size_t(abs_i % t.gather_slots)];
         t.tx_build[abs_i] = tx;
     } else {

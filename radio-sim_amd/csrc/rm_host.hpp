@@ -476,9 +476,11 @@ bool overlap_wanted(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, c
                     const int64_t *air_us);
 int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
                       const int32_t *n_per, const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world,
-                      int gather_slots);
+                      int gather_slots, const int32_t *gathered_idx);
+// gathered / gathered_idx: the ticks' frames where an all-gather of per-rank blocks left them, [rank][tick][slot] -- as records, or
+// as source indices (then start_us / air_us give the ticks' time spans and every record is built from the node table)
 int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
               const rm_tx_record *const *dev_new, const int32_t *n_per, const int64_t *start_us, const int64_t *air_us,
-              const rm_tx_record *gathered = nullptr, int gather_world = 0, int gather_slots = 0);
+              const rm_tx_record *gathered = nullptr, int gather_world = 0, int gather_slots = 0, const int32_t *gathered_idx = nullptr);
 
 } // namespace rmh
