@@ -63,7 +63,9 @@ WORKLOADS = {
 }
 # per-workload overrides: 16 channels; tick length (c4: one frame time, so the 5% are the concurrent set)
 # (c5: a result slot per tick of a batch holds ~45 k heard links; the per-receiver lists of RM_SINR_SCAN=0 want 2^25 entries: --link-capacity)
-EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23), "c5": dict(link_capacity=1 << 18)}
+# (c4: a tick of 5000 frames holds 0.5 M heard links and millions of list entries: 32 result slots of 2^23 per context)
+EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23, batch=32),
+         "c5": dict(link_capacity=1 << 18, batch=64)}
 
 
 def baseline_metric():
@@ -704,7 +706,7 @@ def main():
 
         from radio_sim_amd import dist as D
         use_sharded = world > 1 or args.force_sharded
-        batch = max(1, min(args.batch if not (stateful and args.batch_default) else 64, rsa.MAX_BATCH))
+        batch = max(1, min(extra.get("batch", args.batch) if (args.batch_default and world == 1 and not as_rank) else args.batch, rsa.MAX_BATCH))
         tps = batch                          # ticks per step: a step is one launch sequence
         if args.steps <= 0:
             args.steps = -(-1920 // tps)

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round evidence, run on the GPU box from the repository root:
-#   RM_COMMIT=<commit> ROUND=r04 [PARTS="bench pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
+#   RM_COMMIT=<commit> ROUND=r04 [PARTS="bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
 # Writes under gpurun_out/$ROUND/; the summaries to be judged are then copied into profiles/.  One gpurun call may run
 # 20 minutes: PARTS selects what a call collects (every part leaves its own summaries; pmc_traffic.json is per call and its
 # entries are merged into profiles/pmc_traffic.json (python tools/pmc_merge.py gpurun_out/$ROUND/pmc_traffic.json)).
 set -e -o pipefail
 R=$PWD
 ROUND=${ROUND:-r04}
-PARTS=${PARTS:-bench pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank}
+PARTS=${PARTS:-bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank}
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 stamp() { for f in "$@"; do echo "# commit ${RM_COMMIT:-unrecorded}" >> $f; done; }
@@ -21,6 +21,7 @@ stats() {
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 $R/bench.py "$@" > $O/${ROUND}_${name}_bench.json 2> $O/st_$name.err
     cp $(find $O/st_$name -name "*kernel_stats.csv" | head -1) $O/${ROUND}_${name}_kernel_stats.csv
     stamp $O/${ROUND}_${name}_kernel_stats.csv
+    (cd $R && python tools/trace_timed_avg.py $O/st_$name $O/${ROUND}_${name}_bench.json $O/${ROUND}_${name}_timed_kernel_avg.json > /dev/null) || true
     rm -rf $O/st_$name
     echo "stats $name done"
 }
@@ -44,6 +45,8 @@ echo "bench done"
 # roofline.kernel_avg_us has to agree with
 stats c3 $LEAN
 stats c3_sequential $LEAN --inflight 1 --batch 1 --steps 400 --warmup 40
+fi
+if has stats2; then
 stats c4 $LEAN --workload c4
 stats c5 $LEAN --workload c5
 stats m1 $LEAN --workload m1 --batch 16 --steps 24 --warmup 6
@@ -57,7 +60,7 @@ pmc c3 128 $LEAN --inflight 1 --steps 6 --warmup 2
 fi
 if has pmc_m1; then pmc m1 16 $LEAN --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3; fi
 if has pmc_tick; then pmc c3_tick 1 $LEAN --inflight 1 --batch 1 --steps 200 --warmup 20; fi
-if has pmc_c4; then pmc c4 128 $LEAN --workload c4 --inflight 1 --steps 6 --warmup 2; fi
+if has pmc_c4; then pmc c4 32 $LEAN --workload c4 --inflight 1 --steps 6 --warmup 2; fi
 if has pmc_c5; then pmc c5 64 $LEAN --workload c5 --steps 8 --warmup 2; pmc c5_tick 1 $LEAN --workload c5 --batch 1 --steps 60 --warmup 12; fi
 if has pmc_dense; then
 stats dense --dense-only
