@@ -50,42 +50,48 @@ __global__ void __launch_bounds__(256) k_ov_count(const NodesDev nd, const Model
     const int slot = blockIdx.y;
     const int f0 = ov.slot_first[slot], f1 = ov.slot_first[slot + 1];
     const int i = f0 + int(blockIdx.x) * 256 + int(threadIdx.x);
-    if (i >= f1) return;
-    const rm_tx_record r = ov.tx[i];
-    float4 f;
-    double thr64;
-    tx_prefilter(m, r, f, thr64);
-    const bool valid = r.src >= 0 && r.src < nd.n;
-    if (!valid) f.w = -1.f;
-    float inv = 0.f;
-    if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) { // (the sweep's second-level filter applies to this frame)
-        const float cut = __builtin_sqrtf(f.w);
-        if (1.01f * (2.0f * float(m.f32_slack)) / (0.15f * cut) + 1e-5f <= float(kShadowPad)) inv = float(kShadowBins) / f.w;
-    }
-    ov.fr_f[i] = f;
-    ov.fr_m[i] = make_int4(__float_as_int(inv), r.src, r.channel, i);
-    ov.fr_t[i] = make_longlong2(r.start_us, r.start_us + r.air_us);
-    uint32_t bin = 0xFFFFFFFFu;
-    int next = -1;
-    if (valid) {
-        // the node's chain of frames (half duplex does not ask for reach)
-        const unsigned long long stamp = (unsigned long long)ov.stamp << 32;
-        const unsigned long long old = atomicExch(&ov.self_slot[r.src], stamp | (unsigned long long)uint32_t(i));
-        if ((old >> 32) == ov.stamp) next = int(uint32_t(old));
-        if (f.w >= 0.f) {
-            if (f.w < __builtin_inff()) {
-                const int cell = ov_cell1(f.y, ov.half, ov.inv) * kSgG + ov_cell1(f.x, ov.half, ov.inv);
-                bin = uint32_t(cell) * uint32_t(ov.n_slots) + uint32_t(slot);
-                atomicAdd(&ov.bin_cnt[bin], 1u);
-                atomicMax(&ov.misc[8 + (i & (kSgMax - 1))], __float_as_uint(sqrt_up(f.w))); // (radii are >= 0: their bits order like they do)
-            } else {
-                ov.every[atomicAdd(&ov.misc[0], 1u)] = uint32_t(i); // no bound, or outside the fp32 frame: everybody looks at it
+    float radius = 0.f; // of a frame that goes into the grid (its reach at the interference level)
+    if (i < f1) { // (no early return: the wave reduces the radii together below)
+        const rm_tx_record r = ov.tx[i];
+        float4 f;
+        double thr64;
+        tx_prefilter(m, r, f, thr64);
+        const bool valid = r.src >= 0 && r.src < nd.n;
+        if (!valid) f.w = -1.f;
+        float inv = 0.f;
+        if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) { // (the sweep's second-level filter applies to this frame)
+            const float cut = __builtin_sqrtf(f.w);
+            if (1.01f * (2.0f * float(m.f32_slack)) / (0.15f * cut) + 1e-5f <= float(kShadowPad)) inv = float(kShadowBins) / f.w;
+        }
+        ov.fr_f[i] = f;
+        ov.fr_m[i] = make_int4(__float_as_int(inv), r.src, r.channel, i);
+        ov.fr_t[i] = make_longlong2(r.start_us, r.start_us + r.air_us);
+        uint32_t bin = 0xFFFFFFFFu;
+        int next = -1;
+        if (valid) {
+            // the node's chain of frames (half duplex does not ask for reach)
+            const unsigned long long stamp = (unsigned long long)ov.stamp << 32;
+            const unsigned long long old = atomicExch(&ov.self_slot[r.src], stamp | (unsigned long long)uint32_t(i));
+            if ((old >> 32) == ov.stamp) next = int(uint32_t(old));
+            if (f.w >= 0.f) {
+                if (f.w < __builtin_inff()) {
+                    const int cell = ov_cell1(f.y, ov.half, ov.inv) * kSgG + ov_cell1(f.x, ov.half, ov.inv);
+                    bin = uint32_t(cell) * uint32_t(ov.n_slots) + uint32_t(slot);
+                    atomicAdd(&ov.bin_cnt[bin], 1u);
+                    radius = sqrt_up(f.w);
+                } else {
+                    ov.every[atomicAdd(&ov.misc[0], 1u)] = uint32_t(i); // no bound, or outside the fp32 frame: everybody looks at it
+                }
             }
         }
+        ov.self_next[i] = next;
+        ov.fr_bin[i] = bin;
+        ov.defer[i] = 0;
     }
-    ov.self_next[i] = next;
-    ov.fr_bin[i] = bin;
-    ov.defer[i] = 0;
+    // the largest radius on the air: one atomic per WAVE (radii are >= 0: their bits order like they do) -- one per frame on 64
+    // words was 8000 atomics per word and batch, most of this kernel's time
+    radius = wave_max(radius);
+    if ((threadIdx.x & 63) == 0 && radius > 0.f) atomicMax(&ov.misc[8 + ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y * 7) & (kSgMax - 1))], __float_as_uint(radius));
 }
 
 // sum of one block of kOvScanBlock bins
