@@ -3,7 +3,7 @@
 #   RM_COMMIT=<commit> ROUND=r04 [PARTS="bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
 # Writes under gpurun_out/$ROUND/; the summaries to be judged are then copied into profiles/.  One gpurun call may run
 # 20 minutes: PARTS selects what a call collects (every part leaves its own summaries; pmc_traffic.json is per call and its
-# entries are merged into profiles/pmc_traffic.json (python tools/pmc_merge.py gpurun_out/$ROUND/pmc_traffic.json)).
+# entries are merged into profiles/pmc_traffic.json (python tools/pmc_merge.py gpurun_out/$ROUND/pmc_traffic_*.json)).
 set -e -o pipefail
 R=$PWD
 ROUND=${ROUND:-r04}
@@ -32,7 +32,7 @@ pmc() {
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pf_$key -- python3 $R/bench.py "$@" > $O/pf_$key.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pw_$key -- python3 $R/bench.py "$@" > $O/pw_$key.log 2>&1
     rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU --output-format csv -d $O/ps_$key -- python3 $R/bench.py "$@" > $O/ps_$key.log 2>&1
-    (cd $R && python tools/pmc_traffic.py $O/pf_$key $O/pw_$key $key $tpl $O/${ROUND}_${key}_pmc.csv $O/pmc_traffic.json $O/ps_$key profiles/${ROUND}_${key}_pmc.csv)
+    (cd $R && python tools/pmc_traffic.py $O/pf_$key $O/pw_$key $key $tpl $O/${ROUND}_${key}_pmc.csv $O/pmc_traffic_${PARTS// /_}.json $O/ps_$key profiles/${ROUND}_${key}_pmc.csv)
     rm -rf $O/pf_$key $O/pw_$key $O/ps_$key
     echo "pmc $key done"
 }
