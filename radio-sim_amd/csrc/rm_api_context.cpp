@@ -185,6 +185,8 @@ rm::NodesDev nodes_dev(rm_context *c)
     nd.bbox_xy = c->d_bbox_xy.p;
     nd.bbox_z = c->d_bbox_z.p;
     nd.wg_box_xy = c->d_wg_box_xy.p;
+    nd.grp_chmask = c->d_grp_chmask.p;
+    nd.wg_chmask = c->d_wg_chmask.p;
     nd.wg_box_z = c->d_wg_box_z.p;
     return nd;
 }
@@ -300,7 +302,7 @@ void rm_destroy(rm_context *c)
     c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rx_rec32.release(); c->d_rxf.release(); c->d_bbox_xy.release();
-    c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release();
+    c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release(); c->d_grp_chmask.release(); c->d_wg_chmask.release();
     c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release();
     c->air.pool.release(); c->air.head.release(); c->air.tail.release(); c->air.mark.release(); c->air.bad.release();
     {

@@ -137,7 +137,58 @@ int rebuild_receivers(rm_context *c)
             const int k = perm[size_t(i)];
             items[size_t(i)] = KdItem{{c->x[k], c->y[k], c->z[k]}, k, 0};
         }
-        kd_split(items.data(), 0, count, 3); // up to 8 threads
+        // Several channels in the table (BASELINE configs[3]: 16): receivers are ordered by CHANNEL first, by place inside a
+        // channel -- a group of 64 then holds one channel (two, where two classes meet), the filter drops a frame for the
+        // whole group by its channel mask (NodesDev::grp_chmask) before any distance is computed, and a frame's near
+        // groups are its co-channel ones: a sixteenth of the pair tests.  The order is engine-internal: results are ranked by
+        // node index whatever it is.  (RM_CHANNEL_ORDER=0: by place only.)
+        std::vector<std::pair<int, int>> classes; // [lo, hi) of every channel class
+        {
+            static const bool off = [] {
+                const char *e = std::getenv("RM_CHANNEL_ORDER");
+                return e && std::atoi(e) == 0;
+            }();
+            bool several = false;
+            for (int i = 1; i < count && !several; ++i) several = c->channel[size_t(items[size_t(i)].idx)] != c->channel[size_t(items[0].idx)];
+            if (several && !off) {
+                std::stable_sort(items.begin(), items.end(), [c](const KdItem &a, const KdItem &b) { return c->channel[size_t(a.idx)] < c->channel[size_t(b.idx)]; });
+                int lo = 0;
+                for (int i = 1; i <= count; ++i)
+                    if (i == count || c->channel[size_t(items[size_t(i)].idx)] != c->channel[size_t(items[size_t(lo)].idx)]) {
+                        classes.push_back({lo, i});
+                        lo = i;
+                    }
+                if (classes.size() > 64 || size_t(count) / classes.size() < 4 * size_t(rm::kGroup)) classes.clear(); // (too many, too small: by place after all)
+            }
+        }
+        if (classes.empty()) {
+            kd_split(items.data(), 0, count, 3); // up to 8 threads
+        } else {
+            for (const auto &cl : classes) {
+                // the class begins in the middle of a group of 64: its nearest receivers (along its widest axis) fill that group up,
+                // the rest is split from a group boundary on
+                int lo = cl.first;
+                const int hi = cl.second;
+                const int head = (rm::kGroup - lo % rm::kGroup) % rm::kGroup;
+                if (head > 0 && hi - lo > head) {
+                    double mn[3], mx[3];
+                    for (int a = 0; a < 3; ++a) mn[a] = mx[a] = items[size_t(lo)].v[a];
+                    for (int i = lo + 1; i < hi; ++i)
+                        for (int a = 0; a < 3; ++a) {
+                            mn[a] = std::min(mn[a], items[size_t(i)].v[a]);
+                            mx[a] = std::max(mx[a], items[size_t(i)].v[a]);
+                        }
+                    int axis = 0;
+                    for (int a = 1; a < 3; ++a)
+                        if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+                    std::nth_element(items.begin() + lo, items.begin() + lo + head, items.begin() + hi, [axis](const KdItem &a, const KdItem &b) {
+                        return a.v[axis] < b.v[axis] || (a.v[axis] == b.v[axis] && a.idx < b.idx);
+                    });
+                    lo += head;
+                }
+                kd_split(items.data(), lo, hi, 3);
+            }
+        }
         for (int i = 0; i < count; ++i) perm[size_t(i)] = items[size_t(i)].idx;
         c->rx_sorted = true;
     }
@@ -293,6 +344,8 @@ int prepare_nodes(rm_context *c)
     RM_HIP(c->d_bbox_xy.ensure(std::max(groups, 1)));
     RM_HIP(c->d_bbox_z.ensure(std::max(groups, 1)));
     RM_HIP(c->d_wg_box_xy.ensure(std::max(groups / 16 + 1, 1)));
+    RM_HIP(c->d_grp_chmask.ensure(std::max(groups, 1)));
+    RM_HIP(c->d_wg_chmask.ensure(std::max(groups / 16 + 1, 1)));
     RM_HIP(c->d_wg_box_z.ensure(std::max(groups / 16 + 1, 1)));
     RM_HIP(rm::launch_prep_rx(c->stream, nodes_dev(c), model_dev(c)));
     c->prefilter_dirty = false;

@@ -150,6 +150,8 @@ struct NodesDev {
     float2 *bbox_z;                          //                 (minz, maxz)
     float4 *wg_box_xy;                       // per filter workgroup (16 groups = 1024 receivers): union of its boxes
     float2 *wg_box_z;
+    uint32_t *grp_chmask;                    // per group of 64: bit (channel & 31) of every receiver with its radio on -- a frame on a channel
+    uint32_t *wg_chmask;                     // whose bit is not set cannot be heard in the group (per filter workgroup: the OR of its groups)
 };
 
 // SINR across ticks: the frames on the air leave their significant links in per-receiver lists that live on the

@@ -40,9 +40,13 @@ __global__ void __launch_bounds__(64) k_prep_rx(NodesDev nd, ModelDev m)
     const float lox = wave_min(ok ? r.x : inf_), hix = wave_max(ok ? r.x : -inf_);
     const float loy = wave_min(ok ? r.y : inf_), hiy = wave_max(ok ? r.y : -inf_);
     const float loz = wave_min(ok ? r.z : inf_), hiz = wave_max(ok ? r.z : -inf_);
+    // the channels heard in the group: bit (channel & 31) of every receiver that can be a candidate at all
+    uint32_t chm = (ok && i < nd.n_rx) ? (1u << (uint32_t(nd.channel[min(i, nd.n_rx - 1)]) & 31u)) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) chm |= uint32_t(__shfl_xor(int(chm), d));
     if (lane == 0) {
         nd.bbox_xy[g] = make_float4(lox, loy, hix, hiy);
         nd.bbox_z[g] = make_float2(loz, hiz);
+        nd.grp_chmask[g] = chm;
     }
 }
 
@@ -55,9 +59,11 @@ __global__ void __launch_bounds__(256) k_wg_boxes(NodesDev nd, int n_wg)
     const float inf_ = __builtin_inff();
     float4 xy = make_float4(inf_, inf_, -inf_, -inf_);
     float2 z = make_float2(inf_, -inf_);
+    uint32_t chm = 0u;
     for (int g = b * 16; g < min(n_groups, b * 16 + 16); ++g) {
         const float4 q = nd.bbox_xy[g];
         const float2 qz = nd.bbox_z[g];
+        chm |= nd.grp_chmask[g];
         xy.x = fminf(xy.x, q.x);
         xy.y = fminf(xy.y, q.y);
         xy.z = fmaxf(xy.z, q.z);
@@ -67,6 +73,7 @@ __global__ void __launch_bounds__(256) k_wg_boxes(NodesDev nd, int n_wg)
     }
     nd.wg_box_xy[b] = xy;
     nd.wg_box_z[b] = z;
+    nd.wg_chmask[b] = chm;
 }
 
 // Changed nodes written in place: the source table by node index, the receiver table (SoA arrays
@@ -462,8 +469,10 @@ template <int RPT> struct WgRx {
     int fch[RPT], forig[RPT];
     float4 bxy[RPT];
     float2 bz[RPT];
+    uint32_t bmask[RPT]; // the groups' channel masks
     float4 wxy;
     float2 wz;
+    uint32_t wmask;      // ... and the workgroup's
 };
 
 template <int RPT, bool SHADOW>
@@ -494,18 +503,22 @@ RM_D void wg_rx_load(const NodesDev &nd, const TickDev &t, WgRx<RPT> &rx)
         const bool ok = live && g * kGroup < t.n_rx;
         rx.bxy[r] = ok ? nd.bbox_xy[g] : make_float4(0.f, 0.f, 0.f, 0.f);
         rx.bz[r] = ok ? nd.bbox_z[g] : make_float2(0.f, 0.f);
+        rx.bmask[r] = ok ? nd.grp_chmask[g] : 0u;
     }
     // union box of the workgroup's 4*RPT groups
     if (RPT == 4) {
         rx.wxy = nd.wg_box_xy[wg];
         rx.wz = nd.wg_box_z[wg];
+        rx.wmask = nd.wg_chmask[wg];
     } else {
         const float inf_ = __builtin_inff();
         rx.wxy = make_float4(inf_, inf_, -inf_, -inf_);
         rx.wz = make_float2(inf_, -inf_);
+        rx.wmask = 0u;
         for (int g = wg * kWavesPerBlock * RPT; g < min(n_groups, (wg + 1) * kWavesPerBlock * RPT); ++g) { // uniform
             const float4 q = nd.bbox_xy[g];
             const float2 qz = nd.bbox_z[g];
+            rx.wmask |= nd.grp_chmask[g];
             rx.wxy.x = fminf(rx.wxy.x, q.x);
             rx.wxy.y = fminf(rx.wxy.y, q.y);
             rx.wxy.z = fmaxf(rx.wxy.z, q.z);
@@ -572,6 +585,8 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
     const float2 (&bz)[RPT] = rx.bz;
     const float4 wxy = rx.wxy;
     const float2 wz = rx.wz;
+    const uint32_t (&bmask)[RPT] = rx.bmask;
+    const uint32_t wmask = rx.wmask;
     __syncthreads();
 
     uint32_t round = 0;
@@ -601,7 +616,7 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
             const float dx = fmaxf(fmaxf(wxy.x - tfa.x, tfa.x - wxy.z), 0.f);
             const float dy = fmaxf(fmaxf(wxy.y - tfa.y, tfa.y - wxy.w), 0.f);
             const float dz = fmaxf(fmaxf(wz.x - tfa.z, tfa.z - wz.y), 0.f);
-            hit = dist2_f32(dx, dy, dz) <= tfa.w;
+            hit = dist2_f32(dx, dy, dz) <= tfa.w && ((wmask >> (uint32_t(cha) & 31u)) & 1u) != 0u; // (nobody here listens on its channel)
         }
         const uint64_t hm = ballot64(hit);
         if (hm) {
@@ -632,6 +647,7 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
                 uint64_t todo = 0;
                 {
                     const float4 tf = s_txf[c0 + min(lane, nt - 1)];
+                    const uint32_t tchb = uint32_t(s_ch[c0 + min(lane, nt - 1)]) & 31u;
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {
                         near[r] = 0;
@@ -639,7 +655,7 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
                             const float dx = fmaxf(fmaxf(bxy[r].x - tf.x, tf.x - bxy[r].z), 0.f);
                             const float dy = fmaxf(fmaxf(bxy[r].y - tf.y, tf.y - bxy[r].w), 0.f);
                             const float dz = fmaxf(fmaxf(bz[r].x - tf.z, tf.z - bz[r].y), 0.f);
-                            near[r] = ballot64(lane < nt && dist2_f32(dx, dy, dz) <= tf.w);
+                            near[r] = ballot64(lane < nt && dist2_f32(dx, dy, dz) <= tf.w && ((bmask[r] >> tchb) & 1u) != 0u);
                         }
                         todo |= near[r];
                     }

@@ -152,6 +152,7 @@ struct rm_context : TickSlot {
     DevBuf<rm::RxRecord> d_rx_rec;
     DevBuf<rm::RxCompact> d_rx_rec32;
     DevBuf<float4> d_rxf, d_bbox_xy, d_wg_box_xy;
+    DevBuf<uint32_t> d_grp_chmask, d_wg_chmask;
     DevBuf<float2> d_wg_box_z;
     DevBuf<float2> d_bbox_z;
     DevBuf<double> d_n2n;
