@@ -30,11 +30,23 @@ def main():
             continue
         # the sequential leg and the host-transfer legs launch other kernels; a kernel of the sequence is launched once per step
         timed = durs[-steps:] if len(durs) >= steps else durs
-        line_us = next((v["avg_us"] for k, v in line["roofline"]["kernels"].items() if k.split("<")[0] == base), None)
+        line_us = line_kernel_us(line, name)
         out["kernels"][name] = {"dispatches_in_trace": len(durs), "timed_avg_us": sum(timed) / len(timed), "all_avg_us": sum(durs) / len(durs),
                                 "line_avg_us": line_us, "line_over_trace": (line_us / (sum(timed) / len(timed))) if line_us else None}
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
+
+
+def line_kernel_us(line, trace_name):
+    """the line's average for the kernel rocprofv3 calls `trace_name`: the same name (template arguments as the launch site spells
+    them may differ from the trace's -- RM_MODEL_LOGDIST / 4), else the only kernel of the same base name"""
+    ks = line["roofline"]["kernels"]
+    norm = lambda n: n.replace(" ", "")
+    for k, v in ks.items():
+        if norm(k) == norm(trace_name):
+            return v["avg_us"]
+    same = [v["avg_us"] for k, v in ks.items() if k.split("<")[0] == trace_name.split("<")[0]]
+    return same[0] if len(same) == 1 else None
 
 
 def collections_by_kernel(trace_dir):
