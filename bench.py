@@ -733,6 +733,7 @@ def main():
             if ok and args.collective != "lib" and os.environ.get("RM_BENCH_NO_LIB_COLLECTIVE") == "1":
                 ok = 0
             if ok:
+                joined = 1
                 for e in engines:
                     if world > 1:
                         e.set_partition_spatial(rank, world) if spatial else e.set_partition(lo, hi - lo)
@@ -741,7 +742,22 @@ def main():
                         uid = uid.to(dev)
                         dist.broadcast(uid, src=0)
                         uid = uid.cpu()
-                    e.comm_init_rank(uid.numpy(), world, rank)
+                    try:
+                        e.comm_init_rank(uid.numpy(), world, rank)
+                    except rsa.RadioMediumError as err:     # (reported, and every rank then takes torch's collective together)
+                        print("bench: rank %d could not join the library's communicator: %s" % (rank, err), file=sys.stderr)
+                        joined = 0
+                        break
+                if world > 1:
+                    flag = torch.tensor([joined], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    joined = int(flag.item())
+                if not joined:
+                    if args.collective == "lib":
+                        raise SystemExit("--collective lib: a rank could not join the library's communicator")
+                    for e in engines:
+                        e.comm_destroy()
+                    lib_dist = False
             elif args.collective == "lib":
                 raise SystemExit("--collective lib: RCCL could not be bound inside libradiomedium_hip.so on every rank")
             else:

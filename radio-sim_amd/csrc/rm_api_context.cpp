@@ -230,7 +230,7 @@ int build_shadow_table(rm_context *c)
 void TickSlot::release_all()
 {
     d_tx.release(); d_p_txf.release(); d_p_ch.release(); d_p_src.release(); d_p_inv.release();
-    d_cnt.release(); d_off.release(); d_slot_tot.release(); d_slot_off.release();
+    d_cnt.release(); d_off.release(); d_dense_mask.release(); d_slot_tot.release(); d_slot_off.release();
     d_counters.release(); d_shards.release(); d_cursor.release(); d_cand_tot.release(); d_seg_off.release(); d_a_e.release();
     d_st_pkt.release(); d_st_dst.release(); d_st_next.release(); d_head.release(); d_st_blk.release(); d_st_aux.release();
     d_st_lin.release(); d_st_sinr.release(); d_st_prob.release(); d_st_orig.release(); d_st_flags.release(); d_st_coll.release();

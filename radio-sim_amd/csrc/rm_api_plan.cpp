@@ -410,9 +410,10 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         const size_t cells = size_t(rm::dense_tick_cells(nd, t));
         RM_HIP(ts.d_cnt.ensure(std::max<size_t>(cells, 1)));
         RM_HIP(ts.d_off.ensure(std::max<size_t>(cells, 1)));
+        RM_HIP(ts.d_dense_mask.ensure(std::max<size_t>(cells, 1) * 16));
         if (t.gather_src) RM_HIP(hipMemcpyAsync(t.tx_build, t.gather_src, size_t(t.n_active) * sizeof(rm_tx_record), hipMemcpyHostToDevice, s));
         RM_TRY(stage(RM_STAGE_FILTER));
-        RM_HIP(rm::launch_dense_tick(s, nd, m, t, ts.d_cnt.p, ts.d_off.p));
+        RM_HIP(rm::launch_dense_tick(s, nd, m, t, ts.d_cnt.p, ts.d_off.p, ts.d_dense_mask.p));
         ts.compact_pending = false;
         ts.last.seg_ordered = 0;
         ts.last_model = m;

@@ -8,41 +8,72 @@
 // (Simulator.getNodes(), UDGMRadioMedium.java:95): one exact evaluation per (frame, node) from the node-ordered columns of
 // the source table (coalesced: 5 bytes per node for the Null medium, 37 for the unit disc) and an ordered compaction; what
 // is left is record writing -- 17 bytes per heard link (25 with the SINR column) in runs of whole cache lines.
-//   k_dense_count   (frame, chunk of 1024 consecutive nodes): the links heard in the chunk
-//   k_dense_scan    one workgroup: the chunks' offsets (frame-major), the packet offsets, the tick's counters
-//   k_dense_write   the same evaluation again (cheaper than keeping four million verdicts between the launches), every
-//                   thread's heard links to offset(cell) + rank in the chunk: consecutive threads write consecutive records
-// The fixed-segment tick of rm_tick.hip took 0.31 ms for 200 frames x 20 k nodes (one workgroup per frame, two evaluations
-// and a bitmap pass over the node indices in LDS).  A one-launch form of this file -- the chunks' offsets by decoupled
-// look-back over (frame, chunk) states, in one and in two levels -- was built and measured at 75-84 us for the Null medium
-// against 67 us for these three launches with the same evaluation; it is not in the tree.
+//   k_dense_count   (chunk of 1024 consecutive nodes, eight frames): the chunk's columns once, in registers; per frame the heard
+//                   links as 16 lane masks (a wave's 64 consecutive nodes each) and their number
+//   k_dense_write   (frame, chunk): the records of the masks' set bits.  A lane's node is 64 * k + lane of the wave's 256, so
+//                   every store instruction of a wave writes consecutive records: whole lines, one array at a time.  The
+//                   chunk's offset is the sum of the counts before it, taken by the workgroup itself from the (L2-resident)
+//                   counts -- up to 8192 (frame, chunk) cells; beyond that k_dense_scan (one workgroup) lays them out first.
+// History.  The fixed-segment tick of rm_tick.hip took 0.31 ms for 200 frames x 20 k nodes (one workgroup per frame, two
+// evaluations and a bitmap pass over the node indices in LDS).  Round 4's first form of this file -- count, one-workgroup scan,
+// write with the evaluation repeated, four consecutive nodes per thread -- took 14 + 10.5 + 35.5 us for the Null medium on that
+// shape (28 + 10.5 + 47 for the unit disc).  A one-launch form -- offsets by decoupled look-back over (frame, chunk) states, in
+// one and in two levels -- was built and measured at 75-84 us; it is not in the tree.
 #include "rm_device.hpp"
 
 #include <stdlib.h>
 
 namespace rm {
 
-constexpr int kDnPer = 4;                  // consecutive nodes per thread
+constexpr int kDnPer = 4;                  // nodes per thread: 64 * k + lane of the wave's 256 consecutive nodes
 constexpr int kDnChunk = 256 * kDnPer;     // nodes per workgroup
+constexpr int kDnFrames = 8;               // frames per workgroup of the count pass
+constexpr int kDnFusedCells = 8192;        // up to here the write pass sums the counts before its cell itself
+
+// a node's columns as the media read them (what a medium does not read is not loaded)
+struct DnNode {
+    double x, y, z, rxprob;
+    int channel, int_id;
+    bool enabled;
+};
+
+template <int MODEL>
+RM_D DnNode dense_node(const NodesDev &nd, int j, bool valid)
+{
+    DnNode n{};
+    n.enabled = false;
+    if (!valid) return n;
+    n.enabled = nd.senabled[j] != 0;
+    n.channel = nd.schannel[j];
+    if (MODEL == RM_MODEL_N2N) {
+        n.int_id = nd.sint_id[j];
+        n.rxprob = nd.srxprob[j];
+    }
+    if (MODEL == RM_MODEL_UDGM || MODEL == RM_MODEL_UDGM_CONST) {
+        n.x = nd.sx[j], n.y = nd.sy[j], n.z = nd.sz[j];
+        if (MODEL == RM_MODEL_UDGM) n.rxprob = nd.srxprob[j];
+    }
+    return n;
+}
 
 // The reference's tests for one (frame, node) link, in its order, from the node-ordered columns (eval_link's arithmetic:
 // the same helpers, one rounding at a time).  The dense tick runs only where no draw can happen, so a heard link is
-// delivered unless the frame's transmission failed (txSuccess <= 0).
+// delivered unless the frame's transmission failed (txSuccess <= 0), and its rssi is the packet's transmit power (the
+// reference media hand it through).
 template <int MODEL>
-RM_D bool dense_eval(const ModelDev &m, const NodesDev &nd, const rm_tx_record &tx, int j, double &rssi)
+RM_D bool dense_eval(const ModelDev &m, const rm_tx_record &tx, int src_int_id, int j, const DnNode &n)
 {
     if (tx.src < 0 || j == tx.src) return false;       // padding record; node != source
-    if (!nd.senabled[j]) return false;                  // radio.isEnabled()
-    if (nd.schannel[j] != tx.channel) return false;     // radio.getWirelessChannel() == channel
-    rssi = tx.txpower;                                  // reference media hand the packet's transmit power through
+    if (!n.enabled) return false;                       // radio.isEnabled()
+    if (n.channel != tx.channel) return false;          // radio.getWirelessChannel() == channel
     if (MODEL == RM_MODEL_NULL) return true;
     if (MODEL == RM_MODEL_N2N) { // N2NRadioMedium.java:28-37
-        const int sid = nd.sint_id[tx.src], did = nd.sint_id[j];
+        const int sid = src_int_id, did = n.int_id;
         double p = 0.0;
-        if (m.n2n != nullptr && sid > 0 && did > 0 && sid <= m.n2n_m && did <= m.n2n_m) p = m.n2n[int64_t(sid - 1) * m.n2n_m + (did - 1)] * nd.srxprob[j];
+        if (m.n2n != nullptr && sid > 0 && did > 0 && sid <= m.n2n_m && did <= m.n2n_m) p = m.n2n[int64_t(sid - 1) * m.n2n_m + (did - 1)] * n.rxprob;
         return p > 0.0;
     }
-    const double d = ref_distance(tx.x, tx.y, tx.z, nd.sx[j], nd.sy[j], nd.sz[j]);
+    const double d = ref_distance(tx.x, tx.y, tx.z, n.x, n.y, n.z);
     if (MODEL == RM_MODEL_UDGM_CONST) return d < m.const_range;
     // UDGMRadioMedium.java:67-81 ; Math.pow(v, 2.0) == v*v
     const double d2 = d * d, dmax = m.udgm_range;
@@ -50,7 +81,7 @@ RM_D bool dense_eval(const ModelDev &m, const NodesDev &nd, const rm_tx_record &
     double ratio = d2 / (dmax * dmax);
     if (ratio > 1.0) return false;
     ratio = 1.0 - ratio * (1.0 - m.udgm_ratio_rx);
-    return ratio * nd.srxprob[j] > 0.0;
+    return ratio * n.rxprob > 0.0;
 }
 
 // the frame's record: given, or built from its source index (the count pass leaves it where every later reader looks)
@@ -60,27 +91,81 @@ RM_D rm_tx_record dense_frame(const NodesDev &nd, const TickDev &t, int q)
 }
 
 template <int MODEL>
-__global__ void __launch_bounds__(256) k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *cell_cnt, int chunks)
+__global__ void __launch_bounds__(256)
+k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *cell_cnt, unsigned long long *cell_mask, int chunks)
 {
-    __shared__ uint32_t s_w[4];
-    const int q = blockIdx.y, chunk = blockIdx.x;
-    const rm_tx_record tx = dense_frame(nd, t, q);
-    if (t.src_list && chunk == 0 && threadIdx.x == 0) t.tx_build[t.first_new + q] = tx;
-    const int j0 = nd.rx_first + chunk * kDnChunk + int(threadIdx.x) * kDnPer;
+    __shared__ uint32_t s_w[kDnFrames][4];
+    const int chunk = blockIdx.x, q0 = int(blockIdx.y) * kDnFrames;
+    const int n_new = t.n_active - t.first_new;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jw = nd.rx_first + chunk * kDnChunk + wave * (64 * kDnPer);
     const int j_end = nd.rx_first + nd.pos_span;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kDnPer; ++k) {
-        double rssi;
-        if (j0 + k < j_end && dense_eval<MODEL>(m, nd, tx, j0 + k, rssi)) ++cnt;
+    // the workgroup's frames first, one per thread: a record named by its source index is two dependent round trips, and eight
+    // of them one after the other were most of this kernel's time
+    __shared__ rm_tx_record s_tx[kDnFrames];
+    __shared__ int s_sid[kDnFrames];
+    if (threadIdx.x < kDnFrames && q0 + int(threadIdx.x) < n_new) {
+        const int q = q0 + int(threadIdx.x);
+        const rm_tx_record tx = dense_frame(nd, t, q);
+        if (t.src_list && chunk == 0) t.tx_build[t.first_new + q] = tx;
+        s_tx[threadIdx.x] = tx;
+        s_sid[threadIdx.x] = (MODEL == RM_MODEL_N2N && tx.src >= 0) ? nd.sint_id[tx.src] : 0;
     }
-    for (int d = 32; d >= 1; d >>= 1) cnt += uint32_t(__shfl_xor(int(cnt), d));
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    DnNode node[kDnPer];
+#pragma unroll
+    for (int k = 0; k < kDnPer; ++k) node[k] = dense_node<MODEL>(nd, jw + k * 64 + lane, jw + k * 64 + lane < j_end);
     __syncthreads();
-    if (threadIdx.x == 0) cell_cnt[size_t(q) * size_t(chunks) + size_t(chunk)] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    for (int f = 0; f < kDnFrames; ++f) { // block-uniform
+        const int q = q0 + f;
+        uint32_t cnt = 0;
+        if (q < n_new) {
+            const rm_tx_record tx = s_tx[f];
+            const int sid = s_sid[f];
+            const size_t cell = size_t(q) * size_t(chunks) + size_t(chunk);
+#pragma unroll
+            for (int k = 0; k < kDnPer; ++k) {
+                const uint64_t hm = ballot64(dense_eval<MODEL>(m, tx, sid, jw + k * 64 + lane, node[k]));
+                if (lane == 0) cell_mask[cell * 16u + uint32_t(wave * kDnPer + k)] = hm;
+                cnt += uint32_t(__popcll(hm));
+            }
+        }
+        if (lane == 0) s_w[f][wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < kDnFrames && q0 + int(threadIdx.x) < n_new) {
+        const int f = threadIdx.x;
+        cell_cnt[size_t(q0 + f) * size_t(chunks) + size_t(chunk)] = s_w[f][0] + s_w[f][1] + s_w[f][2] + s_w[f][3];
+    }
 }
 
-// one workgroup: exclusive scan of the cells (frame-major: a frame's chunks in node order), packet offsets, counters
+// what every tick leaves for the one that follows and for its readers, whichever kernel lays the cells out
+RM_D void dense_tick_tail(const ModelDev &m, const TickDev &t, int tid, int n_threads)
+{
+    for (int i = tid; i < t.shift; i += n_threads) t.slot_off[i] = 0u;
+    write_pkt_interference(m, t, tid, n_threads);
+    // what the sweep's first kernel does for the tick that follows (the other parity's counters start at zero)
+    if (tid < 8) t.next_counters[tid] = 0u;
+    for (int i = tid; i < kShards; i += n_threads) t.next_shard_count[i * kShardStride] = 0u;
+    if (!t.use_matrix)
+        for (int i = tid; i < t.zero_len; i += n_threads) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
+        }
+}
+RM_D void dense_tick_total(const TickDev &t, uint32_t total, int tid, int n_threads)
+{
+    const int n_new = t.n_active - t.first_new;
+    for (int i = t.shift + n_new + tid; i <= t.n_cnt; i += n_threads) t.slot_off[i] = total; // (the padding slots are empty)
+    if (tid == 0) {
+        t.out_count[0] = min(total, t.cap);
+        t.out_count[1] = (total > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
+        t.out_count[2] = total;
+        t.out_count[3] = 0u;
+    }
+}
+
+// one workgroup (ticks of more than kDnFusedCells cells): exclusive scan of the cells (frame-major: a frame's chunks in node
+// order), packet offsets, counters
 __global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const TickDev t, const uint32_t *cell_cnt, uint32_t *cell_off, int chunks)
 {
     __shared__ uint32_t s_wave[16];
@@ -98,63 +183,60 @@ __global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const Tic
         }
         carry += total;
     }
-    for (int i = t.shift + n_new + int(threadIdx.x); i <= t.n_cnt; i += 1024) t.slot_off[i] = carry; // (the padding slots are empty)
-    for (int i = int(threadIdx.x); i < t.shift; i += 1024) t.slot_off[i] = 0u;
-    write_pkt_interference(m, t, threadIdx.x, 1024);
-    // what the sweep's first kernel does for the tick that follows (the other parity's counters start at zero)
-    if (threadIdx.x < 8) t.next_counters[threadIdx.x] = 0u;
-    if (threadIdx.x < uint32_t(kShards)) t.next_shard_count[threadIdx.x * kShardStride] = 0u;
-    if (!t.use_matrix)
-        for (int i = int(threadIdx.x); i < t.zero_len; i += 1024) {
-            t.cursor[i] = 0u;
-            t.cand_tot_next[i] = 0u;
-        }
-    if (threadIdx.x == 0) {
-        t.out_count[0] = min(carry, t.cap);
-        t.out_count[1] = (carry > t.cap || t.stage_count[1] != 0u) ? 1u : 0u;
-        t.out_count[2] = carry;
-        t.out_count[3] = 0u;
-    }
+    dense_tick_total(t, carry, threadIdx.x, 1024);
+    dense_tick_tail(m, t, threadIdx.x, 1024);
 }
 
-template <int MODEL>
-__global__ void __launch_bounds__(256) k_dense_write(const NodesDev nd, const ModelDev m, const TickDev t, const uint32_t *cell_off, int chunks)
+template <bool FUSED>
+__global__ void __launch_bounds__(256)
+k_dense_write(const ModelDev m, const TickDev t, const uint32_t *cell_cnt, const uint32_t *cell_off, const unsigned long long *cell_mask,
+              int rx_first, int chunks)
 {
     __shared__ uint32_t s_w[4];
     const int q = blockIdx.y, chunk = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cell = uint32_t(q) * uint32_t(chunks) + uint32_t(chunk);
+    // the cell's sixteen masks, one per lane (and again in the lanes above: every lane has company to shuffle with)
+    const unsigned long long mk = cell_mask[size_t(cell) * 16u + uint32_t(lane & 15)];
     const rm_tx_record tx = t.tx[t.first_new + q]; // (built by the count pass when the tick named its frames by source index)
-    const int j0 = nd.rx_first + chunk * kDnChunk + int(threadIdx.x) * kDnPer;
-    const int j_end = nd.rx_first + nd.pos_span;
-    bool heard[kDnPer];
-    double rssi[kDnPer];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kDnPer; ++k) {
-        rssi[k] = 0.0;
-        heard[k] = j0 + k < j_end && dense_eval<MODEL>(m, nd, tx, j0 + k, rssi[k]);
-        cnt += heard[k] ? 1u : 0u;
+    uint32_t base;
+    if (FUSED) { // the counts of the cells before this one
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < cell; i += 256u) part += cell_cnt[i];
+        for (int d = 32; d >= 1; d >>= 1) part += uint32_t(__shfl_xor(int(part), d));
+        if (lane == 0) s_w[wave] = part;
+        __syncthreads();
+        base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    } else {
+        base = cell_off[cell];
     }
-    const uint32_t inc = wave_inclusive_scan(cnt, lane);
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint32_t o = cell_off[size_t(q) * size_t(chunks) + size_t(chunk)] + inc - cnt;
-    for (int w = 0; w < wave; ++w) o += s_w[w];
+    const uint32_t pc = uint32_t(__popcll(mk));
+    const uint32_t inc = wave_inclusive_scan((lane < 16) ? pc : 0u, lane); // (lanes 0..15: the cell's masks in node order)
+    if (FUSED) {
+        if (chunk == 0 && threadIdx.x == 0) t.slot_off[t.shift + q] = base; // a frame's first cell: its packet offset
+        if (cell + 1u == uint32_t(t.n_active - t.first_new) * uint32_t(chunks)) { // the last cell knows the tick's total
+            const uint32_t total = base + uint32_t(__shfl(int(inc), 15));
+            dense_tick_total(t, total, threadIdx.x, 256);
+        }
+        if (cell == 0u) dense_tick_tail(m, t, threadIdx.x, 256);
+    }
     const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
     const uint8_t verdict = (draws_possible && tx_success(m, tx) <= 0.0) ? uint8_t(RM_INTERFERED) : uint8_t(RM_DELIVERED);
+    const int jw = rx_first + chunk * kDnChunk + wave * (64 * kDnPer);
 #pragma unroll
     for (int k = 0; k < kDnPer; ++k) {
-        if (!heard[k]) continue;
-        if (o < t.cap) {
-            // (plain stores: the L2 puts a wave's 4-, 16- and 32-byte pieces together into whole lines; nontemporal stores of
-            // the same records took 100 us instead of 31)
+        const int i = wave * kDnPer + k;
+        const unsigned long long hm = (unsigned long long)__shfl((long long)mk, i);
+        const uint32_t before = uint32_t(__shfl(int(inc - ((lane < 16) ? pc : 0u)), i));
+        if (!((hm >> lane) & 1ull)) continue;
+        const uint32_t o = base + before + lane_prefix(hm);
+        if (o < t.cap) { // consecutive lanes, consecutive records: every store instruction writes whole lines of one array
             t.out_pkt[o] = q;
-            t.out_dst[o] = j0 + k;
+            t.out_dst[o] = jw + k * 64 + lane;
             t.out_verdict[o] = verdict;
-            t.out_rssi[o] = rssi[k];
+            t.out_rssi[o] = tx.txpower; // reference media hand the packet's transmit power through
             if (t.out_sinr) t.out_sinr[o] = 0.0;
         }
-        ++o;
     }
 }
 
@@ -179,26 +261,26 @@ bool dense_tick_applies(const TickDev &t, const LaunchCfg &cfg, const ModelDev &
     return share >= 1.0 / 16.0 && share * double(t.n_rx) > double(kFrameSegMax);
 }
 
-hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off)
+hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off,
+                             unsigned long long *cell_mask)
 {
     const int n_new = t.n_active - t.first_new;
     const int chunks = cdiv(nd.pos_span, kDnChunk);
     if (n_new <= 0 || chunks <= 0) return hipSuccess;
-    const dim3 grid(chunks, n_new), block(256);
-#define RM_DN(MODEL)                                                                                   \
-    do {                                                                                               \
-        RM_KLAUNCH((k_dense_count<MODEL>), grid, block, 0, s, nd, m, t, cell_cnt, chunks);             \
-        RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);         \
-        RM_KLAUNCH((k_dense_write<MODEL>), grid, block, 0, s, nd, m, t, cell_off, chunks);             \
-    } while (0)
+    const dim3 grid_c(chunks, cdiv(n_new, kDnFrames)), grid(chunks, n_new), block(256);
     switch (m.kind) {
-    case RM_MODEL_NULL: RM_DN(RM_MODEL_NULL); break;
-    case RM_MODEL_UDGM: RM_DN(RM_MODEL_UDGM); break;
-    case RM_MODEL_UDGM_CONST: RM_DN(RM_MODEL_UDGM_CONST); break;
-    case RM_MODEL_N2N: RM_DN(RM_MODEL_N2N); break;
+    case RM_MODEL_NULL: RM_KLAUNCH((k_dense_count<RM_MODEL_NULL>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_UDGM: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_UDGM_CONST: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM_CONST>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_N2N: RM_KLAUNCH((k_dense_count<RM_MODEL_N2N>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
     default: return hipErrorInvalidValue;
     }
-#undef RM_DN
+    if (long(n_new) * long(chunks) <= long(kDnFusedCells)) {
+        RM_KLAUNCH((k_dense_write<true>), grid, block, 0, s, m, t, cell_cnt, cell_off, cell_mask, nd.rx_first, chunks);
+    } else {
+        RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);
+        RM_KLAUNCH((k_dense_write<false>), grid, block, 0, s, m, t, cell_cnt, cell_off, cell_mask, nd.rx_first, chunks);
+    }
     return hipGetLastError();
 }
 

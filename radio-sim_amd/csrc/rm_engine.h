@@ -592,7 +592,8 @@ hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, 
 // (rm_dense.hip) the tick of a medium in which a frame is heard by a large share of all nodes: node-order evaluation, ordered compaction
 bool dense_tick_applies(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m, const NodesDev &nd, bool whole_or_range);
 int dense_tick_cells(const NodesDev &nd, const TickDev &t);
-hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off);
+hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off,
+                             unsigned long long *cell_mask); // cell_mask: 16 lane masks per (frame, chunk) cell
 
 // reception stage (rm_events.hip)
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,

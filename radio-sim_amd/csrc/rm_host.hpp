@@ -83,6 +83,7 @@ struct TickSlot {
     DevBuf<float> d_p_inv;
 
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
+    DevBuf<unsigned long long> d_dense_mask; // the dense tick's heard links: 16 lane masks per (frame, chunk of 1024 nodes)
 
     DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
     DevBuf<uint32_t> d_shards;   // two parities x kShards x kShardStride append counters
