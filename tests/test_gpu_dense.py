@@ -66,6 +66,30 @@ def test_dense_and_culled_forms_agree_and_alternate(rsa, O, monkeypatch):
         eng.close()
 
 
+def test_dense_tick_with_more_cells_than_the_write_pass_sums_itself(rsa, O, monkeypatch):
+    """5000 nodes x 1700 frames = 8500 (frame, chunk) cells: beyond 8192 the cells are laid out by the scan kernel instead of
+    by the write pass (rm_dense.hip, kDnFusedCells); a short range keeps the tick small, the knob sends it the dense way"""
+    n, t = 5000, 1700
+    nd, rng = _nodes(O, n, 300.0, 13, channels=(26, 11))
+    params = {"udgm_transmission_range": 30.0}
+    monkeypatch.setenv("RM_DENSE_TICK", "1")
+    eng = rsa.Engine(0)
+    try:
+        configure_engine(eng, nd, "udgm", params)
+        eng.set_link_capacity(1 << 20)
+        mdl = oracle_model(O, "udgm", params)
+        for k, tt in enumerate((t, 1638, t)): # (1638 * 5 = 8190 cells: the other side of the limit, on the same context)
+            srcs = np.sort(rng.choice(n, tt, replace=False)).astype(np.int32)
+            pk = nd.packets(srcs, k * 1000, 8128)
+            cpu = O.tick_mt(mdl, nd, pk, cap=1 << 20)
+            assert cpu.count > 50_000
+            gpu = eng.tick(to_tx_records(rsa, pk), k * 1000, k * 1000 + 1000, cap=1 << 20)
+            assert_same(gpu, cpu, "tick %d" % k)
+            np.testing.assert_array_equal(gpu.pkt_offset, np.concatenate([[0], np.cumsum(np.bincount(cpu.pkt, minlength=tt))]))
+    finally:
+        eng.close()
+
+
 def test_dense_tick_on_index_partitions_padding_and_capacity(rsa, O):
     """receivers = an index range (two ranks together = the whole tick), padding records among the frames, and a link capacity
     that is too small is reported, never silently truncated"""
