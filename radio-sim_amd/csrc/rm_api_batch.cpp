@@ -44,6 +44,29 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
     ticks_v.resize(size_t(n));
     rm::TickDev *const ticks = ticks_v.data();
     for (int b = 0; b < n; ++b) ticks[b] = plans[b].t;
+    {
+        // large tables: the near-frame lists of the filter's phase A (k_near_lists), per tick and block of kNearSb workgroups.
+        // RM_NEAR_LISTS=0 keeps phase A on all frames.
+        static const bool off = [] { const char *e = std::getenv("RM_NEAR_LISTS"); return e && std::atoi(e) == 0; }();
+        const rm::TickDev &t0 = ticks[0];
+        const int n_wg = (t0.n_rx + rm::kGroup * 16 - 1) / (rm::kGroup * 16), n_sb = (n_wg + rm::kNearSb - 1) / rm::kNearSb;
+        int max_eval = 0;
+        bool same = true;
+        for (int b = 0; b < n; ++b) {
+            max_eval = std::max(max_eval, ticks[b].n_active - ticks[b].first_eval);
+            same = same && ticks[b].filter_mode == rm::kFilterWg && ticks[b].rpt == 4 && ticks[b].n_rx == t0.n_rx;
+        }
+        const size_t entries = size_t(n) * size_t(n_sb) * size_t(max_eval);
+        if (!off && same && plans[0].cfg.bbox && !plans[0].cfg.f64_filter && n_wg >= 4 * rm::kNearSb && max_eval >= 512 && entries <= (size_t(1) << 28)) {
+            RM_HIP(c->d_near_list.ensure(entries));
+            RM_HIP(c->d_near_cnt.ensure(size_t(n) * size_t(n_sb)));
+            for (int b = 0; b < n; ++b) {
+                ticks[b].near_list = c->d_near_list.p + size_t(b) * size_t(n_sb) * size_t(max_eval);
+                ticks[b].near_cnt = c->d_near_cnt.p + size_t(b) * size_t(n_sb);
+                ticks[b].near_cap = max_eval;
+            }
+        }
+    }
     // the descriptors go to device memory (k_store_ticks, ordered on the stream after the previous
     // batch's kernels, which read the same array)
     RM_HIP(c->d_ticks.ensure(RM_MAX_BATCH));

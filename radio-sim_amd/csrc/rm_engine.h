@@ -259,6 +259,7 @@ struct OvDev {
     uint32_t *pair_tail;        // [kShards * kShardStride]
     uint32_t pair_seg;
 };
+constexpr int kNearSb = 16;   // filter workgroups (of 1024 receivers) per block of the near-frame lists
 constexpr int kOvScanBlock = 4096;
 
 struct TickDev {
@@ -318,6 +319,11 @@ struct TickDev {
     float4 *p_txf;          // [n_eval]
     int32_t *p_ch, *p_src;  // [n_eval]
     float *p_inv;           // [n_eval]
+    // batches over large tables: per block of kNearSb filter workgroups (16 k receivers) the frames near its box, found by a
+    // pre-pass (k_near_lists) -- phase A of a workgroup then looks at these few dozen instead of at every frame of the tick
+    const int32_t *near_list; // [blocks][near_cap] frame numbers (nullptr: phase A looks at all frames)
+    const uint32_t *near_cnt; // [blocks]
+    int near_cap;
     int32_t *a_e;           // [..] link-entry index of an A record (SINR results are looked up through it)
     int32_t *st_pkt;        // eval-relative frame index
     int32_t *st_dst;        // receiver engine position

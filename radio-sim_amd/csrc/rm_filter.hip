@@ -558,17 +558,24 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
     // exposed round trip per 1024 frames), the first ones before anything else
     constexpr int kUnrollA = 4;
     float4 af[kUnrollA];
-    int ach[kUnrollA], asrc[kUnrollA];
+    int ach[kUnrollA], asrc[kUnrollA], ae[kUnrollA];
     float ainv[kUnrollA];
+    // the frames phase A looks at: all of the tick's, or (RPT == 4, large tables in batches) the list of those near this
+    // workgroup's block of kNearSb workgroups
+    const int32_t *const near_list = (RPT == 4 && t.near_list) ? t.near_list + size_t(wg / kNearSb) * size_t(t.near_cap) : nullptr;
+    const int n_look = near_list ? uniform_i(int(min(t.near_cnt[wg / kNearSb], uint32_t(t.near_cap)))) : n_eval;
     auto request = [&](int g0) {
 #pragma unroll
         for (int u = 0; u < kUnrollA; ++u) {
-            const int e = g0 + u * kBlock + int(threadIdx.x);
+            const int i = g0 + u * kBlock + int(threadIdx.x);
             af[u] = make_float4(0.f, 0.f, 0.f, -1.f);
             ach[u] = 0;
             asrc[u] = -1;
             ainv[u] = 0.f;
-            if (e < n_eval) {
+            ae[u] = -1;
+            if (i < n_look) {
+                const int e = near_list ? near_list[i] : i;
+                ae[u] = e;
                 af[u] = t.p_txf[e];
                 ach[u] = t.p_ch[e];
                 if (SHADOW) {
@@ -590,16 +597,15 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
     __syncthreads();
 
     uint32_t round = 0;
-    for (int g0 = 0; g0 < n_eval; g0 += kUnrollA * kBlock) { // block-uniform
+    for (int g0 = 0; g0 < n_look; g0 += kUnrollA * kBlock) { // block-uniform
     if (g0) request(g0);
 #pragma unroll 1
     for (int u = 0; u < kUnrollA; ++u) { // rolled: one copy of phase B; the records are selected, not indexed
         const int f0 = g0 + u * kBlock;
-        if (f0 >= n_eval) break; // block-uniform
+        if (f0 >= n_look) break; // block-uniform
         // phase A: this thread's frame against the workgroup box
-        const int e = f0 + int(threadIdx.x);
         float4 tfa = af[0];
-        int cha = ach[0], srca = asrc[0];
+        int cha = ach[0], srca = asrc[0], e = ae[0];
         float inva = ainv[0];
 #pragma unroll
         for (int k = 1; k < kUnrollA; ++k) {
@@ -610,9 +616,10 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
             cha = (u == k) ? ach[k] : cha;
             srca = (u == k) ? asrc[k] : srca;
             inva = (u == k) ? ainv[k] : inva;
+            e = (u == k) ? ae[k] : e;
         }
         bool hit = false;
-        if (e < n_eval) {
+        if (e >= 0) {
             const float dx = fmaxf(fmaxf(wxy.x - tfa.x, tfa.x - wxy.z), 0.f);
             const float dy = fmaxf(fmaxf(wxy.y - tfa.y, tfa.y - wxy.w), 0.f);
             const float dz = fmaxf(fmaxf(wz.x - tfa.z, tfa.z - wz.y), 0.f);
@@ -636,7 +643,7 @@ RM_D void filter_wg_tick(const NodesDev &nd, const ModelDev &m, const TickDev &t
         }
         __syncthreads();
         const int n_near = uniform_i(int(s_n));
-        const bool last = f0 + kBlock >= n_eval;
+        const bool last = f0 + kBlock >= n_look;
         if (!last && n_near + kBlock <= kNearLds) continue; // room for another 256 frames
 
         // phase B: chunks of 64 near frames, every wave for its own groups
@@ -769,6 +776,71 @@ __global__ void __launch_bounds__(kBlock, RPT == 4 ? 4 : (RPT == 2 ? 5 : 6)) k_f
 __global__ void __launch_bounds__(256) k_tick_prep_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
     tick_prep_body(nd, m, ticks[blockIdx.z]);
+}
+
+// The near-frame lists of a batch over a large table (blockIdx.x = block of kNearSb filter workgroups, blockIdx.z = tick): at
+// a million receivers a tick has a thousand filter workgroups, and every one of them reading and testing every frame of the
+// tick was 27 MB of L2 reads per tick and a third of the filter's time; a block's box (16 k receivers) is near to a few
+// dozen of a thousand frames, and its workgroups look at those.
+__global__ void __launch_bounds__(256) k_near_lists(const NodesDev nd, const TickDev *__restrict__ ticks, const int n_wg)
+{
+    __shared__ float s_box[6];
+    __shared__ uint32_t s_mask, s_n;
+    const TickDev &t = ticks[blockIdx.z];
+    const int sb = blockIdx.x, lane = threadIdx.x & 63;
+    const int n_eval = t.n_active - t.first_eval;
+    if (t.near_list == nullptr) return;
+    if (threadIdx.x < 64) { // the union of the block's workgroup boxes and channel masks
+        const float inf_ = __builtin_inff();
+        const int w = sb * kNearSb + lane;
+        const bool ok = lane < kNearSb && w < n_wg;
+        const float4 q = ok ? nd.wg_box_xy[w] : make_float4(inf_, inf_, -inf_, -inf_);
+        const float2 qz = ok ? nd.wg_box_z[w] : make_float2(inf_, -inf_);
+        float x0 = q.x, y0 = q.y, x1 = q.z, y1 = q.w, z0 = qz.x, z1 = qz.y;
+        uint32_t mk = ok ? nd.wg_chmask[w] : 0u;
+        for (int d = 8; d >= 1; d >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, d));
+            y0 = fminf(y0, __shfl_xor(y0, d));
+            z0 = fminf(z0, __shfl_xor(z0, d));
+            x1 = fmaxf(x1, __shfl_xor(x1, d));
+            y1 = fmaxf(y1, __shfl_xor(y1, d));
+            z1 = fmaxf(z1, __shfl_xor(z1, d));
+            mk |= uint32_t(__shfl_xor(int(mk), d));
+        }
+        if (threadIdx.x == 0) {
+            s_box[0] = x0, s_box[1] = y0, s_box[2] = x1, s_box[3] = y1, s_box[4] = z0, s_box[5] = z1;
+            s_mask = mk;
+            s_n = 0u;
+        }
+    }
+    __syncthreads();
+    const float x0 = s_box[0], y0 = s_box[1], x1 = s_box[2], y1 = s_box[3], z0 = s_box[4], z1 = s_box[5];
+    const uint32_t mk = s_mask;
+    int32_t *const list = const_cast<int32_t *>(t.near_list) + size_t(sb) * size_t(t.near_cap);
+    for (int e0 = 0; e0 < n_eval; e0 += 256) { // block-uniform
+        const int e = e0 + int(threadIdx.x);
+        bool hit = false;
+        if (e < n_eval) {
+            const float4 f = t.p_txf[e];
+            const uint32_t ch = uint32_t(t.p_ch[e]) & 31u;
+            const float dx = fmaxf(fmaxf(x0 - f.x, f.x - x1), 0.f);
+            const float dy = fmaxf(fmaxf(y0 - f.y, f.y - y1), 0.f);
+            const float dz = fmaxf(fmaxf(z0 - f.z, f.z - z1), 0.f);
+            hit = dist2_f32(dx, dy, dz) <= f.w && ((mk >> ch) & 1u) != 0u; // (the workgroups' own test, against the larger box)
+        }
+        const uint64_t hm = ballot64(hit);
+        if (hm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, uint32_t(__popcll(hm)));
+            base = uniform_u(base);
+            if (hit) list[base + lane_prefix(hm)] = e;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) const_cast<uint32_t *>(t.near_cnt)[sb] = s_n;
+    // (Padding the list to the next 1024 entries with -1, so that phase A can ask for its entries before it knows the length --
+    // one round trip less per workgroup and tick -- was measured: 255 instead of 220 us per 64 ticks at a million receivers,
+    // the three extra loads per thread cost more than the round trip.)
 }
 
 template <int RPT, bool SHADOW>
@@ -917,6 +989,10 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
     const TickDev &t0 = ticks[0];
     RM_KLAUNCH(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
+    if (t0.near_list != nullptr) { // (every tick of the batch has its lists, or none has)
+        const int n_wg = cdiv(t0.n_rx, kGroup * 16);
+        RM_KLAUNCH(k_near_lists, dim3(cdiv(n_wg, kNearSb), 1, n), dim3(256), 0, s, nd, b, n_wg);
+    }
     // A workgroup keeps its receivers for `per_wg` ticks: as many as leave a few thousand workgroups for the chip (a table
     // of a million receivers has a thousand tiles: 16 ticks = 4 per workgroup; 100 k receivers: one tick per workgroup).
     const int tiles = cdiv(t0.n_slabs, kWavesPerBlock);

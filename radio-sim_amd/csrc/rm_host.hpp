@@ -307,6 +307,8 @@ struct rm_context : TickSlot {
     const rm_tx_record *host_src = nullptr; // the tick being prepared reads its records from this host-mapped block (prepare_tick)
     uint32_t transmit_seq = 0;
     DevBuf<rm::TickDev> d_ticks; // [RM_MAX_BATCH] descriptors of the running rm_batch_* call
+    DevBuf<int32_t> d_near_list;  // [ticks][blocks of kNearSb filter workgroups][frames] near-frame lists of a batch over a large table
+    DevBuf<uint32_t> d_near_cnt;  // [ticks][blocks]
     // larger batches: k_fetch_ticks reads them from pinned, host-mapped memory (two staging buffers, each
     // guarded by an event: it is rewritten only after the kernel that read it has completed)
     rm::TickDev *h_ticks[2] = {nullptr, nullptr};
