@@ -65,7 +65,7 @@ WORKLOADS = {
 # (c5: a result slot per tick of a batch holds ~45 k heard links; the per-receiver lists of RM_SINR_SCAN=0 want 2^25 entries: --link-capacity)
 # (c4: a tick of 5000 frames holds 0.5 M heard links and millions of list entries: 32 result slots of 2^23 per context)
 EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23, batch=32),
-         "c5": dict(link_capacity=1 << 18, batch=64)}
+         "c5": dict(link_capacity=1 << 18, batch=128)}
 
 
 def baseline_metric():

@@ -499,13 +499,20 @@ public:
         const size_t n = simulator->getNodes().size();
         if (!sync(simulator, simulator->getNodes())) return false; // the device mirrors the node table first
         if (n == 0) return true;
-        nodes.resize(n); rssi.resize(n); receiving.resize(n); channel.resize(n);
+        // room for every node, kept between the calls (a step's answer is a few of them: four fresh vectors of n elements --
+        // allocated, zeroed, paged in -- cost more than the query itself at 100 k nodes)
+        if (chgNodes_.size() < n) {
+            chgNodes_.resize(n); chgRssi_.resize(n); chgRecv_.resize(n); chgChan_.resize(n);
+        }
         int32_t count = 0;
-        if (rm_node_info_changed(ctx_, nodes.data(), rssi.data(), receiving.data(), channel.data(), int32_t(n), &count) != RM_OK) {
+        if (rm_node_info_changed(ctx_, chgNodes_.data(), chgRssi_.data(), chgRecv_.data(), chgChan_.data(), int32_t(n), &count) != RM_OK) {
             lastError = rm_last_error();
             return false;
         }
-        nodes.resize(size_t(count)); rssi.resize(size_t(count)); receiving.resize(size_t(count)); channel.resize(size_t(count));
+        nodes.assign(chgNodes_.begin(), chgNodes_.begin() + count);
+        rssi.assign(chgRssi_.begin(), chgRssi_.begin() + count);
+        receiving.assign(chgRecv_.begin(), chgRecv_.begin() + count);
+        channel.assign(chgChan_.begin(), chgChan_.begin() + count);
         return true;
     }
 
@@ -597,6 +604,8 @@ private:
         uploaded_ = sim->nodesVersion();
         return true;
     }
+    std::vector<int32_t> chgNodes_, chgRecv_, chgChan_; // nodeInfoChanged: room for every node
+    std::vector<double> chgRssi_;
     int kind_;
     bool tickMode_ = false, deviceEvents_ = false;
     std::vector<RadioPacket *> queue_;   // tick mode: transmit() calls since the last flush

@@ -45,6 +45,7 @@
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sys/socket.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -83,12 +84,58 @@ struct Connection {
     // pending output
     std::string out;
     uint64_t messagesIn = 0, messagesOut = 0;
-    // the node-info array of this emulator's time-step messages as it was sent last: the nodes' objects joined by commas.
-    // A step rewrites only the objects of nodes whose fields changed (in place when the new text is as long as the old).
-    std::vector<int32_t> infoNodes;   // this connection's nodes (node index), in registration order
-    std::string infoBody;
-    std::vector<uint32_t> infoAt;     // infoBody offset of node k's object
-    bool infoStale = true;            // the body has to be put together again from the nodes' texts
+    // The node-info array of this emulator's time-step messages as it was sent last: the nodes' objects joined by commas, kept
+    // in pieces of kInfoPiece nodes (every piece but the first begins with the comma that joins it to the one before).  A
+    // step rewrites only the objects of nodes whose fields changed; an object whose text changes its length -- a reception
+    // beginning or ending swaps "-99.99" for seventeen digits -- moves the few KB behind it in its piece, not the 7 MB
+    // behind it in the array.
+    static constexpr size_t kInfoPiece = 64;
+    std::vector<int32_t> infoNodes;      // this connection's nodes (node index), in registration order
+    std::vector<std::string> infoPieces;
+    std::vector<uint32_t> infoAt;        // offset of node k's object in its piece (piece k / kInfoPiece)
+    std::vector<uint16_t> infoLen;       // ... its length, and the length of the part that never changes: {"node-id":<id>,"rssi":
+    std::vector<uint16_t> infoHead;
+    size_t infoBytes = 0;                // the pieces' lengths, summed
+    // A time-step message in flight goes out of the pieces themselves (copying the array into `out` was most of what a step's
+    // messages cost): `out` is cut at stepMark, and between the two parts go stepHead, the pieces and "]}}\r\n".  The pieces
+    // are not touched while any of the message is unsent -- settleStep() copies the rest into `out` before that.
+    static constexpr size_t kNoStep = ~size_t(0);
+    size_t stepMark = kNoStep; // bytes of `out` that go before the step message (kNoStep: none in flight)
+    size_t stepOff = 0;        // bytes of the step message already sent
+    std::string stepHead;
+    static const char *stepTail() { return "]}}\r\n"; }
+    size_t stepLen() const { return stepHead.size() + infoBytes + 5; }
+    size_t pending() const { return out.size() + (stepMark == kNoStep ? 0 : stepLen() - stepOff); }
+    // the unsent part of the step message as (pointer, length) runs, at most `max_runs` of them
+    template <class F> void stepRuns(F &&run, size_t max_runs) const
+    {
+        size_t off = stepOff, runs = 0;
+        auto part = [&](const char *p, size_t len) {
+            if (off >= len) {
+                off -= len;
+                return;
+            }
+            if (runs < max_runs) run(p + off, len - off);
+            ++runs;
+            off = 0;
+        };
+        part(stepHead.data(), stepHead.size());
+        for (const std::string &pc : infoPieces) {
+            if (runs >= max_runs) return;
+            part(pc.data(), pc.size());
+        }
+        part(stepTail(), 5);
+    }
+    void settleStep() // the unsent rest of the step message becomes ordinary output
+    {
+        if (stepMark == kNoStep) return;
+        std::string rest;
+        rest.reserve(stepLen() - stepOff);
+        stepRuns([&](const char *p, size_t len) { rest.append(p, len); }, ~size_t(0));
+        out.insert(stepMark, rest);
+        stepMark = kNoStep;
+        stepOff = 0;
+    }
 
     bool setTime(int64_t time) // JSONClientConnection.java:361-367
     {
@@ -168,7 +215,7 @@ public:
             who.push_back(nullptr);
             for (auto &c : conns_)
                 if (c->fd >= 0) {
-                    fds.push_back({c->fd, short(POLLIN | (c->out.empty() ? 0 : POLLOUT)), 0});
+                    fds.push_back({c->fd, short(POLLIN | (c->pending() == 0 ? 0 : POLLOUT)), 0});
                     who.push_back(c.get());
                 }
             const int n = ::poll(fds.data(), nfds_t(fds.size()), 500);
@@ -245,10 +292,43 @@ private:
     {
         for (auto &cp : conns_) {
             Connection &c = *cp;
-            while (c.fd >= 0 && !c.out.empty()) {
-                const ssize_t n = ::send(c.fd, c.out.data(), c.out.size(), MSG_NOSIGNAL);
+            while (c.fd >= 0 && c.pending() != 0) {
+                // what is pending, in order: out[0, stepMark), the step message (head, node-info body, tail), the rest of out
+                constexpr int kIov = 512;
+                iovec iov[kIov + 2];
+                int ni = 0;
+                auto add = [&](const char *p, size_t len) {
+                    if (len) iov[ni++] = iovec{const_cast<char *>(p), len};
+                };
+                const bool step = c.stepMark != Connection::kNoStep;
+                const size_t before = step ? c.stepMark : c.out.size();
+                add(c.out.data(), before);
+                if (step) {
+                    size_t runs_len = 0;
+                    c.stepRuns([&](const char *p, size_t len) { add(p, len), runs_len += len; }, size_t(kIov));
+                    // (the rest of `out` only behind the WHOLE of the message's rest: a long array takes several calls)
+                    if (runs_len == c.stepLen() - c.stepOff) add(c.out.data() + before, c.out.size() - before);
+                }
+                msghdr mh{};
+                mh.msg_iov = iov;
+                mh.msg_iovlen = size_t(ni);
+                const ssize_t n = ::sendmsg(c.fd, &mh, MSG_NOSIGNAL);
                 if (n > 0) {
-                    c.out.erase(0, size_t(n));
+                    size_t left = size_t(n);
+                    const size_t a = std::min(left, before);
+                    c.out.erase(0, a);
+                    left -= a;
+                    if (step) {
+                        c.stepMark -= a;
+                        const size_t sv = std::min(left, c.stepLen() - c.stepOff);
+                        c.stepOff += sv;
+                        left -= sv;
+                        if (c.stepOff == c.stepLen()) {
+                            c.stepMark = Connection::kNoStep;
+                            c.stepOff = 0;
+                        }
+                        c.out.erase(0, left);
+                    }
                     continue;
                 }
                 if (n < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) break;
@@ -256,8 +336,9 @@ private:
             }
             // a peer that has stopped reading: the reference blocks that connection's own thread; one thread serves all
             // of them here, so the connection is given up once its backlog passes the cap
-            if (c.fd >= 0 && c.out.size() > kMaxBacklog) {
-                std::fprintf(stderr, "%s: %zu bytes unsent, peer not reading: closing\n", c.name.c_str(), c.out.size());
+            if (c.fd >= 0 && c.pending() > kMaxBacklog) {
+                std::fprintf(stderr, "%s: %zu bytes unsent, peer not reading: closing\n", c.name.c_str(), c.pending());
+                c.stepMark = Connection::kNoStep;
                 c.out.clear();
                 close(c);
             }
@@ -267,6 +348,7 @@ private:
     void close(Connection &c) // JSONClientConnection.close: the simulator keeps whatever referred to it
     {
         if (c.fd >= 0) {
+            c.settleStep();
             if (!c.out.empty()) { // what was already "written" in the reference's blocking send: one bounded attempt
                 const timeval tv{0, 200 * 1000};   // (a peer that does not read must not stall the poll loop)
                 ::setsockopt(c.fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
@@ -467,57 +549,87 @@ private:
     // ---- the node-info of a time-step message (net/JSONClientConnection.java:326-353: every node of the connection, every
     // step).  Writing a hundred thousand objects per step -- a shortest-digits double each -- was 4.3 ms of a step whose
     // evaluation takes 0.8; but between two steps most nodes' fields are what they were (idle, or still locked on the same
-    // frame).  So every node keeps the text of its object, every connection the joined text it sent last, and a step asks
-    // the device which nodes differ from what was reported last (rm_node_info_changed) and rewrites only those.
+    // frame).  So every connection keeps the array as it sent it last (Connection::infoPieces), and a step asks the device
+    // which nodes differ from what was reported last (rm_node_info_changed) and rewrites those objects' fields where they lie.
     struct NodeText {
         std::string quotedId; // the node id as a JSON string
-        std::string head;   // {"node-id":<id>,"rssi":   -- written once
-        std::string text;   // the whole object as it was sent last
         Connection *conn = nullptr;
         uint32_t slot = 0;  // place among its connection's nodes
     };
     std::vector<NodeText> nodeText_;   // by node index
-    static void writeNodeObject(NodeText &t, const Info &v)
+    std::vector<int32_t> chgIdx_, chgRecv_, chgChan_;
+    std::vector<double> chgRssi_;
+    // the part of a node's object behind "rssi": -- <rssi>,"receiving":<r>,"wireless-channel":<c>} -- into buf (at least 112 bytes)
+    static size_t writeNodeFields(char *buf, const Info &v)
     {
-        t.text.assign(t.head);
-        append_double(t.text, v.rssi);
-        t.text += ",\"receiving\":";
-        append_int(t.text, v.receiving);
-        t.text += ",\"wireless-channel\":";
-        append_int(t.text, v.channel);
-        t.text += '}';
+        std::string tmp; // (short: stays in the string's own buffer for every value but a seventeen-digit rssi)
+        append_double(tmp, v.rssi);
+        size_t n = tmp.size();
+        std::memcpy(buf, tmp.data(), n);
+        auto lit = [&](const char *t) {
+            const size_t l = std::strlen(t);
+            std::memcpy(buf + n, t, l);
+            n += l;
+        };
+        auto num = [&](int64_t x) { n = size_t(std::to_chars(buf + n, buf + n + 24, x).ptr - buf); };
+        lit(",\"receiving\":");
+        num(v.receiving);
+        lit(",\"wireless-channel\":");
+        num(v.channel);
+        buf[n++] = '}';
+        return n;
     }
-    void noteNode(Node *n, Connection *c) // a node seen for the first time
+    void noteNode(Node *n, Connection *c) // a node seen for the first time: its object joins its connection's array
     {
         if (nodeText_.size() <= size_t(n->index)) nodeText_.resize(size_t(n->index) + 1);
         NodeText &t = nodeText_[size_t(n->index)];
         t.quotedId.clear();
         Json::quote(n->getId(), t.quotedId);
-        t.head = "{\"node-id\":";
-        t.head += t.quotedId;
-        t.head += ",\"rssi\":";
         t.conn = c;
         t.slot = uint32_t(c->infoNodes.size());
+        c->settleStep(); // (a step message in flight reads the pieces)
         c->infoNodes.push_back(n->index);
-        c->infoStale = true;
-        writeNodeObject(t, {n->getRadio().getRSSI(), n->getRadio().getReceivingState(), n->getRadio().getWirelessChannel()});
+        if (t.slot % Connection::kInfoPiece == 0) c->infoPieces.emplace_back();
+        std::string &piece = c->infoPieces.back();
+        const size_t size0 = piece.size();
+        if (t.slot) piece += ',';
+        const size_t at = piece.size();
+        piece += "{\"node-id\":";
+        piece += t.quotedId;
+        piece += ",\"rssi\":";
+        const size_t head = piece.size() - at;
+        char buf[128];
+        piece.append(buf, writeNodeFields(buf, {n->getRadio().getRSSI(), n->getRadio().getReceivingState(), n->getRadio().getWirelessChannel()}));
+        if (piece.size() - at > 65000) throw std::runtime_error("node id too long for a node-info object");
+        c->infoAt.push_back(uint32_t(at));
+        c->infoHead.push_back(uint16_t(head));
+        c->infoLen.push_back(uint16_t(piece.size() - at));
+        c->infoBytes += piece.size() - size0;
     }
     void applyNodeInfo(int32_t index, const Info &v)
     {
-        NodeText &t = nodeText_[size_t(index)];
-        const size_t before = t.text.size();
-        writeNodeObject(t, v);
+        const NodeText &t = nodeText_[size_t(index)];
         Connection &c = *t.conn;
-        if (c.infoStale) return;
-        if (t.text.size() == before) std::memcpy(&c.infoBody[c.infoAt[t.slot]], t.text.data(), before); // same length: in place
-        else c.infoStale = true;
+        char buf[128];
+        const size_t len = writeNodeFields(buf, v);
+        std::string &piece = c.infoPieces[t.slot / Connection::kInfoPiece];
+        const size_t at = size_t(c.infoAt[t.slot]) + c.infoHead[t.slot], before = size_t(c.infoLen[t.slot]) - c.infoHead[t.slot];
+        if (len == before) { // same length: in place
+            std::memcpy(&piece[at], buf, len);
+            return;
+        }
+        piece.replace(at, before, buf, len);
+        const size_t last = std::min(c.infoNodes.size(), (t.slot / Connection::kInfoPiece + 1) * Connection::kInfoPiece);
+        for (size_t k = size_t(t.slot) + 1; k < last; ++k) c.infoAt[k] = uint32_t(c.infoAt[k] + len - before);
+        c.infoLen[t.slot] = uint16_t(c.infoHead[t.slot] + len);
+        c.infoBytes = c.infoBytes + len - before;
     }
     // once per step, before the time-step messages: bring the nodes' texts up to the device's radio state
     void refreshNodeInfo()
     {
         if (medium_) {
-            std::vector<int32_t> idx, recv, chan;
-            std::vector<double> rssi;
+            std::vector<int32_t> &idx = chgIdx_, &recv = chgRecv_, &chan = chgChan_; // (members: their room is kept between the steps)
+            std::vector<double> &rssi = chgRssi_;
             if (!medium_->nodeInfoChanged(idx, rssi, recv, chan)) {
                 mediumError("node-info");
                 throw std::runtime_error("node-info failed");
@@ -525,6 +637,7 @@ private:
             for (size_t k = 0; k < idx.size(); ++k)
                 if (size_t(idx[k]) < nodeText_.size() && nodeText_[size_t(idx[k])].conn) applyNodeInfo(idx[k], {rssi[k], recv[k], chan[k]});
             nodeInfoChanges_ += idx.size();
+            if (stepMessages_ > 0) nodeInfoChangesLater_ += idx.size();
         } else { // no medium: nothing ever starts a reception, the host's radios are the state
             for (Node *n : sim_.getNodes())
                 if (size_t(n->index) < nodeText_.size() && nodeText_[size_t(n->index)].conn)
@@ -533,28 +646,18 @@ private:
     }
     void emulateToTime(Connection &c, int64_t time, int64_t timeId) // JSONClientConnection.java:326-353
     {
-        if (c.infoStale) { // (a node joined, or an object changed its length: the joined text once more)
-            c.infoBody.clear();
-            c.infoAt.resize(c.infoNodes.size());
-            for (size_t k = 0; k < c.infoNodes.size(); ++k) {
-                if (k) c.infoBody += ',';
-                c.infoAt[k] = uint32_t(c.infoBody.size());
-                c.infoBody += nodeText_[size_t(c.infoNodes[k])].text;
-            }
-            c.infoStale = false;
-        }
         if (!c.open()) return; // send() on a closed connection: nothing goes out
         // {"command":"time-step","id":..,"parameters":{"time":..,"node-info":[{..},..]}} -- written directly: this is
-        // the one message whose size grows with the node count
-        std::string &o = c.out;
-        o += "{\"command\":\"time-step\",\"id\":";
+        // the one message whose size grows with the node count, and its array goes out of the pieces themselves (Connection::stepMark)
+        std::string &o = c.stepHead;
+        o.assign("{\"command\":\"time-step\",\"id\":");
         append_int(o, timeId);
         o += ",\"parameters\":{\"time\":";
         append_int(o, time);
         o += ",\"node-info\":[";
-        o += c.infoBody;
-        o += "]}}";
-        c.sent();
+        c.stepMark = c.out.size();
+        c.stepOff = 0;
+        ++c.messagesOut;
     }
     void stepTime(int64_t time, int64_t id) // :171-194
     {
@@ -570,9 +673,12 @@ private:
         emulatorsLeft_ = int(emulators_.size());
         const std::vector<Connection *> em = emulators_;
         const auto t0 = std::chrono::steady_clock::now();
+        for (Connection *e : em) e->settleStep(); // (a step message still in flight: its unsent rest is copied before the body changes)
         refreshNodeInfo();
         for (Connection *e : em) emulateToTime(*e, time, waitingForTimeId_);
-        usStepMessages_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (stepMessages_++ == 0) usFirstStepMessages_ = us; // (the first one writes every node's object: reported on its own)
+        else usStepMessages_ += us;
     }
     void emulatorTimeStepped(Connection &client, int64_t id) // :134-153
     {
@@ -921,11 +1027,14 @@ public:
     void printStats() const
     {
         const double k = steps_ ? 1.0 / double(steps_) : 0.0;
+        const double k1 = stepMessages_ > 1 ? 1.0 / double(stepMessages_ - 1) : 0.0;
         std::fprintf(stderr,
                      "rsim_server: %llu steps, %llu transmissions, %llu deliveries, time %lld; per step: time-step messages %.1f us "
-                     "(%.1f node objects rewritten), medium (tick + drain, deliveries on the host) %.1f us, receive messages %.1f us\n",
+                     "(the first one, with every node's object written, %.1f us; %.1f node objects rewritten per step after it), "
+                     "medium (tick + drain, deliveries on the host) %.1f us, receive messages %.1f us\n",
                      (unsigned long long)steps_, (unsigned long long)transmissions_, (unsigned long long)deliveries_,
-                     (long long)sim_.getTime(), usStepMessages_ * k, double(nodeInfoChanges_) * k, usMedium_ * k, usReceiveMessages_ * k);
+                     (long long)sim_.getTime(), usStepMessages_ * k1, usFirstStepMessages_, double(nodeInfoChangesLater_) * k1, usMedium_ * k,
+                     usReceiveMessages_ * k);
     }
 
 private:
@@ -948,6 +1057,8 @@ private:
     double usStepMessages_ = 0, usMedium_ = 0, usReceiveMessages_ = 0; // the server's own work per step (printStats)
     const RadioPacket *framedPacket_ = nullptr; // deliverRadioPacket: the packet whose constant text is in framedHead_ / framedTail_
     std::string framedHead_, framedTail_;
+    uint64_t stepMessages_ = 0, nodeInfoChangesLater_ = 0;
+    double usFirstStepMessages_ = 0;
     uint64_t nodeInfoChanges_ = 0;     // node objects rewritten for time-step messages (the rest went out as they were)
 };
 

@@ -212,6 +212,45 @@ def test_nodes_time_steps_and_events(server):
         p.close()
 
 
+def test_step_message_in_flight_when_the_next_step_begins(server):
+    """The node-info array of a time-step message goes out of the connection's own copy of it, not through the output buffer
+    (rsim_server.cpp, Connection::stepMark).  An emulator that answers a step from the message's first bytes and reads the
+    rest later: the next step begins while most of the first message is unsent -- its rest is set aside before the array
+    is touched -- and what is written after a step message (a command reply, a log event) comes after it on the wire."""
+    ctl = connect(server)
+    emu = Peer.__new__(Peer)
+    emu.s = socket.socket()
+    emu.s.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4096)   # (before connect: a small window keeps the server's send short)
+    emu.s.settimeout(10)
+    emu.s.connect(("127.0.0.1", server))
+    emu.s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+    emu.buf = b""
+    assert emu.line() + b"\r\n" == GREETING
+    n = 60_000
+    emu.raw("".join('{"command":"node-config-set","parameters":{"node-id":%d,"position":[%d.5,2.0]}}' % (i + 1, i) for i in range(n)))
+    emu.send({"command": "subscribe-event", "id": 1})
+    assert emu.line(30.0) == b'{"id":1,"reply":"OK"}'
+    objs = ",".join('{"node-id":"%d","rssi":-99.99,"receiving":0,"wireless-channel":26}' % (i + 1) for i in range(n)).encode()
+    ctl.send({"command": "time-set", "id": 10, "parameters": {"time": 1000}})
+    head = b'{"command":"time-step","id":1001,"parameters":{"time":1000,"node-info":['
+    while len(emu.buf) < len(head):
+        emu.buf += emu.s.recv(4096)
+    assert emu.buf.startswith(head)
+    emu.send({"reply": "OK", "id": 1001})                # answered from the first bytes; megabytes of the message are unsent
+    assert ctl.line() == b'{"reply":"OK","id":10}'
+    emu.send({"command": "log", "parameters": {"node-id": 1, "message": "between"}})   # goes behind the step message
+    time.sleep(0.3)                                       # (two sockets: the server is to see the log first)
+    ctl.send({"command": "time-set", "id": 11, "parameters": {"time": 2000}})           # ... and so does the next step
+    time.sleep(0.2)
+    assert emu.line(60.0) == head + objs + b"]}}"
+    assert emu.line() == b'{"event":{"time":1000,"type":"log","source":"1","event-data":{"logMessage":"between"}},"id":0}'
+    assert emu.line(60.0) == head.replace(b"1001", b"1002").replace(b'"time":1000', b'"time":2000') + objs + b"]}}"
+    emu.send({"reply": "OK", "id": 1002})
+    assert ctl.line() == b'{"reply":"OK","id":11}'
+    ctl.close()
+    emu.close()
+
+
 def test_framing(server):
     c = connect(server)
     # brace counting: CR / LF between messages, braces and escaped quotes inside strings, nested objects

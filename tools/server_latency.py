@@ -1,6 +1,8 @@
 """Round trip of one simulated tick through the radio-link server (radio-sim_amd/host/rsim_server): a time controller and
 one emulator connection over TCP on the GPU box, UDGM medium, `n` nodes, `k` transmissions per tick.
-    python tools/server_latency.py [n] [k] [ticks]
+    python tools/server_latency.py [n] [k] [ticks] [packet bytes]
+(packet bytes: 8 by default -- a frame shorter than the tick, every radio idle again when the step ends; 127 is a full
+802.15.4 frame, 4 ms on the air: receptions span the steps, and thousands of nodes report a changed state every step)
 What is timed is what an emulator sees: time-set -> time-step (with node-info of all its nodes) -> k transmit commands
 -> its OK -> the receive messages -> the controller's reply.  The Python client's JSON work is part of it."""
 import json
@@ -17,6 +19,7 @@ from test_host_server import GREETING, Peer  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+pkt_hex = "".join("%02x" % (i & 255) for i in range(int(sys.argv[4]) if len(sys.argv) > 4 else 8))
 exe = os.path.join(ROOT, "radio-sim_amd", "host", "rsim_server")
 proc = subprocess.Popen([exe, "--port", "0", "--bind", "127.0.0.1", "--seed", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 try:
@@ -42,7 +45,7 @@ try:
                 break
             got += 1
         for s in rng.choice(n, k, replace=False):
-            emu.send({"command": "transmit", "node-id": int(s) + 1, "time": t * 1000 + 10, "packet-data": "0102030405060708"})
+            emu.send({"command": "transmit", "node-id": int(s) + 1, "time": t * 1000 + 10, "packet-data": pkt_hex})
         emu.send({"reply": "OK", "id": step["id"]})
         ctl.line()
         return step
@@ -60,7 +63,7 @@ try:
             got += 1
         if m.get("id") == 3 and "reply" in m:
             break
-    print(json.dumps({"nodes": n, "tx_per_tick": k, "ticks": ticks, "us_per_tick": dt * 1e6, "receive_messages": got}))
+    print(json.dumps({"nodes": n, "tx_per_tick": k, "ticks": ticks, "packet_bytes": len(pkt_hex) // 2, "us_per_tick": dt * 1e6, "receive_messages": got}))
 finally:
     proc.terminate()
     proc.wait(timeout=10)
