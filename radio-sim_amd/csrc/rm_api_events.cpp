@@ -61,11 +61,24 @@ int ev_ensure_nodes(rm_context *c)
 }
 
 // hand the evaluated tick of slot `ts` to the reception stage (Simulator.generate*Events for every packet / heard link)
-int ev_append(rm_context *c, TickSlot &ts)
+// the append that was left for the next drain, now on its own
+int ev_flush_append(rm_context *c)
+{
+    rm_context::Events::Pending &p = c->ev.pending;
+    if (!p.on) return RM_OK;
+    p.on = false;
+    RM_HIP(hipSetDevice(c->device));
+    RM_HIP(rm::launch_ev_append(c->stream, ev_dev(c), p.ls, p.tx, p.n_new, p.now, p.immediate, p.dropped));
+    c->ev.par ^= 1; // the launch wrote the other set of tails
+    return RM_OK;
+}
+
+int ev_append(rm_context *c, TickSlot &ts, bool may_wait)
 {
     if (!c->ev.on || !ts.have_result || ts.last_n_new <= 0) {
         return RM_OK;
     }
+    RM_TRY(ev_flush_append(c));
     RM_TRY(ev_ensure_nodes(c));
     const rm::TickDev &t = ts.last;
     rm::EvLinkSrc ls{};
@@ -87,10 +100,23 @@ int ev_append(rm_context *c, TickSlot &ts)
         ls.n_scan = 0;
         dropped = t.out_count + 1;
     }
+    ls.per_frame_verdict = (!ts.last_cfg.stochastic && !is_sinr(c)) ? 1 : 0;
     const int immediate = (c->params.kind == RM_MODEL_UDGM_CONST) ? 1 : 0;
+    c->ev.next_packet += ts.last_n_new;
+    static const bool never_wait = [] { const char *e = std::getenv("RM_EV_FUSE"); return e && std::atoi(e) == 0; }();
+    if (may_wait && !never_wait) { // (the closed loop: rm_events_process comes next, and takes the append into its first launch)
+        rm_context::Events::Pending &p = c->ev.pending;
+        p.on = true;
+        p.ls = ls;
+        p.tx = t.tx + t.first_new;
+        p.n_new = ts.last_n_new;
+        p.now = c->current_time;
+        p.immediate = immediate;
+        p.dropped = dropped;
+        return RM_OK;
+    }
     RM_HIP(rm::launch_ev_append(c->stream, ev_dev(c), ls, t.tx + t.first_new, ts.last_n_new, c->current_time, immediate, dropped));
     c->ev.par ^= 1; // the launch wrote the other set of tails
-    c->ev.next_packet += ts.last_n_new;
     return RM_OK;
 }
 
@@ -134,8 +160,10 @@ int rm_events_disable(rm_context *c)
     rm_context::Events &v = c->ev;
     if (v.on || v.h_out) {
         (void)hipSetDevice(c->device);
+        (void)ev_flush_append(c);
         (void)hipStreamSynchronize(c->stream);
     }
+    v.pending.on = false;
     v.d_st.release(); v.d_pk.release(); v.d_ldst.release(); v.d_lrssi.release(); v.d_lverdict.release();
     v.d_gtime.release(); v.d_gmeta.release(); v.d_gref.release(); v.d_grank.release(); v.d_cnt.release(); v.d_off.release(); v.d_grun.release(); v.d_run_rec.release();
     v.d_recv_key.release(); v.d_send_key.release(); v.d_receiving.release(); v.d_sending.release(); v.d_latched.release();
@@ -208,7 +236,15 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
     const uint32_t seq = ++c->ev.seq;
     // (the ring window the drain looks at: at most the packets numbered since the oldest pending one of the last drain)
     const int64_t window = c->ev.next_packet - c->ev.oldest_packet;
-    RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq, uint32_t(std::min<int64_t>(std::max<int64_t>(window, 1), 0x7FFFFFFF))));
+    rm_context::Events::Pending &pend = c->ev.pending;
+    if (pend.on) {
+        pend.on = false;
+        RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq, uint32_t(std::min<int64_t>(std::max<int64_t>(window, 1), 0x7FFFFFFF)),
+                                   &pend.ls, pend.tx, pend.n_new, pend.now, pend.immediate, pend.dropped));
+        c->ev.par ^= 1; // (the first launch appended: it wrote the other set of tails)
+    } else {
+        RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq, uint32_t(std::min<int64_t>(std::max<int64_t>(window, 1), 0x7FFFFFFF))));
+    }
     c->current_time = time_us; // Simulator.java:156
     volatile const uint32_t *flag = &o.hdr->seq;
     bool seen = false;

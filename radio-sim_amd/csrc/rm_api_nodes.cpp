@@ -453,6 +453,7 @@ int rm_node_count(const rm_context *c) { return c ? c->n : fail(RM_ERR_INVALID, 
 int rm_set_partition(rm_context *c, int32_t first, int32_t count)
 {
     if (!c || first < 0 || count < 0 || first + count > c->n) return fail(RM_ERR_INVALID, "partition out of range");
+    RM_TRY(ev_flush_append(c)); // (whose Transcievers live here is part of what an append writes)
     c->rx_first = first;
     c->rx_count = count;
     c->sp_part = c->sp_parts = 0;
@@ -465,6 +466,7 @@ int rm_set_partition_spatial(rm_context *c, int32_t part, int32_t n_parts)
 {
     if (!c || n_parts < 1 || part < 0 || part >= n_parts) return fail(RM_ERR_INVALID, "partition out of range");
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_flush_append(c));
     c->rx_first = 0;
     c->rx_count = -1;
     c->sp_part = (n_parts > 1) ? part : 0;

@@ -108,6 +108,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
 {
     const rm::PlanKnobs knobs = knobs_in ? *knobs_in : rm::read_plan_knobs();
     const int n_new = n_active - first_new;
+    RM_TRY(ev_flush_append(c)); // (the tick before, if its append was left for a drain that did not come: its records are about to go)
     ts.have_result = false;
     ts.compact_pending = false;
     ts.last_n_new = n_new;
@@ -552,7 +553,7 @@ int materialize(rm_context *c, TickSlot &ts)
 }
 
 int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list, int64_t src_start_us,
-             int64_t src_air_us, int air_mode, uint32_t air_oldest)
+             int64_t src_air_us, int air_mode, uint32_t air_oldest, bool ev_may_wait)
 {
     TickPlan plan;
     RM_TRY(prepare_tick(c, *c, plan, false, tx, n_active, first_new, src_list, src_start_us, src_air_us, air_mode, air_oldest));
@@ -562,7 +563,7 @@ int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new,
             // a tick without receivers on this rank: its packets exist all the same (slot_off of an empty tick is not written)
             RM_HIP(hipMemsetAsync(c->d_slot_off.p, 0, (size_t(std::max(c->last.n_cnt, 0)) + 2) * sizeof(uint32_t), c->stream));
         }
-        RM_TRY(ev_append(c, *c));
+        RM_TRY(ev_append(c, *c, ev_may_wait));
     }
     return RM_OK;
 }

@@ -175,6 +175,7 @@ int tick_run_host(rm_context *c)
     const size_t total = c->pending.size();
     bool zero_copy = false;
     int staged = -1;
+    RM_TRY(ev_flush_append(c)); // (an append left for a drain reads the records of the tick before out of d_tx)
     if (!sinr) RM_HIP(c->d_tx.ensure(std::max<size_t>(total, 1)));
     if (total) {
         // through pinned staging: the copy is asynchronous, the buffer is reused only after its copy has completed
@@ -407,6 +408,7 @@ int rm_transmit(rm_context *c, int32_t src, int64_t start_us, int64_t hex_length
             // the kernel declined (unbounded range or more links than its LDS lists hold) and changed nothing
         }
     }
+    RM_TRY(ev_flush_append(c));
     RM_HIP(c->d_tx.ensure(1));
     RM_HIP(rm::launch_store_record(c->stream, rec, c->d_tx.p));
     RM_TRY(run_tick(c, c->d_tx.p, 1, 0));
@@ -488,8 +490,10 @@ int rm_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
     if (!is_sinr(c)) {
+        RM_TRY(ev_flush_append(c));
         RM_HIP(c->d_tx.ensure(std::max(n, 1)));
-        return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us);
+        // (the closed loop's call: rm_events_process follows at once and takes this tick's append into its first launch)
+        return run_tick(c, c->d_tx.p, n, 0, dev_src, start_us, air_us, kAirNone, 0, true);
     }
     return air_tick_device(c, t_begin_us, dev_src, nullptr, n, start_us, air_us, start_us + air_us, false);
 }

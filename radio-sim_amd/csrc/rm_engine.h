@@ -472,6 +472,7 @@ struct EvLinkSrc {
     const uint32_t *off;   // [n_new] first link of packet q (compact arrays: [n_new + 1], cnt == nullptr)
     const uint32_t *cnt;   // [n_new] or nullptr
     int n_scan;            // segments: entries of cnt to scan for the pool positions (n_cnt), 0 = off is the scan
+    int per_frame_verdict; // every link of a frame carries the same verdict (no draws, no SINR: the frame's transmission failed or not)
 };
 
 // the delivery list of one drain in host-mapped memory
@@ -605,7 +606,11 @@ hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,
                             int immediate, const uint32_t *dropped_flag);
 // window: the host's bound on the pending packets (0: unknown)
-hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window);
+// (fresh_*: the tick whose append has been left for this drain -- append and selection in one launch; e.par is then the parity
+// that append reads)
+hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window,
+                           const EvLinkSrc *fresh_ls = nullptr, const rm_tx_record *fresh_tx = nullptr, int fresh_n = 0, int64_t fresh_now = 0,
+                           int fresh_immediate = 0, const uint32_t *fresh_dropped = nullptr);
 hipError_t launch_node_info(hipStream_t s, const EvDev &e, const NodesDev &nd, const int32_t *dev_nodes, int n, double base_rssi,
                             const NodeInfoOut &out, uint32_t seq);
 hipError_t launch_node_info_changed(hipStream_t s, const EvDev &e, const NodesDev &nd, int n, double base_rssi, double *rep_rssi,

@@ -48,9 +48,8 @@ RM_D bool owned(const EvDev &e, int node)
 // One evaluated tick handed to the event stage: per packet an EvPacket (event times, ladders, packet
 // number) and a copy of its heard links.  What Simulator.generate*Events does per call, for the whole tick.
 template <bool SEG>
-__global__ void __launch_bounds__(256)
-k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ tx, int n_new, int64_t now, int immediate,
-            const uint32_t *dropped_flag)
+RM_D void ev_append_body(const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *__restrict__ tx, int n_new, int64_t now, int immediate,
+                         const uint32_t *dropped_flag, const int blk, const int n_blk)
 {
     __shared__ uint32_t s_off[SEG ? kFusedScanMax + 1 : 1];
     __shared__ uint32_t s_wave[4];
@@ -74,7 +73,7 @@ k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ 
     const int lane = threadIdx.x & 63;
     int64_t wave_top = kI64Min; // latest event of this wave's packets that waits in the queue's top list
     if (!err) {
-        for (int q = blockIdx.x * 4 + wave_index(); q < n_new; q += gridDim.x * 4) { // wave-uniform
+        for (int q = blk * 4 + wave_index(); q < n_new; q += n_blk * 4) { // wave-uniform
             const rm_tx_record r = tx[q];
             const uint32_t cnt = uniform_u(SEG ? ls.cnt[q] : (ls.off[q + 1] - ls.off[q]));
             const uint32_t src0 = uniform_u(ls.off[q]);
@@ -130,7 +129,7 @@ k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ 
         if (m4 != kI64Min) amax_i64(&st.top_max, m4);
     }
     // the tails after this tick, for the next launch (see EvTails): every workgroup computed the same values
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         EvTails nt = tl;
         nt.err = tl.err | err;
         if (!err) {
@@ -142,22 +141,101 @@ k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ 
     }
 }
 
+template <bool SEG>
+__global__ void __launch_bounds__(256)
+k_ev_append(const EvDev e, const EvLinkSrc ls, const rm_tx_record *__restrict__ tx, int n_new, int64_t now, int immediate,
+            const uint32_t *dropped_flag)
+{
+    ev_append_body<SEG>(e, ls, tx, n_new, now, immediate, dropped_flag, int(blockIdx.x), int(gridDim.x));
+}
+
 // ============================================================================ drain
 // k_ev_select: which (packet, flank) groups fire in processAllEvents(T)?  Sort key = (time, meta).
 RM_D uint64_t ev_meta(uint32_t lad_rel, uint32_t order, uint32_t phase) { return (uint64_t(lad_rel) << 40) | (uint64_t(order) << 1) | phase; }
 
-__global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
+// The tick whose append runs in the SAME launch as the selection (k_ev_append_select): its packets are not in the ring yet, so
+// the selection derives what it needs of them -- event times, ladders, flags, deliveries -- from the tick's own records, the
+// way the append does.
+struct EvFresh {
+    EvLinkSrc ls;
+    const rm_tx_record *tx;
+    int n_new;
+    int64_t now;
+    int immediate;
+    const uint32_t *dropped_flag;
+};
+
+template <bool FRESH, bool SEG>
+RM_D void ev_select_body(const EvDev &e, const int64_t T, const uint32_t blk, const EvFresh &fr)
 {
     EvState &st = *e.st;
-    const uint32_t head = st.pk_head, w = st.tails[e.par].pk_tail - head;
+    const EvTails tl = st.tails[e.par]; // (FRESH: the tails before the tick's append, which writes the other set)
+    const uint32_t head = st.pk_head, w_old = tl.pk_tail - head;
+    uint32_t w = w_old;
+    EvOrder ord;
+    if (FRESH) { // does the append keep the tick?  (its own tests: ev_append_body)
+        __shared__ uint32_t s_tot[4];
+        uint32_t total = 0;
+        if (SEG) {
+            uint32_t part = 0;
+            for (int i = threadIdx.x; i < fr.ls.n_scan; i += 256) part += fr.ls.cnt[i];
+            for (int d = 32; d >= 1; d >>= 1) part += uint32_t(__shfl_xor(int(part), d));
+            if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = part;
+            __syncthreads();
+            total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+        } else {
+            total = fr.ls.off[fr.n_new];
+        }
+        bool err = fr.dropped_flag && *fr.dropped_flag != 0u;
+        err = err || (tl.pk_tail - head + uint32_t(fr.n_new) > e.pk_mask + 1u);
+        err = err || (tl.pool_tail - st.pool_head + total > e.pool_mask + 1u);
+        if (!err) w += uint32_t(fr.n_new);
+        ord.top_start = st.top_start;
+        ord.ladders = st.ladders;
+        ord.top_max = 0;
+        ord.top_nonempty = 0;
+    }
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x * blockDim.x >= ((w + 63u) & ~63u)) return; // (the grid is sized for the host's bound on the window)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk * blockDim.x >= ((w + 63u) & ~63u)) return; // (the grid is sized for the host's bound on the window)
+    const uint32_t i = blk * blockDim.x + threadIdx.x;
     const uint32_t idx = (head + i) & e.pk_mask;
     EvPacket p{};
     bool valid = false;
-    if (i < w) {
+    if (i < w_old) {
         p = e.pk[idx];
+        valid = !(p.flags & kEvDone);
+    } else if (FRESH && i < w) { // a packet of the tick being appended
+        const int q = int(i - w_old);
+        const rm_tx_record r = fr.tx[q];
+        const uint32_t cnt = SEG ? fr.ls.cnt[q] : (fr.ls.off[q + 1] - fr.ls.off[q]);
+        const uint32_t src0 = fr.ls.off[q];
+        uint32_t n_deliver = 0;
+        if (fr.ls.per_frame_verdict) { // (one load instead of a chain of them: this thread has the packet to itself)
+            if (cnt != 0u && fr.ls.verdict[src0] == RM_DELIVERED) n_deliver = cnt;
+        } else {
+            uint32_t j = 0;
+            for (; j + 8u <= cnt; j += 8u) { // eight loads in flight
+                uint8_t v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v8[u] = fr.ls.verdict[src0 + j + uint32_t(u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) n_deliver += (v8[u] == RM_DELIVERED) ? 1u : 0u;
+            }
+            for (; j < cnt; ++j) n_deliver += (fr.ls.verdict[src0 + j] == RM_DELIVERED) ? 1u : 0u;
+        }
+        int64_t t0 = r.start_us; // Simulator.java:323-326
+        if (t0 < fr.now) t0 = fr.now;
+        p.t0 = t0;
+        p.t1 = t0 + r.air_us;
+        p.gseq = tl.gseq_next + q;
+        p.src = r.src;
+        p.lad0 = ev_ladder(ord, p.t0);
+        p.lad1 = ev_ladder(ord, p.t1);
+        p.flags = 0u;
+        if (fr.immediate) p.flags |= kEvImmediate | kEvNoTx;
+        else if (r.src < 0 || !owned(e, r.src)) p.flags |= kEvNoTx;
+        if (r.src < 0) p.flags |= kEvStartDone | kEvDone;
+        p.n_deliver = n_deliver;
         valid = !(p.flags & kEvDone);
     }
     // the oldest packet with events still queued BEFORE this drain: k_ev_finish moves the ring heads up to it (the
@@ -171,7 +249,7 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
         __syncthreads();
         if (threadIdx.x == 0 && s_live != 0xFFFFFFFFu) atomicMin(&st.first_live, s_live); // one per workgroup
     }
-    const int64_t gseq_head = e.pk[head & e.pk_mask].gseq;
+    const int64_t gseq_head = (FRESH && w_old == 0u) ? tl.gseq_next : e.pk[head & e.pk_mask].gseq; // (an empty ring: the tick's first packet)
     const uint32_t rel = uint32_t(p.gseq - gseq_head);
     const int32_t lb = st.ladders;
     const bool imm = (p.flags & kEvImmediate) != 0u;
@@ -215,15 +293,96 @@ __global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
     }
 }
 
+__global__ void __launch_bounds__(256) k_ev_select(const EvDev e, int64_t T)
+{
+    ev_select_body<false, false>(e, T, blockIdx.x, EvFresh{});
+}
+
+// The closed loop's tick and drain follow each other at once (Simulator.java:155-165): the tick's append and the drain's
+// selection in ONE launch -- the first n_append workgroups append, the others select; neither reads what the other writes.
+template <bool SEG>
+__global__ void __launch_bounds__(256) k_ev_append_select(const EvDev e, const EvFresh fr, const int64_t T, const int n_append)
+{
+    if (int(blockIdx.x) < n_append)
+        ev_append_body<SEG>(e, fr.ls, fr.tx, fr.n_new, fr.now, fr.immediate, fr.dropped_flag, int(blockIdx.x), n_append);
+    else
+        ev_select_body<true, SEG>(e, T, blockIdx.x - uint32_t(n_append), fr);
+}
+
+// A fired end group's deliveries, into the host-mapped list at the place its rank gives them, and its run record.  One wave.
+// (verdict_first / d_first / rssi_first: the first 64 links' records, asked for by the caller in front of whatever it had to
+// wait for.)
+RM_D void ev_write_deliveries(const EvDev &e, const EvOut &out, const int64_t gseq, const uint32_t cnt, const uint32_t off0, const bool imm,
+                              const uint32_t n_del, const uint32_t first, const uint32_t run, const int lane, const uint8_t verdict_first,
+                              const int d_first, const double rssi_first)
+{
+    if (n_del == 0u) return;
+    if (lane == 0) { // the run: the packet's number once, not with each delivery -- left in device memory
+        // (write-through: the workgroup that finishes the drain, on whatever XCD, copies all runs to the host in one go;
+        // a thousand scattered 16-byte writes over PCIe cost more than the deliveries' packet numbers had)
+        if (run < out.run_cap) {
+            __hip_atomic_store(&e.run_rec[2u * run], (unsigned long long)gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&e.run_rec[2u * run + 1u], (unsigned long long)first | ((unsigned long long)n_del << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    uint32_t seen = 0;
+    for (uint32_t j0 = 0; j0 < cnt; j0 += 64) { // wave-uniform
+        const uint32_t j = j0 + lane;
+        bool deliver = false;
+        uint32_t o = 0;
+        if (j < cnt) {
+            o = (off0 + j) & e.pool_mask;
+            deliver = (j0 == 0u ? verdict_first : e.l_verdict[o]) == RM_DELIVERED;
+        }
+        const uint64_t dm = ballot64(deliver);
+        if (deliver) {
+            const uint32_t nth = seen + lane_prefix(dm); // n-th delivered link of the packet in node order
+            // queued end events pop in reverse insertion order = reverse node order; the constant-loss
+            // medium delivers synchronously in node order
+            const uint32_t pos = first + (imm ? nth : (n_del - 1u - nth));
+            if (pos < out.cap) { // host-mapped memory: write-through stores at system scope (drained by the storing workgroup
+                // before it reports in or ends: no release fence, which would also write back this XCD's whole L2)
+                __hip_atomic_store(&out.dst[pos], j0 == 0u ? d_first : e.l_dst[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&out.rssi[pos], j0 == 0u ? rssi_first : e.l_rssi[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        seen += uint32_t(__popcll(dm));
+    }
+}
+
 // k_ev_emit: one wave per fired group: its place in the pop order, and every event's (rank, event) key to the fields of
 // the node it touches (the last-writer contest).  The deliveries themselves are written by k_ev_apply: they depend on
 // nothing the contest decides, and their stores into host-mapped memory (PCIe-bound) then run under the state update.
-__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
+__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out, const int share)
 {
     const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
     for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
         const uint32_t ref = uniform_u(e.g_ref[g]);
+        // (the packet's fields and its first 64 links' nodes are asked for here, in front of the pass over the keys: they
+        // depend on nothing the pass finds, and behind it they were two more dependent round trips per group)
+        const EvPacket &p = e.pk[ref >> 1];
+        const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
+        const int src = uniform_i(p.src);
+        const bool start = (ref & 1u) != 0u;
+        const bool imm = (fl & kEvImmediate) != 0u;
+        // (share: every share-th end group's deliveries go out from here -- the host-mapped list is PCIe-bound, 0.5 MB per
+        // drain, and half of it under this kernel's pass and contest leaves k_ev_apply the other half)
+        const bool mine = !start && share > 0 && (g % uint32_t(share)) == 0u;
+        const uint32_t n_del_g = mine ? uniform_u(e.cnt_by_rank[g]) : 0u;
+        int d_first = 0;
+        uint8_t sending_first = 0, verdict_first = 0;
+        double rssi_first = 0.0;
+        if (uint32_t(lane) < cnt && (!(imm && !start) || n_del_g != 0u)) {
+            const uint32_t o = (off0 + uint32_t(lane)) & e.pool_mask;
+            d_first = e.l_dst[o];
+            if (start) sending_first = e.sending[d_first];
+            if (n_del_g != 0u) {
+                verdict_first = e.l_verdict[o];
+                rssi_first = e.l_rssi[o];
+            }
+        }
         // The group's place in the queue's pop order = the number of fired groups with a smaller key (keys are unique), and
         // the place of its deliveries in the list = the deliveries of those groups: one pass of the wave over all groups'
         // keys (a few thousand, L2-resident) -- no sort, no scan, no launch in between.
@@ -264,20 +423,16 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
                 e.g_run[g] = run;       // ... as this run of the list
             }
         }
-        const EvPacket &p = e.pk[ref >> 1];
-        const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
-        const int src = uniform_i(p.src);
-        const bool start = (ref & 1u) != 0u;
-        const bool imm = (fl & kEvImmediate) != 0u;
+        if (mine) ev_write_deliveries(e, out, p.gseq, cnt, off0, imm, n_del_g, first, uniform_u(run), lane, verdict_first, d_first, rssi_first);
         if (start) {
             // ReceptionEvent start flank: setReceiving = clearSending + latch (Transciever.java:80-84)
             for (uint32_t j = lane; j < cnt; j += 64) {
                 const uint32_t o = (off0 + j) & e.pool_mask;
                 const unsigned long long k = ev_key(r, kEvRxStart, o);
-                const int d = e.l_dst[o];
+                const int d = (j < 64u) ? d_first : e.l_dst[o];
                 amax_key(&e.recv_key[d], k);
                 // clearSending only matters on a node that is sending or starts to in this drain (marked by k_ev_select)
-                if (e.sending[d] || __hip_atomic_load(&e.send_key[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)
+                if (((j < 64u) ? sending_first : e.sending[d]) || __hip_atomic_load(&e.send_key[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)
                     amax_key(&e.send_key[d], k);
             }
             // TransmissionEvent start: setSending = clearReceiving + sendingPacket (Transciever.java:106-109)
@@ -290,7 +445,7 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
             if (!imm)
                 for (uint32_t j = lane; j < cnt; j += 64) { // end flank: clearReceiving, whichever packet
                     const uint32_t o = (off0 + j) & e.pool_mask;
-                    amax_key(&e.recv_key[e.l_dst[o]], ev_key(r, kEvRxEnd, o));
+                    amax_key(&e.recv_key[(j < 64u) ? d_first : e.l_dst[o]], ev_key(r, kEvRxEnd, o));
                 }
             if (lane == 0 && !(fl & kEvNoTx)) amax_key(&e.send_key[src], ev_key(r, kEvTxEnd, 0u)); // clearSending
         }
@@ -300,55 +455,33 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e)
 RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t seq);
 
 // k_ev_apply: the last writer of a field writes it (and clears its key); the workgroup that is done last finishes the drain.
-__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out, int64_t T, uint32_t seq)
+__global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out, int64_t T, uint32_t seq, const int share)
 {
     __shared__ uint32_t s_lastwg;
     const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
     for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
+        // (everything indexed by the group at once, then the packet, then the first 64 links' records at once: four dependent
+        // round trips per group instead of seven)
         const uint32_t ref = uniform_u(e.g_ref[g]);
         const uint32_t r = uniform_u(e.g_rank[g]);
+        const uint32_t n_del_g = uniform_u(e.cnt_by_rank[g]), first_g = uniform_u(e.off_by_rank[g]), run_g = uniform_u(e.g_run[g]);
         EvPacket &p = e.pk[ref >> 1];
         const uint32_t cnt = uniform_u(p.link_cnt), off0 = uniform_u(p.link_off), fl = uniform_u(p.flags);
         const int src = uniform_i(p.src);
         const bool start = (ref & 1u) != 0u;
         const bool imm = (fl & kEvImmediate) != 0u;
-        if (!start) { // the group's deliveries, into the host-mapped list at the place its rank gives them
-            const uint32_t n_del = uniform_u(e.cnt_by_rank[g]), first = uniform_u(e.off_by_rank[g]);
-            if (n_del != 0u && lane == 0) { // the run: the packet's number once, not with each delivery -- left in device memory
-                // (write-through: the workgroup that finishes the drain, on whatever XCD, copies all runs to the host in one go;
-                // a thousand scattered 16-byte writes over PCIe cost more than the deliveries' packet numbers had)
-                const uint32_t run = e.g_run[g];
-                if (run < out.run_cap) {
-                    __hip_atomic_store(&e.run_rec[2u * run], (unsigned long long)p.gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&e.run_rec[2u * run + 1u], (unsigned long long)first | ((unsigned long long)n_del << 32), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            uint32_t seen = 0;
-            for (uint32_t j0 = 0; n_del != 0u && j0 < cnt; j0 += 64) { // wave-uniform
-                const uint32_t j = j0 + lane;
-                bool deliver = false;
-                uint32_t o = 0;
-                if (j < cnt) {
-                    o = (off0 + j) & e.pool_mask;
-                    deliver = e.l_verdict[o] == RM_DELIVERED;
-                }
-                const uint64_t dm = ballot64(deliver);
-                if (deliver) {
-                    const uint32_t nth = seen + lane_prefix(dm); // n-th delivered link of the packet in node order
-                    // queued end events pop in reverse insertion order = reverse node order; the constant-loss
-                    // medium delivers synchronously in node order
-                    const uint32_t pos = first + (imm ? nth : (n_del - 1u - nth));
-                    if (pos < out.cap) { // host-mapped memory: write-through stores at system scope (drained below, before the
-                        // workgroup is counted: no release fence, which would also write back this XCD's whole L2)
-                        __hip_atomic_store(&out.dst[pos], e.l_dst[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(&out.rssi[pos], e.l_rssi[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                }
-                seen += uint32_t(__popcll(dm));
-            }
+        int d_first = 0;
+        double rssi_first = 0.0;
+        uint8_t verdict_first = 0;
+        if (uint32_t(lane) < cnt) {
+            const uint32_t o = (off0 + uint32_t(lane)) & e.pool_mask;
+            d_first = e.l_dst[o];
+            if (start || n_del_g != 0u) rssi_first = e.l_rssi[o];
+            if (!start) verdict_first = e.l_verdict[o];
         }
+        if (!start && !(share > 0 && (g % uint32_t(share)) == 0u)) // (the other end groups' deliveries left with k_ev_emit)
+            ev_write_deliveries(e, out, p.gseq, cnt, off0, imm, n_del_g, first_g, run_g, lane, verdict_first, d_first, rssi_first);
         // the fired flank is done (k_ev_select of the next drain reads this; the other flank's wave reads only the bits
         // that never change)
         if (lane == 0) atomicOr(&p.flags, start ? kEvStartDone : (kEvDone | kEvStartDone));
@@ -356,10 +489,10 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out
             for (uint32_t j = lane; j < cnt; j += 64) {
                 const uint32_t o = (off0 + j) & e.pool_mask;
                 const unsigned long long k = ev_key(r, kEvRxStart, o);
-                const int d = e.l_dst[o];
+                const int d = (j < 64u) ? d_first : e.l_dst[o];
                 if (e.recv_key[d] == k) {
                     e.receiving[d] = 1;
-                    e.latched[d] = e.l_rssi[o];
+                    e.latched[d] = (j < 64u) ? rssi_first : e.l_rssi[o];
                     e.recv_key[d] = 0ull;
                 }
                 if (e.send_key[d] == k) {
@@ -383,7 +516,7 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out
                 for (uint32_t j = lane; j < cnt; j += 64) {
                     const uint32_t o = (off0 + j) & e.pool_mask;
                     const unsigned long long k = ev_key(r, kEvRxEnd, o);
-                    const int d = e.l_dst[o];
+                    const int d = (j < 64u) ? d_first : e.l_dst[o];
                     if (e.recv_key[d] == k) {
                         e.receiving[d] = 0;
                         e.recv_key[d] = 0ull;
@@ -587,16 +720,41 @@ hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, 
     return hipGetLastError();
 }
 
-hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window)
+hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int64_t time_us, uint32_t seq, uint32_t window,
+                           const EvLinkSrc *fresh_ls, const rm_tx_record *fresh_tx, int fresh_n, int64_t fresh_now, int fresh_immediate,
+                           const uint32_t *fresh_dropped)
 {
     // Three launches.  Selection (what fires before time_us; `window`: the host's bound on the pending packets); every
     // fired group's wave finds its place in the pop order by counting, writes its deliveries and enters the last-writer
     // contest of the radio fields; the winners write the state and the workgroup that is done last finishes the drain.
     const uint32_t pk_cap = e.pk_mask + 1u;
     const uint32_t w = (window == 0u || window > pk_cap) ? pk_cap : window;
-    RM_KLAUNCH(k_ev_select, dim3(cdiv(int(w), 256)), dim3(256), 0, s, e, time_us);
-    RM_KLAUNCH(k_ev_emit, dim3(512), dim3(256), 0, s, e);
-    RM_KLAUNCH(k_ev_apply, dim3(512), dim3(256), 0, s, e, out, time_us, seq);
+    EvDev after = e;
+    if (fresh_ls && fresh_n > 0) {
+        // the tick that was evaluated last has not been appended yet (rm_api_events.cpp: ev_append defers it to here): e.par is
+        // the parity its append reads, the stages behind it take the other one
+        EvFresh fr{};
+        fr.ls = *fresh_ls;
+        fr.tx = fresh_tx;
+        fr.n_new = fresh_n;
+        fr.now = fresh_now;
+        fr.immediate = fresh_immediate;
+        fr.dropped_flag = fresh_dropped;
+        const int n_append = max(1, min(256, cdiv(fresh_n, 4)));
+        const dim3 grid(n_append + cdiv(int(w), 256));
+        if (fr.ls.n_scan > 0) {
+            if (fr.ls.n_scan > kFusedScanMax) return hipErrorInvalidValue;
+            RM_KLAUNCH(k_ev_append_select<true>, grid, dim3(256), 0, s, e, fr, time_us, n_append);
+        } else {
+            RM_KLAUNCH(k_ev_append_select<false>, grid, dim3(256), 0, s, e, fr, time_us, n_append);
+        }
+        after.par = e.par ^ 1;
+    } else {
+        RM_KLAUNCH(k_ev_select, dim3(cdiv(int(w), 256)), dim3(256), 0, s, e, time_us);
+    }
+    static const int share = [] { const char *v = getenv("RM_EV_SHARE"); return v ? atoi(v) : 2; }(); // (0: every delivery from k_ev_apply)
+    RM_KLAUNCH(k_ev_emit, dim3(512), dim3(256), 0, s, after, out, share);
+    RM_KLAUNCH(k_ev_apply, dim3(512), dim3(256), 0, s, after, out, time_us, seq, share);
     return hipGetLastError();
 }
 

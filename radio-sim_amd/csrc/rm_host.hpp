@@ -206,6 +206,16 @@ struct rm_context : TickSlot {
         int64_t next_packet = 0;  // host mirror of EvTails::gseq_next
         int64_t oldest_packet = 0; // number of the oldest pending packet as the last drain published it (a bound on the ring window)
         int par = 0;              // which EvState::tails are current (flips with every appended tick)
+        // the tick evaluated last, not handed to the rings yet: a drain that follows at once takes it along (append + selection in
+        // one launch, rm_events.hip); anything else that comes first -- another tick above all -- appends it on its own
+        struct Pending {
+            bool on = false;
+            rm::EvLinkSrc ls{};
+            const rm_tx_record *tx = nullptr;
+            int n_new = 0, immediate = 0;
+            int64_t now = 0;
+            const uint32_t *dropped = nullptr;
+        } pending;
     } ev;
     DevBuf<uint8_t> d_enabled;   // Transciever.isEnabled by node index
 
@@ -419,7 +429,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
 int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan);
 int materialize(rm_context *c, TickSlot &ts);
 int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
-             int64_t src_start_us = 0, int64_t src_air_us = 0, int air_mode = kAirNone, uint32_t air_oldest = 0);
+             int64_t src_start_us = 0, int64_t src_air_us = 0, int air_mode = kAirNone, uint32_t air_oldest = 0, bool ev_may_wait = false);
 int drain_profile(rm_context *c);
 // a sampled launch sequence: begin_sample() returns the sample (or nullptr: not sampled) and routes the kernel probes of
 // this thread to it; sample_stage() names the stage of the launches that follow; end_sample() unroutes.  (ProbeScope
@@ -438,7 +448,8 @@ struct ProbeScope {
 // ---- rm_api_events.cpp: the reception stage
 rm::EvDev ev_dev(rm_context *c);
 int ev_ensure_nodes(rm_context *c);
-int ev_append(rm_context *c, TickSlot &ts);
+int ev_append(rm_context *c, TickSlot &ts, bool may_wait = false);
+int ev_flush_append(rm_context *c);
 
 // ---- rm_api_tick.cpp: results of an evaluated tick, the host-mapped result block
 rm_tx_record make_record(const rm_context *c, int32_t src, int64_t start_us, int64_t air_us, const double *txpower,
