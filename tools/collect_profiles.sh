@@ -61,7 +61,7 @@ fi
 if has pmc_m1; then pmc m1 16 $LEAN --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3; fi
 if has pmc_tick; then pmc c3_tick 1 $LEAN --inflight 1 --batch 1 --steps 200 --warmup 20; fi
 if has pmc_c4; then pmc c4 32 $LEAN --workload c4 --inflight 1 --steps 6 --warmup 2; fi
-if has pmc_c5; then pmc c5 64 $LEAN --workload c5 --steps 8 --warmup 2; pmc c5_tick 1 $LEAN --workload c5 --batch 1 --steps 60 --warmup 12; fi
+if has pmc_c5; then pmc c5 128 $LEAN --workload c5 --steps 6 --warmup 2; pmc c5_tick 1 $LEAN --workload c5 --batch 1 --steps 60 --warmup 12; fi
 if has pmc_dense; then
 stats dense --dense-only
 pmc dense 1 --dense-only
@@ -75,6 +75,8 @@ stamp $O/${ROUND}_c3_events_kernel_stats.csv
 rm -rf $O/ev_stats
 # ... and the closed loop through the C ABI
 (cd $R && tools/loop_latency > $O/${ROUND}_closed_loop_c_abi.jsonl 2> /dev/null || true)
+# ... and what the PCIe link takes of a tick's 0.55 MB of delivery records, by store width (tools/pcie_store_width.hip)
+(cd $R && [ -x tools/pcie_store_width ] && tools/pcie_store_width > $O/${ROUND}_pcie_store_width.jsonl 2> /dev/null || true)
 echo "events done"
 fi
 if has asrank; then
