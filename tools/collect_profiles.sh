@@ -84,6 +84,6 @@ if has asrank; then
 cd $R
 tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c3.jsonl 8 c3 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c3.jsonl > $O/${ROUND}_asrank8_c3.txt
 tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c4.jsonl 8 c4 256 32 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c4.jsonl > $O/${ROUND}_asrank8_c4.txt
-tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c5.jsonl 8 c5 64 64 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c5.jsonl > $O/${ROUND}_asrank8_c5.txt
+tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c5.jsonl 8 c5 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c5.jsonl > $O/${ROUND}_asrank8_c5.txt
 fi
 echo "all done: $PARTS"

@@ -29,14 +29,14 @@ import os
 import sys
 
 STAGE = (("k_dense_count<0>", "k_dense_count_null"), ("k_dense_write<0>", "k_dense_write_null"), ("k_dense_count<1>", "k_dense_count_udgm"),
-         ("k_dense_write<1>", "k_dense_write_udgm"), ("k_dense_scan", "k_dense_scan"), ("k_ov_pairs", "k_ov_pairs"), ("k_ov_exact", "k_ov_exact"), ("k_ov_verdict", "k_ov_verdict"), ("k_ov_", "k_ov_index"),
+         ("k_dense_write<1>", "k_dense_write_udgm"), ("k_dense_write", "k_dense_write"), ("k_dense_scan", "k_dense_scan"), ("k_ov_pairs", "k_ov_pairs"), ("k_ov_exact", "k_ov_exact"), ("k_ov_verdict", "k_ov_verdict"), ("k_ov_", "k_ov_index"),
          ("k_sinr_scan", "k_sinr_scan"), ("k_tick_frames", "k_tick_frames"), ("k_frames_cand", "k_filter"), ("k_tick_prep", "k_filter"), ("k_filter", "k_filter"), ("k_near_pairs", "k_filter"), ("k_exact", "k_exact"),
          ("k_reorder", "k_reorder"), ("k_self_entries", "k_self_entries"), ("k_sinr", "k_sinr"),
          ("k_cell_off", "k_cell_off+k_slot_scan"), ("k_slot_scan", "k_cell_off+k_slot_scan"), ("k_finalize", "k_finalize"))
 
 
 # access pattern of a stage's reads -> calibration entry (profiles/fetch_calibration.json)
-PATTERN = {"k_dense_count_null": "stream4", "k_dense_write_null": "stream4", "k_dense_count_udgm": "stream16", "k_dense_write_udgm": "stream16",
+PATTERN = {"k_dense_count_null": "stream4", "k_dense_write_null": "stream4", "k_dense_count_udgm": "stream16", "k_dense_write_udgm": "stream16", "k_dense_write": "stream16",
            "k_dense_scan": "stream4", "k_ov_pairs": "gather32", "k_ov_exact": "gather32", "k_ov_verdict": "stream16", "k_ov_index": "stream16", "k_sinr_scan": "gather32",
            "k_filter": "stream16", "k_reorder": "runs8", "k_self_entries": "stream4", "k_exact": "gather32", "k_sinr": "gather32",
            "k_finalize": "gather32", "k_cell_off+k_slot_scan": "stream4", "k_tick_frames": "stream16"}
