@@ -46,8 +46,9 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
     for (int b = 0; b < n; ++b) ticks[b] = plans[b].t;
     {
         // large tables: the near-frame lists of the filter's phase A (k_near_lists), per tick and block of kNearSb workgroups.
-        // RM_NEAR_LISTS=0 keeps phase A on all frames.
-        static const bool off = [] { const char *e = std::getenv("RM_NEAR_LISTS"); return e && std::atoi(e) == 0; }();
+        // RM_NEAR_LISTS=0 keeps phase A on all frames, 2 takes the lists for tables and ticks of any size (tests; read per batch).
+        const char *e_knob = std::getenv("RM_NEAR_LISTS");
+        const bool off = e_knob && std::atoi(e_knob) == 0, always = e_knob && std::atoi(e_knob) == 2;
         const rm::TickDev &t0 = ticks[0];
         const int n_wg = (t0.n_rx + rm::kGroup * 16 - 1) / (rm::kGroup * 16), n_sb = (n_wg + rm::kNearSb - 1) / rm::kNearSb;
         int max_eval = 0;
@@ -57,7 +58,7 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
             same = same && ticks[b].filter_mode == rm::kFilterWg && ticks[b].rpt == 4 && ticks[b].n_rx == t0.n_rx;
         }
         const size_t entries = size_t(n) * size_t(n_sb) * size_t(max_eval);
-        if (!off && same && plans[0].cfg.bbox && !plans[0].cfg.f64_filter && n_wg >= 4 * rm::kNearSb && max_eval >= 512 && entries <= (size_t(1) << 28)) {
+        if (!off && same && plans[0].cfg.bbox && !plans[0].cfg.f64_filter && ((n_wg >= 4 * rm::kNearSb && max_eval >= 512) || (always && max_eval >= 1)) && entries <= (size_t(1) << 28)) {
             RM_HIP(c->d_near_list.ensure(entries));
             RM_HIP(c->d_near_cnt.ensure(size_t(n) * size_t(n_sb)));
             for (int b = 0; b < n; ++b) {

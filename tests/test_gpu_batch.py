@@ -10,6 +10,17 @@ pytestmark = pytest.mark.gpu
 
 AIR = 8128
 
+
+@pytest.fixture(autouse=True, params=[None, "2"], ids=["", "near-lists"])
+def near_lists(request, monkeypatch):
+    """Every case twice: as the sizes here send it, and with the near-frame lists of the batch filter (k_near_lists: phase A of a
+    filter workgroup looks at the frames near its block of 16 workgroups) taken at any size -- by themselves they begin at 64
+    workgroups and 512 frames per tick (tests/test_gpu_fullsize.py runs there)."""
+    if request.param:
+        monkeypatch.setenv("RM_NEAR_LISTS", request.param)
+        monkeypatch.setenv("RM_WG_RPT", "4")      # (the lists go with the filter's 1024-receiver workgroups: taken here at any size, too)
+
+
 CASES = [
     ("udgm", {}, False),                                                    # reference UDGM, no draws
     ("udgm", dict(udgm_success_ratio_rx=0.8), True),                        # every heard link draws
@@ -70,11 +81,12 @@ def test_batch_matches_the_oracle_tick_by_tick(engine, rsa, O, kind, params, los
         d.free()
 
 
-def test_batch_equals_single_ticks_and_slot0_is_the_plain_result(engine, rsa, O):
+def test_batch_equals_single_ticks_and_slot0_is_the_plain_result(engine, rsa, O, near_lists, request):
     n = 20000
     nd = _layout(O, n, seed=9, lossy=True)
     params = dict(udgm_success_ratio_rx=0.9)
     configure_engine(engine, nd, "udgm", params)
+    engine.profile_enable(1)
     srcs = _ticks(n, 5, 400, seed=2)
     dev = [DeviceArray(s) for s in srcs]
     starts = [1000 * b for b in range(5)]
@@ -89,6 +101,8 @@ def test_batch_equals_single_ticks_and_slot0_is_the_plain_result(engine, rsa, O)
     for b in range(5):
         assert_same(engine.batch_result_copy(b, 400), singles[b], "tick %d" % b)
     assert engine.rng_state == after_singles
+    # (the second parametrisation does what it says: the batch's filter went through the near-frame lists)
+    assert any(k.startswith("k_near_lists") for k in engine.profile_kernels()) == ("near-lists" in request.node.name)
     assert_same(engine.result_copy(400), singles[0], "slot 0 through rm_result_copy")
     # a plain tick after a batch reuses slot 0 and is unaffected by the other slots
     engine.seed(5)

@@ -251,10 +251,14 @@ def test_a_full_pair_list_defers_frames_and_is_grown(rsa, O, monkeypatch):
         eng.close()
 
 
-def test_overlapping_batch_receiver_sharded(rsa, O):
+@pytest.mark.parametrize("near_lists", [None, "2"])
+def test_overlapping_batch_receiver_sharded(rsa, O, monkeypatch, near_lists):
     """Two and three receiver regions on one GPU: every rank sweeps the gathered frames of all ranks ([rank][tick][slot] source
     indices, padding included) against its receivers, keeps ALL frames on the air, and the ranks' links merged by node index
     are the whole batch's."""
+    if near_lists:
+        monkeypatch.setenv("RM_NEAR_LISTS", near_lists)   # (the batch filter's near-frame lists at these sizes too: padding frames, regions)
+        monkeypatch.setenv("RM_WG_RPT", "4")
     from radio_sim_amd import dist as D
     n, t, nb = 30_000, 240, 7
     nd, rng = _nodes(O, n, seed=14)
