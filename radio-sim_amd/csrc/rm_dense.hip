@@ -130,6 +130,9 @@ k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *ce
         const int q = q0 + int(threadIdx.x);
         const rm_tx_record tx = dense_frame(nd, t, q);
         if (t.src_list && chunk == 0) t.tx_build[t.first_new + q] = tx;
+        // (a caller's record with a transmit probability the node table does not have, in a tick planned without draws:
+        // reported when the result is read, as the other forms of the tick do)
+        if (chunk == 0 && t.check_txprob && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u;
         s_tx[threadIdx.x] = tx;
         s_sid[threadIdx.x] = (MODEL == RM_MODEL_N2N && tx.src >= 0) ? nd.sint_id[tx.src] : 0;
     }

@@ -216,10 +216,14 @@ def test_batched_sharded_driver_through_rccl_with_one_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
+    import socket
     for extra, env in ((["--batch", "16"], {}), (["--force-sharded", "--inflight", "3", "--batch", "16"], {"RM_DIST_SINGLE": "1"})):
+        with socket.socket() as sk:                    # (a port of its own per run: the one before may still be in TIME_WAIT)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "8",
                             "--warmup", "2", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, MASTER_PORT="29547", **env))
+                           env=dict(os.environ, MASTER_PORT=str(port), **env))
         assert p.returncode == 0, p.stderr[-2000:]
         lines = p.stdout.splitlines()
         assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[:500]
