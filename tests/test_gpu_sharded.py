@@ -194,7 +194,7 @@ def test_sharded_driver_with_frames_on_the_air_on_one_gpu():
     outs = []
     for extra in ([], ["--force-sharded"]):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c5", "--nodes", "200000", "--steps", "14",
-                            "--warmup", "10", "--no-cpu-baseline", "--no-host-transfer"] + extra, capture_output=True, text=True, timeout=600)
+                            "--warmup", "10", "--batch", "1", "--link-capacity", str(1 << 21), "--no-cpu-baseline", "--no-host-transfer"] + extra, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
         outs.append(json.loads(line))
@@ -202,7 +202,9 @@ def test_sharded_driver_with_frames_on_the_air_on_one_gpu():
     if sinr_lists_forced():                            # (the list form: tools/knob_sweep.sh)
         assert ("1 rebuilt those" if os.environ.get("RM_AIR_LISTS") != "0" else "0 added their frames to per-receiver lists") in outs[1]["config"]["workload"]
     else:
-        assert "by scan, 0 added their frames to per-receiver lists, 0 rebuilt those" in outs[1]["config"]["workload"]
+        import re
+        m = re.search(r"(\d+) lone ticks among the frames by scan, 0 added their frames to per-receiver lists, 0 rebuilt those", outs[1]["config"]["workload"])
+        assert m and int(m.group(1)) >= 24, outs[1]["config"]["workload"]
 
 
 def test_batched_sharded_driver_through_rccl_with_one_rank():
