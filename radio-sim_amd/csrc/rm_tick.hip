@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(256) k_frames_cand(const NodesDev nd, const Mo
 // ---------------------------------------------------------------------------------------------------
 // The tick's result written straight from the frames' segments into the host-mapped block of
 // rm_tick_flush* (header, packet offsets, Tx-failure flags, records): every workgroup redoes the scan
-// of the per-frame counts in LDS, a wave copies a frame's links to their compact place, the workgroup
+// of the per-frame counts in LDS and copies runs of 256 consecutive compact records, the workgroup
 // that finishes last publishes the sequence number the host polls.  Same layout as k_pack_tick
 // (rm_transmit.hip) writes from the compact arrays.
 template <int SCAN>
@@ -827,7 +827,6 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
     __shared__ uint32_t s_off[scan_lds(SCAN)];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_last;
-    const int lane = threadIdx.x & 63;
     constexpr bool kRegScan = (SCAN == 3 || SCAN == 4);
     SmallCounts<scan_per(SCAN)> pre{};
     if (kRegScan) pre = small_scan_load<scan_per(SCAN)>(t.cursor, t.n_cnt);
@@ -837,30 +836,31 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
     const uint32_t room = dropped ? 0u : v.links;
     const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
     const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
-    // Workgroups go round the XCDs (blockIdx % 8), and the stores below gather in an XCD's own L2 until its workgroups'
-    // fences write them out: every XCD packs ONE contiguous eighth of the frames, so that a line of the host's block is
-    // filled by one L2 and crosses the link as one full write (frames dealt out wave by wave shared a third of their lines
-    // between two XCDs).
-    const uint32_t per_x = (np + 7u) / 8u, xcd = blockIdx.x & 7u;
-    const uint32_t waves_x = max(1u, (gridDim.x / 8u) * 4u), wave_x = (blockIdx.x / 8u) * 4u + uint32_t(wave_index());
-    for (uint32_t k = wave_x; k < per_x && (gridDim.x & 7u) == 0u; k += waves_x) { // wave-uniform
-        const uint32_t q = xcd * per_x + k;
-        if (q >= np) break;
-        const int slot = int(q) + t.shift;
-        const uint32_t src0 = uniform_u(t.seg_off[slot]);
-        const uint32_t len = uniform_u(t.cursor[slot]);
-        const uint32_t dst0 = uniform_u(s_off[slot]);
-        for (uint32_t c = lane; c < len; c += 64) {
-            const uint32_t d = dst0 + c;
-            if (d < room) {
-                v.dst[d] = t.a_dst[src0 + c];
-                v.rssi[d] = t.a_rssi[src0 + c];
-                v.verdict[d] = t.a_verdict[src0 + c];
-                if (v.sinr != nullptr && t.out_sinr != nullptr) v.sinr[d] = t.a_sinr[src0 + c]; // (the SINR extension only)
+    // The copy is laid out by its OUTPUT: a workgroup takes 256 consecutive records of the compact arrays at a time, every
+    // thread finds its record's frame in the scanned offsets (a binary search in LDS) and its place in that frame's segment.
+    // Every store instruction of a wave then writes 64 consecutive records -- whole, aligned lines of the host's block, from
+    // ONE workgroup (one XCD's L2) -- where a wave per frame wrote the frame's 44 records wherever they fell: two frames, two
+    // waves, often two XCDs shared most lines, and every shared line crossed the link as two partial writes.
+    {
+        const uint32_t limit = min(total, room);
+        const int n_cnt = t.n_cnt;
+        for (uint32_t o0 = blockIdx.x * 256u; o0 < limit; o0 += gridDim.x * 256u) { // block-uniform
+            const uint32_t o = o0 + threadIdx.x;
+            if (o >= limit) continue;
+            int lo = 0, hi = n_cnt; // the last slot whose offset is <= o (slots without links share their successor's offset)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= o) lo = mid;
+                else hi = mid;
             }
+            const uint32_t src = t.seg_off[lo] + (o - s_off[lo]);
+            v.dst[o] = t.a_dst[src];
+            v.rssi[o] = t.a_rssi[src];
+            v.verdict[o] = t.a_verdict[src];
+            if (v.sinr != nullptr && t.out_sinr != nullptr) v.sinr[o] = t.a_sinr[src]; // (the SINR extension only)
         }
-        if (lane == 0) {
-            v.pkt_offset[q] = dst0;
+        for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < np; q += gridDim.x * 256u) {
+            v.pkt_offset[q] = s_off[int(q) + t.shift];
             v.pkt_interference[q] = (draws_possible && tx_success(m, t.tx[t.first_new + int(q)]) <= 0.0) ? 1 : 0;
             if (q + 1 == np) v.pkt_offset[np] = total;
         }
@@ -1031,7 +1031,7 @@ hipError_t launch_pack_frames(hipStream_t s, const ModelDev &m, const TickDev &t
 {
     static const int wgs = [] { // (developer knob: workgroups of the pack, a multiple of the eight XCDs)
         const char *e = getenv("RM_PACK_WGS");
-        return e ? max(8, min(1024, atoi(e) & ~7)) : 64;
+        return e ? max(8, min(1024, atoi(e) & ~7)) : 128;
     }();
     const dim3 grid(wgs), block(256);
     const int scan = scan_variant(t.n_cnt);
