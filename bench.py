@@ -2,7 +2,7 @@
 """bench.py -- Tx->Rx link evaluations per second of the MI355X radio-medium engine.
 
 A "step" is one pass of the hot path over one batch of synthetic input: ONE launch sequence that
-sweeps `ticks_per_step` simulated ticks (64 on one GPU, 128 per rank on several; `--batch`).  In
+sweeps `ticks_per_step` simulated ticks (128 on one GPU, 64 per rank and at most 512 on several; `--batch`).  In
 every tick T = 1% of N nodes transmit a 127-byte frame; the engine evaluates all T x (N-1) links
 (log-distance path loss + log-normal shadowing, BASELINE.json configs[2]: 100k nodes, 1% concurrent
 Tx) and leaves the ordered heard-link records (receiver, rssi, verdict) in HBM, one result slot per
@@ -11,24 +11,40 @@ starts.  `value` = link evaluations of the K timed steps / their wall time, what
 
 The benchmarked medium carries no state from tick to tick (no on-air list, no random draws with
 the reference's default probabilities; RadioMedium.transmit treats every packet on its own), and a
-lone tick of this size is a ~30 us chain of three dependent launches on a mostly idle device.
-So `--batch` ticks (default 64) go through ONE launch sequence (rm_batch_run_sources_device), and
-`--inflight` contexts (default 2), each with its own stream, take the batches in turn.  The
+lone tick of this size is a 13 us launch on a mostly idle device.
+So `--batch` ticks (default 128) go through ONE launch sequence (rm_batch_run_sources_device), and
+`--inflight` contexts (default 3), each with its own stream, take the batches in turn.  The
 strictly sequential rate (one tick at a time, what a closed-loop simulation sees) is measured in
 the same run and printed as "sequential_ticks".
 
     python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|udgm|m1|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: receivers are range-partitioned over the ranks; per batch each rank packs the Tx records of
+N > 1: receivers are partitioned over the ranks (regions of the plane); per batch each rank packs the source indices of
 the transmitters it owns for all ticks of the batch, the ranks all-gather them over RCCL/xGMI (ONE
-collective per batch, on the context's own stream and process group; the other context's sweep runs
+collective per batch, on the context's own stream and communicator; the other contexts' sweeps run
 under it) and every rank sweeps the gathered frames against its receivers.  Default scaling is
 STRONG: the BASELINE config itself (100k nodes for configs[2]; `--workload c4` for the 8-GPU config),
 its receivers split over the ranks.  `--scaling weak` grows the node count as 100k x sqrt(N) at constant
 density and Tx fraction instead, so that the link evaluations per GPU and tick stay those of the 1-GPU
 config; `--as-rank R:W` runs one rank's share of a W-GPU run (strong scaling, or weak with --scaling weak) on one GPU, without the
 collective.  Rank 0 prints ONE JSON line.
+
+Map of this file.  What the driver runs is `python bench.py` with no flags (and `--gpus N --steps K --warmup W`): main() ->
+measure(): workload c3 = BASELINE configs[2], 128 ticks per launch, three contexts; its timed region is the K steps between
+fence() and fence() (barrier + synchronize on both sides, MAX over ranks), and `value`, `ms_per_step`, `roofline` come from it
+alone.  Everything else on the line is an extra key measured AFTER the timed region, each by its own function, and none of it
+enters `value`:
+    roofline_object()     the `roofline` object of a run (kernel intervals from the library's probes, 8(d) bytes, cross-check)
+    cpu_baseline()        `cpu_baseline`: the oracle (oracle/rm_oracle.c) on a bounded sample, rank 0, one GPU only
+    sequential (inline)   `sequential_ticks`: the same ticks one at a time on one context
+    host_transfer_legs()  `with_host_transfer`: the PCIe-inclusive closed loops (never `value`)
+    scale_probe()         `at_1M_nodes`: a short run at a million nodes
+    dense_probe()         `dense_layout`: the reference's default Null medium and a unit disc over the whole field
+Modes behind flags (none of them the driver's path): --workload (the other BASELINE configs), --as-rank R:W (one rank's share on
+one GPU), --dense-only, --force-sharded / --collective / --partition (the multi-GPU driver on one GPU, rehearsals), --nodes,
+--link-capacity, --batch, --inflight.  spawn_ranks() starts the ranks of `--gpus N` when no launcher did; dry_run() is the
+CPU-only rehearsal of the launch contract (tests/test_bench_launch.py).
 """
 import argparse
 import copy
@@ -87,11 +103,11 @@ def parse():
     ap.add_argument("--cpu-sample-ticks", type=float, default=5.0)
     ap.add_argument("--inflight", type=int, default=0,
                     help="engine contexts per GPU, each with its own stream, taking the batches in turn (ticks are "
-                         "independent for the media without an on-air list); default 2, 3 with several GPUs")
+                         "independent for the media without an on-air list); default 3 (1 for the media with frames that stay on the air)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 128); 1 = one tick per sequence; "
-                         "default 64, 128 with several GPUs (one all-gather per batch: fewer, larger collectives, and "
-                         "the stream hand-over around a collective is amortised over more ticks)")
+                    help="ticks per launch sequence (rm_batch_run_sources_device, at most 512); 1 = one tick per sequence; "
+                         "default 128 (the workload's own for c4 / c5), 64 per rank up to 512 with several GPUs (one all-gather per "
+                         "batch: fewer, larger collectives, and the stream hand-over around a collective is amortised over more ticks)")
     ap.add_argument("--as-rank", default="", metavar="R:W",
                     help="one process, no collective: sweep the weak-scaling workload of W ranks against the receiver "
                          "range of rank R only (what one GPU of a W-GPU run computes per tick)")
