@@ -251,6 +251,49 @@ def test_step_message_in_flight_when_the_next_step_begins(server):
     emu.close()
 
 
+def test_node_info_objects_that_change_their_length(server):
+    """The node-info array of a connection is kept as it was sent last, in pieces of 64 objects, and a changed node's
+    fields are rewritten where they lie (rsim_server.cpp, Connection::infoPieces): objects that grow and shrink at the
+    beginning, the end and the seams of the pieces, step after step -- the message is what writing every object afresh gives."""
+    ctl, emu = connect(server), connect(server)
+    n = 150
+    chan = {i: 26 for i in range(1, n + 1)}
+    state = {i: 0 for i in range(1, n + 1)}
+    for i in range(1, n + 1):
+        emu.send({"command": "node-config-set", "parameters": {"node-id": i, "position": [float(i), 0.0]}})
+
+    def expect(step_id, time_us):
+        objs = ",".join('{"node-id":"%d","rssi":-99.99,"receiving":%d,"wireless-channel":%d}' % (i, state[i], chan[i]) for i in range(1, n + 1))
+        return ('{"command":"time-step","id":%d,"parameters":{"time":%d,"node-info":[%s]}}' % (step_id, time_us, objs)).encode()
+
+    def step(k):
+        emu.send({"command": "time-get", "id": 500 + k})  # (two sockets: the server has read everything above when it answers this)
+        assert emu.line().startswith(('{"id":%d,"reply":"OK"' % (500 + k)).encode())
+        ctl.send({"command": "time-set", "id": 10 + k, "parameters": {"time": 1000 * (k + 1)}})
+        assert emu.line() == expect(1001 + k, 1000 * (k + 1))
+        emu.send({"reply": "OK", "id": 1001 + k})
+        assert ctl.line() == ('{"reply":"OK","id":%d}' % (10 + k)).encode()
+
+    step(0)
+    rounds = [{1: 5, 64: 123456, 65: 7, 128: 11, 150: 2000000000},          # first / last object, both sides of the seams
+              {1: 26, 2: 1, 63: 100, 64: 26, 129: -4, 150: 3},
+              {i: (i * 7919) % 100000 for i in range(1, n + 1, 3)}]          # every third object, lengths of one to five digits
+    for k, change in enumerate(rounds):
+        for i, c in change.items():
+            emu.send({"command": "node-config-set", "parameters": {"node-id": i, "wireless-channel": c}})
+            chan[i] = c
+        if k == 1:                                       # a radio switched off reports state 3: same length, in place
+            emu.send({"command": "node-config-set", "parameters": {"node-id": 64, "radio-state": "disabled"}})
+            state[64] = 3
+        step(k + 1)
+    emu.send({"command": "node-config-set", "parameters": {"node-id": n + 1, "position": [0.5, 0.5]}})   # a node joins behind them
+    chan[n + 1], state[n + 1] = 26, 0
+    n += 1
+    step(len(rounds) + 1)
+    ctl.close()
+    emu.close()
+
+
 def test_framing(server):
     c = connect(server)
     # brace counting: CR / LF between messages, braces and escaped quotes inside strings, nested objects
