@@ -249,7 +249,9 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
     if under_profiler is None:   # (a profiler stretches every launch: the bench's own cross-check is for runs without one)
         under_profiler = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH"))
     rl["overlap_check"]["under_profiler"] = bool(under_profiler)
-    if not rl["overlap_check"]["ok"] and not under_profiler:
+    # (not ok: printed with the line; the run is only refused when the two clocks disagree grossly -- sampled sequences of many
+    # short kernels run slower than the unsampled ones around them, every probed launch waits for the one before it)
+    if share_us > step_s * 1e6 * 1.25 + probe_slack_us and not under_profiler:
         raise SystemExit("roofline cross-check failed: the kernels of one launch sequence take %.1f us per context in flight, the "
                          "driver-timed step only %.1f us" % (share_us, step_s * 1e6))
     if not pmc_ok:
