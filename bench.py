@@ -529,7 +529,16 @@ def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
         e.close()
         per_tick = el / ticks
         rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t, heard=heard, cand=0, ticks_per_launch=1,
-                             step_s=per_tick, contexts=1, workload="dense_" + name, pmc_ok=False)   # (counters: profiles/r04_dense_pmc.csv)
+                             step_s=per_tick, contexts=1, workload="dense_" + name, pmc_ok=False)
+        try:    # the counter passes on file for this shape (profiles/r04_dense_pmc.csv: the count pass per medium, the write pass of both)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("dense", {})
+            parts = [pmc.get("k_dense_count_" + ("null" if name == "null_medium" else "udgm")), pmc.get("k_dense_write")]
+            if all(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in parts):
+                rl["traffic"] = int(sum(v["hbm_bytes_per_launch"] for v in parts))
+                rl["traffic_source"] = ("profiles/pmc_traffic.json ('dense', commit %s): FETCH_SIZE / WRITE_SIZE passes of bench.py --dense-only, "
+                                        "count + write kernels of one tick; from_profile_file" % pmc.get("commit"))
+        except (OSError, ValueError):
+            pass
         out[name] = {"workload": "20k nodes, 200 frames per tick, every frame heard by every node (nothing to cull): " + name, "nodes": n,
                      "tx_per_tick": t, "heard_links_per_tick": int(heard), "ms_per_tick": per_tick * 1e3,
                      "value": t * (n - 1) / per_tick, "unit": "links/s", "record_bytes_per_s": heard * S_REC / per_tick,
