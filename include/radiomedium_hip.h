@@ -34,7 +34,11 @@
 extern "C" {
 #endif
 
-/* 4: rm_profile_enable times every kernel by its own dispatch (rm_profile_kernels; RM_STAGE_EMPTY is always 0);
+/* 5: a partitioned context that is handed all ranks' source indices keeps, per tick, only the frames that can matter to
+ *    its receivers (results unchanged: packets keep their numbers); the ranks' node-table digests ride in the all-gather of
+ *    rm_dist_batch_run_sources_device (rm_table_digest, rm_batch_run_gathered_blocks_device, RM_GATHER_TRAILER): a rank
+ *    whose copy of the node table differs makes the batch RM_ERR_STATE on every rank.
+ * 4: rm_profile_enable times every kernel by its own dispatch (rm_profile_kernels; RM_STAGE_EMPTY is always 0);
  *    rm_batch_run_sources_device / rm_batch_run_gathered_sources_device / rm_dist_batch_run_sources_device take ticks of
  *    the SINR medium whose frames outlive their tick (rm_air_batch_stats); rm_node_info_changed.
  * 3: rm_host_result.pkt is NULL (a link's packet follows from pkt_offset: the column no longer crosses PCIe) and so is
@@ -44,7 +48,7 @@ extern "C" {
  *    rm_group_*, rm_events_*, rm_node_info, rm_tick_run_records_device, rm_set_partition_spatial and the draw-node
  *    exchange were added; rm_tick_run_device refuses the SINR medium (rm_tick_run_records_device takes it).  A host
  *    built against another version must not load this library: compare rm_abi_version() with RM_ABI_VERSION. */
-#define RM_ABI_VERSION 4
+#define RM_ABI_VERSION 5
 
 #define RM_OK 0
 #define RM_ERR_INVALID (-1)   /* bad argument */
@@ -320,6 +324,18 @@ int rm_batch_run_gathered_device(rm_context *ctx, int32_t n_ticks, const int64_t
 int rm_batch_run_gathered_sources_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                                          const int32_t *dev_src_all, int32_t world, int32_t slots, const int64_t *start_us,
                                          int64_t air_us);
+/* the same with every rank's block as rm_dist_batch_run_sources_device's own all-gather leaves it: n_ticks * slots source
+ * indices followed by RM_GATHER_TRAILER words, the first two of them the rank's rm_table_digest (low word, high word).
+ * Every rank builds the other ranks' records from ITS copy of the node table (the reference has no change hook --
+ * net/SimulatorJSONHandler.java:105-143 -- so a host may miss an update): a block whose digest differs from this
+ * context's makes every tick of the batch read as RM_ERR_STATE. */
+#define RM_GATHER_TRAILER 4
+int rm_batch_run_gathered_blocks_device(rm_context *ctx, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                        const int32_t *dev_blocks /* [world][n_ticks * slots + RM_GATHER_TRAILER] */, int32_t world,
+                                        int32_t slots, const int64_t *start_us, int64_t air_us);
+/* digest of the node table as this context holds it: a function of its content (node count and every node's fields),
+ * whatever sequence of rm_nodes_upload / rm_node_update / rm_nodes_move calls produced it */
+int rm_table_digest(const rm_context *ctx, uint64_t *digest);
 int rm_batch_result_device(rm_context *ctx, int32_t slot, rm_device_result *out);
 int rm_batch_result_count(rm_context *ctx, int32_t slot, uint32_t *count, uint32_t *dropped); /* synchronises */
 int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,

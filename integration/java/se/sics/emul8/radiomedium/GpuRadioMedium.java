@@ -50,7 +50,7 @@ public class GpuRadioMedium extends AbstractRadioMedium {
     private static final byte INTERFERED = 1, DELIVERED = 2;
 
     /** RM_ABI_VERSION of the include/radiomedium_hip.h this shim and its JNI glue were written against */
-    private static final int ABI_VERSION = 4;
+    private static final int ABI_VERSION = 5;
 
     static {
         System.loadLibrary("radiomedium_jni"); // integration/jni/rm_jni.c, links libradiomedium_hip.so

@@ -92,6 +92,9 @@ def lib():
         L.orc_tick_mt.restype = C.c_int64
         L.orc_tick_mt.argtypes = [C.POINTER(Model), C.POINTER(Nodes), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_udgm_pow_sensitivity.restype = None
+        L.orc_udgm_pow_sensitivity.argtypes = [C.POINTER(Model), C.POINTER(Nodes), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.orc_count_links.restype = C.c_int64
         L.orc_count_links.argtypes = [C.POINTER(Model), C.POINTER(Nodes), C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.POINTER(C.c_int64)]
@@ -385,3 +388,15 @@ def count_links(mdl, nodes, active, first_new=0, threads=1):
     heard = L.orc_count_links(C.byref(mdl), C.byref(ns), active.ctypes.data, len(active), first_new, threads,
                               C.byref(deliv))
     return heard, deliv.value
+
+
+def udgm_pow_sensitivity(mdl, nodes, packets, d2_ulp, dmax2_ulp):
+    """TEST-ONLY: UDGMRadioMedium.java:69,74 with Math.pow's results moved by whole ulps against x * x
+    -> (links evaluated, heard, heard/unheard flips, heard links whose p differs, largest relative change of p)"""
+    L = lib()
+    packets = np.ascontiguousarray(np.atleast_1d(packets), dtype=PACKET_DTYPE)
+    ns = nodes.as_struct()
+    out = (C.c_int64 * 4)()
+    rel = C.c_double(0.0)
+    L.orc_udgm_pow_sensitivity(C.byref(mdl), C.byref(ns), packets.ctypes.data, len(packets), int(d2_ulp), int(dmax2_ulp), out, C.byref(rel))
+    return int(out[0]), int(out[1]), int(out[2]), int(out[3]), float(rel.value)

@@ -85,6 +85,60 @@ double orc_udgm_rx_probability(const orc_model_t *m, const orc_nodes_t *nd, cons
     return ratio * nd->rxprob[dst];
 }
 
+/* TEST-ONLY: what the one JDK assumption this oracle takes on faith can cost.  UDGMRadioMedium.java:69,74 square through
+ * Math.pow(v, 2.0); this file restates them as v * v (fdlibm's e_pow and HotSpot's intrinsic special-case y == 2), but the
+ * Java SE specification only promises a result within 1 ulp.  The same function with distanceSquared and
+ * distanceMaxSquared moved by whole ulps (d2_ulp, dmax2_ulp in {-1, 0, +1}: what a pow that is not special-cased may
+ * legally return), compared link by link with the unperturbed one over every (packet, receiver) pair:
+ *   out[0] links evaluated (filters of UDGMRadioMedium.java:102 applied)
+ *   out[1] links heard unperturbed (p > 0)
+ *   out[2] links whose heard / unheard status differs
+ *   out[3] links heard both ways whose p differs at all
+ *  *max_rel  largest |p' - p| / p over the links heard both ways
+ * tests/test_oracle_pow_ulp.py holds the counts for the golden scenarios and the BASELINE layouts. */
+static double ulp_step(double v, int k)
+{
+    while (k > 0) { v = nextafter(v, INFINITY); k--; }
+    while (k < 0) { v = nextafter(v, -INFINITY); k++; }
+    return v;
+}
+static double udgm_rx_probability_ulp(const orc_model_t *m, const orc_nodes_t *nd, const orc_packet_t *p, int32_t dst, int d2_ulp, int dmax2_ulp)
+{
+    double distance = orc_distance(p->x, p->y, p->z, nd->x[dst], nd->y[dst], nd->z[dst]);
+    double distanceSquared = ulp_step(distance * distance, d2_ulp);
+    double distanceMax = m->udgm_transmission_range;
+    if (distanceMax == 0.0) return 0.0;
+    double distanceMaxSquared = ulp_step(distanceMax * distanceMax, dmax2_ulp);
+    double ratio = distanceSquared / distanceMaxSquared;
+    if (ratio > 1.0) return 0.0;
+    ratio = 1.0 - ratio * (1.0 - m->udgm_success_ratio_rx);
+    return ratio * nd->rxprob[dst];
+}
+void orc_udgm_pow_sensitivity(const orc_model_t *m, const orc_nodes_t *nd, const orc_packet_t *pk, int32_t n_pk, int32_t d2_ulp,
+                              int32_t dmax2_ulp, int64_t *out, double *max_rel)
+{
+    int64_t n_eval = 0, n_heard = 0, n_flip = 0, n_diff = 0;
+    double worst = 0.0;
+    for (int32_t pi = 0; pi < n_pk; pi++) {
+        const orc_packet_t *p = &pk[pi];
+        for (int32_t j = 0; j < nd->n; j++) {
+            if (j == p->src || !nd->enabled[j] || nd->channel[j] != p->channel) continue;
+            const double p0 = orc_udgm_rx_probability(m, nd, p, j);
+            const double p1 = udgm_rx_probability_ulp(m, nd, p, j, d2_ulp, dmax2_ulp);
+            n_eval++;
+            if (p0 > 0.0) n_heard++;
+            if ((p0 > 0.0) != (p1 > 0.0)) n_flip++;
+            else if (p0 > 0.0 && p1 != p0) {
+                n_diff++;
+                const double rel = fabs(p1 - p0) / p0;
+                if (rel > worst) worst = rel;
+            }
+        }
+    }
+    out[0] = n_eval; out[1] = n_heard; out[2] = n_flip; out[3] = n_diff;
+    *max_rel = worst;
+}
+
 /* N2NRadioMedium.java:28-37 */
 double orc_n2n_rx_probability(const orc_model_t *m, const orc_nodes_t *nd, const orc_packet_t *p, int32_t dst)
 {

@@ -196,6 +196,9 @@ double orc_sim_rssi(const orc_sim_t *s, int32_t node, double base_rssi);
 int32_t orc_sim_receiving_state(const orc_sim_t *s, int32_t node, int32_t enabled);
 int32_t orc_sim_receiving_packet(const orc_sim_t *s, int32_t node);
 int32_t orc_sim_sending_packet(const orc_sim_t *s, int32_t node);
+/* TEST-ONLY (rm_oracle.c): what Math.pow(v, 2.0) != v * v by whole ulps would change, link by link */
+void orc_udgm_pow_sensitivity(const orc_model_t *m, const orc_nodes_t *nd, const orc_packet_t *pk, int32_t n_pk, int32_t d2_ulp,
+                              int32_t dmax2_ulp, int64_t *out /* [4] */, double *max_rel);
 /* bare queue: op_kind 0 = addEvent(op_time), 1 = pop everything with time < op_time; returns the popped
  * events' insertion numbers in pop order (or -error) */
 int64_t orc_evq_replay(const int64_t *op_time, const int32_t *op_kind, int64_t n_ops, int64_t *out_id, int64_t cap);

@@ -51,8 +51,13 @@ __global__ void __launch_bounds__(256) k_ov_count(const NodesDev nd, const Model
     const int f0 = ov.slot_first[slot], f1 = ov.slot_first[slot + 1];
     const int i = f0 + int(blockIdx.x) * 256 + int(threadIdx.x);
     float radius = 0.f; // of a frame that goes into the grid (its reach at the interference level)
+    // (a tick swept over a rank's frame list, k_rank_frames: its slot holds n_new frames -- the device's count -- and padding behind them)
+    const int bt = slot - (ov.n_slots - ov.n_ticks);
+    const int live = (bt >= 0) ? min(f1 - f0, ov.ticks[bt].n_new) : f1 - f0;
     if (i < f1) { // (no early return: the wave reduces the radii together below)
-        const rm_tx_record r = ov.tx[i];
+        rm_tx_record r{};
+        r.src = -1;
+        if (i - f0 < live) r = ov.tx[i];
         float4 f;
         double thr64;
         tx_prefilter(m, r, f, thr64);

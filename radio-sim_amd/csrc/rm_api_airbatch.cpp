@@ -14,6 +14,14 @@ struct AfterArg {
     int max_slot_frames, max_new, max_links;
 };
 
+// metres around the partition's boxes inside which a frame that stays on the air is kept for this rank (RM_RANK_MARGIN)
+float rank_margin()
+{
+    const char *e = std::getenv("RM_RANK_MARGIN");
+    const double v = e ? std::atof(e) : 64.0;
+    return float(v > 0.0 ? v : 0.0);
+}
+
 int interference_stages(rm_context *c, void *arg)
 {
     const AfterArg &a = *static_cast<const AfterArg *>(arg);
@@ -43,8 +51,9 @@ bool overlap_wanted(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, c
 
 int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
                       const int32_t *n_per, const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world,
-                      int gather_slots, const int32_t *gathered_idx)
+                      int gather_slots, const int32_t *gathered_idx, int gather_block, int digest_off)
 {
+    if (gather_block <= 0) gather_block = n_ticks * gather_slots;
     // what the batched kernels carry: no java.util.Random draws (the draw stage walks compact records tick by tick and knows
     // nothing of verdicts that come later), time that does not run backwards inside the batch
     if (maybe_draws(c))
@@ -60,6 +69,10 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
         return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run overlapping ticks one "
                                   "at a time (the batched form needs the spatially sorted receiver table)");
     rm_context::Overlap &o = c->ov;
+    RM_HIP(o.ticks.ensure(RM_MAX_BATCH));
+    // a receiver partition keeps, of all ranks' gathered frames, those that can matter to its receivers (k_rank_frames) -- at the
+    // interference floor, with a margin: these frames stay on the air while receivers may move (rm_api_batch.cpp)
+    const bool rank_frames = gathered_idx != nullptr && rank_frames_wanted(c);
     // the window: batches whose last frame has left the air go, and when the clock went back the frames that had already
     // left stay off (air_tick_device's rules)
     RM_TRY(air_window_expire(c, t_begin_us[0]));
@@ -73,7 +86,9 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     const size_t live = c->air_tail - c->air_head;
     if (live > 0 && t_begin_us[0] < c->air_max_t_begin)
         RM_HIP(rm::launch_air_expire(c->stream, c->d_air.p + c->air_head, int(live), c->air_max_t_begin));
-    c->air_max_t_begin = std::max(c->air_max_t_begin, t_begin_us[n_ticks - 1]);
+    // (air_max_t_begin is raised only once nothing can refuse the batch any more: a caller that is told to run the ticks one at
+    // a time must find the window's clock where it was, or its first lone tick would retire frames that are still on the air
+    // for the earlier ticks of the batch)
     c->air.valid = false; // (whatever the per-receiver lists hold is stale now)
 
     // ---- the ticks' plans: swept as the medium without SINR, every tick's frames built at its place of the window's tail
@@ -110,9 +125,15 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
                 t.gather_src = gathered + size_t(b) * size_t(gather_slots);
             }
             t.gather_slots = gather_slots;
-            t.gather_stride = n_ticks * gather_slots;
+            t.gather_stride = gather_block;
             t.tx_build = const_cast<rm_tx_record *>(tx);
+            if (rank_frames && !pl.empty) {
+                RM_TRY(plan_rank_frames(c, ts, t, n_per[b]));
+                t.fl_pad = 1; // (the slots behind the listed frames: padding records, the window is walked as a whole)
+                t.fl_ov_n_new = &o.ticks.p[b].n_new;
+            }
             ts.last = t;
+            if (t.n_pub > 0) ts.last.slot_off = ts.d_slot_off.p;
         }
         // (an empty tick has nothing to sweep and nothing to ask: it stays out of the launch, its result slot holds an empty result)
         if (!pl.empty) {
@@ -124,6 +145,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     }
     if (run_plans.empty()) { // nothing transmits in the whole batch
         for (int b = 0; b < n_ticks; ++b) slots_v[size_t(b)]->have_result = true;
+        c->air_max_t_begin = std::max(c->air_max_t_begin, t_begin_us[n_ticks - 1]);
         return RM_OK;
     }
     c->t_begin = t_begin_us[0];
@@ -131,6 +153,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     if (!batched)
         return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run overlapping ticks one "
                                   "at a time (the batched form takes non-empty ticks of at most 8192 frames over an fp32 frame)");
+    c->air_max_t_begin = std::max(c->air_max_t_begin, t_begin_us[n_ticks - 1]);
 
     // ---- the index's shape: time slots = the window's batches, then the ticks
     const int n_wslots = int(c->air_batches.size());
@@ -145,6 +168,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
             RM_HIP(hipEventSynchronize(o.h_ev[g]));
             RM_HIP(hipHostFree(o.h_desc[g]));
             o.h_desc[g] = nullptr;
+            o.h_desc_bytes[g] = 0;
         }
         const size_t want = std::max<size_t>(desc_bytes * 2, 1 << 16);
         RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_desc[g]), want, hipHostMallocDefault));
@@ -154,9 +178,13 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
         RM_HIP(hipEventSynchronize(o.h_ev[g])); // (the copy that read this block last has completed)
     }
     if (!o.h_flag) {
-        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_flag), 64, hipHostMallocDefault));
-        *o.h_flag = 0u;
+        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_flag), 128, hipHostMallocDefault));
+        o.h_flag[0] = o.h_flag[16] = 0u;
+        for (int k = 0; k < 2; ++k) RM_HIP(hipEventCreateWithFlags(&o.h_flag_ev[k], hipEventDisableTiming));
+    } else if (o.h_flag_used[g]) {
+        RM_HIP(hipEventSynchronize(o.h_flag_ev[g])); // (the copy of the overflow flag of the batch that used this generation last has landed)
     }
+    uint32_t *const h_flag = o.h_flag + 16 * g; // (one word per generation, a line apart: read here, written by that batch's last copy)
     rm::OvTick *const h_ticks = reinterpret_cast<rm::OvTick *>(o.h_desc[g]);
     int32_t *const h_first = reinterpret_cast<int32_t *>(o.h_desc[g] + sizeof(rm::OvTick) * size_t(n_ticks));
     std::vector<int64_t> slot_end;
@@ -216,9 +244,9 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
         size_t want = o.pair_cap;
         if (want == 0) want = forced ? forced : std::max<size_t>(size_t(1) << 20, 512 * total_new); // (RM_OV_PAIR_CAP: tests start too small)
         else if (!forced) want = std::max(want, 512 * total_new);
-        if (*o.h_flag != 0u) {
+        if (*h_flag != 0u) {
             want = std::max(want, std::min<size_t>(o.pair_cap * 2, size_t(1) << 27));
-            *o.h_flag = 0u;
+            *h_flag = 0u;
         }
         want = (want + rm::kShards - 1) / rm::kShards * rm::kShards;
         if (want > o.pair_cap) {
@@ -293,9 +321,20 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     arg.max_new = max_new;
     arg.max_links = int(std::min<uint64_t>(c->cap, 1u << 30));
 
-    const int rc = launch_batch(c, run_slots.data(), run_plans.data(), int(run_plans.size()), &ms, interference_stages, &arg);
+    rm::RankFramesArgs rf{};
+    rf.gather_base = gathered_idx;
+    rf.world = gather_world;
+    rf.gather_block = gather_block;
+    rf.digest_off = digest_off;
+    rf.mine = c->table_digest;
+    rf.margin = rank_margin();
+    rf.use_chmask = 0; // (a receiver may change its channel while these frames are on the air)
+    const int rc = launch_batch(c, run_slots.data(), run_plans.data(), int(run_plans.size()), &ms, interference_stages, &arg,
+                                (rank_frames || digest_off >= 0) && gathered_idx ? &rf : nullptr);
     if (rc != RM_OK) return rc;
-    RM_HIP(hipMemcpyAsync(o.h_flag, o.misc.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipMemcpyAsync(h_flag, o.misc.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RM_HIP(hipEventRecord(o.h_flag_ev[g], c->stream));
+    o.h_flag_used[g] = true;
 
     // ---- the batch's frames are on the air now
     c->air_tail += total_new;

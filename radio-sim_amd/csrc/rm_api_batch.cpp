@@ -33,11 +33,36 @@ TickSlot *slot_of(rm_context *c, int32_t slot)
     return c->extra_slots[size_t(slot) - 1].get();
 }
 
+// A batch of gathered source indices over a receiver partition keeps, per tick, only the frames that can matter to the
+// partition's receivers (k_rank_frames).  RM_RANK_FRAMES=0: every rank keeps every frame, as before round 5 (read per call: tests).
+bool rank_frames_wanted(rm_context *c)
+{
+    const char *e = std::getenv("RM_RANK_FRAMES");
+    if (e && std::atoi(e) == 0) return false;
+    return part_count(c) != c->n && part_count(c) > 0;
+}
+
+int plan_rank_frames(rm_context *c, TickSlot &ts, rm::TickDev &t, int n_pub)
+{
+    (void)c;
+    RM_HIP(ts.d_fl_src.ensure(size_t(std::max(n_pub, 1))));
+    RM_HIP(ts.d_fl_map.ensure(size_t(std::max(n_pub, 1))));
+    RM_HIP(ts.d_fl_lb.ensure(size_t(std::max(n_pub, 1)) + 1));
+    RM_HIP(ts.d_slot_off_loc.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
+    t.fl_src = ts.d_fl_src.p;
+    t.fl_map = ts.d_fl_map.p;
+    t.fl_lb = ts.d_fl_lb.p;
+    t.n_pub = n_pub;
+    t.pub_off = ts.d_slot_off.p;       // what the result readers take for the packets' offsets: by global packet number
+    t.slot_off = ts.d_slot_off_loc.p;  // the kernels' own: by listed frame
+    return RM_OK;
+}
+
 } // namespace rmh
 
 // the launch sequence of n prepared ticks in four launches (sorted table, fp32 frame)
 int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n, const rm::ModelDev *m_override,
-                      int (*after_sweep)(rm_context *, void *), void *after_arg)
+                      int (*after_sweep)(rm_context *, void *), void *after_arg, const rm::RankFramesArgs *rank_frames)
 {
     const double tc0 = g_clock.on ? HostClock::now() : 0;
     static thread_local std::vector<rm::TickDev> ticks_v; // (RM_MAX_BATCH descriptors: not on the stack)
@@ -72,7 +97,7 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
     // batch's kernels, which read the same array)
     RM_HIP(c->d_ticks.ensure(RM_MAX_BATCH));
     rm::TickDev *dev_ticks = c->d_ticks.p;
-    const bool by_copy = n > 2 * 6; // beyond two k_store_ticks launches: one fetch from pinned, host-mapped memory
+    const bool by_copy = n > 2 * 5; // beyond two k_store_ticks launches (five descriptors each): one fetch from pinned, host-mapped memory
     if (by_copy) {
         const int g = c->h_ticks_gen;
         c->h_ticks_gen ^= 1;
@@ -103,6 +128,12 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
         return RM_OK;
     };
     if (!by_copy) RM_HIP(rm::launch_store_ticks(s, ticks, n, dev_ticks));
+    if (rank_frames) {
+        // the ticks' frame lists: the descriptors' frame counts are the device's from here on (the medium itself, not the
+        // sweep's override: the SINR medium's candidate level is its interference floor)
+        RM_TRY(stage(RM_STAGE_FILTER));
+        RM_HIP(rm::launch_rank_frames(s, nd, model_dev(c), dev_ticks, n, *rank_frames));
+    }
     // RM_BATCH_FRAMES=1: the batch through the one-frame-per-workgroup kernel of the closed-loop tick instead of the
     // three sweep stages (one launch; the compact arrays on demand, per slot)
     static const bool batch_frames = std::getenv("RM_BATCH_FRAMES") != nullptr;
@@ -153,9 +184,10 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
 int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                    const int32_t *const *dev_src, const rm_tx_record *const *dev_new, const int32_t *n_per,
                    const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world, int gather_slots,
-                   const int32_t *gathered_idx)
+                   const int32_t *gathered_idx, int gather_block, int digest_off)
 {
     const bool any_gathered = gathered || gathered_idx;
+    if (gather_block <= 0) gather_block = n_ticks * gather_slots; // (a rank's block of the gathered buffer, in its elements)
     if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || !t_begin_us || !t_end_us || (!n_per && !any_gathered) ||
         (!dev_src && !dev_new && !any_gathered) || ((dev_src || gathered_idx) && (!start_us || !air_us)) ||
         (any_gathered && (gather_world < 1 || gather_slots < 1)))
@@ -181,7 +213,7 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         // verified on the device: every frame of tick b has to lie inside [t_begin[b], t_end[b]], and the ticks must not overlap.
         if (start_us && air_us && (dev_src || any_gathered) && overlap_wanted(c, n_ticks, t_begin_us, n_per, start_us, air_us))
             return batch_run_overlap(c, n_ticks, t_begin_us, t_end_us, dev_src, n_per, start_us, air_us, gathered, gather_world, gather_slots,
-                                     gathered_idx);
+                                     gathered_idx, gather_block, digest_off);
         if (!dev_src && !gathered_idx)
             for (int b = 0; b < n_ticks; ++b)
                 if (t_end_us[b] < t_begin_us[b] || (b + 1 < n_ticks && t_end_us[b] > t_begin_us[b + 1]))
@@ -208,6 +240,11 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
     TickSlot **const slots = slots_v.data();
     TickPlan *const plans = plans_v.data();
     bool batched = true;
+    bool rank_frames = false;
+    if (gathered_idx) {
+        RM_TRY(prepare_nodes(c)); // (the partition's receivers: rank_frames_wanted asks for their number)
+        rank_frames = rank_frames_wanted(c);
+    }
     for (int b = 0; b < n_ticks; ++b) {
         TickSlot &ts = *slot_of(c, b);
         slots[b] = &ts;
@@ -238,9 +275,11 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
                 t.gather_src = gathered + size_t(b) * size_t(gather_slots);
             }
             t.gather_slots = gather_slots;
-            t.gather_stride = n_ticks * gather_slots;
+            t.gather_stride = gather_block;
             t.tx_build = ts.d_tx.p;
+            if (rank_frames && !plans[b].empty) RM_TRY(plan_rank_frames(c, ts, t, n_per[b]));
             ts.last = t;
+            if (t.n_pub > 0) ts.last.slot_off = ts.d_slot_off.p; // (result readers: the offsets by global packet number)
         }
         batched = batched && !plans[b].empty && rm::batch_eligible(plans[b].t, plans[b].cfg, model_dev(c)) &&
                   plans[b].t.rpt == plans[0].t.rpt;
@@ -267,7 +306,15 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
             g_clock.acc[0] += th1 - th0;
             g_clock.acc[1] += HostClock::now() - th1;
         }
-        const int rc = launch_batch(c, slots, plans, n_ticks);
+        rm::RankFramesArgs rf{};
+        rf.gather_base = gathered_idx;
+        rf.world = gather_world;
+        rf.gather_block = gather_block;
+        rf.digest_off = digest_off;
+        rf.mine = c->table_digest;
+        rf.margin = 0.f;     // nothing of these ticks outlives them
+        rf.use_chmask = 1;
+        const int rc = launch_batch(c, slots, plans, n_ticks, nullptr, nullptr, nullptr, (rank_frames || digest_off >= 0) && gathered_idx ? &rf : nullptr);
         g_clock.report();
         return rc;
     }

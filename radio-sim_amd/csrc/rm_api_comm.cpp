@@ -202,6 +202,24 @@ int rm_batch_run_gathered_sources_device(rm_context *c, int32_t n_ticks, const i
     return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, start_us, air_v.data(), nullptr, world, slots, dev_src_all);
 }
 
+// The same with every rank's block as the library's own all-gather leaves it: n_ticks * slots source indices, then
+// RM_GATHER_TRAILER words -- the rank's node-table digest (rm_table_digest) in the first two.  Every rank builds the other
+// ranks' records from ITS copy of the node table; a rank whose copy differs from this context's (it missed an
+// rm_node_update: the reference has no change hook, net/SimulatorJSONHandler.java:105-143) would yield silently wrong
+// verdicts -- here every tick of the batch reads as RM_ERR_STATE instead, on every rank.
+int rm_batch_run_gathered_blocks_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
+                                        const int32_t *dev_blocks, int32_t world, int32_t slots, const int64_t *start_us, int64_t air_us)
+{
+    if (!c || n_ticks < 1 || n_ticks > RM_MAX_BATCH || slots < 1 || world < 1 || !dev_blocks || !start_us || !t_begin_us || !t_end_us || air_us < 0)
+        return fail(RM_ERR_INVALID, "bad arguments");
+    RM_HIP(hipSetDevice(c->device));
+    static thread_local std::vector<int64_t> air_v;
+    air_v.assign(size_t(n_ticks), air_us);
+    const int mine = n_ticks * slots;
+    return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, start_us, air_v.data(), nullptr, world, slots, dev_blocks,
+                     mine + rm::kGatherTrailer, mine);
+}
+
 int rm_dist_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us,
                                      const int32_t *dev_src, int32_t slots, const int64_t *start_us, int64_t air_us)
 {
@@ -209,15 +227,15 @@ int rm_dist_batch_run_sources_device(rm_context *c, int32_t n_ticks, const int64
         return fail(RM_ERR_INVALID, "bad arguments");
     RM_HIP(hipSetDevice(c->device));
     // the all-gather carries the source INDICES (4 bytes per frame): every rank has the whole node table and builds the
-    // records of all ranks' frames itself
+    // records of all ranks' frames itself -- so the tables have to agree: each rank's block ends with its table's digest
     const size_t mine = size_t(n_ticks) * size_t(slots);
-    const int32_t *all = dev_src;
-    if (c->comm) {
-        RM_HIP(c->d_dist_idx.ensure(mine * size_t(c->comm_world)));
-        RM_TRY(comm_all_gather(c, dev_src, c->d_dist_idx.p, mine * sizeof(int32_t)));
-        all = c->d_dist_idx.p;
-    }
-    return rm_batch_run_gathered_sources_device(c, n_ticks, t_begin_us, t_end_us, all, c->comm ? c->comm_world : 1, slots, start_us, air_us);
+    if (!c->comm) return rm_batch_run_gathered_sources_device(c, n_ticks, t_begin_us, t_end_us, dev_src, 1, slots, start_us, air_us);
+    const size_t block = mine + size_t(rm::kGatherTrailer);
+    RM_HIP(c->d_dist_stage.ensure(block));
+    RM_HIP(c->d_dist_idx.ensure(block * size_t(c->comm_world)));
+    RM_HIP(rm::launch_stage_block(c->stream, dev_src, int(mine), c->table_digest, c->d_dist_stage.p));
+    RM_TRY(comm_all_gather(c, c->d_dist_stage.p, c->d_dist_idx.p, block * sizeof(int32_t)));
+    return rm_batch_run_gathered_blocks_device(c, n_ticks, t_begin_us, t_end_us, c->d_dist_idx.p, c->comm_world, slots, start_us, air_us);
 }
 
 int rm_dist_tick_run_sources_device(rm_context *c, int64_t t_begin_us, int64_t t_end_us, const int32_t *dev_src, int32_t slots,

@@ -231,6 +231,7 @@ void TickSlot::release_all()
 {
     d_tx.release(); d_p_txf.release(); d_p_ch.release(); d_p_src.release(); d_p_inv.release();
     d_cnt.release(); d_off.release(); d_dense_mask.release(); d_slot_tot.release(); d_slot_off.release();
+    d_fl_src.release(); d_fl_map.release(); d_fl_lb.release(); d_slot_off_loc.release();
     d_counters.release(); d_shards.release(); d_cursor.release(); d_cand_tot.release(); d_seg_off.release(); d_a_e.release();
     d_st_pkt.release(); d_st_dst.release(); d_st_next.release(); d_head.release(); d_st_blk.release(); d_st_aux.release();
     d_st_lin.release(); d_st_sinr.release(); d_st_prob.release(); d_st_orig.release(); d_st_flags.release(); d_st_coll.release();
@@ -313,6 +314,7 @@ void rm_destroy(rm_context *c)
         for (int g = 0; g < 2; ++g) {
             if (o.h_ev[g]) (void)hipEventDestroy(o.h_ev[g]);
             if (o.h_desc[g]) (void)hipHostFree(o.h_desc[g]);
+            if (o.h_flag_ev[g]) (void)hipEventDestroy(o.h_flag_ev[g]);
         }
         if (o.h_flag) (void)hipHostFree(o.h_flag);
     }
@@ -320,7 +322,7 @@ void rm_destroy(rm_context *c)
     c->d_enabled.release();
     c->d_member.release(); c->d_draw_nodes.release(); c->d_all_off.release(); c->d_all_nodes.release();
     (void)rm_comm_destroy(c);
-    c->d_dist_mine.release(); c->d_dist_all.release(); c->d_dist_idx.release();
+    c->d_dist_mine.release(); c->d_dist_all.release(); c->d_dist_idx.release(); c->d_dist_stage.release();
     (void)rm_events_disable(c);
     c->release_all();
     for (auto &sl : c->extra_slots) sl->release_all();

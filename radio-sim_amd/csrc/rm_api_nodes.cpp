@@ -334,6 +334,29 @@ int patch_nodes(rm_context *c, const int32_t *nodes, int count)
     return RM_OK;
 }
 
+// ---- the node table's digest (rm_table_digest; rm_context::table_digest)
+static uint64_t bits_of(double v)
+{
+    uint64_t b;
+    std::memcpy(&b, &v, sizeof(b));
+    return b;
+}
+static uint64_t node_hash(const rm_context *c, int i)
+{
+    uint64_t h = rm::host_mix64(0x9E3779B97F4A7C15ull * uint64_t(i + 1));
+    const uint64_t f[8] = {bits_of(c->x[i]), bits_of(c->y[i]), bits_of(c->z[i]), bits_of(c->txpower[i]), bits_of(c->txprob[i]), bits_of(c->rxprob[i]),
+                           (uint64_t(uint32_t(c->channel[i])) << 32) | uint64_t(uint32_t(c->int_id[i])), uint64_t(c->enabled[i] ? 1 : 0)};
+    for (uint64_t v : f) h = rm::host_mix64(h ^ v);
+    return h;
+}
+static void finish_digest(rm_context *c) { c->table_digest = rm::host_mix64(c->table_xor ^ rm::host_mix64(uint64_t(c->n) + 0xD1B54A32D192ED03ull)); }
+static void digest_all(rm_context *c)
+{
+    c->table_xor = 0;
+    for (int i = 0; i < c->n; ++i) c->table_xor ^= node_hash(c, i);
+    finish_digest(c);
+}
+
 int prepare_nodes(rm_context *c)
 {
     if (c->rx_dirty || c->prefilter_dirty) c->air.valid = false; // whatever the SINR lists' entries were computed from has changed
@@ -404,6 +427,7 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
         c->rx_count = -1;
     }
     c->rx_dirty = true;
+    digest_all(c);
     return select_region(c); // a spatial partition: the same region of the new table
 }
 
@@ -423,8 +447,11 @@ int rm_node_update(rm_context *c, int32_t i, double x, double y, double z, doubl
     if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return fail(RM_ERR_INVALID, "position must be finite");
     RM_HIP(hipSetDevice(c->device));
     note_probabilities(c, c->rxprob[i], c->txprob[i], rxprob, txprob);
+    c->table_xor ^= node_hash(c, i);
     c->x[i] = x; c->y[i] = y; c->z[i] = z; c->txpower[i] = txpower; c->channel[i] = channel;
     c->enabled[i] = enabled; c->rxprob[i] = rxprob; c->txprob[i] = txprob;
+    c->table_xor ^= node_hash(c, i);
+    finish_digest(c);
     return patch_nodes(c, &i, 1);
 }
 
@@ -439,11 +466,21 @@ int rm_nodes_move(rm_context *c, int32_t count, const int32_t *nodes, const doub
     RM_HIP(hipSetDevice(c->device));
     for (int k = 0; k < count; ++k) {
         const int i = nodes[k];
+        c->table_xor ^= node_hash(c, i);
         c->x[i] = x[k];
         c->y[i] = y[k];
         c->z[i] = z ? z[k] : 0.0; // Position.java:44-46: set(x, y) puts z at 0
+        c->table_xor ^= node_hash(c, i);
     }
+    finish_digest(c);
     return patch_nodes(c, nodes, count);
+}
+
+int rm_table_digest(const rm_context *c, uint64_t *digest)
+{
+    if (!c || !digest) return fail(RM_ERR_INVALID, "NULL argument");
+    *digest = c->table_digest;
+    return RM_OK;
 }
 
 int64_t rm_receiver_table_builds(const rm_context *c) { return c ? c->table_sorts : 0; }

@@ -24,6 +24,9 @@ rm_tx_record make_record(const rm_context *c, int32_t src, int64_t start_us, int
 // what the kernels' flag word (counters[6], HostHeader::span_flag) says about a tick's records
 const char *record_flag_message(uint32_t flag)
 {
+    if (flag == 3u)
+        return "the ranks' node tables differ (rm_table_digest): a rank built the frames' records from another copy of the node "
+               "table than this context holds -- every rank needs every rm_node_update / rm_nodes_move of the others";
     return flag == 2u ? "a record given in device memory has a txprob strictly between 0 and 1, but no node probability asks for "
                         "java.util.Random draws: records in device memory must carry their source node's txprob"
                       : "a frame of this SINR tick lies outside the tick's [t_begin, t_end]: the batch was not self-contained";

@@ -277,6 +277,18 @@ struct TickDev {
     const int32_t *gather_idx; // ... or, instead of records, the frames' SOURCE INDICES in the same layout (what the all-gather of a
                                // sharded batch carries): k_tick_prep builds the record from the node table (src_start_us / src_air_us)
     int gather_slots, gather_stride;
+    // A rank's frame list (k_rank_frames; gathered source indices over a receiver PARTITION): of the world * slots frames of the tick
+    // only those whose reach touches the partition's receivers are kept -- fl_src (their source indices: the tick becomes an
+    // ordinary build-mode tick, src_list = fl_src, n_active = their number, both written into the descriptor ON THE DEVICE) and
+    // fl_map (local frame -> the frame's number among the gathered slots: packets keep their global numbers in the results);
+    // fl_lb[g] = listed frames before gathered slot g ([n_pub + 1]); pub_off[n_pub + 1]: the packets' offsets by GLOBAL number,
+    // written by the reorder stage's publisher (slot_off stays local).  n_pub = world * slots (0: no list).
+    int32_t *fl_src, *fl_map;
+    uint32_t *fl_lb;
+    uint32_t *pub_off;
+    int n_pub;
+    int fl_pad;             // the tick's records are part of the on-air window: the slots behind the listed frames get padding records
+    int32_t *fl_ov_n_new;   // (a batch of overlapping SINR ticks) OvTick::n_new of this tick, in device memory: patched as n_active is
     int n_active;
     int first_new;          // frames [first_new, n_active) get verdicts
     int first_eval;         // frames [first_eval, n_active) are swept by the filter kernel
@@ -553,6 +565,21 @@ bool batch_eligible(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m);
 hipError_t launch_store_ticks(hipStream_t s, const TickDev *ticks, int n, TickDev *dev_ticks);
 hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                                const TickDev *dev_ticks, const LaunchCfg &cfg);
+// (rm_filter.hip) the rank-level frame lists of a batch of gathered ticks: which of all ranks' frames can matter to THIS partition's
+// receivers (m: the medium whose candidate level bounds the reach -- the SINR medium's interference floor where it has one);
+// margin: metres added around the partition's boxes (frames that stay on the air: a receiver may move while they do);
+// digests: the ranks' node-table digests as the all-gather left them (gather_base + r * gather_block + digest_off, two words
+// each; digest_off < 0: none) -- a rank whose table differs from `mine` makes every tick of the batch RM_ERR_STATE
+struct RankFramesArgs {
+    const int32_t *gather_base;
+    int world, gather_block, digest_off;
+    uint64_t mine;
+    float margin;
+    int use_chmask;
+};
+hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, const RankFramesArgs &a);
+constexpr int kGatherTrailer = RM_GATHER_TRAILER; // words behind a rank's source indices in its block of a sharded batch
+hipError_t launch_stage_block(hipStream_t s, const int32_t *src, int n, uint64_t digest, int32_t *dst);
 hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,

@@ -424,7 +424,12 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
         const int aidx = air_alloc(t, want, air_sub(t));
         if (want) air_link(t, aidx, pos, txs.start_us, txs.air_us, 0.0, kAirSelf);
     }
-    if (e >= n_eval) return;
+    if (e >= n_eval) {
+        // (a rank's frame list, records kept on the air: the slots behind the listed frames hold padding, as the unlisted
+        // frames' own slots would have -- whoever walks the window later finds records everywhere)
+        if (t.fl_pad && e < t.n_pub) t.tx_build[t.first_eval + e] = make_tx_record(nd, -1, t.src_start_us, 0);
+        return;
+    }
     const int abs_i = t.first_eval + e;
     rm_tx_record tx;
     if (t.src_list && abs_i >= t.first_new) {
@@ -841,6 +846,131 @@ __global__ void __launch_bounds__(256) k_near_lists(const NodesDev nd, const Tic
     // (Padding the list to the next 1024 entries with -1, so that phase A can ask for its entries before it knows the length --
     // one round trip less per workgroup and tick -- was measured: 255 instead of 220 us per 64 ticks at a million receivers,
     // the three extra loads per thread cost more than the round trip.)
+}
+
+// A rank's frame list (one workgroup per tick of a batch of GATHERED ticks over a receiver partition).  The all-gather hands
+// every rank the source indices of all ranks' frames; a region of the plane hears nothing of most of them, and what every
+// later stage did per frame -- the pre-pass, the near-frame lists, the per-frame scans, the reorder stage's walk, the
+// interference stages' index -- it did for all of them: a rank's time did not follow its links.  Here the tick's frames are
+// tested ONCE against the union of the partition's filter-workgroup boxes with the workgroups' own expression (so a frame
+// that could pass any workgroup's test passes this one: monotone in every |d|, the union box contains every box) and the
+// survivors' source indices are compacted IN ORDER into fl_src: the tick goes on as a build-mode tick of those frames only,
+// its descriptor patched here on the device (n_active, n_cnt, src_list) -- the host sizes grids for all frames and never
+// learns the count.  Packets keep their global numbers: fl_map (local -> gathered slot) for the records' packet column,
+// fl_lb (gathered slot -> listed frames before it) for the offsets by global number, and the per-packet Tx-failure flag of
+// EVERY gathered slot is written here (it depends on the source's txProbability alone).  A frame whose source is one of the
+// partition's own receivers is always kept (half duplex asks for no reach).  The ranks' node-table digests ride in the
+// gathered blocks: a rank that built its records from another table than this one flags every tick (RM_ERR_STATE).
+__global__ void __launch_bounds__(256) k_rank_frames(const NodesDev nd, const ModelDev m, TickDev *__restrict__ ticks, const RankFramesArgs a)
+{
+    __shared__ float s_box[4][6];
+    __shared__ uint32_t s_msk[4], s_wcnt[4];
+    TickDev &t = ticks[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = wave_index();
+    const int T = t.n_pub;
+    if (a.digest_off >= 0)
+        for (int r = int(threadIdx.x); r < a.world; r += 256) {
+            const int32_t *d = a.gather_base + size_t(r) * size_t(a.gather_block) + size_t(a.digest_off);
+            const uint64_t v = uint64_t(uint32_t(d[0])) | (uint64_t(uint32_t(d[1])) << 32);
+            if (v != a.mine) t.stage_count[6] = 3u; // read as RM_ERR_STATE with the tick's result
+        }
+    if (T <= 0 || t.gather_idx == nullptr) return; // block-uniform: no list for this tick (the digests were all there was to do)
+    const float inf_ = __builtin_inff();
+    float x0 = inf_, y0 = inf_, z0 = inf_, x1 = -inf_, y1 = -inf_, z1 = -inf_;
+    uint32_t mk = 0u;
+    const int n_wg = (t.n_rx + kGroup * 16 - 1) / (kGroup * 16);
+    for (int w = int(threadIdx.x); w < n_wg; w += 256) {
+        const float4 q = nd.wg_box_xy[w];
+        const float2 qz = nd.wg_box_z[w];
+        x0 = fminf(x0, q.x), y0 = fminf(y0, q.y), x1 = fmaxf(x1, q.z), y1 = fmaxf(y1, q.w);
+        z0 = fminf(z0, qz.x), z1 = fmaxf(z1, qz.y);
+        mk |= nd.wg_chmask[w];
+    }
+    x0 = wave_min(x0), y0 = wave_min(y0), z0 = wave_min(z0);
+    x1 = wave_max(x1), y1 = wave_max(y1), z1 = wave_max(z1);
+    for (int d = 32; d >= 1; d >>= 1) mk |= uint32_t(__shfl_xor(int(mk), d));
+    if (lane == 0) {
+        s_box[wave][0] = x0, s_box[wave][1] = y0, s_box[wave][2] = z0, s_box[wave][3] = x1, s_box[wave][4] = y1, s_box[wave][5] = z1;
+        s_msk[wave] = mk;
+    }
+    __syncthreads();
+    x0 = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0])) - a.margin;
+    y0 = fminf(fminf(s_box[0][1], s_box[1][1]), fminf(s_box[2][1], s_box[3][1])) - a.margin;
+    z0 = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2])) - a.margin;
+    x1 = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3])) + a.margin;
+    y1 = fmaxf(fmaxf(s_box[0][4], s_box[1][4]), fmaxf(s_box[2][4], s_box[3][4])) + a.margin;
+    z1 = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5])) + a.margin;
+    mk = a.use_chmask ? (s_msk[0] | s_msk[1] | s_msk[2] | s_msk[3]) : 0xFFFFFFFFu;
+    const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
+    uint32_t base = 0; // frames listed so far (block-uniform)
+    for (int i0 = 0; i0 < T; i0 += 256) { // block-uniform
+        const int i = i0 + int(threadIdx.x);
+        bool hit = false;
+        int src = -1;
+        if (i < T) {
+            src = t.gather_idx[size_t(i / t.gather_slots) * size_t(t.gather_stride) + size_t(i % t.gather_slots)];
+            const rm_tx_record tx = make_tx_record(nd, src, t.src_start_us, t.src_air_us);
+            t.pkt_interference[i] = (draws_possible && tx_success(m, tx) <= 0.0) ? 1 : 0; // (write_pkt_interference's rule, by global number)
+            if (tx.src >= 0) {
+                float4 f;
+                double thr64;
+                tx_prefilter(m, tx, f, thr64);
+                const float dx = fmaxf(fmaxf(x0 - f.x, f.x - x1), 0.f);
+                const float dy = fmaxf(fmaxf(y0 - f.y, f.y - y1), 0.f);
+                const float dz = fmaxf(fmaxf(z0 - f.z, f.z - z1), 0.f);
+                hit = dist2_f32(dx, dy, dz) <= f.w && ((mk >> (uint32_t(tx.channel) & 31u)) & 1u) != 0u;
+                if (!hit) hit = engine_pos(nd, tx.src) >= 0; // a receiver of this partition that is on the air itself: half duplex
+            }
+        }
+        const uint64_t hm = ballot64(hit);
+        if (lane == 0) s_wcnt[wave] = uint32_t(__popcll(hm));
+        __syncthreads();
+        uint32_t k = base + lane_prefix(hm);
+        for (int w = 0; w < wave; ++w) k += s_wcnt[w];
+        const uint32_t tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (i < T) t.fl_lb[i] = k;
+        if (hit) {
+            t.fl_src[k] = src;
+            t.fl_map[k] = i;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        t.fl_lb[T] = base;
+        t.n_active = int(base);
+        t.n_cnt = max(kTxChunk, int((base + uint32_t(kTxChunk) - 1u) / uint32_t(kTxChunk)) * kTxChunk);
+        t.src_list = t.fl_src;
+        t.gather_idx = nullptr;
+        if (t.fl_ov_n_new) *t.fl_ov_n_new = int(base);
+    }
+}
+
+// a rank's block of a sharded batch as it goes into the all-gather: its source indices, then the trailer (the node table's
+// digest in two words, two spare words)
+__global__ void __launch_bounds__(256) k_stage_block(const int32_t *__restrict__ src, int n, uint64_t digest, int32_t *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+    if (i == 0) {
+        dst[n] = int32_t(uint32_t(digest));
+        dst[n + 1] = int32_t(uint32_t(digest >> 32));
+        dst[n + 2] = 0;
+        dst[n + 3] = 0;
+    }
+}
+
+hipError_t launch_stage_block(hipStream_t s, const int32_t *src, int n, uint64_t digest, int32_t *dst)
+{
+    RM_KLAUNCH(k_stage_block, dim3(cdiv(max(n, 1), 256)), dim3(256), 0, s, src, n, digest, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, const RankFramesArgs &a)
+{
+    if (n <= 0) return hipSuccess;
+    RM_KLAUNCH(k_rank_frames, dim3(n), dim3(256), 0, s, nd, m, dev_ticks, a);
+    return hipGetLastError();
 }
 
 template <int RPT, bool SHADOW>

@@ -83,6 +83,10 @@ struct TickSlot {
     DevBuf<float> d_p_inv;
 
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
+    // a rank's frame list (k_rank_frames): the listed frames' source indices and gathered-slot numbers, the listed frames before
+    // every gathered slot, and the tick's LOCAL offsets (d_slot_off then holds the offsets by global packet number)
+    DevBuf<int32_t> d_fl_src, d_fl_map;
+    DevBuf<uint32_t> d_fl_lb, d_slot_off_loc;
     DevBuf<unsigned long long> d_dense_mask; // the dense tick's heard links: 16 lane masks per (frame, chunk of 1024 nodes)
 
     DevBuf<uint32_t> d_counters; // two parities x 8: [1] dropped flag, [2..5] out_count
@@ -243,6 +247,12 @@ struct rm_context : TickSlot {
     DevBuf<rm_tx_record> d_dist_mine, d_dist_all; // this rank's packed frames / the frames of all ranks [rank][tick][slot]
     DevBuf<int32_t> d_dist_idx;                   // the gathered source indices [rank][tick][slot] (what crosses the links)
     uint32_t cap = 1u << 22;
+    // Digest of the node table (rm_table_digest): xor over the nodes of a 64-bit hash of (index, every field), mixed with the node
+    // count -- a function of the table's CONTENT, whatever sequence of uploads and updates produced it.  Ranks that exchange
+    // source indices build each other's records from their own copies of the table: the digests ride in the all-gather and a
+    // rank whose copy differs is found out (rm_dist_batch_run_sources_device, rm_batch_run_gathered_blocks_device).
+    uint64_t table_xor = 0, table_digest = 0;
+    DevBuf<int32_t> d_dist_stage; // this rank's block of a sharded batch: its source indices, then the trailer with the digest
 
     int64_t current_time = 0;
     int64_t t_begin = 0, t_end = 0;
@@ -292,7 +302,11 @@ struct rm_context : TickSlot {
         size_t h_desc_bytes[2] = {0, 0};
         hipEvent_t h_ev[2] = {nullptr, nullptr};
         int gen = 0;
-        uint32_t *h_flag = nullptr; // pinned: OvDev::misc[1] of the batch before (frames were deferred, the pair list was full: grown for the next one)
+        uint32_t *h_flag = nullptr; // pinned, one word per generation: OvDev::misc[1] of the batch that used the generation last (frames
+                                    // were deferred, the pair list was full: grown for the next batch of that generation); read only
+                                    // after that batch's copy has landed (h_flag_ev)
+        hipEvent_t h_flag_ev[2] = {nullptr, nullptr};
+        bool h_flag_used[2] = {false, false};
         uint64_t batches = 0, ticks_done = 0, last_frames = 0;
     } ov;
     bool dev_records_from_caller = false; // the tick being prepared takes rm_tx_record arrays the caller built in device memory
@@ -485,17 +499,23 @@ TickSlot *slot_of(rm_context *c, int32_t slot);
 // the launch sequence of n prepared ticks; m_override: the model the sweep runs with (a batch of overlapping SINR ticks
 // sweeps with the medium without SINR), after_sweep: issued behind the last sweep stage, inside the sampled sequence
 int launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *plans, int n, const rm::ModelDev *m_override = nullptr,
-                 int (*after_sweep)(rm_context *, void *) = nullptr, void *after_arg = nullptr);
+                 int (*after_sweep)(rm_context *, void *) = nullptr, void *after_arg = nullptr, const rm::RankFramesArgs *rank_frames = nullptr);
+// a rank's frame list for tick `t` of a batch of gathered source indices (plan and slot prepared; n_pub gathered slots)
+bool rank_frames_wanted(rm_context *c);
+int plan_rank_frames(rm_context *c, TickSlot &ts, rm::TickDev &t, int n_pub);
 // ---- rm_api_airbatch.cpp
 bool overlap_wanted(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int32_t *n_per, const int64_t *start_us,
                     const int64_t *air_us);
 int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
                       const int32_t *n_per, const int64_t *start_us, const int64_t *air_us, const rm_tx_record *gathered, int gather_world,
-                      int gather_slots, const int32_t *gathered_idx);
+                      int gather_slots, const int32_t *gathered_idx, int gather_block = 0, int digest_off = -1);
 // gathered / gathered_idx: the ticks' frames where an all-gather of per-rank blocks left them, [rank][tick][slot] -- as records, or
 // as source indices (then start_us / air_us give the ticks' time spans and every record is built from the node table)
 int batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, const int64_t *t_end_us, const int32_t *const *dev_src,
               const rm_tx_record *const *dev_new, const int32_t *n_per, const int64_t *start_us, const int64_t *air_us,
-              const rm_tx_record *gathered = nullptr, int gather_world = 0, int gather_slots = 0, const int32_t *gathered_idx = nullptr);
+              const rm_tx_record *gathered = nullptr, int gather_world = 0, int gather_slots = 0, const int32_t *gathered_idx = nullptr,
+              int gather_block = 0, int digest_off = -1);
+// (gather_block: elements from one rank's block of the gathered buffer to the next, 0 = n_ticks * gather_slots; digest_off: where
+// in a rank's block of source indices its node-table digest lies -- two words, rm_table_digest -- or -1)
 
 } // namespace rmh

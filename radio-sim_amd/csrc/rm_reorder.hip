@@ -56,6 +56,9 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
             t.out_count[2] = total;
             t.out_count[3] = vmax;
         }
+        // a rank's frame list (k_rank_frames): the packets' offsets by GLOBAL number -- an unlisted packet has no links here
+        if (publisher && t.fl_lb != nullptr)
+            for (int g = int(threadIdx.x); g <= t.n_pub; g += int(blockDim.x)) t.pub_off[g] = s_off[t.shift + int(t.fl_lb[g])];
     } else if (publisher && threadIdx.x == 0) {
         const uint32_t total = t.slot_off[t.n_cnt];
         t.out_count[0] = total < t.cap ? total : t.cap;
@@ -89,6 +92,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         if (q64 >= n_new) break; // (MODE 2 walks every frame of the block)
         const int q = int(q64);
         const int slot = q + t.shift;
+        const int q_pub = t.fl_map ? uniform_i(t.fl_map[q]) : q; // the packet's number in the result (a rank's frame list: global)
         if (kLdsCounts) {
             src0 = uint32_t(__builtin_amdgcn_readlane(int(my_src), i));
             len = uint32_t(__builtin_amdgcn_readlane(int(my_len), i));
@@ -124,7 +128,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
             }
             const uint32_t d = dst0 + rank;
             if (valid && d < t.cap) {
-                t.out_pkt[d] = q;
+                t.out_pkt[d] = q_pub;
                 t.out_dst[d] = mine;
                 t.out_rssi[d] = in_rssi;
                 uint8_t vv = v;
@@ -141,7 +145,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         }
     }
     }
-    if (!STOCH) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    if (!STOCH && t.fl_map == nullptr) write_pkt_interference(m, t, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); // (a frame list: k_rank_frames wrote them, by global number)
     if (SINR && t.air.pool != nullptr && !t.seg_ordered && publisher) air_end(t);
 }
 
@@ -610,7 +614,10 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     int fpw = max(2, min(32, max_new / 256));
     if (share > 1) fpw = min(256, fpw * 4 * share);
     if (const char *e = getenv("RM_FPW")) fpw = max(1, atoi(e));
-    const dim3 grid(max(1, min(2048, cdiv(max_new, 4 * fpw))), 1, n), block(256);
+    // (a rank's frame list: the device walks the listed frames only -- about 1/share of them and a halo; the grid only has to be
+    // large enough to be busy, every wave strides over whatever frames there are)
+    const int walk = (ticks[0].n_pub > 0 && share > 1) ? max(64, min(max_new, max_new * 3 / share)) : max_new;
+    const dim3 grid(max(1, min(2048, cdiv(walk, 4 * fpw))), 1, n), block(256);
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
         if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3, true>), grid, block, 0, s, m, b);
         else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4, true>), grid, block, 0, s, m, b);

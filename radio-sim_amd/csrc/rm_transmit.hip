@@ -30,7 +30,7 @@ void host_lcg_jump_map(uint64_t steps, uint64_t *A, uint64_t *C) { lcg_jump_map(
 // Several independent ticks per launch (rm_batch_*): blockIdx.z selects the tick.  The ticks'
 // descriptors sit in device memory (read with scalar loads at a uniform address); k_store_ticks
 // writes them there from its kernel arguments, kStoreTicks at a time (4 KB of arguments).
-constexpr int kStoreTicks = 6;
+constexpr int kStoreTicks = 5;
 struct TickGroup {
     TickDev t[kStoreTicks];
 };

@@ -370,6 +370,34 @@ class Engine:
         check(self._L.rm_batch_run_gathered_sources_device(self._h, len(tb), tb.ctypes.data, te.ctypes.data, C.c_void_p(dev_src_all_ptr),
                                                            world, slots, st.ctypes.data, int(air_us)))
 
+    GATHER_TRAILER = 4   # RM_GATHER_TRAILER: words behind a rank's source indices in its block (digest low, high, two spare)
+
+    def table_digest(self):
+        """rm_table_digest: a function of the node table's content as this context holds it"""
+        d = C.c_uint64(0)
+        check(self._L.rm_table_digest(self._h, C.byref(d)))
+        return int(d.value)
+
+    @staticmethod
+    def gather_blocks(per_rank_sources, digests):
+        """what the library's all-gather of a sharded batch delivers: per rank its [ticks][slots] source indices, then the
+        trailer with the rank's table digest -> int32 [world][ticks * slots + GATHER_TRAILER]"""
+        rows = []
+        for src, dg in zip(per_rank_sources, digests):
+            flat = np.ascontiguousarray(src, dtype=np.int32).reshape(-1)
+            tr = np.array([dg & 0xFFFFFFFF, (dg >> 32) & 0xFFFFFFFF, 0, 0], dtype=np.uint32).view(np.int32)
+            rows.append(np.concatenate([flat, tr]))
+        return np.stack(rows)
+
+    def batch_run_gathered_blocks_device(self, t_begin, t_end, dev_blocks_ptr, world, slots, start_us, air_us):
+        """as batch_run_gathered_sources_device with every rank's block followed by its trailer (gather_blocks): the ranks'
+        node-table digests are compared with this context's on the device"""
+        tb = np.ascontiguousarray(t_begin, dtype=np.int64)
+        te = np.ascontiguousarray(t_end, dtype=np.int64)
+        st = np.ascontiguousarray(start_us, dtype=np.int64)
+        check(self._L.rm_batch_run_gathered_blocks_device(self._h, len(tb), tb.ctypes.data, te.ctypes.data, C.c_void_p(dev_blocks_ptr),
+                                                          world, slots, st.ctypes.data, int(air_us)))
+
     def prepared(self, name, *args):
         """A call with its arguments converted once: `name` is an entry point that takes the context first; numpy arrays are
         passed by address (and kept alive by the closure).  The returned function costs one ctypes call -- what a host

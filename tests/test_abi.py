@@ -27,7 +27,7 @@ def test_header_symbols_exported(rsa):
 def test_binding_covers_header(rsa):
     from radio_sim_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().rm_abi_version() == 4
+    assert _lib.lib().rm_abi_version() == 5
 
 
 def test_struct_layouts(rsa):

@@ -342,3 +342,152 @@ def test_sharded_sinr_with_frames_on_the_air_from_device_records(rsa, O, world, 
     finally:
         for e in engs:
             e.close()
+
+
+# ---- round 5: a rank's frame list (k_rank_frames) and the node-table digest that rides in the all-gather
+
+def _gathered_batch(rng, n, own, world, n_ticks, t):
+    """source indices as the all-gather of a sharded batch leaves them: [rank][tick][slot], -1 = padding"""
+    ticks = [np.sort(rng.choice(n, t, replace=False)).astype(np.int32) for _ in range(n_ticks)]
+    slots = max(int((own[s] == r).sum()) for s in ticks for r in range(world)) + 2
+    packed = np.full((world, n_ticks, slots), -1, dtype=np.int32)
+    for b, s in enumerate(ticks):
+        for r in range(world):
+            mine = s[own[s] == r]
+            packed[r, b, :len(mine)] = mine
+    return packed, slots
+
+
+@pytest.mark.parametrize("kind,params,air", [("udgm", {}, 8128), ("logdist", {"ld_sigma_db": 4.0, "ld_seed": 5}, 8128),
+                                             ("logdist", {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 6}, 1000)])
+@pytest.mark.parametrize("world,mode", [(3, "spatial"), (8, "spatial"), (3, "index")])
+def test_rank_frame_lists_change_nothing(rsa, O, monkeypatch, kind, params, air, world, mode):
+    """A partitioned context keeps, of all ranks' gathered frames, only those that can matter to its receivers (k_rank_frames);
+    RM_RANK_FRAMES=0 keeps every frame as before.  Every tick's records, packet numbers, offsets by packet and Tx-failure flags
+    are the same either way, and the ranks' links merged by node index are the oracle's (16 channels, a dead transmitter and a
+    source with txProbability 0 among the frames; self-contained SINR ticks in the third medium)."""
+    from radio_sim_amd import dist as D
+    from util import DeviceArray
+    n, n_ticks, t = 20_000, 5, 300
+    rng = np.random.default_rng(23)
+    nd = O.NodeTable(n)
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    nd.channel[:] = 11 + rng.integers(0, 16, n)
+    nd.txprob[rng.choice(n, 40, replace=False)] = 0.0
+    nd.enabled[rng.choice(n, 200, replace=False)] = 0
+    own, put = owners_and_setter(rsa, D, nd, n, world, mode)
+    packed, slots = _gathered_batch(rng, n, own, world, n_ticks, t)
+    dev = DeviceArray(packed.reshape(-1))
+    t0 = np.arange(n_ticks, dtype=np.int64) * 1000
+    mdl = oracle_model(O, kind, params)
+    results = {}
+    try:
+        for knob in ("1", "0"):
+            monkeypatch.setenv("RM_RANK_FRAMES", knob)
+            per_rank = []
+            for r in range(world):
+                eng = rsa.Engine(0)
+                try:
+                    eng.upload_table(nd)
+                    eng.set_model(KINDS[kind], **{_PARAM_MAP[k]: v for k, v in params.items()})
+                    put(eng, r)
+                    eng.batch_run_gathered_sources_device(t0, t0 + 1000, dev.ptr.value, world, slots, t0, air)
+                    per_rank.append([eng.batch_result_copy(b, world * slots) for b in range(n_ticks)])
+                finally:
+                    eng.close()
+            results[knob] = per_rank
+        heard = 0
+        for b in range(n_ticks):
+            order = packed[:, b, :].reshape(-1)
+            real = np.nonzero(order >= 0)[0]
+            cpu = O.tick(mdl, nd, nd.packets(order[real], int(t0[b]), air))
+            for r in range(world):
+                a, z = results["1"][r][b], results["0"][r][b]
+                for f in ("pkt", "dst", "verdict", "rssi", "sinr", "pkt_interference", "pkt_offset"):
+                    np.testing.assert_array_equal(getattr(a, f), getattr(z, f), err_msg="rank %d tick %d: %s" % (r, b, f))
+                assert a.count == z.count and np.all(own[a.dst] == r)
+                np.testing.assert_array_equal(np.diff(a.pkt_offset.astype(np.int64)), np.bincount(a.pkt, minlength=world * slots))
+            parts = [results["1"][r][b] for r in range(world)]
+            merged = D.merge_shard_links([(p.pkt, p.dst, p.verdict, p.rssi, p.sinr) for p in parts], world * slots)
+            np.testing.assert_array_equal(merged[0], real[cpu.pkt])
+            for k, f in enumerate(("dst", "verdict", "rssi", "sinr"), start=1):
+                np.testing.assert_array_equal(merged[k], getattr(cpu, f), err_msg="tick %d %s" % (b, f))
+            np.testing.assert_array_equal(parts[0].pkt_interference[real], cpu.pkt_interference)
+            heard += cpu.count
+        assert heard > 2000
+    finally:
+        dev.free()
+
+
+def test_a_rank_one_node_update_behind_is_found_out(rsa, O):
+    """Every rank builds the other ranks' records from ITS copy of the node table (the all-gather carries source indices): a
+    rank that missed an rm_node_update would yield silently wrong verdicts.  The ranks' table digests ride in the gathered
+    blocks (rm_table_digest, rm_batch_run_gathered_blocks_device): with one context one update behind, every tick of the batch
+    reads as RM_ERR_STATE on every rank; after the update has reached it, the same batch is the oracle's."""
+    from radio_sim_amd import dist as D
+    from util import DeviceArray
+    n, world, n_ticks, t = 8000, 3, 4, 120
+    rng = np.random.default_rng(31)
+    nd = O.NodeTable(n)
+    side = 50.0 * np.sqrt(np.pi * n / 20.0)
+    nd.x, nd.y = rng.uniform(0, side, n), rng.uniform(0, side, n)
+    params = {"ld_sigma_db": 4.0, "ld_seed": 9}
+    engs = [rsa.Engine(0) for _ in range(world)]
+    dev = []
+    try:
+        for r, e in enumerate(engs):
+            e.upload_table(nd)
+            e.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+            e.set_partition_spatial(r, world)
+        own = engs[0].partition_of_nodes(world)
+        assert len({e.table_digest() for e in engs}) == 1
+        packed, slots = _gathered_batch(rng, n, own, world, n_ticks, t)
+        mover = int(packed[0, 0, 0])                     # a node that transmits in tick 0
+        nd.x[mover] += 35.0
+        nd.txpower[mover] = -3.0
+        for e in engs[:-1]:                              # ... and the last rank's host never hears of its move
+            e.update_node(mover, nd.x[mover], nd.y[mover], nd.z[mover], nd.txpower[mover], int(nd.channel[mover]), 1, 1.0, 1.0)
+        digests = [e.table_digest() for e in engs]
+        assert digests[0] == digests[1] != digests[2]
+        t0 = np.arange(n_ticks, dtype=np.int64) * 1000
+
+        def run():
+            blocks = rsa.Engine.gather_blocks([packed[r] for r in range(world)], [e.table_digest() for e in engs])
+            d = DeviceArray(blocks.reshape(-1))
+            dev.append(d)
+            for e in engs:
+                e.batch_run_gathered_blocks_device(t0, t0 + 1000, d.ptr.value, world, slots, t0, 8128)
+
+        run()
+        for e in engs:
+            for b in range(n_ticks):
+                with pytest.raises(rsa.RadioMediumError) as err:
+                    e.batch_result_copy(b, world * slots)
+                assert err.value.code == -5 and "node table" in str(err.value)
+        engs[-1].update_node(mover, nd.x[mover], nd.y[mover], nd.z[mover], nd.txpower[mover], int(nd.channel[mover]), 1, 1.0, 1.0)
+        assert len({e.table_digest() for e in engs}) == 1
+        # the digest is a function of the table's content, not of how it came about: a fresh upload of the same table agrees
+        fresh = rsa.Engine(0)
+        try:
+            fresh.upload_table(nd)
+            assert fresh.table_digest() == engs[0].table_digest()
+        finally:
+            fresh.close()
+        run()
+        mdl = oracle_model(O, "logdist", params)
+        for b in range(n_ticks):
+            order = packed[:, b, :].reshape(-1)
+            real = np.nonzero(order >= 0)[0]
+            cpu = O.tick(mdl, nd, nd.packets(order[real], int(t0[b]), 8128))
+            parts = [e.batch_result_copy(b, world * slots) for e in engs]
+            merged = D.merge_shard_links([(p.pkt, p.dst, p.verdict, p.rssi, p.sinr) for p in parts], world * slots)
+            np.testing.assert_array_equal(merged[0], real[cpu.pkt])
+            np.testing.assert_array_equal(merged[1], cpu.dst)
+            np.testing.assert_array_equal(merged[3], cpu.rssi)
+            assert cpu.count > 100
+    finally:
+        for d in dev:
+            d.free()
+        for e in engs:
+            e.close()
