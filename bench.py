@@ -160,100 +160,133 @@ def kernel_stage(name):
     return None
 
 
-def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_per_launch, step_s, contexts, workload, pmc_ok=True,
-                    tick_key=False, pairs_per_launch=0, under_profiler=None):
-    """The result line's `roofline`.
+def required_bytes(n_loc, t_per_tick, heard, ticks_per_launch, sinr_column, tile_reuse=1):
+    """What ONE launch sequence of this shape has to move at the least: section 8(d)'s bytes with the two terms the launch shape
+    changes -- a heard-link record is 17 bytes where the medium has no sinr column (rm_device_result.sinr is NULL: the column
+    is neither allocated nor written), and a filter workgroup that keeps its receivers for `tile_reuse` ticks of the launch
+    (rm_filter.hip: filter_wg_body) fetches the receiver table once per that many ticks, not once per tick."""
+    rec = S_REC if sinr_column else S_REC - 8
+    return int((n_loc * S_NODE / max(1, tile_reuse) + t_per_tick * S_TX + heard * rec) * ticks_per_launch)
 
-    achieved = section 8(d)'s bytes of everything ONE launch sequence processes, (N_loc*37 + T*56 + H*25) x ticks per launch,
-    over the device time of the sequence's kernels; frac = achieved / 8 TB/s.  A kernel's duration is its OWN dispatch interval:
-    every sampled launch of the timed region carries a pair of HIP events bound to that dispatch (rm_profile_enable ->
-    hipExtLaunchKernelGGL), the interval `rocprofv3 --kernel-trace --stats` reports for the same kernel (the summaries under
-    profiles/ are of this command; `kernel` / `kernel_avg_us` name the dominant one).  With several contexts in flight a
-    kernel's interval overlaps the other contexts' kernels, so one interval may be longer than the step; what cannot be is the
-    per-context share: the intervals of one launch sequence, summed, over the contexts in flight (`overlap_check`), which is
-    what `achieved` divides by.  `kernels` prices every kernel with ITS OWN bytes:
-      filter     ticks x (N_loc*16 pre-filter records + T*28 frame records + cand*12 candidate entries written)
-      exact      ticks x (cand*(12 + 32) entries and receiver records + H*13 staged link records written)
-      reorder    ticks x (H*13 read + H*17 written)
-      tick       the one-launch tick: the whole of section 8(d)'s bytes of its tick
-    `traffic` = HBM bytes of ALL kernels of a launch sequence from the PMC passes on file (profiles/pmc_traffic.json: collected
-    by tools/collect_profiles.sh at the commit named there, not in this run: marked from_profile_file), so that
-    traffic / algorithmic_bytes_per_launch compares like with like; `valu_issue` = the kernels' vector-issue time from the same
-    file over THIS run's driver-timed step: the share of the chip's issue slots the step uses -- the resource that binds
-    these integer / fp32 / fp64 sweeps (the HBM fraction is small by construction)."""
-    b_tick = n_loc * S_NODE + t_per_tick * S_TX + heard * S_REC
-    b_launch = b_tick * ticks_per_launch
-    own = {"filter": (n_loc * 16 + t_per_tick * 28 + cand * 12) * ticks_per_launch,
-           "exact": (cand * 44 + heard * 13) * ticks_per_launch,
-           "reorder": heard * 30 * ticks_per_launch,
-           "tick": b_launch,
-           "ov_pairs": (heard * 49 + t_per_tick * 64 * 48) * ticks_per_launch + pairs_per_launch * 16,
-           "ov_exact": pairs_per_launch * (16 + 32 + 64 + 16),
-           "ov_verdict": heard * 34 * ticks_per_launch,
-           # the dense tick (rm_dense.hip): both passes read the node-ordered columns (N*37 at most, L2-resident after the first
-           # frame), the second writes the records: it is priced with the whole of 8(d)'s bytes of its tick
-           "dense": b_launch, "dense_count": n_loc * S_NODE + t_per_tick * S_TX}
-    per_kernel = {}
+
+def tile_reuse_of(n_loc, ticks_per_launch):
+    """ticks a filter workgroup sweeps with one load of its 1024 receivers (launch_filter_batch's rule, rm_filter.hip)"""
+    tiles = -(-n_loc // 1024)
+    return max(1, min(ticks_per_launch, (tiles * ticks_per_launch) // 3072)) if ticks_per_launch > 1 else 1
+
+
+def kernel_table(kernels, n_samples, own):
+    """per kernel: average interval, launches per sequence, its own algorithmic bytes"""
+    out = {}
     for name, k in kernels.items():
         if k["launches"] == 0:
             continue
         us = k["ms"] / k["launches"] * 1e3
         st = kernel_stage(name)
         b = own.get(st)
-        # launches of this kernel per sampled sequence (a stage may launch a kernel more than once)
-        per_seq = k["launches"] / max(1, n_samples)
-        per_kernel[name] = {"avg_us": us, "launches_sampled": k["launches"], "launches_per_sequence": per_seq, "stage": st,
-                            "algorithmic_bytes": b, "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
-                            "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
+        out[name] = {"avg_us": us, "launches_sampled": k["launches"], "launches_per_sequence": k["launches"] / max(1, n_samples), "stage": st,
+                     "algorithmic_bytes": b, "achieved_GBps": (b / (us * 1e-6) / 1e9) if (b and us > 0) else None,
+                     "hbm_frac": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (b and us > 0) else None}
+    return out
+
+
+def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_per_launch, step_s, contexts, workload, pmc_ok=True,
+                    tick_key=False, pairs_per_launch=0, under_profiler=None, alone=None, sinr_column=False, tile_reuse=1):
+    """The result line's `roofline`, for the DOMINANT kernel of a launch sequence:
+
+      achieved = bytes of ONE launch sequence / the dominant kernel's average duration, frac = achieved / 8 TB/s.
+
+    The duration is the kernel's OWN dispatch interval (a pair of HIP events bound to that dispatch: rm_profile_enable ->
+    hipExtLaunchKernelGGL -- what `rocprofv3 --kernel-trace --stats` reports for the same kernel), taken from launch sequences
+    that run ALONE on the device (`alone`: probed sequences on one context after the timed region, nothing else in flight), so
+    an interval is the kernel's time, not the time it shared with other contexts' kernels.  The bytes: `required_bytes` --
+    section 8(d)'s figure for this launch shape (required_bytes(): 17-byte records without a sinr column, a receiver tile
+    charged once per reuse window); the plain 8(d) figure is carried beside it (`algorithmic_bytes_per_launch`, `frac_8d`).
+    No kernel can move its launch's required bytes faster than the HBM: frac > 1 refuses the line.
+
+    `bound` names the resource the STEP uses most of: `hbm` (bytes of the step / driver-timed step / 8 TB/s) or `valu` (the
+    kernels' vector-issue time, SQ_ACTIVE_INST_VALU from the PMC passes on file, / the driver-timed step) -- SURVEY.md 8(d):
+    these culled sweeps are issue-bound, not HBM-bound, and the line says so.
+    `contended`: the same kernels' intervals as sampled INSIDE the timed region (several contexts in flight: every interval is
+    stretched by the others' kernels).  Kept only for the cross-check: their sum over the contexts in flight cannot exceed the
+    driver-timed step by more than the probes' own cost, which is measured in the same run (`alone.probe_cost_us_per_launch`:
+    the same sequences with and without probes)."""
+    b_tick = n_loc * S_NODE + t_per_tick * S_TX + heard * S_REC
+    b_launch = b_tick * ticks_per_launch
+    b_req = required_bytes(n_loc, t_per_tick, heard, ticks_per_launch, sinr_column, tile_reuse)
+    rec_w = 17 if not sinr_column else 25
+    own = {"filter": (n_loc * 16 // max(1, tile_reuse) + t_per_tick * 28 + cand * 12) * ticks_per_launch,
+           "exact": (cand * 44 + heard * 13) * ticks_per_launch,
+           "reorder": heard * (13 + rec_w) * ticks_per_launch,
+           "tick": b_req,
+           "ov_pairs": (heard * 49 + t_per_tick * 64 * 48) * ticks_per_launch + pairs_per_launch * 16,
+           "ov_exact": pairs_per_launch * (16 + 32 + 64 + 16),
+           "ov_verdict": heard * 34 * ticks_per_launch,
+           # the dense tick (rm_dense.hip): the count pass reads the node-ordered columns, the write pass writes the records
+           "dense": heard * rec_w * ticks_per_launch, "dense_count": n_loc * S_NODE + t_per_tick * S_TX}
+    cont = kernel_table(kernels, n_samples, own)
+    src = alone if (alone and alone.get("kernels")) else None
+    per_kernel = kernel_table(src["kernels"], src["n_samples"], own) if src else cont
     priced = {n: v for n, v in per_kernel.items() if v["stage"] is not None}
     if priced:
         dominant = max(priced, key=lambda n: priced[n]["avg_us"] * priced[n]["launches_per_sequence"])
         kern_us = priced[dominant]["avg_us"]
     else:
         dominant, kern_us = None, 0.0
-    seq_us = sum(v["avg_us"] * v["launches_per_sequence"] for v in per_kernel.values())
+    achieved = b_req / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+    frac = achieved / HBM_PEAK_GBS
+    if frac > 1.0:
+        raise SystemExit("roofline refused: %s would have moved the launch's required bytes (%d) in %.1f us = %.2f x the HBM peak"
+                         % (dominant, b_req, kern_us, frac))
+    seq_us = sum(v["avg_us"] * v["launches_per_sequence"] for v in cont.values())
+    launches_per_seq = sum(v["launches_per_sequence"] for v in cont.values())
     share_us = seq_us / max(1, contexts)
-    probe_slack_us = 3.0 * sum(v["launches_per_sequence"] for v in per_kernel.values()) / max(1, contexts)
-    # achieved: the bytes of one launch sequence over the device time its kernels take -- every kernel's own interval, summed;
-    # with several contexts in flight the sequences overlap and each kernel's interval is stretched by the others', so the sum
-    # is divided by the contexts in flight.  (The whole launch's bytes over the DOMINANT kernel's interval alone -- the other
-    # kernels' time left out -- is printed as dominant_kernel.launch_bytes_over_this_kernel_frac: it overstates a sequence of
-    # several comparable kernels, 0.93 for configs[4]'s twelve.)
-    achieved = b_launch / (share_us * 1e-6) / 1e9 if share_us > 0 else 0.0
-    dom = dict(priced[dominant]) if dominant else None
-    if dom:
-        dom["name"] = dominant
-        dom["launch_bytes_over_this_kernel_frac"] = b_launch / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS if kern_us > 0 else None
-    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-          "traffic": None, "kernel": dominant, "kernel_avg_us": kern_us, "launches_sampled": n_samples,
-          "kernel_time_source": "HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL start/stop) on the sampled launch "
-                                "sequences of the timed region: the interval rocprofv3 --kernel-trace reports (+ ~1.4 us per launch: "
-                                "tools/probe_check.hip)",
-          "sequence_kernel_us": seq_us, "contexts_in_flight": contexts,
-          "algorithmic_bytes_per_launch": b_launch,
-          "algorithmic_bytes_per_tick": "N_loc*37 + T*56 + H*25 = %d" % b_tick,
-          "dominant_kernel": dom,
-          "kernels": per_kernel,
-          "overlap_check": {"kernel_us_per_sequence": seq_us, "contexts_in_flight": contexts, "per_context_share_us": share_us,
-                            "step_us": step_s * 1e6, "ok": bool(share_us <= step_s * 1e6 * 1.02 + probe_slack_us),
-                            "probe_slack_us": probe_slack_us,
-                            "what": "the kernel intervals of one launch sequence, summed, over the contexts in flight: cannot exceed the "
-                                    "driver-timed step (+ 3 us per probed launch: what the event pair adds to a sampled launch -- 1.4 us, "
-                                    "tools/probe_check.hip -- and the overlap of consecutive short kernels it takes away are in the "
-                                    "sampled intervals and not in the average step)"},
-          "whole_step": {"algorithmic_bytes": b_launch, "ms_per_step": step_s * 1e3, "achieved": b_launch / step_s / 1e9,
-                         "frac": b_launch / step_s / 1e9 / HBM_PEAK_GBS,
-                         "note": "SURVEY.md 8(d) bytes of one step over the driver-timed step (kernels + launch gaps + host): no overlap can "
-                                 "inflate or deflate it"},
-          "valu_issue": None, "traffic_source": "no PMC pass on file for this workload and launch shape"}
+    probe_cost = (alone or {}).get("probe_cost_us_per_launch")
+    probe_slack_us = (probe_cost if probe_cost is not None else 0.0) * launches_per_seq / max(1, contexts)
     if under_profiler is None:   # (a profiler stretches every launch: the bench's own cross-check is for runs without one)
         under_profiler = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH"))
-    rl["overlap_check"]["under_profiler"] = bool(under_profiler)
-    # (not ok: printed with the line; the run is only refused when the two clocks disagree grossly -- sampled sequences of many
-    # short kernels run slower than the unsampled ones around them, every probed launch waits for the one before it)
-    if share_us > step_s * 1e6 * 1.25 + probe_slack_us and not under_profiler:
-        raise SystemExit("roofline cross-check failed: the kernels of one launch sequence take %.1f us per context in flight, the "
-                         "driver-timed step only %.1f us" % (share_us, step_s * 1e6))
+    check_ok = bool(share_us <= step_s * 1e6 * 1.02 + probe_slack_us) if cont else None
+    hbm_step = b_req / step_s / 1e9 / HBM_PEAK_GBS if step_s > 0 else 0.0
+    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+          "traffic": None, "kernel": dominant, "kernel_avg_us": kern_us,
+          "kernel_time_source": ("probed launch sequences alone on the device, after the timed region (one context, nothing else in flight)"
+                                 if src else "probed launch sequences of the timed region (contended: no separate pass in this mode)") +
+                                ": HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL start/stop), the interval "
+                                "rocprofv3 --kernel-trace reports",
+          "launches_sampled": (src["n_samples"] if src else n_samples),
+          "required_bytes_per_launch": b_req,
+          "required_bytes": "(N_loc*37/%d + T*56 + H*%d) x %d ticks: 8(d) for this launch shape (%s; a receiver tile is fetched once per %d "
+                            "ticks of the launch)" % (max(1, tile_reuse), rec_w, ticks_per_launch,
+                                                      "25-byte records" if sinr_column else "17-byte records: no sinr column without the SINR extension",
+                                                      max(1, tile_reuse)),
+          "algorithmic_bytes_per_launch": b_launch,
+          "algorithmic_bytes_per_tick": "N_loc*37 + T*56 + H*25 = %d" % b_tick,
+          "frac_8d": (b_launch / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
+          "kernels": per_kernel,
+          "step": {"hbm_frac": hbm_step, "valu_frac": None,
+                   "what": "the driver-timed step's use of the two resources: required bytes / step / 8 TB/s, and the kernels' vector-issue "
+                           "time / step; `bound` names the larger"},
+          "contended": {"kernels": cont, "sequence_kernel_us": seq_us, "contexts_in_flight": contexts, "launches_sampled": n_samples} if src else None,
+          "overlap_check": {"kernel_us_per_sequence": seq_us, "contexts_in_flight": contexts, "per_context_share_us": share_us,
+                            "step_us": step_s * 1e6, "ok": check_ok, "probe_cost_us_per_launch": probe_cost,
+                            "probe_slack_us": probe_slack_us, "under_profiler": bool(under_profiler),
+                            "what": "the kernel intervals of one launch sequence of the timed region, summed, over the contexts in flight: "
+                                    "at most the driver-timed step x 1.02 + what the probes cost the sampled launches (measured in this "
+                                    "run: the same sequences with and without probes)"},
+          "whole_step": {"algorithmic_bytes": b_launch, "required_bytes": b_req, "ms_per_step": step_s * 1e3,
+                         "achieved": b_req / step_s / 1e9, "frac": hbm_step,
+                         "note": "required bytes of one step over the driver-timed step (kernels + launch gaps + host)"},
+          "valu_issue": None, "traffic_source": "no PMC pass on file for this workload and launch shape"}
+    if alone:
+        rl["alone"] = {k: v for k, v in alone.items() if k != "kernels"}
+        au = alone.get("step_us_probed")
+        su = sum(v["avg_us"] * v["launches_per_sequence"] for v in per_kernel.values())
+        if au:   # one stream, one context: the sequence's kernel intervals cannot add up to more than the wall time of the probed step
+            rl["alone"]["kernel_us_per_sequence"] = su
+            rl["alone"]["ok"] = bool(su <= au * 1.02 + 1.0)
+    if check_ok is False and not under_profiler:
+        rl["overlap_check"]["note"] = ("the two clocks disagree: `achieved` / `frac` do not depend on the contended intervals (they come from "
+                                       "the launch sequences that ran alone); see the top-level key roofline_check_failed")
     if not pmc_ok:
         return rl
     try:
@@ -268,6 +301,7 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
             by_stage = {k: int(v["hbm_bytes_per_launch"] * scale) for k, v in ents.items()}
             rl["traffic"] = int(sum(by_stage.values()))
             rl["traffic_by_kernel"] = by_stage
+            rl["traffic_over_required"] = rl["traffic"] / b_req if b_req else None
             rl["traffic_over_algorithmic"] = rl["traffic"] / b_launch if b_launch else None
             rl["traffic_from_profile_file"] = True
             rl["traffic_source"] = ("%s (commit %s; all kernels of a launch sequence, per launch of %d ticks, scaled to %d): rocprofv3 "
@@ -284,9 +318,40 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
                                     "what": "SQ_ACTIVE_INST_VALU (quad-cycles over 1024 SIMDs at 2.4 GHz) of every kernel of one launch "
                                             "sequence, summed, over THIS run's driver-timed step: the share of the chip's vector issue "
                                             "slots the step uses"}
+                rl["step"]["valu_frac"] = rl["valu_issue"]["chip_utilisation"]
+                if rl["step"]["valu_frac"] > rl["step"]["hbm_frac"]:
+                    rl["bound"] = "valu"
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return rl
+
+
+def probe_pass(eng, sync, calls):
+    """The same launch sequences ALONE on the device (one context, nothing else in flight): once without probes, once with
+    every launch probed -- the kernels' own intervals for the roofline line, and what a probe costs a launch in this run.
+    `calls`: 2k prepared steps (the first k run unprobed, the last k probed); sync(): wait for the context's stream."""
+    k = len(calls) // 2
+    if k < 1:
+        return None
+    sync()
+    t0 = time.perf_counter()
+    for c in calls[:k]:
+        c()
+    sync()
+    t_plain = (time.perf_counter() - t0) / k
+    eng.profile_enable(1)
+    t0 = time.perf_counter()
+    for c in calls[k:2 * k]:
+        c()
+    sync()
+    t_probed = (time.perf_counter() - t0) / k
+    n_samples, _ = eng.profile_read()
+    kernels = {name: {"launches": l, "ms": ms, "stage": st} for name, (l, ms, st) in eng.profile_kernels().items()}
+    eng.profile_enable(0)
+    launches = sum(v["launches"] for v in kernels.values()) / max(1, n_samples)
+    return {"kernels": kernels, "n_samples": n_samples, "sequences": k, "step_us_plain": t_plain * 1e6, "step_us_probed": t_probed * 1e6,
+            "launches_per_sequence": launches,
+            "probe_cost_us_per_launch": max(0.0, (t_probed - t_plain) * 1e6 / max(1.0, launches))}
 
 
 def cpu_baseline(wl, nodes, sources, cpu_ticks):
@@ -382,8 +447,16 @@ def scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch, ticks=384, 
     except Exception:
         cand = 0
     per_tick = el / ticks
+    alone = None
+    if batch > 1:   # the same launch sequences alone on the device: the kernels' own intervals
+        t0 = np.arange(batch, dtype=np.int64) * W.TICK_US
+        ptrs = np.array([src_dev[kk].data_ptr() for kk in range(batch)], dtype=np.uint64)
+        call = engines[0].prepared("rm_batch_run_sources_device", batch, t0, t0 + W.TICK_US, ptrs, np.full(batch, t_per_tick, dtype=np.int32),
+                                   t0, np.full(batch, W.AIR_US, dtype=np.int64))
+        alone = probe_pass(engines[0], streams[0].synchronize, [call] * 8)
     rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t_per_tick, heard=heard, cand=cand,
-                         ticks_per_launch=batch, step_s=per_tick * batch, contexts=inflight, workload="m1")
+                         ticks_per_launch=batch, step_s=per_tick * batch, contexts=inflight, workload="m1", alone=alone,
+                         tile_reuse=engines[0].batch_tile_reuse() if batch > 1 else 1)
     for e in engines:
         e.close()
     return {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "ticks_in_flight": inflight * batch,
@@ -526,15 +599,18 @@ def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
         n_samples, _ = e.profile_read()
         kernels = {nm: {"launches": l, "ms": ms, "stage": sg} for nm, (l, ms, sg) in e.profile_kernels().items()}
         e.profile_enable(0)
+        with torch.cuda.stream(st):
+            alone = probe_pass(e, st.synchronize, calls[:16])
         e.close()
         per_tick = el / ticks
         rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t, heard=heard, cand=0, ticks_per_launch=1,
-                             step_s=per_tick, contexts=1, workload="dense_" + name, pmc_ok=False)
+                             step_s=per_tick, contexts=1, workload="dense_" + name, pmc_ok=False, alone=alone)
         try:    # the counter passes on file for this shape (profiles/r04_dense_pmc.csv: the count pass per medium, the write pass of both)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("dense", {})
             parts = [pmc.get("k_dense_count_" + ("null" if name == "null_medium" else "udgm")), pmc.get("k_dense_write")]
             if all(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in parts):
                 rl["traffic"] = int(sum(v["hbm_bytes_per_launch"] for v in parts))
+                rl["traffic_over_required"] = rl["traffic"] / rl["required_bytes_per_launch"]
                 rl["traffic_source"] = ("profiles/pmc_traffic.json ('dense', commit %s): FETCH_SIZE / WRITE_SIZE passes of bench.py --dense-only, "
                                         "count + write kernels of one tick; from_profile_file" % pmc.get("commit"))
         except (OSError, ValueError):
@@ -958,6 +1034,27 @@ def main():
         heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
         if dropped:
             raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
+        # the same launch sequences ALONE on the device (context 0, nothing else in flight), with and without probes: the
+        # kernels' own intervals for the roofline line.  Every rank of a sharded run makes the same calls (a collective inside).
+        alone = None
+        sinr_column = model in ("logdist_sinr16", "logdist_sinr_overlap")
+        if sharded is None:
+            with torch.cuda.stream(stream):
+                n_probe = 4 if batch > 1 else 64
+                if batch > 1:
+                    probe_calls = [step_call(0, warm_ticks + (j % max(1, args.steps)) * batch, batch, clock[0] + j * batch)
+                                   for j in range(2 * n_probe)]
+                    clock[0] += 2 * n_probe * batch
+                else:
+                    probe_calls = []
+                    for j in range(2 * n_probe):
+                        t0p = (clock[0] + j) * tick_us
+                        probe_calls.append(eng.prepared("rm_tick_run_sources_device", t0p, t0p + tick_us,
+                                                        ctypes.c_void_p(src_dev[(warm_ticks + j) % pool].data_ptr()), t_per_tick, t0p, W.AIR_US))
+                    clock[0] += 2 * n_probe
+                alone = probe_pass(eng, stream.synchronize, probe_calls)
+            fence()
+        tile_reuse = eng.batch_tile_reuse() if batch > 1 else 1
 
         if world > 1:
             rdev = dev if backend == "nccl" else torch.device("cpu")
@@ -1003,6 +1100,15 @@ def main():
             seq_samples, _ = eng.profile_read()
             seq_kernels = {name: {"launches": l, "ms": ms, "stage": st} for name, (l, ms, st) in eng.profile_kernels().items()}
             eng.profile_enable(0)
+            clock[0] += seq_ticks
+            with torch.cuda.stream(stream):   # the lone tick alone, every launch probed / none probed
+                seq_calls = []
+                for j in range(128):
+                    t0p = (clock[0] + j) * tick_us
+                    seq_calls.append(eng.prepared("rm_tick_run_sources_device", t0p, t0p + tick_us,
+                                                  ctypes.c_void_p(src_dev[(warm_ticks + j) % pool].data_ptr()), t_per_tick, t0p, W.AIR_US))
+                clock[0] += 128
+                seq_alone = probe_pass(eng, stream.synchronize, seq_calls)
             sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
                           "ms_per_tick": el / seq_ticks * 1e3,
                           "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
@@ -1017,7 +1123,7 @@ def main():
                 cand1 = 0
             rl = roofline_object(kernels=seq_kernels, n_samples=seq_samples, n_loc=n_loc, t_per_tick=t_per_tick, heard=heard, cand=cand1,
                                  ticks_per_launch=1, step_s=sequential["ms_per_tick"] * 1e-3, contexts=1, workload=args.workload,
-                                 pmc_ok=(args.nodes == 0), tick_key=True)
+                                 pmc_ok=(args.nodes == 0), tick_key=True, alone=seq_alone, sinr_column=sinr_column)
             rl["bound_note"] = ("latency: a lone tick of this size is a chain of dependent launches and memory round trips on a mostly idle "
                                 "device; neither HBM bytes nor issue slots bind it (DESIGN.md section 4.8)")
             sequential["roofline"] = rl
@@ -1033,7 +1139,8 @@ def main():
                 pairs, _, interferers = eng.air_batch_pairs()
             roofline = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n_loc, t_per_tick=t_per_tick, heard=heard, cand=cand,
                                        ticks_per_launch=batch, step_s=step_s, contexts=inflight, workload=args.workload,
-                                       pmc_ok=(world == 1 and not as_rank and args.nodes == 0), pairs_per_launch=pairs)
+                                       pmc_ok=(world == 1 and not as_rank and args.nodes == 0), pairs_per_launch=pairs, alone=alone,
+                                       sinr_column=sinr_column, tile_reuse=tile_reuse)
             if pairs:
                 roofline["surviving_pairs_per_launch"] = pairs
                 roofline["interfering_pairs_per_launch"] = interferers
@@ -1051,7 +1158,7 @@ def main():
                 "vs_baseline": None,
                 "dtype": "f64",
                 "data": "synthetic",
-                "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": W.TICK_US, "ticks_in_flight": inflight * batch,
+                "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": tick_us, "ticks_in_flight": inflight * batch,
                            "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
                            "step": "one launch sequence sweeping ticks_per_step simulated ticks",
                            "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
@@ -1061,6 +1168,9 @@ def main():
                                            else "torch.distributed around the engine calls")) if world > 1 else "none"},
                 "roofline": roofline,
             }
+            if roofline["overlap_check"]["ok"] is False and not roofline["overlap_check"]["under_profiler"]:
+                out["roofline_check_failed"] = ("the kernel intervals sampled inside the timed region add up to more than the driver-timed step "
+                                                "allows (overlap_check): roofline.achieved / frac come from the launch sequences that ran alone")
             if sequential is not None:
                 out["sequential_ticks"] = sequential
             if world == 1 and not stateful and not as_rank and not args.no_host_transfer:

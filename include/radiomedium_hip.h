@@ -336,6 +336,9 @@ int rm_batch_run_gathered_blocks_device(rm_context *ctx, int32_t n_ticks, const 
 /* digest of the node table as this context holds it: a function of its content (node count and every node's fields),
  * whatever sequence of rm_nodes_upload / rm_node_update / rm_nodes_move calls produced it */
 int rm_table_digest(const rm_context *ctx, uint64_t *digest);
+/* ticks of the last batch a filter workgroup swept with one load of its 1024 receivers: the receiver table left HBM once per
+ * that many ticks of the launch (what a roofline has to charge the launch for the table) */
+int rm_batch_tile_reuse(const rm_context *ctx);
 int rm_batch_result_device(rm_context *ctx, int32_t slot, rm_device_result *out);
 int rm_batch_result_count(rm_context *ctx, int32_t slot, uint32_t *count, uint32_t *dropped); /* synchronises */
 int rm_batch_result_copy(rm_context *ctx, int32_t slot, int32_t *pkt, int32_t *dst, uint8_t *verdict, double *rssi,

@@ -161,6 +161,7 @@ SIGNATURES = {
     "rm_batch_run_gathered_sources_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "rm_batch_run_gathered_blocks_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "rm_table_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rm_batch_tile_reuse": (C.c_int, [C.c_void_p]),
     "rm_comm_available": (C.c_int, []),
     "rm_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "rm_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),

@@ -155,6 +155,7 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
     }
     RM_TRY(stage(RM_STAGE_FILTER));
     RM_HIP(rm::launch_batch_stage(s, 0, nd, m, ticks, n, dev_ticks, cfg));
+    c->last_tile_reuse = rm::filter_ticks_per_wg(ticks[0], n);
     RM_TRY(stage(RM_STAGE_EXACT));
     RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, dev_ticks, cfg));
     if (plans[0].sinr) {
@@ -347,6 +348,8 @@ int rm_batch_run_gathered_device(rm_context *c, int32_t n_ticks, const int64_t *
     if (!dev_gathered) return fail(RM_ERR_INVALID, "bad arguments");
     return batch_run(c, n_ticks, t_begin_us, t_end_us, nullptr, nullptr, nullptr, nullptr, nullptr, dev_gathered, world, slots);
 }
+
+int rm_batch_tile_reuse(const rm_context *c) { return c ? c->last_tile_reuse : fail(RM_ERR_INVALID, "ctx is NULL"); }
 
 int rm_batch_result_device(rm_context *c, int32_t slot, rm_device_result *out)
 {

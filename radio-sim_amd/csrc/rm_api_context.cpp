@@ -381,6 +381,7 @@ int rm_set_model(rm_context *c, const rm_model_params *p)
 {
     if (!c || !p) return fail(RM_ERR_INVALID, "NULL argument");
     RM_TRY(validate_model(p));
+    RM_TRY(ev_flush_append(c)); // (the tick before was evaluated by the old medium: its append does not wait for the next drain)
     const bool was_geo = is_geometric(c);
     c->params = *p;
     if (was_geo != is_geometric(c)) c->rx_dirty = true;

@@ -102,7 +102,6 @@ int ev_append(rm_context *c, TickSlot &ts, bool may_wait)
     }
     ls.per_frame_verdict = (!ts.last_cfg.stochastic && !is_sinr(c)) ? 1 : 0;
     const int immediate = (c->params.kind == RM_MODEL_UDGM_CONST) ? 1 : 0;
-    c->ev.next_packet += ts.last_n_new;
     static const bool never_wait = [] { const char *e = std::getenv("RM_EV_FUSE"); return e && std::atoi(e) == 0; }();
     if (may_wait && !never_wait) { // (the closed loop: rm_events_process comes next, and takes the append into its first launch)
         rm_context::Events::Pending &p = c->ev.pending;
@@ -113,10 +112,12 @@ int ev_append(rm_context *c, TickSlot &ts, bool may_wait)
         p.now = c->current_time;
         p.immediate = immediate;
         p.dropped = dropped;
+        c->ev.next_packet += ts.last_n_new; // (numbered once the append is queued: a failed launch leaves the numbering where it was)
         return RM_OK;
     }
     RM_HIP(rm::launch_ev_append(c->stream, ev_dev(c), ls, t.tx + t.first_new, ts.last_n_new, c->current_time, immediate, dropped));
     c->ev.par ^= 1; // the launch wrote the other set of tails
+    c->ev.next_packet += ts.last_n_new;
     return RM_OK;
 }
 
@@ -275,6 +276,7 @@ int rm_node_info(rm_context *c, const int32_t *nodes, int32_t n, double *rssi, i
     if (n == 0) return RM_OK;
     if (!nodes && n > c->n) return fail(RM_ERR_INVALID, "more nodes than the table holds");
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_flush_append(c)); // (an append left for the next drain runs with the state it was planned with, before anything reads or resets it)
     RM_TRY(ev_ensure_nodes(c));
     rm_context::Events &v = c->ev;
     if (v.info_n < n) {
@@ -318,6 +320,7 @@ int rm_node_info_changed(rm_context *c, int32_t *nodes, double *rssi, int32_t *r
     if (n == 0) return RM_OK;
     if (cap < n) return fail(RM_ERR_CAPACITY, "room for every node, please: a first call reports them all");
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_flush_append(c)); // (an append left for the next drain runs with the state it was planned with, before anything reads or resets it)
     RM_TRY(ev_ensure_nodes(c));
     rm_context::Events &v = c->ev;
     if (v.rep_n != n) { // a new table: nothing of it has been reported

@@ -390,6 +390,7 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
             return fail(RM_ERR_INVALID, "node positions must be finite");
     }
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_flush_append(c)); // (an append left for the next drain reads the tick's records and the radio-state arrays as they are now)
     c->n = n;
     c->x.assign(x, x + n);
     c->y.assign(y, y + n);
@@ -446,6 +447,7 @@ int rm_node_update(rm_context *c, int32_t i, double x, double y, double z, doubl
     if (!c || i < 0 || i >= c->n) return fail(RM_ERR_INVALID, "node index out of range");
     if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return fail(RM_ERR_INVALID, "position must be finite");
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_flush_append(c));
     note_probabilities(c, c->rxprob[i], c->txprob[i], rxprob, txprob);
     c->table_xor ^= node_hash(c, i);
     c->x[i] = x; c->y[i] = y; c->z[i] = z; c->txpower[i] = txpower; c->channel[i] = channel;
@@ -464,6 +466,7 @@ int rm_nodes_move(rm_context *c, int32_t count, const int32_t *nodes, const doub
             return fail(RM_ERR_INVALID, "position must be finite");
     }
     RM_HIP(hipSetDevice(c->device));
+    RM_TRY(ev_flush_append(c));
     for (int k = 0; k < count; ++k) {
         const int i = nodes[k];
         c->table_xor ^= node_hash(c, i);

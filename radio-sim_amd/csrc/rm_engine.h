@@ -580,6 +580,7 @@ struct RankFramesArgs {
 hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, const RankFramesArgs &a);
 constexpr int kGatherTrailer = RM_GATHER_TRAILER; // words behind a rank's source indices in its block of a sharded batch
 hipError_t launch_stage_block(hipStream_t s, const int32_t *src, int n, uint64_t digest, int32_t *dst);
+int filter_ticks_per_wg(const TickDev &t0, int n);
 hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
 hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,

@@ -1110,6 +1110,16 @@ hipError_t launch_filter(hipStream_t s, const NodesDev &nd, const ModelDev &m, c
     return hipGetLastError();
 }
 
+// ticks of a batch a filter workgroup sweeps with ONE load of its receivers (rm_batch_tile_reuse reports it: the receiver
+// table leaves HBM once per that many ticks of a launch)
+int filter_ticks_per_wg(const TickDev &t0, int n)
+{
+    const int tiles = cdiv(t0.n_slabs, kWavesPerBlock);
+    int per_wg = max(1, min(n, (tiles * n) / 3072));
+    if (const char *e = getenv("RM_FILTER_TICKS_PER_WG")) per_wg = max(1, min(n, atoi(e)));
+    return per_wg;
+}
+
 // rm_batch_*, stage 0: every tick's pre-pass and two-level filter (blockIdx.z = tick); `ticks` are the host
 // copies of the descriptors (grid sizes), `b` the same descriptors in device memory
 hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n, const TickDev *b,
@@ -1126,8 +1136,7 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     // A workgroup keeps its receivers for `per_wg` ticks: as many as leave a few thousand workgroups for the chip (a table
     // of a million receivers has a thousand tiles: 16 ticks = 4 per workgroup; 100 k receivers: one tick per workgroup).
     const int tiles = cdiv(t0.n_slabs, kWavesPerBlock);
-    int per_wg = max(1, min(n, (tiles * n) / 3072));
-    if (const char *e = getenv("RM_FILTER_TICKS_PER_WG")) per_wg = max(1, min(n, atoi(e)));
+    const int per_wg = filter_ticks_per_wg(t0, n);
     const dim3 grid(tiles, 1, cdiv(n, per_wg)), block(kBlock);
     if (t0.rpt == 4) {
         if (cfg.shadow) RM_KLAUNCH((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b, n, per_wg);

@@ -247,6 +247,7 @@ struct rm_context : TickSlot {
     DevBuf<rm_tx_record> d_dist_mine, d_dist_all; // this rank's packed frames / the frames of all ranks [rank][tick][slot]
     DevBuf<int32_t> d_dist_idx;                   // the gathered source indices [rank][tick][slot] (what crosses the links)
     uint32_t cap = 1u << 22;
+    int last_tile_reuse = 1; // ticks of the last batch a filter workgroup swept with one load of its receivers (rm_batch_tile_reuse)
     // Digest of the node table (rm_table_digest): xor over the nodes of a 64-bit hash of (index, every field), mixed with the node
     // count -- a function of the table's CONTENT, whatever sequence of uploads and updates produced it.  Ranks that exchange
     // source indices build each other's records from their own copies of the table: the digests ride in the all-gather and a

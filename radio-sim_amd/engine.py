@@ -372,6 +372,10 @@ class Engine:
 
     GATHER_TRAILER = 4   # RM_GATHER_TRAILER: words behind a rank's source indices in its block (digest low, high, two spare)
 
+    def batch_tile_reuse(self):
+        """ticks of the last batch a filter workgroup swept with one load of its receivers"""
+        return int(self._L.rm_batch_tile_reuse(self._h))
+
     def table_digest(self):
         """rm_table_digest: a function of the node table's content as this context holds it"""
         d = C.c_uint64(0)
