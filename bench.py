@@ -79,8 +79,10 @@ WORKLOADS = {
 }
 # per-workload overrides: 16 channels; tick length (c4: one frame time, so the 5% are the concurrent set)
 # (c5: a result slot per tick of a batch holds ~45 k heard links; the per-receiver lists of RM_SINR_SCAN=0 want 2^25 entries: --link-capacity)
-# (c4: a tick of 5000 frames holds 0.5 M heard links and millions of list entries: 32 result slots of 2^23 per context)
-EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 23, batch=32),
+# (c4: a tick of 5000 frames has ~150 k candidates at the interference floor and ~14 k heard links; the interference is summed per
+# receiver -- no list entries -- so a result slot of 2^20 holds it and 128 ticks go through one launch sequence.  RM_SINR_ACC=0 -- the
+# per-receiver lists -- wants --link-capacity 8388608 --batch 32)
+EXTRA = {"c3x6": dict(link_capacity=1 << 22), "c4": dict(channels16=True, tick_us=8128, link_capacity=1 << 20, batch=128),
          "c5": dict(link_capacity=1 << 18, batch=128)}
 
 
@@ -1011,10 +1013,12 @@ def main():
         fence()
         # kernel probes (a pair of HIP events bound to the kernel's own dispatch: no stream time) on every n-th launch sequence
         # of every context; few launches: all of them
+        # (the roofline line takes its kernel times from sequences that run alone after the timed region; the samples inside
+        # it only feed the cross-check: every fourth sequence of a context, so that the probes cost the headline next to nothing)
         launches = args.steps
-        every = args.profile_every if batch == 1 else 1
-        if launches <= 4 * inflight:
-            every = 1
+        every = args.profile_every if batch == 1 else 4
+        if launches <= 8 * inflight:
+            every = 1 if launches <= 2 * inflight else 2
         for e in engines:
             e.profile_enable(every)
         t_start = time.perf_counter()

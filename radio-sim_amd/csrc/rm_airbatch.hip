@@ -43,6 +43,32 @@ RM_D int ov_cell1(float x, float half, float inv)
     return min(max(c, 0), kSgG - 1);
 }
 
+// ---- the batch's descriptors --------------------------------------------------------------------------------------------
+// One launch in front of the batch: the ticks' descriptors and the slots' first frames come out of the host's pinned block (the
+// device reads it itself, as k_fetch_ticks does), the batch's counters start at zero.  (Two copies and two fills on the stream
+// used to do this, and a third copy took the overflow flag back: five stream operations between two batches, 50 us of an idle
+// device each time; the flag now goes to the host's word from k_ov_verdict.)
+__global__ void __launch_bounds__(256) k_ov_begin(const OvTick *__restrict__ h_ticks, const int32_t *__restrict__ h_first, int n_ticks, int n_slots,
+                                                  OvTick *ticks, int32_t *slot_first, uint32_t *misc, uint32_t *pair_tail)
+{
+    const int tid = int(blockIdx.x) * 256 + int(threadIdx.x), step = int(gridDim.x) * 256;
+    static_assert(sizeof(OvTick) % 4 == 0, "");
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(h_ticks);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(ticks);
+    for (int i = tid; i < n_ticks * int(sizeof(OvTick) / 4); i += step) dst[i] = src[i];
+    for (int i = tid; i <= n_slots; i += step) slot_first[i] = h_first[i];
+    for (int i = tid; i < 8 + kSgMax; i += step) misc[i] = 0u;
+    for (int i = tid; i < kShards * kShardStride; i += step) pair_tail[i] = 0u;
+}
+
+hipError_t launch_ov_begin(hipStream_t s, const OvTick *h_ticks, const int32_t *h_first, int n_ticks, int n_slots, OvTick *ticks,
+                           int32_t *slot_first, uint32_t *misc, uint32_t *pair_tail)
+{
+    RM_KLAUNCH(k_ov_begin, dim3(max(1, min(64, cdiv(n_ticks * int(sizeof(OvTick) / 4), 256)))), dim3(256), 0, s, h_ticks, h_first, n_ticks,
+               n_slots, ticks, slot_first, misc, pair_tail);
+    return hipGetLastError();
+}
+
 // ---- index ----------------------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) k_ov_count(const NodesDev nd, const ModelDev m, const OvDev ov)
@@ -54,6 +80,20 @@ __global__ void __launch_bounds__(256) k_ov_count(const NodesDev nd, const Model
     // (a tick swept over a rank's frame list, k_rank_frames: its slot holds n_new frames -- the device's count -- and padding behind them)
     const int bt = slot - (ov.n_slots - ov.n_ticks);
     const int live = (bt >= 0) ? min(f1 - f0, ov.ticks[bt].n_new) : f1 - f0;
+    if (bt >= 0) {
+        // the pair stage's items: this tick's frames behind those of the ticks before it (their counts summed here: at most
+        // RM_MAX_BATCH words), tick << 16 | frame; the last tick's first workgroup publishes the total
+        __shared__ uint32_t s_part[4];
+        uint32_t before = 0;
+        for (int b = int(threadIdx.x); b < bt; b += 256) before += uint32_t(max(ov.ticks[b].n_new, 0));
+        for (int d = 32; d >= 1; d >>= 1) before += uint32_t(__shfl_xor(int(before), d));
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
+        __syncthreads();
+        before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const int li = int(blockIdx.x) * 256 + int(threadIdx.x);
+        if (li < live) ov.items[before + uint32_t(li)] = (uint32_t(bt) << 16) | uint32_t(li);
+        if (bt == ov.n_ticks - 1 && blockIdx.x == 0 && threadIdx.x == 0) ov.misc[3] = before + uint32_t(max(live, 0));
+    }
     if (i < f1) { // (no early return: the wave reduces the radii together below)
         rm_tx_record r{};
         r.src = -1;
@@ -198,11 +238,15 @@ __global__ void __launch_bounds__(256, INLINE ? 2 : 6) k_ov_pairs(const NodesDev
     // A resident grid: a wave takes every (gridDim.x * kOvW)-th (tick, frame) item.  (One workgroup per four frames was 16 000
     // workgroups per launch of 64 ticks, and the launch took as long as the same grid of workgroups that leave at once:
     // it was bound by the rate at which workgroups with 23 KB of LDS can be placed, not by what they did.)
-    const int items = ov.n_ticks * ov.max_new;
+    // The (tick, frame) items, dense and tick-major (OvDev::items, written by k_ov_count: a tick's frame count is the device's -- a
+    // rank's frame list keeps a fraction of the gathered slots).  A wave takes every (gridDim.x * kOvW)-th item, so at any moment
+    // the whole chip works on a few neighbouring ticks and their part of the index stays in the L2.  (Dealing the waves to the
+    // ticks instead -- every tick of the batch in flight at once -- was measured: 792 against 630 us per 128 ticks.)
+    const int items = uniform_i(int(ov.misc[3]));
     for (int item = int(blockIdx.x) * kOvW + wave; item < items; item += int(gridDim.x) * kOvW) { // wave-uniform
-    const int b_tick = uniform_i(item / ov.max_new), q = uniform_i(item - (item / ov.max_new) * ov.max_new);
+    const uint32_t it = uniform_u(ov.items[item]);
+    const int b_tick = int(it >> 16), q = int(it & 0xFFFFu);
     const OvTick &tk = ov.ticks[b_tick];
-    if (q >= tk.n_new) continue;
     if (INLINE && ov.defer[tk.frame_first + q] == 0) continue;
     const uint32_t l_first = uniform_u(tk.slot_off[tk.shift + q]);
     const uint32_t len = uniform_u(tk.slot_off[tk.shift + q + 1]) - l_first;
@@ -561,6 +605,9 @@ __global__ void __launch_bounds__(256) k_ov_exact(const NodesDev nd, const Model
 
 __global__ void __launch_bounds__(256) k_ov_verdict(const ModelDev m, const OvDev ov)
 {
+    // (frames were deferred -- the pair list was full: the host grows it for a later batch.  Its word, in pinned memory.)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ov.h_flag != nullptr)
+        *reinterpret_cast<volatile uint32_t *>(ov.h_flag) = ov.misc[1]; // (read two batches later, behind an event: no fence, no write-back of the L2 for it)
     const OvTick &tk = ov.ticks[blockIdx.y];
     if (tk.n_new <= 0) return;
     if (tk.flags[1] != 0u) return;

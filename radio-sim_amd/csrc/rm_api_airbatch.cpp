@@ -171,14 +171,14 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
             o.h_desc_bytes[g] = 0;
         }
         const size_t want = std::max<size_t>(desc_bytes * 2, 1 << 16);
-        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_desc[g]), want, hipHostMallocDefault));
+        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_desc[g]), want, hipHostMallocMapped)); // (read by the device itself: k_ov_begin)
         o.h_desc_bytes[g] = want;
         if (!o.h_ev[g]) RM_HIP(hipEventCreateWithFlags(&o.h_ev[g], hipEventDisableTiming));
     } else {
         RM_HIP(hipEventSynchronize(o.h_ev[g])); // (the copy that read this block last has completed)
     }
     if (!o.h_flag) {
-        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_flag), 128, hipHostMallocDefault));
+        RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&o.h_flag), 128, hipHostMallocMapped)); // (written by the device itself: k_ov_verdict)
         o.h_flag[0] = o.h_flag[16] = 0u;
         for (int k = 0; k < 2; ++k) RM_HIP(hipEventCreateWithFlags(&o.h_flag_ev[k], hipEventDisableTiming));
     } else if (o.h_flag_used[g]) {
@@ -218,6 +218,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     RM_HIP(o.every.ensure(n_frames));
     RM_HIP(o.self_next.ensure(n_frames));
     RM_HIP(o.defer.ensure(n_frames));
+    RM_HIP(o.items.ensure(std::max<size_t>(total_new, 1)));
     if (o.bin_cnt.n < n_bins) { // (the counts are zero between two batches: k_ov_fill takes every one back down)
         RM_HIP(o.bin_cnt.ensure(n_bins));
         RM_HIP(hipMemsetAsync(o.bin_cnt.p, 0, o.bin_cnt.n * sizeof(uint32_t), c->stream));
@@ -254,8 +255,6 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
             o.pair_cap = want;
         }
     }
-    RM_HIP(hipMemsetAsync(o.misc.p, 0, (8 + rm::kSgMax) * sizeof(uint32_t), c->stream));
-    RM_HIP(hipMemsetAsync(o.pair_tail.p, 0, size_t(rm::kShards) * rm::kShardStride * sizeof(uint32_t), c->stream));
 
     // ---- descriptors
     AfterArg arg{};
@@ -281,6 +280,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     ov.every = o.every.p;
     ov.defer = o.defer.p;
     ov.misc = o.misc.p;
+    ov.items = o.items.p;
     ov.self_slot = c->d_self_slot.p;
     ov.self_next = o.self_next.p;
     ov.stamp = c->air.stamp;
@@ -289,6 +289,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     ov.pairs = o.pairs.p;
     ov.pair_tail = o.pair_tail.p;
     ov.pair_seg = uint32_t(o.pair_cap / rm::kShards);
+    ov.h_flag = h_flag;
     int slot_lo = 0;
     for (int b = 0; b < n_ticks; ++b) {
         const rm::TickDev &t = plans_v[size_t(b)].t;
@@ -313,8 +314,8 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
         k.hd = t.st_coll;
         k.flags = t.stage_count;
     }
-    RM_HIP(hipMemcpyAsync(o.ticks.p, h_ticks, sizeof(rm::OvTick) * size_t(n_ticks), hipMemcpyHostToDevice, c->stream));
-    RM_HIP(hipMemcpyAsync(o.slot_first.p, h_first, sizeof(int32_t) * (size_t(n_slots) + 1), hipMemcpyHostToDevice, c->stream));
+    // the descriptors into device memory and the batch's counters to zero: one launch (the device reads the pinned block itself)
+    RM_HIP(rm::launch_ov_begin(c->stream, h_ticks, h_first, n_ticks, n_slots, o.ticks.p, o.slot_first.p, o.misc.p, o.pair_tail.p));
     RM_HIP(hipEventRecord(o.h_ev[g], c->stream));
     arg.cfg = run_plans[0].cfg;
     arg.max_slot_frames = max_slot_frames;
@@ -329,11 +330,35 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     rf.mine = c->table_digest;
     rf.margin = rank_margin();
     rf.use_chmask = 0; // (a receiver may change its channel while these frames are on the air)
+    if (rank_frames) {
+        // these frames stay on the air: the box they are selected against goes into the ring (rm::CullEntry), and the partition's
+        // box as it is now is held against the entries of the batches that still have frames on the air
+        if (!c->d_cull_ring.p || !c->air_culled) {
+            RM_HIP(c->d_cull_ring.ensure(rm::kCullRing));
+            std::vector<rm::CullEntry> none(rm::kCullRing);
+            for (auto &e : none) e.end_us = INT64_MIN;
+            RM_HIP(hipMemcpyAsync(c->d_cull_ring.p, none.data(), sizeof(rm::CullEntry) * rm::kCullRing, hipMemcpyHostToDevice, c->stream));
+            RM_HIP(hipStreamSynchronize(c->stream)); // (the host vector goes away; once per window that was empty)
+            for (auto &e : c->cull_end) e = INT64_MIN;
+            c->air_culled = true;
+        }
+        const int slot = int(c->cull_seq % uint32_t(rm::kCullRing));
+        if (c->cull_end[slot] > t_begin_us[0])
+            return fail(RM_ERR_STATE, "more than 16 batches of frames selected for this partition are on the air at once: use larger batches");
+        int64_t batch_end = INT64_MIN;
+        for (int b = 0; b < n_ticks; ++b)
+            if (n_per[b] > 0) batch_end = std::max(batch_end, start_us[b] + air_us[b]);
+        c->cull_end[slot] = batch_end;
+        c->cull_seq++;
+        rf.ring = c->d_cull_ring.p;
+        rf.ring_slot = slot;
+        rf.t_first = t_begin_us[0];
+        rf.batch_end = batch_end;
+    }
     const int rc = launch_batch(c, run_slots.data(), run_plans.data(), int(run_plans.size()), &ms, interference_stages, &arg,
                                 (rank_frames || digest_off >= 0) && gathered_idx ? &rf : nullptr);
     if (rc != RM_OK) return rc;
-    RM_HIP(hipMemcpyAsync(h_flag, o.misc.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    RM_HIP(hipEventRecord(o.h_flag_ev[g], c->stream));
+    RM_HIP(hipEventRecord(o.h_flag_ev[g], c->stream)); // (k_ov_verdict has written this generation's overflow word)
     o.h_flag_used[g] = true;
 
     // ---- the batch's frames are on the air now

@@ -45,11 +45,9 @@ bool rank_frames_wanted(rm_context *c)
 int plan_rank_frames(rm_context *c, TickSlot &ts, rm::TickDev &t, int n_pub)
 {
     (void)c;
-    RM_HIP(ts.d_fl_src.ensure(size_t(std::max(n_pub, 1))));
     RM_HIP(ts.d_fl_map.ensure(size_t(std::max(n_pub, 1))));
     RM_HIP(ts.d_fl_lb.ensure(size_t(std::max(n_pub, 1)) + 1));
     RM_HIP(ts.d_slot_off_loc.ensure(size_t(std::max(t.n_cnt, 0)) + 2));
-    t.fl_src = ts.d_fl_src.p;
     t.fl_map = ts.d_fl_map.p;
     t.fl_lb = ts.d_fl_lb.p;
     t.n_pub = n_pub;
@@ -132,7 +130,11 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
         // the ticks' frame lists: the descriptors' frame counts are the device's from here on (the medium itself, not the
         // sweep's override: the SINR medium's candidate level is its interference floor)
         RM_TRY(stage(RM_STAGE_FILTER));
-        RM_HIP(rm::launch_rank_frames(s, nd, model_dev(c), dev_ticks, n, *rank_frames));
+        int max_frames = 1;
+        for (int b = 0; b < n; ++b) max_frames = std::max(max_frames, ticks[b].n_pub);
+        rm::RankFramesArgs rf = *rank_frames;
+        rf.sweep_level = m.ld_level;
+        RM_HIP(rm::launch_rank_frames(s, nd, model_dev(c), dev_ticks, n, max_frames, rf));
     }
     // RM_BATCH_FRAMES=1: the batch through the one-frame-per-workgroup kernel of the closed-loop tick instead of the
     // three sweep stages (one launch; the compact arrays on demand, per slot)
@@ -158,9 +160,13 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
     c->last_tile_reuse = rm::filter_ticks_per_wg(ticks[0], n);
     RM_TRY(stage(RM_STAGE_EXACT));
     RM_HIP(rm::launch_batch_stage(s, 1, nd, m, ticks, n, dev_ticks, cfg));
-    if (plans[0].sinr) {
+    if (plans[0].sinr && ticks[0].acc_lo == nullptr) { // (the per-receiver lists: SELF entries, then the walks; sums per receiver need neither)
         RM_TRY(stage(RM_STAGE_SINR));
         RM_HIP(rm::launch_batch_stage(s, 3, nd, m, ticks, n, dev_ticks, cfg));
+    }
+    if (plans[0].sinr && ticks[0].acc_lo != nullptr) { // sums per receiver: sinr and verdict of every heard link, full lanes
+        RM_TRY(stage(RM_STAGE_SINR));
+        RM_HIP(rm::launch_sinr_acc_batch(s, m, n, dev_ticks, int(std::min<uint32_t>(c->cap, 1u << 22))));
     }
     RM_TRY(stage(RM_STAGE_REORDER));
     RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, dev_ticks, cfg));
@@ -301,8 +307,23 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         return fail(RM_ERR_STATE, "gathered records go through the batched kernels only (sorted receiver table, fp32 frame, "
                                   "at most 8192 frames per tick, no empty tick)");
     if (batched) {
+        // SINR ticks named by source indices: one start and one air time per tick, so all of a tick's frames overlap each other and
+        // a heard link's interference is its receiver's sum over ALL the tick's candidates less its own power -- summed per receiver
+        // by the exact stage, no per-receiver lists (RM_SINR_ACC=0 keeps the lists; records given by the caller have their own
+        // time spans and keep them too)
+        const char *e_acc = std::getenv("RM_SINR_ACC");
+        const bool acc = sinr && (dev_src || gathered_idx) && !(e_acc && std::atoi(e_acc) == 0);
         if (sinr)
-            for (int b = 0; b < n_ticks; ++b) plans[b].t.reset_heads = 1;
+            for (int b = 0; b < n_ticks; ++b) {
+                rm::TickDev &t = plans[b].t;
+                if (acc) {
+                    t.acc_lo = reinterpret_cast<unsigned long long *>(t.st_lin);   // (link-sized buffers of the slot: room for every receiver)
+                    t.acc_hi = reinterpret_cast<unsigned long long *>(t.st_sinr);
+                    if (size_t(t.n_rx) > slots[b]->d_st_lin.n) return fail(RM_ERR_CAPACITY, "link capacity below the receiver count");
+                } else {
+                    t.reset_heads = 1;
+                }
+            }
         if (g_clock.on) {
             g_clock.acc[0] += th1 - th0;
             g_clock.acc[1] += HostClock::now() - th1;

@@ -231,7 +231,7 @@ void TickSlot::release_all()
 {
     d_tx.release(); d_p_txf.release(); d_p_ch.release(); d_p_src.release(); d_p_inv.release();
     d_cnt.release(); d_off.release(); d_dense_mask.release(); d_slot_tot.release(); d_slot_off.release();
-    d_fl_src.release(); d_fl_map.release(); d_fl_lb.release(); d_slot_off_loc.release();
+    d_fl_map.release(); d_fl_lb.release(); d_slot_off_loc.release();
     d_counters.release(); d_shards.release(); d_cursor.release(); d_cand_tot.release(); d_seg_off.release(); d_a_e.release();
     d_st_pkt.release(); d_st_dst.release(); d_st_next.release(); d_head.release(); d_st_blk.release(); d_st_aux.release();
     d_st_lin.release(); d_st_sinr.release(); d_st_prob.release(); d_st_orig.release(); d_st_flags.release(); d_st_coll.release();
@@ -304,13 +304,13 @@ void rm_destroy(rm_context *c)
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rx_rec32.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release(); c->d_grp_chmask.release(); c->d_wg_chmask.release();
-    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_rng.release(); c->d_ticks.release(); c->d_near_list.release(); c->d_near_cnt.release();
+    c->d_n2n.release(); c->d_shadow_tbl.release(); c->d_air.release(); c->d_air_alt.release(); c->d_cull_ring.release(); c->d_rng.release(); c->d_ticks.release(); c->d_near_list.release(); c->d_near_cnt.release();
     c->air.pool.release(); c->air.head.release(); c->air.tail.release(); c->air.mark.release(); c->air.bad.release();
     {
         rm_context::Overlap &o = c->ov;
         o.fr_f.release(); o.e_f.release(); o.fr_m.release(); o.e_m.release(); o.fr_t.release(); o.e_t.release();
         o.fr_bin.release(); o.bin_cnt.release(); o.bin_off.release(); o.block_sum.release(); o.every.release(); o.misc.release();
-        o.pair_tail.release(); o.self_next.release(); o.defer.release(); o.slot_first.release(); o.ticks.release(); o.pairs.release();
+        o.pair_tail.release(); o.items.release(); o.self_next.release(); o.defer.release(); o.slot_first.release(); o.ticks.release(); o.pairs.release();
         for (int g = 0; g < 2; ++g) {
             if (o.h_ev[g]) (void)hipEventDestroy(o.h_ev[g]);
             if (o.h_desc[g]) (void)hipHostFree(o.h_desc[g]);

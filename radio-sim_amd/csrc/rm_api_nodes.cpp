@@ -494,6 +494,8 @@ int rm_set_partition(rm_context *c, int32_t first, int32_t count)
 {
     if (!c || first < 0 || count < 0 || first + count > c->n) return fail(RM_ERR_INVALID, "partition out of range");
     RM_TRY(ev_flush_append(c)); // (whose Transcievers live here is part of what an append writes)
+    if (c->air_culled && c->air_tail > c->air_head)
+        return fail(RM_ERR_STATE, "frames on the air were kept for the present partition's region only: change the partition once they have left the air");
     c->rx_first = first;
     c->rx_count = count;
     c->sp_part = c->sp_parts = 0;
@@ -507,6 +509,8 @@ int rm_set_partition_spatial(rm_context *c, int32_t part, int32_t n_parts)
     if (!c || n_parts < 1 || part < 0 || part >= n_parts) return fail(RM_ERR_INVALID, "partition out of range");
     RM_HIP(hipSetDevice(c->device));
     RM_TRY(ev_flush_append(c));
+    if (c->air_culled && c->air_tail > c->air_head && !(c->sp_parts == ((n_parts > 1) ? n_parts : 0) && c->sp_part == ((n_parts > 1) ? part : 0)))
+        return fail(RM_ERR_STATE, "frames on the air were kept for the present partition's region only: change the partition once they have left the air");
     c->rx_first = 0;
     c->rx_count = -1;
     c->sp_part = (n_parts > 1) ? part : 0;

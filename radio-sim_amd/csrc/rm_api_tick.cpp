@@ -24,6 +24,10 @@ rm_tx_record make_record(const rm_context *c, int32_t src, int64_t start_us, int
 // what the kernels' flag word (counters[6], HostHeader::span_flag) says about a tick's records
 const char *record_flag_message(uint32_t flag)
 {
+    if (flag == 4u)
+        return "a receiver of this partition has left the region (plus RM_RANK_MARGIN) that frames still on the air were selected "
+               "for (it moved, or its radio was switched on): this rank no longer holds every frame that can interfere there -- let "
+               "the frames leave the air, or run with RM_RANK_FRAMES=0";
     if (flag == 3u)
         return "the ranks' node tables differ (rm_table_digest): a rank built the frames' records from another copy of the node "
                "table than this context holds -- every rank needs every rm_node_update / rm_nodes_move of the others";
@@ -510,6 +514,7 @@ namespace rmh {
 int air_window_expire(rm_context *c, int64_t t_begin_us)
 {
     if (c->air_batches.empty()) c->air_max_t_begin = INT64_MIN;
+    if (c->air_batches.empty()) c->air_culled = false; // (nothing on the air that was selected for a region)
     {
         bool fifo = true; // live batches form a suffix of the window?
         size_t first_live = c->air_batches.size();
@@ -552,14 +557,17 @@ int air_window_reserve(rm_context *c, size_t n_more)
     const size_t n = n_more;
     const size_t live = c->air_tail - c->air_head;
     if (c->air_tail + size_t(n) > c->d_air.n) {
+        // The window slides to the front of the OTHER of two buffers: one copy on the context's stream -- ordered behind every
+        // kernel that still reads either buffer -- and no allocation, no synchronisation in the steady state (a steady stream of
+        // batches used to pay a hipMalloc, a stream synchronisation and a hipFree every third batch: the device ran dry each time).
         const size_t want = std::max<size_t>(4 * (live + size_t(n)), 1 << 16);
-        DevBuf<rm_tx_record> fresh;
-        RM_HIP(fresh.ensure(want));
+        if (c->d_air_alt.n < want) {
+            RM_HIP(hipStreamSynchronize(c->stream)); // (the buffer about to be replaced may still be read by kernels in flight)
+            RM_HIP(c->d_air_alt.ensure(std::max(want, c->d_air.n)));
+        }
         if (live)
-            RM_HIP(hipMemcpyAsync(fresh.p, c->d_air.p + c->air_head, live * sizeof(rm_tx_record), hipMemcpyDeviceToDevice, c->stream));
-        RM_HIP(hipStreamSynchronize(c->stream));
-        c->d_air.release();
-        c->d_air = fresh;
+            RM_HIP(hipMemcpyAsync(c->d_air_alt.p, c->d_air.p + c->air_head, live * sizeof(rm_tx_record), hipMemcpyDeviceToDevice, c->stream));
+        std::swap(c->d_air, c->d_air_alt);
         c->air_head = 0;
         c->air_tail = live;
     }
@@ -606,6 +614,9 @@ int air_tick_device(rm_context *c, int64_t t_begin_us, const int32_t *dev_src, c
         c->air.valid = false;
         return rc;
     }
+    // the frames on the air were selected for this partition's region: are its receivers still inside what they were selected for?
+    if (c->air_culled && live > 0 && c->d_cull_ring.p && c->last.stage_count)
+        RM_HIP(rm::launch_cull_check(c->stream, nodes_dev(c), c->d_cull_ring.p, t_begin_us, c->last.stage_count + 6));
     if (air_mode == kAirRebuild)
         for (auto &bt : c->air_batches) bt.tick = c->air.tick;
     c->air_tail += size_t(n);

@@ -250,11 +250,13 @@ struct OvDev {
     longlong2 *e_t;
     uint8_t *defer;             // [n_frames] 1: the frame's pairs did not all fit the pair list -- its sums are formed by the second go
     uint32_t *every;            // [n_frames] frames without a cell (no bound, outside the frame)
-    uint32_t *misc;             // [0] entries of `every`, [1] a frame was deferred (the pair list was full), [2] pairs that interfered (statistics), [8 .. 8 + kSgMax) largest radius (float bits)
+    uint32_t *misc;             // [0] entries of `every`, [1] a frame was deferred (the pair list was full), [2] pairs that interfered (statistics), [3] items of the pair stage, [8 .. 8 + kSgMax) largest radius (float bits)
+    uint32_t *items;            // [sum of the ticks' new frames] tick << 16 | frame, tick-major (k_ov_count)
     unsigned long long *self_slot; // [n] stamp << 32 | newest frame of the node
     int32_t *self_next;         // [n_frames]
     uint32_t stamp;
     float half, inv;
+    uint32_t *h_flag;           // the host's word (pinned) that takes misc[1] at the batch's end
     OvPair *pairs;              // kShards regions of pair_seg entries
     uint32_t *pair_tail;        // [kShards * kShardStride]
     uint32_t pair_seg;
@@ -278,12 +280,12 @@ struct TickDev {
                                // sharded batch carries): k_tick_prep builds the record from the node table (src_start_us / src_air_us)
     int gather_slots, gather_stride;
     // A rank's frame list (k_rank_frames; gathered source indices over a receiver PARTITION): of the world * slots frames of the tick
-    // only those whose reach touches the partition's receivers are kept -- fl_src (their source indices: the tick becomes an
-    // ordinary build-mode tick, src_list = fl_src, n_active = their number, both written into the descriptor ON THE DEVICE) and
+    // only those whose reach touches the partition's receivers are kept: their records and pre-filter records are written in
+    // place, n_active = their number -- written into the descriptor ON THE DEVICE -- and
     // fl_map (local frame -> the frame's number among the gathered slots: packets keep their global numbers in the results);
     // fl_lb[g] = listed frames before gathered slot g ([n_pub + 1]); pub_off[n_pub + 1]: the packets' offsets by GLOBAL number,
     // written by the reorder stage's publisher (slot_off stays local).  n_pub = world * slots (0: no list).
-    int32_t *fl_src, *fl_map;
+    int32_t *fl_map;
     uint32_t *fl_lb;
     uint32_t *pub_off;
     int n_pub;
@@ -349,6 +351,11 @@ struct TickDev {
     uint8_t *st_flags;      // 0 = dead candidate
     uint8_t *st_coll;
     int32_t *head;          // [n_rx]
+    // SINR ticks whose frames are named by source indices (one start, one air time: all of a tick's frames overlap each other) sum
+    // the interference per RECEIVER instead of keeping per-receiver lists: every candidate at the interference floor adds its
+    // linear power in Q80 to acc[pos] (two words; exact whatever the order), a heard link's interference is that sum less its own
+    // power, and bit 63 of acc_hi[pos] says that the receiver is on the air itself (half duplex).  nullptr: the lists.
+    unsigned long long *acc_lo, *acc_hi; // [n_rx], zeroed by the tick's pre-pass
     // ordered records: A = (packet, engine position) order, B = (packet, node index) order
     uint32_t *out_count;    // [0] heard links stored, [1] dropped flag, [2] heard links total, [3] max per frame
     int32_t *a_pkt, *a_dst;
@@ -570,19 +577,36 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
 // margin: metres added around the partition's boxes (frames that stay on the air: a receiver may move while they do);
 // digests: the ranks' node-table digests as the all-gather left them (gather_base + r * gather_block + digest_off, two words
 // each; digest_off < 0: none) -- a rank whose table differs from `mine` makes every tick of the batch RM_ERR_STATE
+// Frames that stay on the air after they were selected for a partition (a batch of overlapping SINR ticks): the selection holds
+// while every receiver of the partition stays inside the box it was made against -- the partition's box plus the margin.  Each
+// such batch leaves that box and the time its last frame ends in a ring on the device; every later batch (and every lone tick
+// over such a window) compares the partition's box AS IT IS NOW with the entries whose frames are still on the air, and a
+// receiver that has left one of them -- it moved, its radio was switched on -- makes the tick RM_ERR_STATE instead of
+// silently missing an interferer that was never kept for this rank.
+struct CullEntry {
+    float lo[3], hi[3];
+    int64_t end_us;
+};
+constexpr int kCullRing = 16;
 struct RankFramesArgs {
     const int32_t *gather_base;
     int world, gather_block, digest_off;
     uint64_t mine;
     float margin;
     int use_chmask;
+    double sweep_level; // the candidate level of the sweep that follows (its pre-filter records are written here)
+    CullEntry *ring;    // frames that stay on the air: the ring of boxes (nullptr: nothing of these ticks outlives them)
+    int ring_slot;      // ... this batch's entry
+    int64_t t_first, batch_end; // the batch's first t_begin, the end of its last frame
 };
-hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, const RankFramesArgs &a);
+hipError_t launch_cull_check(hipStream_t s, const NodesDev &nd, const CullEntry *ring, int64_t t_begin, uint32_t *flag_word);
+hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, int max_frames, const RankFramesArgs &a);
 constexpr int kGatherTrailer = RM_GATHER_TRAILER; // words behind a rank's source indices in its block of a sharded batch
 hipError_t launch_stage_block(hipStream_t s, const int32_t *src, int n, uint64_t digest, int32_t *dst);
 int filter_ticks_per_wg(const TickDev &t0, int n);
 hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
+hipError_t launch_sinr_acc_batch(hipStream_t s, const ModelDev &m, int n, const TickDev *dev_ticks, int max_links);
 hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                              const TickDev *dev_ticks);
 hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
@@ -621,6 +645,8 @@ hipError_t launch_draws_apply(hipStream_t s, const ModelDev &m, const TickDev &t
                               int rank);
 
 // (rm_airbatch.hip) a batch of SINR ticks with frames that outlive their tick: index of the frames, then pairs / exact / verdicts
+hipError_t launch_ov_begin(hipStream_t s, const OvTick *h_ticks, const int32_t *h_first, int n_ticks, int n_slots, OvTick *ticks,
+                           int32_t *slot_first, uint32_t *misc, uint32_t *pair_tail);
 hipError_t launch_ov_index(hipStream_t s, const NodesDev &nd, const ModelDev &m, const OvDev &ov, int max_slot_frames);
 hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, const OvDev &ov, int max_new, int max_links, const LaunchCfg &cfg);
 

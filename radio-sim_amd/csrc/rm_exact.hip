@@ -33,6 +33,16 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
     const bool dropped = t.stage_count[1] != 0u;
     const uint32_t n_own = dropped ? 0u : min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
     constexpr bool kRegScan = (SEG == 3 || SEG == 4);
+    const bool acc_mode = SINR && t.acc_lo != nullptr; // block-uniform: interference summed per receiver, no lists (TickDev::acc_lo)
+    if (acc_mode && publisher && t.src_air_us > 0) {
+        // half duplex: every frame's source that is a receiver here is on the air itself (the pre-pass zeroed the words; the
+        // sums' additions never reach bit 63)
+        const int n_eval = t.n_active - t.first_eval;
+        for (int e = int(threadIdx.x); e < n_eval; e += int(blockDim.x)) {
+            const int pos = engine_pos(nd, t.tx[t.first_eval + e].src);
+            if (pos >= 0) atomicOr(&t.acc_hi[pos], 1ull << 63);
+        }
+    }
     SmallCounts<scan_per(SEG)> pre{};
     if (kRegScan && !PACKED && (blockIdx.x == 0 || blockIdx.x * blockDim.x < n_own)) pre = small_scan_load<scan_per(SEG)>(t.cand_tot, t.n_cnt);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -114,8 +124,22 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             const LinkEval ev = eval_link<MODEL, SINR>(m, nd, tx, rx_, is_new);
             fl = ev.append ? ev.flags : uint8_t(0);
             if (ev.append && MODEL != RM_MODEL_NULL && MODEL != RM_MODEL_UDGM_CONST && tx_success(m, tx) <= 0.0) fl |= kFlagTxDead;
-            if (SEG == 0 || SINR) t.st_flags[idx] = fl; // read by the ordered scatter / the SINR pass only
-            if (ev.append) {
+            if (SEG == 0 || (SINR && !acc_mode)) t.st_flags[idx] = fl; // read by the ordered scatter / the SINR pass only
+            if (ev.append && acc_mode) {
+                // the interferer's power joins its receiver's sum (Q80: exact, any order); nothing of the entry is kept
+                if ((fl & kFlagInterferer) && t.src_air_us > 0) {
+                    const U128 v = q80_from_double(ev.lin);
+                    if ((v.lo | v.hi) != 0ull) {
+                        const unsigned long long old = atomicAdd(&t.acc_lo[pos], (unsigned long long)v.lo);
+                        const unsigned long long carry = (old + v.lo < old) ? 1ull : 0ull; // (the low words' running sum is exact mod 2^64: so is the carry count)
+                        if (v.hi + carry) atomicAdd(&t.acc_hi[pos], (unsigned long long)(v.hi + carry));
+                    }
+                }
+                orig = rx_.orig;
+                rssi = ev.aux;
+                prob = rx_.rxprob;
+                wanted = ev.wanted;
+            } else if (ev.append) {
                 orig = rx_.orig;
                 if (MODEL == RM_MODEL_LOGDIST) {
                     rssi = ev.aux;
@@ -163,11 +187,22 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
             uint32_t base = 0;
             if (valid && lane == ri.start && ri.total) base = atomicAdd(&t.cursor[slot], ri.total);
             base = __shfl(base, ri.start);
+            if (acc_mode) {
+                // the heard links' places in the A records, one list per tick: k_sinr_acc takes them with full lanes once every
+                // receiver's sum is complete (one atomic per wave)
+                const uint64_t wm = ballot64(wanted);
+                if (wm) {
+                    uint32_t hb = 0;
+                    if (lane == __ffsll((long long)wm) - 1) hb = atomicAdd(&t.stage_count[0], uint32_t(__popcll(wm)));
+                    hb = uint32_t(__shfl(int(hb), __ffsll((long long)wm) - 1));
+                    if (wanted) t.st_next[hb + lane_prefix(wm)] = int(((SEG == 1 || kRegScan) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before);
+                }
+            }
             if (wanted) {
                 const uint32_t o = ((SEG == 1 || kRegScan) ? s_seg[slot] : t.seg_off[slot]) + base + ri.before;
                 t.a_dst[o] = orig;
                 t.a_rssi[o] = rssi;
-                if (SINR) t.a_e[o] = int(idx);
+                if (SINR) t.a_e[o] = acc_mode ? L.pos : int(idx); // (the sums are looked up by receiver, the lists by entry)
                 if (STOCH) {
                     t.a_prob[o] = prob;
                     t.a_verdict[o] = uint8_t(0); // pending: k_apply_draws decides
@@ -395,6 +430,32 @@ __global__ void __launch_bounds__(256) k_sinr_batch(const ModelDev m, const Tick
     sinr_body(m, ticks[blockIdx.z]);
 }
 
+// Interference summed per receiver (TickDev::acc_lo): one lane per heard link of the tick, full lanes, once the exact stage has
+// completed every receiver's sum -- the receiver's sum less this link's own power (it joined the sum iff it reaches the
+// interference floor: eval_link's rule and its arithmetic), then air_sinr's formula; sinr and a collision's verdict go into the
+// link's A record, where the reorder stage finds them.  (Done inside the reorder stage's per-frame waves it ran three lanes
+// of 64 through the logarithm: 184 us per 32 ticks of configs[3] for that stage alone.)
+__global__ void __launch_bounds__(256) k_sinr_acc_batch(const ModelDev m, const TickDev *__restrict__ ticks)
+{
+    const TickDev &t = ticks[blockIdx.z];
+    if (t.acc_lo == nullptr || t.stage_count[1] != 0u) return; // (nothing of a dropped tick)
+    const uint32_t n = min(t.stage_count[0], t.cap);
+    const bool on_air = t.src_air_us > 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t o = uint32_t(t.st_next[i]);
+        const int pos = t.a_e[o];
+        const double rssi = t.a_rssi[o];
+        U128 acc;
+        acc.lo = t.acc_lo[pos];
+        const unsigned long long hi = t.acc_hi[pos];
+        acc.hi = hi & ~(1ull << 63);
+        if (rssi >= m.ld_ifloor && on_air) acc = u128_sub(acc, q80_from_double(det_pow10(rssi / 10.0)));
+        const double sinr = rssi - 10.0 * det_log10(q80_to_double(acc) + m.ld_noise_lin);
+        t.a_sinr[o] = sinr;
+        if (((hi >> 63) != 0ull && on_air) || !(sinr >= m.ld_capture)) t.a_verdict[o] = uint8_t(RM_INTERFERED);
+    }
+}
+
 // ============================================================================ ordered scatter
 
 // frames beyond what the fused scans hold: seg_off / slot_off from a one-workgroup scan kernel
@@ -578,6 +639,12 @@ do {                                                                            
     default: return hipErrorInvalidValue;
     }
 #undef RM_EXB
+    return hipGetLastError();
+}
+
+hipError_t launch_sinr_acc_batch(hipStream_t s, const ModelDev &m, int n, const TickDev *b, int max_links)
+{
+    RM_KLAUNCH(k_sinr_acc_batch, dim3(max(1, min(64, cdiv(max(max_links, 1), 1024))), 1, n), dim3(256), 0, s, m, b);
     return hipGetLastError();
 }
 

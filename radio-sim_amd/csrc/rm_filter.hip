@@ -394,6 +394,17 @@ __global__ void __launch_bounds__(kBlock, F64 ? 2 : 6) k_filter(const NodesDev n
 
 constexpr int kNearLds = 512; // near-frame records held in LDS between two phase-B rounds
 
+constexpr int kRfThreads = 256;
+RM_D float prefilter_inv(const ModelDev &m, const float4 &f) // (bins / thr of the frame for the shadowed medium's table, 0: not usable)
+{
+    float inv = 0.f;
+    if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) {
+        const double cut = sqrt(double(f.w));
+        if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
+    }
+    return inv;
+}
+
 RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
 {
     const int n_eval = t.n_active - t.first_eval;
@@ -408,6 +419,11 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
         }
     if (t.reset_heads) // SINR tick of a batch: every receiver's link list starts empty
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n_rx; i += gridDim.x * blockDim.x) t.head[i] = -1;
+    if (t.acc_lo) // ... or, summed per receiver (TickDev::acc_lo): every receiver's sum starts at zero, nobody is on the air yet
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n_rx; i += gridDim.x * blockDim.x) {
+            t.acc_lo[i] = 0ull;
+            t.acc_hi[i] = 0ull;
+        }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (t.air.pool != nullptr) { // block-uniform.  SINR with the lists that live across ticks:
         if (blockIdx.x == 0 && threadIdx.x == 0 && t.air.bad[0]) t.stage_count[1] = 1u; // the lists are broken until the host rebuilds them
@@ -424,12 +440,7 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
         const int aidx = air_alloc(t, want, air_sub(t));
         if (want) air_link(t, aidx, pos, txs.start_us, txs.air_us, 0.0, kAirSelf);
     }
-    if (e >= n_eval) {
-        // (a rank's frame list, records kept on the air: the slots behind the listed frames hold padding, as the unlisted
-        // frames' own slots would have -- whoever walks the window later finds records everywhere)
-        if (t.fl_pad && e < t.n_pub) t.tx_build[t.first_eval + e] = make_tx_record(nd, -1, t.src_start_us, 0);
-        return;
-    }
+    if (e >= n_eval) return;
     const int abs_i = t.first_eval + e;
     rm_tx_record tx;
     if (t.src_list && abs_i >= t.first_new) {
@@ -451,11 +462,7 @@ RM_D void tick_prep_body(const NodesDev &nd, const ModelDev &m, const TickDev &t
     float4 f;
     double thr64;
     tx_prefilter(m, tx, f, thr64);
-    float inv = 0.f;
-    if (m.shadow_tbl && f.w > 0.f && f.w < __builtin_inff()) {
-        const double cut = sqrt(double(f.w));
-        if (2.0 * m.f32_slack / (0.15 * cut) + 1e-5 <= kShadowPad) inv = float(kShadowBins) / f.w;
-    }
+    const float inv = prefilter_inv(m, f);
     t.p_txf[e] = f;
     t.p_ch[e] = tx.channel;
     t.p_src[e] = tx.src;
@@ -854,32 +861,68 @@ __global__ void __launch_bounds__(256) k_near_lists(const NodesDev nd, const Tic
 // interference stages' index -- it did for all of them: a rank's time did not follow its links.  Here the tick's frames are
 // tested ONCE against the union of the partition's filter-workgroup boxes with the workgroups' own expression (so a frame
 // that could pass any workgroup's test passes this one: monotone in every |d|, the union box contains every box) and the
-// survivors' source indices are compacted IN ORDER into fl_src: the tick goes on as a build-mode tick of those frames only,
-// its descriptor patched here on the device (n_active, n_cnt, src_list) -- the host sizes grids for all frames and never
-// learns the count.  Packets keep their global numbers: fl_map (local -> gathered slot) for the records' packet column,
-// fl_lb (gathered slot -> listed frames before it) for the offsets by global number, and the per-packet Tx-failure flag of
-// EVERY gathered slot is written here (it depends on the source's txProbability alone).  A frame whose source is one of the
-// partition's own receivers is always kept (half duplex asks for no reach).  The ranks' node-table digests ride in the
-// gathered blocks: a rank that built its records from another table than this one flags every tick (RM_ERR_STATE).
-__global__ void __launch_bounds__(256) k_rank_frames(const NodesDev nd, const ModelDev m, TickDev *__restrict__ ticks, const RankFramesArgs a)
+// survivors are compacted IN ORDER: the tick goes on as a tick of those frames only, its descriptor patched here on the
+// device (n_active, n_cnt) -- the host sizes grids for all frames and never learns the count.  This launch is also the
+// listed frames' pre-pass (k_tick_prep_batch is not launched for such a batch): their on-air records, their pre-filter
+// records at the SWEEP's candidate level (sweep_level: a batch of overlapping SINR ticks sweeps at the sensitivity and lists
+// at the interference floor), the counters later kernels add to.  Packets keep their global numbers: fl_map (local ->
+// gathered slot) for the records' packet column, fl_lb (gathered slot -> listed frames before it) for the offsets by global
+// number, and the per-packet Tx-failure flag of EVERY gathered slot is written here (it depends on the source's
+// txProbability alone).  A frame whose source is one of the partition's own receivers is always kept (half duplex asks for
+// no reach).  The ranks' node-table digests ride in the gathered blocks: a rank that built its records from another table
+// than this one flags every tick (RM_ERR_STATE).
+// (256 threads per tick, eight frames per thread and round -- 2048 frames per round, their loads all issued before any is used:
+// a tick of a thousand frames is one round of independent round trips.  A workgroup of 1024 threads per tick was measured: alone
+// on the device 36 us per 512 ticks, but 243 us with two other contexts' kernels in flight -- it waits for a compute unit with
+// room for all sixteen of its waves.)
+constexpr int kRfPer = 8;
+__global__ void __launch_bounds__(kRfThreads) k_rank_frames(const NodesDev nd, const ModelDev m, TickDev *__restrict__ ticks, const RankFramesArgs a)
 {
-    __shared__ float s_box[4][6];
-    __shared__ uint32_t s_msk[4], s_wcnt[4];
+    constexpr int kWaves = kRfThreads / 64;
+    __shared__ float s_box[kWaves][6];
+    __shared__ uint32_t s_msk[kWaves], s_wcnt[kRfPer][kWaves];
     TickDev &t = ticks[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = wave_index();
+    const int tid = int(threadIdx.x), lane = tid & 63, wave = wave_index();
     const int T = t.n_pub;
     if (a.digest_off >= 0)
-        for (int r = int(threadIdx.x); r < a.world; r += 256) {
+        for (int r = tid; r < a.world; r += kRfThreads) {
             const int32_t *d = a.gather_base + size_t(r) * size_t(a.gather_block) + size_t(a.digest_off);
             const uint64_t v = uint64_t(uint32_t(d[0])) | (uint64_t(uint32_t(d[1])) << 32);
             if (v != a.mine) t.stage_count[6] = 3u; // read as RM_ERR_STATE with the tick's result
         }
     if (T <= 0 || t.gather_idx == nullptr) return; // block-uniform: no list for this tick (the digests were all there was to do)
+    // ---- the first round's source indices: requested before anything else
+    int src[kRfPer];
+    auto request = [&](const int i0) {
+#pragma unroll
+        for (int u = 0; u < kRfPer; ++u) {
+            const int i = i0 + u * kRfThreads + tid;
+            src[u] = -1;
+            if (i < T) src[u] = t.gather_idx[size_t(i / t.gather_slots) * size_t(t.gather_stride) + size_t(i % t.gather_slots)];
+        }
+    };
+    request(0);
+    // ---- k_tick_prep's duties for the counters
+    if (tid < 8) t.next_counters[tid] = 0u;
+    for (int i = tid; i < kShards; i += kRfThreads) t.next_shard_count[i * kShardStride] = 0u;
+    if (!t.use_matrix)
+        for (int i = tid; i < t.zero_len; i += kRfThreads) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
+        }
+    if (t.reset_heads)
+        for (int i = tid; i < t.n_rx; i += kRfThreads) t.head[i] = -1;
+    if (t.acc_lo)
+        for (int i = tid; i < t.n_rx; i += kRfThreads) {
+            t.acc_lo[i] = 0ull;
+            t.acc_hi[i] = 0ull;
+        }
+    // ---- the partition's box: the union of its filter workgroups' boxes and channel masks
     const float inf_ = __builtin_inff();
     float x0 = inf_, y0 = inf_, z0 = inf_, x1 = -inf_, y1 = -inf_, z1 = -inf_;
     uint32_t mk = 0u;
     const int n_wg = (t.n_rx + kGroup * 16 - 1) / (kGroup * 16);
-    for (int w = int(threadIdx.x); w < n_wg; w += 256) {
+    for (int w = tid; w < n_wg; w += kRfThreads) {
         const float4 q = nd.wg_box_xy[w];
         const float2 qz = nd.wg_box_z[w];
         x0 = fminf(x0, q.x), y0 = fminf(y0, q.y), x1 = fmaxf(x1, q.z), y1 = fmaxf(y1, q.w);
@@ -894,56 +937,134 @@ __global__ void __launch_bounds__(256) k_rank_frames(const NodesDev nd, const Mo
         s_msk[wave] = mk;
     }
     __syncthreads();
-    x0 = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0])) - a.margin;
-    y0 = fminf(fminf(s_box[0][1], s_box[1][1]), fminf(s_box[2][1], s_box[3][1])) - a.margin;
-    z0 = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2])) - a.margin;
-    x1 = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3])) + a.margin;
-    y1 = fmaxf(fmaxf(s_box[0][4], s_box[1][4]), fmaxf(s_box[2][4], s_box[3][4])) + a.margin;
-    z1 = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5])) + a.margin;
-    mk = a.use_chmask ? (s_msk[0] | s_msk[1] | s_msk[2] | s_msk[3]) : 0xFFFFFFFFu;
+    mk = 0u;
+    for (int w = 0; w < kWaves; ++w) {
+        x0 = fminf(x0, s_box[w][0]), y0 = fminf(y0, s_box[w][1]), z0 = fminf(z0, s_box[w][2]);
+        x1 = fmaxf(x1, s_box[w][3]), y1 = fmaxf(y1, s_box[w][4]), z1 = fmaxf(z1, s_box[w][5]);
+        mk |= s_msk[w];
+    }
+    if (a.ring != nullptr) { // (block-uniform) frames that stay on the air: is every receiver still where the frames on the air were selected for?
+        if (tid < kCullRing && tid != a.ring_slot) {
+            const CullEntry e = a.ring[tid];
+            if (e.end_us > a.t_first && (x0 < e.lo[0] || y0 < e.lo[1] || z0 < e.lo[2] || x1 > e.hi[0] || y1 > e.hi[1] || z1 > e.hi[2]))
+                t.stage_count[6] = 4u; // read as RM_ERR_STATE with the tick's result
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            CullEntry e;
+            e.lo[0] = x0 - a.margin, e.lo[1] = y0 - a.margin, e.lo[2] = z0 - a.margin;
+            e.hi[0] = x1 + a.margin, e.hi[1] = y1 + a.margin, e.hi[2] = z1 + a.margin;
+            e.end_us = a.batch_end;
+            a.ring[a.ring_slot] = e;
+        }
+    }
+    x0 -= a.margin, y0 -= a.margin, z0 -= a.margin, x1 += a.margin, y1 += a.margin, z1 += a.margin;
+    if (!a.use_chmask) mk = 0xFFFFFFFFu;
     const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
     uint32_t base = 0; // frames listed so far (block-uniform)
-    for (int i0 = 0; i0 < T; i0 += 256) { // block-uniform
-        const int i = i0 + int(threadIdx.x);
-        bool hit = false;
-        int src = -1;
-        if (i < T) {
-            src = t.gather_idx[size_t(i / t.gather_slots) * size_t(t.gather_stride) + size_t(i % t.gather_slots)];
-            const rm_tx_record tx = make_tx_record(nd, src, t.src_start_us, t.src_air_us);
-            t.pkt_interference[i] = (draws_possible && tx_success(m, tx) <= 0.0) ? 1 : 0; // (write_pkt_interference's rule, by global number)
-            if (tx.src >= 0) {
-                float4 f;
-                double thr64;
-                tx_prefilter(m, tx, f, thr64);
-                const float dx = fmaxf(fmaxf(x0 - f.x, f.x - x1), 0.f);
-                const float dy = fmaxf(fmaxf(y0 - f.y, f.y - y1), 0.f);
-                const float dz = fmaxf(fmaxf(z0 - f.z, f.z - z1), 0.f);
-                hit = dist2_f32(dx, dy, dz) <= f.w && ((mk >> (uint32_t(tx.channel) & 31u)) & 1u) != 0u;
-                if (!hit) hit = engine_pos(nd, tx.src) >= 0; // a receiver of this partition that is on the air itself: half duplex
+    for (int i0 = 0; i0 < T; i0 += kRfPer * kRfThreads) { // block-uniform: one round per 2048 frames
+        if (i0) request(i0);
+        // ---- which frames matter here
+        uint64_t hms[kRfPer];
+        float4 fl[kRfPer]; // pre-filter records at the LIST's level
+#pragma unroll
+        for (int u = 0; u < kRfPer; ++u) {
+            const int i = i0 + u * kRfThreads + tid;
+            bool hit = false;
+            fl[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+            if (i < T) {
+                const rm_tx_record r = make_tx_record(nd, src[u], t.src_start_us, t.src_air_us);
+                t.pkt_interference[i] = (draws_possible && tx_success(m, r) <= 0.0) ? 1 : 0; // (write_pkt_interference's rule, by global number)
+                if (r.src >= 0) {
+                    double thr64;
+                    tx_prefilter(m, r, fl[u], thr64);
+                    const float4 f = fl[u];
+                    const float dx = fmaxf(fmaxf(x0 - f.x, f.x - x1), 0.f);
+                    const float dy = fmaxf(fmaxf(y0 - f.y, f.y - y1), 0.f);
+                    const float dz = fmaxf(fmaxf(z0 - f.z, f.z - z1), 0.f);
+                    hit = dist2_f32(dx, dy, dz) <= f.w && ((mk >> (uint32_t(r.channel) & 31u)) & 1u) != 0u;
+                    if (!hit) hit = engine_pos(nd, r.src) >= 0; // a receiver of this partition that is on the air itself: half duplex
+                }
+            }
+            hms[u] = ballot64(hit);
+            if (lane == 0) s_wcnt[u][wave] = uint32_t(__popcll(hms[u]));
+        }
+        __syncthreads();
+        // ---- ordered compaction: frame i = i0 + u * 256 + tid comes after the frames of the chunks before u and of the waves before its own
+#pragma unroll
+        for (int u = 0; u < kRfPer; ++u) {
+            const int i = i0 + u * kRfThreads + tid;
+            uint32_t k = base + lane_prefix(hms[u]);
+            uint32_t tot = 0;
+            for (int w = 0; w < kWaves; ++w) {
+                const uint32_t c = s_wcnt[u][w];
+                if (w < wave) k += c;
+                tot += c;
+            }
+            base += tot;
+            if (i < T) t.fl_lb[i] = k;
+            if (i < T && ((hms[u] >> lane) & 1ull)) {
+                // (the listed frames' records are fetched again -- a fifth of the frames, L2-resident -- rather than kept for all eight)
+                const rm_tx_record r = make_tx_record(nd, src[u], t.src_start_us, t.src_air_us);
+                t.fl_map[k] = i;
+                t.tx_build[k] = r;
+                float4 f = fl[u];
+                if (a.sweep_level != m.ld_level) { // (the sweep's own cut-off: the medium without SINR sweeps at the sensitivity)
+                    double thr64;
+                    tx_prefilter_at(m, a.sweep_level, r, f, thr64);
+                }
+                t.p_txf[k] = f;
+                t.p_ch[k] = r.channel;
+                t.p_src[k] = r.src;
+                t.p_inv[k] = prefilter_inv(m, f);
             }
         }
-        const uint64_t hm = ballot64(hit);
-        if (lane == 0) s_wcnt[wave] = uint32_t(__popcll(hm));
-        __syncthreads();
-        uint32_t k = base + lane_prefix(hm);
-        for (int w = 0; w < wave; ++w) k += s_wcnt[w];
-        const uint32_t tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        if (i < T) t.fl_lb[i] = k;
-        if (hit) {
-            t.fl_src[k] = src;
-            t.fl_map[k] = i;
-        }
-        base += tot;
-        __syncthreads();
+        __syncthreads(); // (the next round's counts overwrite s_wcnt)
     }
-    if (threadIdx.x == 0) {
+    // (records kept on the air: the slots behind the listed frames hold padding, as the unlisted frames' own slots would
+    // have -- whoever walks the window later finds records everywhere)
+    if (t.fl_pad)
+        for (int e = int(base) + tid; e < T; e += kRfThreads) t.tx_build[e] = make_tx_record(nd, -1, t.src_start_us, 0);
+    if (tid == 0) {
         t.fl_lb[T] = base;
         t.n_active = int(base);
         t.n_cnt = max(kTxChunk, int((base + uint32_t(kTxChunk) - 1u) / uint32_t(kTxChunk)) * kTxChunk);
-        t.src_list = t.fl_src;
-        t.gather_idx = nullptr;
+        t.gather_idx = nullptr; // (the records are in place: nothing of the gathered layout is needed any more)
         if (t.fl_ov_n_new) *t.fl_ov_n_new = int(base);
     }
+}
+
+// a lone tick over a window of frames that were selected for this partition (CullEntry): the same comparison, on its own
+__global__ void __launch_bounds__(256) k_cull_check(const NodesDev nd, const CullEntry *__restrict__ ring, int64_t t_begin, uint32_t *flag_word)
+{
+    __shared__ float s_box[4][6];
+    const int tid = int(threadIdx.x), lane = tid & 63, wave = wave_index();
+    const float inf_ = __builtin_inff();
+    float x0 = inf_, y0 = inf_, z0 = inf_, x1 = -inf_, y1 = -inf_, z1 = -inf_;
+    const int n_wg = (nd.n_rx + kGroup * 16 - 1) / (kGroup * 16);
+    for (int w = tid; w < n_wg; w += 256) {
+        const float4 q = nd.wg_box_xy[w];
+        const float2 qz = nd.wg_box_z[w];
+        x0 = fminf(x0, q.x), y0 = fminf(y0, q.y), x1 = fmaxf(x1, q.z), y1 = fmaxf(y1, q.w);
+        z0 = fminf(z0, qz.x), z1 = fmaxf(z1, qz.y);
+    }
+    x0 = wave_min(x0), y0 = wave_min(y0), z0 = wave_min(z0);
+    x1 = wave_max(x1), y1 = wave_max(y1), z1 = wave_max(z1);
+    if (lane == 0) s_box[wave][0] = x0, s_box[wave][1] = y0, s_box[wave][2] = z0, s_box[wave][3] = x1, s_box[wave][4] = y1, s_box[wave][5] = z1;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        x0 = fminf(x0, s_box[w][0]), y0 = fminf(y0, s_box[w][1]), z0 = fminf(z0, s_box[w][2]);
+        x1 = fmaxf(x1, s_box[w][3]), y1 = fmaxf(y1, s_box[w][4]), z1 = fmaxf(z1, s_box[w][5]);
+    }
+    if (tid < kCullRing) {
+        const CullEntry e = ring[tid];
+        if (e.end_us > t_begin && (x0 < e.lo[0] || y0 < e.lo[1] || z0 < e.lo[2] || x1 > e.hi[0] || y1 > e.hi[1] || z1 > e.hi[2])) *flag_word = 4u;
+    }
+}
+
+hipError_t launch_cull_check(hipStream_t s, const NodesDev &nd, const CullEntry *ring, int64_t t_begin, uint32_t *flag_word)
+{
+    RM_KLAUNCH(k_cull_check, dim3(1), dim3(256), 0, s, nd, ring, t_begin, flag_word);
+    return hipGetLastError();
 }
 
 // a rank's block of a sharded batch as it goes into the all-gather: its source indices, then the trailer (the node table's
@@ -966,10 +1087,11 @@ hipError_t launch_stage_block(hipStream_t s, const int32_t *src, int n, uint64_t
     return hipGetLastError();
 }
 
-hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, const RankFramesArgs &a)
+hipError_t launch_rank_frames(hipStream_t s, const NodesDev &nd, const ModelDev &m, TickDev *dev_ticks, int n, int max_frames, const RankFramesArgs &a)
 {
     if (n <= 0) return hipSuccess;
-    RM_KLAUNCH(k_rank_frames, dim3(n), dim3(256), 0, s, nd, m, dev_ticks, a);
+    (void)max_frames;
+    RM_KLAUNCH(k_rank_frames, dim3(n), dim3(kRfThreads), 0, s, nd, m, dev_ticks, a);
     return hipGetLastError();
 }
 
@@ -1128,7 +1250,8 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     int max_eval = 0;
     for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
     const TickDev &t0 = ticks[0];
-    RM_KLAUNCH(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
+    if (t0.n_pub <= 0) // (a rank's frame lists: k_rank_frames was this batch's pre-pass as well)
+        RM_KLAUNCH(k_tick_prep_batch, dim3(cdiv(max_eval, 256), 1, n), dim3(256), 0, s, nd, m, b);
     if (t0.near_list != nullptr) { // (every tick of the batch has its lists, or none has)
         const int n_wg = cdiv(t0.n_rx, kGroup * 16);
         RM_KLAUNCH(k_near_lists, dim3(cdiv(n_wg, kNearSb), 1, n), dim3(256), 0, s, nd, b, n_wg);

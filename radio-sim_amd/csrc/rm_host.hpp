@@ -83,9 +83,9 @@ struct TickSlot {
     DevBuf<float> d_p_inv;
 
     DevBuf<uint32_t> d_cnt, d_off, d_slot_tot, d_slot_off;
-    // a rank's frame list (k_rank_frames): the listed frames' source indices and gathered-slot numbers, the listed frames before
+    // a rank's frame list (k_rank_frames): the listed frames' gathered-slot numbers, the listed frames before
     // every gathered slot, and the tick's LOCAL offsets (d_slot_off then holds the offsets by global packet number)
-    DevBuf<int32_t> d_fl_src, d_fl_map;
+    DevBuf<int32_t> d_fl_map;
     DevBuf<uint32_t> d_fl_lb, d_slot_off_loc;
     DevBuf<unsigned long long> d_dense_mask; // the dense tick's heard links: 16 lane masks per (frame, chunk of 1024 nodes)
 
@@ -268,7 +268,13 @@ struct rm_context : TickSlot {
         int64_t end_us;
         uint32_t tick; // AirLists::tick of the call that put the batch on the air
     };
-    DevBuf<rm_tx_record> d_air;
+    // the window holds frames that were selected for this partition's region (k_rank_frames over a batch of overlapping SINR ticks:
+    // rm::CullEntry): the boxes the selections were made against, and until when each matters
+    bool air_culled = false;
+    DevBuf<rm::CullEntry> d_cull_ring;
+    int64_t cull_end[rm::kCullRing] = {};
+    uint32_t cull_seq = 0;
+    DevBuf<rm_tx_record> d_air, d_air_alt; // (the window's buffer and the one it slides into when this one is used up: air_window_reserve)
     std::vector<AirBatch> air_batches;
     size_t air_head = 0, air_tail = 0;
     // the per-receiver interferer lists of the frames on the air, alive on the device from tick to tick (rm::AirDev):
@@ -292,7 +298,7 @@ struct rm_context : TickSlot {
         DevBuf<float4> fr_f, e_f;
         DevBuf<int4> fr_m, e_m;
         DevBuf<longlong2> fr_t, e_t;
-        DevBuf<uint32_t> fr_bin, bin_cnt, bin_off, block_sum, every, misc, pair_tail;
+        DevBuf<uint32_t> fr_bin, bin_cnt, bin_off, block_sum, every, misc, pair_tail, items;
         DevBuf<int32_t> self_next, slot_first;
         DevBuf<uint8_t> defer;
         DevBuf<rm::OvTick> ticks;

@@ -40,7 +40,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
             in_rssi = t.a_rssi[o];
             v = t.a_verdict[o];
             if (STOCH) in_prob = t.a_prob[o];
-            if (SINR && !t.seg_ordered) in_e = t.a_e[o]; // (ordered segments carry sinr and verdict themselves)
+            if (SINR && !t.seg_ordered && t.acc_lo == nullptr) in_e = t.a_e[o]; // (ordered segments and summed ticks carry sinr and verdict themselves)
         }
     }
 
@@ -83,6 +83,44 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 my_len = s_off[sl + 1] - s_off[sl];
                 if (my_len) my_src = t.seg_off[sl];
             }
+            // A frame with a handful of heard links (sixteen channels: three per frame) is its LANE's own business: the lane ranks its
+            // frame's links in registers and writes them -- 64 frames at a time and their loads all in flight together, where a
+            // wave per frame went through the same dependent round trips for three live lanes of 64 (configs[3]: 5000 frames
+            // per tick, 445 us of this stage per 128 ticks).  Longer frames keep the wave.
+            constexpr uint32_t kLaneMax = 8;
+            const bool lane_frames = !t.seg_ordered && !(SINR && t.air.pool != nullptr);
+            if (lane_frames && my_len != 0u && my_len <= kLaneMax) {
+                const int q = int(q0 + int64_t(ib + lane) * G);
+                const int slot = q + t.shift;
+                const uint32_t dst0 = s_off[slot];
+                const int q_pub = t.fl_map ? t.fl_map[q] : q;
+                int dd[kLaneMax];
+#pragma unroll
+                for (uint32_t k = 0; k < kLaneMax; ++k) dd[k] = (k < my_len) ? t.a_dst[my_src + k] : 0x7fffffff;
+#pragma unroll
+                for (uint32_t k = 0; k < kLaneMax; ++k) {
+                    if (k >= my_len) break;
+                    uint32_t rank = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < kLaneMax; ++j) rank += (dd[j] < dd[k]) ? 1u : 0u;
+                    const uint32_t o = my_src + k, d = dst0 + rank;
+                    if (d >= t.cap) continue;
+                    t.out_pkt[d] = q_pub;
+                    t.out_dst[d] = dd[k];
+                    t.out_rssi[d] = t.a_rssi[o];
+                    uint8_t vv = t.a_verdict[o];
+                    if (SINR && t.acc_lo != nullptr) {
+                        t.out_sinr[d] = t.a_sinr[o];
+                    } else if (SINR) {
+                        const int e = t.a_e[o];
+                        t.out_sinr[d] = t.st_sinr[e];
+                        if (t.st_coll[e]) vv = RM_INTERFERED;
+                    }
+                    t.out_verdict[d] = vv;
+                    if (STOCH) t.out_prob[d] = t.a_prob[o];
+                }
+                my_len = 0u; // done
+            }
             todo = ballot64(my_len != 0u);
         }
     while (todo) { // wave-uniform
@@ -109,10 +147,12 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 in_rssi = valid ? t.a_rssi[o] : 0.0;
                 v = valid ? t.a_verdict[o] : uint8_t(0);
                 in_prob = (STOCH && valid) ? t.a_prob[o] : 1.0;
-                in_e = (SINR && valid && !t.seg_ordered) ? t.a_e[o] : 0;
+                in_e = (SINR && valid && !t.seg_ordered && t.acc_lo == nullptr) ? t.a_e[o] : 0;
             }
             SinrOut so = {0.0, false};
-            if (SINR && t.seg_ordered) { // the one-launch tick: k_sinr_frames / k_sinr_scan have written sinr and verdict into the segment
+            if (SINR && t.acc_lo != nullptr) { // interference summed per receiver: k_sinr_acc has left sinr and verdict in the A record
+                if (valid) so.sinr = t.a_sinr[o];
+            } else if (SINR && t.seg_ordered) { // the one-launch tick: k_sinr_frames / k_sinr_scan have written sinr and verdict into the segment
                 if (valid) so.sinr = t.a_sinr[o];
             } else if (SINR && t.air.pool != nullptr && valid) { // the lists that live across ticks: the walk happens here, one lane per heard link
                 const rm_tx_record &w = t.tx[t.first_new + q];
@@ -132,7 +172,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
                 t.out_dst[d] = mine;
                 t.out_rssi[d] = in_rssi;
                 uint8_t vv = v;
-                if (SINR && (t.seg_ordered || t.air.pool != nullptr)) {
+                if (SINR && (t.seg_ordered || t.air.pool != nullptr || t.acc_lo != nullptr)) {
                     t.out_sinr[d] = so.sinr;
                     if (so.collided) vv = RM_INTERFERED;
                 } else if (SINR) {

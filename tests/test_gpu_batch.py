@@ -205,11 +205,15 @@ def test_batch_refusals(engine, rsa, O):
     recs.free()
 
 
-def test_sinr_batch_of_self_contained_ticks(engine, rsa, O):
+@pytest.mark.parametrize("acc", ["1", "0"])
+def test_sinr_batch_of_self_contained_ticks(engine, rsa, O, monkeypatch, acc):
     """The SINR extension in a batch: allowed when no frame outlives its tick (air time <= tick length),
     every tick then equals the oracle's answer for its own frames; the last tick's frames stay on the
-    air for the one-tick-at-a-time calls that follow, and for a batch that begins while they are (the overlap form)."""
+    air for the one-tick-at-a-time calls that follow, and for a batch that begins while they are (the overlap form).
+    Both forms of the interference sums: per receiver in Q80 by the exact stage (round 5, the default for ticks named by
+    source indices), and through the per-receiver lists (RM_SINR_ACC=0)."""
     from radio_sim_amd import _lib
+    monkeypatch.setenv("RM_SINR_ACC", acc)
     n = 6000
     nd = _layout(O, n, seed=41)
     rng = np.random.default_rng(12)

@@ -175,6 +175,45 @@ def test_c4_16_channels_sinr_capture_full_size(rsa, O):
         eng.close()
 
 
+@pytest.mark.parametrize("acc,lists", [("1", None), ("0", None), ("1", "2")])
+def test_c4_batch_of_full_size_ticks(rsa, O, monkeypatch, acc, lists):
+    """BASELINE configs[3] as the bench runs it: ticks of 5000 frames over 100k nodes on 16 channels in ONE launch sequence
+    (rm_batch_run_sources_device, air time = tick length: self-contained ticks) -- every link of two ticks against the oracle,
+    with the interference summed per receiver (the default), through the per-receiver lists (RM_SINR_ACC=0), and with the
+    filter's near-frame lists forced."""
+    from radio_sim_amd import workload as W
+    from util import DeviceArray
+    monkeypatch.setenv("RM_SINR_ACC", acc)
+    if lists:
+        monkeypatch.setenv("RM_NEAR_LISTS", lists)
+    n, t, n_ticks = 100_000, 5000, 2
+    src_nd = W.make_nodes(n, 4, channels16=True)
+    nd = O.NodeTable(n)
+    nd.x, nd.y, nd.channel = src_nd.x, src_nd.y, src_nd.channel
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 0xC0FFEE}
+    eng = rsa.Engine(0)
+    dev = []
+    try:
+        eng.upload_table(nd)
+        eng.set_model(KINDS["logdist"], **{_PARAM_MAP[k]: v for k, v in params.items()})
+        eng.set_link_capacity(1 << 22)
+        srcs = [W.choose_sources(n, t, 0xC0FFEE04, k) for k in range(n_ticks)]
+        dev = [DeviceArray(s) for s in srcs]
+        tb = np.arange(n_ticks, dtype=np.int64) * 8128
+        eng.batch_run_sources_device(tb, tb + 8128, [d.ptr.value for d in dev], [t] * n_ticks, tb, [8128] * n_ticks)
+        mdl = oracle_model(O, "logdist", params)
+        for b in range(n_ticks):
+            pk = nd.packets(srcs[b], int(tb[b]), 8128)
+            gpu = eng.batch_result_copy(b, t, cap=1 << 21)
+            assert gpu.count > 10_000
+            cpu = _whole_tick_check(O, mdl, nd, pk[:0], pk, gpu, "configs[3], batch tick %d (acc=%s)" % (b, acc))
+            assert (cpu.verdict == O.INTERFERED).sum() > 100
+    finally:
+        for d in dev:
+            d.free()
+        eng.close()
+
+
 def test_c5_one_million_nodes_multi_tick_overlap(rsa, O):
     """BASELINE configs[4] shape: 1M nodes, 0.1% new frames per tick (1000), 8128 us frames over
     1000 us ticks: the on-air list grows over the ticks; SINR with time overlap.  Three ticks; the

@@ -254,8 +254,8 @@ def test_a_full_pair_list_defers_frames_and_is_grown(rsa, O, monkeypatch):
 @pytest.mark.parametrize("near_lists", [None, "2"])
 def test_overlapping_batch_receiver_sharded(rsa, O, monkeypatch, near_lists):
     """Two and three receiver regions on one GPU: every rank sweeps the gathered frames of all ranks ([rank][tick][slot] source
-    indices, padding included) against its receivers, keeps ALL frames on the air, and the ranks' links merged by node index
-    are the whole batch's."""
+    indices, padding included) against its receivers, keeps the frames on the air that can matter to its region (k_rank_frames:
+    at the interference floor, with a margin), and the ranks' links merged by node index are the whole batch's."""
     if near_lists:
         monkeypatch.setenv("RM_NEAR_LISTS", near_lists)   # (the batch filter's near-frame lists at these sizes too: padding frames, regions)
         monkeypatch.setenv("RM_WG_RPT", "4")
@@ -305,6 +305,88 @@ def test_overlapping_batch_receiver_sharded(rsa, O, monkeypatch, near_lists):
                 d.free()
             for e in engs:
                 e.close()
+
+
+def test_receivers_that_move_while_selected_frames_are_on_the_air(rsa, O):
+    """A partitioned context keeps the frames on the air that can matter to its region as it was when they were transmitted
+    (plus RM_RANK_MARGIN, 64 m).  A receiver that moves a few metres in mid-air changes nothing about that -- the batch after
+    the move equals the oracle, which evaluates every frame on the air against the node table as it is now.  A receiver that is
+    put far outside its rank's region may be reached by frames this rank never kept: every tick of the next batch -- and a lone
+    tick -- then reads as RM_ERR_STATE instead of a verdict that silently lacks an interferer; once the frames have left the
+    air the rank goes on."""
+    n, t, nb, world = 20_000, 200, 4, 2
+    nd, rng = _nodes(O, n, seed=21)
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 5}
+    rep = Replay(O, nd, params)
+    engs = [_engine(rsa, nd, params) for _ in range(world)]
+    dev = []
+    try:
+        for r, e in enumerate(engs):
+            e.set_partition_spatial(r, world)
+        own = engs[0].partition_of_nodes(world)
+
+        def batch(k0, check=True, expect_error_on=()):
+            ticks = [np.sort(rng.choice(n, t, replace=False)).astype(np.int32) for _ in range(nb)]
+            slots = max(int((own[s] == r).sum()) for s in ticks for r in range(world)) + 1
+            packed = np.full((world, nb, slots), -1, dtype=np.int32)
+            for b, s in enumerate(ticks):
+                for r in range(world):
+                    mine = s[own[s] == r]
+                    packed[r, b, :len(mine)] = mine
+            d = DeviceArray(packed.reshape(-1))
+            dev.append(d)
+            starts = [(k0 + b) * TICK for b in range(nb)]
+            for e in engs:
+                e.batch_run_gathered_sources_device(starts, [s + TICK for s in starts], d.ptr.value, world, slots, starts, 8128)
+            for b in range(nb):
+                order = packed[:, b, :].reshape(-1)
+                real = order >= 0
+                cpu = rep.tick(starts[b], order[real], starts[b], 8128, check=check)
+                parts = []
+                for r, e in enumerate(engs):
+                    if r in expect_error_on:
+                        with pytest.raises(rsa.RadioMediumError) as err:
+                            e.batch_result_copy(b, world * slots)
+                        assert err.value.code == -5 and "left the region" in str(err.value)
+                    else:
+                        parts.append(e.batch_result_copy(b, world * slots))
+                if check and not expect_error_on:
+                    renum = np.cumsum(real) - 1
+                    pk = np.concatenate([renum[p.pkt] for p in parts])
+                    key = np.lexsort((np.concatenate([p.dst for p in parts]), pk))
+                    for f in ("dst", "rssi", "sinr", "verdict"):
+                        np.testing.assert_array_equal(np.concatenate([getattr(p, f) for p in parts])[key], getattr(cpu, f), err_msg="tick %d %s" % (k0 + b, f))
+                    assert cpu.count > 3000
+
+        batch(0)
+        # a few metres, in mid-air: every rank hears of it; nothing to complain about
+        movers = rng.choice(n, 50, replace=False).astype(np.int32)
+        nd.x[movers] += rng.uniform(-5, 5, 50)
+        nd.y[movers] += rng.uniform(-5, 5, 50)
+        for e in engs:
+            e.move_nodes(movers, nd.x[movers], nd.y[movers])
+        batch(nb)
+        # one of rank 0's receivers is put at the far corner of the other rank's region
+        far = int(np.nonzero(own == 0)[0][7])
+        other = np.nonzero(own == 1)[0]
+        nd.x[far], nd.y[far] = float(nd.x[other].max()), float(nd.y[other].max())
+        for e in engs:
+            e.move_nodes(np.array([far], dtype=np.int32), nd.x[[far]], nd.y[[far]])
+        batch(2 * nb, check=False, expect_error_on=(0,))
+        lone = DeviceArray(np.sort(rng.choice(n, 50, replace=False)).astype(np.int32))
+        dev.append(lone)
+        engs[0].tick_run_sources_device(3 * nb * TICK, (3 * nb + 1) * TICK, lone.ptr.value, 50, 3 * nb * TICK, 320)
+        with pytest.raises(rsa.RadioMediumError) as err:
+            engs[0].result_copy(50)
+        assert err.value.code == -5 and "left the region" in str(err.value)
+        # ... and when every frame that was selected before the move has left the air, the rank goes on (its box is what it is now)
+        rep.onair = rep.onair[:0]
+        batch(40)
+    finally:
+        for d in dev:
+            d.free()
+        for e in engs:
+            e.close()
 
 
 def test_refusals(rsa, O):

@@ -415,7 +415,7 @@ def test_rank_frame_lists_change_nothing(rsa, O, monkeypatch, kind, params, air,
                 np.testing.assert_array_equal(merged[k], getattr(cpu, f), err_msg="tick %d %s" % (b, f))
             np.testing.assert_array_equal(parts[0].pkt_interference[real], cpu.pkt_interference)
             heard += cpu.count
-        assert heard > 2000
+        assert heard > 1000
     finally:
         dev.free()
 
