@@ -561,6 +561,22 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
         links = sum(v.count for v in views)
         out["batch_result_view"] = {"us_per_tick": el / (reps_b * nb) * 1e6, "value": links_per_tick * reps_b * nb / el,
                                     "unit": "links/s", "ticks_per_launch": nb, "bytes_out_per_tick": links / nb * 13}
+        # the same with the reference's own UDGM medium: a heard link's rssi is its packet's transmit power (UDGMRadioMedium.java:95),
+        # so ONE value per packet crosses the link and a link is 5 bytes (node, verdict) instead of 13 (ABI version 5)
+        with torch.cuda.stream(stream):
+            eng.set_model(rsa.MODEL_UDGM)
+            for _ in range(2):
+                eng.batch_run_sources_device(t_b, t_b + tick_us, ptrs, cnt, t_b, air)
+                views, _ = eng.batch_result_view(nb)
+            t0 = time.perf_counter()
+            for _ in range(reps_b):
+                eng.batch_run_sources_device(t_b, t_b + tick_us, ptrs, cnt, t_b, air)
+                views, _ = eng.batch_result_view(nb)
+            el = time.perf_counter() - t0
+        links = sum(v.count for v in views)
+        out["batch_result_view_udgm"] = {"us_per_tick": el / (reps_b * nb) * 1e6, "value": links_per_tick * reps_b * nb / el, "unit": "links/s",
+                                         "ticks_per_launch": nb, "bytes_out_per_tick": links / nb * 5 + t_per_tick * 13,
+                                         "what": "reference UDGM, rssi once per packet: rm_host_result.rssi is NULL, pkt_rssi carries it"}
     return out
 
 

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-/* 5: a partitioned context that is handed all ranks' source indices keeps, per tick, only the frames that can matter to
+/* 5: rm_host_result.rssi is NULL for the reference's four media and pkt_rssi carries one value per packet;
+ *    a partitioned context that is handed all ranks' source indices keeps, per tick, only the frames that can matter to
  *    its receivers (results unchanged: packets keep their numbers); the ranks' node-table digests ride in the all-gather of
  *    rm_dist_batch_run_sources_device (rm_table_digest, rm_batch_run_gathered_blocks_device, RM_GATHER_TRAILER): a rank
  *    whose copy of the node table differs makes the batch RM_ERR_STATE on every rank.
@@ -219,10 +220,31 @@ typedef struct rm_host_result {
                                       * (4 of a record's 17 bytes that need not cross PCIe; rm_tick_flush still fills its caller's array) */
     const int32_t *dst;              /* [count] receiver node index (ascending per packet) */
     const uint8_t *verdict;          /* [count] RM_INTERFERED / RM_DELIVERED */
-    const double *rssi;              /* [count] */
+    const double *rssi;              /* [count] -- or NULL (ABI version 5) for the reference's four media: a heard link's rssi is its
+                                      * packet's transmit power there (UDGMRadioMedium.java:95, NullRadioMedium.java:57,
+                                      * N2NRadioMedium.java:51, UDGMConstantLossRadioMedium.java:22), and it crosses PCIe once per packet: */
     const double *sinr;              /* [count] with the SINR extension, else NULL (as rm_device_result.sinr) */
+    const double *pkt_rssi;          /* [n_packets] when rssi is NULL: link i of packet q has rssi pkt_rssi[q] (5 bytes per link
+                                      * instead of 13); NULL when rssi is not (rm_tick_flush still fills its caller's array) */
 } rm_host_result;
 int rm_tick_flush_view(rm_context *ctx, rm_host_result *out);
+
+/* A medium in which a frame is heard by a large share of all nodes -- the reference's default NullRadioMedium (every same-channel
+ * node: NullRadioMedium.java:62-73), a lossless N2N matrix, a unit disc over a small field -- is evaluated in node order, and
+ * what its tick leaves IS its result: per (packet, chunk of 1024 consecutive nodes) cell sixteen 64-bit lane masks -- bit l
+ * of mask k set: node rx_first + 1024 * chunk + 64 * k + l heard the packet -- and the cell's count.  A heard link's rssi is
+ * its packet's transmit power, its verdict its packet's (pkt_interference): nothing else distinguishes links of such a medium,
+ * so the 17-byte records (68 MB for 4 M links) are written only when rm_result_device / rm_result_copy / a host view asks.
+ * All pointers are device memory, valid until the next evaluating call; RM_ERR_STATE when the last tick took another form. */
+typedef struct rm_dense_result {
+    const unsigned long long *cell_mask; /* [n_packets][chunks][16] */
+    const uint32_t *cell_count;          /* [n_packets][chunks] */
+    const uint32_t *count;               /* [1] heard links of the tick */
+    const uint32_t *pkt_offset;          /* [n_packets + 1] */
+    const uint8_t *pkt_interference;     /* [n_packets] */
+    int32_t n_packets, chunks, rx_first;
+} rm_dense_result;
+int rm_result_dense(rm_context *ctx, rm_dense_result *out);
 
 /* evaluate the enqueued tick without copying anything out (then rm_result_copy / rm_result_device) */
 int rm_tick_run(rm_context *ctx);

@@ -320,21 +320,25 @@ public class GpuRadioMedium extends AbstractRadioMedium {
                 queue.clear();
                 return;
             }
-            java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[5];
+            java.nio.ByteBuffer[] v = new java.nio.ByteBuffer[6];
             int[] counts = new int[2];
             if (rc == 0) rc = nTickFlushView(ctx, v, counts);
             if (rc != 0) log.error("radio medium: {}", nLastError());
             java.nio.IntBuffer off = rc == 0 ? v[0].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer() : null;
             java.nio.IntBuffer d = rc == 0 ? v[2].order(java.nio.ByteOrder.nativeOrder()).asIntBuffer() : null;
-            java.nio.DoubleBuffer r = rc == 0 ? v[4].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer() : null;
+            // ABI version 5: the links' rssi (v[4]) -- or, for the reference's own media, one value per PACKET (v[5]): a heard link's
+            // rssi is packet.getTransmitPower() there (UDGMRadioMedium.java:95), and it crosses PCIe once per packet
+            boolean perPacket = rc == 0 && v[4].capacity() == 0 && counts[0] > 0;
+            java.nio.DoubleBuffer r = rc == 0 ? v[perPacket ? 5 : 4].order(java.nio.ByteOrder.nativeOrder()).asDoubleBuffer() : null;
             int k = 0; // index into the engine's packets of this tick
             for (RadioPacket p : queue) { // arrival order, then node order: the per-packet calls
                 if (kind != MODEL_UDGM_CONST) sim.generateTransmissionEvents(p); // whatever the native call said
                 if (rc != 0 || k >= enqueued.size() || enqueued.get(k) != p) continue; // not evaluated: no receivers
                 for (int i = off.get(k); i < off.get(k + 1); i++) {
                     Node node = nodes[d.get(i)];
-                    if (kind == MODEL_UDGM_CONST) sim.deliverRadioPacket(p, node, r.get(i));
-                    else sim.generateReceptionEvents(p, node, r.get(i), v[3].get(i) == DELIVERED);
+                    double rssi = r.get(perPacket ? k : i);
+                    if (kind == MODEL_UDGM_CONST) sim.deliverRadioPacket(p, node, rssi);
+                    else sim.generateReceptionEvents(p, node, rssi, v[3].get(i) == DELIVERED);
                 }
                 k++;
             }

@@ -171,9 +171,11 @@ JNIEXPORT jint JFN(nTickFlushView)(JNIEnv *env, jclass cls, jlong ctx, jobjectAr
     if (rc != RM_OK) return rc;
     jint c[2] = {(jint)r.count, (jint)r.n_packets};
     (*env)->SetIntArrayRegion(env, counts, 0, 2, c);
-    void *ptr[5] = {(void *)r.pkt_offset, (void *)r.pkt_interference, (void *)r.dst, (void *)r.verdict, (void *)r.rssi};
-    jlong len[5] = {((jlong)r.n_packets + 1) * 4, (jlong)r.n_packets, (jlong)r.count * 4, (jlong)r.count, (jlong)r.count * 8};
-    for (int i = 0; i < 5; i++)
+    /* (ABI version 5) views[4]: the links' rssi -- or, for the reference's media, NULL and views[5] the PACKETS' rssi */
+    void *ptr[6] = {(void *)r.pkt_offset, (void *)r.pkt_interference, (void *)r.dst, (void *)r.verdict, (void *)r.rssi, (void *)r.pkt_rssi};
+    jlong len[6] = {((jlong)r.n_packets + 1) * 4, (jlong)r.n_packets, (jlong)r.count * 4, (jlong)r.count, r.rssi ? (jlong)r.count * 8 : 0,
+                    r.pkt_rssi ? (jlong)r.n_packets * 8 : 0};
+    for (int i = 0; i < 6; i++)
         (*env)->SetObjectArrayElement(env, views, i, (*env)->NewDirectByteBuffer(env, ptr[i], len[i] > 0 ? len[i] : 0));
     return RM_OK;
 }

@@ -54,6 +54,12 @@ class DeviceResult(C.Structure):
                 ("verdict", C.c_void_p), ("rssi", C.c_void_p), ("sinr", C.c_void_p), ("capacity", C.c_uint32)]
 
 
+class DenseResult(C.Structure):
+    """rm_dense_result"""
+    _fields_ = [("cell_mask", C.c_void_p), ("cell_count", C.c_void_p), ("count", C.c_void_p), ("pkt_offset", C.c_void_p),
+                ("pkt_interference", C.c_void_p), ("n_packets", C.c_int32), ("chunks", C.c_int32), ("rx_first", C.c_int32)]
+
+
 class KernelTime(C.Structure):
     """rm_kernel_time"""
     _fields_ = [("name", C.c_char * 96), ("stage", C.c_int32), ("launches", C.c_uint32), ("total_ms", C.c_double)]
@@ -62,7 +68,7 @@ class KernelTime(C.Structure):
 class HostResult(C.Structure):
     _fields_ = [("count", C.c_uint32), ("n_packets", C.c_uint32), ("pkt_offset", C.c_void_p),
                 ("pkt_interference", C.c_void_p), ("pkt", C.c_void_p), ("dst", C.c_void_p), ("verdict", C.c_void_p),
-                ("rssi", C.c_void_p), ("sinr", C.c_void_p)]
+                ("rssi", C.c_void_p), ("sinr", C.c_void_p), ("pkt_rssi", C.c_void_p)]
 
 
 class DeliveryView(C.Structure):
@@ -150,6 +156,7 @@ SIGNATURES = {
     "rm_tick_run_sources_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
                                              C.c_int64]),
     "rm_result_device": (C.c_int, [C.c_void_p, C.POINTER(DeviceResult)]),
+    "rm_result_dense": (C.c_int, [C.c_void_p, C.POINTER(DenseResult)]),
     "rm_result_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rm_result_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                  C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),

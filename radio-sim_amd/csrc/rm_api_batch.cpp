@@ -423,8 +423,11 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
     RM_HIP(hipMemcpyAsync(c->d_pack.p, c->h_pack, sizeof(rm::PackSlot) * size_t(n_slots), hipMemcpyHostToDevice, c->stream));
     rm::HostView v{};
     rm::BatchCounts *counts = nullptr;
+    bool pkt_rssi = true; // one rssi per packet (the reference's media) if every slot allows it
+    for (int b = 0; b < n_slots; ++b) pkt_rssi = pkt_rssi && host_pkt_rssi(c, *slot_of(c, b));
     for (int attempt = 0;; ++attempt) {
         v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
+        if (pkt_rssi) v.rssi = nullptr;
         counts = stage_counts(c->h_stage);
         const uint32_t seq = ++c->stage_seq;
         RM_HIP(rm::launch_pack_batch(c->stream, c->d_pack.p, n_slots, v, counts, c->d_pack_done.p, seq));
@@ -449,7 +452,8 @@ int rm_batch_result_view(rm_context *c, int32_t n_slots, rm_host_result *out, in
         r.pkt = nullptr; // (ABI version 3: pkt_offset says it all)
         r.dst = v.dst + bc.link_base;
         r.verdict = v.verdict + bc.link_base;
-        r.rssi = v.rssi + bc.link_base;
+        r.rssi = v.rssi ? v.rssi + bc.link_base : nullptr;
+        r.pkt_rssi = v.rssi ? nullptr : v.pkt_rssi + ps.pkt_base;
         r.sinr = ps.t.out_sinr ? v.sinr + bc.link_base : nullptr;
         int st = RM_OK;
         if (bc.span_flag)

@@ -157,6 +157,7 @@ rm::NodesDev nodes_dev(rm_context *c)
 {
     rm::NodesDev nd{};
     nd.n = c->n;
+    nd.srec = c->d_srec.p;
     nd.sx = c->d_x.p;
     nd.sy = c->d_y.p;
     nd.sz = c->d_z.p;
@@ -300,7 +301,7 @@ void rm_destroy(rm_context *c)
             (void)hipEventDestroy(k.b);
         }
     c->d_x.release(); c->d_y.release(); c->d_z.release(); c->d_txpower.release(); c->d_txprob.release(); c->d_rxprob_node.release();
-    c->d_channel.release(); c->d_int_id.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
+    c->d_channel.release(); c->d_int_id.release(); c->d_srec.release(); c->d_rx_x.release(); c->d_rx_y.release(); c->d_rx_z.release();
     c->d_rx_rxprob.release(); c->d_rx_channel.release(); c->d_rx_int_id.release(); c->d_rx_orig.release();
     c->d_pos_of.release(); c->d_rx_enabled.release(); c->d_rx_rec.release(); c->d_rx_rec32.release(); c->d_rxf.release(); c->d_bbox_xy.release();
     c->d_bbox_z.release(); c->d_wg_box_xy.release(); c->d_wg_box_z.release(); c->d_grp_chmask.release(); c->d_wg_chmask.release();

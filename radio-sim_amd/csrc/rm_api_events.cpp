@@ -80,6 +80,7 @@ int ev_append(rm_context *c, TickSlot &ts, bool may_wait)
     }
     RM_TRY(ev_flush_append(c));
     RM_TRY(ev_ensure_nodes(c));
+    if (ts.dense_pending) RM_TRY(materialize(c, ts)); // (the reception stage reads records)
     const rm::TickDev &t = ts.last;
     rm::EvLinkSrc ls{};
     const uint32_t *dropped = nullptr;

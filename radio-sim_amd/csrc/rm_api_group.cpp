@@ -198,6 +198,7 @@ static int group_merge(rm_group *g, int n_new, int32_t *pkt, int32_t *dst, uint8
         o.dst = v.dst;
         o.verdict = v.verdict;
         o.rssi = v.rssi;
+        o.pkt_rssi = v.rssi ? nullptr : v.pkt_rssi;
         o.sinr = c->last.out_sinr ? v.sinr : nullptr;
         const int st = stage_status(c, v);
         if (st != RM_OK && first_error == RM_OK) {
@@ -233,7 +234,7 @@ static int group_merge(rm_group *g, int n_new, int32_t *pkt, int32_t *dst, uint8
                 if (pkt) pkt[w] = q;
                 if (dst) dst[w] = o.dst[i];
                 if (verdict) verdict[w] = o.verdict[i];
-                if (rssi) rssi[w] = o.rssi[i];
+                if (rssi) rssi[w] = o.rssi ? o.rssi[i] : o.pkt_rssi[q];
                 if (sinr) sinr[w] = o.sinr ? o.sinr[i] : 0.0;
             }
             ++w;

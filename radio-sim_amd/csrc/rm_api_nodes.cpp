@@ -414,6 +414,20 @@ int rm_nodes_upload(rm_context *c, int32_t n, const double *x, const double *y, 
     RM_TRY(upload(c->d_channel, c->channel, c->stream));
     RM_TRY(upload(c->d_int_id, c->int_id, c->stream));
     RM_TRY(upload(c->d_enabled, c->enabled, c->stream));
+    {
+        std::vector<rm::SrcRecord> sr(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            rm::SrcRecord &r = sr[size_t(i)];
+            r.x = c->x[i], r.y = c->y[i], r.z = c->z[i];
+            r.txpower = c->txpower[i];
+            r.txprob = c->txprob[i];
+            r.channel = c->channel[i];
+            r.int_id = c->int_id[i];
+            r.pad[0] = r.pad[1] = 0.0;
+        }
+        RM_TRY(upload(c->d_srec, sr, c->stream));
+        RM_HIP(hipStreamSynchronize(c->stream)); // (the host vector goes away)
+    }
     RM_HIP(hipStreamSynchronize(c->stream));
     if (c->ev.on) RM_TRY(ev_ensure_nodes(c));
     recompute_frame(c);

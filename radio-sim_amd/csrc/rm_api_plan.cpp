@@ -111,6 +111,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     RM_TRY(ev_flush_append(c)); // (the tick before, if its append was left for a drain that did not come: its records are about to go)
     ts.have_result = false;
     ts.compact_pending = false;
+    ts.dense_pending = ts.dense_result = false;
     ts.last_n_new = n_new;
     RM_TRY(prepare_nodes(c));
 
@@ -414,7 +415,13 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         RM_HIP(ts.d_dense_mask.ensure(std::max<size_t>(cells, 1) * 16));
         if (t.gather_src) RM_HIP(hipMemcpyAsync(t.tx_build, t.gather_src, size_t(t.n_active) * sizeof(rm_tx_record), hipMemcpyHostToDevice, s));
         RM_TRY(stage(RM_STAGE_FILTER));
-        RM_HIP(rm::launch_dense_tick(s, nd, m, t, ts.d_cnt.p, ts.d_off.p, ts.d_dense_mask.p));
+        const char *e_lazy = std::getenv("RM_DENSE_LAZY"); // 0: the records at once, as before ABI version 5 (read per tick: tests)
+        const bool lazy = !(e_lazy && std::atoi(e_lazy) == 0);
+        RM_HIP(rm::launch_dense_tick(s, nd, m, t, ts.d_cnt.p, ts.d_off.p, ts.d_dense_mask.p, lazy));
+        ts.dense_pending = lazy;
+        ts.dense_result = true;
+        ts.dense_rx_first = nd.rx_first;
+        ts.dense_chunks = (nd.pos_span + 1023) / 1024;
         ts.compact_pending = false;
         ts.last.seg_ordered = 0;
         ts.last_model = m;
@@ -546,6 +553,11 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
 // the compact packet-major arrays of a tick that so far only has its per-frame segments
 int materialize(rm_context *c, TickSlot &ts)
 {
+    if (ts.dense_pending) { // the dense tick's records, from its cells' lane masks
+        RM_HIP(rm::launch_dense_write(c->stream, ts.last_model, ts.last, ts.d_cnt.p, ts.d_off.p, ts.d_dense_mask.p, ts.dense_rx_first,
+                                      ts.dense_chunks));
+        ts.dense_pending = false;
+    }
     if (!ts.compact_pending) return RM_OK;
     RM_HIP(rm::launch_reorder(c->stream, ts.last_model, ts.last, ts.last_cfg));
     ts.compact_pending = false;

@@ -90,6 +90,7 @@ rm::HostView stage_view(char *base, uint32_t links, uint32_t packets, size_t *by
     o += pad64(sizeof(rm::BatchCounts) * RM_MAX_BATCH); // per-slot counts of rm_batch_result_view (stage_counts)
     v.pkt_offset = reinterpret_cast<uint32_t *>(base + o); o += pad64((size_t(packets) + 1) * 4);
     v.pkt_interference = reinterpret_cast<uint8_t *>(base + o); o += pad64(size_t(packets) + 1);
+    v.pkt_rssi = reinterpret_cast<double *>(base + o); o += pad64((size_t(packets) + 1) * 8);
     v.dst = reinterpret_cast<int32_t *>(base + o); o += pad64(size_t(links) * 4);
     v.rssi = reinterpret_cast<double *>(base + o); o += pad64(size_t(links) * 8);
     v.sinr = reinterpret_cast<double *>(base + o); o += pad64(size_t(links) * 8);
@@ -124,6 +125,13 @@ int ensure_stage(rm_context *c, uint32_t links, uint32_t packets)
     return RM_OK;
 }
 
+bool host_pkt_rssi(const rm_context *c, const TickSlot &ts)
+{
+    static const bool keep = std::getenv("RM_HOST_LINK_RSSI") != nullptr;
+    // (a rank's frame list keeps the records of its listed frames only: an unlisted packet's power is not at hand)
+    return !keep && c->params.kind != RM_MODEL_LOGDIST && ts.last.n_pub == 0;
+}
+
 // pack the evaluated tick of slot `ts` into the host-mapped block and wait for it
 int pack_to_stage(rm_context *c, TickSlot &ts, rm::HostView *view)
 {
@@ -132,9 +140,11 @@ int pack_to_stage(rm_context *c, TickSlot &ts, rm::HostView *view)
                                   "rm_draw_counts_device and call rm_tick_finish_draws first");
     const int n_new = std::max(ts.last_n_new, 0);
     const int have_offsets = (n_new > 0 && part_count(c) > 0) ? 1 : 0;
+    if (ts.dense_pending) RM_TRY(materialize(c, ts));
     RM_TRY(ensure_stage(c, 0, uint32_t(n_new)));
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const rm::HostView v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
+        rm::HostView v = stage_view(c->h_stage, c->stage_links, c->stage_packets, nullptr);
+        if (host_pkt_rssi(c, ts)) v.rssi = nullptr; // (the packets' transmit power instead: pkt_rssi)
         const uint32_t seq = ++c->stage_seq;
         if (ts.compact_pending) // straight from the frames' segments: no compact arrays in between
             RM_HIP(rm::launch_pack_frames(c->stream, ts.last_model, ts.last, n_new, v, c->d_pack_done.p, seq));
@@ -248,7 +258,7 @@ int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *dropped
 {
     if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
-    RM_TRY(materialize(c, ts));
+    if (!ts.dense_pending) RM_TRY(materialize(c, ts)); // (a dense tick's totals do not wait for its records)
     uint32_t oc[5];
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
@@ -317,7 +327,8 @@ int rm_tick_flush_view(rm_context *c, rm_host_result *out)
     out->pkt = nullptr; // (ABI version 3: pkt_offset says it all)
     out->dst = v.dst;
     out->verdict = v.verdict;
-    out->rssi = v.rssi;
+    out->rssi = v.rssi;                                // NULL for the reference's media: ...
+    out->pkt_rssi = v.rssi ? nullptr : v.pkt_rssi;     // ... their links carry the packet's transmit power
     out->sinr = c->last.out_sinr ? v.sinr : nullptr; // written by the SINR extension only
     return stage_status(c, v);
 }
@@ -340,7 +351,10 @@ int rm_tick_flush(rm_context *c, int32_t *pkt, int32_t *dst, uint8_t *verdict, d
         }
         if (dst) std::memcpy(dst, v.dst, k * sizeof(int32_t));
         if (verdict) std::memcpy(verdict, v.verdict, k);
-        if (rssi) std::memcpy(rssi, v.rssi, k * sizeof(double));
+        if (rssi && v.rssi) std::memcpy(rssi, v.rssi, k * sizeof(double));
+        else if (rssi) // one rssi per packet crossed the link: the caller's array is filled from the offsets
+            for (uint32_t q = 0; q < v.hdr->n_packets; ++q)
+                for (uint32_t i = v.pkt_offset[q], e = std::min(v.pkt_offset[q + 1], k); i < e; ++i) rssi[i] = v.pkt_rssi[q];
         if (sinr && c->last.out_sinr) std::memcpy(sinr, v.sinr, k * sizeof(double));
         else if (sinr) std::memset(sinr, 0, k * sizeof(double));
     }
@@ -637,6 +651,23 @@ int rm_tick_run_records_device(rm_context *c, int64_t t_begin_us, int64_t t_end_
     c->t_begin = t_begin_us;
     c->t_end = t_end_us;
     return air_tick_device(c, t_begin_us, nullptr, dev_new, n_new, 0, 0, latest_end_us, false);
+}
+
+// The last tick's heard links as the dense tick leaves them (rm_dense.hip): per (packet, chunk of 1024 consecutive nodes) cell
+// sixteen lane masks -- bit l of mask k: node rx_first + 1024 * chunk + 64 * k + l heard the packet -- and the cell's count.
+int rm_result_dense(rm_context *c, rm_dense_result *out)
+{
+    if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
+    if (!c->have_result || !c->dense_result) return fail(RM_ERR_STATE, "the last tick did not take the dense form (rm_result_device has its records)");
+    out->cell_mask = c->d_dense_mask.p;
+    out->cell_count = c->d_cnt.p;
+    out->count = c->last.out_count + 2;
+    out->pkt_offset = c->d_slot_off.p + c->last.shift;
+    out->pkt_interference = c->d_pkt_interf.p;
+    out->n_packets = c->last_n_new;
+    out->chunks = c->dense_chunks;
+    out->rx_first = c->dense_rx_first;
+    return RM_OK;
 }
 
 int rm_result_device(rm_context *c, rm_device_result *out)

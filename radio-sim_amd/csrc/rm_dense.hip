@@ -286,8 +286,22 @@ bool dense_tick_applies(const TickDev &t, const LaunchCfg &cfg, const ModelDev &
     return share >= 1.0 / 16.0 && share * double(t.n_rx) > double(kFrameSegMax);
 }
 
+// the record pass on its own (a tick whose records were left for whoever asks for them: launch_dense_tick with lazy_write)
+hipError_t launch_dense_write(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *cell_cnt, const uint32_t *cell_off,
+                              const unsigned long long *cell_mask, int rx_first, int chunks)
+{
+    const int n_new = t.n_active - t.first_new;
+    if (n_new <= 0 || chunks <= 0) return hipSuccess;
+    RM_KLAUNCH((k_dense_write<false>), dim3(chunks, n_new), dim3(256), 0, s, m, t, cell_cnt, cell_off, cell_mask, rx_first, chunks);
+    return hipGetLastError();
+}
+
+// lazy_write: the tick ends with its cells -- the heard links of every (frame, 1024 nodes) cell as sixteen lane masks, the cells'
+// counts and offsets, the packets' offsets and the totals (k_dense_scan).  That IS the result of such a medium: a link's rssi is
+// its packet's transmit power, its verdict its packet's; the 17-byte records -- 68 MB for 4 M links -- are written when somebody
+// asks for them (materialize -> launch_dense_write).
 hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off,
-                             unsigned long long *cell_mask)
+                             unsigned long long *cell_mask, bool lazy_write)
 {
     const int n_new = t.n_active - t.first_new;
     const int chunks = cdiv(nd.pos_span, kDnChunk);
@@ -300,7 +314,9 @@ hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &
     case RM_MODEL_N2N: RM_KLAUNCH((k_dense_count<RM_MODEL_N2N>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
     default: return hipErrorInvalidValue;
     }
-    if (long(n_new) * long(chunks) <= long(kDnFusedCells)) {
+    if (lazy_write) {
+        RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);
+    } else if (long(n_new) * long(chunks) <= long(kDnFusedCells)) {
         RM_KLAUNCH((k_dense_write<true>), grid, block, 0, s, m, t, cell_cnt, cell_off, cell_mask, nd.rx_first, chunks);
     } else {
         RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);

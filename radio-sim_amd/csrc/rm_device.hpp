@@ -141,15 +141,16 @@ RM_D rm_tx_record make_tx_record(const NodesDev &nd, int s, int64_t start_us, in
         r.src = -1;
         r.channel = 0;
     } else {
-        r.x = nd.sx[s];
-        r.y = nd.sy[s];
-        r.z = nd.sz[s];
-        r.txpower = nd.stxpower[s];
-        r.txprob = nd.stxprob[s];
+        const SrcRecord sr = nd.srec[s]; // (one line: position, power, probability, channel)
+        r.x = sr.x;
+        r.y = sr.y;
+        r.z = sr.z;
+        r.txpower = sr.txpower;
+        r.txprob = sr.txprob;
         r.start_us = start_us;
         r.air_us = air_us;
         r.src = s;
-        r.channel = nd.schannel[s];
+        r.channel = sr.channel;
     }
     return r;
 }

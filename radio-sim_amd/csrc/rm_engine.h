@@ -130,8 +130,18 @@ struct alignas(32) RxCompact {
     uint32_t flags;   // bit 0: rxprob != 1.0
 };
 
+// What a RadioPacket copies from its source (RadioPacket.java:46-52), one aligned 64-byte record per node: a frame named by its
+// source index is ONE gather (the columns below cost six lines per frame; at a million nodes each of them left the L2).
+struct alignas(64) SrcRecord {
+    double x, y, z, txpower, txprob;
+    int32_t channel, int_id;
+    double pad[2];
+};
+static_assert(sizeof(SrcRecord) == 64, "one cache line");
+
 struct NodesDev {
     int n;                                   // nodes in the simulator
+    const SrcRecord *srec;                   // [n] the source table by node index, as records
     const double *sx, *sy, *sz, *stxpower, *stxprob;
     const double *srxprob;                   // Transciever.rxProbability by node index (the dense tick visits receivers in node order)
     const int32_t *schannel, *sint_id;
@@ -401,7 +411,10 @@ struct HostView {
     uint32_t *pkt_offset;       // [packets + 1]
     uint8_t *pkt_interference;  // [packets]
     int32_t *dst;               // (no packet column: a link's packet follows from pkt_offset)
-    double *rssi, *sinr;
+    double *rssi, *sinr;        // rssi == nullptr: the medium hands the packet's transmit power through (UDGMRadioMedium.java:95,
+                                // NullRadioMedium.java:57, N2NRadioMedium.java:51, UDGMConstantLossRadioMedium.java:22) -- it is sent once
+                                // per PACKET (pkt_rssi), not with every link: 8 of a link's 13 bytes that need not cross PCIe
+    double *pkt_rssi;           // [packets] the packets' transmit power
     uint8_t *verdict;
     uint32_t links, packets;    // room
 };
@@ -654,7 +667,9 @@ hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, 
 bool dense_tick_applies(const TickDev &t, const LaunchCfg &cfg, const ModelDev &m, const NodesDev &nd, bool whole_or_range);
 int dense_tick_cells(const NodesDev &nd, const TickDev &t);
 hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off,
-                             unsigned long long *cell_mask); // cell_mask: 16 lane masks per (frame, chunk) cell
+                             unsigned long long *cell_mask, bool lazy_write); // cell_mask: 16 lane masks per (frame, chunk) cell
+hipError_t launch_dense_write(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *cell_cnt, const uint32_t *cell_off,
+                              const unsigned long long *cell_mask, int rx_first, int chunks);
 
 // reception stage (rm_events.hip)
 hipError_t launch_ev_append(hipStream_t s, const EvDev &e, const EvLinkSrc &ls, const rm_tx_record *tx, int n_new, int64_t now,

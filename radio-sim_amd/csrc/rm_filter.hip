@@ -92,6 +92,13 @@ __global__ void __launch_bounds__(256) k_patch_nodes(NodesDev nd, const NodePatc
     const_cast<double *>(nd.srxprob)[p.node] = p.rxprob;
     const_cast<int32_t *>(nd.schannel)[p.node] = p.channel;
     const_cast<uint8_t *>(nd.senabled)[p.node] = uint8_t(p.enabled);
+    SrcRecord *sr = const_cast<SrcRecord *>(nd.srec) + p.node;
+    sr->x = p.x;
+    sr->y = p.y;
+    sr->z = p.z;
+    sr->txpower = p.txpower;
+    sr->txprob = p.txprob;
+    sr->channel = p.channel;
     if (p.pos < 0) return;
     const_cast<double *>(nd.x)[p.pos] = p.x;
     const_cast<double *>(nd.y)[p.pos] = p.y;

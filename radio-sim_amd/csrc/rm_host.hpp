@@ -128,6 +128,10 @@ struct TickSlot {
     // the closed-loop tick (rm_tick.hip) leaves per-frame ordered segments; the compact packet-major
     // arrays of rm_device_result are produced (k_reorder) when somebody asks for them
     bool compact_pending = false;
+    // the dense tick (rm_dense.hip) leaves the heard links as lane masks per (frame, 1024 nodes) cell: the records are written
+    // when somebody asks for them (materialize); rm_result_dense hands out the masks themselves
+    bool dense_pending = false, dense_result = false;
+    int dense_rx_first = 0, dense_chunks = 0;
     rm::ModelDev last_model{};
     rm::LaunchCfg last_cfg{};
 
@@ -150,6 +154,7 @@ struct rm_context : TickSlot {
     // device-resident source table (SoA, node-index order): what a packet copies from its source
     DevBuf<double> d_x, d_y, d_z, d_txpower, d_txprob, d_rxprob_node;
     DevBuf<int32_t> d_channel, d_int_id;
+    DevBuf<rm::SrcRecord> d_srec; // ... and the same as one 64-byte record per node (what a packet copies from its source)
     // device-resident receiver table of this partition (SoA, engine order = spatially sorted)
     DevBuf<double> d_rx_x, d_rx_y, d_rx_z, d_rx_rxprob;
     DevBuf<int32_t> d_rx_channel, d_rx_int_id, d_rx_orig, d_pos_of;
@@ -483,6 +488,9 @@ rm::HostView stage_view(char *base, uint32_t links, uint32_t packets, size_t *by
 rm::BatchCounts *stage_counts(char *base);
 int ensure_stage(rm_context *c, uint32_t links, uint32_t packets);
 int pack_to_stage(rm_context *c, TickSlot &ts, rm::HostView *view);
+// does this slot's result go to the host with ONE rssi per packet?  The reference's media hand the packet's transmit power to
+// every heard link unchanged; the log-distance medium computes a link's own (RM_HOST_LINK_RSSI=1 keeps the column for all)
+bool host_pkt_rssi(const rm_context *c, const TickSlot &ts);
 int stage_status(rm_context *c, const rm::HostView &v);
 int tick_run_host(rm_context *c);
 // The SINR medium's tick: the frames of earlier ticks that are still on the air stay resident on the device (the window

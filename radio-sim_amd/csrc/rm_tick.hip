@@ -122,12 +122,13 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
     if (build) { // RadioPacket(node, time, data) copies txpower / channel from its source, RadioPacket.java:46-52
         const bool pad = s_idx < 0 || s_idx >= nd.n;
         const int sc = pad ? 0 : s_idx;
-        tx.x = nd.sx[sc];
-        tx.y = nd.sy[sc];
-        tx.z = nd.sz[sc];
-        tx.txpower = nd.stxpower[sc];
-        tx.txprob = nd.stxprob[sc];
-        tx.channel = nd.schannel[sc];
+        const SrcRecord sr = nd.srec[sc]; // (one line of the source table, not six)
+        tx.x = sr.x;
+        tx.y = sr.y;
+        tx.z = sr.z;
+        tx.txpower = sr.txpower;
+        tx.txprob = sr.txprob;
+        tx.channel = sr.channel;
         tx.start_us = t.src_start_us;
         tx.air_us = t.src_air_us;
         tx.src = s_idx;
@@ -855,13 +856,15 @@ k_pack_frames(const ModelDev m, const TickDev t, int n_new, HostView v, uint32_t
             }
             const uint32_t src = t.seg_off[lo] + (o - s_off[lo]);
             v.dst[o] = t.a_dst[src];
-            v.rssi[o] = t.a_rssi[src];
+            if (v.rssi) v.rssi[o] = t.a_rssi[src]; // (nullptr: the packet's transmit power, once per packet below)
             v.verdict[o] = t.a_verdict[src];
             if (v.sinr != nullptr && t.out_sinr != nullptr) v.sinr[o] = t.a_sinr[src]; // (the SINR extension only)
         }
         for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < np; q += gridDim.x * 256u) {
             v.pkt_offset[q] = s_off[int(q) + t.shift];
-            v.pkt_interference[q] = (draws_possible && tx_success(m, t.tx[t.first_new + int(q)]) <= 0.0) ? 1 : 0;
+            const rm_tx_record txq = t.tx[t.first_new + int(q)];
+            v.pkt_interference[q] = (draws_possible && tx_success(m, txq) <= 0.0) ? 1 : 0;
+            if (!v.rssi) v.pkt_rssi[q] = txq.txpower;
             if (q + 1 == np) v.pkt_offset[np] = total;
         }
     }

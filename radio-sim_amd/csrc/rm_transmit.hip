@@ -102,11 +102,14 @@ k_pack_tick(TickDev t, int n_new, int have_offsets, HostView v, uint32_t *done_c
     for (uint32_t i = tid; i < n; i += step) {
         v.dst[i] = t.out_dst[i];
         v.verdict[i] = t.out_verdict[i];
-        v.rssi[i] = t.out_rssi[i];
+        if (v.rssi) v.rssi[i] = t.out_rssi[i];     // (nullptr: the packet's transmit power, once per packet below)
         if (t.out_sinr) v.sinr[i] = t.out_sinr[i]; // no SINR extension: no sinr column crosses the link (8 of 25 bytes)
     }
     const uint32_t np = min(uint32_t(max(n_new, 0)), v.packets);
-    for (uint32_t i = tid; i < np; i += step) v.pkt_interference[i] = t.pkt_interference[i];
+    for (uint32_t i = tid; i < np; i += step) {
+        v.pkt_interference[i] = t.pkt_interference[i];
+        if (!v.rssi) v.pkt_rssi[i] = t.tx[t.first_new + int(i)].txpower;
+    }
     for (uint32_t i = tid; i <= np; i += step) v.pkt_offset[i] = have_offsets ? t.slot_off[t.shift + i] : 0u;
     __shared__ uint32_t s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its stores, ...
@@ -156,11 +159,14 @@ k_pack_batch(const PackSlot *__restrict__ slots, int n_slots, HostView v, BatchC
         const uint32_t o = link_base + i;
         v.dst[o] = t.out_dst[i];
         v.verdict[o] = t.out_verdict[i];
-        v.rssi[o] = t.out_rssi[i];
+        if (v.rssi) v.rssi[o] = t.out_rssi[i];
         if (t.out_sinr) v.sinr[o] = t.out_sinr[i];
     }
     const uint32_t np = uint32_t(max(ps.n_new, 0));
-    for (uint32_t i = tid; i < np; i += step) v.pkt_interference[ps.pkt_base + i] = t.pkt_interference[i];
+    for (uint32_t i = tid; i < np; i += step) {
+        v.pkt_interference[ps.pkt_base + i] = t.pkt_interference[i];
+        if (!v.rssi) v.pkt_rssi[ps.pkt_base + i] = t.tx[t.first_new + int(i)].txpower;
+    }
     for (uint32_t i = tid; i <= np; i += step) v.pkt_offset[ps.pkt_base + uint32_t(b) + i] = ps.have_offsets ? t.slot_off[t.shift + i] : 0u;
     if (tid == 0) {
         BatchCounts c{};

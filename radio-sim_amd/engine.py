@@ -48,6 +48,7 @@ class HostTickView:
         self.count = r.count
         self._n_packets = r.n_packets
         self._ptr = {k: getattr(r, v[0]) for k, v in self._FIELDS.items()}
+        self._pkt_rssi = r.pkt_rssi   # (ABI version 5) the reference's media: one rssi per packet, no per-link column
 
     def __getattr__(self, name):
         spec = HostTickView._FIELDS.get(name)
@@ -58,6 +59,9 @@ class HostTickView:
         if name == "pkt" and not p:   # (the block carries no packet column since ABI version 3: it follows from the offsets)
             off = self.pkt_offset.astype(np.int64)
             a = np.repeat(np.arange(self._n_packets, dtype=np.int32), np.diff(off))[:n]
+        elif name == "rssi" and not p:   # (one value per packet crossed the link: a link's rssi is its packet's transmit power)
+            per_pkt = _wrap(self._pkt_rssi, np.float64, self._n_packets) if self._n_packets else np.zeros(0)
+            a = np.repeat(per_pkt, np.diff(self.pkt_offset.astype(np.int64)))[:n]
         else:
             a = np.zeros(n) if (name == "sinr" and not p) else _wrap(p, spec[1], n)
         setattr(self, name, a)
@@ -475,6 +479,12 @@ class Engine:
                                            poff.ctypes.data))
         k = cnt.value
         return TickResult(k, pkt[:k], dst[:k], verdict[:k], rssi[:k], sinr[:k], pint[:n_new], poff)
+
+    def result_dense(self):
+        """rm_result_dense: the dense tick's heard links as lane masks per (packet, 1024 nodes) cell -- device pointers"""
+        r = _lib.DenseResult()
+        check(self._L.rm_result_dense(self._h, C.byref(r)))
+        return r
 
     def result_device(self):
         r = DeviceResult()

@@ -433,8 +433,10 @@ public:
             if (kind_ != RM_MODEL_UDGM_CONST) sim->generateTransmissionEvents(packet);
             for (uint32_t i = r.pkt_offset[k]; i < r.pkt_offset[k + 1]; ++i) {
                 Node *node = nodes[size_t(r.dst[i])];
-                if (kind_ == RM_MODEL_UDGM_CONST) sim->deliverRadioPacket(packet, node, r.rssi[i]);
-                else sim->generateReceptionEvents(packet, node, r.rssi[i], r.verdict[i] == RM_DELIVERED);
+                // (the reference's media hand the packet's transmit power through -- UDGMRadioMedium.java:95 --: one value per packet)
+                const double rssi = r.rssi ? r.rssi[i] : r.pkt_rssi[k];
+                if (kind_ == RM_MODEL_UDGM_CONST) sim->deliverRadioPacket(packet, node, rssi);
+                else sim->generateReceptionEvents(packet, node, rssi, r.verdict[i] == RM_DELIVERED);
             }
         }
     }

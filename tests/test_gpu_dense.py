@@ -131,3 +131,49 @@ def test_dense_tick_on_index_partitions_padding_and_capacity(rsa, O):
         assert e.value.code == -4
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("kind,params", [("null", {}), ("udgm", {"udgm_transmission_range": 400.0})])
+def test_the_masks_are_the_result_and_the_records_come_on_request(rsa, O, kind, params, monkeypatch):
+    """rm_result_dense (ABI version 5): the dense tick ends with its cells -- per (packet, 1024 consecutive nodes) sixteen lane masks
+    and a count; the 17-byte records are written when somebody asks (rm_result_copy here), and are what RM_DENSE_LAZY=0 -- the
+    records at once, as before -- gives.  The masks decoded on the host are the oracle's heard sets, packet by packet."""
+    n, t = 20_000, 64
+    nd, rng = _nodes(O, n, 250.0, 9, channels=(26, 26, 11))
+    srcs = np.sort(rng.choice(n, t, replace=False)).astype(np.int32)
+    pk = nd.packets(srcs, 0, 8128)
+    cpu = O.tick_mt(oracle_model(O, kind, params), nd, pk, cap=1 << 22)
+    eng = rsa.Engine(0)
+    d = DeviceArray(srcs)
+    try:
+        configure_engine(eng, nd, kind, params)
+        eng.set_link_capacity(1 << 22)
+        eng.tick_run_sources_device(0, 1000, d.ptr.value, t, 0, 8128)
+        heard, dropped = eng.result_count()            # the totals do not wait for the records
+        assert heard == cpu.count and not dropped
+        r = eng.result_dense()
+        assert r.n_packets == t and r.chunks == -(-n // 1024) and r.rx_first == 0
+        masks = DeviceArray.read(r.cell_mask, np.uint64, t * r.chunks * 16).reshape(t, r.chunks * 16)
+        counts = DeviceArray.read(r.cell_count, np.uint32, t * r.chunks).reshape(t, r.chunks)
+        off = DeviceArray.read(r.pkt_offset, np.uint32, t + 1)
+        bits = np.unpackbits(masks.view(np.uint8).reshape(t, -1), axis=1, bitorder="little")[:, :n]
+        np.testing.assert_array_equal(bits.sum(axis=1), np.bincount(cpu.pkt, minlength=t))
+        np.testing.assert_array_equal(counts.sum(axis=1), np.bincount(cpu.pkt, minlength=t))
+        np.testing.assert_array_equal(off, np.concatenate([[0], np.cumsum(np.bincount(cpu.pkt, minlength=t))]))
+        q, j = np.nonzero(bits)
+        np.testing.assert_array_equal(q, cpu.pkt)
+        np.testing.assert_array_equal(j, cpu.dst)
+        lazy = eng.result_copy(t, cap=1 << 22)         # ... and now the records
+        assert_same(lazy, cpu, kind + " records on request")
+        monkeypatch.setenv("RM_DENSE_LAZY", "0")
+        eng.tick_run_sources_device(1000, 2000, d.ptr.value, t, 1000, 8128)
+        assert_same(eng.result_copy(t, cap=1 << 22), cpu, kind + " records at once")
+        monkeypatch.delenv("RM_DENSE_LAZY")
+        # a tick that takes another form has no masks to hand out
+        configure_engine(eng, nd, "logdist", {})
+        eng.tick_run_sources_device(2000, 3000, d.ptr.value, t, 2000, 8128)
+        with pytest.raises(rsa.RadioMediumError):
+            eng.result_dense()
+    finally:
+        d.free()
+        eng.close()
