@@ -193,7 +193,7 @@ def kernel_table(kernels, n_samples, own):
 
 
 def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_per_launch, step_s, contexts, workload, pmc_ok=True,
-                    tick_key=False, pairs_per_launch=0, under_profiler=None, alone=None, sinr_column=False, tile_reuse=1):
+                    tick_key=False, pairs_per_launch=0, under_profiler=None, alone=None, sinr_column=False, tile_reuse=1, required=None):
     """The result line's `roofline`, for the DOMINANT kernel of a launch sequence:
 
       achieved = bytes of ONE launch sequence / the dominant kernel's average duration, frac = achieved / 8 TB/s.
@@ -215,7 +215,7 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
     the same sequences with and without probes)."""
     b_tick = n_loc * S_NODE + t_per_tick * S_TX + heard * S_REC
     b_launch = b_tick * ticks_per_launch
-    b_req = required_bytes(n_loc, t_per_tick, heard, ticks_per_launch, sinr_column, tile_reuse)
+    b_req = required_bytes(n_loc, t_per_tick, heard, ticks_per_launch, sinr_column, tile_reuse) if required is None else int(required[0])
     rec_w = 17 if not sinr_column else 25
     own = {"filter": (n_loc * 16 // max(1, tile_reuse) + t_per_tick * 28 + cand * 12) * ticks_per_launch,
            "exact": (cand * 44 + heard * 13) * ticks_per_launch,
@@ -257,7 +257,8 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
                                 "rocprofv3 --kernel-trace reports",
           "launches_sampled": (src["n_samples"] if src else n_samples),
           "required_bytes_per_launch": b_req,
-          "required_bytes": "(N_loc*37/%d + T*56 + H*%d) x %d ticks: 8(d) for this launch shape (%s; a receiver tile is fetched once per %d "
+          "required_bytes": required[1] if required is not None else
+                            "(N_loc*37/%d + T*56 + H*%d) x %d ticks: 8(d) for this launch shape (%s; a receiver tile is fetched once per %d "
                             "ticks of the launch)" % (max(1, tile_reuse), rec_w, ticks_per_launch,
                                                       "25-byte records" if sinr_column else "17-byte records: no sinr column without the SINR extension",
                                                       max(1, tile_reuse)),
@@ -583,12 +584,14 @@ def host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick
 def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
     """Layouts the spatial cull cannot help: 20k nodes, 200 frames per tick, every frame heard by every node -- the reference
     UDGM medium with a range beyond the square's diagonal, and the reference's DEFAULT medium (NullRadioMedium.java:47-77:
-    every same-channel node hears everything).  4 M heard links per tick are evaluated in node order, compacted and written
-    (rm_dense.hip); one tick at a time.  The roofline is the record-writing one: SURVEY.md 8(d)'s bytes of the tick
-    (N*37 + T*56 + H*25) over the kernels' own time."""
+    every same-channel node hears everything).  4 M heard links per tick are evaluated in node order (rm_dense.hip), one tick at a
+    time.  Two legs per medium: the tick as it ends by default -- the heard links as lane masks per (frame, 1024 nodes) cell, which
+    IS the result of such a medium (rm_result_dense: a link's rssi and verdict are its packet's) -- and, `_records`, the same tick
+    with its 17-byte records written out every time (RM_DENSE_LAZY=0: 68 MB of record writes per tick)."""
     out = {}
     nodes = W.make_nodes(n, 3)
     side = W.side_length(n)
+    chunks = -(-n // 1024)
     for name, kind, kw in (("udgm_everyone_in_range", rsa.MODEL_UDGM, dict(udgm_transmission_range=float(side * 1.5))),
                            ("null_medium", rsa.MODEL_NULL, {})):
         e = rsa.Engine(device_ordinal)
@@ -601,42 +604,56 @@ def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
         with torch.cuda.stream(st):
             src_dev = torch.from_numpy(np.stack(srcs)).to(dev)
             st.synchronize()
-            calls = [e.prepared("rm_tick_run_sources_device", k * 1000, k * 1000 + 1000, ctypes.c_void_p(src_dev[k % 4].data_ptr()), t, k * 1000,
-                                W.AIR_US) for k in range(ticks)]   # (the arguments converted once: the loop times the engine, not the binding)
-            for k in range(3):
-                calls[k]()
-            heard, dropped = e.result_count()
-            st.synchronize()
-            e.profile_enable(4)
-            t0 = time.perf_counter()
-            for call in calls:
-                call()
-            st.synchronize()
-            el = time.perf_counter() - t0
-            heard, dropped = e.result_count()
-        n_samples, _ = e.profile_read()
-        kernels = {nm: {"launches": l, "ms": ms, "stage": sg} for nm, (l, ms, sg) in e.profile_kernels().items()}
-        e.profile_enable(0)
-        with torch.cuda.stream(st):
-            alone = probe_pass(e, st.synchronize, calls[:16])
+            ticks_only = [e.prepared("rm_tick_run_sources_device", k * 1000, k * 1000 + 1000, ctypes.c_void_p(src_dev[k % 4].data_ptr()), t, k * 1000,
+                                     W.AIR_US) for k in range(ticks)]   # (the arguments converted once: the loop times the engine, not the binding)
+            for leg, calls in (("", ticks_only), ("_records", ticks_only)):
+                # (the records at once: RM_DENSE_LAZY=0 is read per tick -- the write pass is then one of the tick's own launches)
+                if leg:
+                    os.environ["RM_DENSE_LAZY"] = "0"
+                else:
+                    os.environ.pop("RM_DENSE_LAZY", None)
+                for k in range(3):
+                    calls[k]()
+                heard, dropped = e.result_count()
+                st.synchronize()
+                e.profile_enable(4)
+                t0 = time.perf_counter()
+                for call in calls:
+                    call()
+                st.synchronize()
+                el = time.perf_counter() - t0
+                heard, dropped = e.result_count()
+                n_samples, _ = e.profile_read()
+                kernels = {nm: {"launches": l, "ms": ms, "stage": sg} for nm, (l, ms, sg) in e.profile_kernels().items()}
+                e.profile_enable(0)
+                alone = probe_pass(e, st.synchronize, calls[:16])
+                per_tick = el / ticks
+                if leg == "":   # node columns in, lane masks + counts + packet offsets out
+                    req = (n * S_NODE + t * S_TX + t * chunks * (16 * 8 + 4) + (t + 1) * 4,
+                           "N*37 + T*56 in, T x %d cells x (16 lane masks + a count) + the packets' offsets out: the dense tick's own result "
+                           "(rm_result_dense); the records are not written" % chunks)
+                else:
+                    req = (n * S_NODE + t * S_TX + heard * (S_REC - 8), "N*37 + T*56 + H*17: 8(d) with 17-byte records (no sinr column)")
+                rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t, heard=heard, cand=0, ticks_per_launch=1,
+                                     step_s=per_tick, contexts=1, workload="dense_" + name, pmc_ok=False, alone=alone, required=req)
+                if leg == "_records":
+                    try:    # the counter passes on file for this shape (the count pass per medium, the write pass of both)
+                        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("dense", {})
+                        parts = [pmc.get("k_dense_count_" + ("null" if name == "null_medium" else "udgm")), pmc.get("k_dense_write")]
+                        if all(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in parts):
+                            rl["traffic"] = int(sum(v["hbm_bytes_per_launch"] for v in parts))
+                            rl["traffic_over_required"] = rl["traffic"] / rl["required_bytes_per_launch"]
+                            rl["traffic_source"] = ("profiles/pmc_traffic.json ('dense', commit %s): FETCH_SIZE / WRITE_SIZE passes of bench.py "
+                                                    "--dense-only, count + write kernels of one tick; from_profile_file" % pmc.get("commit"))
+                    except (OSError, ValueError):
+                        pass
+                out[name + leg] = {"workload": "20k nodes, 200 frames per tick, every frame heard by every node (nothing to cull): " + name +
+                                               (" -- records written every tick" if leg else " -- lane masks (rm_result_dense)"),
+                                   "nodes": n, "tx_per_tick": t, "heard_links_per_tick": int(heard), "ms_per_tick": per_tick * 1e3,
+                                   "value": t * (n - 1) / per_tick, "unit": "links/s",
+                                   "record_bytes_per_s": (heard * (S_REC - 8) / per_tick) if leg else None, "roofline": rl, "dropped": bool(dropped)}
+            os.environ.pop("RM_DENSE_LAZY", None)
         e.close()
-        per_tick = el / ticks
-        rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t, heard=heard, cand=0, ticks_per_launch=1,
-                             step_s=per_tick, contexts=1, workload="dense_" + name, pmc_ok=False, alone=alone)
-        try:    # the counter passes on file for this shape (profiles/r04_dense_pmc.csv: the count pass per medium, the write pass of both)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("dense", {})
-            parts = [pmc.get("k_dense_count_" + ("null" if name == "null_medium" else "udgm")), pmc.get("k_dense_write")]
-            if all(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in parts):
-                rl["traffic"] = int(sum(v["hbm_bytes_per_launch"] for v in parts))
-                rl["traffic_over_required"] = rl["traffic"] / rl["required_bytes_per_launch"]
-                rl["traffic_source"] = ("profiles/pmc_traffic.json ('dense', commit %s): FETCH_SIZE / WRITE_SIZE passes of bench.py --dense-only, "
-                                        "count + write kernels of one tick; from_profile_file" % pmc.get("commit"))
-        except (OSError, ValueError):
-            pass
-        out[name] = {"workload": "20k nodes, 200 frames per tick, every frame heard by every node (nothing to cull): " + name, "nodes": n,
-                     "tx_per_tick": t, "heard_links_per_tick": int(heard), "ms_per_tick": per_tick * 1e3,
-                     "value": t * (n - 1) / per_tick, "unit": "links/s", "record_bytes_per_s": heard * S_REC / per_tick,
-                     "roofline": rl, "dropped": bool(dropped)}
     return out
 
 

@@ -49,7 +49,12 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <deque>
 #include <unordered_map>
@@ -69,6 +74,93 @@ using emul8::RadioPacket;
 static bool g_verbose = false;
 #define VLOG(...) do { if (g_verbose) { std::fprintf(stderr, __VA_ARGS__); std::fputc('\n', stderr); } } while (0)
 
+// The reference serialises on a thread per connection (net/JSONClientConnection.java:118-131: every connection's reader thread
+// writes its own replies).  Here one thread owns the protocol state, and the two jobs whose volume grows with the simulation --
+// rewriting the changed nodes' node-info objects, writing a step's receive messages -- are cut into independent parts and
+// handed to a few workers: run(parts, fn) calls fn(part) for every part on the pool (the caller takes parts too) and returns
+// when all are done.  Nothing else runs while a job does: the workers touch only what their part owns.
+class Workers {
+public:
+    explicit Workers(unsigned n)
+    {
+        for (unsigned i = 0; i + 1 < n; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    ~Workers()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    unsigned size() const { return unsigned(threads_.size()) + 1; }
+    void run(unsigned parts, const std::function<void(unsigned)> &fn)
+    {
+        if (parts == 0) return;
+        if (threads_.empty() || parts == 1) {
+            for (unsigned p = 0; p < parts; ++p) fn(p);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            parts_ = parts;
+            next_.store(0);
+            left_.store(parts);
+            ++job_;
+        }
+        cv_.notify_all();
+        take();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_.load() == 0 && busy_ == 0; }); // (no worker is still looking at this job when the next is posted)
+        fn_ = nullptr;
+    }
+
+private:
+    void take()
+    {
+        for (;;) {
+            const unsigned p = next_.fetch_add(1);
+            if (p >= parts_) return;
+            (*fn_)(p);
+            if (left_.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> g(m_);
+                done_.notify_all();
+            }
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || job_ != seen; });
+                if (quit_) return;
+                seen = job_;
+                if (fn_ == nullptr) continue; // (the job was over before this worker woke)
+                ++busy_;
+            }
+            take();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                --busy_;
+            }
+            done_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned parts_ = 0;
+    std::atomic<unsigned> next_{0}, left_{0};
+    uint64_t job_ = 0;
+    unsigned busy_ = 0;
+    bool quit_ = false;
+};
+
 // net/ClientConnection.java + net/JSONClientConnection.java: one peer
 struct Connection {
     int fd = -1;
@@ -81,8 +173,20 @@ struct Connection {
     int depth = 0;                          // JsonText: open braces
     std::string text;                       // bytes of the unit being read
     int64_t payloadLeft = 0;                // SizedPayload: bytes still to come
-    // pending output
+    // pending output: `out`, and behind ALL of it the bulk segments -- a step's receive messages as the workers wrote them, one
+    // string per worker and connection, sent where they lie (joining them into `out` would copy 13 MB a step at the BASELINE size)
     std::string out;
+    std::deque<std::string> bulk;
+    size_t bulkOff = 0;        // bytes of bulk.front() already sent
+    size_t bulkBytes = 0;      // unsent bytes in the bulk segments
+    std::string &tail() { return bulk.empty() ? out : bulk.back(); } // where the next message is appended
+    void noteTail(size_t before) { if (!bulk.empty()) bulkBytes += bulk.back().size() - before; }
+    void settleBulk() // the bulk segments' unsent rest becomes ordinary output (something has to go out BEHIND `out` but before them: never, normally)
+    {
+        for (size_t i = 0; i < bulk.size(); ++i) out.append(bulk[i], i == 0 ? bulkOff : 0, std::string::npos);
+        bulk.clear();
+        bulkOff = bulkBytes = 0;
+    }
     uint64_t messagesIn = 0, messagesOut = 0;
     // The node-info array of this emulator's time-step messages as it was sent last: the nodes' objects joined by commas, kept
     // in pieces of kInfoPiece nodes (every piece but the first begins with the comma that joins it to the one before).  A
@@ -105,7 +209,7 @@ struct Connection {
     std::string stepHead;
     static const char *stepTail() { return "]}}\r\n"; }
     size_t stepLen() const { return stepHead.size() + infoBytes + 5; }
-    size_t pending() const { return out.size() + (stepMark == kNoStep ? 0 : stepLen() - stepOff); }
+    size_t pending() const { return out.size() + (stepMark == kNoStep ? 0 : stepLen() - stepOff) + bulkBytes; }
     // the unsent part of the step message as (pointer, length) runs, at most `max_runs` of them
     template <class F> void stepRuns(F &&run, size_t max_runs) const
     {
@@ -148,17 +252,21 @@ struct Connection {
     bool send(const Json &json) // :261-287 (useLength = false)
     {
         if (fd < 0) return false; // output == null after close()
-        json.append_to(out);
-        out += "\r\n";
+        std::string &o = tail();
+        const size_t before = o.size();
+        json.append_to(o);
+        o += "\r\n";
+        noteTail(before);
         ++messagesOut;
         return true;
     }
     // the same for a message whose minimal JSON text the caller has written itself (the per-node and per-delivery
     // messages: no object tree for a hundred thousand node-infos)
     bool open() const { return fd >= 0; }
-    void sent()
+    void sent(size_t before) // (a message written straight into tail(), which was `before` bytes long)
     {
-        out += "\r\n";
+        tail() += "\r\n";
+        noteTail(before);
         ++messagesOut;
     }
 };
@@ -185,6 +293,10 @@ public:
             sim_.addRadioListener(pcap_.get());
         }
         if (!opt_.noMedium) setMedium(new emul8::NullRadioMedium(opt_.device)); // Main.java:67-71
+        unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = std::getenv("RSIM_SERVER_THREADS")) threads = unsigned(std::max(1, std::atoi(e)));
+        if (threads > 1) workers_.reset(new Workers(threads));
+        if (const char *e = std::getenv("RSIM_PARALLEL_FROM")) kParallelFrom = size_t(std::max(1, std::atoi(e)));
     }
 
     int listenOn()
@@ -309,6 +421,12 @@ private:
                     // (the rest of `out` only behind the WHOLE of the message's rest: a long array takes several calls)
                     if (runs_len == c.stepLen() - c.stepOff) add(c.out.data() + before, c.out.size() - before);
                 }
+                // the bulk segments: only behind the WHOLE of what precedes them
+                size_t ahead = 0;
+                for (int k = 0; k < ni; ++k) ahead += iov[k].iov_len;
+                if (ahead == c.pending() - c.bulkBytes)
+                    for (size_t k = 0; k < c.bulk.size() && ni < kIov; ++k)
+                        add(c.bulk[k].data() + (k == 0 ? c.bulkOff : 0), c.bulk[k].size() - (k == 0 ? c.bulkOff : 0));
                 msghdr mh{};
                 mh.msg_iov = iov;
                 mh.msg_iovlen = size_t(ni);
@@ -327,7 +445,19 @@ private:
                             c.stepMark = Connection::kNoStep;
                             c.stepOff = 0;
                         }
-                        c.out.erase(0, left);
+                        const size_t b = std::min(left, c.out.size());
+                        c.out.erase(0, b);
+                        left -= b;
+                    }
+                    while (left > 0 && !c.bulk.empty()) { // what went out of the bulk segments
+                        const size_t have = c.bulk.front().size() - c.bulkOff, took = std::min(left, have);
+                        c.bulkOff += took;
+                        c.bulkBytes -= took;
+                        left -= took;
+                        if (took == have) {
+                            c.bulk.pop_front();
+                            c.bulkOff = 0;
+                        }
                     }
                     continue;
                 }
@@ -340,6 +470,8 @@ private:
                 std::fprintf(stderr, "%s: %zu bytes unsent, peer not reading: closing\n", c.name.c_str(), c.pending());
                 c.stepMark = Connection::kNoStep;
                 c.out.clear();
+                c.bulk.clear();
+                c.bulkOff = c.bulkBytes = 0;
                 close(c);
             }
         }
@@ -349,6 +481,7 @@ private:
     {
         if (c.fd >= 0) {
             c.settleStep();
+            c.settleBulk();
             if (!c.out.empty()) { // what was already "written" in the reference's blocking send: one bounded attempt
                 const timeval tv{0, 200 * 1000};   // (a peer that does not read must not stall the poll loop)
                 ::setsockopt(c.fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
@@ -606,7 +739,9 @@ private:
         c->infoLen.push_back(uint16_t(piece.size() - at));
         c->infoBytes += piece.size() - size0;
     }
-    void applyNodeInfo(int32_t index, const Info &v)
+    // rewrites the node's fields where they lie in its piece; returns by how much the piece's length changed (the caller keeps the
+    // connection's infoBytes: pieces are rewritten by several workers at once, each piece by one of them)
+    long applyNodeInfo(int32_t index, const Info &v)
     {
         const NodeText &t = nodeText_[size_t(index)];
         Connection &c = *t.conn;
@@ -616,13 +751,48 @@ private:
         const size_t at = size_t(c.infoAt[t.slot]) + c.infoHead[t.slot], before = size_t(c.infoLen[t.slot]) - c.infoHead[t.slot];
         if (len == before) { // same length: in place
             std::memcpy(&piece[at], buf, len);
-            return;
+            return 0;
         }
         piece.replace(at, before, buf, len);
         const size_t last = std::min(c.infoNodes.size(), (t.slot / Connection::kInfoPiece + 1) * Connection::kInfoPiece);
         for (size_t k = size_t(t.slot) + 1; k < last; ++k) c.infoAt[k] = uint32_t(c.infoAt[k] + len - before);
         c.infoLen[t.slot] = uint16_t(c.infoHead[t.slot] + len);
-        c.infoBytes = c.infoBytes + len - before;
+        return long(len) - long(before);
+    }
+    // the changed nodes' objects, rewritten by the workers: a piece (64 objects) belongs to ONE worker, so the changes are first
+    // dealt to their pieces' owners (every worker deals its share of the list), then every owner rewrites what it was dealt
+    void applyNodeInfoParallel(const std::vector<int32_t> &idx, const std::vector<double> &rssi, const std::vector<int32_t> &recv,
+                               const std::vector<int32_t> &chan)
+    {
+        const unsigned T = workers_->size();
+        const size_t n = idx.size();
+        dealt_.resize(size_t(T) * T);
+        for (auto &d : dealt_) d.clear();
+        workers_->run(T, [&](unsigned t) {
+            const size_t k0 = n * t / T, k1 = n * (t + 1) / T;
+            for (size_t k = k0; k < k1; ++k) {
+                if (size_t(idx[k]) >= nodeText_.size()) continue;
+                const NodeText &nt = nodeText_[size_t(idx[k])];
+                if (!nt.conn) continue;
+                const size_t piece = nt.slot / Connection::kInfoPiece;
+                const unsigned owner = unsigned((piece + (reinterpret_cast<uintptr_t>(nt.conn) >> 6)) % T);
+                dealt_[size_t(t) * T + owner].push_back(uint32_t(k));
+            }
+        });
+        std::vector<std::vector<std::pair<Connection *, long>>> grown(T);
+        workers_->run(T, [&](unsigned owner) {
+            auto &mine = grown[owner];
+            for (unsigned from = 0; from < T; ++from)
+                for (uint32_t k : dealt_[size_t(from) * T + owner]) {
+                    const long d = applyNodeInfo(idx[k], {rssi[k], recv[k], chan[k]});
+                    if (d == 0) continue;
+                    Connection *c = nodeText_[size_t(idx[k])].conn;
+                    if (mine.empty() || mine.back().first != c) mine.emplace_back(c, 0L);
+                    mine.back().second += d;
+                }
+        });
+        for (const auto &g : grown)
+            for (const auto &cd : g) cd.first->infoBytes = size_t(long(cd.first->infoBytes) + cd.second);
     }
     // once per step, before the time-step messages: bring the nodes' texts up to the device's radio state
     void refreshNodeInfo()
@@ -634,14 +804,24 @@ private:
                 mediumError("node-info");
                 throw std::runtime_error("node-info failed");
             }
-            for (size_t k = 0; k < idx.size(); ++k)
-                if (size_t(idx[k]) < nodeText_.size() && nodeText_[size_t(idx[k])].conn) applyNodeInfo(idx[k], {rssi[k], recv[k], chan[k]});
+            if (workers_ && idx.size() >= kParallelFrom) {
+                applyNodeInfoParallel(idx, rssi, recv, chan);
+            } else {
+                for (size_t k = 0; k < idx.size(); ++k)
+                    if (size_t(idx[k]) < nodeText_.size() && nodeText_[size_t(idx[k])].conn) {
+                        Connection *c = nodeText_[size_t(idx[k])].conn;
+                        c->infoBytes = size_t(long(c->infoBytes) + applyNodeInfo(idx[k], {rssi[k], recv[k], chan[k]}));
+                    }
+            }
             nodeInfoChanges_ += idx.size();
             if (stepMessages_ > 0) nodeInfoChangesLater_ += idx.size();
         } else { // no medium: nothing ever starts a reception, the host's radios are the state
             for (Node *n : sim_.getNodes())
-                if (size_t(n->index) < nodeText_.size() && nodeText_[size_t(n->index)].conn)
-                    applyNodeInfo(n->index, {n->getRadio().getRSSI(), n->getRadio().getReceivingState(), n->getRadio().getWirelessChannel()});
+                if (size_t(n->index) < nodeText_.size() && nodeText_[size_t(n->index)].conn) {
+                    Connection *c = nodeText_[size_t(n->index)].conn;
+                    c->infoBytes = size_t(long(c->infoBytes) + applyNodeInfo(n->index, {n->getRadio().getRSSI(), n->getRadio().getReceivingState(),
+                                                                                            n->getRadio().getWirelessChannel()}));
+                }
         }
     }
     void emulateToTime(Connection &c, int64_t time, int64_t timeId) // JSONClientConnection.java:326-353
@@ -655,6 +835,7 @@ private:
         o += ",\"parameters\":{\"time\":";
         append_int(o, time);
         o += ",\"node-info\":[";
+        c.settleBulk(); // (receive messages of the step before that the peer has not taken yet go out first)
         c.stepMark = c.out.size();
         c.stepOff = 0;
         ++c.messagesOut;
@@ -697,15 +878,56 @@ private:
         sim_.emulatorTimeStepDone(stepTime_);
         mediumError("time step");
         const auto t1 = std::chrono::steady_clock::now();
-        framedPacket_ = nullptr;
-        for (const emul8::MediumCall &call : sim_.calls)
-            if (call.kind == emul8::MediumCall::DELIVER) deliverRadioPacket(*call.packet, *call.destination, call.rssi);
+        framed_ = Framed();
+        if (workers_ && sim_.calls.size() >= kParallelFrom) {
+            deliverParallel(sim_.calls);
+        } else {
+            for (const emul8::MediumCall &call : sim_.calls)
+                if (call.kind == emul8::MediumCall::DELIVER) deliverRadioPacket(*call.packet, *call.destination, call.rssi);
+        }
         sim_.calls.clear();
         usMedium_ += std::chrono::duration<double, std::micro>(t1 - t0).count();
         usReceiveMessages_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         ++steps_;
         prunePackets();
         if (timeController_) timeController_->send(Json::object().add("reply", Json::of("OK")).add("id", Json::of(timeControllerLastTimeId_)));
+    }
+    // RadioPacket.toJsonDestination, written directly (tens of thousands per tick).  The deliveries of one packet come one after
+    // the other, and all but the receiver and its rssi is the packet's: that text is put together once per packet; the rssi's
+    // digits are kept while it stays the same (the reference's media hand the packet's transmit power to every receiver).
+    struct Framed {
+        const RadioPacket *packet = nullptr;
+        std::string head, tail, rssiText;
+        double rssi = 0;
+        bool haveRssi = false;
+    };
+    void writeReceive(std::string &o, const RadioPacket &p, const Node &dst, double rssi, Framed &f) const
+    {
+        if (&p != f.packet) {
+            f.packet = &p;
+            f.head.assign(",\"time-start\":");
+            append_int(f.head, p.getStartTime());
+            f.head += ",\"time-end\":";
+            append_int(f.head, p.getEndTime());
+            f.head += ",\"rf-power\":";
+            f.tail.assign(",\"wireless-channel\":");
+            append_int(f.tail, p.getWirelessChannel());
+            f.tail += ",\"packet-data\":";
+            Json::quote(p.getPacketDataAsHex(), f.tail);
+            f.tail += "}\r\n";
+        }
+        if (!f.haveRssi || std::memcmp(&rssi, &f.rssi, sizeof(double)) != 0) {
+            f.rssi = rssi;
+            f.haveRssi = true;
+            f.rssiText.clear();
+            append_double(f.rssiText, rssi);
+        }
+        o += "{\"command\":\"receive\",\"node-id\":";
+        if (size_t(dst.index) < nodeText_.size() && !nodeText_[size_t(dst.index)].quotedId.empty()) o += nodeText_[size_t(dst.index)].quotedId;
+        else Json::quote(dst.getId(), o);
+        o += f.head;
+        o += f.rssiText;
+        o += f.tail;
     }
     void deliverRadioPacket(const RadioPacket &p, Node &dst, double rssi) // :356-364 + RadioPacket.toJsonDestination
     {
@@ -714,30 +936,57 @@ private:
             VLOG("Node %s has no client connection", dst.getId().c_str());
             return;
         }
-        // RadioPacket.toJsonDestination, written directly (tens of thousands per tick).  The deliveries of one packet come one
-        // after the other, and all but the receiver and its rssi is the packet's: that text is put together once per packet.
-        if (&p != framedPacket_) {
-            framedPacket_ = &p;
-            framedHead_.assign(",\"time-start\":");
-            append_int(framedHead_, p.getStartTime());
-            framedHead_ += ",\"time-end\":";
-            append_int(framedHead_, p.getEndTime());
-            framedHead_ += ",\"rf-power\":";
-            framedTail_.assign(",\"wireless-channel\":");
-            append_int(framedTail_, p.getWirelessChannel());
-            framedTail_ += ",\"packet-data\":";
-            Json::quote(p.getPacketDataAsHex(), framedTail_);
-            framedTail_ += '}';
-        }
-        std::string &o = cc->out;
-        o += "{\"command\":\"receive\",\"node-id\":";
-        if (size_t(dst.index) < nodeText_.size() && !nodeText_[size_t(dst.index)].quotedId.empty()) o += nodeText_[size_t(dst.index)].quotedId;
-        else Json::quote(dst.getId(), o);
-        o += framedHead_;
-        append_double(o, rssi);
-        o += framedTail_;
-        cc->sent();
+        std::string &o = cc->tail();
+        const size_t before = o.size();
+        writeReceive(o, p, dst, rssi, framed_);
+        cc->noteTail(before);
+        ++cc->messagesOut;
         ++deliveries_;
+    }
+    // a step's deliveries written by the workers: contiguous shares of the call list, each into its own string per connection;
+    // the strings join their connections' output as segments, in the order of the shares -- a connection's messages stay in the
+    // queue's pop order, and nothing is copied a second time
+    void deliverParallel(const std::vector<emul8::MediumCall> &calls)
+    {
+        const unsigned T = workers_->size();
+        struct Share {
+            std::vector<std::pair<Connection *, std::string>> per;
+            std::vector<uint64_t> count;
+        };
+        std::vector<Share> shares(T);
+        const size_t n = calls.size();
+        workers_->run(T, [&](unsigned t) {
+            Share &sh = shares[t];
+            Framed f;
+            Connection *last = nullptr;
+            size_t lastAt = 0;
+            for (size_t k = n * t / T; k < n * (t + 1) / T; ++k) {
+                const emul8::MediumCall &call = calls[k];
+                if (call.kind != emul8::MediumCall::DELIVER) continue;
+                Connection *cc = connectionOf(call.destination);
+                if (!cc || !cc->connected) continue;
+                if (cc != last) {
+                    last = cc;
+                    for (lastAt = 0; lastAt < sh.per.size() && sh.per[lastAt].first != cc; ++lastAt) {}
+                    if (lastAt == sh.per.size()) {
+                        sh.per.emplace_back(cc, std::string());
+                        sh.per.back().second.reserve(size_t(420) * (n / T + 1) / std::max<size_t>(1, sh.per.size()));
+                        sh.count.push_back(0);
+                    }
+                }
+                writeReceive(sh.per[lastAt].second, *call.packet, *call.destination, call.rssi, f);
+                ++sh.count[lastAt];
+            }
+        });
+        for (Share &sh : shares)
+            for (size_t i = 0; i < sh.per.size(); ++i) {
+                Connection *cc = sh.per[i].first;
+                if (sh.per[i].second.empty()) continue;
+                cc->bulkBytes += sh.per[i].second.size();
+                cc->bulk.push_back(std::move(sh.per[i].second));
+                cc->messagesOut += sh.count[i];
+                deliveries_ += sh.count[i];
+            }
     }
     // The medium refers to a packet until its last event has fired, or until a failed evaluation dropped it; it
     // names the packets it has let go of (by identity -- counting from the front of a queue would free an older,
@@ -1055,8 +1304,11 @@ private:
     int64_t stepTime_ = 0, timeControllerLastTimeId_ = -1, waitingForTimeId_ = -1, messageId_ = 1000;
     uint64_t steps_ = 0, transmissions_ = 0, deliveries_ = 0;
     double usStepMessages_ = 0, usMedium_ = 0, usReceiveMessages_ = 0; // the server's own work per step (printStats)
-    const RadioPacket *framedPacket_ = nullptr; // deliverRadioPacket: the packet whose constant text is in framedHead_ / framedTail_
-    std::string framedHead_, framedTail_;
+    Framed framed_; // deliverRadioPacket: the packet whose constant text is at hand
+    // the workers (Workers above): RSIM_SERVER_THREADS, default min(hardware threads, 8); 1 = everything on the protocol's thread
+    std::unique_ptr<Workers> workers_;
+    size_t kParallelFrom = 2048; // changed nodes / medium calls of a step from which the workers are worth waking (RSIM_PARALLEL_FROM: tests)
+    std::vector<std::vector<uint32_t>> dealt_;    // applyNodeInfoParallel: [dealer][owner] -> places in the change list
     uint64_t stepMessages_ = 0, nodeInfoChangesLater_ = 0;
     double usFirstStepMessages_ = 0;
     uint64_t nodeInfoChanges_ = 0;     // node objects rewritten for time-step messages (the rest went out as they were)

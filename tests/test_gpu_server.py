@@ -39,12 +39,19 @@ def info_json(ident, rssi, state, channel):
 
 
 @pytest.mark.parametrize("model,mode", [("udgm", "tick"), ("udgm", "packet"), ("nullrm", "tick"), ("n2n-link", "tick"),
-                                        ("log-distance", "tick"), ("log-distance", "packet"), ("log-distance-sinr", "tick")])
+                                        ("log-distance", "tick"), ("log-distance", "packet"), ("log-distance-sinr", "tick"),
+                                        ("udgm", "tick-workers"), ("nullrm", "tick-workers"), ("log-distance", "tick-workers")])
 def test_server_end_to_end(O, model, mode):
     """`log-distance`: the engine's extension medium selected over the wire (the option string and its optional numeric
     parameters are the only additions to the protocol).  With "sinr": true the verdicts of the frames of one evaluation
     depend on each other, so the oracle evaluates what the server evaluates together: everything sent between two points
     where the server has to settle (a node-config-set, the end of the step), against the frames still on the air."""
+    # "tick-workers": the node-info rewrites and the receive messages of every step go through the server's worker threads
+    # (RSIM_PARALLEL_FROM=1: at the BASELINE sizes they do by themselves) -- every byte as before
+    env = dict(os.environ)
+    if mode == "tick-workers":
+        env.update(RSIM_PARALLEL_FROM="1", RSIM_SERVER_THREADS="4")
+        mode = "tick"
     sinr = model == "log-distance-sinr"
     n_reg = 90 if model != "n2n-link" else 24      # nodes registered before the first step
     late = model == "udgm"                         # one more node joins in mid-run (the node table grows under the medium)
@@ -75,7 +82,7 @@ def test_server_end_to_end(O, model, mode):
         mdl = O.model(KINDS["udgm" if model == "udgm" else "null"])
 
     args = [_build(), "--port", "0", "--bind", "127.0.0.1", "--seed", str(seed)] + (["--per-packet"] if mode == "packet" else [])
-    proc = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    proc = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     try:
         first = proc.stdout.readline()
         assert first.startswith("Server started."), first + proc.stderr.read()
