@@ -1162,7 +1162,7 @@ def main():
                                  ticks_per_launch=1, step_s=sequential["ms_per_tick"] * 1e-3, contexts=1, workload=args.workload,
                                  pmc_ok=(args.nodes == 0), tick_key=True, alone=seq_alone, sinr_column=sinr_column)
             rl["bound_note"] = ("latency: a lone tick of this size is a chain of dependent launches and memory round trips on a mostly idle "
-                                "device; neither HBM bytes nor issue slots bind it (DESIGN.md section 4.8)")
+                                "device; neither HBM bytes nor issue slots bind it (DESIGN.md section 4.7)")
             sequential["roofline"] = rl
 
         if rank == 0:

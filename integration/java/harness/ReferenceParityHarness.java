@@ -19,6 +19,19 @@
  *   java -cp '/tmp/h:build:lib/*' ReferenceParityHarness <repo>/tests/golden
  *
  * The scenarios of the build's own extension medium (logdist_*.npz) have no reference class and are skipped.
+ *
+ * Which scenarios would expose a JVM whose Math.pow(x, 2.0) is not x * x (tests/test_oracle_pow_ulp.py bounds what that may
+ * change when the result is off by the one ulp the specification allows; DESIGN.md section 2 has the table):
+ *   - NONE of the verdicts of udgm_default.npz and udgm_stochastic.npz (random positions: no distance is the range to the
+ *     last bit), and no probability there moves by more than 3.4e-16 relative -- a java.util.Random draw (steps of 2^-53)
+ *     would have to fall inside that sliver of p for a delivered / interfered flag to differ;
+ *   - exactly the receivers AT the range: const_lattice.npz exercises UDGMConstantLossRadioMedium (no pow, strict <), and
+ *     the UDGM boundary cases of the known-answer tests K2 / K3 (a receiver at (30, 40, 0) from a source at the origin, range
+ *     50 -- and every 3-4-5 / 14-48 lattice point of tests/test_gpu_parity.py::test_boundary_lattice) are heard
+ *     (UDGMRadioMedium.java:76: ratio > 1 is out, ratio == 1 is in) only if distanceSquared / distanceMaxSquared come out
+ *     exactly 2500: with distanceSquared one ulp up or distanceMaxSquared one ulp down all 20 such points of the lattice turn
+ *     unheard.  A run of this harness on a lattice scenario (add one with make_golden.py: integer offsets, range 50) is what
+ *     settles the assumption; the random-layout scenarios cannot.
  */
 import java.io.ByteArrayOutputStream;
 import java.io.File;

@@ -653,7 +653,9 @@ hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, 
     const dim3 grid2(min(int(grid.x), 256));
     if (sh) RM_KLAUNCH((k_ov_pairs<true, true>), grid2, block, 0, s, nd, m, ov);
     else RM_KLAUNCH((k_ov_pairs<false, true>), grid2, block, 0, s, nd, m, ov);
-    RM_KLAUNCH(k_ov_verdict, dim3(max(1, min(64, cdiv(max(max_links, 1), 256))), ov.n_ticks), dim3(256), 0, s, m, ov);
+    // (a receiver partition hears 1 / share of a tick's links: as many workgroups per tick would each find a handful)
+    const int share = (nd.n_rx > 0 && nd.n_rx < nd.n) ? max(1, nd.n / nd.n_rx) : 1;
+    RM_KLAUNCH(k_ov_verdict, dim3(max(1, min(max(4, 64 / share), cdiv(max(max_links, 1), 256))), ov.n_ticks), dim3(256), 0, s, m, ov);
     return hipGetLastError();
 }
 

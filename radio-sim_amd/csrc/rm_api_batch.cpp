@@ -166,7 +166,8 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
     }
     if (plans[0].sinr && ticks[0].acc_lo != nullptr) { // sums per receiver: sinr and verdict of every heard link, full lanes
         RM_TRY(stage(RM_STAGE_SINR));
-        RM_HIP(rm::launch_sinr_acc_batch(s, m, n, dev_ticks, int(std::min<uint32_t>(c->cap, 1u << 22))));
+        RM_HIP(rm::launch_sinr_acc_batch(s, m, n, dev_ticks, int(std::min<uint32_t>(c->cap, 1u << 22)),
+                                         (nd.n_rx > 0 && nd.n_rx < nd.n) ? std::max(1, nd.n / nd.n_rx) : 1));
     }
     RM_TRY(stage(RM_STAGE_REORDER));
     RM_HIP(rm::launch_batch_stage(s, 2, nd, m, ticks, n, dev_ticks, cfg));

@@ -112,15 +112,9 @@ RM_D rm_tx_record dense_frame(const NodesDev &nd, const TickDev &t, int q)
     return t.src_list ? make_tx_record(nd, t.src_list[q], t.src_start_us, t.src_air_us) : t.tx[t.first_new + q];
 }
 
-RM_D void dense_tick_tail(const ModelDev &m, const TickDev &t, int tid, int n_threads);
-RM_D void dense_tick_total(const TickDev &t, uint32_t total, int tid, int n_threads);
-
-// FINISH: the workgroup that is done last lays the cells out itself -- offsets, packet offsets, totals, what the next tick expects --
-// so that a tick whose records are left for whoever asks (launch_dense_tick: lazy_write) is ONE launch (up to kDnFusedCells cells;
-// a scan kernel of its own behind this one was 6.6 us of a 16 us tick)
-template <int MODEL, bool FINISH>
+template <int MODEL>
 __global__ void __launch_bounds__(256)
-k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *cell_cnt, unsigned long long *cell_mask, int chunks, uint32_t *cell_off)
+k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *cell_cnt, unsigned long long *cell_mask, int chunks)
 {
     __shared__ uint32_t s_w[kDnFrames][4];
     const int chunk = blockIdx.x, q0 = int(blockIdx.y) * kDnFrames;
@@ -167,33 +161,6 @@ k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *ce
         const int f = threadIdx.x;
         cell_cnt[size_t(q0 + f) * size_t(chunks) + size_t(chunk)] = s_w[f][0] + s_w[f][1] + s_w[f][2] + s_w[f][3];
     }
-    if (!FINISH) return;
-    __shared__ uint32_t s_last;
-    __shared__ uint32_t s_scan[4];
-    __threadfence(); // this workgroup's counts are out before it is counted as done
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&t.stage_count[7], 1u) == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence(); // ... and the last one sees everybody's
-    const int cells = n_new * chunks;
-    const int per = (cells + 255) / 256; // (at most kDnFusedCells / 256 = 32 consecutive cells per thread)
-    const int i0 = min(cells, int(threadIdx.x) * per), i1 = min(cells, i0 + per);
-    uint32_t sum = 0;
-    for (int i = i0; i < i1; ++i) sum += __hip_atomic_load(&cell_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t inc = wave_inclusive_scan(sum, lane);
-    if (lane == 63) s_scan[wave] = inc;
-    __syncthreads();
-    uint32_t run = inc - sum;
-    for (int w = 0; w < wave; ++w) run += s_scan[w];
-    const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-    for (int i = i0; i < i1; ++i) {
-        cell_off[i] = run;
-        if (i % chunks == 0) t.slot_off[t.shift + i / chunks] = run; // a frame's first cell: its packet offset
-        run += __hip_atomic_load(&cell_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    dense_tick_total(t, total, threadIdx.x, 256);
-    dense_tick_tail(m, t, threadIdx.x, 256);
 }
 
 // what every tick leaves for the one that follows and for its readers, whichever kernel lays the cells out
@@ -229,6 +196,31 @@ __global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const Tic
     __shared__ uint32_t s_wave[16];
     const int n_new = t.n_active - t.first_new;
     const int cells = n_new * chunks;
+    if (cells <= 8 * 1024) {
+        // up to eight consecutive cells per thread, all asked for at once: one round trip, one scan (the loop below is a chain of
+        // a round trip and two barriers per 1024 cells -- 6.6 us for the 4000 cells of the bench's tick, as long as the count pass)
+        const int i0 = int(threadIdx.x) * 8;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = (i0 + k < cells) ? cell_cnt[i0 + k] : 0u;
+            sum += v[k];
+        }
+        dense_tick_tail(m, t, threadIdx.x, 1024); // (its loads and stores depend on nothing here: they fly under the scan)
+        uint32_t total;
+        uint32_t run = block_exclusive_scan_1024(sum, s_wave, total);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k;
+            if (i < cells) {
+                cell_off[i] = run;
+                if (i % chunks == 0) t.slot_off[t.shift + i / chunks] = run; // a frame's first cell: its packet offset
+            }
+            run += v[k];
+        }
+        dense_tick_total(t, total, threadIdx.x, 1024);
+        return;
+    }
     uint32_t carry = 0;
     for (int base = 0; base < cells; base += 1024) {
         const int i = base + int(threadIdx.x);
@@ -340,23 +332,16 @@ hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &
     const int chunks = cdiv(nd.pos_span, kDnChunk);
     if (n_new <= 0 || chunks <= 0) return hipSuccess;
     const dim3 grid_c(chunks, cdiv(n_new, kDnFrames)), grid(chunks, n_new), block(256);
-    const bool finish = lazy_write && long(n_new) * long(chunks) <= long(kDnFusedCells); // the count pass lays the cells out itself
-#define RM_DN(MODEL)                                                                                                              \
-    do {                                                                                                                          \
-        if (finish) RM_KLAUNCH((k_dense_count<MODEL, true>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks, cell_off); \
-        else RM_KLAUNCH((k_dense_count<MODEL, false>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks, cell_off);     \
-    } while (0)
     switch (m.kind) {
-    case RM_MODEL_NULL: RM_DN(RM_MODEL_NULL); break;
-    case RM_MODEL_UDGM: RM_DN(RM_MODEL_UDGM); break;
-    case RM_MODEL_UDGM_CONST: RM_DN(RM_MODEL_UDGM_CONST); break;
-    case RM_MODEL_N2N: RM_DN(RM_MODEL_N2N); break;
+    case RM_MODEL_NULL: RM_KLAUNCH((k_dense_count<RM_MODEL_NULL>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_UDGM: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_UDGM_CONST: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM_CONST>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_N2N: RM_KLAUNCH((k_dense_count<RM_MODEL_N2N>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
     default: return hipErrorInvalidValue;
     }
-#undef RM_DN
-    if (finish) {
-        // (one launch)
-    } else if (lazy_write) {
+    // (the count pass's last workgroup laying the cells out itself -- one launch instead of two -- was built and measured: every
+    // workgroup's release fence writes its XCD's L2 back, 47 us for the count pass instead of 5.6 + 6.6 for the two launches)
+    if (lazy_write) {
         RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);
     } else if (long(n_new) * long(chunks) <= long(kDnFusedCells)) {
         RM_KLAUNCH((k_dense_write<true>), grid, block, 0, s, m, t, cell_cnt, cell_off, cell_mask, nd.rx_first, chunks);

@@ -619,7 +619,7 @@ hipError_t launch_stage_block(hipStream_t s, const int32_t *src, int n, uint64_t
 int filter_ticks_per_wg(const TickDev &t0, int n);
 hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                               const TickDev *dev_ticks, const LaunchCfg &cfg);
-hipError_t launch_sinr_acc_batch(hipStream_t s, const ModelDev &m, int n, const TickDev *dev_ticks, int max_links);
+hipError_t launch_sinr_acc_batch(hipStream_t s, const ModelDev &m, int n, const TickDev *dev_ticks, int max_links, int share);
 hipError_t launch_sinr_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,
                              const TickDev *dev_ticks);
 hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev *ticks, int n,

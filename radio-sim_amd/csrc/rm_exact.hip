@@ -642,9 +642,10 @@ do {                                                                            
     return hipGetLastError();
 }
 
-hipError_t launch_sinr_acc_batch(hipStream_t s, const ModelDev &m, int n, const TickDev *b, int max_links)
+hipError_t launch_sinr_acc_batch(hipStream_t s, const ModelDev &m, int n, const TickDev *b, int max_links, int share)
 {
-    RM_KLAUNCH(k_sinr_acc_batch, dim3(max(1, min(64, cdiv(max(max_links, 1), 1024))), 1, n), dim3(256), 0, s, m, b);
+    // (a receiver partition hears 1 / share of a tick's links: fewer workgroups per tick, each with something to do)
+    RM_KLAUNCH(k_sinr_acc_batch, dim3(max(1, min(max(4, 64 / max(share, 1)), cdiv(max(max_links, 1), 1024))), 1, n), dim3(256), 0, s, m, b);
     return hipGetLastError();
 }
 

@@ -653,6 +653,10 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     const int share = (nd.n_rx > 0 && nd.n_rx < nd.n) ? max(1, nd.n / nd.n_rx) : 1;
     int fpw = max(2, min(32, max_new / 256));
     if (share > 1) fpw = min(256, fpw * 4 * share);
+    // (SINR ticks summed per receiver -- sixteen channels, three links per frame: the lanes take the frames one each, a workgroup
+    // walks 256 frames per pass and every workgroup redoes the scan over all the tick's frames: few, long workgroups.
+    // configs[3]: 64 / 256 frames per wave 12.3 / 12.2 us per tick against 12.8 with 19)
+    if (ticks[0].acc_lo != nullptr && share == 1) fpw = 256;
     if (const char *e = getenv("RM_FPW")) fpw = max(1, atoi(e));
     // (a rank's frame list: the device walks the listed frames only -- about 1/share of them and a halo; the grid only has to be
     // large enough to be busy, every wave strides over whatever frames there are)

@@ -455,6 +455,11 @@ private:
                         c.bulkBytes -= took;
                         left -= took;
                         if (took == have) {
+                            // (the segment's room -- megabytes, its pages touched -- serves the next step's messages again)
+                            if (spare_.size() < 64 && c.bulk.front().capacity() >= 4096) {
+                                spare_.push_back(std::move(c.bulk.front()));
+                                spare_.back().clear();
+                            }
                             c.bulk.pop_front();
                             c.bulkOff = 0;
                         }
@@ -952,9 +957,14 @@ private:
         struct Share {
             std::vector<std::pair<Connection *, std::string>> per;
             std::vector<uint64_t> count;
+            std::string spare;
         };
         std::vector<Share> shares(T);
         const size_t n = calls.size();
+        for (unsigned t = 0; t < T && !spare_.empty(); ++t) { // a string that has held a share's messages before, for each share's first connection
+            shares[t].spare = std::move(spare_.back());
+            spare_.pop_back();
+        }
         workers_->run(T, [&](unsigned t) {
             Share &sh = shares[t];
             Framed f;
@@ -970,7 +980,8 @@ private:
                     for (lastAt = 0; lastAt < sh.per.size() && sh.per[lastAt].first != cc; ++lastAt) {}
                     if (lastAt == sh.per.size()) {
                         sh.per.emplace_back(cc, std::string());
-                        sh.per.back().second.reserve(size_t(420) * (n / T + 1) / std::max<size_t>(1, sh.per.size()));
+                        if (sh.per.size() == 1 && sh.spare.capacity() != 0) sh.per.back().second = std::move(sh.spare);
+                        else sh.per.back().second.reserve(size_t(420) * (n / T + 1) / std::max<size_t>(1, sh.per.size()));
                         sh.count.push_back(0);
                     }
                 }
@@ -1305,6 +1316,7 @@ private:
     uint64_t steps_ = 0, transmissions_ = 0, deliveries_ = 0;
     double usStepMessages_ = 0, usMedium_ = 0, usReceiveMessages_ = 0; // the server's own work per step (printStats)
     Framed framed_; // deliverRadioPacket: the packet whose constant text is at hand
+    std::vector<std::string> spare_; // bulk segments that have been sent: their room for the next step's receive messages
     // the workers (Workers above): RSIM_SERVER_THREADS, default min(hardware threads, 8); 1 = everything on the protocol's thread
     std::unique_ptr<Workers> workers_;
     size_t kParallelFrom = 2048; // changed nodes / medium calls of a step from which the workers are worth waking (RSIM_PARALLEL_FROM: tests)

@@ -57,6 +57,17 @@ def scenario(name):
         nd.x, nd.y = xx.ravel().copy(), yy.ravel().copy()
         src = np.arange(0, nd.n, 17)
         return nd, "udgm_const", {}, None, None, [(0, nd.packets(src, 0, 320))]
+    if name == "udgm_lattice":
+        # receivers AT the range: a 10 m lattice, range 50 -- (50, 0), (30, 40), (40, 30) and their mirror images are heard
+        # (UDGMRadioMedium.java:76: ratio == 1 is in) exactly as long as Math.pow(d, 2.0) and Math.pow(50, 2.0) both come out
+        # 2500 to the last bit: the scenario that pins the one JDK assumption (tests/test_oracle_pow_ulp.py) on a real JVM
+        g = np.arange(0, 24) * 10.0
+        xx, yy = np.meshgrid(g, g)
+        nd = O.NodeTable(xx.size)
+        nd.x, nd.y = xx.ravel().copy(), yy.ravel().copy()
+        nd.rxprob[::5] = 0.75
+        src = np.arange(5, nd.n, 23)
+        return nd, "udgm", {"udgm_success_ratio_rx": 0.5}, None, 7, [(0, nd.packets(src, 0, 8128))]
     if name == "n2n":
         n = 200
         nd = O.NodeTable(n)
@@ -96,7 +107,7 @@ def scenario(name):
     raise KeyError(name)
 
 
-SCENARIOS = ["udgm_default", "udgm_stochastic", "const_lattice", "n2n", "null", "logdist_shadow",
+SCENARIOS = ["udgm_default", "udgm_stochastic", "udgm_lattice", "const_lattice", "n2n", "null", "logdist_shadow",
              "logdist_sinr_overlap"]
 
 

@@ -4,7 +4,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SCENARIOS = ["udgm_default", "udgm_stochastic", "const_lattice", "n2n", "null", "logdist_shadow",
+SCENARIOS = ["udgm_default", "udgm_stochastic", "udgm_lattice", "const_lattice", "n2n", "null", "logdist_shadow",
              "logdist_sinr_overlap"]
 NODE_FIELDS = ("x", "y", "z", "txpower", "channel", "enabled", "rxprob", "txprob", "int_id")
 

@@ -25,7 +25,7 @@ def _build():
     lib = os.path.join(ROOT, "radio-sim_amd", "csrc")
     deps = [os.path.join(HOST, f) for f in ("rsim_server.cpp", "json.hpp", "radiomedium.hpp")]
     if (not os.path.exists(BIN)) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", BIN, deps[0], "-L" + lib, "-lradiomedium_hip", "-Wl,-rpath," + lib])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-o", BIN, deps[0], "-L" + lib, "-lradiomedium_hip", "-Wl,-rpath," + lib])
     return BIN
 
 

@@ -24,7 +24,7 @@ def build_server(rsa, tmp_path):
         return os.environ["RSIM_SERVER_EXE"]
     lib = os.path.dirname(rsa.library_path())
     exe = os.path.join(str(tmp_path), "rsim_server")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe, os.path.join(HOST, "rsim_server.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-o", exe, os.path.join(HOST, "rsim_server.cpp"),
                            "-L" + lib, "-lradiomedium_hip", "-Wl,-rpath," + lib])
     return exe
 

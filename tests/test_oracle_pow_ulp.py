@@ -3,7 +3,7 @@
 UDGMRadioMedium.java:69,74 square the distance and the range through Math.pow(v, 2.0).  The oracle (and the engine) restate
 that as v * v: fdlibm's e_pow and HotSpot's intrinsic both special-case y == 2.  No JVM exists here to confirm it, and the
 Java SE specification only promises a result within 1 ulp.  This test re-runs every golden scenario of the UDGM medium, the
-K2 / K3 boundary lattice and the five BASELINE layouts through a test-only oracle entry (orc_udgm_pow_sensitivity) with
+K2 / K3 boundary lattice (and the golden scenario built on one, udgm_lattice) and the five BASELINE layouts through a test-only oracle entry (orc_udgm_pow_sensitivity) with
 distanceSquared and distanceMaxSquared moved by one ulp either way -- everything a pow that is not special-cased may legally
 return -- and holds the outcome to the committed table: how many heard / unheard verdicts flip, how many probabilities move
 at all, and by how much at most.
@@ -56,6 +56,7 @@ def _baseline(O, index, n, packets, ratio_rx):
 TABLE = {
     'golden udgm_default': (75136, 901, {(1, 0): (0, 0, 0.000e+00), (-1, 0): (0, 0, 0.000e+00), (0, 1): (0, 0, 0.000e+00), (0, -1): (0, 0, 0.000e+00), (1, -1): (0, 0, 0.000e+00), (-1, 1): (0, 0, 0.000e+00)}),
     'golden udgm_stochastic': (179850, 2758, {(1, 0): (0, 417, 2.462e-16), (-1, 0): (0, 377, 2.200e-16), (0, 1): (0, 423, 2.200e-16), (0, -1): (0, 461, 2.462e-16), (1, -1): (0, 844, 2.772e-16), (-1, 1): (0, 777, 3.334e-16)}),
+    'golden udgm_lattice': (14375, 1654, {(1, 0): (226, 312, 1.850e-16), (-1, 0): (0, 370, 2.961e-16), (0, 1): (0, 682, 2.961e-16), (0, -1): (226, 656, 1.850e-16), (1, -1): (226, 868, 1.850e-16), (-1, 1): (0, 942, 4.441e-16)}),
     'lattice ratioRx=1.0': (11024, 7844, {(1, 0): (20, 0, 0.000e+00), (-1, 0): (0, 0, 0.000e+00), (0, 1): (0, 0, 0.000e+00), (0, -1): (20, 0, 0.000e+00), (1, -1): (20, 0, 0.000e+00), (-1, 1): (0, 0, 0.000e+00)}),
     'lattice ratioRx=0.5': (11024, 7844, {(1, 0): (20, 2480, 4.428e-16), (-1, 0): (0, 2684, 4.381e-16), (0, 1): (0, 3000, 4.381e-16), (0, -1): (20, 2688, 4.428e-16), (1, -1): (20, 4600, 4.428e-16), (-1, 1): (0, 4884, 4.441e-16)}),
     'BASELINE configs[0] layout (64 nodes, 1 packets) ratioRx=0.5': (63, 12, {(1, 0): (0, 5, 1.926e-16), (-1, 0): (0, 4, 1.793e-16), (0, 1): (0, 4, 1.793e-16), (0, -1): (0, 5, 3.333e-16), (1, -1): (0, 5, 3.852e-16), (-1, 1): (0, 8, 3.852e-16)}),
@@ -69,6 +70,7 @@ TABLE = {
 def scenarios(O):
     yield "golden udgm_default", _golden(O, "udgm_default")
     yield "golden udgm_stochastic", _golden(O, "udgm_stochastic")
+    yield "golden udgm_lattice", _golden(O, "udgm_lattice")
     yield "lattice ratioRx=1.0", _lattice(O, 1.0)
     yield "lattice ratioRx=0.5", _lattice(O, 0.5)
     for index, n, packets in ((1, 64, 1), (2, 10_000, 100), (3, 100_000, 64), (4, 100_000, 64), (5, 1_000_000, 16)):
@@ -99,7 +101,7 @@ def test_pow_within_one_ulp_changes_only_exact_lattice_hits(O):
             w = want_per[v]
             assert (flips, moved) == (w[0], w[1]), "%s %s" % (name, v)
             assert rel <= w[2] * 1.001 + 1e-300 and rel <= 4.5e-16, "%s %s: p moves by %.3g" % (name, v, rel)
-        if not name.startswith("lattice"):
+        if "lattice" not in name:
             assert all(f == 0 for f, _, _ in per.values()), "%s: a verdict flipped on a layout without exact lattice hits" % name
     # the lattice: exactly the 20 points at d == 50 flip, and only when the ratio is pushed above 1
     for name in ("lattice ratioRx=1.0", "lattice ratioRx=0.5"):

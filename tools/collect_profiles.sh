@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round evidence, run on the GPU box from the repository root:
-#   RM_COMMIT=<commit> ROUND=r04 [PARTS="bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
+#   RM_COMMIT=<commit> ROUND=r05 [PARTS="bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
 # Writes under gpurun_out/$ROUND/; the summaries to be judged are then copied into profiles/.  One gpurun call may run
 # 20 minutes: PARTS selects what a call collects (every part leaves its own summaries; pmc_traffic.json is per call and its
 # entries are merged into profiles/pmc_traffic.json (python tools/pmc_merge.py gpurun_out/$ROUND/pmc_traffic_*.json)).
 set -e -o pipefail
 R=$PWD
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 PARTS=${PARTS:-bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank}
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -21,7 +21,7 @@ stats() {
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 $R/bench.py "$@" > $O/${ROUND}_${name}_bench.json 2> $O/st_$name.err
     cp $(find $O/st_$name -name "*kernel_stats.csv" | head -1) $O/${ROUND}_${name}_kernel_stats.csv
     stamp $O/${ROUND}_${name}_kernel_stats.csv
-    (cd $R && python tools/trace_timed_avg.py $O/st_$name $O/${ROUND}_${name}_bench.json $O/${ROUND}_${name}_timed_kernel_avg.json > /dev/null) || true
+    (cd $R && python tools/trace_timed_avg.py $O/st_$name $O/${ROUND}_${name}_bench.json $O/${ROUND}_${name}_timed_kernel_avg.json > /dev/null) || echo "trace_timed_avg FAILED for $name (no ${ROUND}_${name}_timed_kernel_avg.json)" | tee -a $O/failures.log
     rm -rf $O/st_$name
     echo "stats $name done"
 }
@@ -60,7 +60,7 @@ pmc c3 128 $LEAN --inflight 1 --steps 6 --warmup 2
 fi
 if has pmc_m1; then pmc m1 16 $LEAN --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3; fi
 if has pmc_tick; then pmc c3_tick 1 $LEAN --inflight 1 --batch 1 --steps 200 --warmup 20; fi
-if has pmc_c4; then pmc c4 32 $LEAN --workload c4 --inflight 1 --steps 6 --warmup 2; fi
+if has pmc_c4; then pmc c4 128 $LEAN --workload c4 --inflight 1 --steps 4 --warmup 2; fi
 if has pmc_c5; then pmc c5 128 $LEAN --workload c5 --steps 6 --warmup 2; pmc c5_tick 1 $LEAN --workload c5 --batch 1 --steps 60 --warmup 12; fi
 if has pmc_dense; then
 stats dense --dense-only
@@ -70,20 +70,20 @@ if has ev; then
 # the reception stage (device events): tick + drain, deliveries to the host
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ev_stats -- python3 $R/tools/events_latency.py c3 100 > $O/ev_stats.log 2>&1
 cp $(find $O/ev_stats -name "*kernel_stats.csv" | head -1) $O/${ROUND}_c3_events_kernel_stats.csv
-grep -o "{\"workload\".*}" $O/ev_stats.log > $O/${ROUND}_c3_events.json || true
+grep -o "{\"workload\".*}" $O/ev_stats.log > $O/${ROUND}_c3_events.json || echo "events_latency printed no result line" | tee -a $O/failures.log
 stamp $O/${ROUND}_c3_events_kernel_stats.csv
 rm -rf $O/ev_stats
 # ... and the closed loop through the C ABI
-(cd $R && tools/loop_latency > $O/${ROUND}_closed_loop_c_abi.jsonl 2> /dev/null || true)
+(cd $R && tools/loop_latency > $O/${ROUND}_closed_loop_c_abi.jsonl 2> $O/loop_latency.err) || echo "loop_latency FAILED (see loop_latency.err)" | tee -a $O/failures.log
 # ... and what the PCIe link takes of a tick's 0.55 MB of delivery records, by store width (tools/pcie_store_width.hip)
-(cd $R && [ -x tools/pcie_store_width ] && tools/pcie_store_width > $O/${ROUND}_pcie_store_width.jsonl 2> /dev/null || true)
+if [ -x $R/tools/pcie_store_width ]; then (cd $R && tools/pcie_store_width > $O/${ROUND}_pcie_store_width.jsonl 2> /dev/null) || echo "pcie_store_width FAILED" | tee -a $O/failures.log; fi
 echo "events done"
 fi
 if has asrank; then
 # one rank's share of an 8-GPU run, rank by rank (compute side of strong scaling)
 cd $R
 tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c3.jsonl 8 c3 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c3.jsonl > $O/${ROUND}_asrank8_c3.txt
-tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c4.jsonl 8 c4 256 32 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c4.jsonl > $O/${ROUND}_asrank8_c4.txt
+tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c4.jsonl 8 c4 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c4.jsonl > $O/${ROUND}_asrank8_c4.txt
 tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c5.jsonl 8 c5 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c5.jsonl > $O/${ROUND}_asrank8_c5.txt
 fi
 echo "all done: $PARTS"
