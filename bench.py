@@ -237,6 +237,7 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
         dominant, kern_us = None, 0.0
     achieved = b_req / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
     frac = achieved / HBM_PEAK_GBS
+    frac_8d = (b_launch / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None
     if frac > 1.0:
         raise SystemExit("roofline refused: %s would have moved the launch's required bytes (%d) in %.1f us = %.2f x the HBM peak"
                          % (dominant, b_req, kern_us, frac))
@@ -264,7 +265,9 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
                                                       max(1, tile_reuse)),
           "algorithmic_bytes_per_launch": b_launch,
           "algorithmic_bytes_per_tick": "N_loc*37 + T*56 + H*25 = %d" % b_tick,
-          "frac_8d": (b_launch / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
+          # (the plain 8(d) bytes over the same interval; above 1 the figure charges bytes this launch shape never moves -- tiles
+          # fetched once per reuse window, columns it does not write -- and is left out rather than printed as a fraction of a peak)
+          "frac_8d": frac_8d if (frac_8d is not None and frac_8d <= 1.0) else None,
           "kernels": per_kernel,
           "step": {"hbm_frac": hbm_step, "valu_frac": None,
                    "what": "the driver-timed step's use of the two resources: required bytes / step / 8 TB/s, and the kernels' vector-issue "
@@ -705,6 +708,577 @@ def dry_run(args, rank, world, result_fd):
                                          "warmup": args.warmup, "rank_sum": total}) + "\n").encode())
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# One configuration through the bench.  `measure()` is the path the driver runs (`python bench.py [--gpus N --steps K
+# --warmup W]`), top to bottom: set-up, input, the mode's issue function, the timed region, the result line.  Every mode is one
+# function that returns `issue(k0, k1, plan_only)` -- "put ticks k0 .. k1-1 on the device":
+#     mode_batches          rm_batch_run_sources_device, `inflight` contexts in turn -- ONE GPU, THE DRIVER'S DEFAULT
+#     mode_as_rank          --as-rank R:W: one rank's share behind the call a real rank makes behind its all-gather
+#     mode_lib_dist         several GPUs: rm_dist_batch_run_sources_device (stage + ncclAllGather + sweep, one call per batch)
+#     mode_torch_batches    several GPUs / --force-sharded: torch.distributed runs the collective around the engine calls
+#     mode_torch_ticks      ... one tick at a time (draws, frames that stay on the air)
+#     mode_lone_ticks       --batch 1: rm_tick_run_sources_device per tick
+
+class Env:
+    """what the process is: rank, world, device, the (optional) process group"""
+
+
+class Run:
+    """the state of one configuration: workload, engines, input, clock"""
+
+
+def setup(args, env):
+    """workload -> nodes, medium, `inflight` engine contexts (each with its own stream), the receiver partition"""
+    rsa, W, torch = env.rsa, env.W, env.torch
+    run = Run()
+    run.args, run.env = args, env
+    idx, n, frac, model, desc = WORKLOADS[args.workload]
+    run.as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
+    if run.as_rank and args.scaling == "weak":
+        n = int(round(n * run.as_rank[1] ** 0.5))
+        desc += " -- compute of rank %d of %d (weak scaling: %d nodes), no collective" % (run.as_rank[0], run.as_rank[1], n)
+    elif run.as_rank:
+        desc += " -- compute of rank %d of %d (strong scaling: its share of the %d receivers), no collective" % (run.as_rank[0], run.as_rank[1], n)
+    elif args.nodes > 0:
+        n = args.nodes
+        desc += " -- node count overridden: %d" % n
+    elif env.world > 1 and args.scaling == "weak":
+        # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
+        n = int(round(n * env.world ** 0.5))
+        desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, env.world)
+    run.idx, run.n, run.model, run.desc = idx, n, model, desc
+    run.t_per_tick = int(round(frac * n))
+    extra = dict(EXTRA.get(args.workload, {}))
+    if args.link_capacity > 0:
+        extra["link_capacity"] = args.link_capacity
+    run.extra = extra
+    run.tick_us = extra.get("tick_us", W.TICK_US)
+    # the SINR extension looks at every frame on the air: ticks are chained through the frames on the air unless no frame
+    # outlives its tick -- ONE context, one timeline; a batch of such ticks is still one launch sequence (rm_airbatch.hip)
+    run.stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > run.tick_us
+    run.sinr_column = model in ("logdist_sinr16", "logdist_sinr_overlap")
+    run.nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
+    if args.spatial_ids:
+        # Morton order of the positions: index ranges become spatial regions (what a host that assigns node ids by
+        # location gives the range partition of the multi-GPU mode)
+        nodes = run.nodes
+        side = float(max(nodes.x.max(), nodes.y.max())) + 1e-9
+        qx = np.minimum((nodes.x / side * 65536).astype(np.uint64), 65535)
+        qy = np.minimum((nodes.y / side * 65536).astype(np.uint64), 65535)
+
+        def spread(v):
+            v = (v | (v << 8)) & np.uint64(0x00FF00FF)
+            v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
+            v = (v | (v << 2)) & np.uint64(0x33333333)
+            return (v | (v << 1)) & np.uint64(0x55555555)
+        order = np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
+        for f in ("x", "y", "z", "txpower", "channel", "enabled", "rxprob", "txprob"):
+            setattr(nodes, f, np.ascontiguousarray(getattr(nodes, f)[order]))
+        run.desc += " -- node ids along a Morton curve (--spatial-ids)"
+    kind_name, kw = W.model_kwargs(model)
+    kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
+    run.inflight = max(1, args.inflight) if not run.stateful else 1
+    run.engines, run.streams = [], []
+    share = run.as_rank[1] if run.as_rank else env.world
+    for _ in range(run.inflight):
+        e = rsa.Engine(env.device_ordinal)
+        st = torch.cuda.Stream(device=env.dev)
+        e.set_stream(st.cuda_stream)
+        e.upload_table(run.nodes)
+        e.set_model(kind, **kw)
+        # (a rank's share of the links: its result slots -- up to 512 per context -- are sized for it, with a margin)
+        e.set_link_capacity(max(1 << 17, extra.get("link_capacity", 1 << 21) * 2 // share) if share > 1 else extra.get("link_capacity", 1 << 21))
+        run.engines.append(e)
+        run.streams.append(st)
+    run.eng, run.stream = run.engines[0], run.streams[0]
+    # receiver partitioning (strong scaling): rank r owns a region of the plane, or the receivers [lo, hi)
+    run.spatial = args.partition == "spatial"
+    run.part_r, run.part_w = (run.as_rank if run.as_rank else (env.rank, env.world))
+    run.lo = (n * run.part_r) // run.part_w
+    run.hi = (n * (run.part_r + 1)) // run.part_w
+    run.own = None                          # owner of every node (who packs a transmitter's record)
+    if run.part_w > 1:
+        from radio_sim_amd import dist as D0
+        run.own = D0.owners(n, run.part_w, run.eng if run.spatial else None)
+    run.n_loc = int((run.own == run.part_r).sum()) if run.own is not None else n
+    if run.as_rank:
+        for e in run.engines:
+            if run.spatial:
+                e.set_partition_spatial(run.part_r, run.part_w)
+            else:
+                e.set_partition(run.lo, run.hi - run.lo)
+        run.desc += " (%s partition: %d receivers)" % (args.partition, run.n_loc)
+    # a step is one launch sequence of `batch` ticks
+    run.batch = max(1, min(extra.get("batch", args.batch) if (args.batch_default and env.world == 1 and not run.as_rank) else args.batch, rsa.MAX_BATCH))
+    run.steps = args.steps if args.steps > 0 else -(-1920 // run.batch)
+    run.warmup = args.warmup if args.warmup >= 0 else -(-192 // run.batch)
+    run.warm_ticks, run.ticks = run.warmup * run.batch, (run.warmup + run.steps) * run.batch
+    # synthetic input: a pool of distinct ticks (a multiple of the batch), reused in turn by longer runs
+    run.pool = min(run.ticks, -(-2112 // run.batch) * run.batch)
+    run.sources = [W.choose_sources(n, run.t_per_tick, 0xC0FFEE00 + idx, k) for k in range(run.pool)]
+    run.clock = 0          # simulated ticks issued so far: simulated time never runs backwards (the SINR medium keeps frames on the air)
+    run.links_done = 0
+    run.last_run = (run.eng, 0)   # (context, result slot) of the last tick issued
+    run.ctx_rr = 0
+    run.prepared, run.keep_alive = {}, []
+    return run
+
+
+def join_library_collective(run):
+    """several GPUs, --collective lib: one RCCL communicator per context inside libradiomedium_hip.so (rank 0 makes the ids,
+    torch.distributed -- only the out-of-band channel here -- hands them round).  False: torch runs the collective."""
+    args, env = run.args, run.env
+    rsa, torch, dist = env.rsa, env.torch, env.dist
+    ok = 1 if rsa.Engine.comm_available() else 0
+    if env.world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=env.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if ok and args.collective != "lib" and os.environ.get("RM_BENCH_NO_LIB_COLLECTIVE") == "1":
+        ok = 0
+    if not ok:
+        if args.collective == "lib":
+            raise SystemExit("--collective lib: RCCL could not be bound inside libradiomedium_hip.so on every rank")
+        print("bench: the library could not bind RCCL on every rank: torch.distributed runs the collective", file=sys.stderr)
+        return False
+    joined = 1
+    for e in run.engines:
+        if env.world > 1:
+            e.set_partition_spatial(env.rank, env.world) if run.spatial else e.set_partition(run.lo, run.hi - run.lo)
+        uid = torch.from_numpy(rsa.Engine.comm_unique_id() if env.rank == 0 else np.zeros(128, dtype=np.uint8))
+        if env.world > 1:
+            uid = uid.to(env.dev)
+            dist.broadcast(uid, src=0)
+            uid = uid.cpu()
+        try:
+            e.comm_init_rank(uid.numpy(), env.world, env.rank)
+        except rsa.RadioMediumError as err:     # (reported, and every rank then takes torch's collective together)
+            print("bench: rank %d could not join the library's communicator: %s" % (env.rank, err), file=sys.stderr)
+            joined = 0
+            break
+    if env.world > 1:
+        flag = torch.tensor([joined], dtype=torch.int32, device=env.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        joined = int(flag.item())
+    if not joined:
+        if args.collective == "lib":
+            raise SystemExit("--collective lib: a rank could not join the library's communicator")
+        for e in run.engines:
+            e.comm_destroy()
+    return bool(joined)
+
+
+def step_times(run, nb, tk):
+    return np.arange(tk, tk + nb, dtype=np.int64) * run.tick_us
+
+
+def issue_steps(run, step_call):
+    """the issue function of the batched single-process modes: contexts take the batches in turn; every step is a prepared call
+    (its arguments converted once: what the interpreter adds per step would otherwise bound a rank whose share of a batch
+    needs less device time than the argument conversion takes)"""
+    def issue(k0, k1, plan_only=False):
+        with run.env.torch.cuda.stream(run.stream):
+            rr = run.ctx_rr
+            for k in range(k0, k1, run.batch):
+                nb = min(run.batch, k1 - k)
+                g = rr % run.inflight
+                rr += 1
+                call = step_call(g, k, nb, run.clock + k - k0)
+                if not plan_only:
+                    call()
+                    run.last_run = (run.engines[g], nb - 1)
+            if plan_only:
+                return
+            run.ctx_rr = rr
+        run.clock += k1 - k0
+    return issue
+
+
+def cached(run, key, make):
+    if key not in run.prepared:
+        run.prepared[key] = make()
+    return run.prepared[key]
+
+
+def mode_batches(run):
+    """ONE GPU, the driver's default: `batch` ticks per rm_batch_run_sources_device call, the source lists resident in HBM"""
+    W, torch = run.env.W, run.env.torch
+    with torch.cuda.stream(run.stream):
+        run.src_dev = torch.from_numpy(np.stack(run.sources)).to(run.env.dev)                    # [ticks, T] int32
+    run.stream.synchronize()
+
+    def step_call(g, k, nb, tk):
+        def make():
+            t0 = step_times(run, nb, tk)
+            ptrs = np.array([run.src_dev[kk % run.pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64)
+            return run.engines[g].prepared("rm_batch_run_sources_device", nb, t0, t0 + run.tick_us, ptrs, np.full(nb, run.t_per_tick, dtype=np.int32),
+                                           t0, np.full(nb, W.AIR_US, dtype=np.int64))
+        return cached(run, (g, k, nb, tk), make)
+    run.step_call = step_call
+    return issue_steps(run, step_call)
+
+
+def padded_sources(run, ranks):
+    """every rank's transmitters of every tick in a fixed number of slots (src = -1: padding), on the device"""
+    from radio_sim_amd import dist as D
+    torch = run.env.torch
+    run.slots = D.slots_needed(run.n, run.part_w, run.sources, run.own)
+    return {r: torch.from_numpy(np.stack([D.pad_sources(s[run.own[s] == r] if run.own is not None else s, run.slots)
+                                          for s in run.sources])).to(run.env.dev) for r in ranks}
+
+
+def mode_as_rank(run):
+    """--as-rank R:W on one GPU: what the all-gather of the source indices would deliver, [rank][tick][slot]; the call builds
+    every rank's records from the node table, as a rank of a real run does behind its collective"""
+    W, torch, args = run.env.W, run.env.torch, run.args
+    with torch.cuda.stream(run.stream):
+        run.src_dev = torch.from_numpy(np.stack(run.sources)).to(run.env.dev)
+        if args.host_cull > 0:
+            nodes, mine, m = run.nodes, run.eng.partition_nodes(), args.host_cull
+            bx0, bx1, by0, by1 = nodes.x[mine].min(), nodes.x[mine].max(), nodes.y[mine].min(), nodes.y[mine].max()
+            run.sources = [s[(nodes.x[s] >= bx0 - m) & (nodes.x[s] <= bx1 + m) & (nodes.y[s] >= by0 - m) & (nodes.y[s] <= by1 + m)]
+                           for s in run.sources]
+            run.desc += " -- HOST-CULLED frames (experiment): %.0f of %d per tick" % (np.mean([len(s) for s in run.sources]), run.t_per_tick)
+        pad_dev = padded_sources(run, range(run.part_w))
+    run.stream.synchronize()
+
+    def step_call(g, k, nb, tk):
+        def make():
+            t0 = step_times(run, nb, tk)
+            k_in = k % run.pool                      # (the pool is a multiple of the batch: the window does not wrap)
+            gathered = torch.stack([pad_dev[r][k_in:k_in + nb] for r in range(run.part_w)]).contiguous()
+            run.keep_alive.append(gathered)
+            return run.engines[g].prepared("rm_batch_run_gathered_sources_device", nb, t0, t0 + run.tick_us, ctypes.c_void_p(gathered.data_ptr()),
+                                           run.part_w, run.slots, t0, W.AIR_US)
+        return cached(run, (g, k, nb, tk), make)
+    run.step_call = step_call
+    return issue_steps(run, step_call)
+
+
+def mode_lib_dist(run):
+    """several GPUs: per batch ONE call -- this rank's block (source indices + the node table's digest) staged, ncclAllGather
+    inside the library on the context's stream, the frame list, the sweep"""
+    W, torch = run.env.W, run.env.torch
+    with torch.cuda.stream(run.stream):
+        run.src_dev = torch.from_numpy(np.stack(run.sources)).to(run.env.dev)
+        pad_dev = padded_sources(run, [run.env.rank])
+    run.stream.synchronize()
+
+    def step_call(g, k, nb, tk):
+        def make():
+            t0 = step_times(run, nb, tk)
+            return run.engines[g].prepared("rm_dist_batch_run_sources_device", nb, t0, t0 + run.tick_us,
+                                           ctypes.c_void_p(pad_dev[run.env.rank][k % run.pool].data_ptr()), run.slots, t0, W.AIR_US)
+        return cached(run, (g, k, nb, tk), make)
+    run.step_call = step_call
+    return issue_steps(run, step_call)
+
+
+def make_sharded_driver(run):
+    """torch.distributed around the engine calls (radio-sim_amd/dist.py: ShardedTick); also the gloo rehearsal on one GPU"""
+    from radio_sim_amd import dist as D
+    env, torch = run.env, run.env.torch
+    with torch.cuda.stream(run.stream):
+        # every rank packs the frames whose source it owns into a fixed number of slots (padded with src = -1), then the
+        # ranks all-gather the slots over RCCL
+        run.slots = D.slots_needed(run.n, env.world, run.sources, run.own)
+        pad = np.stack([D.pad_sources(s[run.own[s] == env.rank] if run.own is not None else s, run.slots) for s in run.sources])
+        run.src_dev = torch.from_numpy(pad).to(env.dev)
+        run.sharded = D.ShardedTick(run.engines, env.dist, run.n, env.rank, env.world, run.slots, env.dev, run.streams, may_draw=False,
+                                    batch=run.batch, on_air=run.stateful, spatial=run.spatial)
+    run.stream.synchronize()
+    return run.sharded
+
+
+def mode_torch_batches(run):
+    """sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream"""
+    W = run.env.W
+    sharded = make_sharded_driver(run)
+
+    def issue(k0, k1, plan_only=False):
+        if plan_only:
+            return
+        with run.env.torch.cuda.stream(sharded.comm):
+            for k in range(k0, k1, run.batch):
+                t_b = (run.clock - k0 + np.arange(k, min(k + run.batch, k1), dtype=np.int64)) * run.tick_us
+                g = run.ctx_rr % run.inflight
+                run.ctx_rr += 1
+                sharded.run_batch(g, run.src_dev[k % run.pool].data_ptr(), t_b, W.AIR_US, run.tick_us)
+                run.last_run = (run.engines[g], len(t_b) - 1)
+        run.clock += k1 - k0
+    return issue
+
+
+def mode_torch_ticks(run):
+    """sharded, one tick at a time: the driver prefetches tick k+1 (pack + all-gather) while tick k is swept"""
+    W = run.env.W
+    sharded = make_sharded_driver(run)
+
+    def issue(k0, k1, plan_only=False):
+        if plan_only:
+            return
+        with run.env.torch.cuda.stream(sharded.comm):
+            base = run.clock - k0      # simulated time never runs backwards (frames on the air)
+            if k1 > k0:
+                sharded.stage(run.src_dev[k0 % run.pool].data_ptr(), (base + k0) * run.tick_us, W.AIR_US)
+            for k in range(k0, k1):
+                cur = sharded.staged
+                if k + 1 < k1:
+                    sharded.stage(run.src_dev[(k + 1) % run.pool].data_ptr(), (base + k + 1) * run.tick_us, W.AIR_US)
+                sharded.sweep(cur, (base + k) * run.tick_us + run.tick_us)
+        run.clock += k1 - k0
+    return issue
+
+
+def mode_lone_ticks(run):
+    """--batch 1 on one GPU: one rm_tick_run_sources_device call per tick (the frames' Tx records are built from the resident
+    node state inside the sweep)"""
+    W, torch = run.env.W, run.env.torch
+    with torch.cuda.stream(run.stream):
+        run.src_dev = torch.from_numpy(np.stack(run.sources)).to(run.env.dev)
+    run.stream.synchronize()
+
+    def issue(k0, k1, plan_only=False):
+        if plan_only:
+            return
+        with torch.cuda.stream(run.stream):
+            for k in range(k0, k1):
+                t0 = (run.clock + k - k0) * run.tick_us
+                run.engines[k % run.inflight].tick_run_sources_device(t0, t0 + run.tick_us, run.src_dev[k % run.pool].data_ptr(), run.t_per_tick,
+                                                                      t0, W.AIR_US)
+                if run.stateful:
+                    run.links_done += run.engines[0].last_link_evaluations()
+        run.clock += k1 - k0
+    return issue
+
+
+def pick_mode(run):
+    """which issue function this configuration takes"""
+    args, env = run.args, run.env
+    run.sharded, run.step_call, run.lib_dist = None, None, False
+    use_sharded = env.world > 1 or args.force_sharded
+    # who runs the collective of a sharded batch: the library (one C call per batch) or torch.distributed around the engine calls
+    want_lib = run.batch > 1 and ((env.world > 1 and args.collective != "torch" and env.backend == "nccl")
+                                  or (env.world == 1 and args.collective == "lib" and not run.as_rank))
+    if want_lib and join_library_collective(run):
+        run.lib_dist = True
+        return mode_lib_dist(run)
+    if run.as_rank and run.batch > 1:
+        return mode_as_rank(run)
+    if use_sharded:
+        return mode_torch_batches(run) if run.batch > 1 else mode_torch_ticks(run)
+    return mode_batches(run) if run.batch > 1 else mode_lone_ticks(run)
+
+
+def fence(run):
+    env = run.env
+    for st in run.streams:
+        st.synchronize()
+    env.torch.cuda.synchronize()   # includes the communication stream
+    if env.world > 1:
+        env.dist.barrier()
+        env.torch.cuda.synchronize()
+
+
+def timed_region(run, issue):
+    """set-up passes, W warm-up steps, then EXACTLY K steps between two fences (barrier + synchronize on both sides); returns the
+    elapsed time of this rank and the kernel intervals sampled inside the region (for the cross-check only)"""
+    # set-up, not a step: every context sweeps one batch once, so that its result slots and link buffers exist before the
+    # warm-up (the W warm-up steps alone need not reach every context)
+    for _ in range(run.inflight):
+        issue(0, min(run.ticks, run.batch))
+    fence(run)
+    issue(0, run.warm_ticks)
+    issue(run.warm_ticks, run.ticks, plan_only=True)     # the timed steps' calls, arguments converted
+    fence(run)
+    # kernel probes on a few launch sequences of every context: the roofline line takes its kernel times from sequences that run
+    # alone after the region; these samples only feed the cross-check, so that the probes cost the headline next to nothing
+    every = run.args.profile_every if run.batch == 1 else 4
+    if run.steps <= 8 * run.inflight:
+        every = 1 if run.steps <= 2 * run.inflight else 2
+    for e in run.engines:
+        e.profile_enable(every)
+    t_start = time.perf_counter()
+    run.links_done = 0
+    issue(run.warm_ticks, run.ticks)
+    fence(run)
+    elapsed = time.perf_counter() - t_start
+    n_samples, kernels = 0, {}
+    for e in run.engines:
+        ns, _ = e.profile_read()
+        for name, (launches, ms, stage) in e.profile_kernels().items():
+            k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "stage": stage})
+            k["launches"] += launches
+            k["ms"] += ms
+        e.profile_enable(0)
+        n_samples += ns
+    return elapsed, n_samples, kernels
+
+
+def alone_pass(run):
+    """the same launch sequences ALONE on the device (context 0, nothing else in flight), with and without probes: the kernels'
+    own intervals for the roofline line.  Every rank of a sharded run makes the same calls (a collective inside)."""
+    if run.sharded is not None:
+        return None
+    W, torch = run.env.W, run.env.torch
+    with torch.cuda.stream(run.stream):
+        n_probe = 4 if run.batch > 1 else 64
+        if run.batch > 1:
+            calls = [run.step_call(0, run.warm_ticks + (j % max(1, run.steps)) * run.batch, run.batch, run.clock + j * run.batch)
+                     for j in range(2 * n_probe)]
+            run.clock += 2 * n_probe * run.batch
+        else:
+            calls = lone_tick_calls(run, 2 * n_probe)
+        alone = probe_pass(run.eng, run.stream.synchronize, calls)
+    fence(run)
+    return alone
+
+
+def lone_tick_calls(run, count):
+    """`count` prepared rm_tick_run_sources_device calls at the simulated times that follow"""
+    W = run.env.W
+    calls = []
+    for j in range(count):
+        t0 = (run.clock + j) * run.tick_us
+        calls.append(run.eng.prepared("rm_tick_run_sources_device", t0, t0 + run.tick_us,
+                                      ctypes.c_void_p(run.src_dev[(run.warm_ticks + j) % run.pool].data_ptr()), run.t_per_tick, t0, W.AIR_US))
+    run.clock += count
+    return calls
+
+
+def sequential_leg(run, links_per_tick, timed_ticks, heard):
+    """`sequential_ticks`: the same ticks again, one at a time on one context -- the closed loop a simulation sees"""
+    W, torch, args = run.env.W, run.env.torch, run.args
+    fence(run)
+    run.eng.profile_enable(args.profile_every)
+    t_seq = time.perf_counter()
+    with torch.cuda.stream(run.stream):
+        seq_ticks = min(timed_ticks, 1920)
+        for k in range(run.warm_ticks, run.warm_ticks + seq_ticks):
+            t0 = (run.clock + k - run.warm_ticks) * run.tick_us
+            run.eng.tick_run_sources_device(t0, t0 + run.tick_us, run.src_dev[k % run.pool].data_ptr(), run.t_per_tick, t0, W.AIR_US)
+    fence(run)
+    el = time.perf_counter() - t_seq
+    seq_samples, _ = run.eng.profile_read()
+    seq_kernels = {name: {"launches": l, "ms": ms, "stage": st} for name, (l, ms, st) in run.eng.profile_kernels().items()}
+    run.eng.profile_enable(0)
+    run.clock += seq_ticks
+    with torch.cuda.stream(run.stream):   # the lone tick alone, every launch probed / none probed
+        seq_alone = probe_pass(run.eng, run.stream.synchronize, lone_tick_calls(run, 128))
+    sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
+                  "ms_per_tick": el / seq_ticks * 1e3,
+                  "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
+                          "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
+    if run.env.rank == 0 and run.env.world == 1 and not run.as_rank:
+        # the one-launch tick against the same roofline: the tick's required bytes over the kernel's own interval (the tick is a
+        # chain of dependent round trips on a mostly idle device: bound by latency, neither by HBM nor by issue slots)
+        try:
+            cand1, _ = run.eng.slot_stats(0)
+        except Exception:
+            cand1 = 0
+        rl = roofline_object(kernels=seq_kernels, n_samples=seq_samples, n_loc=run.n_loc, t_per_tick=run.t_per_tick, heard=heard, cand=cand1,
+                             ticks_per_launch=1, step_s=sequential["ms_per_tick"] * 1e-3, contexts=1, workload=args.workload,
+                             pmc_ok=(args.nodes == 0), tick_key=True, alone=seq_alone, sinr_column=run.sinr_column)
+        rl["bound_note"] = ("latency: a lone tick of this size is a chain of dependent launches and memory round trips on a mostly idle "
+                            "device; neither HBM bytes nor issue slots bind it (DESIGN.md section 4.7)")
+        sequential["roofline"] = rl
+    return sequential
+
+
+def measure(args, env):
+    """ONE configuration through the whole bench -- what the driver runs; rank 0 gets the result line's dictionary"""
+    args = copy.copy(args)
+    W, torch, dist = env.W, env.torch, env.dist
+    run = setup(args, env)
+    issue = pick_mode(run)
+    elapsed, n_samples, kernels = timed_region(run, issue)
+
+    eng, batch, world = run.eng, run.batch, env.world
+    heard, dropped = run.last_run[0].batch_result_count(run.last_run[1]) if batch > 1 else eng.result_count()
+    if dropped:
+        raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
+    alone = alone_pass(run)
+    tile_reuse = eng.batch_tile_reuse() if batch > 1 else 1
+    if world > 1:   # the contract: MAX over ranks of the timed region
+        rdev = env.dev if env.backend == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        hsum = torch.tensor([heard], dtype=torch.float64, device=rdev)
+        dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
+        heard_total = float(hsum.item())
+    else:
+        heard_total = float(heard)
+    links_per_tick = run.t_per_tick * (run.n - 1) if not run.as_rank else run.t_per_tick * run.n_loc
+    timed_ticks = run.steps * batch
+    value = links_per_tick * timed_ticks / elapsed
+    if run.stateful and run.sharded is None and batch == 1:
+        # the links the ticks resolved: the new frames against every receiver; the frames still on the air stay on the device
+        # and are not swept again (SURVEY.md section 8d, C5)
+        value = run.links_done / elapsed
+    if run.stateful:
+        inc, reb = eng.air_list_stats()
+        ob, ot = eng.air_batch_stats()
+        run.desc += (" -- %.2e link evaluations per tick (new frames only; the frames still on the air stay on the device: %d ticks in %d "
+                     "batches found their interferers through the batch's index of the frames on the air, %d lone ticks among the frames by "
+                     "scan, %d added their frames to per-receiver lists, %d rebuilt those)"
+                     % (value * elapsed / timed_ticks, ot, ob, eng.air_scan_ticks(), inc, reb))
+    sequential = None
+    if (run.inflight > 1 or batch > 1) and run.sharded is None and world == 1:
+        sequential = sequential_leg(run, links_per_tick, timed_ticks, heard)
+
+    result = None
+    if env.rank == 0:
+        try:
+            cand, _ = (run.last_run[0].slot_stats(run.last_run[1]) if batch > 1 else eng.slot_stats(0))
+        except Exception:
+            cand = 0
+        step_s = elapsed / run.steps
+        pairs = interferers = 0
+        if run.stateful and batch > 1:
+            pairs, _, interferers = eng.air_batch_pairs()
+        roofline = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=run.n_loc, t_per_tick=run.t_per_tick, heard=heard, cand=cand,
+                                   ticks_per_launch=batch, step_s=step_s, contexts=run.inflight, workload=args.workload,
+                                   pmc_ok=(world == 1 and not run.as_rank and args.nodes == 0), pairs_per_launch=pairs, alone=alone,
+                                   sinr_column=run.sinr_column, tile_reuse=tile_reuse)
+        if pairs:
+            roofline["surviving_pairs_per_launch"] = pairs
+            roofline["interfering_pairs_per_launch"] = interferers
+        result = {
+            "metric": baseline_metric(), "value": value, "unit": "links/s", "n_gpus": world, "steps": run.steps, "warmup": run.warmup,
+            "ms_per_step": step_s * 1e3, "ms_per_tick": elapsed / timed_ticks * 1e3, "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": run.desc, "nodes": run.n, "tx_per_tick": run.t_per_tick, "tick_us": run.tick_us,
+                       "ticks_in_flight": run.inflight * batch, "ticks_per_step": batch, "ticks_per_launch": batch, "contexts": run.inflight,
+                       "step": "one launch sequence sweeping ticks_per_step simulated ticks",
+                       "air_us": W.AIR_US, "medium": run.model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
+                       "sharding": ("receivers partitioned over %d ranks (%s), RCCL all-gather of Tx source indices per batch of ticks (%s)"
+                                    % (world, "regions of the k-d order" if run.spatial else "node index ranges",
+                                       "ncclAllGather inside libradiomedium_hip.so: stage + collective + frame list + sweep in one call"
+                                       if run.lib_dist else "torch.distributed around the engine calls")) if world > 1 else "none"},
+            "roofline": roofline,
+        }
+        if roofline["overlap_check"]["ok"] is False and not roofline["overlap_check"]["under_profiler"]:
+            result["roofline_check_failed"] = ("the kernel intervals sampled inside the timed region add up to more than the driver-timed "
+                                               "step allows (overlap_check): roofline.achieved / frac come from the launch sequences that ran alone")
+        if sequential is not None:
+            result["sequential_ticks"] = sequential
+        # extra keys, each measured by its own function AFTER the timed region; none of them enters `value`
+        if world == 1 and not run.stateful and not run.as_rank and not args.no_host_transfer:
+            result["with_host_transfer"] = host_transfer_legs(env.rsa, W, eng, run.stream, torch, run.nodes, run.sources, run.n, run.t_per_tick,
+                                                              run.tick_us, run.src_dev, run.pool, batch)
+        if world == 1 and args.workload == "c3" and not args.no_scale_probe:
+            result["at_1M_nodes"] = scale_probe(env.rsa, W, torch, env.dev, env.device_ordinal, run.inflight, batch)
+            result["dense_layout"] = dense_probe(env.rsa, W, torch, env.dev, env.device_ordinal)
+        if world == 1 and not args.no_cpu_baseline:
+            st, mt = cpu_baseline(args.workload, run.nodes, run.sources, args.cpu_sample_ticks)
+            result["cpu_baseline"] = st
+            result["cpu_baseline_all_cores"] = mt
+    for e in run.engines:
+        e.close()
+    return result
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.as_rank:
@@ -714,50 +1288,52 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env = Env()
+    env.rank = int(os.environ.get("RANK", "0"))
+    env.world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("RM_BENCH_DRY_RUN") == "1":
-        return dry_run(args, rank, world, result_fd)
+        return dry_run(args, env.rank, env.world, result_fd)
     if args.inflight <= 0:
         args.inflight = 3
     args.batch_default = args.batch <= 0
     if args.batch <= 0:
         # several GPUs: a rank's share of a tick shrinks with the ranks, a batch's fixed costs (five launches, the collective)
         # do not: more ticks per launch sequence
-        args.batch = 128 if world == 1 else min(512, 64 * world)
+        args.batch = 128 if env.world == 1 else min(512, 64 * env.world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        args.gpus = world      # under a launcher the launcher's world size is the truth
+    if env.world != args.gpus:
+        args.gpus = env.world      # under a launcher the launcher's world size is the truth
 
     import torch
     import radio_sim_amd as rsa
     from radio_sim_amd import workload as W
-
+    env.torch, env.rsa, env.W = torch, rsa, W
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # RM_FORCE_DEVICE / RM_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with one GPU
-    device_ordinal = int(os.environ.get("RM_FORCE_DEVICE", local_rank))
-    backend = os.environ.get("RM_DIST_BACKEND", "nccl")
-    torch.cuda.set_device(device_ordinal)
-    dev = torch.device("cuda", device_ordinal)
-    dist = None
+    env.device_ordinal = int(os.environ.get("RM_FORCE_DEVICE", local_rank))
+    env.backend = os.environ.get("RM_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(env.device_ordinal)
+    env.dev = torch.device("cuda", env.device_ordinal)
+    env.dist = None
     # RM_DIST_SINGLE=1 with --force-sharded: a one-rank process group, so that the collectives of the
     # sharded driver go through RCCL itself on a box with one GPU
-    if world > 1 or (args.force_sharded and os.environ.get("RM_DIST_SINGLE") == "1"):
+    if env.world > 1 or (args.force_sharded and os.environ.get("RM_DIST_SINGLE") == "1"):
         import torch.distributed as dist
+        env.dist = dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:      # the launcher (torchrun) normally supplies it; a one-rank rehearsal picks a free one
             import socket
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if env.backend == "nccl":
+            dist.init_process_group("nccl", rank=env.rank, world_size=env.world, device_id=env.dev)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(env.backend, rank=env.rank, world_size=env.world)
 
     if args.dense_only:
-        d = dense_probe(rsa, W, torch, dev, device_ordinal)
+        d = dense_probe(rsa, W, torch, env.dev, env.device_ordinal)
         lead = d["null_medium"]
         out = {"metric": baseline_metric(), "value": lead["value"], "unit": "links/s", "n_gpus": 1, "steps": 24, "warmup": 3,
                "ms_per_step": lead["ms_per_tick"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -766,467 +1342,8 @@ def main():
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         return
 
-    def measure(args):
-        """one configuration through the whole bench; rank 0 gets the result line's dictionary"""
-        args = copy.copy(args)
-        result = None
-        idx, n, frac, model, desc = WORKLOADS[args.workload]
-        extra0 = EXTRA.get(args.workload, {})
-        as_rank = tuple(int(v) for v in args.as_rank.split(":")) if args.as_rank else None
-        if as_rank and args.scaling == "weak":
-            n = int(round(n * as_rank[1] ** 0.5))
-            desc += " -- compute of rank %d of %d (weak scaling: %d nodes), no collective" % (as_rank[0], as_rank[1], n)
-        elif as_rank:
-            desc += " -- compute of rank %d of %d (strong scaling: its share of the %d receivers), no collective" % (as_rank[0], as_rank[1], n)
-        elif args.nodes > 0:
-            n = args.nodes
-            desc += " -- node count overridden: %d" % n
-        elif world > 1 and args.scaling == "weak":
-            # per-GPU link evaluations per tick fixed: T x N_loc = f*N * N/world = const  =>  N ~ sqrt(world)
-            n = int(round(n * world ** 0.5))
-            desc += " -- weak scaling: %d nodes on %d GPUs, same density and Tx fraction" % (n, world)
-        t_per_tick = int(round(frac * n))
-        extra = dict(EXTRA.get(args.workload, {}))
-        if args.link_capacity > 0:
-            extra["link_capacity"] = args.link_capacity
-        tick_us = extra.get("tick_us", W.TICK_US)
-        # the SINR extension looks at every frame on the air: ticks are chained through the frames on the air unless no frame
-        # outlives its tick -- ONE context, one timeline; a batch of such ticks is still one launch sequence (rm_airbatch.hip)
-        stateful = model in ("logdist_sinr16", "logdist_sinr_overlap") and W.AIR_US > tick_us
-        nodes = W.make_nodes(n, idx, channels16=extra.get("channels16", False))
-        if args.spatial_ids:
-            # Morton order of the positions: index ranges become spatial regions (what a host that assigns node ids by
-            # location gives the range partition of the multi-GPU mode)
-            side = float(max(nodes.x.max(), nodes.y.max())) + 1e-9
-            qx = np.minimum((nodes.x / side * 65536).astype(np.uint64), 65535)
-            qy = np.minimum((nodes.y / side * 65536).astype(np.uint64), 65535)
-
-            def spread(v):
-                v = (v | (v << 8)) & np.uint64(0x00FF00FF)
-                v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
-                v = (v | (v << 2)) & np.uint64(0x33333333)
-                return (v | (v << 1)) & np.uint64(0x55555555)
-            order = np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
-            for f in ("x", "y", "z", "txpower", "channel", "enabled", "rxprob", "txprob"):
-                setattr(nodes, f, np.ascontiguousarray(getattr(nodes, f)[order]))
-            desc += " -- node ids along a Morton curve (--spatial-ids)"
-        kind_name, kw = W.model_kwargs(model)
-        kind = {"udgm": rsa.MODEL_UDGM, "udgm_const": rsa.MODEL_UDGM_CONST, "logdist": rsa.MODEL_LOGDIST}[kind_name]
-
-        inflight = max(1, args.inflight) if not stateful else 1
-        engines, streams = [], []
-        for _ in range(inflight):
-            e = rsa.Engine(device_ordinal)
-            st = torch.cuda.Stream(device=dev)
-            e.set_stream(st.cuda_stream)
-            e.upload_table(nodes)
-            e.set_model(kind, **kw)
-            # (a rank's share of the links: its result slots -- up to 512 per context -- are sized for it, with a margin)
-            share = as_rank[1] if as_rank else world
-            e.set_link_capacity(max(1 << 17, extra.get("link_capacity", 1 << 21) * 2 // share) if share > 1 else extra.get("link_capacity", 1 << 21))
-            engines.append(e)
-            streams.append(st)
-        eng, stream = engines[0], streams[0]
-
-        # receiver partitioning (strong scaling): rank r owns a region of the plane, or the receivers [lo, hi)
-        spatial = args.partition == "spatial"
-        part_r, part_w = (as_rank if as_rank else (rank, world))
-        lo = (n * part_r) // part_w
-        hi = (n * (part_r + 1)) // part_w
-        own = None                          # owner of every node (who packs a transmitter's record)
-        if part_w > 1:
-            from radio_sim_amd import dist as D0
-            own = D0.owners(n, part_w, eng if spatial else None)
-        n_loc = int((own == part_r).sum()) if own is not None else n
-        if as_rank:
-            for e in engines:
-                if spatial:
-                    e.set_partition_spatial(part_r, part_w)
-                else:
-                    e.set_partition(lo, hi - lo)
-            desc += " (%s partition: %d receivers)" % (args.partition, n_loc)
-
-        from radio_sim_amd import dist as D
-        use_sharded = world > 1 or args.force_sharded
-        batch = max(1, min(extra.get("batch", args.batch) if (args.batch_default and world == 1 and not as_rank) else args.batch, rsa.MAX_BATCH))
-        tps = batch                          # ticks per step: a step is one launch sequence
-        if args.steps <= 0:
-            args.steps = -(-1920 // tps)
-        if args.warmup < 0:
-            args.warmup = -(-192 // tps)
-        warm_ticks, ticks = args.warmup * tps, (args.warmup + args.steps) * tps
-        base_seed = 0xC0FFEE00 + idx
-        # synthetic input: a pool of distinct ticks (a multiple of the batch), reused in turn by longer runs
-        pool = min(ticks, -(-2112 // tps) * tps)
-        sources = [W.choose_sources(n, t_per_tick, base_seed, k) for k in range(pool)]
-        # who runs the collective of a sharded batch: the library (one C call per batch: pack, ncclAllGather, sweep) or
-        # torch.distributed around the engine calls
-        lib_dist = batch > 1 and ((world > 1 and args.collective != "torch" and backend == "nccl")
-                                                  or (world == 1 and args.collective == "lib" and not as_rank))
-        if lib_dist:
-            # one communicator per context (their collectives are independent): rank 0 makes the ids, torch.distributed -- here
-            # only the out-of-band channel -- hands them round, every rank joins with ncclCommInitRank inside the library.
-            # If the library cannot have RCCL on some rank (rm_comm_available), every rank falls back to torch's collective.
-            ok = 1 if rsa.Engine.comm_available() else 0
-            if world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if ok and args.collective != "lib" and os.environ.get("RM_BENCH_NO_LIB_COLLECTIVE") == "1":
-                ok = 0
-            if ok:
-                joined = 1
-                for e in engines:
-                    if world > 1:
-                        e.set_partition_spatial(rank, world) if spatial else e.set_partition(lo, hi - lo)
-                    uid = torch.from_numpy(rsa.Engine.comm_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8))
-                    if world > 1:
-                        uid = uid.to(dev)
-                        dist.broadcast(uid, src=0)
-                        uid = uid.cpu()
-                    try:
-                        e.comm_init_rank(uid.numpy(), world, rank)
-                    except rsa.RadioMediumError as err:     # (reported, and every rank then takes torch's collective together)
-                        print("bench: rank %d could not join the library's communicator: %s" % (rank, err), file=sys.stderr)
-                        joined = 0
-                        break
-                if world > 1:
-                    flag = torch.tensor([joined], dtype=torch.int32, device=dev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    joined = int(flag.item())
-                if not joined:
-                    if args.collective == "lib":
-                        raise SystemExit("--collective lib: a rank could not join the library's communicator")
-                    for e in engines:
-                        e.comm_destroy()
-                    lib_dist = False
-            elif args.collective == "lib":
-                raise SystemExit("--collective lib: RCCL could not be bound inside libradiomedium_hip.so on every rank")
-            else:
-                print("bench: the library could not bind RCCL on every rank: torch.distributed runs the collective", file=sys.stderr)
-                lib_dist = False
-        if lib_dist:
-            use_sharded = False
-        pad_dev, slots = None, 0
-        with torch.cuda.stream(stream):
-            if lib_dist or (as_rank and batch > 1):
-                # every rank's transmitters of every tick in a fixed number of slots (src = -1: padding)
-                src_dev = torch.from_numpy(np.stack(sources)).to(dev)
-                if as_rank and args.host_cull > 0:
-                    mine = eng.partition_nodes()
-                    bx0, bx1, by0, by1 = nodes.x[mine].min(), nodes.x[mine].max(), nodes.y[mine].min(), nodes.y[mine].max()
-                    m = args.host_cull
-                    sources = [s[(nodes.x[s] >= bx0 - m) & (nodes.x[s] <= bx1 + m) & (nodes.y[s] >= by0 - m) & (nodes.y[s] <= by1 + m)]
-                               for s in sources]
-                    desc += " -- HOST-CULLED frames (experiment): %.0f of %d per tick" % (np.mean([len(s) for s in sources]), t_per_tick)
-                slots = D.slots_needed(n, part_w, sources, own)
-                ranks = range(part_w) if as_rank else [rank]
-                pad_dev = {r: torch.from_numpy(np.stack([D.pad_sources(s[own[s] == r] if own is not None else s, slots)
-                                                         for s in sources])).to(dev) for r in ranks}
-                sharded = None
-            elif not use_sharded:
-                src_dev = torch.from_numpy(np.stack(sources)).to(dev)                    # [ticks, T] int32
-                sharded = None
-            else:
-                # every rank packs the frames whose source it owns into a fixed number of slots
-                # (padded with src = -1), then the ranks all-gather the slots over RCCL
-                slots = D.slots_needed(n, world, sources, own)
-                pad = np.stack([D.pad_sources(s[own[s] == rank] if own is not None else s, slots) for s in sources])
-                src_dev = torch.from_numpy(pad).to(dev)
-                sharded = D.ShardedTick(engines, dist, n, rank, world, slots, dev, streams, may_draw=False, batch=batch, on_air=stateful,
-                                        spatial=spatial)
-        stream.synchronize()
-        links_done = [0]
-        last_run = [eng, 0]     # (context, result slot) of the last tick issued
-        ctx_rr = [0]
-        _bargs = {}
-
-        clock = [0]   # simulated ticks issued so far: simulated time never runs backwards (the SINR medium keeps frames on the air)
-
-        def batch_args(k, nb, tk):
-            """arguments of one rm_batch_run_sources_device call for the source lists k .. k+nb-1 at simulated ticks tk .."""
-            if (k, nb) not in _bargs:   # what does not depend on the simulated time: built once per source-list window
-                _bargs[(k, nb)] = (np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64),
-                                   np.full(nb, t_per_tick, dtype=np.int32), np.full(nb, W.AIR_US, dtype=np.int64))
-            ptrs, cnt, air = _bargs[(k, nb)]
-            t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
-            return (t0, t0 + tick_us, ptrs, cnt, t0, air)
-
-        prepared = {}   # (context, source window, ticks, simulated tick) -> the step's call, its arguments converted once
-        keep_alive = []
-
-        def step_call(g, k, nb, tk):
-            """One step = one launch sequence of nb ticks on context g, as a closure that costs ONE ctypes call: what the
-            interpreter adds per step would otherwise bound a rank whose share of a batch needs less device time than the
-            argument conversion takes.  Built before the timed region (`plan_only`)."""
-            key = (g, k, nb, tk)
-            if key in prepared:
-                return prepared[key]
-            t0 = np.arange(tk, tk + nb, dtype=np.int64) * tick_us
-            e = engines[g]
-            if lib_dist:
-                call = e.prepared("rm_dist_batch_run_sources_device", nb, t0, t0 + tick_us, ctypes.c_void_p(pad_dev[rank][k % pool].data_ptr()),
-                                  slots, t0, W.AIR_US)
-            elif pad_dev is not None:
-                # --as-rank: what the all-gather of the source indices would deliver, [rank][tick][slot]; the call builds every
-                # rank's records from the node table, as a rank of a real run does behind its collective
-                k_in = k % pool                      # (the pool is a multiple of the batch: the window does not wrap)
-                gathered = torch.stack([pad_dev[r][k_in:k_in + nb] for r in range(part_w)]).contiguous()
-                keep_alive.append(gathered)
-                call = e.prepared("rm_batch_run_gathered_sources_device", nb, t0, t0 + tick_us, ctypes.c_void_p(gathered.data_ptr()), part_w,
-                                  slots, t0, W.AIR_US)
-            else:
-                ptrs = np.array([src_dev[kk % pool].data_ptr() for kk in range(k, k + nb)], dtype=np.uint64)
-                call = e.prepared("rm_batch_run_sources_device", nb, t0, t0 + tick_us, ptrs, np.full(nb, t_per_tick, dtype=np.int32), t0,
-                                  np.full(nb, W.AIR_US, dtype=np.int64))
-            prepared[key] = call
-            return call
-
-        def run_range(k0, k1, plan_only=False):
-            """ticks k0 .. k1-1; the sharded driver prefetches tick k+1 while tick k is swept.  plan_only: build the steps'
-            calls without issuing them (and leave the clock where it is)"""
-            with torch.cuda.stream(stream if sharded is None else sharded.comm):
-                if sharded is None and batch > 1:
-                    rr = ctx_rr[0]
-                    for k in range(k0, k1, batch):
-                        nb = min(batch, k1 - k)
-                        g = rr % inflight       # contexts take the batches in turn
-                        rr += 1
-                        call = step_call(g, k, nb, clock[0] + k - k0)
-                        if not plan_only:
-                            call()
-                            last_run[:] = [engines[g], nb - 1]
-                    if plan_only:
-                        return
-                    ctx_rr[0] = rr
-                elif plan_only:
-                    return
-                elif batch > 1:
-                    # sharded, `batch` ticks per step: packing, one all-gather and the sweep on the context's stream
-                    for k in range(k0, k1, batch):
-                        t_b = (clock[0] - k0 + np.arange(k, min(k + batch, k1), dtype=np.int64)) * tick_us
-                        g = ctx_rr[0] % inflight
-                        ctx_rr[0] += 1
-                        sharded.run_batch(g, src_dev[k % pool].data_ptr(), t_b, W.AIR_US, tick_us)
-                        last_run[:] = [engines[g], len(t_b) - 1]
-                elif sharded is None:
-                    for k in range(k0, k1):
-                        t0 = (clock[0] + k - k0) * tick_us
-                        # one call: the frames' Tx records are built from the resident node state inside the sweep
-                        engines[k % inflight].tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick,
-                                                                      t0, W.AIR_US)
-                        if stateful:
-                            links_done[0] += engines[0].last_link_evaluations()
-                else:
-                    base = clock[0] - k0      # simulated time never runs backwards (frames on the air)
-                    if k1 > k0:
-                        sharded.stage(src_dev[k0 % pool].data_ptr(), (base + k0) * tick_us, W.AIR_US)
-                    for k in range(k0, k1):
-                        cur = sharded.staged
-                        if k + 1 < k1:
-                            sharded.stage(src_dev[(k + 1) % pool].data_ptr(), (base + k + 1) * tick_us, W.AIR_US)
-                        sharded.sweep(cur, (base + k) * tick_us + tick_us)
-            clock[0] += k1 - k0
-
-        def fence():
-            for st in streams:
-                st.synchronize()
-            torch.cuda.synchronize()   # includes the communication stream
-            if world > 1:
-                dist.barrier()
-                torch.cuda.synchronize()
-
-        # set-up, not a step: every context sweeps one batch once, so that its result slots and link
-        # buffers exist before the warm-up (the W warm-up steps alone need not reach every context)
-        for _ in range(inflight):
-            run_range(0, min(ticks, batch))
-        fence()
-        run_range(0, warm_ticks)
-        run_range(warm_ticks, ticks, plan_only=True)     # the timed steps' calls, arguments converted
-        fence()
-        # kernel probes (a pair of HIP events bound to the kernel's own dispatch: no stream time) on every n-th launch sequence
-        # of every context; few launches: all of them
-        # (the roofline line takes its kernel times from sequences that run alone after the timed region; the samples inside
-        # it only feed the cross-check: every fourth sequence of a context, so that the probes cost the headline next to nothing)
-        launches = args.steps
-        every = args.profile_every if batch == 1 else 4
-        if launches <= 8 * inflight:
-            every = 1 if launches <= 2 * inflight else 2
-        for e in engines:
-            e.profile_enable(every)
-        t_start = time.perf_counter()
-        links_done[0] = 0
-        run_range(warm_ticks, ticks)
-        fence()
-        elapsed = time.perf_counter() - t_start
-        n_samples, kernels = 0, {}
-        for e in engines:
-            ns, _ = e.profile_read()
-            for name, (launches, ms, stage) in e.profile_kernels().items():
-                k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "stage": stage})
-                k["launches"] += launches
-                k["ms"] += ms
-            e.profile_enable(0)
-            n_samples += ns
-        heard, dropped = last_run[0].batch_result_count(last_run[1]) if batch > 1 else eng.result_count()
-        if dropped:
-            raise SystemExit("heard links were dropped for capacity: the measurement is invalid")
-        # the same launch sequences ALONE on the device (context 0, nothing else in flight), with and without probes: the
-        # kernels' own intervals for the roofline line.  Every rank of a sharded run makes the same calls (a collective inside).
-        alone = None
-        sinr_column = model in ("logdist_sinr16", "logdist_sinr_overlap")
-        if sharded is None:
-            with torch.cuda.stream(stream):
-                n_probe = 4 if batch > 1 else 64
-                if batch > 1:
-                    probe_calls = [step_call(0, warm_ticks + (j % max(1, args.steps)) * batch, batch, clock[0] + j * batch)
-                                   for j in range(2 * n_probe)]
-                    clock[0] += 2 * n_probe * batch
-                else:
-                    probe_calls = []
-                    for j in range(2 * n_probe):
-                        t0p = (clock[0] + j) * tick_us
-                        probe_calls.append(eng.prepared("rm_tick_run_sources_device", t0p, t0p + tick_us,
-                                                        ctypes.c_void_p(src_dev[(warm_ticks + j) % pool].data_ptr()), t_per_tick, t0p, W.AIR_US))
-                    clock[0] += 2 * n_probe
-                alone = probe_pass(eng, stream.synchronize, probe_calls)
-            fence()
-        tile_reuse = eng.batch_tile_reuse() if batch > 1 else 1
-
-        if world > 1:
-            rdev = dev if backend == "nccl" else torch.device("cpu")
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
-            hsum = torch.tensor([heard], dtype=torch.float64, device=rdev)
-            dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
-            heard_total = float(hsum.item())
-        else:
-            heard_total = float(heard)
-
-        links_per_tick = t_per_tick * (n - 1) if not as_rank else t_per_tick * n_loc
-        timed_ticks = args.steps * tps
-        value = links_per_tick * timed_ticks / elapsed
-        if stateful and sharded is None and batch == 1:
-            # the links the ticks resolved: the new frames against every receiver; the frames still on the air stay on the
-            # device (as records the new frames' links are tested against, or as entries of per-receiver lists) and are not
-            # swept again (SURVEY.md section 8d, C5)
-            value = links_done[0] / elapsed
-
-        sequential = None
-        if stateful:
-            inc, reb = engines[0].air_list_stats()
-            scans = engines[0].air_scan_ticks()
-            ob, ot = engines[0].air_batch_stats()
-            desc += (" -- %.2e link evaluations per tick (new frames only; the frames still on the air stay on the device: %d ticks in %d "
-                     "batches found their interferers through the batch's index of the frames on the air, %d lone ticks among the frames by "
-                     "scan, %d added their frames to per-receiver lists, %d rebuilt those)"
-                     % (value * elapsed / timed_ticks, ot, ob, scans, inc, reb))
-        if (inflight > 1 or batch > 1) and sharded is None and world == 1:
-            # the same ticks again, one at a time on one context
-            fence()
-            eng.profile_enable(args.profile_every)
-            t_seq = time.perf_counter()
-            with torch.cuda.stream(stream):
-                seq_ticks = min(timed_ticks, 1920)
-                for k in range(warm_ticks, warm_ticks + seq_ticks):
-                    t0 = (clock[0] + k - warm_ticks) * tick_us
-                    eng.tick_run_sources_device(t0, t0 + tick_us, src_dev[k % pool].data_ptr(), t_per_tick, t0, W.AIR_US)
-            fence()
-            el = time.perf_counter() - t_seq
-            seq_samples, _ = eng.profile_read()
-            seq_kernels = {name: {"launches": l, "ms": ms, "stage": st} for name, (l, ms, st) in eng.profile_kernels().items()}
-            eng.profile_enable(0)
-            clock[0] += seq_ticks
-            with torch.cuda.stream(stream):   # the lone tick alone, every launch probed / none probed
-                seq_calls = []
-                for j in range(128):
-                    t0p = (clock[0] + j) * tick_us
-                    seq_calls.append(eng.prepared("rm_tick_run_sources_device", t0p, t0p + tick_us,
-                                                  ctypes.c_void_p(src_dev[(warm_ticks + j) % pool].data_ptr()), t_per_tick, t0p, W.AIR_US))
-                clock[0] += 128
-                seq_alone = probe_pass(eng, stream.synchronize, seq_calls)
-            sequential = {"ticks_in_flight": 1, "ticks": seq_ticks, "value": links_per_tick * seq_ticks / el, "unit": "links/s",
-                          "ms_per_tick": el / seq_ticks * 1e3,
-                          "what": "the closed loop: one tick at a time on one context, its ordered heard links left in HBM "
-                                  "(rm_tick_run_sources_device; one launch per tick for the geometric media, rm_tick.hip)"}
-
-        if rank == 0 and sequential is not None and world == 1 and not as_rank:
-            # the one-launch tick against the same roofline: section 8(d)'s bytes of ONE tick over the kernel's own interval (the
-            # tick is a chain of dependent round trips on a mostly idle device: bound by latency, neither by HBM nor by issue slots)
-            try:
-                cand1, _ = eng.slot_stats(0)
-            except Exception:
-                cand1 = 0
-            rl = roofline_object(kernels=seq_kernels, n_samples=seq_samples, n_loc=n_loc, t_per_tick=t_per_tick, heard=heard, cand=cand1,
-                                 ticks_per_launch=1, step_s=sequential["ms_per_tick"] * 1e-3, contexts=1, workload=args.workload,
-                                 pmc_ok=(args.nodes == 0), tick_key=True, alone=seq_alone, sinr_column=sinr_column)
-            rl["bound_note"] = ("latency: a lone tick of this size is a chain of dependent launches and memory round trips on a mostly idle "
-                                "device; neither HBM bytes nor issue slots bind it (DESIGN.md section 4.7)")
-            sequential["roofline"] = rl
-
-        if rank == 0:
-            try:
-                cand, _ = (last_run[0].slot_stats(last_run[1]) if batch > 1 else eng.slot_stats(0))
-            except Exception:
-                cand = 0
-            step_s = elapsed / args.steps
-            pairs = 0
-            if stateful and batch > 1:
-                pairs, _, interferers = eng.air_batch_pairs()
-            roofline = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n_loc, t_per_tick=t_per_tick, heard=heard, cand=cand,
-                                       ticks_per_launch=batch, step_s=step_s, contexts=inflight, workload=args.workload,
-                                       pmc_ok=(world == 1 and not as_rank and args.nodes == 0), pairs_per_launch=pairs, alone=alone,
-                                       sinr_column=sinr_column, tile_reuse=tile_reuse)
-            if pairs:
-                roofline["surviving_pairs_per_launch"] = pairs
-                roofline["interfering_pairs_per_launch"] = interferers
-            out = {
-                "metric": baseline_metric(),
-                "value": value,
-                "unit": "links/s",
-                "n_gpus": world,
-                "steps": args.steps,
-                "warmup": args.warmup,
-                "ms_per_step": step_s * 1e3,
-                "ms_per_tick": elapsed / timed_ticks * 1e3,
-                "higher_is_better": True,
-                "scaling": args.scaling if world > 1 else "strong",
-                "vs_baseline": None,
-                "dtype": "f64",
-                "data": "synthetic",
-                "config": {"workload": desc, "nodes": n, "tx_per_tick": t_per_tick, "tick_us": tick_us, "ticks_in_flight": inflight * batch,
-                           "ticks_per_step": tps, "ticks_per_launch": batch, "contexts": inflight,
-                           "step": "one launch sequence sweeping ticks_per_step simulated ticks",
-                           "air_us": W.AIR_US, "medium": model, "heard_links_last_tick": heard_total, "candidate_links_last_tick": cand,
-                           "sharding": ("receivers partitioned over %d ranks (%s), RCCL all-gather of Tx records per batch of ticks (%s)"
-                                        % (world, "regions of the k-d order" if spatial else "node index ranges",
-                                           "ncclAllGather inside libradiomedium_hip.so: pack + collective + sweep in one call" if lib_dist
-                                           else "torch.distributed around the engine calls")) if world > 1 else "none"},
-                "roofline": roofline,
-            }
-            if roofline["overlap_check"]["ok"] is False and not roofline["overlap_check"]["under_profiler"]:
-                out["roofline_check_failed"] = ("the kernel intervals sampled inside the timed region add up to more than the driver-timed step "
-                                                "allows (overlap_check): roofline.achieved / frac come from the launch sequences that ran alone")
-            if sequential is not None:
-                out["sequential_ticks"] = sequential
-            if world == 1 and not stateful and not as_rank and not args.no_host_transfer:
-                out["with_host_transfer"] = host_transfer_legs(rsa, W, eng, stream, torch, nodes, sources, n, t_per_tick, tick_us,
-                                                               src_dev, pool, batch)
-            if world == 1 and args.workload == "c3" and not args.no_scale_probe:
-                out["at_1M_nodes"] = scale_probe(rsa, W, torch, dev, device_ordinal, inflight, batch)
-                out["dense_layout"] = dense_probe(rsa, W, torch, dev, device_ordinal)
-            if world == 1 and not args.no_cpu_baseline:
-                st, mt = cpu_baseline(args.workload, nodes, sources, args.cpu_sample_ticks)
-                out["cpu_baseline"] = st
-                out["cpu_baseline_all_cores"] = mt
-            result = out
-        for e in engines:
-            e.close()
-        return result
-
-    out = measure(args)
-    if world > 1 and args.scaling == "strong" and not args.no_weak_probe and not args.as_rank and args.nodes == 0:
+    out = measure(args, env)
+    if env.world > 1 and args.scaling == "strong" and not args.no_weak_probe and not args.as_rank and args.nodes == 0:
         # the same run once more with the node count grown as sqrt(GPUs) (constant link evaluations per GPU and tick):
         # printed as an extra key, the headline stays the BASELINE config
         a2 = copy.copy(args)
@@ -1235,7 +1352,7 @@ def main():
         a2.warmup = 2 if args.warmup < 0 else min(args.warmup, 2)
         a2.no_cpu_baseline = True
         try:
-            w = measure(a2)
+            w = measure(a2, env)
             if out is not None and w is not None:
                 out["weak_scaling"] = {k: w[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_tick", "config")}
         except Exception as e:   # the headline line is printed whatever happens to the extra pass
@@ -1244,8 +1361,8 @@ def main():
     if out is not None:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         sys.stdout.flush()
-    if dist is not None:
-        dist.destroy_process_group()
+    if env.dist is not None:
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
