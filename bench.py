@@ -239,8 +239,9 @@ def roofline_object(kernels, n_samples, n_loc, t_per_tick, heard, cand, ticks_pe
     frac = achieved / HBM_PEAK_GBS
     frac_8d = (b_launch / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None
     if frac > 1.0:
-        raise SystemExit("roofline refused: %s would have moved the launch's required bytes (%d) in %.1f us = %.2f x the HBM peak"
-                         % (dominant, b_req, kern_us, frac))
+        raise SystemExit("roofline refused: %s would have moved the launch's required bytes (%d: %d receivers, %d frames and %d heard links "
+                         "per tick, %d ticks) in %.1f us = %.2f x the HBM peak"
+                         % (dominant, b_req, n_loc, t_per_tick, heard, ticks_per_launch, kern_us, frac))
     seq_us = sum(v["avg_us"] * v["launches_per_sequence"] for v in cont.values())
     launches_per_seq = sum(v["launches_per_sequence"] for v in cont.values())
     share_us = seq_us / max(1, contexts)
@@ -588,8 +589,9 @@ def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
     """Layouts the spatial cull cannot help: 20k nodes, 200 frames per tick, every frame heard by every node -- the reference
     UDGM medium with a range beyond the square's diagonal, and the reference's DEFAULT medium (NullRadioMedium.java:47-77:
     every same-channel node hears everything).  4 M heard links per tick are evaluated in node order (rm_dense.hip), one tick at a
-    time.  Two legs per medium: the tick as it ends by default -- the heard links as lane masks per (frame, 1024 nodes) cell, which
-    IS the result of such a medium (rm_result_dense: a link's rssi and verdict are its packet's) -- and, `_records`, the same tick
+    time.  Two legs per medium: the tick as it ends by default -- ONE launch, the heard links as lane masks per (frame, 1024 nodes)
+    cell, which IS the result of such a medium (rm_result_dense: a link's rssi and verdict are its packet's; offsets and totals
+    are laid out when a reader asks) -- and, `_records`, the same tick
     with its 17-byte records written out every time (RM_DENSE_LAZY=0: 68 MB of record writes per tick)."""
     out = {}
     nodes = W.make_nodes(n, 3)
@@ -631,10 +633,10 @@ def dense_probe(rsa, W, torch, dev, device_ordinal, n=20_000, t=200, ticks=24):
                 e.profile_enable(0)
                 alone = probe_pass(e, st.synchronize, calls[:16])
                 per_tick = el / ticks
-                if leg == "":   # node columns in, lane masks + counts + packet offsets out
-                    req = (n * S_NODE + t * S_TX + t * chunks * (16 * 8 + 4) + (t + 1) * 4,
-                           "N*37 + T*56 in, T x %d cells x (16 lane masks + a count) + the packets' offsets out: the dense tick's own result "
-                           "(rm_result_dense); the records are not written" % chunks)
+                if leg == "":   # node columns in, lane masks + counts out
+                    req = (n * S_NODE + t * S_TX + t * chunks * (16 * 8 + 4),
+                           "N*37 + T*56 in, T x %d cells x (16 lane masks + a count) out: the dense tick's own result (rm_result_dense lays "
+                           "the cells out -- packet offsets, totals -- when it is called; the records are not written)" % chunks)
                 else:
                     req = (n * S_NODE + t * S_TX + heard * (S_REC - 8), "N*37 + T*56 + H*17: 8(d) with 17-byte records (no sinr column)")
                 rl = roofline_object(kernels=kernels, n_samples=n_samples, n_loc=n, t_per_tick=t, heard=heard, cand=0, ticks_per_launch=1,

@@ -32,7 +32,14 @@ constexpr int kOvW = 4;          // new frames per workgroup: one per wave
 constexpr int kOvLinks = 64;     // heard links of the frame handled together (one per lane)
 constexpr int kOvNear = 128;     // near frames gathered between two pair phases
 constexpr int kOvStage = 128;    // surviving pairs a wave holds before it writes them out
-constexpr int kOvPU = 2;         // pairs per lane tested together
+#ifndef RM_OV_PU
+#define RM_OV_PU 1
+#endif
+#ifndef RM_OV_OCC
+#define RM_OV_OCC 6
+#endif
+constexpr int kOvPU = RM_OV_PU;  // pairs per lane tested together (2: 657 instead of 632 us per 128 ticks of configs[4] -- spills at 80 VGPRs)
+constexpr int kOvOcc = RM_OV_OCC; // workgroups of k_ov_pairs per CU the register budget is set for
 static_assert(kOvNear >= 2 * 64, "room for 64 more candidates whenever the list holds at most kOvNear - 64");
 static_assert(kOvStage >= 2 * 64, "room for 64 more pairs whenever the stage holds at most kOvStage - 64");
 static_assert(kOvLinks * kOvNear <= (1 << 16), "pair indices are divided by multiplication");
@@ -220,10 +227,9 @@ RM_D void wave_lds_fence()
 // INLINE: the second go for the frames whose pairs did not all fit the list (OvDev::defer) -- their links' sums are formed
 // from scratch, every surviving pair evaluated where it is found (what k_ov_exact has added for such a frame is discarded).
 template <bool SHADOW, bool INLINE>
-__global__ void __launch_bounds__(256, INLINE ? 2 : 6) k_ov_pairs(const NodesDev nd, const ModelDev m, const OvDev ov)
+__global__ void __launch_bounds__(256, INLINE ? 2 : kOvOcc) k_ov_pairs(const NodesDev nd, const ModelDev m, const OvDev ov)
 {
-    __shared__ float4 s_rxf[kOvW][kOvLinks];   // the links' receivers in the fp32 frame (+ channel bits)
-    __shared__ int s_dst[kOvW][kOvLinks];      // ... node index
+    __shared__ float4 s_rxf[kOvW][kOvLinks];   // the links' receivers in the fp32 frame; .w: the node index's bits (one read per pair)
     __shared__ int s_pos[kOvW][kOvLinks];      // ... engine position
     __shared__ float4 s_ff[kOvW][kOvNear];     // the near frames: pre-filter record at the interference level
     __shared__ float s_inv[kOvW][kOvNear];
@@ -388,7 +394,7 @@ __global__ void __launch_bounds__(256, INLINE ? 2 : 6) k_ov_pairs(const NodesDev
                         pc[u] = c;
                         const float4 f = s_ff[wave][c];
                         const float4 v = s_rxf[wave][l];
-                        const int d = s_dst[wave][l];
+                        const int d = __float_as_int(v.w);
                         const float s2 = dist2_f32(v.x - f.x, v.y - f.y, v.z - f.z);
                         const int fsrc = s_src[wave][c];
                         hit[u] = s2 <= f.w && fsrc != d;
@@ -482,8 +488,8 @@ __global__ void __launch_bounds__(256, INLINE ? 2 : 6) k_ov_pairs(const NodesDev
             tk.hd[o] = hd;
             tk.acc_lo[o] = 0ull;
             tk.acc_hi[o] = 0ull;
-            s_dst[wave][lane] = node;
             s_pos[wave][lane] = pos;
+            rxf.w = __int_as_float(node); // (the channel bits are not looked at here: the link was heard on the frame's channel)
             s_rxf[wave][lane] = rxf;
         }
         n_near = 0;

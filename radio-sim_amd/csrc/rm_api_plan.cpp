@@ -111,7 +111,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
     RM_TRY(ev_flush_append(c)); // (the tick before, if its append was left for a drain that did not come: its records are about to go)
     ts.have_result = false;
     ts.compact_pending = false;
-    ts.dense_pending = ts.dense_result = false;
+    ts.dense_pending = ts.dense_result = ts.dense_layout_pending = false;
     ts.last_n_new = n_new;
     RM_TRY(prepare_nodes(c));
 
@@ -419,6 +419,7 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
         const bool lazy = !(e_lazy && std::atoi(e_lazy) == 0);
         RM_HIP(rm::launch_dense_tick(s, nd, m, t, ts.d_cnt.p, ts.d_off.p, ts.d_dense_mask.p, lazy));
         ts.dense_pending = lazy;
+        ts.dense_layout_pending = lazy;
         ts.dense_result = true;
         ts.dense_rx_first = nd.rx_first;
         ts.dense_chunks = (nd.pos_span + 1023) / 1024;
@@ -551,9 +552,19 @@ int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan)
 }
 
 // the compact packet-major arrays of a tick that so far only has its per-frame segments
+// a dense tick that ended with its cells: their offsets, the packets' offsets, the totals
+int dense_layout(rm_context *c, TickSlot &ts)
+{
+    if (!ts.dense_layout_pending) return RM_OK;
+    RM_HIP(rm::launch_dense_layout(c->stream, ts.last_model, ts.last, ts.d_cnt.p, ts.d_off.p, ts.dense_chunks));
+    ts.dense_layout_pending = false;
+    return RM_OK;
+}
+
 int materialize(rm_context *c, TickSlot &ts)
 {
     if (ts.dense_pending) { // the dense tick's records, from its cells' lane masks
+        RM_TRY(dense_layout(c, ts));
         RM_HIP(rm::launch_dense_write(c->stream, ts.last_model, ts.last, ts.d_cnt.p, ts.d_off.p, ts.d_dense_mask.p, ts.dense_rx_first,
                                       ts.dense_chunks));
         ts.dense_pending = false;

@@ -258,7 +258,8 @@ int result_count(rm_context *c, TickSlot &ts, uint32_t *count, uint32_t *dropped
 {
     if (!ts.have_result) return fail(RM_ERR_STATE, "no evaluated tick");
     RM_HIP(hipSetDevice(c->device));
-    if (!ts.dense_pending) RM_TRY(materialize(c, ts)); // (a dense tick's totals do not wait for its records)
+    if (!ts.dense_pending) RM_TRY(materialize(c, ts)); // (a dense tick's totals do not wait for its records,
+    else RM_TRY(dense_layout(c, ts));                  //  only for its cells' layout)
     uint32_t oc[5];
     RM_HIP(hipMemcpyAsync(oc, ts.last.out_count, sizeof(oc), hipMemcpyDeviceToHost, c->stream));
     RM_HIP(hipStreamSynchronize(c->stream));
@@ -659,6 +660,8 @@ int rm_result_dense(rm_context *c, rm_dense_result *out)
 {
     if (!c || !out) return fail(RM_ERR_INVALID, "NULL argument");
     if (!c->have_result || !c->dense_result) return fail(RM_ERR_STATE, "the last tick did not take the dense form (rm_result_device has its records)");
+    RM_HIP(hipSetDevice(c->device));
+    RM_TRY(dense_layout(c, *c)); // (pkt_offset and count: laid out when the first reader asks)
     out->cell_mask = c->d_dense_mask.p;
     out->cell_count = c->d_cnt.p;
     out->count = c->last.out_count + 2;

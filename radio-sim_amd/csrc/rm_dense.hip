@@ -112,9 +112,23 @@ RM_D rm_tx_record dense_frame(const NodesDev &nd, const TickDev &t, int q)
     return t.src_list ? make_tx_record(nd, t.src_list[q], t.src_start_us, t.src_air_us) : t.tx[t.first_new + q];
 }
 
+// what every tick leaves for the one that follows and for its readers, whichever kernel lays the cells out
+RM_D void dense_tick_tail(const ModelDev &m, const TickDev &t, int tid, int n_threads)
+{
+    for (int i = tid; i < t.shift; i += n_threads) t.slot_off[i] = 0u;
+    write_pkt_interference(m, t, tid, n_threads);
+    // what the sweep's first kernel does for the tick that follows (the other parity's counters start at zero)
+    if (tid < 8) t.next_counters[tid] = 0u;
+    for (int i = tid; i < kShards; i += n_threads) t.next_shard_count[i * kShardStride] = 0u;
+    if (!t.use_matrix)
+        for (int i = tid; i < t.zero_len; i += n_threads) {
+            t.cursor[i] = 0u;
+            t.cand_tot_next[i] = 0u;
+        }
+}
 template <int MODEL>
 __global__ void __launch_bounds__(256)
-k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *cell_cnt, unsigned long long *cell_mask, int chunks)
+k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *cell_cnt, unsigned long long *cell_mask, int chunks, const int with_tail)
 {
     __shared__ uint32_t s_w[kDnFrames][4];
     const int chunk = blockIdx.x, q0 = int(blockIdx.y) * kDnFrames;
@@ -161,22 +175,10 @@ k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *ce
         const int f = threadIdx.x;
         cell_cnt[size_t(q0 + f) * size_t(chunks) + size_t(chunk)] = s_w[f][0] + s_w[f][1] + s_w[f][2] + s_w[f][3];
     }
+    // a tick that ends with its cells (the layout and the records on request): what the tick that follows relies on is left here
+    if (with_tail && blockIdx.x == 0 && blockIdx.y == 0) dense_tick_tail(m, t, threadIdx.x, 256);
 }
 
-// what every tick leaves for the one that follows and for its readers, whichever kernel lays the cells out
-RM_D void dense_tick_tail(const ModelDev &m, const TickDev &t, int tid, int n_threads)
-{
-    for (int i = tid; i < t.shift; i += n_threads) t.slot_off[i] = 0u;
-    write_pkt_interference(m, t, tid, n_threads);
-    // what the sweep's first kernel does for the tick that follows (the other parity's counters start at zero)
-    if (tid < 8) t.next_counters[tid] = 0u;
-    for (int i = tid; i < kShards; i += n_threads) t.next_shard_count[i * kShardStride] = 0u;
-    if (!t.use_matrix)
-        for (int i = tid; i < t.zero_len; i += n_threads) {
-            t.cursor[i] = 0u;
-            t.cand_tot_next[i] = 0u;
-        }
-}
 RM_D void dense_tick_total(const TickDev &t, uint32_t total, int tid, int n_threads)
 {
     const int n_new = t.n_active - t.first_new;
@@ -191,7 +193,7 @@ RM_D void dense_tick_total(const TickDev &t, uint32_t total, int tid, int n_thre
 
 // one workgroup (ticks of more than kDnFusedCells cells): exclusive scan of the cells (frame-major: a frame's chunks in node
 // order), packet offsets, counters
-__global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const TickDev t, const uint32_t *cell_cnt, uint32_t *cell_off, int chunks)
+__global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const TickDev t, const uint32_t *cell_cnt, uint32_t *cell_off, int chunks, const int with_tail)
 {
     __shared__ uint32_t s_wave[16];
     const int n_new = t.n_active - t.first_new;
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const Tic
             v[k] = (i0 + k < cells) ? cell_cnt[i0 + k] : 0u;
             sum += v[k];
         }
-        dense_tick_tail(m, t, threadIdx.x, 1024); // (its loads and stores depend on nothing here: they fly under the scan)
+        if (with_tail) dense_tick_tail(m, t, threadIdx.x, 1024); // (its loads and stores depend on nothing here: they fly under the scan)
         uint32_t total;
         uint32_t run = block_exclusive_scan_1024(sum, s_wave, total);
 #pragma unroll
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(1024) k_dense_scan(const ModelDev m, const Tic
         carry += total;
     }
     dense_tick_total(t, carry, threadIdx.x, 1024);
-    dense_tick_tail(m, t, threadIdx.x, 1024);
+    if (with_tail) dense_tick_tail(m, t, threadIdx.x, 1024);
 }
 
 template <bool FUSED>
@@ -321,10 +323,19 @@ hipError_t launch_dense_write(hipStream_t s, const ModelDev &m, const TickDev &t
     return hipGetLastError();
 }
 
-// lazy_write: the tick ends with its cells -- the heard links of every (frame, 1024 nodes) cell as sixteen lane masks, the cells'
-// counts and offsets, the packets' offsets and the totals (k_dense_scan).  That IS the result of such a medium: a link's rssi is
-// its packet's transmit power, its verdict its packet's; the 17-byte records -- 68 MB for 4 M links -- are written when somebody
-// asks for them (materialize -> launch_dense_write).
+// the cells' layout on its own (a tick that ended with its cells): cell and packet offsets, the totals
+hipError_t launch_dense_layout(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *cell_cnt, uint32_t *cell_off, int chunks)
+{
+    if (t.n_active - t.first_new <= 0 || chunks <= 0) return hipSuccess;
+    RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks, 0);
+    return hipGetLastError();
+}
+
+// lazy_write: the tick ends with its cells -- the heard links of every (frame, 1024 nodes) cell as sixteen lane masks and the
+// cells' counts: ONE launch.  That IS the result of such a medium: a link's rssi is its packet's transmit power, its verdict its
+// packet's.  What is derived from the cells is derived when somebody asks: the layout (cell and packet offsets, totals:
+// launch_dense_layout -- rm_result_dense, rm_result_count) and the 17-byte records, 68 MB for 4 M links (materialize ->
+// launch_dense_write).
 hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off,
                              unsigned long long *cell_mask, bool lazy_write)
 {
@@ -333,20 +344,20 @@ hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &
     if (n_new <= 0 || chunks <= 0) return hipSuccess;
     const dim3 grid_c(chunks, cdiv(n_new, kDnFrames)), grid(chunks, n_new), block(256);
     switch (m.kind) {
-    case RM_MODEL_NULL: RM_KLAUNCH((k_dense_count<RM_MODEL_NULL>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
-    case RM_MODEL_UDGM: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
-    case RM_MODEL_UDGM_CONST: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM_CONST>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
-    case RM_MODEL_N2N: RM_KLAUNCH((k_dense_count<RM_MODEL_N2N>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks); break;
+    case RM_MODEL_NULL: RM_KLAUNCH((k_dense_count<RM_MODEL_NULL>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks, lazy_write ? 1 : 0); break;
+    case RM_MODEL_UDGM: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks, lazy_write ? 1 : 0); break;
+    case RM_MODEL_UDGM_CONST: RM_KLAUNCH((k_dense_count<RM_MODEL_UDGM_CONST>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks, lazy_write ? 1 : 0); break;
+    case RM_MODEL_N2N: RM_KLAUNCH((k_dense_count<RM_MODEL_N2N>), grid_c, block, 0, s, nd, m, t, cell_cnt, cell_mask, chunks, lazy_write ? 1 : 0); break;
     default: return hipErrorInvalidValue;
     }
     // (the count pass's last workgroup laying the cells out itself -- one launch instead of two -- was built and measured: every
     // workgroup's release fence writes its XCD's L2 back, 47 us for the count pass instead of 5.6 + 6.6 for the two launches)
     if (lazy_write) {
-        RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);
+        // (nothing more: the layout is one more launch and a tick's worth of latency that a reader of the masks never needs)
     } else if (long(n_new) * long(chunks) <= long(kDnFusedCells)) {
         RM_KLAUNCH((k_dense_write<true>), grid, block, 0, s, m, t, cell_cnt, cell_off, cell_mask, nd.rx_first, chunks);
     } else {
-        RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks);
+        RM_KLAUNCH(k_dense_scan, dim3(1), dim3(1024), 0, s, m, t, cell_cnt, cell_off, chunks, 1);
         RM_KLAUNCH((k_dense_write<false>), grid, block, 0, s, m, t, cell_cnt, cell_off, cell_mask, nd.rx_first, chunks);
     }
     return hipGetLastError();

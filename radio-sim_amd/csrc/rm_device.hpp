@@ -20,6 +20,12 @@ RM_D float wave_max(float v)
     for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
     return v;
 }
+RM_D int wave_max_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
 
 RM_D float round_up_to_float(double v)
 {

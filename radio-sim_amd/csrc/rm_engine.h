@@ -668,6 +668,7 @@ bool dense_tick_applies(const TickDev &t, const LaunchCfg &cfg, const ModelDev &
 int dense_tick_cells(const NodesDev &nd, const TickDev &t);
 hipError_t launch_dense_tick(hipStream_t s, const NodesDev &nd, const ModelDev &m, const TickDev &t, uint32_t *cell_cnt, uint32_t *cell_off,
                              unsigned long long *cell_mask, bool lazy_write); // cell_mask: 16 lane masks per (frame, chunk) cell
+hipError_t launch_dense_layout(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *cell_cnt, uint32_t *cell_off, int chunks);
 hipError_t launch_dense_write(hipStream_t s, const ModelDev &m, const TickDev &t, const uint32_t *cell_cnt, const uint32_t *cell_off,
                               const unsigned long long *cell_mask, int rx_first, int chunks);
 

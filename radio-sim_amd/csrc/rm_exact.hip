@@ -31,7 +31,10 @@ RM_D void exact_body(const NodesDev &nd, const ModelDev &m, const TickDev &t)
     // A tick whose candidates did not fit the link capacity is reported as RM_ERR_CAPACITY; its shards
     // hold gaps where runs were dropped, so none of its entries is touched (no link of it is reported).
     const bool dropped = t.stage_count[1] != 0u;
-    const uint32_t n_own = dropped ? 0u : min(t.shard_count[(PACKED ? threadIdx.x : blockIdx.y) * kShardStride], t.seg_cap); // kBlock == kShards
+    // (shards beyond the tick's mask are never appended to -- a batch uses 64 of the 256, a receiver partition 8: their counters
+    // are not even read, each is a cache line of its own)
+    const uint32_t sh_own = PACKED ? threadIdx.x : blockIdx.y; // kBlock == kShards
+    const uint32_t n_own = (dropped || sh_own > t.shard_mask) ? 0u : min(t.shard_count[sh_own * kShardStride], t.seg_cap);
     constexpr bool kRegScan = (SEG == 3 || SEG == 4);
     const bool acc_mode = SINR && t.acc_lo != nullptr; // block-uniform: interference summed per receiver, no lists (TickDev::acc_lo)
     if (acc_mode && publisher && t.src_air_us > 0) {

@@ -1110,6 +1110,248 @@ k_filter_wg_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict
     filter_wg_body<RPT, SHADOW>(nd, m, ticks, first, min(per_wg, n_ticks - first));
 }
 
+// The batch filter over the near-frame lists, SIXTEEN ticks at a time (RPT == 4: the large tables the lists are made for).
+// With the lists a workgroup's phase A has a few dozen frames per tick to look at -- a few lanes of one round -- and what a
+// tick cost was what every tick costs whatever its size: three dependent round trips (list length -> list entry -> record),
+// three workgroup barriers and some eighty wave instructions of loop and bookkeeping per wave, 977 workgroups x 128 ticks of
+// them per launch at a million receivers (two thirds of the filter's time there).  Here a wave asks for the lists of FOUR ticks
+// per round (one per unrolled request: its lanes are the list's entries) and the workgroup's four waves for sixteen; the near
+// frames of all of them are compacted into the same LDS list with their tick beside them, and phase B runs over full chunks of
+// 64 near frames of mixed ticks: a frame's candidates go to ITS tick's shards (one allocation per frame and wave, by the lane
+// the frame sits in), through its tick's descriptor.  The tests are filter_wg_tick's, expression for expression; the order of
+// the candidates inside a tick's shards never mattered (the reorder stage sorts).
+constexpr int kGrpTicks = 4 * kWavesPerBlock;
+
+template <bool SHADOW>
+__global__ void __launch_bounds__(kBlock, SHADOW ? 5 : 6)
+k_filter_wg_group(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks, const int n_ticks, const int per_wg)
+{
+    constexpr int RPT = 4;
+    __shared__ float4 s_txf[kNearLds];
+    __shared__ int s_ch[kNearLds];
+    __shared__ int s_e[kNearLds];
+    __shared__ uint16_t s_tk[kNearLds]; // the frame's tick (index into `ticks`: at most RM_MAX_BATCH)
+    __shared__ float s_inv[SHADOW ? kNearLds : 1];
+    __shared__ int s_src[SHADOW ? kNearLds : 1];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kTxChunk][RPT];
+    __shared__ uint32_t s_tbl[SHADOW ? kShadowBins : 1];
+    __shared__ uint32_t s_n;
+
+    const int first = int(blockIdx.z) * per_wg, count = min(per_wg, n_ticks - first);
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    const int wg = blockIdx.x;
+    const int sb = wg / kNearSb;
+    const int slab = wg * kWavesPerBlock + wave;
+    const int jbase = slab * (kGroup * RPT);
+    WgRx<RPT> rx;
+    wg_rx_load<RPT, SHADOW>(nd, ticks[first], rx); // (the receiver tiling is the same for every tick of a launch)
+    const bool live = slab < ticks[first].n_slabs;
+    const int n_rx = ticks[first].n_rx;
+    const float (&fx)[RPT] = rx.fx, (&fy)[RPT] = rx.fy, (&fz)[RPT] = rx.fz;
+    const int (&fch)[RPT] = rx.fch, (&forig)[RPT] = rx.forig;
+    const float4 (&bxy)[RPT] = rx.bxy;
+    const float2 (&bz)[RPT] = rx.bz;
+    const float4 wxy = rx.wxy;
+    const float2 wz = rx.wz;
+    const uint32_t (&bmask)[RPT] = rx.bmask;
+    const uint32_t wmask = rx.wmask;
+
+    if (SHADOW) s_tbl[threadIdx.x] = m.shadow_tbl[threadIdx.x];
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+
+    uint32_t round = 0;
+    for (int b0 = 0; b0 < count; b0 += kGrpTicks) { // block-uniform
+        const int g = min(kGrpTicks, count - b0);
+        // the lists' lengths (every wave reads all sixteen: nothing to agree on through LDS)
+        int cnt_l = 0;
+        if (lane < g) {
+            const TickDev &T = ticks[first + b0 + lane];
+            cnt_l = int(min(T.near_cnt[sb], uint32_t(T.near_cap)));
+        }
+        const int rounds = (uniform_i(wave_max_i(cnt_l)) + 63) >> 6;
+        constexpr int kUnrollA = 4;
+        float4 af[kUnrollA];
+        int ach[kUnrollA], asrc[kUnrollA], ae[kUnrollA];
+        float ainv[kUnrollA];
+        for (int r = 0; r < rounds; ++r) { // block-uniform
+#pragma unroll
+            for (int u = 0; u < kUnrollA; ++u) { // this wave's tick of request u: u * 4 + wave
+                const int tb = u * kWavesPerBlock + wave;
+                const int c = uniform_i(__shfl(cnt_l, tb));
+                const int k = (r << 6) + lane;
+                af[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+                ach[u] = 0;
+                asrc[u] = -1;
+                ainv[u] = 0.f;
+                ae[u] = -1;
+                if (k < c) {
+                    const TickDev &T = ticks[first + b0 + tb];
+                    const int e = T.near_list[size_t(sb) * size_t(T.near_cap) + size_t(k)];
+                    ae[u] = e;
+                    af[u] = T.p_txf[e];
+                    ach[u] = T.p_ch[e];
+                    if (SHADOW) {
+                        ainv[u] = T.p_inv[e];
+                        asrc[u] = T.p_src[e];
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int u = 0; u < kUnrollA; ++u) { // rolled: one copy of phase B; the records are selected, not indexed
+                if (u * kWavesPerBlock >= g) break; // block-uniform
+                float4 tfa = af[0];
+                int cha = ach[0], srca = asrc[0], e = ae[0];
+                float inva = ainv[0];
+#pragma unroll
+                for (int k = 1; k < kUnrollA; ++k) {
+                    tfa.x = (u == k) ? af[k].x : tfa.x;
+                    tfa.y = (u == k) ? af[k].y : tfa.y;
+                    tfa.z = (u == k) ? af[k].z : tfa.z;
+                    tfa.w = (u == k) ? af[k].w : tfa.w;
+                    cha = (u == k) ? ach[k] : cha;
+                    srca = (u == k) ? asrc[k] : srca;
+                    inva = (u == k) ? ainv[k] : inva;
+                    e = (u == k) ? ae[k] : e;
+                }
+                // phase A: this thread's frame against the workgroup box
+                bool hit = false;
+                if (e >= 0) {
+                    const float dx = fmaxf(fmaxf(wxy.x - tfa.x, tfa.x - wxy.z), 0.f);
+                    const float dy = fmaxf(fmaxf(wxy.y - tfa.y, tfa.y - wxy.w), 0.f);
+                    const float dz = fmaxf(fmaxf(wz.x - tfa.z, tfa.z - wz.y), 0.f);
+                    hit = dist2_f32(dx, dy, dz) <= tfa.w && ((wmask >> (uint32_t(cha) & 31u)) & 1u) != 0u; // (nobody here listens on its channel)
+                }
+                const uint64_t hm = ballot64(hit);
+                if (hm) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n, uint32_t(__popcll(hm)));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (hit) {
+                        const uint32_t k = base + lane_prefix(hm);
+                        s_txf[k] = tfa;
+                        s_ch[k] = cha;
+                        s_e[k] = e;
+                        s_tk[k] = uint16_t(first + b0 + u * kWavesPerBlock + wave);
+                        if (SHADOW) {
+                            s_inv[k] = inva;
+                            s_src[k] = srca;
+                        }
+                    }
+                }
+                __syncthreads();
+                const int n_near = uniform_i(int(s_n));
+                const bool last = r + 1 >= rounds && (u + 1 >= kUnrollA || (u + 1) * kWavesPerBlock >= g);
+                if (!last && n_near + kBlock <= kNearLds) continue; // room for another 256 frames
+
+                // phase B: chunks of 64 near frames (of any of the group's ticks), every wave for its own groups
+                if (live) {
+                    for (int c0 = 0; c0 < n_near; c0 += kTxChunk) {
+                        const int nt = min(kTxChunk, n_near - c0);
+                        uint64_t near[RPT];
+                        uint64_t todo = 0;
+                        {
+                            const float4 tf = s_txf[c0 + min(lane, nt - 1)];
+                            const uint32_t tchb = uint32_t(s_ch[c0 + min(lane, nt - 1)]) & 31u;
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) {
+                                near[q] = 0;
+                                if ((slab * RPT + q) * kGroup < n_rx) {
+                                    const float dx = fmaxf(fmaxf(bxy[q].x - tf.x, tf.x - bxy[q].z), 0.f);
+                                    const float dy = fmaxf(fmaxf(bxy[q].y - tf.y, tf.y - bxy[q].w), 0.f);
+                                    const float dz = fmaxf(fmaxf(bz[q].x - tf.z, tf.z - bz[q].y), 0.f);
+                                    near[q] = ballot64(lane < nt && dist2_f32(dx, dy, dz) <= tf.w && ((bmask[q] >> tchb) & 1u) != 0u);
+                                }
+                                todo |= near[q];
+                            }
+                        }
+                        uint32_t my_total = 0;
+                        uint64_t walk = todo;
+                        while (walk) {
+                            const int ti = __ffsll((long long)walk) - 1; // wave-uniform
+                            walk &= walk - 1;
+                            const float4 tf = s_txf[c0 + ti];
+                            const int tch = s_ch[c0 + ti];
+                            uint64_t mask[RPT];
+                            uint32_t total = 0;
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) {
+                                mask[q] = 0;
+                                if ((near[q] >> ti) & 1ull) {
+                                    const float s2 = dist2_f32(fx[q] - tf.x, fy[q] - tf.y, fz[q] - tf.z);
+                                    bool h = (s2 <= tf.w) && (fch[q] == tch);
+                                    if (SHADOW && h) {
+                                        const int bin = min(kShadowBins - 1, int(s2 * s_inv[c0 + ti]));
+                                        const uint32_t a = uint32_t(s_src[c0 + ti]), bb = uint32_t(forig[q]);
+                                        const uint64_t key = (uint64_t(a < bb ? a : bb) << 32) | uint64_t(a < bb ? bb : a);
+                                        h = uint32_t(mix64(m.ld_seed_mixed ^ key) >> 32) <= s_tbl[bin];
+                                    }
+                                    mask[q] = ballot64(h);
+                                    total += uint32_t(__popcll(mask[q]));
+                                }
+                            }
+                            if (total) {
+                                if (lane == ti) my_total = total;
+                                if (lane < RPT) {
+                                    uint64_t v = mask[0];
+#pragma unroll
+                                    for (int q = 1; q < RPT; ++q) v = (lane == q) ? mask[q] : v;
+                                    s_mask[wave][ti][lane] = v;
+                                }
+                            }
+                        }
+                        uint64_t have = ballot64(my_total != 0u);
+                        if (have == 0) continue;
+                        // the lane of a frame with candidates: its tick's counters and shards
+                        uint32_t my_base = 0;
+                        if (my_total != 0u) {
+                            const int my_e = s_e[c0 + lane];
+                            const int my_tk = int(s_tk[c0 + lane]);
+                            const TickDev &T = ticks[my_tk];
+                            if (!T.use_matrix && T.first_eval + my_e >= T.first_new) atomicAdd(&T.cand_tot[my_e - T.cnt_base], my_total);
+                            const uint32_t shard = (uint32_t(slab) + (round + uint32_t(c0 >> 6)) * 37u + uint32_t(my_tk) * 101u + uint32_t(lane) * 7u) & T.shard_mask;
+                            const uint32_t base = atomicAdd(&T.shard_count[shard * kShardStride], my_total);
+                            if (base + my_total > T.seg_cap) { // the shard is full: drop the run, flag the tick
+                                T.stage_count[1] = 1u;
+                                my_total = 0u;
+                            }
+                            my_base = shard * T.seg_cap + base;
+                        }
+                        have = ballot64(my_total != 0u);
+                        walk = have;
+                        while (walk) {
+                            const int ti = __ffsll((long long)walk) - 1;
+                            walk &= walk - 1;
+                            const uint32_t fbase = uniform_u(uint32_t(__shfl(int(my_base), ti)));
+                            const int e_ti = s_e[c0 + ti];
+                            const TickDev &T = ticks[uniform_i(int(s_tk[c0 + ti]))];
+                            uint32_t pre = 0;
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) {
+                                const uint64_t mk = s_mask[wave][ti][q];
+                                if (mk == 0) continue;
+                                if ((mk >> lane) & 1ull) {
+                                    const uint32_t idx = fbase + pre + lane_prefix(mk);
+                                    T.st_pkt[idx] = e_ti;
+                                    T.st_dst[idx] = jbase + q * kGroup + lane;
+                                    if (T.use_matrix) T.st_blk[idx] = fbase; // the run's base: only the ordered scatter of unsorted tables ranks inside it
+                                }
+                                pre += uint32_t(__popcll(mk));
+                            }
+                        }
+                    }
+                }
+                round += uint32_t(kNearLds / kTxChunk);
+                __syncthreads(); // every wave is done with the LDS records
+                if (threadIdx.x == 0) s_n = 0u;
+                __syncthreads();
+                if (last) break;
+            }
+        }
+    }
+}
+
 // ============================================================================ launchers
 
 hipError_t launch_patch_nodes(hipStream_t s, const NodesDev &nd, const NodePatch *dev_list, int n, const NodePatch &one)
@@ -1268,7 +1510,19 @@ hipError_t launch_filter_batch(hipStream_t s, const NodesDev &nd, const ModelDev
     const int tiles = cdiv(t0.n_slabs, kWavesPerBlock);
     const int per_wg = filter_ticks_per_wg(t0, n);
     const dim3 grid(tiles, 1, cdiv(n, per_wg)), block(kBlock);
-    if (t0.rpt == 4) {
+    // The lists of sixteen ticks at a time pay where a list is a few dozen frames -- many blocks (a million receivers), or few
+    // frames for this partition's part of the plane; with lists of hundreds of frames (configs[2] / [3] at 100 k receivers: seven
+    // blocks) a round of the per-tick form is already full and the grouped one was measured 6 % / 13 % slower.
+    // RM_FILTER_GROUP=0 / 1: never / whenever the launch allows it (read per launch: tests).
+    const char *e_grp = getenv("RM_FILTER_GROUP");
+    const int n_sb = cdiv(tiles, kNearSb);
+    const double seen = double(max_eval) * fmin(1.0, 1.3 * double(t0.n_rx) / double(max(nd.n, 1)) + 0.02); // frames this partition keeps
+    bool group = n_sb >= 32 || seen * 1.5 / double(n_sb) <= 128.0;
+    if (e_grp) group = atoi(e_grp) != 0;
+    if (t0.rpt == 4 && t0.near_list != nullptr && per_wg > 1 && group) {
+        if (cfg.shadow) RM_KLAUNCH((k_filter_wg_group<true>), grid, block, 0, s, nd, m, b, n, per_wg);
+        else RM_KLAUNCH((k_filter_wg_group<false>), grid, block, 0, s, nd, m, b, n, per_wg);
+    } else if (t0.rpt == 4) {
         if (cfg.shadow) RM_KLAUNCH((k_filter_wg_batch<4, true>), grid, block, 0, s, nd, m, b, n, per_wg);
         else RM_KLAUNCH((k_filter_wg_batch<4, false>), grid, block, 0, s, nd, m, b, n, per_wg);
     } else if (t0.rpt == 2) {

@@ -131,6 +131,7 @@ struct TickSlot {
     // the dense tick (rm_dense.hip) leaves the heard links as lane masks per (frame, 1024 nodes) cell: the records are written
     // when somebody asks for them (materialize); rm_result_dense hands out the masks themselves
     bool dense_pending = false, dense_result = false;
+    bool dense_layout_pending = false; // ... and so are the cells' offsets and the totals (dense_layout)
     int dense_rx_first = 0, dense_chunks = 0;
     rm::ModelDev last_model{};
     rm::LaunchCfg last_cfg{};
@@ -454,6 +455,7 @@ int prepare_tick(rm_context *c, TickSlot &ts, TickPlan &plan, bool want_wg, cons
                  int air_mode = kAirNone, uint32_t air_oldest = 0, const rm::PlanKnobs *knobs_in = nullptr);
 int launch_tick(rm_context *c, TickSlot &ts, const TickPlan &plan);
 int materialize(rm_context *c, TickSlot &ts);
+int dense_layout(rm_context *c, TickSlot &ts); // (the cells' offsets and totals of a dense tick that ended with its cells)
 int run_tick(rm_context *c, const rm_tx_record *tx, int n_active, int first_new, const int32_t *src_list = nullptr,
              int64_t src_start_us = 0, int64_t src_air_us = 0, int air_mode = kAirNone, uint32_t air_oldest = 0, bool ev_may_wait = false);
 int drain_profile(rm_context *c);

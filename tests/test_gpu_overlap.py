@@ -389,6 +389,43 @@ def test_receivers_that_move_while_selected_frames_are_on_the_air(rsa, O):
             e.close()
 
 
+def test_a_batch_refused_late_leaves_the_window_where_it_was(rsa, O):
+    """A batch can be refused after its ticks were planned (here: a tick of more than 8192 frames), with the advice to run the
+    ticks one at a time.  The frames of the batch before are then still on the air for the EARLIER ticks of the refused batch:
+    the window's clock must not have moved to the batch's last tick, or the first lone tick would retire them (clock went back)
+    and their interference would be lost without a word.  Every lone tick after the refusal against the oracle."""
+    n = 30_000
+    nd, rng = _nodes(O, n, seed=9)
+    params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 5}
+    eng = _engine(rsa, nd, params, cap=1 << 24)
+    dev = []
+    try:
+        rep = Replay(O, nd, params)
+        first = [np.sort(rng.choice(n, 300, replace=False)).astype(np.int32) for _ in range(3)]
+        starts, _ = _run_batch(eng, dev, first, 0, 2500)            # frames end at 2500, 3500, 4500
+        for b in range(3):
+            _same(eng.batch_result_copy(b, 300), rep.tick(starts[b], first[b], starts[b], 2500), "first batch, tick %d" % b)
+        second = [np.sort(rng.choice(n, t, replace=False)).astype(np.int32) for t in (300, 300, 8200)]
+        with pytest.raises(rsa.RadioMediumError) as e:
+            _run_batch(eng, dev, second, 3000, 2500)
+        assert e.value.code == -5 and "one at a time" in str(e.value)
+        interfered = 0
+        for b, srcs in enumerate(second):
+            t0 = 3000 + b * TICK
+            d = DeviceArray(srcs)
+            dev.append(d)
+            eng.tick_run_sources_device(t0, t0 + TICK, d.ptr.value, len(srcs), t0, 2500)
+            cpu = rep.tick(t0, srcs, t0, 2500)
+            _same(eng.result_copy(len(srcs)), cpu, "lone tick %d after the refusal" % b)
+            if b < 2:      # (what the frames of the first batch, still on the air, do to the refused batch's earlier ticks)
+                interfered += int((cpu.verdict == O.INTERFERED).sum())
+        assert interfered > 20
+    finally:
+        for d in dev:
+            d.free()
+        eng.close()
+
+
 def test_refusals(rsa, O):
     """ticks out of time order and links that draw are refused (RM_ERR_STATE), nothing is left half done"""
     n = 5000
