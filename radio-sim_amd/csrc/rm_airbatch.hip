@@ -39,7 +39,7 @@ constexpr int kOvStage = 128;    // surviving pairs a wave holds before it write
 #define RM_OV_OCC 6
 #endif
 constexpr int kOvPU = RM_OV_PU;  // pairs per lane tested together (2: 657 instead of 632 us per 128 ticks of configs[4] -- spills at 80 VGPRs)
-constexpr int kOvOcc = RM_OV_OCC; // workgroups of k_ov_pairs per CU the register budget is set for
+constexpr int kOvOcc = RM_OV_OCC; // workgroups of k_ov_pairs per CU the register budget is set for (with a resident grid of as many: 4 / 5 / 6 / 7 -> 724 / 649 / 627 / 707 us per 128 ticks of configs[4]; 7 spills 25 VGPRs)
 static_assert(kOvNear >= 2 * 64, "room for 64 more candidates whenever the list holds at most kOvNear - 64");
 static_assert(kOvStage >= 2 * 64, "room for 64 more pairs whenever the stage holds at most kOvStage - 64");
 static_assert(kOvLinks * kOvNear <= (1 << 16), "pair indices are divided by multiplication");
@@ -651,7 +651,7 @@ hipError_t launch_ov_sinr(hipStream_t s, const NodesDev &nd, const ModelDev &m, 
     const bool sh = cfg.shadow && m.shadow_tbl;
     if (sh) RM_KLAUNCH((k_ov_pairs<true, false>), grid, block, 0, s, nd, m, ov);
     else RM_KLAUNCH((k_ov_pairs<false, false>), grid, block, 0, s, nd, m, ov);
-    int gx = 8;
+    int gx = 16; // (workgroups per shard; measured on configs[4], 128 ticks: 4 / 8 / 16 / 32 / 64 -> 475 / 440 / 389 / 387 / 386 us; a rank's share at 512: 2 / 8 / 16 -> 366 / 225 / 198)
     if (const char *e = getenv("RM_OV_EXACT_GX")) gx = max(1, atoi(e));
     RM_KLAUNCH(k_ov_exact, dim3(gx, kShards), dim3(256), 0, s, nd, m, ov);
     // the frames whose pairs did not fit the list (none, normally: the grid leaves at once -- one workgroup per CU, so that

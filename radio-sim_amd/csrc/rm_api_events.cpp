@@ -248,10 +248,18 @@ int rm_events_process(rm_context *c, int64_t time_us, rm_delivery_view *out)
         RM_HIP(rm::launch_ev_drain(c->stream, ev_dev(c), o, time_us, seq, uint32_t(std::min<int64_t>(std::max<int64_t>(window, 1), 0x7FFFFFFF))));
     }
     c->current_time = time_us; // Simulator.java:156
-    volatile const uint32_t *flag = &o.hdr->seq;
+    // (the header's four quarters carry the drain's number each, rm::EvHeader: all four have to have arrived)
+    const uint32_t *const f0 = &o.hdr->seq, *const f1 = &o.hdr->seq1, *const f2 = &o.hdr->seq2, *const f3 = &o.hdr->seq3;
+    auto arrived = [&]() {
+        return __atomic_load_n(f0, __ATOMIC_ACQUIRE) == seq && __atomic_load_n(f1, __ATOMIC_ACQUIRE) == seq &&
+               __atomic_load_n(f2, __ATOMIC_ACQUIRE) == seq && __atomic_load_n(f3, __ATOMIC_ACQUIRE) == seq;
+    };
     bool seen = false;
-    for (int spin = 0; spin < 400000 && !seen; ++spin) seen = (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq);
-    if (!seen) RM_HIP(hipStreamSynchronize(c->stream));
+    for (int spin = 0; spin < 400000 && !seen; ++spin) seen = arrived();
+    if (!seen) {
+        RM_HIP(hipStreamSynchronize(c->stream));
+        if (!arrived()) return fail(RM_ERR_HIP, "the drain finished without its header");
+    }
     out->count = o.hdr->count;
     out->pending_packets = o.hdr->pending_packets;
     out->oldest_packet = o.hdr->oldest_packet;

@@ -113,10 +113,10 @@ RM_D rm_tx_record dense_frame(const NodesDev &nd, const TickDev &t, int q)
 }
 
 // what every tick leaves for the one that follows and for its readers, whichever kernel lays the cells out
-RM_D void dense_tick_tail(const ModelDev &m, const TickDev &t, int tid, int n_threads)
+RM_D void dense_tick_tail(const ModelDev &m, const TickDev &t, int tid, int n_threads, bool with_interference = true)
 {
     for (int i = tid; i < t.shift; i += n_threads) t.slot_off[i] = 0u;
-    write_pkt_interference(m, t, tid, n_threads);
+    if (with_interference) write_pkt_interference(m, t, tid, n_threads);
     // what the sweep's first kernel does for the tick that follows (the other parity's counters start at zero)
     if (tid < 8) t.next_counters[tid] = 0u;
     for (int i = tid; i < kShards; i += n_threads) t.next_shard_count[i * kShardStride] = 0u;
@@ -149,6 +149,10 @@ k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *ce
         if (chunk == 0 && t.check_txprob && tx.src >= 0 && tx.txprob > 0.0 && tx.txprob < 1.0) t.stage_count[6] = 2u;
         s_tx[threadIdx.x] = tx;
         s_sid[threadIdx.x] = (MODEL == RM_MODEL_N2N && tx.src >= 0) ? nd.sint_id[tx.src] : 0;
+        if (with_tail && chunk == 0) { // the packet's Tx-failure flag, from the record in hand (write_pkt_interference's expression)
+            const bool draws_possible = (m.kind == RM_MODEL_UDGM || m.kind == RM_MODEL_N2N || m.kind == RM_MODEL_LOGDIST);
+            t.pkt_interference[q] = (draws_possible && tx_success(m, tx) <= 0.0) ? 1 : 0;
+        }
     }
     DnNode node[kDnPer];
 #pragma unroll
@@ -176,7 +180,7 @@ k_dense_count(const NodesDev nd, const ModelDev m, const TickDev t, uint32_t *ce
         cell_cnt[size_t(q0 + f) * size_t(chunks) + size_t(chunk)] = s_w[f][0] + s_w[f][1] + s_w[f][2] + s_w[f][3];
     }
     // a tick that ends with its cells (the layout and the records on request): what the tick that follows relies on is left here
-    if (with_tail && blockIdx.x == 0 && blockIdx.y == 0) dense_tick_tail(m, t, threadIdx.x, 256);
+    if (with_tail && blockIdx.x == 0 && blockIdx.y == 0) dense_tick_tail(m, t, threadIdx.x, 256, false); // (the flags: by the frames' own workgroups, above)
 }
 
 RM_D void dense_tick_total(const TickDev &t, uint32_t total, int tid, int n_threads)

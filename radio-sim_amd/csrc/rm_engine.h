@@ -470,7 +470,11 @@ struct EvState {
     EvTails tails[2];
     // (its own 128-byte line: k_ev_select's workgroups add to n_groups and take minima here at the same time)
     alignas(128) uint32_t first_live; // window index of the oldest packet with events still queued (0xFFFFFFFF: none)
+    // k_ev_apply's "last workgroup" count in two levels: 512 workgroups that finish together on ONE word were six microseconds of
+    // atomics in a row (a word takes ~88 per microsecond); sixteen words, a line each, then one (kEvDoneSub)
+    alignas(128) uint32_t done_sub[16 * 32];
 };
+constexpr int kEvDoneSub = 16;
 
 struct EvDev {
     EvState *st;
@@ -508,17 +512,22 @@ struct EvLinkSrc {
 };
 
 // the delivery list of one drain in host-mapped memory
+// Four quarters of 16 bytes, each written by ONE 16-byte store and each carrying the drain's sequence number: a quarter whose
+// number is the expected one is complete (a store of 16 aligned bytes arrives as a whole), so the device need not wait for the
+// fields to be acknowledged before it writes "the" number -- the host waits for all four (rm_events_process).
 struct EvHeader {
+    uint32_t seq;        // quarter 0
     uint32_t count;      // deliveries written
     uint32_t total;      // deliveries of the drain (count < total: the block was too small)
     uint32_t err;
+    uint32_t seq1;       // quarter 1
     uint32_t pending_packets;
-    int64_t next_packet; // number the next transmitted packet gets
-    int64_t time;
-    uint32_t seq;        // written last
     uint32_t runs;       // runs of the delivery list (one per packet that delivers in this drain)
+    uint32_t pad1;
+    uint32_t seq2, pad2; // quarter 2
+    int64_t next_packet; // number the next transmitted packet gets
+    uint32_t seq3, pad3; // quarter 3
     int64_t oldest_packet; // number of the oldest packet with events still queued (== next_packet: none)
-    uint32_t pad[4];
 };
 static_assert(sizeof(EvHeader) == 64, "one line of host-mapped memory");
 // (the deliveries of one fired end group -- one packet -- are adjacent in the list: the packet number is sent once per run,

@@ -354,10 +354,25 @@ RM_D void ev_write_deliveries(const EvDev &e, const EvOut &out, const int64_t gs
 // k_ev_emit: one wave per fired group: its place in the pop order, and every event's (rank, event) key to the fields of
 // the node it touches (the last-writer contest).  The deliveries themselves are written by k_ev_apply: they depend on
 // nothing the contest decides, and their stores into host-mapped memory (PCIe-bound) then run under the state update.
-__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out, const int share)
+__global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out, const int share, const int lds_keys)
 {
     const uint32_t G = min(e.st->n_groups, e.g_cap);
     const int lane = threadIdx.x & 63;
+    // the groups' keys, once per workgroup: every wave's pass below reads all of them, and four waves fetching the same 40 KB
+    // from the L2 each was most of the pass (a closed-loop drain has ~2000 groups; more than kEmitKeys: the pass reads global memory)
+    constexpr uint32_t kEmitKeys = 2048;
+    __shared__ int64_t s_time[kEmitKeys];
+    __shared__ uint64_t s_meta[kEmitKeys];
+    __shared__ uint32_t s_cnt[kEmitKeys];
+    const bool in_lds = lds_keys != 0 && G <= kEmitKeys;
+    if (in_lds && blockIdx.x * 4u < G) {
+        for (uint32_t k = threadIdx.x; k < G; k += 256u) {
+            s_time[k] = e.g_time[k];
+            s_meta[k] = e.g_meta[k];
+            s_cnt[k] = e.cnt_by_rank[k];
+        }
+    }
+    __syncthreads();
     for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
         const uint32_t ref = uniform_u(e.g_ref[g]);
         // (the packet's fields and its first 64 links' nodes are asked for here, in front of the pass over the keys: they
@@ -388,9 +403,9 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out,
         // keys (a few thousand, L2-resident) -- no sort, no scan, no launch in between.
         uint32_t r = 0, first = 0, run = 0;
         {
-            const int64_t tg = e.g_time[g];
-            const uint64_t mg = e.g_meta[g];
-            for (uint32_t k0 = 0; k0 < G; k0 += 64 * 8) { // eight groups per lane in flight: the pass is a chain of L2 round trips
+            const int64_t tg = in_lds ? s_time[g] : e.g_time[g];
+            const uint64_t mg = in_lds ? s_meta[g] : e.g_meta[g];
+            for (uint32_t k0 = 0; k0 < G; k0 += 64 * 8) { // eight groups per lane in flight: from global memory the pass is a chain of L2 round trips
                 int64_t tk[8];
                 uint64_t mk[8];
                 uint32_t ck[8];
@@ -398,9 +413,15 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out,
                 for (int u = 0; u < 8; ++u) {
                     const uint32_t k = k0 + uint32_t(u) * 64u + uint32_t(lane);
                     const bool in = k < G;
-                    tk[u] = in ? e.g_time[k] : int64_t(0x7FFFFFFFFFFFFFFFll);
-                    mk[u] = in ? e.g_meta[k] : ~0ull;
-                    ck[u] = in ? e.cnt_by_rank[k] : 0u;
+                    if (in_lds) { // (wave-uniform)
+                        tk[u] = in ? s_time[k] : int64_t(0x7FFFFFFFFFFFFFFFll);
+                        mk[u] = in ? s_meta[k] : ~0ull;
+                        ck[u] = in ? s_cnt[k] : 0u;
+                    } else {
+                        tk[u] = in ? e.g_time[k] : int64_t(0x7FFFFFFFFFFFFFFFll);
+                        mk[u] = in ? e.g_meta[k] : ~0ull;
+                        ck[u] = in ? e.cnt_by_rank[k] : 0u;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -537,7 +558,16 @@ __global__ void __launch_bounds__(256) k_ev_apply(const EvDev e, const EvOut out
         // header's sequence number: every storing wave drains its stores before the workgroup reports in)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) s_lastwg = (atomicAdd(&e.st->done_apply, 1u) == gridDim.x - 1u) ? 1u : 0u;
+        if (threadIdx.x == 0) { // two levels (EvState::done_sub): the last of its sixteenth reports to the one word
+            const uint32_t sub = blockIdx.x & uint32_t(kEvDoneSub - 1);
+            const uint32_t in_sub = (gridDim.x - sub + uint32_t(kEvDoneSub - 1)) / uint32_t(kEvDoneSub); // workgroups with this residue
+            uint32_t last = 0u;
+            if (atomicAdd(&e.st->done_sub[sub * 32u], 1u) == in_sub - 1u) {
+                e.st->done_sub[sub * 32u] = 0u;
+                last = (atomicAdd(&e.st->done_apply, 1u) == min(gridDim.x, uint32_t(kEvDoneSub)) - 1u) ? 1u : 0u;
+            }
+            s_lastwg = last;
+        }
         __syncthreads();
         if (!s_lastwg) return;
         if (threadIdx.x == 0) e.st->done_apply = 0u;
@@ -552,6 +582,37 @@ RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t s
     EvState &st = *e.st;
     const EvTails tl = st.tails[e.par];
     const uint32_t head = st.pk_head, tail = tl.pk_tail;
+    // thread 0's part first -- loads that depend on each other (the ring heads, the oldest packet still queued) -- so that it
+    // flies under the copy of the runs and its wait, not behind them
+    uint32_t total = 0, runs = 0, err = 0, new_head = 0;
+    int64_t oldest = 0;
+    if (threadIdx.x == 0) {
+        // ring heads: up to the oldest packet that still had events queued when this drain began (k_ev_select)
+        const uint32_t live = st.first_live;
+        st.first_live = 0xFFFFFFFFu;
+        new_head = head + min(live, tail - head);
+        st.pk_head = new_head;
+        st.pool_head = (new_head == tail) ? tl.pool_tail
+                                          : __hip_atomic_load(&e.pk[new_head & e.pk_mask].link_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        EvOrder o;
+        o.top_start = st.top_start;
+        o.top_max = st.top_max;
+        o.ladders = st.ladders;
+        o.top_nonempty = (st.top_max != kI64Min) ? 1 : 0;
+        ev_drain(o, T);
+        st.top_start = o.top_start;
+        st.ladders = o.ladders;
+        if (!o.top_nonempty) st.top_max = kI64Min;
+        st.t_prev = T;
+        total = st.n_deliv;
+        runs = __hip_atomic_load(&st.n_dgroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st.n_groups > e.g_cap) st.err |= 4u;
+        err = st.err | tl.err;
+        // the ring head's own number: a tick that did not fit the rings was numbered but left nothing here, so
+        // "next - pending" would skip packets that are still queued
+        oldest = (new_head == tail) ? tl.gseq_next
+                                    : __hip_atomic_load(&e.pk[new_head & e.pk_mask].gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     { // the runs of the delivery list, from where the groups' waves left them: one coalesced copy to the host
         const uint32_t runs_all = min(__hip_atomic_load(&st.n_dgroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), out.run_cap);
         for (uint32_t r = threadIdx.x; r < runs_all; r += blockDim.x) {
@@ -565,49 +626,26 @@ RM_D void ev_finish_body(const EvDev &e, const EvOut &out, int64_t T, uint32_t s
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    // ring heads: up to the oldest packet that still had events queued when this drain began (k_ev_select)
-    const uint32_t live = st.first_live;
-    st.first_live = 0xFFFFFFFFu;
-    const uint32_t new_head = head + min(live, tail - head);
-    st.pk_head = new_head;
-    st.pool_head = (new_head == tail) ? tl.pool_tail
-                                      : __hip_atomic_load(&e.pk[new_head & e.pk_mask].link_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    EvOrder o;
-    o.top_start = st.top_start;
-    o.top_max = st.top_max;
-    o.ladders = st.ladders;
-    o.top_nonempty = (st.top_max != kI64Min) ? 1 : 0;
-    ev_drain(o, T);
-    st.top_start = o.top_start;
-    st.ladders = o.ladders;
-    if (!o.top_nonempty) st.top_max = kI64Min;
-    st.t_prev = T;
-    const uint32_t total = st.n_deliv, runs = st.n_dgroups;
-    if (st.n_groups > e.g_cap) st.err |= 4u;
     st.n_groups = 0u;
     st.n_deliv = 0u;
     st.n_dgroups = 0u;
-    // The header lives in host-mapped memory: write-through stores, drained, then the sequence number the host
-    // polls.  (A system-scope release fence here would also write back every dirty line the drain's kernels left in
-    // this XCD's L2 -- microseconds, and nothing the host reads: the delivery records were stored by an earlier
-    // launch.)
-    __hip_atomic_store(&out.hdr->count, min(total, out.cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out.hdr->total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out.hdr->runs, min(runs, out.run_cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out.hdr->err, st.err | tl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out.hdr->pending_packets, tail - new_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out.hdr->next_packet, tl.gseq_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // the ring head's own number: a tick that did not fit the rings was numbered but left nothing here, so
-    // "next - pending" would skip packets that are still queued
-    const int64_t oldest = (new_head == tail) ? tl.gseq_next
-                                              : __hip_atomic_load(&e.pk[new_head & e.pk_mask].gseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&out.hdr->oldest_packet, oldest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // an overflow is reported by the drain that follows it, once: the rings take the next ticks again
     st.err = 0u;
     st.tails[e.par].err = 0u;
-    __hip_atomic_store(&out.hdr->time, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&out.hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // The header lives in host-mapped memory: four 16-byte stores, each with the sequence number the host polls (EvHeader) --
+    // no waiting between the fields and "the" number.  (Nor a system-scope release fence: it would also write back every dirty
+    // line the drain's kernels left in this XCD's L2 -- microseconds, and nothing the host reads: the delivery records and
+    // the runs were stored, and waited for, before this.)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 *const q = reinterpret_cast<u32x4 *>(out.hdr);
+    auto store16 = [](u32x4 *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { // one write-through store of 16 bytes at system scope
+        const u32x4 v = {a, b, c, d};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    };
+    store16(q + 0, seq, min(total, out.cap), total, err);
+    store16(q + 1, seq, tail - new_head, min(runs, out.run_cap), 0u);
+    store16(q + 2, seq, 0u, uint32_t(uint64_t(tl.gseq_next)), uint32_t(uint64_t(tl.gseq_next) >> 32));
+    store16(q + 3, seq, 0u, uint32_t(uint64_t(oldest)), uint32_t(uint64_t(oldest) >> 32));
 }
 
 // ============================================================================ node-info
@@ -753,7 +791,8 @@ hipError_t launch_ev_drain(hipStream_t s, const EvDev &e, const EvOut &out, int6
         RM_KLAUNCH(k_ev_select, dim3(cdiv(int(w), 256)), dim3(256), 0, s, e, time_us);
     }
     static const int share = [] { const char *v = getenv("RM_EV_SHARE"); return v ? atoi(v) : 2; }(); // (0: every delivery from k_ev_apply)
-    RM_KLAUNCH(k_ev_emit, dim3(512), dim3(256), 0, s, after, out, share);
+    static const int lds_keys = [] { const char *v = getenv("RM_EV_EMIT_LDS"); return v ? atoi(v) : 1; }(); // (0: the rank pass reads global memory)
+    RM_KLAUNCH(k_ev_emit, dim3(512), dim3(256), 0, s, after, out, share, lds_keys);
     RM_KLAUNCH(k_ev_apply, dim3(512), dim3(256), 0, s, after, out, time_us, seq, share);
     return hipGetLastError();
 }

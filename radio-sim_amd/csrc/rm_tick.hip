@@ -59,8 +59,20 @@ RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
     return dist2_f32(dx, dy, dz) <= f.w;
 }
 
+// Which frame does workgroup b take?  The hardware deals workgroups to the eight XCDs in turn (b % 8), each with its own L2.  With
+// xcd_map the frames of a tick are dealt in EIGHTHS instead -- XCD x takes the x-th eighth of the slots -- so that, where the
+// caller's frame order is a spatial order (node ids assigned along a space-filling curve), the frames that share receiver groups
+// share an L2 as well and a group's records leave HBM for one XCD, not for up to eight (RM_TICK_XCD_MAP=1; a pure renaming of
+// the workgroups: every slot is still taken exactly once).
+RM_D int xcd_slot(const int b, const int n)
+{
+    const int per = n >> 3, rem = n & 7, x = b & 7;
+    return x * per + min(x, rem) + (b >> 3);
+}
+
 template <int MODEL, bool STOCH, bool SHADOW, bool FLAT, bool SINR = false>
-RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev &t, const int seg_len, const ScanDev *sdp = nullptr)
+RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev &t, const int seg_len, const ScanDev *sdp = nullptr,
+                           const int xcd_map = 0)
 {
     // one LDS block, carved by hand: the lists are dead when a frame that outgrew its segment orders its links,
     // and that ordering wants all of it for a bitmap over the node indices (below)
@@ -78,7 +90,7 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
     __shared__ uint32_t s_n1[2], s_n2[2], s_nc[2], s_nres, s_base; // the lists' fill counts, by round parity
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
-    const int slot = blockIdx.x;
+    const int slot = (xcd_map && int(blockIdx.x) < t.n_cnt) ? xcd_slot(int(blockIdx.x), t.n_cnt) : int(blockIdx.x);
     const int n_new = t.n_active - t.first_new;
     const int n_groups = (nd.n_rx + kGroup - 1) / kGroup;
     const int n_boxes = (n_groups + 15) / 16;
@@ -551,9 +563,9 @@ RM_D void tick_frames_body(const NodesDev &nd, const ModelDev &m, const TickDev 
 }
 
 template <int MODEL, bool STOCH, bool SHADOW, bool FLAT>
-__global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len)
+__global__ void __launch_bounds__(256) k_tick_frames(const NodesDev nd, const ModelDev m, const TickDev t, const int seg_len, const int xcd_map)
 {
-    tick_frames_body<MODEL, STOCH, SHADOW, FLAT>(nd, m, t, seg_len);
+    tick_frames_body<MODEL, STOCH, SHADOW, FLAT>(nd, m, t, seg_len, nullptr, xcd_map);
 }
 
 // ... and as the first launch of the SINR medium's tick by scan (rm_airscan.hip): the heard links as the medium without SINR
@@ -914,14 +926,16 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     dim3 grid(t.n_cnt);
     const dim3 block(256);
     const int n_groups = cdiv(nd.n_rx, kGroup);
+    const char *e_xcd = getenv("RM_TICK_XCD_MAP"); // (read per tick: tests and experiments switch it)
+    const int xcd_map = (e_xcd && atoi(e_xcd) != 0) ? 1 : 0;
     static const int flat_max = [] {
         const char *e = getenv("RM_FR_FLAT_MAX");
         return e ? max(0, min(kFrGroups * 2, atoi(e))) : kFrFlatGroups;
     }();
 #define RM_FR2(M_, MODEL, ST, SH)                                                                                      \
     do {                                                                                                               \
-        if (n_groups <= flat_max) RM_KLAUNCH((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, M_, t, seg_len); \
-        else RM_KLAUNCH((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, M_, t, seg_len);         \
+        if (n_groups <= flat_max) RM_KLAUNCH((k_tick_frames<MODEL, ST, SH, true>), grid, block, 0, s, nd, M_, t, seg_len, xcd_map); \
+        else RM_KLAUNCH((k_tick_frames<MODEL, ST, SH, false>), grid, block, 0, s, nd, M_, t, seg_len, xcd_map);         \
     } while (0)
 #define RM_FR3(M_, MODEL, SH)                                                                                          \
     do {                                                                                                               \

@@ -51,6 +51,21 @@ def test_logdist_models(engine, rsa, O, params):
     assert np.all(gpu.rssi >= params.get("ld_sensitivity_dbm", -95.0))
 
 
+@pytest.mark.parametrize("t", [1, 7, 8, 9, 150, 333])
+def test_lone_tick_with_its_frames_dealt_to_the_xcds_in_eighths(engine, rsa, O, monkeypatch, t):
+    """RM_TICK_XCD_MAP=1 renames the workgroups of the one-launch tick (XCD x takes the x-th eighth of the frames, rm_tick.hip:
+    xcd_slot): every frame is still evaluated exactly once and lands in its own slot -- frame counts around the multiples of 8."""
+    monkeypatch.setenv("RM_TICK_XCD_MAP", "1")
+    n = 6000
+    nd = _layout(O, n, seed=77)
+    rng = np.random.default_rng(t)
+    src = np.sort(rng.choice(n, t, replace=False))
+    params = {"ld_sigma_db": 4.0, "ld_seed": 99}
+    gpu, cpu = run_both(O, rsa, engine, nd, "logdist", params, nd.packets(src, 0, 8128))
+    assert cpu.count > 5 * t
+    assert_same(gpu, cpu, "xcd map, %d frames" % t)
+
+
 def test_logdist_tx_power_override_and_probabilities(engine, rsa, O):
     n = 3000
     nd = _layout(O, n, seed=5)

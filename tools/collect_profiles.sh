@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence, run on the GPU box from the repository root:
-#   RM_COMMIT=<commit> ROUND=r05 [PARTS="bench stats2 pmc_c3 pmc_m1 pmc_tick pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
+#   RM_COMMIT=<commit> ROUND=r05 [PARTS="bench stats2 pmc_c3 pmc_m1 pmc_tick xcd pmc_c4 pmc_c5 pmc_dense ev asrank"] bash tools/collect_profiles.sh
 # Writes under gpurun_out/$ROUND/; the summaries to be judged are then copied into profiles/.  One gpurun call may run
 # 20 minutes: PARTS selects what a call collects (every part leaves its own summaries; pmc_traffic.json is per call and its
 # entries are merged into profiles/pmc_traffic.json (python tools/pmc_merge.py gpurun_out/$ROUND/pmc_traffic_*.json)).
@@ -60,6 +60,14 @@ pmc c3 128 $LEAN --inflight 1 --steps 6 --warmup 2
 fi
 if has pmc_m1; then pmc m1 16 $LEAN --workload m1 --inflight 1 --batch 16 --steps 12 --warmup 3; fi
 if has pmc_tick; then pmc c3_tick 1 $LEAN --inflight 1 --batch 1 --steps 200 --warmup 20; fi
+if has xcd; then
+# the experiment of DESIGN.md section 4.7: the lone tick's frames dealt to the XCDs in eighths, node ids along a Morton curve
+# (what the frame order has to be for it) -- time per tick without a profiler, then the counters, map off and on
+for v in 0 1; do
+    RM_TICK_XCD_MAP=$v python3 $R/bench.py $LEAN --spatial-ids --inflight 1 --batch 1 --steps 400 --warmup 40 > $O/${ROUND}_c3_tick_spatial_xcd${v}_bench.json 2> $O/xcd$v.err || echo "xcd $v bench FAILED" | tee -a $O/failures.log
+    RM_TICK_XCD_MAP=$v pmc c3_tick_spatial_xcd$v 1 $LEAN --spatial-ids --inflight 1 --batch 1 --steps 200 --warmup 20
+done
+fi
 if has pmc_c4; then pmc c4 128 $LEAN --workload c4 --inflight 1 --steps 4 --warmup 2; fi
 if has pmc_c5; then pmc c5 128 $LEAN --workload c5 --steps 6 --warmup 2; pmc c5_tick 1 $LEAN --workload c5 --batch 1 --steps 60 --warmup 12; fi
 if has pmc_dense; then
