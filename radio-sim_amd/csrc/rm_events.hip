@@ -365,16 +365,33 @@ __global__ void __launch_bounds__(256) k_ev_emit(const EvDev e, const EvOut out,
     __shared__ uint64_t s_meta[kEmitKeys];
     __shared__ uint32_t s_cnt[kEmitKeys];
     const bool in_lds = lds_keys != 0 && G <= kEmitKeys;
-    if (in_lds && blockIdx.x * 4u < G) {
-        for (uint32_t k = threadIdx.x; k < G; k += 256u) {
-            s_time[k] = e.g_time[k];
-            s_meta[k] = e.g_meta[k];
-            s_cnt[k] = e.cnt_by_rank[k];
+    // (this wave's first group is asked for in front of the staging: its chain -- group -> packet -> links -- starts a round trip earlier)
+    const uint32_t g_first = blockIdx.x * 4 + wave_index();
+    const uint32_t ref_first = (g_first < G) ? e.g_ref[g_first] : 0u;
+    if (in_lds && blockIdx.x * 4u < G) { // eight keys per thread, every load in flight before the first store: ONE round trip
+        constexpr int kPer = int(kEmitKeys / 256u);
+        int64_t tk[kPer];
+        uint64_t mk[kPer];
+        uint32_t ck[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t k = uint32_t(u) * 256u + threadIdx.x;
+            const bool in = k < G;
+            tk[u] = in ? e.g_time[k] : 0;
+            mk[u] = in ? e.g_meta[k] : 0ull;
+            ck[u] = in ? e.cnt_by_rank[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t k = uint32_t(u) * 256u + threadIdx.x;
+            s_time[k] = tk[u];
+            s_meta[k] = mk[u];
+            s_cnt[k] = ck[u];
         }
     }
     __syncthreads();
-    for (uint32_t g = blockIdx.x * 4 + wave_index(); g < G; g += gridDim.x * 4) { // wave-uniform
-        const uint32_t ref = uniform_u(e.g_ref[g]);
+    for (uint32_t g = g_first; g < G; g += gridDim.x * 4) { // wave-uniform
+        const uint32_t ref = uniform_u(g == g_first ? ref_first : e.g_ref[g]);
         // (the packet's fields and its first 64 links' nodes are asked for here, in front of the pass over the keys: they
         // depend on nothing the pass finds, and behind it they were two more dependent round trips per group)
         const EvPacket &p = e.pk[ref >> 1];

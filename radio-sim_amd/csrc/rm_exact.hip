@@ -613,6 +613,13 @@ hipError_t launch_exact_batch(hipStream_t s, const NodesDev &nd, const ModelDev 
     // (hundreds of ticks per launch: fewer workgroups per tick, each with more chunks to pipeline -- one rank's share of an
     // 8-GPU tick at 512 ticks per launch: 8 -> 4 workgroups per tick 0.58 -> 0.55 us per tick)
     int gx = max(n >= 256 ? 4 : 8, min(int(kShards), 1024 / n));
+    // (ticks of thousands of frames have hundreds of chunks each -- configs[3]: 5000 frames, ~590 chunks: 8 / 12 / 16 / 32 workgroups
+    // per tick -> 12.1 / 11.3 / 11.7 / 13.1 us per tick with three contexts in flight; configs[2], 1000 frames: 8 / 16 -> 2.86 / 2.94)
+    if (n < 256) {
+        int max_eval = 0;
+        for (int i = 0; i < n; ++i) max_eval = max(max_eval, ticks[i].n_active - ticks[i].first_eval);
+        gx = max(gx, min(16, max_eval / 400));
+    }
     if (const char *e = getenv("RM_EXACT_GRID")) gx = max(1, min(int(kShards), atoi(e)));
     const dim3 grid(gx, 1, n), block(256);
 #define RM_EXB(MODEL)                                                                                                \
