@@ -87,11 +87,17 @@ rm -rf $O/ev_stats
 if [ -x $R/tools/pcie_store_width ]; then (cd $R && tools/pcie_store_width > $O/${ROUND}_pcie_store_width.jsonl 2> /dev/null) || echo "pcie_store_width FAILED" | tee -a $O/failures.log; fi
 echo "events done"
 fi
-if has asrank; then
-# one rank's share of an 8-GPU run, rank by rank (compute side of strong scaling)
+# one rank's share of an 8-GPU run, rank by rank (compute side of strong scaling); asrank = all three, or asrank_c3 / _c4 / _c5
 cd $R
-tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c3.jsonl 8 c3 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c3.jsonl > $O/${ROUND}_asrank8_c3.txt
-tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c4.jsonl 8 c4 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c4.jsonl > $O/${ROUND}_asrank8_c4.txt
-tools/as_rank_sweep.sh $O/${ROUND}_asrank8_c5.jsonl 8 c5 512 128 2> /dev/null && python tools/as_rank_table.py $O/${ROUND}_asrank8_c5.jsonl > $O/${ROUND}_asrank8_c5.txt
+for wl in c3 c4 c5; do
+    if has asrank || has asrank_$wl; then
+        (tools/as_rank_sweep.sh $O/${ROUND}_asrank8_$wl.jsonl 8 $wl 512 128 2> $O/asrank_$wl.err && python tools/as_rank_table.py $O/${ROUND}_asrank8_$wl.jsonl > $O/${ROUND}_asrank8_$wl.txt) || echo "asrank $wl FAILED (see asrank_$wl.err)" | tee -a $O/failures.log
+    fi
+done
+if has server; then
+# the TCP server's own time per step at the BASELINE frame size (tools/server_latency.py: nodes frames steps frame-bytes)
+for th in 8 16; do
+    RSIM_SERVER_THREADS=$th python3 tools/server_latency.py 100000 1000 12 127 > $O/${ROUND}_server_100k_1000_127B_t$th.txt 2>&1 || echo "server_latency t$th FAILED" | tee -a $O/failures.log
+done
 fi
 echo "all done: $PARTS"
