@@ -62,8 +62,10 @@ RM_D bool box_near(const float4 &qb, const float2 &qz, const float4 &f)
 // Which frame does workgroup b take?  The hardware deals workgroups to the eight XCDs in turn (b % 8), each with its own L2.  With
 // xcd_map the frames of a tick are dealt in EIGHTHS instead -- XCD x takes the x-th eighth of the slots -- so that, where the
 // caller's frame order is a spatial order (node ids assigned along a space-filling curve), the frames that share receiver groups
-// share an L2 as well and a group's records leave HBM for one XCD, not for up to eight (RM_TICK_XCD_MAP=1; a pure renaming of
-// the workgroups: every slot is still taken exactly once).
+// share an L2 as well and a group's records leave HBM for one XCD, not for up to eight: 14.0 -> 5.9 MB of counter traffic per tick
+// of configs[2] (4.85 MB algorithmic; 12.8 MB with arbitrary ids, which the renaming neither helps nor hurts), 11.09 -> 11.03 us --
+// the tick is a chain of round trips, not of bytes (profiles/r05_c3_tick_spatial_xcd*).  A pure renaming of the workgroups: every
+// slot is still taken exactly once.  RM_TICK_XCD_MAP=0: workgroup b takes slot b.
 RM_D int xcd_slot(const int b, const int n)
 {
     const int per = n >> 3, rem = n & 7, x = b & 7;
@@ -926,8 +928,8 @@ hipError_t launch_tick_frames(hipStream_t s, const NodesDev &nd, const ModelDev 
     dim3 grid(t.n_cnt);
     const dim3 block(256);
     const int n_groups = cdiv(nd.n_rx, kGroup);
-    const char *e_xcd = getenv("RM_TICK_XCD_MAP"); // (read per tick: tests and experiments switch it)
-    const int xcd_map = (e_xcd && atoi(e_xcd) != 0) ? 1 : 0;
+    const char *e_xcd = getenv("RM_TICK_XCD_MAP"); // 0: workgroup b takes slot b (read per tick: tests and experiments switch it)
+    const int xcd_map = (e_xcd && atoi(e_xcd) == 0) ? 0 : 1;
     static const int flat_max = [] {
         const char *e = getenv("RM_FR_FLAT_MAX");
         return e ? max(0, min(kFrGroups * 2, atoi(e))) : kFrFlatGroups;

@@ -53,9 +53,9 @@ def test_logdist_models(engine, rsa, O, params):
 
 @pytest.mark.parametrize("t", [1, 7, 8, 9, 150, 333])
 def test_lone_tick_with_its_frames_dealt_to_the_xcds_in_eighths(engine, rsa, O, monkeypatch, t):
-    """RM_TICK_XCD_MAP=1 renames the workgroups of the one-launch tick (XCD x takes the x-th eighth of the frames, rm_tick.hip:
-    xcd_slot): every frame is still evaluated exactly once and lands in its own slot -- frame counts around the multiples of 8."""
-    monkeypatch.setenv("RM_TICK_XCD_MAP", "1")
+    """The one-launch tick renames its workgroups (XCD x takes the x-th eighth of the frames, rm_tick.hip: xcd_slot; RM_TICK_XCD_MAP=0
+    turns it off): every frame is still evaluated exactly once and lands in its own slot -- frame counts around the multiples of 8."""
+    monkeypatch.delenv("RM_TICK_XCD_MAP", raising=False)
     n = 6000
     nd = _layout(O, n, seed=77)
     rng = np.random.default_rng(t)

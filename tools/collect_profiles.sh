@@ -62,7 +62,7 @@ if has pmc_m1; then pmc m1 16 $LEAN --workload m1 --inflight 1 --batch 16 --step
 if has pmc_tick; then pmc c3_tick 1 $LEAN --inflight 1 --batch 1 --steps 200 --warmup 20; fi
 if has xcd; then
 # the experiment of DESIGN.md section 4.7: the lone tick's frames dealt to the XCDs in eighths, node ids along a Morton curve
-# (what the frame order has to be for it) -- time per tick without a profiler, then the counters, map off and on
+# (what the frame order has to be for it) -- time per tick without a profiler, then the counters, map off (0) and on (1, the default)
 for v in 0 1; do
     RM_TICK_XCD_MAP=$v python3 $R/bench.py $LEAN --spatial-ids --inflight 1 --batch 1 --steps 400 --warmup 40 > $O/${ROUND}_c3_tick_spatial_xcd${v}_bench.json 2> $O/xcd$v.err || echo "xcd $v bench FAILED" | tee -a $O/failures.log
     RM_TICK_XCD_MAP=$v pmc c3_tick_spatial_xcd$v 1 $LEAN --spatial-ids --inflight 1 --batch 1 --steps 200 --warmup 20
