@@ -12,8 +12,13 @@ namespace rm {
 // A segment of up to 64 links sits one per lane and is ranked with a readlane loop, longer ones by
 // counting through memory.  MODE 1: the scan of the per-frame heard counts is redone in every
 // workgroup (LDS); MODE 2: slot_off comes from k_scan_counts.
+// cwl: log2 of the run of CONSECUTIVE frames a wave takes at a time (its runs are gridDim.x * 4 runs apart).  0 is a frame per
+// step: the waves' frames interleave, every wave gets the same share of a tick whose frames are wave-sized jobs.  Where the
+// lanes take a frame each (three links per frame, thousands of frames), neighbouring lanes with neighbouring frames read
+// neighbouring segments and write neighbouring records: 64 frames G apart were 64 lines per load and per store instruction
+// (configs[3]: 888 MB of counter traffic per 128 ticks for 45 MB of records).
 template <bool STOCH, bool SINR, int MODE>
-RM_D void reorder_body(const ModelDev &m, const TickDev &t)
+RM_D void reorder_body(const ModelDev &m, const TickDev &t, const int cwl)
 {
     __shared__ uint32_t s_off[scan_lds(MODE)];
     __shared__ uint32_t s_wave[4];
@@ -26,14 +31,18 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
 
     // the first frame of this wave: its records are requested before the scan below, so that the
     // scan's round trip and the records' overlap
-    const int q0 = blockIdx.x * 4 + wave_index();
+    const int W = blockIdx.x * 4 + wave_index();
+    const int G = int(gridDim.x) * 4;
+    // the wave's k-th frame: run k >> cwl of its runs, place k & (2^cwl - 1) in it (increasing in k)
+    auto frame_of = [&](const int k) -> int64_t { return ((int64_t(W) + int64_t(k >> cwl) * G) << cwl) + int64_t(k & ((1 << cwl) - 1)); };
+    const int64_t q0 = frame_of(0);
     uint32_t src0 = 0, len = 0;
     int mine = 0x7fffffff, in_e = 0;
     double in_rssi = 0.0, in_prob = 1.0;
     uint8_t v = 0;
     if (q0 < n_new) {
-        src0 = uniform_u(t.seg_off[q0 + t.shift]);
-        len = uniform_u(t.cursor[q0 + t.shift]);
+        src0 = uniform_u(t.seg_off[int(q0) + t.shift]);
+        len = uniform_u(t.cursor[int(q0) + t.shift]);
         if (uint32_t(lane) < len) {
             const uint32_t o = src0 + lane;
             mine = t.a_dst[o];
@@ -66,18 +75,17 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         t.out_count[2] = total;
     }
 
-    // The wave's frames q0, q0 + G, q0 + 2G, ...  With the scan in LDS a frame's count is the difference of two offsets
+    // The wave's frames frame_of(0), frame_of(1), ...  With the scan in LDS a frame's count is the difference of two offsets
     // there, so the frames are looked at 64 at a time, one per lane: one vector load brings the segment offsets of those
     // that heard anything, and only those are walked -- a receiver partition hears nothing of most frames, and a chain of
     // two dependent global loads per frame (offset, count) was most of this stage's time on a rank's share of a tick.
-    const int G = int(gridDim.x) * 4;
     constexpr bool kLdsCounts = (MODE == 1 || kRegScan);
     for (int ib = 0;; ib += 64) { // wave-uniform
-        if (q0 + int64_t(ib) * G >= n_new) break;
+        if (frame_of(ib) >= n_new) break;
         uint32_t my_len = 0, my_src = 0;
         uint64_t todo = ~0ull;
         if (kLdsCounts) {
-            const int64_t qi = q0 + int64_t(ib + lane) * G;
+            const int64_t qi = frame_of(ib + lane);
             if (qi < n_new) {
                 const int sl = int(qi) + t.shift;
                 my_len = s_off[sl + 1] - s_off[sl];
@@ -90,7 +98,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
             constexpr uint32_t kLaneMax = 8;
             const bool lane_frames = !t.seg_ordered && !(SINR && t.air.pool != nullptr);
             if (lane_frames && my_len != 0u && my_len <= kLaneMax) {
-                const int q = int(q0 + int64_t(ib + lane) * G);
+                const int q = int(qi);
                 const int slot = q + t.shift;
                 const uint32_t dst0 = s_off[slot];
                 const int q_pub = t.fl_map ? t.fl_map[q] : q;
@@ -126,7 +134,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
     while (todo) { // wave-uniform
         const int i = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int64_t q64 = q0 + int64_t(ib + i) * G;
+        const int64_t q64 = frame_of(ib + i);
         if (q64 >= n_new) break; // (MODE 2 walks every frame of the block)
         const int q = int(q64);
         const int slot = q + t.shift;
@@ -134,7 +142,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         if (kLdsCounts) {
             src0 = uint32_t(__builtin_amdgcn_readlane(int(my_src), i));
             len = uint32_t(__builtin_amdgcn_readlane(int(my_len), i));
-        } else if (q != q0) {
+        } else if (int64_t(q) != q0) {
             src0 = uniform_u(t.seg_off[slot]);
             len = uniform_u(t.cursor[slot]);
         }
@@ -142,7 +150,7 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {
             const uint32_t o = src0 + c0 + lane;
             const bool valid = c0 + lane < len;
-            if (q != q0 || c0 != 0) { // everything but the prefetched first chunk
+            if (int64_t(q) != q0 || c0 != 0) { // everything but the prefetched first chunk
                 mine = valid ? t.a_dst[o] : 0x7fffffff;
                 in_rssi = valid ? t.a_rssi[o] : 0.0;
                 v = valid ? t.a_verdict[o] : uint8_t(0);
@@ -192,13 +200,13 @@ RM_D void reorder_body(const ModelDev &m, const TickDev &t)
 template <bool STOCH, bool SINR, int MODE>
 __global__ void __launch_bounds__(256) k_reorder(ModelDev m, TickDev t)
 {
-    reorder_body<STOCH, SINR, MODE>(m, t);
+    reorder_body<STOCH, SINR, MODE>(m, t, 0);
 }
 
 template <bool STOCH, int SCAN, bool SINR = false>
-__global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickDev *__restrict__ ticks)
+__global__ void __launch_bounds__(256) k_reorder_batch(const ModelDev m, const TickDev *__restrict__ ticks, const int cwl)
 {
-    reorder_body<STOCH, SINR, SCAN>(m, ticks[blockIdx.z]);
+    reorder_body<STOCH, SINR, SCAN>(m, ticks[blockIdx.z], cwl);
 }
 
 // ============================================================================ Java-RNG draws
@@ -662,18 +670,24 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     // large enough to be busy, every wave strides over whatever frames there are)
     const int walk = (ticks[0].n_pub > 0 && share > 1) ? max(64, min(max_new, max_new * 3 / share)) : max_new;
     const dim3 grid(max(1, min(2048, cdiv(walk, 4 * fpw))), 1, n), block(256);
+    // runs of 64 consecutive frames per wave where the lanes take a frame each (the ticks summed per receiver: sixteen channels,
+    // three links per frame -- configs[3] 229 -> 131 us per 128 ticks, a rank's share 122 -> 78 per 512); single frames where a frame
+    // is a wave's job: runs there leave a tick's few hundred listed frames to three waves (a rank's share of configs[2]: 78 -> 187 us
+    // with runs of 64).  RM_REORDER_RUN: log2 of the run, tests.
+    int cwl = (ticks[0].acc_lo != nullptr) ? 6 : 0;
+    if (const char *e = getenv("RM_REORDER_RUN")) cwl = max(0, min(6, atoi(e)));
     if (m.kind == RM_MODEL_LOGDIST && (m.flags & RM_LD_SINR)) {
-        if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3, true>), grid, block, 0, s, m, b);
-        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4, true>), grid, block, 0, s, m, b);
-        else RM_KLAUNCH((k_reorder_batch<false, 1, true>), grid, block, 0, s, m, b);
+        if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3, true>), grid, block, 0, s, m, b, cwl);
+        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4, true>), grid, block, 0, s, m, b, cwl);
+        else RM_KLAUNCH((k_reorder_batch<false, 1, true>), grid, block, 0, s, m, b, cwl);
     } else if (cfg.stochastic) {
-        if (scan == 3) RM_KLAUNCH((k_reorder_batch<true, 3>), grid, block, 0, s, m, b);
-        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<true, 4>), grid, block, 0, s, m, b);
-        else RM_KLAUNCH((k_reorder_batch<true, 1>), grid, block, 0, s, m, b);
+        if (scan == 3) RM_KLAUNCH((k_reorder_batch<true, 3>), grid, block, 0, s, m, b, cwl);
+        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<true, 4>), grid, block, 0, s, m, b, cwl);
+        else RM_KLAUNCH((k_reorder_batch<true, 1>), grid, block, 0, s, m, b, cwl);
     } else {
-        if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3>), grid, block, 0, s, m, b);
-        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4>), grid, block, 0, s, m, b);
-        else RM_KLAUNCH((k_reorder_batch<false, 1>), grid, block, 0, s, m, b);
+        if (scan == 3) RM_KLAUNCH((k_reorder_batch<false, 3>), grid, block, 0, s, m, b, cwl);
+        else if (scan == 4) RM_KLAUNCH((k_reorder_batch<false, 4>), grid, block, 0, s, m, b, cwl);
+        else RM_KLAUNCH((k_reorder_batch<false, 1>), grid, block, 0, s, m, b, cwl);
     }
     return hipGetLastError();
 }

@@ -17,7 +17,8 @@
 # of the per-receiver sums (RM_SINR_ACC=0), the dense tick that writes its records at once (RM_DENSE_LAZY=0), host views with the
 # rssi per link instead of per packet (RM_HOST_LINK_RSSI=1), the batch filter that takes the near-frame lists of sixteen ticks at
 # a time on tables and batches of any size (RM_NEAR_LISTS=2 RM_WG_RPT=4 RM_FILTER_TICKS_PER_WG=5 / 40 RM_FILTER_GROUP=1) and never (RM_FILTER_GROUP=0), the lone tick's
-# frames dealt to the XCDs in turn instead of in eighths (RM_TICK_XCD_MAP=0), the drain's rank pass from global memory (RM_EV_EMIT_LDS=0).
+# frames dealt to the XCDs in turn instead of in eighths (RM_TICK_XCD_MAP=0), the drain's rank pass from global memory (RM_EV_EMIT_LDS=0),
+# the reorder stage's waves with single frames / runs of 64 / of 8 consecutive frames (RM_REORDER_RUN).
 B=${1:-24}
 FIRST=${2:-0}
 LAST=${3:-99}
@@ -27,7 +28,7 @@ K=("RM_FILTER=wg" "RM_FILTER=wg RM_WG_RPT=4" "RM_FILTER=wg RM_WG_RPT=2" "RM_FILT
    "RM_FILTER_TICKS_PER_WG=3" "RM_NO_ZERO_COPY=1" "RM_FPW=3" "RM_FPW=200" "RM_SINR_GX=5" "RM_GROUP_NO_RCCL=1" "RM_SINR_SCAN=0"
    "RM_DENSE_TICK=1" "RM_DENSE_TICK=0" "RM_NEAR_LISTS=2 RM_WG_RPT=4" "RM_EV_FUSE=0" "RM_EV_SHARE=0" "RM_EV_SHARE=1" "RM_OV_PAIR_CAP=4096"
    "RM_RANK_FRAMES=0" "RM_SINR_ACC=0" "RM_DENSE_LAZY=0" "RM_HOST_LINK_RSSI=1"
-   "RM_NEAR_LISTS=2 RM_WG_RPT=4 RM_FILTER_TICKS_PER_WG=5 RM_FILTER_GROUP=1" "RM_NEAR_LISTS=2 RM_WG_RPT=4 RM_FILTER_TICKS_PER_WG=40 RM_FILTER_GROUP=1" "RM_FILTER_GROUP=0" "RM_TICK_XCD_MAP=0" "RM_EV_EMIT_LDS=0")
+   "RM_NEAR_LISTS=2 RM_WG_RPT=4 RM_FILTER_TICKS_PER_WG=5 RM_FILTER_GROUP=1" "RM_NEAR_LISTS=2 RM_WG_RPT=4 RM_FILTER_TICKS_PER_WG=40 RM_FILTER_GROUP=1" "RM_FILTER_GROUP=0" "RM_TICK_XCD_MAP=0" "RM_EV_EMIT_LDS=0" "RM_REORDER_RUN=0" "RM_REORDER_RUN=6" "RM_REORDER_RUN=3 RM_FPW=5")
 for i in "${!K[@]}"; do
     if [ $i -lt $FIRST ] || [ $i -gt $LAST ]; then continue; fi
     knobs="${K[$i]}"
