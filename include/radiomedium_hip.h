@@ -235,6 +235,8 @@ int rm_tick_flush_view(rm_context *ctx, rm_host_result *out);
  * of mask k set: node rx_first + 1024 * chunk + 64 * k + l heard the packet -- and the cell's count.  A heard link's rssi is
  * its packet's transmit power, its verdict its packet's (pkt_interference): nothing else distinguishes links of such a medium,
  * so the 17-byte records (68 MB for 4 M links) are written only when rm_result_device / rm_result_copy / a host view asks.
+ * The tick itself ends with the masks and the cells' counts (one launch); the packets' offsets and the total are laid out on the
+ * context's stream when this call (or rm_result_count) first asks for them.
  * All pointers are device memory, valid until the next evaluating call; RM_ERR_STATE when the last tick took another form. */
 typedef struct rm_dense_result {
     const unsigned long long *cell_mask; /* [n_packets][chunks][16] */
