@@ -269,8 +269,11 @@ __global__ void __launch_bounds__(256) k_exact(const NodesDev nd, const ModelDev
     exact_body<MODEL, SINR, STOCH, SEG>(nd, m, t);
 }
 
+// (the variant with the scan of up to 2048 per-frame counts in registers -- what a rank's batch of gathered ticks takes, by the
+// HOST's frame count -- came to 129-133 VGPRs: three workgroups per CU instead of four for a stage that is bound by round trips
+// times resident waves; held to 128)
 template <int MODEL, bool STOCH, int SCAN, bool SINR = false>
-__global__ void __launch_bounds__(256) k_exact_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
+__global__ void __launch_bounds__(256, (SCAN == 4 && !SINR) ? 4 : 1) k_exact_batch(const NodesDev nd, const ModelDev m, const TickDev *__restrict__ ticks)
 {
     exact_body<MODEL, SINR, STOCH, SCAN, true>(nd, m, ticks[blockIdx.z]);
 }

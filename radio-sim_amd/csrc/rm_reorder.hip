@@ -665,6 +665,9 @@ hipError_t launch_reorder_batch(hipStream_t s, const NodesDev &nd, const ModelDe
     // walks 256 frames per pass and every workgroup redoes the scan over all the tick's frames: few, long workgroups.
     // configs[3]: 64 / 256 frames per wave 12.3 / 12.2 us per tick against 12.8 with 19)
     if (ticks[0].acc_lo != nullptr && share == 1) fpw = 256;
+    // (a rank's frame list: every listed frame can have links and is a wave's job -- 96 frames per wave left an interior rank's ~250
+    // listed frames to ONE workgroup per tick: 117-121 us per 512 ticks of configs[2] / [4] where the corner rank took 76; 16: 61-65)
+    if (ticks[0].n_pub > 0 && share > 1 && ticks[0].acc_lo == nullptr) fpw = 16;
     if (const char *e = getenv("RM_FPW")) fpw = max(1, atoi(e));
     // (a rank's frame list: the device walks the listed frames only -- about 1/share of them and a halo; the grid only has to be
     // large enough to be busy, every wave strides over whatever frames there are)

@@ -1,8 +1,10 @@
 """A bench run under `rocprofv3 --kernel-trace`: the kernels' average durations over the launches of the TIMED region only.
 rocprofv3's --stats averages every dispatch of a kernel in the process -- set-up and warm-up launches too, which run with
-fewer contexts in flight and are shorter -- while the result line's roofline.kernels are the timed launches' (bench.py
-samples them with events bound to the dispatches).  This takes the last `steps x contexts-in-rotation` dispatches of
-every kernel of the launch sequence from the trace, so that the two can be compared like with like.
+fewer contexts in flight and are shorter -- while the result line carries two sets of intervals (events bound to the
+dispatches): roofline.kernels from launch sequences that ran ALONE after the timed region, roofline.contended.kernels from the
+timed region.  This takes the same dispatches of every kernel of the launch sequence from the trace -- the last 2k (the alone
+pass) and the `steps` before them -- so that like is compared with like.  (For commands without the extra legs: --no-host-transfer
+--no-scale-probe, as tools/collect_profiles.sh runs them; the legs launch the same kernels again.)
 
     python tools/trace_timed_avg.py <dir with *kernel_trace.csv> <bench line json> <out json>"""
 import csv
@@ -19,28 +21,41 @@ def main():
     trace_dir, line_path, out_path = sys.argv[1:4]
     line = json.loads([ln for ln in open(line_path).read().splitlines() if ln.startswith("{")][-1])
     steps = int(line["steps"])
-    wanted = {k.split("<")[0] for k in line["roofline"]["kernels"]}
+    rl = line["roofline"]
+    wanted = {k.split("<")[0] for k in rl["kernels"]}
+    alone = rl.get("alone") or {}
+    k_alone = int(alone.get("sequences") or 0)   # the alone pass: k unprobed sequences, then k probed ones, after the timed region
     rows = collections_by_kernel(trace_dir)
-    out = {"steps": steps, "note": "average duration [us] of the last `steps` dispatches per launch-sequence kernel in the rocprofv3 kernel "
-                                   "trace of the same command (the timed region), beside the line's own event-timed averages",
+    out = {"steps": steps, "alone_sequences": k_alone,
+           "note": "average durations [us] per launch-sequence kernel in the rocprofv3 kernel trace of the same command: the dispatches of "
+                   "the ALONE pass (the last 2k: k unprobed, then k probed -- roofline.kernels are the probed ones' own intervals) and of "
+                   "the TIMED region before them (roofline.contended.kernels), beside the line's own event-timed averages",
            "kernels": {}}
     for name, durs in rows.items():
         base = name.split("<")[0]
         if base not in wanted:
             continue
-        # the sequential leg and the host-transfer legs launch other kernels; a kernel of the sequence is launched once per step
-        timed = durs[-steps:] if len(durs) >= steps else durs
-        line_us = line_kernel_us(line, name)
-        out["kernels"][name] = {"dispatches_in_trace": len(durs), "timed_avg_us": sum(timed) / len(timed), "all_avg_us": sum(durs) / len(durs),
-                                "line_avg_us": line_us, "line_over_trace": (line_us / (sum(timed) / len(timed))) if line_us else None}
+        tail = 2 * k_alone
+        a_plain = durs[len(durs) - tail:len(durs) - k_alone] if tail and len(durs) >= tail else []
+        a_probed = durs[len(durs) - k_alone:] if tail and len(durs) >= tail else []
+        timed = durs[max(0, len(durs) - tail - steps):len(durs) - tail] if len(durs) > tail else durs
+        avg = lambda v: (sum(v) / len(v)) if v else None
+        line_alone = line_kernel_us(rl["kernels"], name)
+        line_cont = line_kernel_us((rl.get("contended") or {}).get("kernels") or {}, name) if tail else line_alone
+        ent = {"dispatches_in_trace": len(durs), "trace_alone_probed_avg_us": avg(a_probed), "trace_alone_unprobed_avg_us": avg(a_plain),
+               "trace_timed_avg_us": avg(timed), "all_avg_us": avg(durs), "line_alone_avg_us": line_alone, "line_contended_avg_us": line_cont}
+        if line_alone and avg(a_probed):
+            ent["line_over_trace_alone"] = line_alone / avg(a_probed)
+        if line_cont and avg(timed):
+            ent["line_over_trace_timed"] = line_cont / avg(timed)
+        out["kernels"][name] = ent
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
-def line_kernel_us(line, trace_name):
+def line_kernel_us(ks, trace_name):
     """the line's average for the kernel rocprofv3 calls `trace_name`: the same name (template arguments as the launch site spells
     them may differ from the trace's -- RM_MODEL_LOGDIST / 4), else the only kernel of the same base name"""
-    ks = line["roofline"]["kernels"]
     norm = lambda n: n.replace(" ", "")
     for k, v in ks.items():
         if norm(k) == norm(trace_name):
