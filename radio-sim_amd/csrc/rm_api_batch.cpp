@@ -16,8 +16,9 @@ struct HostClock {
     void report()
     {
         if (!on || ++calls % 16) return;
-        std::fprintf(stderr, "rm host timing per batch call [us]: checks %.1f  plan %.1f  descriptors %.1f  launches %.1f  total %.1f\n",
-                     acc[0] / 16, acc[1] / 16, acc[2] / 16, acc[3] / 16, (acc[0] + acc[1] + acc[2] + acc[3]) / 16);
+        std::fprintf(stderr, "rm host timing per batch call [us]: checks %.1f  plan %.1f  descriptors %.1f (of which waiting for the batch "
+                             "before last of this context: %.1f)  launches %.1f  total %.1f\n",
+                     acc[0] / 16, acc[1] / 16, acc[2] / 16, acc[4] / 16, acc[3] / 16, (acc[0] + acc[1] + acc[2] + acc[3]) / 16);
         for (double &a : acc) a = 0;
     }
 };
@@ -103,7 +104,9 @@ int rmh::launch_batch(rm_context *c, TickSlot *const *slots, const TickPlan *pla
             RM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ticks[g]), sizeof(rm::TickDev) * RM_MAX_BATCH, hipHostMallocMapped));
             RM_HIP(hipEventCreateWithFlags(&c->h_ticks_ev[g], hipEventDisableTiming));
         } else {
+            const double tw0 = g_clock.on ? HostClock::now() : 0;
             RM_HIP(hipEventSynchronize(c->h_ticks_ev[g]));
+            if (g_clock.on) g_clock.acc[4] += HostClock::now() - tw0;
         }
         std::memcpy(c->h_ticks[g], ticks, sizeof(rm::TickDev) * size_t(n));
         RM_HIP(rm::launch_fetch_ticks(c->stream, c->h_ticks[g], n, dev_ticks)); // the device reads the mapped block itself
