@@ -314,6 +314,9 @@ def test_receivers_that_move_while_selected_frames_are_on_the_air(rsa, O):
     put far outside its rank's region may be reached by frames this rank never kept: every tick of the next batch -- and a lone
     tick -- then reads as RM_ERR_STATE instead of a verdict that silently lacks an interferer; once the frames have left the
     air the rank goes on."""
+    import os
+    if os.environ.get("RM_RANK_FRAMES") == "0":
+        pytest.skip("the run's knobs keep every gathered frame on every rank: nothing is selected, nothing can be missed (tools/knob_sweep.sh)")
     n, t, nb, world = 20_000, 200, 4, 2
     nd, rng = _nodes(O, n, seed=21)
     params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 5}
