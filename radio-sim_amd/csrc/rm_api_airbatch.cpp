@@ -73,6 +73,9 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     // a receiver partition keeps, of all ranks' gathered frames, those that can matter to its receivers (k_rank_frames) -- at the
     // interference floor, with a margin: these frames stay on the air while receivers may move (rm_api_batch.cpp)
     const bool rank_frames = gathered_idx != nullptr && rank_frames_wanted(c);
+    // (refusals come before anything is planned or any window state moves: the ring of boxes the kept frames were selected against)
+    if (rank_frames && c->air_culled && c->cull_end[c->cull_seq % uint32_t(rm::kCullRing)] > t_begin_us[0])
+        return fail(RM_ERR_STATE, "more than 16 batches of frames selected for this partition are on the air at once: use larger batches");
     // the window: batches whose last frame has left the air go, and when the clock went back the frames that had already
     // left stay off (air_tick_device's rules)
     RM_TRY(air_window_expire(c, t_begin_us[0]));
@@ -150,9 +153,15 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
     }
     c->t_begin = t_begin_us[0];
     c->t_end = t_end_us[n_ticks - 1];
-    if (!batched)
+    if (!batched) {
+        // (planned, never launched: a plan hands its slot's counters to the other parity because the tick's first kernel zeroes
+        // them for the tick after it -- a tick that is not launched has zeroed nothing, so the slots go back to where they were, or
+        // the next tick through the sweep kernels would start from the counters of the tick before last)
+        for (int b = 0; b < n_ticks; ++b)
+            if (!plans_v[size_t(b)].empty) slots_v[size_t(b)]->parity ^= 1;
         return fail(RM_ERR_STATE, "the SINR medium carries frames that outlive their tick into the next one: run overlapping ticks one "
                                   "at a time (the batched form takes non-empty ticks of at most 8192 frames over an fp32 frame)");
+    }
     c->air_max_t_begin = std::max(c->air_max_t_begin, t_begin_us[n_ticks - 1]);
 
     // ---- the index's shape: time slots = the window's batches, then the ticks
@@ -342,9 +351,7 @@ int batch_run_overlap(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us,
             for (auto &e : c->cull_end) e = INT64_MIN;
             c->air_culled = true;
         }
-        const int slot = int(c->cull_seq % uint32_t(rm::kCullRing));
-        if (c->cull_end[slot] > t_begin_us[0])
-            return fail(RM_ERR_STATE, "more than 16 batches of frames selected for this partition are on the air at once: use larger batches");
+        const int slot = int(c->cull_seq % uint32_t(rm::kCullRing)); // (free: checked before anything was planned)
         int64_t batch_end = INT64_MIN;
         for (int b = 0; b < n_ticks; ++b)
             if (n_per[b] > 0) batch_end = std::max(batch_end, start_us[b] + air_us[b]);

@@ -307,9 +307,12 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
         c->air_tail = size_t(n_per[n_ticks - 1]);
         c->air_batches.push_back({n_per[n_ticks - 1], start_us[n_ticks - 1] + air_us[n_ticks - 1], 0u});
     }
-    if (any_gathered && !batched)
+    if (any_gathered && !batched) {
+        for (int b = 0; b < n_ticks; ++b) // (planned, never launched: the slots' counter parity goes back, rm_api_airbatch.cpp)
+            if (!plans[b].empty) slots[b]->parity ^= 1;
         return fail(RM_ERR_STATE, "gathered records go through the batched kernels only (sorted receiver table, fp32 frame, "
                                   "at most 8192 frames per tick, no empty tick)");
+    }
     if (batched) {
         // SINR ticks named by source indices: one start and one air time per tick, so all of a tick's frames overlap each other and
         // a heard link's interference is its receiver's sum over ALL the tick's candidates less its own power -- summed per receiver
@@ -323,7 +326,11 @@ int rmh::batch_run(rm_context *c, int32_t n_ticks, const int64_t *t_begin_us, co
                 if (acc) {
                     t.acc_lo = reinterpret_cast<unsigned long long *>(t.st_lin);   // (link-sized buffers of the slot: room for every receiver)
                     t.acc_hi = reinterpret_cast<unsigned long long *>(t.st_sinr);
-                    if (size_t(t.n_rx) > slots[b]->d_st_lin.n) return fail(RM_ERR_CAPACITY, "link capacity below the receiver count");
+                    if (size_t(t.n_rx) > slots[b]->d_st_lin.n) {
+                        for (int k = 0; k < n_ticks; ++k) // (planned, never launched: the slots' counter parity goes back)
+                            if (!plans[k].empty) slots[k]->parity ^= 1;
+                        return fail(RM_ERR_CAPACITY, "link capacity below the receiver count");
+                    }
                 } else {
                     t.reset_heads = 1;
                 }

@@ -392,11 +392,16 @@ def test_receivers_that_move_while_selected_frames_are_on_the_air(rsa, O):
             e.close()
 
 
-def test_a_batch_refused_late_leaves_the_window_where_it_was(rsa, O):
+@pytest.mark.parametrize("lone_form", ["scan", "lists"])
+def test_a_batch_refused_late_leaves_the_window_where_it_was(rsa, O, monkeypatch, lone_form):
     """A batch can be refused after its ticks were planned (here: a tick of more than 8192 frames), with the advice to run the
     ticks one at a time.  The frames of the batch before are then still on the air for the EARLIER ticks of the refused batch:
     the window's clock must not have moved to the batch's last tick, or the first lone tick would retire them (clock went back)
-    and their interference would be lost without a word.  Every lone tick after the refusal against the oracle."""
+    and their interference would be lost without a word.  Nor may the planned, never launched ticks have left their slots'
+    counters on the other parity: the lone ticks through the sweep kernels (`lists`: RM_SINR_SCAN=0) start from them.
+    Every lone tick after the refusal against the oracle."""
+    if lone_form == "lists":
+        monkeypatch.setenv("RM_SINR_SCAN", "0")
     n = 30_000
     nd, rng = _nodes(O, n, seed=9)
     params = {"ld_flags": 1, "ld_sigma_db": 4.0, "ld_seed": 5}
