@@ -10,6 +10,8 @@
 // is left is record writing -- 17 bytes per heard link (25 with the SINR column) in runs of whole cache lines.
 //   k_dense_count   (chunk of 1024 consecutive nodes, eight frames): the chunk's columns once, in registers; per frame the heard
 //                   links as 16 lane masks (a wave's 64 consecutive nodes each) and their number
+//                   -- where the tick ENDS by default: masks and counts are its result (rm_result_dense); what is derived from them is
+//                   derived when somebody asks (launch_dense_layout: offsets and totals; launch_dense_write: the records)
 //   k_dense_write   (frame, chunk): the records of the masks' set bits.  A lane's node is 64 * k + lane of the wave's 256, so
 //                   every store instruction of a wave writes consecutive records: whole lines, one array at a time.  The
 //                   chunk's offset is the sum of the counts before it, taken by the workgroup itself from the (L2-resident)
